@@ -1,0 +1,22 @@
+"""gscodec_studio_amd -- MI355X-native rasterize + quantize hot path of GSCodec Studio.
+
+Public surface (mirrors the reference's ``gsplat`` package for this path only):
+  rendering.rasterization, the operator functions of ``_wrapper`` and
+  ``compression_simulation.{CompressionSimulation, STGCompressionSimulation, fake_quantize_ste, STE}``.
+"""
+from ._wrapper import (
+    fully_fused_projection,
+    isect_offset_encode,
+    isect_tiles,
+    quat_scale_to_covar_preci,
+    rasterize_to_pixels,
+    spherical_harmonics,
+    spherical_harmonics_shared,
+)
+from .rendering import rasterization
+from .version import __version__
+
+__all__ = [
+    "rasterization", "fully_fused_projection", "spherical_harmonics", "spherical_harmonics_shared",
+    "isect_tiles", "isect_offset_encode", "rasterize_to_pixels", "quat_scale_to_covar_preci", "__version__",
+]

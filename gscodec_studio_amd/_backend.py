@@ -1,0 +1,133 @@
+"""Loader of the native C-ABI library ``libgsplat_hip.so`` (ctypes).
+
+Counterpart of the reference's ``gsplat/cuda/_backend.py:79-141`` (which finds or
+JIT-builds a pybind11/torch extension).  Here the native side is a plain shared
+library with a flat C ABI (``include/gsplat_hip.h``); this module
+
+* loads it from the package tree (``gscodec_studio_amd/csrc/libgsplat_hip.so``),
+* derives every function's ctypes prototype by parsing the header, so the header is
+  the single source of truth for the ABI,
+* exposes ``call(name, *args)`` which passes tensors as raw device pointers, appends
+  nothing implicitly, and turns a non-zero status into ``RuntimeError`` with the
+  library's ``gs_last_error()`` message.
+
+There is deliberately NO fallback: if the library is missing or a symbol is absent the
+import of the op fails loudly (a CPU/eager fallback would silently void every parity
+and performance claim made for the HIP path).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Optional, Tuple
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_REPO_DIR = os.path.dirname(_PKG_DIR)
+HEADER_PATH = os.path.join(_REPO_DIR, "include", "gsplat_hip.h")
+LIB_PATH = os.environ.get("GSPLAT_HIP_LIB", os.path.join(_PKG_DIR, "csrc", "libgsplat_hip.so"))
+
+_SCALARS = {
+    "int32_t": ctypes.c_int32,
+    "uint32_t": ctypes.c_uint32,
+    "int64_t": ctypes.c_int64,
+    "uint64_t": ctypes.c_uint64,
+    "size_t": ctypes.c_size_t,
+    "float": ctypes.c_float,
+    "gs_stream_t": ctypes.c_void_p,
+}
+
+
+def _ctype_of(decl: str):
+    """Map one C parameter / return declaration to a ctypes type."""
+    decl = decl.strip()
+    if "*" in decl:
+        if decl.replace("const", "").strip().startswith("char"):
+            return ctypes.c_char_p
+        return ctypes.c_void_p
+    base = decl.replace("const", "").split()[0]
+    return _SCALARS[base]
+
+
+def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[object, List[object], List[str]]]:
+    """Return {function name: (restype, [argtypes], [arg names])} for every prototype."""
+    with open(path, "r") as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)  # strip comments
+    src = re.sub(r"//[^\n]*", " ", src)
+    src = re.sub(r"^\s*#[^\n]*", " ", src, flags=re.M)  # strip preprocessor lines
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(gs_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        ret = ret.replace('extern "C"', "").strip()
+        args = " ".join(args.split())
+        argtypes, argnames = [], []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                argtypes.append(_ctype_of(a))
+                argnames.append(re.findall(r"(\w+)\s*$", a)[0])
+        protos[name] = (_ctype_of(ret), argtypes, argnames)
+    return protos
+
+
+_LIB: Optional[ctypes.CDLL] = None
+_PROTOS: Optional[Dict] = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the native library with prototypes attached."""
+    global _LIB, _PROTOS
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"gscodec_studio_amd: native library not found at {LIB_PATH}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C gscodec_studio_amd/csrc`. There is no CPU fallback."
+        )
+    _PROTOS = parse_header()
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes, _) in _PROTOS.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:  # declared in the header but not exported
+            raise ImportError(f"gscodec_studio_amd: {LIB_PATH} does not export {name}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if L.gs_version() != 1:
+        raise ImportError(f"gscodec_studio_amd: ABI version mismatch: {L.gs_version()} != 1")
+    _LIB = L
+    return L
+
+
+def prototypes() -> Dict:
+    lib()
+    return _PROTOS
+
+
+def ptr(t) -> Optional[int]:
+    """Raw device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def current_stream(device) -> int:
+    import torch
+
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def call(name: str, *args) -> None:
+    """Call an ``int32_t``-status entry point; raise RuntimeError on failure."""
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        msg = L.gs_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{name} failed (status {rc}): {msg}")
+
+
+def query(name: str, *args):
+    """Call a value-returning helper (e.g. gs_sort_temp_bytes)."""
+    return getattr(lib(), name)(*args)

@@ -1,0 +1,621 @@
+"""Operator layer: same public functions as the reference's ``gsplat/cuda/_wrapper.py``
+(lines 47-643, 775-1256), dispatching to the HIP C ABI instead of a pybind module.
+
+Each function keeps the reference's name, argument meaning, defaults, return shapes /
+dtypes and error behaviour (shape asserts in Python, ``RuntimeError`` from native
+failures).  PyTorch owns memory, autograd and streams; every kernel is a call through
+``_backend.call`` with raw device pointers and the current HIP stream.
+
+What is different by design:
+* gradient buffers that a kernel fully overwrites are ``torch.empty`` (no zero-fill pass);
+* SH coefficients shared by all cameras are never expanded to ``[C,N,K,3]``;
+* the tile-intersection prefix sum and the 64-bit radix sort are this library's own
+  kernels (the reference uses ``torch::cumsum`` and ``cub::DeviceRadixSort``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+from typing_extensions import Literal
+
+from . import _backend as B
+
+_CAMERA_MODELS = {"pinhole": 0, "ortho": 1, "fisheye": 2}
+
+
+def _require_gpu(t: Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what}: expected a GPU tensor (got device {t.device}). The HIP path has no CPU "
+            "fallback; the CPU restatement lives in oracle/ and is test infrastructure only."
+        )
+
+
+def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32 tensor, got {t.dtype}")
+    return t.contiguous()
+
+
+def _stream(t: Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _device_of:
+    """``with _device_of(t):`` -- make t's device current (GSPLAT_DEVICE_GUARD equivalent)."""
+
+    def __init__(self, t: Tensor):
+        self._g = torch.cuda.device(t.device)
+
+    def __enter__(self):
+        return self._g.__enter__()
+
+    def __exit__(self, *a):
+        return self._g.__exit__(*a)
+
+
+# ---------------------------------------------------------------------------
+# spherical harmonics  (reference _wrapper.py:47-73, 1226-1256)
+# ---------------------------------------------------------------------------
+def spherical_harmonics(
+    degrees_to_use: int,
+    dirs: Tensor,  # [..., 3]
+    coeffs: Tensor,  # [..., K, 3]
+    masks: Optional[Tensor] = None,
+) -> Tensor:
+    """Computes spherical harmonics.
+
+    Args:
+        degrees_to_use: The degree to be used.
+        dirs: Directions. [..., 3]
+        coeffs: Coefficients. [..., K, 3]
+        masks: Optional boolen masks to skip some computation. [...,] Default: None.
+
+    Returns:
+        Spherical harmonics. [..., 3]
+    """
+    assert (degrees_to_use + 1) ** 2 <= coeffs.shape[-2], coeffs.shape
+    assert dirs.shape[:-1] == coeffs.shape[:-2], (dirs.shape, coeffs.shape)
+    assert dirs.shape[-1] == 3, dirs.shape
+    assert coeffs.shape[-1] == 3, coeffs.shape
+    if masks is not None:
+        assert masks.shape == dirs.shape[:-1], masks.shape
+        masks = masks.contiguous()
+    return _SphericalHarmonics.apply(degrees_to_use, dirs.contiguous(), coeffs.contiguous(), masks, False)
+
+
+def spherical_harmonics_shared(
+    degrees_to_use: int,
+    dirs: Tensor,  # [C, N, 3]
+    coeffs: Tensor,  # [N, K, 3]  (shared by all cameras)
+    masks: Optional[Tensor] = None,  # [C, N]
+) -> Tensor:
+    """SH evaluation for coefficients shared by all C cameras.
+
+    Equivalent to ``spherical_harmonics(deg, dirs, coeffs.expand(C, -1, -1, -1), masks)``
+    (what the reference's ``rasterization`` does, rendering.py:386-390) but never
+    materialises the ``[C,N,K,3]`` coefficient copy (reference _wrapper.py:72) nor the
+    ``[C,N,K,3]`` gradient: the kernel indexes ``[N,K,3]`` directly and the backward
+    sums over cameras in registers.
+    """
+    C, N = dirs.shape[0], dirs.shape[1]
+    assert dirs.shape == (C, N, 3), dirs.shape
+    assert coeffs.dim() == 3 and coeffs.shape[0] == N and coeffs.shape[2] == 3, coeffs.shape
+    assert (degrees_to_use + 1) ** 2 <= coeffs.shape[-2], coeffs.shape
+    if masks is not None:
+        assert masks.shape == (C, N), masks.shape
+        masks = masks.contiguous()
+    return _SphericalHarmonics.apply(degrees_to_use, dirs.contiguous(), coeffs.contiguous(), masks, True)
+
+
+class _SphericalHarmonics(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sh_degree: int, dirs: Tensor, coeffs: Tensor, masks: Optional[Tensor],
+                shared: bool = False) -> Tensor:
+        _require_gpu(coeffs, "spherical_harmonics")
+        dirs, coeffs = _f32c(dirs), _f32c(coeffs)
+        K = coeffs.shape[-2]
+        if shared:
+            C, N = dirs.shape[0], dirs.shape[1]
+        else:
+            C, N = 1, dirs.numel() // 3
+        colors = torch.empty_like(dirs)
+        m8 = masks.view(torch.uint8) if masks is not None else None
+        with _device_of(dirs):
+            B.call("gs_sh_fwd", C, N, K, sh_degree, B.ptr(dirs), B.ptr(coeffs), int(shared), B.ptr(m8),
+                   B.ptr(colors), _stream(dirs))
+        ctx.save_for_backward(dirs, coeffs, masks)
+        ctx.sh_degree = sh_degree
+        ctx.layout = (C, N, shared, K)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors: Tensor):
+        dirs, coeffs, masks = ctx.saved_tensors
+        C, N, shared, K = ctx.layout
+        compute_v_dirs = ctx.needs_input_grad[1]
+        v_colors = _f32c(v_colors)
+        # every row is written by the kernel (zeros for masked / inactive bands): no zero fill
+        v_coeffs = torch.empty_like(coeffs)
+        v_dirs = torch.empty_like(dirs) if compute_v_dirs else None
+        m8 = masks.view(torch.uint8) if masks is not None else None
+        with _device_of(dirs):
+            B.call("gs_sh_bwd", C, N, K, ctx.sh_degree, B.ptr(dirs), B.ptr(coeffs), int(shared), B.ptr(m8),
+                   B.ptr(v_colors), B.ptr(v_coeffs), B.ptr(v_dirs), _stream(dirs))
+        if not ctx.needs_input_grad[2]:
+            v_coeffs = None
+        return None, v_dirs, v_coeffs, None, None
+
+
+# ---------------------------------------------------------------------------
+# quat/scale -> covar/preci  (reference _wrapper.py:76-115, 646-706)
+# ---------------------------------------------------------------------------
+def quat_scale_to_covar_preci(
+    quats: Tensor,  # [N, 4],
+    scales: Tensor,  # [N, 3],
+    compute_covar: bool = True,
+    compute_preci: bool = True,
+    triu: bool = False,
+) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """Converts quaternions and scales to covariance and precision matrices.
+
+    Returns (covars, precis): [N,3,3] each, or [N,6] upper-triangular when ``triu``.
+    """
+    assert quats.dim() == 2 and quats.size(1) == 4, quats.size()
+    assert scales.dim() == 2 and scales.size(1) == 3, scales.size()
+    quats = quats.contiguous()
+    scales = scales.contiguous()
+    covars, precis = _QuatScaleToCovarPreci.apply(quats, scales, compute_covar, compute_preci, triu)
+    return covars if compute_covar else None, precis if compute_preci else None
+
+
+class _QuatScaleToCovarPreci(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, quats, scales, compute_covar, compute_preci, triu):
+        _require_gpu(quats, "quat_scale_to_covar_preci")
+        quats, scales = _f32c(quats), _f32c(scales)
+        N = quats.shape[0]
+        shape = (N, 6) if triu else (N, 3, 3)
+        covars = torch.empty(shape, device=quats.device) if compute_covar else None
+        precis = torch.empty(shape, device=quats.device) if compute_preci else None
+        with _device_of(quats):
+            B.call("gs_quat_scale_to_covar_preci_fwd", N, B.ptr(quats), B.ptr(scales), int(triu), B.ptr(covars),
+                   B.ptr(precis), _stream(quats))
+        ctx.save_for_backward(quats, scales)
+        ctx.flags = (compute_covar, compute_preci, triu)
+        return covars, precis
+
+    @staticmethod
+    def backward(ctx, v_covars, v_precis):
+        quats, scales = ctx.saved_tensors
+        compute_covar, compute_preci, triu = ctx.flags
+        v_covars = _f32c(v_covars) if (compute_covar and v_covars is not None) else None
+        v_precis = _f32c(v_precis) if (compute_preci and v_precis is not None) else None
+        N = quats.shape[0]
+        v_quats = torch.empty_like(quats)
+        v_scales = torch.empty_like(scales)
+        with _device_of(quats):
+            B.call("gs_quat_scale_to_covar_preci_bwd", N, B.ptr(quats), B.ptr(scales), int(triu), B.ptr(v_covars),
+                   B.ptr(v_precis), B.ptr(v_quats), B.ptr(v_scales), _stream(quats))
+        return v_quats, v_scales, None, None, None
+
+
+# ---------------------------------------------------------------------------
+# fully fused projection  (reference _wrapper.py:203-339, 775-898, 1031-1223)
+# ---------------------------------------------------------------------------
+def fully_fused_projection(
+    means: Tensor,  # [N, 3]
+    covars: Optional[Tensor],  # [N, 6] or None
+    quats: Optional[Tensor],  # [N, 4] or None
+    scales: Optional[Tensor],  # [N, 3] or None
+    viewmats: Tensor,  # [C, 4, 4]
+    Ks: Tensor,  # [C, 3, 3]
+    width: int,
+    height: int,
+    eps2d: float = 0.3,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    packed: bool = False,
+    sparse_grad: bool = False,
+    calc_compensations: bool = False,
+    camera_model: Literal["pinhole", "ortho", "fisheye"] = "pinhole",
+):
+    """Projects Gaussians to 2D.
+
+    Unpacked: returns (radii [C,N] i32, means2d [C,N,2], depths [C,N], conics [C,N,3],
+    compensations [C,N] or None); only entries with radii > 0 are valid.
+    Packed: returns (camera_ids [nnz] i64, gaussian_ids [nnz] i64, radii [nnz], means2d,
+    depths, conics, compensations) with all entries valid.
+    """
+    C = viewmats.size(0)
+    N = means.size(0)
+    assert means.size() == (N, 3), means.size()
+    assert viewmats.size() == (C, 4, 4), viewmats.size()
+    assert Ks.size() == (C, 3, 3), Ks.size()
+    means = means.contiguous()
+    if covars is not None:
+        assert covars.size() == (N, 6), covars.size()
+        covars = covars.contiguous()
+    else:
+        assert quats is not None, "covars or quats is required"
+        assert scales is not None, "covars or scales is required"
+        assert quats.size() == (N, 4), quats.size()
+        assert scales.size() == (N, 3), scales.size()
+        quats = quats.contiguous()
+        scales = scales.contiguous()
+    if sparse_grad:
+        assert packed, "sparse_grad is only supported when packed is True"
+    assert camera_model in _CAMERA_MODELS, camera_model
+
+    viewmats = viewmats.contiguous()
+    Ks = Ks.contiguous()
+    if packed:
+        return _FullyFusedProjectionPacked.apply(
+            means, covars, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+            radius_clip, sparse_grad, calc_compensations, camera_model,
+        )
+    return _FullyFusedProjection.apply(
+        means, covars, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+        radius_clip, calc_compensations, camera_model,
+    )
+
+
+class _FullyFusedProjection(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, covars, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
+                far_plane, radius_clip, calc_compensations, camera_model="pinhole"):
+        _require_gpu(means, "fully_fused_projection")
+        means, covars, quats, scales = _f32c(means), _f32c(covars), _f32c(quats), _f32c(scales)
+        viewmats, Ks = _f32c(viewmats), _f32c(Ks)
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        radii = torch.empty((C, N), dtype=torch.int32, device=dev)
+        means2d = torch.empty((C, N, 2), dtype=torch.float32, device=dev)
+        depths = torch.empty((C, N), dtype=torch.float32, device=dev)
+        conics = torch.empty((C, N, 3), dtype=torch.float32, device=dev)
+        # the reference zero-initialises compensations only (fwd.cu:242-245)
+        compensations = torch.zeros((C, N), dtype=torch.float32, device=dev) if calc_compensations else None
+        cm = _CAMERA_MODELS[camera_model]
+        with _device_of(means):
+            B.call("gs_projection_fwd", C, N, B.ptr(means), B.ptr(covars), B.ptr(quats), B.ptr(scales),
+                   B.ptr(viewmats), B.ptr(Ks), int(width), int(height), float(eps2d), float(near_plane),
+                   float(far_plane), float(radius_clip), cm, B.ptr(radii), B.ptr(means2d), B.ptr(depths),
+                   B.ptr(conics), B.ptr(compensations), _stream(means))
+        ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, radii, conics, compensations)
+        ctx.width, ctx.height, ctx.eps2d, ctx.cm = width, height, eps2d, cm
+        ctx.mark_non_differentiable(radii)
+        return radii, means2d, depths, conics, compensations
+
+    @staticmethod
+    def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_compensations):
+        means, covars, quats, scales, viewmats, Ks, radii, conics, compensations = ctx.saved_tensors
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        v_means2d, v_depths, v_conics = _f32c(v_means2d), _f32c(v_depths), _f32c(v_conics)
+        v_compensations = _f32c(v_compensations) if v_compensations is not None else None
+        need = ctx.needs_input_grad
+        # rows are fully written by the kernel -> empty, not zeros
+        v_means = torch.empty_like(means) if need[0] else None
+        v_covars = torch.empty_like(covars) if (covars is not None and need[1]) else None
+        v_quats = torch.empty_like(quats) if (quats is not None and need[2]) else None
+        v_scales = torch.empty_like(scales) if (scales is not None and need[3]) else None
+        v_viewmats = torch.zeros_like(viewmats) if need[4] else None
+        with _device_of(means):
+            B.call("gs_projection_bwd", C, N, B.ptr(means), B.ptr(covars), B.ptr(quats), B.ptr(scales),
+                   B.ptr(viewmats), B.ptr(Ks), int(ctx.width), int(ctx.height), float(ctx.eps2d), ctx.cm,
+                   B.ptr(radii), B.ptr(conics), B.ptr(compensations), B.ptr(v_means2d), B.ptr(v_depths),
+                   B.ptr(v_conics), B.ptr(v_compensations), B.ptr(v_means), B.ptr(v_covars), B.ptr(v_quats),
+                   B.ptr(v_scales), B.ptr(v_viewmats), _stream(means))
+        return (v_means, v_covars, v_quats, v_scales, v_viewmats) + (None,) * 9
+
+
+class _FullyFusedProjectionPacked(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, covars, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
+                far_plane, radius_clip, sparse_grad, calc_compensations, camera_model="pinhole"):
+        _require_gpu(means, "fully_fused_projection(packed)")
+        means, covars, quats, scales = _f32c(means), _f32c(covars), _f32c(quats), _f32c(scales)
+        viewmats, Ks = _f32c(viewmats), _f32c(Ks)
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        cm = _CAMERA_MODELS[camera_model]
+        nblocks = (N + 255) // 256
+        st = _stream(means)
+        common = (C, N, B.ptr(means), B.ptr(covars), B.ptr(quats), B.ptr(scales), B.ptr(viewmats), B.ptr(Ks),
+                  int(width), int(height), float(eps2d), float(near_plane), float(far_plane),
+                  float(radius_clip), cm)
+        with _device_of(means):
+            nnz = 0
+            if C * N > 0:
+                block_cnts = torch.empty(C * nblocks, dtype=torch.int32, device=dev)
+                B.call("gs_projection_packed_count", *common, B.ptr(block_cnts), st)
+                block_accum = torch.empty_like(block_cnts)
+                sb = B.query("gs_cumsum_scratch_bytes", C * nblocks)
+                scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+                B.call("gs_cumsum_i32_i32", C * nblocks, B.ptr(block_cnts), B.ptr(block_accum), B.ptr(scratch),
+                       sb, st)
+                nnz = int(block_accum[-1].item())  # the one host sync (packed_fwd.cu:335)
+            indptr = torch.zeros(C + 1, dtype=torch.int32, device=dev)
+            camera_ids = torch.empty(nnz, dtype=torch.int64, device=dev)
+            gaussian_ids = torch.empty(nnz, dtype=torch.int64, device=dev)
+            radii = torch.empty(nnz, dtype=torch.int32, device=dev)
+            means2d = torch.empty((nnz, 2), dtype=torch.float32, device=dev)
+            depths = torch.empty(nnz, dtype=torch.float32, device=dev)
+            conics = torch.empty((nnz, 3), dtype=torch.float32, device=dev)
+            compensations = torch.zeros(nnz, dtype=torch.float32, device=dev) if calc_compensations else None
+            if nnz > 0:
+                B.call("gs_projection_packed_fill", *common, B.ptr(block_accum), B.ptr(indptr), B.ptr(camera_ids),
+                       B.ptr(gaussian_ids), B.ptr(radii), B.ptr(means2d), B.ptr(depths), B.ptr(conics),
+                       B.ptr(compensations), st)
+        ctx.save_for_backward(camera_ids, gaussian_ids, means, covars, quats, scales, viewmats, Ks, conics,
+                              compensations)
+        ctx.width, ctx.height, ctx.eps2d, ctx.cm, ctx.sparse_grad = width, height, eps2d, cm, sparse_grad
+        ctx.mark_non_differentiable(camera_ids, gaussian_ids, radii)
+        return camera_ids, gaussian_ids, radii, means2d, depths, conics, compensations
+
+    @staticmethod
+    def backward(ctx, v_camera_ids, v_gaussian_ids, v_radii, v_means2d, v_depths, v_conics, v_compensations):
+        (camera_ids, gaussian_ids, means, covars, quats, scales, viewmats, Ks, conics,
+         compensations) = ctx.saved_tensors
+        C, N, nnz = viewmats.shape[0], means.shape[0], camera_ids.shape[0]
+        sparse = ctx.sparse_grad
+        need = ctx.needs_input_grad
+        v_means2d, v_depths, v_conics = _f32c(v_means2d), _f32c(v_depths), _f32c(v_conics)
+        v_compensations = _f32c(v_compensations) if v_compensations is not None else None
+        dev = means.device
+
+        def buf(like: Optional[Tensor], flag: bool, width_: int) -> Optional[Tensor]:
+            if like is None or not flag:
+                return None
+            if sparse:
+                return torch.empty((nnz, width_), dtype=torch.float32, device=dev)
+            return torch.zeros((N, width_), dtype=torch.float32, device=dev)
+
+        v_means = buf(means, need[0], 3)
+        v_covars = buf(covars, need[1], 6)
+        v_quats = buf(quats, need[2], 4)
+        v_scales = buf(scales, need[3], 3)
+        v_viewmats = torch.zeros_like(viewmats) if need[4] else None
+        with _device_of(means):
+            B.call("gs_projection_packed_bwd", C, N, nnz, B.ptr(means), B.ptr(covars), B.ptr(quats), B.ptr(scales),
+                   B.ptr(viewmats), B.ptr(Ks), int(ctx.width), int(ctx.height), float(ctx.eps2d), ctx.cm,
+                   B.ptr(camera_ids), B.ptr(gaussian_ids), B.ptr(conics), B.ptr(compensations), B.ptr(v_means2d),
+                   B.ptr(v_depths), B.ptr(v_conics), B.ptr(v_compensations), int(sparse), B.ptr(v_means),
+                   B.ptr(v_covars), B.ptr(v_quats), B.ptr(v_scales), B.ptr(v_viewmats), _stream(means))
+        if sparse:
+            # reference: torch.sparse_coo_tensor(indices=gaussian_ids[None], values, size, is_coalesced=(C==1))
+            def coo(v: Optional[Tensor], like: Tensor) -> Optional[Tensor]:
+                if v is None:
+                    return None
+                return torch.sparse_coo_tensor(indices=gaussian_ids[None], values=v, size=like.size(),
+                                               is_coalesced=(C == 1))
+
+            v_means = coo(v_means, means)
+            v_covars = coo(v_covars, covars) if covars is not None else None
+            v_quats = coo(v_quats, quats) if quats is not None else None
+            v_scales = coo(v_scales, scales) if scales is not None else None
+        return (v_means, v_covars, v_quats, v_scales, v_viewmats) + (None,) * 10
+
+
+# ---------------------------------------------------------------------------
+# tile intersection  (reference _wrapper.py:342-433)
+# ---------------------------------------------------------------------------
+@torch.no_grad()
+def isect_tiles(
+    means2d: Tensor,  # [C, N, 2] or [nnz, 2]
+    radii: Tensor,  # [C, N] or [nnz]
+    depths: Tensor,  # [C, N] or [nnz]
+    tile_size: int,
+    tile_width: int,
+    tile_height: int,
+    sort: bool = True,
+    packed: bool = False,
+    n_cameras: Optional[int] = None,
+    camera_ids: Optional[Tensor] = None,
+    gaussian_ids: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor, Tensor]:
+    """Maps projected Gaussians to intersecting tiles.
+
+    Returns (tiles_per_gauss i32, isect_ids i64 [n_isects], flatten_ids i32 [n_isects]);
+    an id is ``camera_id << (32 + tile_bits) | tile_id << 32 | float_bits(depth)``.
+    """
+    if packed:
+        nnz = means2d.size(0)
+        assert means2d.shape == (nnz, 2), means2d.size()
+        assert radii.shape == (nnz,), radii.size()
+        assert depths.shape == (nnz,), depths.size()
+        assert camera_ids is not None, "camera_ids is required if packed is True"
+        assert gaussian_ids is not None, "gaussian_ids is required if packed is True"
+        assert n_cameras is not None, "n_cameras is required if packed is True"
+        camera_ids = camera_ids.contiguous()
+        gaussian_ids = gaussian_ids.contiguous()
+        C = n_cameras
+        N = 0
+        n_elems = nnz
+    else:
+        C, N, _ = means2d.shape
+        assert means2d.shape == (C, N, 2), means2d.size()
+        assert radii.shape == (C, N), radii.size()
+        assert depths.shape == (C, N), depths.size()
+        camera_ids = None
+        n_elems = C * N
+    _require_gpu(means2d, "isect_tiles")
+    means2d, depths = _f32c(means2d), _f32c(depths)
+    radii = radii.contiguous()
+    assert radii.dtype == torch.int32, radii.dtype
+    dev = means2d.device
+    st = _stream(means2d)
+
+    n_tiles = tile_width * tile_height
+    # the reference computes floor(log2(x)) + 1 in floating point (isect_tiles.cu:155-157)
+    tile_n_bits = int(math.floor(math.log2(n_tiles))) + 1 if n_tiles > 0 else 1
+    cam_n_bits = int(math.floor(math.log2(C))) + 1 if C > 0 else 1
+    assert tile_n_bits + cam_n_bits <= 32, "tile_n_bits + cam_n_bits must be <= 32"
+
+    tiles_per_gauss = torch.empty(radii.shape, dtype=torch.int32, device=dev)
+    with _device_of(means2d):
+        n_isects = 0
+        cum = None
+        if n_elems > 0:
+            B.call("gs_isect_count", n_elems, B.ptr(means2d), B.ptr(radii), tile_size, tile_width, tile_height,
+                   B.ptr(tiles_per_gauss), st)
+            cum = torch.empty(n_elems, dtype=torch.int64, device=dev)
+            sb = B.query("gs_cumsum_scratch_bytes", n_elems)
+            scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+            B.call("gs_cumsum_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(cum), B.ptr(scratch), sb, st)
+            n_isects = int(cum[-1].item())  # the one host sync (isect_tiles.cu:200)
+        isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
+        flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
+        if n_isects > 0:
+            B.call("gs_isect_emit", n_elems, max(N, 1), B.ptr(camera_ids), B.ptr(means2d), B.ptr(radii),
+                   B.ptr(depths), B.ptr(cum), tile_size, tile_width, tile_height, tile_n_bits, B.ptr(isect_ids),
+                   B.ptr(flatten_ids), st)
+            if sort:
+                ids_sorted = torch.empty_like(isect_ids)
+                flat_sorted = torch.empty_like(flatten_ids)
+                tb = B.query("gs_sort_temp_bytes", n_isects)
+                temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+                B.call("gs_sort_pairs_u64_i32", n_isects, B.ptr(isect_ids), B.ptr(flatten_ids), B.ptr(ids_sorted),
+                       B.ptr(flat_sorted), 0, 32 + tile_n_bits + cam_n_bits, B.ptr(temp), tb, st)
+                isect_ids, flatten_ids = ids_sorted, flat_sorted
+    return tiles_per_gauss, isect_ids, flatten_ids
+
+
+@torch.no_grad()
+def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
+    """Encodes sorted intersection ids to per-(camera, tile) start offsets [C, th, tw] (int32)."""
+    _require_gpu(isect_ids, "isect_offset_encode")
+    isect_ids = isect_ids.contiguous()
+    assert isect_ids.dtype == torch.int64, isect_ids.dtype
+    n_isects = isect_ids.shape[0]
+    n_tiles = tile_width * tile_height
+    tile_n_bits = int(math.floor(math.log2(n_tiles))) + 1 if n_tiles > 0 else 1
+    offsets = torch.empty((n_cameras, tile_height, tile_width), dtype=torch.int32, device=isect_ids.device)
+    with _device_of(isect_ids):
+        B.call("gs_isect_offset_encode", n_isects, B.ptr(isect_ids), n_cameras, n_tiles, tile_n_bits,
+               B.ptr(offsets), _stream(isect_ids))
+    return offsets
+
+
+# ---------------------------------------------------------------------------
+# rasterize to pixels  (reference _wrapper.py:436-568, 901-1028)
+# ---------------------------------------------------------------------------
+def rasterize_to_pixels(
+    means2d: Tensor,  # [C, N, 2] or [nnz, 2]
+    conics: Tensor,  # [C, N, 3] or [nnz, 3]
+    colors: Tensor,  # [C, N, channels] or [nnz, channels]
+    opacities: Tensor,  # [C, N] or [nnz]
+    image_width: int,
+    image_height: int,
+    tile_size: int,
+    isect_offsets: Tensor,  # [C, tile_height, tile_width]
+    flatten_ids: Tensor,  # [n_isects]
+    backgrounds: Optional[Tensor] = None,  # [C, channels]
+    masks: Optional[Tensor] = None,  # [C, tile_height, tile_width]
+    packed: bool = False,
+    absgrad: bool = False,
+) -> Tuple[Tensor, Tensor]:
+    """Rasterizes Gaussians to pixels.
+
+    Returns (render_colors [C,H,W,channels], render_alphas [C,H,W,1]).
+    """
+    C = isect_offsets.size(0)
+    if packed:
+        nnz = means2d.size(0)
+        assert means2d.shape == (nnz, 2), means2d.shape
+        assert conics.shape == (nnz, 3), conics.shape
+        assert colors.shape[0] == nnz, colors.shape
+        assert opacities.shape == (nnz,), opacities.shape
+    else:
+        N = means2d.size(1)
+        assert means2d.shape == (C, N, 2), means2d.shape
+        assert conics.shape == (C, N, 3), conics.shape
+        assert colors.shape[:2] == (C, N), colors.shape
+        assert opacities.shape == (C, N), opacities.shape
+    if backgrounds is not None:
+        assert backgrounds.shape == (C, colors.shape[-1]), backgrounds.shape
+        backgrounds = backgrounds.contiguous()
+    if masks is not None:
+        assert masks.shape == isect_offsets.shape, masks.shape
+        masks = masks.contiguous()
+
+    channels = colors.shape[-1]
+    if channels > 513 or channels == 0:
+        raise ValueError(f"Unsupported number of color channels: {channels}")
+    # NOTE: the reference zero-pads to {1,2,3,4,5,8,9,16,...} channels here because its
+    # kernels are template-instantiated per channel count; the HIP ABI takes a runtime
+    # channel count, so no padding copy is made.
+
+    tile_height, tile_width = isect_offsets.shape[1:3]
+    assert tile_height * tile_size >= image_height, f"Assert Failed: {tile_height} * {tile_size} >= {image_height}"
+    assert tile_width * tile_size >= image_width, f"Assert Failed: {tile_width} * {tile_size} >= {image_width}"
+
+    return _RasterizeToPixels.apply(
+        means2d.contiguous(), conics.contiguous(), colors.contiguous(), opacities.contiguous(), backgrounds,
+        masks, image_width, image_height, tile_size, isect_offsets.contiguous(), flatten_ids.contiguous(), absgrad,
+    )
+
+
+class _RasterizeToPixels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size,
+                isect_offsets, flatten_ids, absgrad):
+        _require_gpu(means2d, "rasterize_to_pixels")
+        means2d, conics, colors, opacities = _f32c(means2d), _f32c(conics), _f32c(colors), _f32c(opacities)
+        backgrounds = _f32c(backgrounds)
+        C, tile_height, tile_width = isect_offsets.shape
+        channels = colors.shape[-1]
+        n_elems = opacities.numel()
+        n_isects = flatten_ids.shape[0]
+        dev = means2d.device
+        render_colors = torch.empty((C, height, width, channels), dtype=torch.float32, device=dev)
+        render_alphas = torch.empty((C, height, width, 1), dtype=torch.float32, device=dev)
+        last_ids = torch.empty((C, height, width), dtype=torch.int32, device=dev)
+        m8 = masks.view(torch.uint8) if masks is not None else None
+        assert isect_offsets.dtype == torch.int32 and flatten_ids.dtype == torch.int32
+        with _device_of(means2d):
+            B.call("gs_rasterize_fwd", C, n_elems, n_isects, channels, B.ptr(means2d), B.ptr(conics), B.ptr(colors),
+                   B.ptr(opacities), B.ptr(backgrounds), B.ptr(m8), width, height, tile_size, tile_width,
+                   tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_colors),
+                   B.ptr(render_alphas), B.ptr(last_ids), _stream(means2d))
+        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids,
+                              render_alphas, last_ids)
+        ctx.width, ctx.height, ctx.tile_size, ctx.absgrad = width, height, tile_size, absgrad
+        return render_colors, render_alphas
+
+    @staticmethod
+    def backward(ctx, v_render_colors: Tensor, v_render_alphas: Tensor):
+        (means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas,
+         last_ids) = ctx.saved_tensors
+        C, tile_height, tile_width = isect_offsets.shape
+        channels = colors.shape[-1]
+        n_elems = opacities.numel()
+        n_isects = flatten_ids.shape[0]
+        v_render_colors = _f32c(v_render_colors)
+        v_render_alphas = _f32c(v_render_alphas)
+        # accumulated with atomics -> zero-filled
+        v_means2d = torch.zeros_like(means2d)
+        v_conics = torch.zeros_like(conics)
+        v_colors = torch.zeros_like(colors)
+        v_opacities = torch.zeros_like(opacities)
+        v_means2d_abs = torch.zeros_like(means2d) if ctx.absgrad else None
+        m8 = masks.view(torch.uint8) if masks is not None else None
+        with _device_of(means2d):
+            B.call("gs_rasterize_bwd", C, n_elems, n_isects, channels, B.ptr(means2d), B.ptr(conics), B.ptr(colors),
+                   B.ptr(opacities), B.ptr(backgrounds), B.ptr(m8), ctx.width, ctx.height, ctx.tile_size,
+                   tile_width, tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_alphas),
+                   B.ptr(last_ids), B.ptr(v_render_colors), B.ptr(v_render_alphas), B.ptr(v_means2d_abs),
+                   B.ptr(v_means2d), B.ptr(v_conics), B.ptr(v_colors), B.ptr(v_opacities), _stream(means2d))
+        if ctx.absgrad:
+            means2d.absgrad = v_means2d_abs
+        if ctx.needs_input_grad[4]:
+            v_backgrounds = (v_render_colors * (1.0 - render_alphas).float()).sum(dim=(1, 2))
+        else:
+            v_backgrounds = None
+        return (v_means2d, v_conics, v_colors, v_opacities, v_backgrounds) + (None,) * 7

@@ -1,0 +1,100 @@
+"""Quantize / dequantize straight-through estimators on the HIP path.
+
+Same functions as the reference's ``gsplat/compression_simulation/ops.py`` (39-75):
+
+* ``fake_quantize_ste(x, lo, hi, bitwidth=8, q_type="noise")`` -> ``{"output_value", "q_step"}``
+    - "noise": ``clamp(x, lo, hi) + U(-0.5, 0.5) * q_step``; the gradient passes where
+      ``lo <= x <= hi``.  The noise tensor is drawn by ``torch.empty_like(x).uniform_`` from
+      the device's default generator exactly as the reference does, so the RNG stream is
+      unchanged; clamp + scale + add run as ONE HIP kernel instead of four torch kernels.
+    - "round": ``STE.apply`` -- clamps the PARAMETER IN PLACE (reference ops.py:63 mutates
+      its input, kept on purpose), rounds half-to-even on the [0, 2^b-1] grid, identity
+      gradient everywhere (including clamped elements).
+* any other ``q_type`` (e.g. "vq", accepted by the reference's config type) raises the same
+  ``UnboundLocalError`` the reference raises.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .. import _backend as B
+from .._wrapper import _device_of, _require_gpu, _stream
+
+
+def _f32(v: float) -> float:
+    """Round a Python double to the nearest fp32 (what torch does with a wrapped scalar)."""
+    return float(np.float32(v))
+
+
+class _NoiseQuant(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, noise: Tensor, lo: float, hi: float, q_step: float) -> Tensor:
+        _require_gpu(x, "fake_quantize_ste")
+        if x.dtype != torch.float32:
+            raise RuntimeError(f"fake_quantize_ste: expected float32, got {x.dtype}")
+        xc = x.contiguous()
+        out = torch.empty_like(xc)
+        with _device_of(xc):
+            B.call("gs_quantize_noise_fwd", xc.numel(), B.ptr(xc), B.ptr(noise), _f32(lo), _f32(hi), _f32(q_step),
+                   B.ptr(out), _stream(xc))
+        ctx.save_for_backward(xc)
+        ctx.bounds = (_f32(lo), _f32(hi))
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, v_out: Tensor):
+        (xc,) = ctx.saved_tensors
+        lo, hi = ctx.bounds
+        v_out = v_out.contiguous()
+        v_x = torch.empty_like(xc)
+        with _device_of(xc):
+            B.call("gs_quantize_noise_bwd", xc.numel(), B.ptr(xc), B.ptr(v_out), lo, hi, B.ptr(v_x), _stream(xc))
+        return v_x.view(v_out.shape), None, None, None, None
+
+
+class STE(torch.autograd.Function):
+    """Round-to-grid straight-through estimator (reference ops.py:57-75).
+
+    ``STE.apply(input, bitdepth=8, min=-1, max=1)``.  ``input`` is clamped IN PLACE.
+    """
+
+    @staticmethod
+    def forward(ctx, input: Tensor, bitdepth: int = 8, min: float = -1, max: float = 1) -> Tensor:
+        _require_gpu(input, "STE")
+        if input.dtype != torch.float32:
+            raise RuntimeError(f"STE: expected float32, got {input.dtype}")
+        if not input.is_contiguous():
+            raise RuntimeError("STE: input must be contiguous (it is clamped in place)")
+        out = torch.empty_like(input)
+        rng = _f32(max - min)  # python arithmetic first, then fp32, as torch does
+        qn = _f32(1 / (2**bitdepth - 1))
+        with _device_of(input):
+            B.call("gs_quantize_round_fwd", input.numel(), B.ptr(input), _f32(min), _f32(max), rng, qn, B.ptr(out),
+                   _stream(input))
+
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output: Tensor):
+        return grad_output, None, None, None
+
+
+def fake_quantize_ste(input: Tensor, lower_bd: float, upper_bd: float, bitwidth: int = 8,
+                      q_type: str = "noise") -> Dict[str, object]:
+    q_step = (upper_bd - lower_bd) / (2**bitwidth - 1)
+
+    if q_type == "round":
+        output_value = STE.apply(input, bitwidth, lower_bd, upper_bd)
+    elif q_type == "noise":
+        noise = torch.empty_like(input, memory_format=torch.contiguous_format).uniform_(-0.5, 0.5)
+        output_value = _NoiseQuant.apply(input, noise, lower_bd, upper_bd, q_step)
+
+    out_dict = {
+        "output_value": output_value,  # UnboundLocalError for unknown q_type, like the reference
+        "q_step": q_step,
+    }
+    return out_dict

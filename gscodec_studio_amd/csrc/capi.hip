@@ -1,0 +1,188 @@
+// capi.hip -- error plumbing, version, compositing dispatch and the small unfused ops.
+#include "gs_common.h"
+#include "rasterize_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+
+void gs_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int32_t gs_version(void) { return GS_ABI_VERSION; }
+extern "C" const char *gs_last_error(void) { return g_err; }
+
+// GS_RASTER_IMPL=ref selects the one-thread-per-pixel baseline kernels; anything else
+// (default) the wave-per-tile kernels.
+static bool use_ref_raster() {
+    const char *e = getenv("GS_RASTER_IMPL");
+    return e != nullptr && strcmp(e, "ref") == 0;
+}
+
+static int32_t check_raster_args(const RasterArgs &a) {
+    if (a.channels == 0 || a.channels > 513) {
+        gs_set_error("rasterize: unsupported number of colour channels: %u", a.channels);
+        return 1;
+    }
+    if (a.tile_size == 0 || a.tile_size > 16) {
+        gs_set_error("rasterize: tile_size must be in [1, 16], got %u", a.tile_size);
+        return 1;
+    }
+    if ((uint64_t)a.tile_width * a.tile_size < a.image_width || (uint64_t)a.tile_height * a.tile_size < a.image_height) {
+        gs_set_error("rasterize: tile grid %ux%u (tile %u) does not cover the %ux%u image", a.tile_width,
+                     a.tile_height, a.tile_size, a.image_width, a.image_height);
+        return 1;
+    }
+    return 0;
+}
+
+extern "C" int32_t gs_rasterize_fwd(
+    uint32_t C, uint32_t n_elems, uint32_t n_isects, uint32_t channels, const float *means2d,
+    const float *conics, const float *colors, const float *opacities, const float *backgrounds,
+    const uint8_t *masks, uint32_t image_width, uint32_t image_height, uint32_t tile_size,
+    uint32_t tile_width, uint32_t tile_height, const int32_t *tile_offsets,
+    const int32_t *flatten_ids, float *render_colors, float *render_alphas, int32_t *last_ids,
+    gs_stream_t stream) {
+    GS_CHECK_ARG(render_colors && render_alphas && last_ids && tile_offsets, "null pointer");
+    GS_CHECK_ARG(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids), "null pointer");
+    RasterArgs a = {C, n_elems, n_isects, channels, means2d, conics, colors, opacities, backgrounds, masks,
+                    image_width, image_height, tile_size, tile_width, tile_height, tile_offsets, flatten_ids,
+                    render_colors, render_alphas, last_ids};
+    if (int32_t rc = check_raster_args(a)) return rc;
+    if (C == 0 || image_width == 0 || image_height == 0) return 0;
+    int32_t rc = use_ref_raster() ? raster_ref_fwd(a, (hipStream_t)stream) : raster_wave_fwd(a, (hipStream_t)stream);
+    if (rc) return rc;
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_rasterize_bwd(
+    uint32_t C, uint32_t n_elems, uint32_t n_isects, uint32_t channels, const float *means2d,
+    const float *conics, const float *colors, const float *opacities, const float *backgrounds,
+    const uint8_t *masks, uint32_t image_width, uint32_t image_height, uint32_t tile_size,
+    uint32_t tile_width, uint32_t tile_height, const int32_t *tile_offsets,
+    const int32_t *flatten_ids, const float *render_alphas, const int32_t *last_ids,
+    const float *v_render_colors, const float *v_render_alphas, float *v_means2d_abs,
+    float *v_means2d, float *v_conics, float *v_colors, float *v_opacities, gs_stream_t stream) {
+    GS_CHECK_ARG(render_alphas && last_ids && v_render_colors && tile_offsets, "null pointer");
+    GS_CHECK_ARG(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids && v_means2d &&
+                                   v_conics && v_colors && v_opacities),
+                 "null pointer");
+    RasterArgs a = {C, n_elems, n_isects, channels, means2d, conics, colors, opacities, backgrounds, masks,
+                    image_width, image_height, tile_size, tile_width, tile_height, tile_offsets, flatten_ids,
+                    nullptr, nullptr, nullptr};
+    RasterGradArgs ga = {render_alphas, last_ids, v_render_colors, v_render_alphas, v_means2d_abs,
+                         v_means2d, v_conics, v_colors, v_opacities};
+    if (int32_t rc = check_raster_args(a)) return rc;
+    if (C == 0 || image_width == 0 || image_height == 0 || n_isects == 0) return 0;
+    int32_t rc = use_ref_raster() ? raster_ref_bwd(a, ga, (hipStream_t)stream) : raster_wave_bwd(a, ga, (hipStream_t)stream);
+    if (rc) return rc;
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// quat/scale -> covariance / precision (unfused public op)
+// reference: gsplat/cuda/csrc/quat_scale_to_covar_preci_fwd.cu:19-91, _bwd.cu:20-113
+// ---------------------------------------------------------------------------
+namespace {
+
+GS_DEV void write_sym(float *dst, const Sym3 &S, int triu, size_t n) {
+    if (triu) {
+        float *o = dst + 6 * n;
+        o[0] = S.xx; o[1] = S.xy; o[2] = S.xz; o[3] = S.yy; o[4] = S.yz; o[5] = S.zz;
+    } else {
+        float *o = dst + 9 * n;
+        o[0] = S.xx; o[1] = S.xy; o[2] = S.xz;
+        o[3] = S.xy; o[4] = S.yy; o[5] = S.yz;
+        o[6] = S.xz; o[7] = S.yz; o[8] = S.zz;
+    }
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) qs2cp_fwd_kernel(
+    uint32_t N, const float *__restrict__ quats, const float *__restrict__ scales, int triu,
+    float *__restrict__ covars, float *__restrict__ precis) {
+    uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    const float *q = quats + 4 * (size_t)n;
+    const float *s = scales + 3 * (size_t)n;
+    Mat3 R = quat_to_rotmat(q[0], q[1], q[2], q[3]);
+    if (covars != nullptr) write_sym(covars, covar_from_rot_scale(R, s[0], s[1], s[2]), triu, n);
+    if (precis != nullptr) write_sym(precis, covar_from_rot_scale(R, 1.f / s[0], 1.f / s[1], 1.f / s[2]), triu, n);
+}
+
+GS_DEV Mat3 read_grad(const float *src, int triu, size_t n) {
+    Mat3 G;
+    if (triu) {
+        // d/d(triu entry): the off-diagonal entry stands for both (i,j) and (j,i)
+        const float *v = src + 6 * n;
+        G.m[0][0] = v[0]; G.m[0][1] = 0.5f * v[1]; G.m[0][2] = 0.5f * v[2];
+        G.m[1][0] = 0.5f * v[1]; G.m[1][1] = v[3]; G.m[1][2] = 0.5f * v[4];
+        G.m[2][0] = 0.5f * v[2]; G.m[2][1] = 0.5f * v[4]; G.m[2][2] = v[5];
+    } else {
+        const float *v = src + 9 * n;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) G.m[i][j] = v[3 * i + j];
+    }
+    return G;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) qs2cp_bwd_kernel(
+    uint32_t N, const float *__restrict__ quats, const float *__restrict__ scales, int triu,
+    const float *__restrict__ v_covars, const float *__restrict__ v_precis,
+    float *__restrict__ v_quats, float *__restrict__ v_scales) {
+    uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    const float *q = quats + 4 * (size_t)n;
+    const float *s = scales + 3 * (size_t)n;
+    Mat3 R = quat_to_rotmat(q[0], q[1], q[2], q[3]);
+    float vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
+    if (v_covars != nullptr)
+        covar_vjp_quat_scale(q[0], q[1], q[2], q[3], s[0], s[1], s[2], R, read_grad(v_covars, triu, n), vq, vs);
+    if (v_precis != nullptr) {
+        // precision = covariance built from 1/s: chain rule d(1/s)/ds = -1/s^2
+        float is0 = 1.f / s[0], is1 = 1.f / s[1], is2 = 1.f / s[2];
+        float vi[3] = {0.f, 0.f, 0.f};
+        covar_vjp_quat_scale(q[0], q[1], q[2], q[3], is0, is1, is2, R, read_grad(v_precis, triu, n), vq, vi);
+        vs[0] += -is0 * is0 * vi[0];
+        vs[1] += -is1 * is1 * vi[1];
+        vs[2] += -is2 * is2 * vi[2];
+    }
+    float *oq = v_quats + 4 * (size_t)n;
+    float *os = v_scales + 3 * (size_t)n;
+    oq[0] = vq[0]; oq[1] = vq[1]; oq[2] = vq[2]; oq[3] = vq[3];
+    os[0] = vs[0]; os[1] = vs[1]; os[2] = vs[2];
+}
+
+} // namespace
+
+extern "C" int32_t gs_quat_scale_to_covar_preci_fwd(
+    uint32_t N, const float *quats, const float *scales, int32_t triu, float *covars, float *precis,
+    gs_stream_t stream) {
+    if (N == 0) return 0;
+    GS_CHECK_ARG(quats && scales, "null pointer");
+    hipLaunchKernelGGL(qs2cp_fwd_kernel, dim3(gs_div_up(N, GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream, N,
+                       quats, scales, triu, covars, precis);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_quat_scale_to_covar_preci_bwd(
+    uint32_t N, const float *quats, const float *scales, int32_t triu, const float *v_covars,
+    const float *v_precis, float *v_quats, float *v_scales, gs_stream_t stream) {
+    if (N == 0) return 0;
+    GS_CHECK_ARG(quats && scales && v_quats && v_scales, "null pointer");
+    hipLaunchKernelGGL(qs2cp_bwd_kernel, dim3(gs_div_up(N, GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream, N,
+                       quats, scales, triu, v_covars, v_precis, v_quats, v_scales);
+    GS_CHECK_LAUNCH();
+    return 0;
+}

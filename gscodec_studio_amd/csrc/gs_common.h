@@ -1,0 +1,239 @@
+// gs_common.h -- shared host/device helpers for libgsplat_hip (gfx950 only).
+//
+// Conventions (differ from the reference, which uses column-major glm types):
+//   * 3x3 matrices are row-major structs (m[r][c]); symmetric 3x3 are 6 scalars
+//     (xx, xy, xz, yy, yz, zz); symmetric 2x2 are 3 scalars (xx, xy, yy).
+//   * quaternions are (w, x, y, z), not necessarily normalised.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gsplat_hip.h"
+
+#define GS_WAVE 64
+#define GS_BLOCK 256
+
+#define GS_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+void gs_set_error(const char *fmt, ...);
+
+#define GS_CHECK_ARG(cond, msg)                                                        \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            gs_set_error("%s: %s", __func__, msg);                                     \
+            return 1;                                                                  \
+        }                                                                              \
+    } while (0)
+
+#define GS_CHECK_LAUNCH()                                                              \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) {                                                        \
+            gs_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_));    \
+            return 2;                                                                  \
+        }                                                                              \
+    } while (0)
+
+static inline uint32_t gs_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------
+// small linear algebra
+// ---------------------------------------------------------------------------
+struct Vec3 {
+    float x, y, z;
+};
+struct Mat3 {
+    float m[3][3];
+};
+struct Sym3 {
+    float xx, xy, xz, yy, yz, zz;
+};
+struct Sym2 {
+    float xx, xy, yy;
+};
+
+GS_DEV Mat3 mat3_zero() {
+    Mat3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r.m[i][j] = 0.f;
+    return r;
+}
+
+GS_DEV Mat3 sym3_to_mat3(const Sym3 &s) {
+    Mat3 r;
+    r.m[0][0] = s.xx; r.m[0][1] = s.xy; r.m[0][2] = s.xz;
+    r.m[1][0] = s.xy; r.m[1][1] = s.yy; r.m[1][2] = s.yz;
+    r.m[2][0] = s.xz; r.m[2][1] = s.yz; r.m[2][2] = s.zz;
+    return r;
+}
+
+GS_DEV Mat3 mat3_mul(const Mat3 &a, const Mat3 &b) {
+    Mat3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+    return r;
+}
+
+// a^T * b
+GS_DEV Mat3 mat3_tmul(const Mat3 &a, const Mat3 &b) {
+    Mat3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            r.m[i][j] = a.m[0][i] * b.m[0][j] + a.m[1][i] * b.m[1][j] + a.m[2][i] * b.m[2][j];
+    return r;
+}
+
+// a * b^T
+GS_DEV Mat3 mat3_mult(const Mat3 &a, const Mat3 &b) {
+    Mat3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            r.m[i][j] = a.m[i][0] * b.m[j][0] + a.m[i][1] * b.m[j][1] + a.m[i][2] * b.m[j][2];
+    return r;
+}
+
+// W * S * W^T for symmetric S -> symmetric
+GS_DEV Sym3 sym3_congruence(const Mat3 &W, const Sym3 &S) {
+    Mat3 Sm = sym3_to_mat3(S);
+    Mat3 WS = mat3_mul(W, Sm);
+    Sym3 r;
+    r.xx = WS.m[0][0] * W.m[0][0] + WS.m[0][1] * W.m[0][1] + WS.m[0][2] * W.m[0][2];
+    r.xy = WS.m[0][0] * W.m[1][0] + WS.m[0][1] * W.m[1][1] + WS.m[0][2] * W.m[1][2];
+    r.xz = WS.m[0][0] * W.m[2][0] + WS.m[0][1] * W.m[2][1] + WS.m[0][2] * W.m[2][2];
+    r.yy = WS.m[1][0] * W.m[1][0] + WS.m[1][1] * W.m[1][1] + WS.m[1][2] * W.m[1][2];
+    r.yz = WS.m[1][0] * W.m[2][0] + WS.m[1][1] * W.m[2][1] + WS.m[1][2] * W.m[2][2];
+    r.zz = WS.m[2][0] * W.m[2][0] + WS.m[2][1] * W.m[2][1] + WS.m[2][2] * W.m[2][2];
+    return r;
+}
+
+// W^T * G * W for symmetric G -> symmetric
+GS_DEV Sym3 sym3_congruence_t(const Mat3 &W, const Sym3 &G) {
+    Mat3 Gm = sym3_to_mat3(G);
+    Mat3 GW = mat3_mul(Gm, W); // G * W
+    Sym3 r;
+    r.xx = W.m[0][0] * GW.m[0][0] + W.m[1][0] * GW.m[1][0] + W.m[2][0] * GW.m[2][0];
+    r.xy = W.m[0][0] * GW.m[0][1] + W.m[1][0] * GW.m[1][1] + W.m[2][0] * GW.m[2][1];
+    r.xz = W.m[0][0] * GW.m[0][2] + W.m[1][0] * GW.m[1][2] + W.m[2][0] * GW.m[2][2];
+    r.yy = W.m[0][1] * GW.m[0][1] + W.m[1][1] * GW.m[1][1] + W.m[2][1] * GW.m[2][1];
+    r.yz = W.m[0][1] * GW.m[0][2] + W.m[1][1] * GW.m[1][2] + W.m[2][1] * GW.m[2][2];
+    r.zz = W.m[0][2] * GW.m[0][2] + W.m[1][2] * GW.m[1][2] + W.m[2][2] * GW.m[2][2];
+    return r;
+}
+
+// rotation matrix of a (possibly un-normalised) quaternion (w,x,y,z).
+// reference behaviour: gsplat/cuda/include/quat.cuh:9-31
+GS_DEV Mat3 quat_to_rotmat(float w, float x, float y, float z) {
+    float inv = rsqrtf(w * w + x * x + y * y + z * z);
+    w *= inv; x *= inv; y *= inv; z *= inv;
+    float xx = x * x, yy = y * y, zz = z * z;
+    float xy = x * y, xz = x * z, yz = y * z;
+    float wx = w * x, wy = w * y, wz = w * z;
+    Mat3 R;
+    R.m[0][0] = 1.f - 2.f * (yy + zz); R.m[0][1] = 2.f * (xy - wz);       R.m[0][2] = 2.f * (xz + wy);
+    R.m[1][0] = 2.f * (xy + wz);       R.m[1][1] = 1.f - 2.f * (xx + zz); R.m[1][2] = 2.f * (yz - wx);
+    R.m[2][0] = 2.f * (xz - wy);       R.m[2][1] = 2.f * (yz + wx);       R.m[2][2] = 1.f - 2.f * (xx + yy);
+    return R;
+}
+
+// Sigma = (R S)(R S)^T   (gsplat/cuda/include/quat_scale_to_covar_preci.cuh:10-41)
+GS_DEV Sym3 covar_from_rot_scale(const Mat3 &R, float sx, float sy, float sz) {
+    Mat3 M;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        M.m[i][0] = R.m[i][0] * sx;
+        M.m[i][1] = R.m[i][1] * sy;
+        M.m[i][2] = R.m[i][2] * sz;
+    }
+    Sym3 S;
+    S.xx = M.m[0][0] * M.m[0][0] + M.m[0][1] * M.m[0][1] + M.m[0][2] * M.m[0][2];
+    S.xy = M.m[0][0] * M.m[1][0] + M.m[0][1] * M.m[1][1] + M.m[0][2] * M.m[1][2];
+    S.xz = M.m[0][0] * M.m[2][0] + M.m[0][1] * M.m[2][1] + M.m[0][2] * M.m[2][2];
+    S.yy = M.m[1][0] * M.m[1][0] + M.m[1][1] * M.m[1][1] + M.m[1][2] * M.m[1][2];
+    S.yz = M.m[1][0] * M.m[2][0] + M.m[1][1] * M.m[2][1] + M.m[1][2] * M.m[2][2];
+    S.zz = M.m[2][0] * M.m[2][0] + M.m[2][1] * M.m[2][1] + M.m[2][2] * M.m[2][2];
+    return S;
+}
+
+// VJP of Sigma = (R S)(R S)^T w.r.t. quaternion and scale, given a SYMMETRISED
+// upstream gradient G (G = v_Sigma + v_Sigma^T already folded: pass the full
+// matrix gradient as Mat3, not assumed symmetric).
+// reference behaviour: quat_scale_to_covar_preci.cuh:43-81, quat.cuh:33-57
+GS_DEV void covar_vjp_quat_scale(
+    float qw, float qx, float qy, float qz, float sx, float sy, float sz,
+    const Mat3 &R, const Mat3 &vSigma, float vq[4], float vs[3]) {
+    // M = R S ; v_M = (G + G^T) M
+    Mat3 Gs;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Gs.m[i][j] = vSigma.m[i][j] + vSigma.m[j][i];
+    Mat3 M;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        M.m[i][0] = R.m[i][0] * sx;
+        M.m[i][1] = R.m[i][1] * sy;
+        M.m[i][2] = R.m[i][2] * sz;
+    }
+    Mat3 vM = mat3_mul(Gs, M);
+    // v_s_j = sum_i R_ij vM_ij ; v_R_ij = vM_ij * s_j
+    vs[0] += R.m[0][0] * vM.m[0][0] + R.m[1][0] * vM.m[1][0] + R.m[2][0] * vM.m[2][0];
+    vs[1] += R.m[0][1] * vM.m[0][1] + R.m[1][1] * vM.m[1][1] + R.m[2][1] * vM.m[2][1];
+    vs[2] += R.m[0][2] * vM.m[0][2] + R.m[1][2] * vM.m[1][2] + R.m[2][2] * vM.m[2][2];
+    Mat3 V;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        V.m[i][0] = vM.m[i][0] * sx;
+        V.m[i][1] = vM.m[i][1] * sy;
+        V.m[i][2] = vM.m[i][2] * sz;
+    }
+    // d R / d q_normalised
+    float inv = rsqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+    float w = qw * inv, x = qx * inv, y = qy * inv, z = qz * inv;
+    float gw = 2.f * (x * (V.m[2][1] - V.m[1][2]) + y * (V.m[0][2] - V.m[2][0]) + z * (V.m[1][0] - V.m[0][1]));
+    float gx = 2.f * (-2.f * x * (V.m[1][1] + V.m[2][2]) + y * (V.m[1][0] + V.m[0][1]) +
+                      z * (V.m[2][0] + V.m[0][2]) + w * (V.m[2][1] - V.m[1][2]));
+    float gy = 2.f * (x * (V.m[1][0] + V.m[0][1]) - 2.f * y * (V.m[0][0] + V.m[2][2]) +
+                      z * (V.m[2][1] + V.m[1][2]) + w * (V.m[0][2] - V.m[2][0]));
+    float gz = 2.f * (x * (V.m[2][0] + V.m[0][2]) + y * (V.m[2][1] + V.m[1][2]) -
+                      2.f * z * (V.m[0][0] + V.m[1][1]) + w * (V.m[1][0] - V.m[0][1]));
+    // through the normalisation: (g - (g . qn) qn) / |q|
+    float dot = gw * w + gx * x + gy * y + gz * z;
+    vq[0] += (gw - dot * w) * inv;
+    vq[1] += (gx - dot * x) * inv;
+    vq[2] += (gy - dot * y) * inv;
+    vq[3] += (gz - dot * z) * inv;
+}
+
+// ---------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------
+GS_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// full-wave sum, result valid in every lane
+GS_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+GS_DEV int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int o = __shfl_xor(v, off, 64);
+        v = v > o ? v : o;
+    }
+    return v;
+}

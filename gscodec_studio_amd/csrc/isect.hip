@@ -1,0 +1,277 @@
+// isect.hip -- R3/R4: gaussian/tile intersection, prefix sums, offset encode (gfx950).
+//
+// Replaces gsplat/cuda/csrc/isect_tiles.cu:16-104 (count + emit passes), the
+// torch::cumsum between them (isect_tiles.cu:199) and isect_offset_encode
+// (isect_tiles.cu:308-354).  The 64-bit radix sort lives in radix_sort.hip.
+//
+// All outputs of this file are integers derived from fp32 inputs with IEEE
+// (correctly rounded) division / floor / ceil, so they are bit-exact against the
+// oracle.  The file is compiled with -ffp-contract=off.
+#include "gs_common.h"
+
+namespace {
+
+struct TileBox {
+    int32_t x0, y0, x1, y1; // min inclusive, max exclusive
+};
+
+// isect_tiles.cu:56-69.  The reference casts a possibly negative float to uint32 and
+// relies on the saturating conversion; here the clamp is explicit.
+GS_DEV TileBox tile_box(float mx, float my, int32_t radius, float tile_size, int32_t tw, int32_t th) {
+    float tr = (float)radius / tile_size;
+    float tx = mx / tile_size;
+    float ty = my / tile_size;
+    TileBox b;
+    b.x0 = min(max(0, (int32_t)floorf(tx - tr)), tw);
+    b.y0 = min(max(0, (int32_t)floorf(ty - tr)), th);
+    b.x1 = min(max(0, (int32_t)ceilf(tx + tr)), tw);
+    b.y1 = min(max(0, (int32_t)ceilf(ty + tr)), th);
+    return b;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) isect_count_kernel(
+    uint32_t n_elems, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+    float tile_size, int32_t tw, int32_t th, int32_t *__restrict__ tiles_per_gauss) {
+    uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (i >= n_elems) return;
+    int32_t r = radii[i];
+    int32_t cnt = 0;
+    if (r > 0) {
+        float2 m = reinterpret_cast<const float2 *>(means2d)[i];
+        TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
+        cnt = (b.y1 - b.y0) * (b.x1 - b.x0);
+    }
+    tiles_per_gauss[i] = cnt;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
+    uint32_t n_elems, uint32_t N, const int64_t *__restrict__ camera_ids,
+    const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+    const float *__restrict__ depths, const int64_t *__restrict__ cum_tiles,
+    float tile_size, int32_t tw, int32_t th, uint32_t tile_n_bits,
+    int64_t *__restrict__ isect_ids, int32_t *__restrict__ flatten_ids) {
+    uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (i >= n_elems) return;
+    int32_t r = radii[i];
+    if (r <= 0) return;
+    float2 m = reinterpret_cast<const float2 *>(means2d)[i];
+    TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
+    int64_t cid = camera_ids != nullptr ? camera_ids[i] : (int64_t)(i / N);
+    int64_t cid_enc = cid << (32 + tile_n_bits);
+    // raw IEEE bits of the (positive) depth, sign-extended like the reference's
+    // (int64_t)*(int32_t*)&depth  (isect_tiles.cu:91)
+    int64_t depth_enc = (int64_t)__float_as_int(depths[i]);
+    int64_t cur = (i == 0) ? 0 : cum_tiles[i - 1];
+    for (int32_t y = b.y0; y < b.y1; ++y) {
+        for (int32_t x = b.x0; x < b.x1; ++x) {
+            int64_t tile_id = (int64_t)y * tw + x;
+            isect_ids[cur] = cid_enc | (tile_id << 32) | depth_enc;
+            flatten_ids[cur] = (int32_t)i;
+            ++cur;
+        }
+    }
+}
+
+// isect_tiles.cu:308-354
+__global__ void __launch_bounds__(GS_BLOCK) isect_offset_encode_kernel(
+    uint32_t n_isects, const int64_t *__restrict__ isect_ids, uint32_t C, uint32_t n_tiles,
+    uint32_t tile_n_bits, int32_t *__restrict__ offsets) {
+    uint32_t idx = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (idx >= n_isects) return;
+    const int64_t tmask = ((int64_t)1 << tile_n_bits) - 1;
+    int64_t cur = isect_ids[idx] >> 32;
+    int64_t id_cur = (cur >> tile_n_bits) * n_tiles + (cur & tmask);
+    if (idx == 0) {
+        for (int64_t i = 0; i <= id_cur; ++i) offsets[i] = 0;
+    }
+    if (idx == n_isects - 1) {
+        for (int64_t i = id_cur + 1; i < (int64_t)C * n_tiles; ++i) offsets[i] = (int32_t)n_isects;
+    }
+    if (idx > 0) {
+        int64_t prev = isect_ids[idx - 1] >> 32;
+        if (prev == cur) return;
+        int64_t id_prev = (prev >> tile_n_bits) * n_tiles + (prev & tmask);
+        for (int64_t i = id_prev + 1; i <= id_cur; ++i) offsets[i] = (int32_t)idx;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// inclusive prefix sum (reduce-then-scan, 3 launches).  2048 items per block.
+// ---------------------------------------------------------------------------
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = GS_BLOCK * SCAN_ITEMS;
+
+GS_DEV int64_t wave_inclusive_scan_i64(int64_t v) {
+    uint32_t lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int64_t o = __shfl_up(v, off, 64);
+        if (lane >= (uint32_t)off) v += o;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one int64 per thread; returns the exclusive prefix and
+// the block total.
+GS_DEV int64_t block_exclusive_scan_i64(int64_t v, int64_t &total, int64_t *s_wave /*[4]*/) {
+    uint32_t lane = threadIdx.x % GS_WAVE, wave = threadIdx.x / GS_WAVE;
+    int64_t inc = wave_inclusive_scan_i64(v);
+    if (lane == GS_WAVE - 1) s_wave[wave] = inc;
+    __syncthreads();
+    int64_t base = 0, t = 0;
+#pragma unroll
+    for (int w = 0; w < GS_BLOCK / GS_WAVE; ++w) {
+        if ((uint32_t)w < wave) base += s_wave[w];
+        t += s_wave[w];
+    }
+    total = t;
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) scan_block_sums_kernel(
+    uint64_t n, const int32_t *__restrict__ in, int64_t *__restrict__ block_sums) {
+    __shared__ int64_t s_wave[GS_BLOCK / GS_WAVE];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint64_t i = base + (uint64_t)k * GS_BLOCK + threadIdx.x;
+        if (i < n) s += in[i];
+    }
+    int64_t total;
+    block_exclusive_scan_i64(s, total, s_wave);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single block: in-place exclusive scan of the block sums
+__global__ void __launch_bounds__(GS_BLOCK) scan_spine_kernel(uint32_t n_blocks, int64_t *__restrict__ block_sums) {
+    __shared__ int64_t s_wave[GS_BLOCK / GS_WAVE];
+    int64_t carry = 0;
+    for (uint32_t base = 0; base < n_blocks; base += GS_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        int64_t v = i < n_blocks ? block_sums[i] : 0;
+        int64_t total;
+        int64_t ex = block_exclusive_scan_i64(v, total, s_wave);
+        if (i < n_blocks) block_sums[i] = carry + ex;
+        carry += total;
+    }
+}
+
+template <typename OutT>
+__global__ void __launch_bounds__(GS_BLOCK) scan_apply_kernel(
+    uint64_t n, const int32_t *__restrict__ in, const int64_t *__restrict__ block_sums,
+    OutT *__restrict__ out) {
+    __shared__ int64_t s_wave[GS_BLOCK / GS_WAVE];
+    // blocked arrangement: thread t owns items [t*ITEMS, (t+1)*ITEMS)
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    int32_t v[SCAN_ITEMS];
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint64_t i = base + k;
+        v[k] = i < n ? in[i] : 0;
+        s += v[k];
+    }
+    int64_t total;
+    int64_t run = block_exclusive_scan_i64(s, total, s_wave) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint64_t i = base + k;
+        run += v[k];
+        if (i < n) out[i] = (OutT)run;
+    }
+}
+
+template <typename OutT>
+int32_t cumsum_impl(uint64_t n, const int32_t *in, OutT *out, void *scratch, size_t scratch_bytes,
+                    hipStream_t st) {
+    if (n == 0) return 0;
+    uint32_t n_blocks = gs_div_up(n, SCAN_TILE);
+    if (scratch == nullptr || scratch_bytes < (size_t)n_blocks * sizeof(int64_t)) {
+        gs_set_error("gs_cumsum: scratch too small (%zu < %zu)", scratch_bytes, (size_t)n_blocks * sizeof(int64_t));
+        return 1;
+    }
+    int64_t *sums = (int64_t *)scratch;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(n_blocks), dim3(GS_BLOCK), 0, st, n, in, sums);
+    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(GS_BLOCK), 0, st, n_blocks, sums);
+    hipLaunchKernelGGL((scan_apply_kernel<OutT>), dim3(n_blocks), dim3(GS_BLOCK), 0, st, n, in, sums, out);
+    return 0;
+}
+
+} // namespace
+
+extern "C" int32_t gs_isect_count(
+    uint32_t n_elems, const float *means2d, const int32_t *radii, uint32_t tile_size,
+    uint32_t tile_width, uint32_t tile_height, int32_t *tiles_per_gauss, gs_stream_t stream) {
+    if (n_elems == 0) return 0;
+    GS_CHECK_ARG(means2d && radii && tiles_per_gauss, "null pointer");
+    GS_CHECK_ARG(tile_size > 0, "tile_size must be > 0");
+    hipLaunchKernelGGL(isect_count_kernel, dim3(gs_div_up(n_elems, GS_BLOCK)), dim3(GS_BLOCK), 0,
+                       (hipStream_t)stream, n_elems, means2d, radii, (float)tile_size, (int32_t)tile_width,
+                       (int32_t)tile_height, tiles_per_gauss);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t gs_cumsum_scratch_bytes(uint64_t n) {
+    return (size_t)(gs_div_up(n, SCAN_TILE) + 1) * sizeof(int64_t);
+}
+
+extern "C" int32_t gs_cumsum_i32(
+    uint64_t n, const int32_t *in, int64_t *out, void *scratch, size_t scratch_bytes, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(in && out, "null pointer");
+    int32_t rc = cumsum_impl<int64_t>(n, in, out, scratch, scratch_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_cumsum_i32_i32(
+    uint64_t n, const int32_t *in, int32_t *out, void *scratch, size_t scratch_bytes, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(in && out, "null pointer");
+    int32_t rc = cumsum_impl<int32_t>(n, in, out, scratch, scratch_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_isect_emit(
+    uint32_t n_elems, uint32_t N, const int64_t *camera_ids, const float *means2d,
+    const int32_t *radii, const float *depths, const int64_t *cum_tiles_per_gauss,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits,
+    int64_t *isect_ids, int32_t *flatten_ids, gs_stream_t stream) {
+    if (n_elems == 0) return 0;
+    GS_CHECK_ARG(means2d && radii && depths && cum_tiles_per_gauss, "null pointer");
+    GS_CHECK_ARG(camera_ids != nullptr || N > 0, "N must be > 0 when camera_ids is NULL");
+    GS_CHECK_ARG(tile_n_bits < 32, "tile_n_bits must be < 32");
+    hipLaunchKernelGGL(isect_emit_kernel, dim3(gs_div_up(n_elems, GS_BLOCK)), dim3(GS_BLOCK), 0,
+                       (hipStream_t)stream, n_elems, N, camera_ids, means2d, radii, depths,
+                       cum_tiles_per_gauss, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
+                       tile_n_bits, isect_ids, flatten_ids);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_isect_offset_encode(
+    uint32_t n_isects, const int64_t *isect_ids_sorted, uint32_t C, uint32_t n_tiles,
+    uint32_t tile_n_bits, int32_t *offsets, gs_stream_t stream) {
+    GS_CHECK_ARG(offsets != nullptr, "null pointer");
+    if ((uint64_t)C * n_tiles == 0) return 0;
+    if (n_isects == 0) {
+        // reference: offsets.fill_(0)  (isect_tiles.cu:385-387)
+        hipError_t e = hipMemsetAsync(offsets, 0, (size_t)C * n_tiles * sizeof(int32_t), (hipStream_t)stream);
+        if (e != hipSuccess) {
+            gs_set_error("gs_isect_offset_encode: memset failed: %s", hipGetErrorString(e));
+            return 2;
+        }
+        return 0;
+    }
+    GS_CHECK_ARG(isect_ids_sorted != nullptr, "null pointer");
+    hipLaunchKernelGGL(isect_offset_encode_kernel, dim3(gs_div_up(n_isects, GS_BLOCK)), dim3(GS_BLOCK), 0,
+                       (hipStream_t)stream, n_isects, isect_ids_sorted, C, n_tiles, tile_n_bits, offsets);
+    GS_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,798 @@
+// projection.hip -- R1: fully fused 3D->2D projection of gaussians, fwd + bwd (gfx950).
+//
+// Replaces the reference kernels
+//   gsplat/cuda/csrc/fully_fused_projection_fwd.cu:22-196
+//   gsplat/cuda/csrc/fully_fused_projection_bwd.cu:24-263
+//   gsplat/cuda/csrc/fully_fused_projection_packed_{fwd,bwd}.cu
+// Design notes (MI355X):
+//   * HBM-streaming kernels: one lane per (camera, gaussian) in fwd, one lane per
+//     gaussian looping over cameras in bwd.  The bwd therefore needs NO atomics and
+//     no warp-segmented reduction (the reference uses cg::labeled_partition, which
+//     does not exist on ROCm) and is deterministic; every gaussian row of the gradient
+//     tensors is written exactly once, so the caller does not zero-fill them.
+//   * Camera constants (viewmat / K, 100 B per camera) are wave-uniform loads and live
+//     in SGPRs.
+//   * All maths are written on symmetric 2x2 / 3x3 forms (6 / 3 scalars), row-major.
+#include "gs_common.h"
+
+namespace {
+
+struct Camera {
+    Mat3 W;       // world->camera rotation
+    float tx, ty, tz;
+    float fx, fy, cx, cy;
+};
+
+GS_DEV Camera load_camera(const float *__restrict__ viewmats, const float *__restrict__ Ks, uint32_t c) {
+    const float *V = viewmats + 16 * c;
+    const float *K = Ks + 9 * c;
+    Camera cam;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cam.W.m[i][j] = V[4 * i + j];
+    cam.tx = V[3]; cam.ty = V[7]; cam.tz = V[11];
+    cam.fx = K[0]; cam.cx = K[2]; cam.fy = K[4]; cam.cy = K[5];
+    return cam;
+}
+
+GS_DEV Sym3 load_covar(
+    const float *__restrict__ covars, const float *__restrict__ quats,
+    const float *__restrict__ scales, uint32_t n) {
+    if (covars != nullptr) {
+        const float *c = covars + 6 * (size_t)n;
+        Sym3 S = {c[0], c[1], c[2], c[3], c[4], c[5]};
+        return S;
+    }
+    const float *q = quats + 4 * (size_t)n;
+    const float *s = scales + 3 * (size_t)n;
+    Mat3 R = quat_to_rotmat(q[0], q[1], q[2], q[3]);
+    return covar_from_rot_scale(R, s[0], s[1], s[2]);
+}
+
+// 2x3 Jacobian of the camera model at pc, plus the projected mean.
+struct Jac {
+    float j00, j01, j02, j10, j11, j12;
+};
+
+// pinhole: gsplat/cuda/include/proj.cuh:80-119 (the x/z, y/z clamp only affects J)
+GS_DEV void pinhole_jac(const Camera &cam, float x, float y, float z, int W, int H,
+                        Jac &J, float &mx, float &my, float &txc, float &tyc) {
+    float tan_fovx = 0.5f * W / cam.fx;
+    float tan_fovy = 0.5f * H / cam.fy;
+    float lim_x_pos = (W - cam.cx) / cam.fx + 0.3f * tan_fovx;
+    float lim_x_neg = cam.cx / cam.fx + 0.3f * tan_fovx;
+    float lim_y_pos = (H - cam.cy) / cam.fy + 0.3f * tan_fovy;
+    float lim_y_neg = cam.cy / cam.fy + 0.3f * tan_fovy;
+    float rz = 1.f / z;
+    float rz2 = rz * rz;
+    txc = z * fminf(lim_x_pos, fmaxf(-lim_x_neg, x * rz));
+    tyc = z * fminf(lim_y_pos, fmaxf(-lim_y_neg, y * rz));
+    J.j00 = cam.fx * rz; J.j01 = 0.f;         J.j02 = -cam.fx * txc * rz2;
+    J.j10 = 0.f;         J.j11 = cam.fy * rz; J.j12 = -cam.fy * tyc * rz2;
+    mx = cam.fx * x * rz + cam.cx;
+    my = cam.fy * y * rz + cam.cy;
+}
+
+// orthographic: proj.cuh:9-37
+GS_DEV void ortho_jac(const Camera &cam, float x, float y, Jac &J, float &mx, float &my) {
+    J.j00 = cam.fx; J.j01 = 0.f; J.j02 = 0.f;
+    J.j10 = 0.f; J.j11 = cam.fy; J.j12 = 0.f;
+    mx = cam.fx * x + cam.cx;
+    my = cam.fy * y + cam.cy;
+}
+
+// fisheye (equidistant): proj.cuh:202-243
+struct FisheyeTerms {
+    float x2, y2, xy, r2, rho, inv_rho, len, theta, a, b;
+};
+
+GS_DEV FisheyeTerms fisheye_terms(float x, float y, float z) {
+    const float eps = 0.0000001f;
+    FisheyeTerms t;
+    t.x2 = x * x + eps;
+    t.y2 = y * y;
+    t.xy = x * y;
+    t.r2 = t.x2 + t.y2;
+    t.rho = t.r2 + z * z;
+    t.inv_rho = 1.f / t.rho;
+    t.len = sqrtf(x * x + y * y) + eps;
+    t.theta = atan2f(t.len, z);
+    t.b = t.theta / t.len / t.r2;
+    t.a = z * t.inv_rho / t.r2;
+    return t;
+}
+
+GS_DEV void fisheye_jac(const Camera &cam, float x, float y, float z, Jac &J, float &mx, float &my) {
+    const float eps = 0.0000001f;
+    FisheyeTerms t = fisheye_terms(x, y, z);
+    float theta_m = atan2f(t.len, z + eps);
+    mx = x * cam.fx * theta_m / t.len + cam.cx;
+    my = y * cam.fy * theta_m / t.len + cam.cy;
+    J.j00 = cam.fx * (t.x2 * t.a + t.y2 * t.b);
+    J.j01 = cam.fx * t.xy * (t.a - t.b);
+    J.j02 = -cam.fx * x * t.inv_rho;
+    J.j10 = cam.fy * t.xy * (t.a - t.b);
+    J.j11 = cam.fy * (t.y2 * t.a + t.x2 * t.b);
+    J.j12 = -cam.fy * y * t.inv_rho;
+}
+
+// cov2d = J Sigma J^T
+GS_DEV Sym2 project_covar(const Jac &J, const Sym3 &S) {
+    float a0 = J.j00 * S.xx + J.j01 * S.xy + J.j02 * S.xz;
+    float a1 = J.j00 * S.xy + J.j01 * S.yy + J.j02 * S.yz;
+    float a2 = J.j00 * S.xz + J.j01 * S.yz + J.j02 * S.zz;
+    float b0 = J.j10 * S.xx + J.j11 * S.xy + J.j12 * S.xz;
+    float b1 = J.j10 * S.xy + J.j11 * S.yy + J.j12 * S.yz;
+    float b2 = J.j10 * S.xz + J.j11 * S.yz + J.j12 * S.zz;
+    Sym2 c;
+    c.xx = a0 * J.j00 + a1 * J.j01 + a2 * J.j02;
+    c.xy = a0 * J.j10 + a1 * J.j11 + a2 * J.j12;
+    c.yy = b0 * J.j10 + b1 * J.j11 + b2 * J.j12;
+    return c;
+}
+
+struct Splat2D {
+    int32_t radius; // 0 => culled
+    float mx, my, depth, ca, cb, cc, comp;
+};
+
+// Shared forward maths.  PACKED selects the packed-kernel radius formula
+// (fully_fused_projection_packed_fwd.cu:183-186) instead of the unpacked one
+// (fully_fused_projection_fwd.cu:167-169).
+template <bool PACKED>
+GS_DEV Splat2D project_one(
+    const Camera &cam, const float *__restrict__ means, const float *__restrict__ covars,
+    const float *__restrict__ quats, const float *__restrict__ scales, uint32_t n,
+    int W, int H, float eps2d, float near_plane, float far_plane, float radius_clip,
+    int camera_model) {
+    Splat2D out;
+    out.radius = 0;
+    const float *p = means + 3 * (size_t)n;
+    float px = p[0], py = p[1], pz = p[2];
+    float x = cam.W.m[0][0] * px + cam.W.m[0][1] * py + cam.W.m[0][2] * pz + cam.tx;
+    float y = cam.W.m[1][0] * px + cam.W.m[1][1] * py + cam.W.m[1][2] * pz + cam.ty;
+    float z = cam.W.m[2][0] * px + cam.W.m[2][1] * py + cam.W.m[2][2] * pz + cam.tz;
+    if (z < near_plane || z > far_plane) return out;
+
+    Sym3 S = load_covar(covars, quats, scales, n);
+    Sym3 Sc = sym3_congruence(cam.W, S);
+
+    Jac J;
+    float mx, my;
+    if (camera_model == GS_CAMERA_PINHOLE) {
+        float tx_, ty_;
+        pinhole_jac(cam, x, y, z, W, H, J, mx, my, tx_, ty_);
+    } else if (camera_model == GS_CAMERA_ORTHO) {
+        ortho_jac(cam, x, y, J, mx, my);
+    } else {
+        fisheye_jac(cam, x, y, z, J, mx, my);
+    }
+    Sym2 c2 = project_covar(J, Sc);
+
+    // blur + compensation (gsplat/cuda/include/utils.cuh:30-37)
+    float det_orig = c2.xx * c2.yy - c2.xy * c2.xy;
+    c2.xx += eps2d;
+    c2.yy += eps2d;
+    float det = c2.xx * c2.yy - c2.xy * c2.xy;
+    if (det <= 0.f) return out;
+    out.comp = sqrtf(fmaxf(0.f, det_orig / det));
+
+    float inv_det = 1.f / det;
+    out.ca = c2.yy * inv_det;
+    out.cb = -c2.xy * inv_det;
+    out.cc = c2.xx * inv_det;
+
+    float b = 0.5f * (c2.xx + c2.yy);
+    float radius;
+    if (PACKED) {
+        float sq = sqrtf(fmaxf(0.1f, b * b - det));
+        float v1 = b + sq, v2 = b - sq;
+        radius = ceilf(3.f * sqrtf(fmaxf(v1, v2)));
+    } else {
+        float v1 = b + sqrtf(fmaxf(0.01f, b * b - det));
+        radius = ceilf(3.f * sqrtf(v1));
+    }
+    if (radius <= radius_clip) return out;
+    if (mx + radius <= 0 || mx - radius >= W || my + radius <= 0 || my - radius >= H) return out;
+
+    out.radius = (int32_t)radius;
+    out.mx = mx; out.my = my; out.depth = z;
+    return out;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) projection_fwd_kernel(
+    uint32_t C, uint32_t N,
+    const float *__restrict__ means, const float *__restrict__ covars,
+    const float *__restrict__ quats, const float *__restrict__ scales,
+    const float *__restrict__ viewmats, const float *__restrict__ Ks,
+    int W, int H, float eps2d, float near_plane, float far_plane, float radius_clip,
+    int camera_model,
+    int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths,
+    float *__restrict__ conics, float *__restrict__ compensations) {
+    // grid = (ceil(N/256), C): the camera index is block-uniform => camera constants in SGPRs
+    uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
+    uint32_t c = blockIdx.y;
+    if (n >= N) return;
+    Camera cam = load_camera(viewmats, Ks, c);
+    Splat2D s = project_one<false>(cam, means, covars, quats, scales, n, W, H, eps2d, near_plane,
+                                   far_plane, radius_clip, camera_model);
+    size_t idx = (size_t)c * N + n;
+    radii[idx] = s.radius;
+    if (s.radius <= 0) return;
+    means2d[2 * idx] = s.mx;
+    means2d[2 * idx + 1] = s.my;
+    depths[idx] = s.depth;
+    conics[3 * idx] = s.ca;
+    conics[3 * idx + 1] = s.cb;
+    conics[3 * idx + 2] = s.cc;
+    if (compensations != nullptr) compensations[idx] = s.comp;
+}
+
+// ---------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------
+struct ProjGrad {
+    float v_px, v_py, v_pz; // d/d mean (world)
+    Sym3 v_S;               // d/d Sigma (world), symmetric full-matrix gradient
+    Mat3 v_W;               // d/d viewmat rotation
+    float v_t[3];           // d/d viewmat translation
+};
+
+// VJP for one (camera, gaussian) pair.  Follows the chain of
+// fully_fused_projection_bwd.cu:68-199 on symmetric forms.
+template <bool NEED_VIEW>
+GS_DEV void project_one_vjp(
+    const Camera &cam, float px, float py, float pz, const Sym3 &S,
+    int W, int H, float eps2d, int camera_model,
+    float ca, float cb, float cc,              // conic
+    float comp, float v_comp, bool has_comp,   // compensation
+    float v_mx, float v_my, float v_depth, float v_ca, float v_cb, float v_cc,
+    ProjGrad &g) {
+    // conic = inverse(cov2d_blur): v_cov = -P G P, G = [[v_ca, v_cb/2],[v_cb/2, v_cc]]
+    float g01 = 0.5f * v_cb;
+    float t00 = ca * v_ca + cb * g01, t01 = ca * g01 + cb * v_cc;
+    float t10 = cb * v_ca + cc * g01, t11 = cb * g01 + cc * v_cc;
+    Sym2 G;
+    G.xx = -(t00 * ca + t01 * cb);
+    G.xy = -(t00 * cb + t01 * cc);
+    G.yy = -(t10 * cb + t11 * cc);
+    if (has_comp) {
+        // utils.cuh:39-73
+        float det_conic = ca * cc - cb * cb;
+        float v_sqr = v_comp * 0.5f / (comp + 1e-6f);
+        float om = 1.f - comp * comp;
+        G.xx += v_sqr * (om * ca - eps2d * det_conic);
+        G.xy += v_sqr * (om * cb);
+        G.yy += v_sqr * (om * cc - eps2d * det_conic);
+    }
+
+    float x = cam.W.m[0][0] * px + cam.W.m[0][1] * py + cam.W.m[0][2] * pz + cam.tx;
+    float y = cam.W.m[1][0] * px + cam.W.m[1][1] * py + cam.W.m[1][2] * pz + cam.ty;
+    float z = cam.W.m[2][0] * px + cam.W.m[2][1] * py + cam.W.m[2][2] * pz + cam.tz;
+    Sym3 Sc = sym3_congruence(cam.W, S);
+
+    Jac J;
+    float mx, my, txc = 0.f, tyc = 0.f;
+    FisheyeTerms ft;
+    if (camera_model == GS_CAMERA_PINHOLE) {
+        pinhole_jac(cam, x, y, z, W, H, J, mx, my, txc, tyc);
+    } else if (camera_model == GS_CAMERA_ORTHO) {
+        ortho_jac(cam, x, y, J, mx, my);
+    } else {
+        fisheye_jac(cam, x, y, z, J, mx, my);
+        ft = fisheye_terms(x, y, z);
+    }
+
+    // v_Sc = J^T G J (symmetric 3x3)
+    float gj00 = G.xx * J.j00 + G.xy * J.j10, gj01 = G.xx * J.j01 + G.xy * J.j11, gj02 = G.xx * J.j02 + G.xy * J.j12;
+    float gj10 = G.xy * J.j00 + G.yy * J.j10, gj11 = G.xy * J.j01 + G.yy * J.j11, gj12 = G.xy * J.j02 + G.yy * J.j12;
+    Sym3 vSc;
+    vSc.xx = J.j00 * gj00 + J.j10 * gj10;
+    vSc.xy = J.j00 * gj01 + J.j10 * gj11;
+    vSc.xz = J.j00 * gj02 + J.j10 * gj12;
+    vSc.yy = J.j01 * gj01 + J.j11 * gj11;
+    vSc.yz = J.j01 * gj02 + J.j11 * gj12;
+    vSc.zz = J.j02 * gj02 + J.j12 * gj12;
+
+    // v_J = 2 G J Sc  (2x3)
+    float vj00 = 2.f * (gj00 * Sc.xx + gj01 * Sc.xy + gj02 * Sc.xz);
+    float vj01 = 2.f * (gj00 * Sc.xy + gj01 * Sc.yy + gj02 * Sc.yz);
+    float vj02 = 2.f * (gj00 * Sc.xz + gj01 * Sc.yz + gj02 * Sc.zz);
+    float vj10 = 2.f * (gj10 * Sc.xx + gj11 * Sc.xy + gj12 * Sc.xz);
+    float vj11 = 2.f * (gj10 * Sc.xy + gj11 * Sc.yy + gj12 * Sc.yz);
+    float vj12 = 2.f * (gj10 * Sc.xz + gj11 * Sc.yz + gj12 * Sc.zz);
+
+    float vx, vy, vz; // d/d pc
+    if (camera_model == GS_CAMERA_PINHOLE) {
+        // proj.cuh:122-199
+        float rz = 1.f / z, rz2 = rz * rz, rz3 = rz2 * rz;
+        float tan_fovx = 0.5f * W / cam.fx, tan_fovy = 0.5f * H / cam.fy;
+        float lim_x_pos = (W - cam.cx) / cam.fx + 0.3f * tan_fovx;
+        float lim_x_neg = cam.cx / cam.fx + 0.3f * tan_fovx;
+        float lim_y_pos = (H - cam.cy) / cam.fy + 0.3f * tan_fovy;
+        float lim_y_neg = cam.cy / cam.fy + 0.3f * tan_fovy;
+        vx = cam.fx * rz * v_mx;
+        vy = cam.fy * rz * v_my;
+        vz = -(cam.fx * x * v_mx + cam.fy * y * v_my) * rz2;
+        float xr = x * rz, yr = y * rz;
+        if (xr <= lim_x_pos && xr >= -lim_x_neg) vx += -cam.fx * rz2 * vj02;
+        else vz += -cam.fx * rz3 * vj02 * txc;
+        if (yr <= lim_y_pos && yr >= -lim_y_neg) vy += -cam.fy * rz2 * vj12;
+        else vz += -cam.fy * rz3 * vj12 * tyc;
+        vz += -cam.fx * rz2 * vj00 - cam.fy * rz2 * vj11 + 2.f * cam.fx * txc * rz3 * vj02 +
+              2.f * cam.fy * tyc * rz3 * vj12;
+    } else if (camera_model == GS_CAMERA_ORTHO) {
+        vx = cam.fx * v_mx;
+        vy = cam.fy * v_my;
+        vz = 0.f;
+    } else {
+        // fisheye: mean2d gradient through J itself (J is the Jacobian of the map),
+        // and d J / d pc from the radial derivatives of a(r,z), b(r,z).
+        // Equivalent in exact arithmetic to proj.cuh:245-343.
+        vx = J.j00 * v_mx + J.j10 * v_my;
+        vy = J.j01 * v_mx + J.j11 * v_my;
+        vz = J.j02 * v_mx + J.j12 * v_my;
+        float r2 = ft.r2, rho = ft.rho, len = ft.len;
+        float inv_rho2 = ft.inv_rho * ft.inv_rho;
+        float inv_r = 1.f / len;
+        float a_z = (r2 - z * z) * inv_rho2 / r2;
+        float a_r = -2.f * z * (2.f * r2 + z * z) * inv_rho2 / (r2 * len);
+        float b_z = -ft.inv_rho / r2;
+        float b_r = (z * ft.inv_rho) / (r2 * len) - 3.f * ft.theta / (r2 * r2);
+        float rx = x * inv_r, ry = y * inv_r;
+        float amb = ft.a - ft.b, amb_r = a_r - b_r, amb_z = a_z - b_z;
+        float q0_r = ft.x2 * a_r + ft.y2 * b_r; // radial part of (x2 a + y2 b)
+        float q1_r = ft.y2 * a_r + ft.x2 * b_r; // radial part of (y2 a + x2 b)
+        // rows scaled by fx / fy
+        float d00x = 2.f * x * ft.a + q0_r * rx, d00y = 2.f * y * ft.b + q0_r * ry, d00z = ft.x2 * a_z + ft.y2 * b_z;
+        float d01x = y * amb + ft.xy * amb_r * rx, d01y = x * amb + ft.xy * amb_r * ry, d01z = ft.xy * amb_z;
+        float d02x = -ft.inv_rho + 2.f * x * x * inv_rho2, d02y = 2.f * ft.xy * inv_rho2, d02z = 2.f * x * z * inv_rho2;
+        float d11x = 2.f * x * ft.b + q1_r * rx, d11y = 2.f * y * ft.a + q1_r * ry, d11z = ft.y2 * a_z + ft.x2 * b_z;
+        float d12x = 2.f * ft.xy * inv_rho2, d12y = -ft.inv_rho + 2.f * y * y * inv_rho2, d12z = 2.f * y * z * inv_rho2;
+        (void)rho;
+        vx += cam.fx * (d00x * vj00 + d01x * vj01 + d02x * vj02) + cam.fy * (d01x * vj10 + d11x * vj11 + d12x * vj12);
+        vy += cam.fx * (d00y * vj00 + d01y * vj01 + d02y * vj02) + cam.fy * (d01y * vj10 + d11y * vj11 + d12y * vj12);
+        vz += cam.fx * (d00z * vj00 + d01z * vj01 + d02z * vj02) + cam.fy * (d01z * vj10 + d11z * vj11 + d12z * vj12);
+    }
+    vz += v_depth;
+
+    // world->camera VJP (gsplat/cuda/include/transform.cuh:19-69)
+    g.v_px += cam.W.m[0][0] * vx + cam.W.m[1][0] * vy + cam.W.m[2][0] * vz;
+    g.v_py += cam.W.m[0][1] * vx + cam.W.m[1][1] * vy + cam.W.m[2][1] * vz;
+    g.v_pz += cam.W.m[0][2] * vx + cam.W.m[1][2] * vy + cam.W.m[2][2] * vz;
+    Sym3 vS = sym3_congruence_t(cam.W, vSc);
+    g.v_S.xx += vS.xx; g.v_S.xy += vS.xy; g.v_S.xz += vS.xz;
+    g.v_S.yy += vS.yy; g.v_S.yz += vS.yz; g.v_S.zz += vS.zz;
+    if (NEED_VIEW) {
+        // v_W = v_pc p^T + 2 vSc W S
+        Mat3 WS = mat3_mul(cam.W, sym3_to_mat3(S));
+        Mat3 vScm = sym3_to_mat3(vSc);
+        Mat3 t = mat3_mul(vScm, WS);
+        float vp[3] = {vx, vy, vz};
+        float pw[3] = {px, py, pz};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) g.v_W.m[i][j] += vp[i] * pw[j] + 2.f * t.m[i][j];
+            g.v_t[i] += vp[i];
+        }
+    }
+}
+
+GS_DEV void grad_zero(ProjGrad &g) {
+    g.v_px = g.v_py = g.v_pz = 0.f;
+    g.v_S = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    g.v_W = mat3_zero();
+    g.v_t[0] = g.v_t[1] = g.v_t[2] = 0.f;
+}
+
+// write the per-gaussian gradient rows
+GS_DEV void store_gaussian_grads(
+    const ProjGrad &g, uint32_t n, bool any,
+    const float *__restrict__ covars, const float *__restrict__ quats,
+    const float *__restrict__ scales,
+    float *__restrict__ v_means, float *__restrict__ v_covars,
+    float *__restrict__ v_quats, float *__restrict__ v_scales) {
+    if (v_means != nullptr) {
+        v_means[3 * (size_t)n] = g.v_px;
+        v_means[3 * (size_t)n + 1] = g.v_py;
+        v_means[3 * (size_t)n + 2] = g.v_pz;
+    }
+    if (covars != nullptr) {
+        if (v_covars != nullptr) {
+            float *o = v_covars + 6 * (size_t)n;
+            // off-diagonals carry both (i,j) and (j,i): fully_fused_projection_bwd.cu:217-222
+            o[0] = g.v_S.xx; o[1] = 2.f * g.v_S.xy; o[2] = 2.f * g.v_S.xz;
+            o[3] = g.v_S.yy; o[4] = 2.f * g.v_S.yz; o[5] = g.v_S.zz;
+        }
+    } else {
+        float vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
+        if (any) {
+            const float *q = quats + 4 * (size_t)n;
+            const float *s = scales + 3 * (size_t)n;
+            Mat3 R = quat_to_rotmat(q[0], q[1], q[2], q[3]);
+            covar_vjp_quat_scale(q[0], q[1], q[2], q[3], s[0], s[1], s[2], R, sym3_to_mat3(g.v_S), vq, vs);
+        }
+        if (v_quats != nullptr) {
+            float *o = v_quats + 4 * (size_t)n;
+            o[0] = vq[0]; o[1] = vq[1]; o[2] = vq[2]; o[3] = vq[3];
+        }
+        if (v_scales != nullptr) {
+            float *o = v_scales + 3 * (size_t)n;
+            o[0] = vs[0]; o[1] = vs[1]; o[2] = vs[2];
+        }
+    }
+}
+
+template <bool NEED_VIEW>
+__global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
+    uint32_t C, uint32_t N,
+    const float *__restrict__ means, const float *__restrict__ covars,
+    const float *__restrict__ quats, const float *__restrict__ scales,
+    const float *__restrict__ viewmats, const float *__restrict__ Ks,
+    int W, int H, float eps2d, int camera_model,
+    const int32_t *__restrict__ radii, const float *__restrict__ conics,
+    const float *__restrict__ compensations,
+    const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
+    const float *__restrict__ v_conics, const float *__restrict__ v_compensations,
+    float *__restrict__ v_means, float *__restrict__ v_covars, float *__restrict__ v_quats,
+    float *__restrict__ v_scales, float *__restrict__ v_viewmats) {
+    __shared__ float s_view[GS_BLOCK / GS_WAVE][12];
+    uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
+    bool in_range = n < N;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    Sym3 S = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool loaded = false;
+    ProjGrad g;
+    grad_zero(g);
+    bool any = false;
+    for (uint32_t c = 0; c < C; ++c) {
+        size_t idx = (size_t)c * N + n;
+        bool vis = in_range && radii[idx] > 0;
+        if (NEED_VIEW) {
+            g.v_W = mat3_zero();
+            g.v_t[0] = g.v_t[1] = g.v_t[2] = 0.f;
+        }
+        if (vis) {
+            if (!loaded) {
+                const float *p = means + 3 * (size_t)n;
+                px = p[0]; py = p[1]; pz = p[2];
+                S = load_covar(covars, quats, scales, n);
+                loaded = true;
+            }
+            Camera cam = load_camera(viewmats, Ks, c);
+            bool has_comp = v_compensations != nullptr;
+            project_one_vjp<NEED_VIEW>(
+                cam, px, py, pz, S, W, H, eps2d, camera_model,
+                conics[3 * idx], conics[3 * idx + 1], conics[3 * idx + 2],
+                has_comp ? compensations[idx] : 0.f, has_comp ? v_compensations[idx] : 0.f, has_comp,
+                v_means2d[2 * idx], v_means2d[2 * idx + 1], v_depths[idx],
+                v_conics[3 * idx], v_conics[3 * idx + 1], v_conics[3 * idx + 2], g);
+            any = true;
+        }
+        if (NEED_VIEW) {
+            // block reduce the 12 viewmat entries for camera c, one atomic set per block
+            float vals[12];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) vals[4 * i + j] = g.v_W.m[i][j];
+                vals[4 * i + 3] = g.v_t[i];
+            }
+            uint32_t wave = threadIdx.x / GS_WAVE, lane = threadIdx.x % GS_WAVE;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                float s = wave_sum(vals[k]);
+                if (lane == 0) s_view[wave][k] = s;
+            }
+            __syncthreads();
+            if (threadIdx.x < 12) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < GS_BLOCK / GS_WAVE; ++w) s += s_view[w][threadIdx.x];
+                if (s != 0.f) atomicAdd(v_viewmats + 16 * c + threadIdx.x, s);
+            }
+            __syncthreads();
+        }
+    }
+    if (in_range) store_gaussian_grads(g, n, any, covars, quats, scales, v_means, v_covars, v_quats, v_scales);
+}
+
+// ---------------------------------------------------------------------------
+// packed (COO) variants
+// ---------------------------------------------------------------------------
+template <bool FILL>
+__global__ void __launch_bounds__(GS_BLOCK) projection_packed_kernel(
+    uint32_t C, uint32_t N,
+    const float *__restrict__ means, const float *__restrict__ covars,
+    const float *__restrict__ quats, const float *__restrict__ scales,
+    const float *__restrict__ viewmats, const float *__restrict__ Ks,
+    int W, int H, float eps2d, float near_plane, float far_plane, float radius_clip,
+    int camera_model,
+    const int32_t *__restrict__ block_accum, int32_t *__restrict__ block_cnts,
+    int32_t *__restrict__ indptr, int64_t *__restrict__ camera_ids,
+    int64_t *__restrict__ gaussian_ids, int32_t *__restrict__ radii,
+    float *__restrict__ means2d, float *__restrict__ depths, float *__restrict__ conics,
+    float *__restrict__ compensations) {
+    __shared__ int32_t s_wave_cnt[GS_BLOCK / GS_WAVE];
+    uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
+    uint32_t c = blockIdx.y;
+    uint32_t nblocks = gridDim.x;
+    Splat2D s;
+    s.radius = 0;
+    if (n < N) {
+        Camera cam = load_camera(viewmats, Ks, c);
+        s = project_one<true>(cam, means, covars, quats, scales, n, W, H, eps2d, near_plane, far_plane,
+                              radius_clip, camera_model);
+    }
+    bool vis = s.radius > 0;
+    unsigned long long ballot = __ballot(vis);
+    uint32_t wave = threadIdx.x / GS_WAVE, lane = threadIdx.x % GS_WAVE;
+    if (lane == 0) s_wave_cnt[wave] = __popcll(ballot);
+    __syncthreads();
+    uint32_t block_id = c * nblocks + blockIdx.x;
+    if (!FILL) {
+        if (threadIdx.x == 0) {
+            int32_t t = 0;
+#pragma unroll
+            for (int w = 0; w < GS_BLOCK / GS_WAVE; ++w) t += s_wave_cnt[w];
+            block_cnts[block_id] = t;
+        }
+        return;
+    }
+    int32_t base = block_id == 0 ? 0 : block_accum[block_id - 1];
+    for (uint32_t w = 0; w < wave; ++w) base += s_wave_cnt[w];
+    if (vis) {
+        unsigned long long lt = (lane == 0) ? 0ull : (ballot & ((1ull << lane) - 1ull));
+        size_t o = (size_t)base + __popcll(lt);
+        camera_ids[o] = c;
+        gaussian_ids[o] = n;
+        radii[o] = s.radius;
+        means2d[2 * o] = s.mx;
+        means2d[2 * o + 1] = s.my;
+        depths[o] = s.depth;
+        conics[3 * o] = s.ca;
+        conics[3 * o + 1] = s.cb;
+        conics[3 * o + 2] = s.cc;
+        if (compensations != nullptr) compensations[o] = s.comp;
+    }
+    // CSR row pointer: first block of every camera row
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        indptr[c] = block_id == 0 ? 0 : block_accum[block_id - 1];
+        if (c == C - 1) indptr[C] = block_accum[C * nblocks - 1];
+    }
+}
+
+template <bool NEED_VIEW>
+__global__ void __launch_bounds__(GS_BLOCK) projection_packed_bwd_kernel(
+    uint32_t C, uint32_t N, uint32_t nnz,
+    const float *__restrict__ means, const float *__restrict__ covars,
+    const float *__restrict__ quats, const float *__restrict__ scales,
+    const float *__restrict__ viewmats, const float *__restrict__ Ks,
+    int W, int H, float eps2d, int camera_model,
+    const int64_t *__restrict__ camera_ids, const int64_t *__restrict__ gaussian_ids,
+    const float *__restrict__ conics, const float *__restrict__ compensations,
+    const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
+    const float *__restrict__ v_conics, const float *__restrict__ v_compensations,
+    int sparse_grad,
+    float *__restrict__ v_means, float *__restrict__ v_covars, float *__restrict__ v_quats,
+    float *__restrict__ v_scales, float *__restrict__ v_viewmats) {
+    uint32_t idx = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (idx >= nnz) return;
+    uint32_t c = (uint32_t)camera_ids[idx];
+    uint32_t n = (uint32_t)gaussian_ids[idx];
+    const float *p = means + 3 * (size_t)n;
+    float px = p[0], py = p[1], pz = p[2];
+    Sym3 S = load_covar(covars, quats, scales, n);
+    Camera cam = load_camera(viewmats, Ks, c);
+    ProjGrad g;
+    grad_zero(g);
+    bool has_comp = v_compensations != nullptr;
+    project_one_vjp<NEED_VIEW>(
+        cam, px, py, pz, S, W, H, eps2d, camera_model, conics[3 * (size_t)idx],
+        conics[3 * (size_t)idx + 1], conics[3 * (size_t)idx + 2],
+        has_comp ? compensations[idx] : 0.f, has_comp ? v_compensations[idx] : 0.f, has_comp,
+        v_means2d[2 * (size_t)idx], v_means2d[2 * (size_t)idx + 1], v_depths[idx],
+        v_conics[3 * (size_t)idx], v_conics[3 * (size_t)idx + 1], v_conics[3 * (size_t)idx + 2], g);
+
+    float vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
+    if (covars == nullptr) {
+        const float *q = quats + 4 * (size_t)n;
+        const float *s = scales + 3 * (size_t)n;
+        Mat3 R = quat_to_rotmat(q[0], q[1], q[2], q[3]);
+        covar_vjp_quat_scale(q[0], q[1], q[2], q[3], s[0], s[1], s[2], R, sym3_to_mat3(g.v_S), vq, vs);
+    }
+    if (sparse_grad) {
+        size_t o = idx;
+        if (v_means != nullptr) {
+            v_means[3 * o] = g.v_px; v_means[3 * o + 1] = g.v_py; v_means[3 * o + 2] = g.v_pz;
+        }
+        if (covars != nullptr) {
+            if (v_covars != nullptr) {
+                float *d = v_covars + 6 * o;
+                d[0] = g.v_S.xx; d[1] = 2.f * g.v_S.xy; d[2] = 2.f * g.v_S.xz;
+                d[3] = g.v_S.yy; d[4] = 2.f * g.v_S.yz; d[5] = g.v_S.zz;
+            }
+        } else {
+            if (v_quats != nullptr) {
+                float *d = v_quats + 4 * o;
+                d[0] = vq[0]; d[1] = vq[1]; d[2] = vq[2]; d[3] = vq[3];
+            }
+            if (v_scales != nullptr) {
+                float *d = v_scales + 3 * o;
+                d[0] = vs[0]; d[1] = vs[1]; d[2] = vs[2];
+            }
+        }
+    } else {
+        // dense: several cameras may hit the same gaussian row
+        size_t o = n;
+        if (v_means != nullptr) {
+            atomicAdd(v_means + 3 * o, g.v_px);
+            atomicAdd(v_means + 3 * o + 1, g.v_py);
+            atomicAdd(v_means + 3 * o + 2, g.v_pz);
+        }
+        if (covars != nullptr) {
+            if (v_covars != nullptr) {
+                float *d = v_covars + 6 * o;
+                atomicAdd(d, g.v_S.xx); atomicAdd(d + 1, 2.f * g.v_S.xy); atomicAdd(d + 2, 2.f * g.v_S.xz);
+                atomicAdd(d + 3, g.v_S.yy); atomicAdd(d + 4, 2.f * g.v_S.yz); atomicAdd(d + 5, g.v_S.zz);
+            }
+        } else {
+            if (v_quats != nullptr) {
+                float *d = v_quats + 4 * o;
+                atomicAdd(d, vq[0]); atomicAdd(d + 1, vq[1]); atomicAdd(d + 2, vq[2]); atomicAdd(d + 3, vq[3]);
+            }
+            if (v_scales != nullptr) {
+                float *d = v_scales + 3 * o;
+                atomicAdd(d, vs[0]); atomicAdd(d + 1, vs[1]); atomicAdd(d + 2, vs[2]);
+            }
+        }
+    }
+    if (NEED_VIEW) {
+        // rows are sorted by camera, so most waves are camera-uniform: reduce when they are
+        float vals[12];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vals[4 * i + j] = g.v_W.m[i][j];
+            vals[4 * i + 3] = g.v_t[i];
+        }
+        uint32_t c0 = __builtin_amdgcn_readfirstlane(c);
+        bool uniform = __all(c == c0) && (__popcll(__ballot(1)) == GS_WAVE);
+        if (uniform) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                float s = wave_sum(vals[k]);
+                if (lane_id() == 0) atomicAdd(v_viewmats + 16 * c0 + k, s);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) atomicAdd(v_viewmats + 16 * c + k, vals[k]);
+        }
+    }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" int32_t gs_projection_fwd(
+    uint32_t C, uint32_t N, const float *means, const float *covars, const float *quats,
+    const float *scales, const float *viewmats, const float *Ks, int32_t image_width,
+    int32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
+    int32_t camera_model, int32_t *radii, float *means2d, float *depths, float *conics,
+    float *compensations, gs_stream_t stream) {
+    GS_CHECK_ARG(means && viewmats && Ks && radii && means2d && depths && conics, "null pointer");
+    GS_CHECK_ARG((covars != nullptr) != (quats != nullptr && scales != nullptr),
+                 "exactly one of covars / (quats, scales) must be given");
+    GS_CHECK_ARG(camera_model >= 0 && camera_model <= 2, "bad camera_model");
+    if (C == 0 || N == 0) return 0;
+    dim3 grid(gs_div_up(N, GS_BLOCK), C);
+    hipLaunchKernelGGL(projection_fwd_kernel, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means,
+                       covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d, near_plane,
+                       far_plane, radius_clip, camera_model, radii, means2d, depths, conics, compensations);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_projection_bwd(
+    uint32_t C, uint32_t N, const float *means, const float *covars, const float *quats,
+    const float *scales, const float *viewmats, const float *Ks, int32_t image_width,
+    int32_t image_height, float eps2d, int32_t camera_model, const int32_t *radii,
+    const float *conics, const float *compensations, const float *v_means2d,
+    const float *v_depths, const float *v_conics, const float *v_compensations, float *v_means,
+    float *v_covars, float *v_quats, float *v_scales, float *v_viewmats, gs_stream_t stream) {
+    GS_CHECK_ARG(means && viewmats && Ks && radii && conics && v_means2d && v_depths && v_conics,
+                 "null pointer");
+    GS_CHECK_ARG((covars != nullptr) != (quats != nullptr && scales != nullptr),
+                 "exactly one of covars / (quats, scales) must be given");
+    GS_CHECK_ARG((v_compensations == nullptr) || (compensations != nullptr),
+                 "v_compensations given without compensations");
+    if (N == 0) return 0;
+    dim3 grid(gs_div_up(N, GS_BLOCK));
+    if (v_viewmats != nullptr) {
+        hipLaunchKernelGGL(projection_bwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
+                           means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
+                           camera_model, radii, conics, compensations, v_means2d, v_depths, v_conics,
+                           v_compensations, v_means, v_covars, v_quats, v_scales, v_viewmats);
+    } else {
+        hipLaunchKernelGGL(projection_bwd_kernel<false>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
+                           means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
+                           camera_model, radii, conics, compensations, v_means2d, v_depths, v_conics,
+                           v_compensations, v_means, v_covars, v_quats, v_scales, v_viewmats);
+    }
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_projection_packed_count(
+    uint32_t C, uint32_t N, const float *means, const float *covars, const float *quats,
+    const float *scales, const float *viewmats, const float *Ks, int32_t image_width,
+    int32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
+    int32_t camera_model, int32_t *block_cnts, gs_stream_t stream) {
+    GS_CHECK_ARG(means && viewmats && Ks && block_cnts, "null pointer");
+    GS_CHECK_ARG((covars != nullptr) != (quats != nullptr && scales != nullptr),
+                 "exactly one of covars / (quats, scales) must be given");
+    if (C == 0 || N == 0) return 0;
+    dim3 grid(gs_div_up(N, GS_BLOCK), C);
+    hipLaunchKernelGGL(projection_packed_kernel<false>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
+                       means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
+                       near_plane, far_plane, radius_clip, camera_model, (const int32_t *)nullptr, block_cnts,
+                       (int32_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (int32_t *)nullptr,
+                       (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_projection_packed_fill(
+    uint32_t C, uint32_t N, const float *means, const float *covars, const float *quats,
+    const float *scales, const float *viewmats, const float *Ks, int32_t image_width,
+    int32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
+    int32_t camera_model, const int32_t *block_accum, int32_t *indptr, int64_t *camera_ids,
+    int64_t *gaussian_ids, int32_t *radii, float *means2d, float *depths, float *conics,
+    float *compensations, gs_stream_t stream) {
+    GS_CHECK_ARG(means && viewmats && Ks && block_accum && indptr, "null pointer");
+    GS_CHECK_ARG((covars != nullptr) != (quats != nullptr && scales != nullptr),
+                 "exactly one of covars / (quats, scales) must be given");
+    if (C == 0 || N == 0) return 0;
+    dim3 grid(gs_div_up(N, GS_BLOCK), C);
+    hipLaunchKernelGGL(projection_packed_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
+                       means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
+                       near_plane, far_plane, radius_clip, camera_model, block_accum, (int32_t *)nullptr,
+                       indptr, camera_ids, gaussian_ids, radii, means2d, depths, conics, compensations);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_projection_packed_bwd(
+    uint32_t C, uint32_t N, uint32_t nnz, const float *means, const float *covars,
+    const float *quats, const float *scales, const float *viewmats, const float *Ks,
+    int32_t image_width, int32_t image_height, float eps2d, int32_t camera_model,
+    const int64_t *camera_ids, const int64_t *gaussian_ids, const float *conics,
+    const float *compensations, const float *v_means2d, const float *v_depths,
+    const float *v_conics, const float *v_compensations, int32_t sparse_grad, float *v_means,
+    float *v_covars, float *v_quats, float *v_scales, float *v_viewmats, gs_stream_t stream) {
+    GS_CHECK_ARG(means && viewmats && Ks, "null pointer");
+    GS_CHECK_ARG((covars != nullptr) != (quats != nullptr && scales != nullptr),
+                 "exactly one of covars / (quats, scales) must be given");
+    if (nnz == 0) return 0;
+    GS_CHECK_ARG(camera_ids && gaussian_ids && conics && v_means2d && v_depths && v_conics, "null pointer");
+    dim3 grid(gs_div_up(nnz, GS_BLOCK));
+    if (v_viewmats != nullptr) {
+        hipLaunchKernelGGL(projection_packed_bwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream,
+                           C, N, nnz, means, covars, quats, scales, viewmats, Ks, image_width, image_height,
+                           eps2d, camera_model, camera_ids, gaussian_ids, conics, compensations, v_means2d,
+                           v_depths, v_conics, v_compensations, sparse_grad, v_means, v_covars, v_quats,
+                           v_scales, v_viewmats);
+    } else {
+        hipLaunchKernelGGL(projection_packed_bwd_kernel<false>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream,
+                           C, N, nnz, means, covars, quats, scales, viewmats, Ks, image_width, image_height,
+                           eps2d, camera_model, camera_ids, gaussian_ids, conics, compensations, v_means2d,
+                           v_depths, v_conics, v_compensations, sparse_grad, v_means, v_covars, v_quats,
+                           v_scales, v_viewmats);
+    }
+    GS_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,141 @@
+// quantize.hip -- Q1/Q2: per-splat quantize/dequantize straight-through estimators (gfx950).
+//
+// Replaces the elementwise torch chains of
+//   gsplat/compression_simulation/ops.py:39-54 (fake_quantize_ste, "noise" mode)
+//   gsplat/compression_simulation/ops.py:57-75 (STE, "round" mode)
+// with one streaming pass each (16-byte loads/stores; pure HBM bandwidth).
+// Arithmetic is IEEE fp32, no contraction, in the reference's operation order, so the
+// outputs are bit-identical to the torch ops (file compiled with -ffp-contract=off).
+#include "gs_common.h"
+
+namespace {
+
+constexpr int Q_VEC = 4;
+
+GS_DEV float q_clamp(float x, float lo, float hi) {
+    // torch.clamp: NaN propagates; min(max(x, lo), hi)
+    float y = x < lo ? lo : x;
+    y = y > hi ? hi : y;
+    return y; // NaN compares false twice -> stays NaN
+}
+
+GS_DEV float q_noise(float x, float nz, float lo, float hi, float q_step) {
+    return __fadd_rn(q_clamp(x, lo, hi), __fmul_rn(nz, q_step));
+}
+
+GS_DEV float q_round(float xc, float lo, float range, float qn) {
+    float norm = __fdiv_rn(__fsub_rn(xc, lo), range);
+    float lvl = rintf(__fdiv_rn(norm, qn)); // round half to even, as torch.round
+    return __fadd_rn(__fmul_rn(__fmul_rn(lvl, qn), range), lo);
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) quant_noise_fwd_kernel(
+    uint64_t n, const float *__restrict__ x, const float *__restrict__ noise, float lo, float hi,
+    float q_step, float *__restrict__ out, int vec_ok) {
+    uint64_t stride = (uint64_t)gridDim.x * GS_BLOCK;
+    uint64_t t = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    uint64_t nv = vec_ok ? n / Q_VEC : 0;
+    for (uint64_t i = t; i < nv; i += stride) {
+        float4 a = reinterpret_cast<const float4 *>(x)[i];
+        float4 z = reinterpret_cast<const float4 *>(noise)[i];
+        float4 r;
+        r.x = q_noise(a.x, z.x, lo, hi, q_step);
+        r.y = q_noise(a.y, z.y, lo, hi, q_step);
+        r.z = q_noise(a.z, z.z, lo, hi, q_step);
+        r.w = q_noise(a.w, z.w, lo, hi, q_step);
+        reinterpret_cast<float4 *>(out)[i] = r;
+    }
+    for (uint64_t i = nv * Q_VEC + t; i < n; i += stride) out[i] = q_noise(x[i], noise[i], lo, hi, q_step);
+}
+
+GS_DEV float q_mask(float x, float v, float lo, float hi) {
+    // autograd of torch.clamp: gradient passes where lo <= x <= hi
+    return (x >= lo && x <= hi) ? v : 0.f;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) quant_noise_bwd_kernel(
+    uint64_t n, const float *__restrict__ x, const float *__restrict__ v_out, float lo, float hi,
+    float *__restrict__ v_x, int vec_ok) {
+    uint64_t stride = (uint64_t)gridDim.x * GS_BLOCK;
+    uint64_t t = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    uint64_t nv = vec_ok ? n / Q_VEC : 0;
+    for (uint64_t i = t; i < nv; i += stride) {
+        float4 a = reinterpret_cast<const float4 *>(x)[i];
+        float4 g = reinterpret_cast<const float4 *>(v_out)[i];
+        float4 r;
+        r.x = q_mask(a.x, g.x, lo, hi);
+        r.y = q_mask(a.y, g.y, lo, hi);
+        r.z = q_mask(a.z, g.z, lo, hi);
+        r.w = q_mask(a.w, g.w, lo, hi);
+        reinterpret_cast<float4 *>(v_x)[i] = r;
+    }
+    for (uint64_t i = nv * Q_VEC + t; i < n; i += stride) v_x[i] = q_mask(x[i], v_out[i], lo, hi);
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) quant_round_fwd_kernel(
+    uint64_t n, float *__restrict__ x, float lo, float hi, float range, float qn,
+    float *__restrict__ out, int vec_ok) {
+    uint64_t stride = (uint64_t)gridDim.x * GS_BLOCK;
+    uint64_t t = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    uint64_t nv = vec_ok ? n / Q_VEC : 0;
+    for (uint64_t i = t; i < nv; i += stride) {
+        float4 a = reinterpret_cast<const float4 *>(x)[i];
+        a.x = q_clamp(a.x, lo, hi); a.y = q_clamp(a.y, lo, hi);
+        a.z = q_clamp(a.z, lo, hi); a.w = q_clamp(a.w, lo, hi);
+        reinterpret_cast<float4 *>(x)[i] = a; // in-place clamp of the parameter (ops.py:63)
+        float4 r;
+        r.x = q_round(a.x, lo, range, qn); r.y = q_round(a.y, lo, range, qn);
+        r.z = q_round(a.z, lo, range, qn); r.w = q_round(a.w, lo, range, qn);
+        reinterpret_cast<float4 *>(out)[i] = r;
+    }
+    for (uint64_t i = nv * Q_VEC + t; i < n; i += stride) {
+        float a = q_clamp(x[i], lo, hi);
+        x[i] = a;
+        out[i] = q_round(a, lo, range, qn);
+    }
+}
+
+uint32_t stream_grid(uint64_t n) {
+    uint64_t blocks = (n / Q_VEC + GS_BLOCK - 1) / GS_BLOCK;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 8) blocks = 256 * 8; // 8 workgroups per CU, grid-stride the rest
+    return (uint32_t)blocks;
+}
+
+bool aligned16(const void *a, const void *b, const void *c) {
+    return ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && ((uintptr_t)c % 16 == 0);
+}
+
+} // namespace
+
+extern "C" int32_t gs_quantize_noise_fwd(
+    uint64_t n, const float *x, const float *noise, float lo, float hi, float q_step, float *out,
+    gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(x && noise && out, "null pointer");
+    hipLaunchKernelGGL(quant_noise_fwd_kernel, dim3(stream_grid(n)), dim3(GS_BLOCK), 0, (hipStream_t)stream, n, x,
+                       noise, lo, hi, q_step, out, (int)aligned16(x, noise, out));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_quantize_noise_bwd(
+    uint64_t n, const float *x, const float *v_out, float lo, float hi, float *v_x, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(x && v_out && v_x, "null pointer");
+    hipLaunchKernelGGL(quant_noise_bwd_kernel, dim3(stream_grid(n)), dim3(GS_BLOCK), 0, (hipStream_t)stream, n, x,
+                       v_out, lo, hi, v_x, (int)aligned16(x, v_out, v_x));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_quantize_round_fwd(
+    uint64_t n, float *x_inplace, float lo, float hi, float range, float q_step_norm, float *out,
+    gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(x_inplace && out, "null pointer");
+    hipLaunchKernelGGL(quant_round_fwd_kernel, dim3(stream_grid(n)), dim3(GS_BLOCK), 0, (hipStream_t)stream, n,
+                       x_inplace, lo, hi, range, q_step_norm, out, (int)aligned16(x_inplace, out, out));
+    GS_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,241 @@
+// radix_sort.hip -- stable LSD radix sort of (uint64 key, int32 value) pairs (gfx950).
+//
+// Replaces cub::DeviceRadixSort::SortPairs as used by the reference's tile binning
+// (gsplat/cuda/csrc/isect_tiles.cu:245-299): keys are
+//   camera_id << (32 + tile_bits) | tile_id << 32 | depth_bits
+// and only bits [0, 32 + tile_bits + cam_bits) are significant.  Stability matters:
+// equal (camera, tile, depth) keys must keep their emission order, as CUB's do.
+//
+// Structure per 8-bit digit pass (3 launches):
+//   1. sort_hist_kernel   : per-block digit histogram -> hist[digit][block]
+//   2. sort_scan_kernel   : one block per digit, exclusive scan over blocks (+ digit total)
+//   3. sort_scatter_kernel: stable local ranking with wave64 ballot matching, scatter.
+// A block owns 4096 consecutive keys; wave w owns 1024 of them and walks them in 16
+// rounds of 64, so (wave, round, lane) order == index order, which is what makes the
+// ballot-based rank stable.  Keys stay in VGPRs between the ranking and scatter phases.
+#include "gs_common.h"
+
+namespace {
+
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+constexpr int SORT_WAVES = GS_BLOCK / GS_WAVE; // 4
+constexpr int SORT_ROUNDS = 16;
+constexpr int SORT_WAVE_KEYS = GS_WAVE * SORT_ROUNDS;  // 1024
+constexpr int SORT_TILE = SORT_WAVES * SORT_WAVE_KEYS; // 4096
+
+struct DigitSpec {
+    uint32_t shift;
+    uint32_t mask;
+    uint32_t flip; // xor applied to the digit (sign bit handling when end_bit == 64)
+};
+
+GS_DEV uint32_t digit_of(uint64_t key, DigitSpec d) { return ((uint32_t)(key >> d.shift) & d.mask) ^ d.flip; }
+
+__global__ void __launch_bounds__(GS_BLOCK) sort_hist_kernel(
+    uint64_t n, const uint64_t *__restrict__ keys, DigitSpec d, uint32_t n_blocks,
+    uint32_t *__restrict__ hist /* [RADIX][n_blocks] */) {
+    __shared__ uint32_t s_hist[RADIX];
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
+#pragma unroll 4
+    for (int k = 0; k < SORT_TILE / GS_BLOCK; ++k) {
+        uint64_t i = base + (uint64_t)k * GS_BLOCK + threadIdx.x;
+        if (i < n) atomicAdd(&s_hist[digit_of(keys[i], d)], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+// block = digit.  In-place exclusive scan of hist[digit][0..n_blocks) and digit total.
+__global__ void __launch_bounds__(GS_BLOCK) sort_scan_kernel(
+    uint32_t n_blocks, uint32_t *__restrict__ hist, uint32_t *__restrict__ totals) {
+    __shared__ uint32_t s_wave[SORT_WAVES];
+    uint32_t *row = hist + (size_t)blockIdx.x * n_blocks;
+    uint32_t lane = threadIdx.x % GS_WAVE, wave = threadIdx.x / GS_WAVE;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_blocks; base += GS_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < n_blocks ? row[i] : 0;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= (uint32_t)off) inc += o;
+        }
+        if (lane == GS_WAVE - 1) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) {
+            if ((uint32_t)w < wave) wbase += s_wave[w];
+            total += s_wave[w];
+        }
+        if (i < n_blocks) row[i] = carry + wbase + inc - v;
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
+    uint64_t n, const uint64_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
+    uint64_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, DigitSpec d,
+    uint32_t n_blocks, const uint32_t *__restrict__ hist_scan, const uint32_t *__restrict__ totals) {
+    __shared__ uint32_t s_cnt[SORT_WAVES][RADIX]; // per-wave digit counters -> per-wave prefix
+    __shared__ uint32_t s_base[RADIX];            // global base of (digit, this block)
+    __shared__ uint32_t s_scan[SORT_WAVES];
+    const uint32_t tid = threadIdx.x, lane = tid % GS_WAVE, wave = tid / GS_WAVE;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) s_cnt[w][tid] = 0;
+    __syncthreads();
+
+    const uint64_t wave_base = (uint64_t)blockIdx.x * SORT_TILE + (uint64_t)wave * SORT_WAVE_KEYS;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint64_t key[SORT_ROUNDS];
+    uint32_t rank[SORT_ROUNDS];
+
+    // phase 1: stable rank of every key within (wave, digit)
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+        uint64_t i = wave_base + (uint64_t)r * GS_WAVE + lane;
+        bool valid = i < n;
+        key[r] = valid ? keys_in[i] : 0;
+        uint32_t dg = digit_of(key[r], d);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; ++b) {
+            bool bit = (dg >> b) & 1u;
+            unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        uint32_t before = __popcll(peers & lt_mask);
+        uint32_t prev = 0;
+        if (valid) prev = s_cnt[wave][dg];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && before == 0) s_cnt[wave][dg] = prev + __popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        rank[r] = prev + before;
+    }
+    __syncthreads();
+
+    // phase 2: digit tid -> prefix over waves, and the block's global base for the digit
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) {
+            uint32_t c = s_cnt[w][tid];
+            s_cnt[w][tid] = run;
+            run += c;
+        }
+        // exclusive scan of the 256 digit totals (identical in every block)
+        uint32_t t = totals[tid];
+        uint32_t inc = t;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= (uint32_t)off) inc += o;
+        }
+        if (lane == GS_WAVE - 1) s_scan[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w)
+            if ((uint32_t)w < wave) wbase += s_scan[w];
+        s_base[tid] = wbase + inc - t + hist_scan[(size_t)tid * n_blocks + blockIdx.x];
+    }
+    __syncthreads();
+
+    // phase 3: scatter
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+        uint64_t i = wave_base + (uint64_t)r * GS_WAVE + lane;
+        if (i < n) {
+            uint32_t dg = digit_of(key[r], d);
+            uint32_t pos = s_base[dg] + s_cnt[wave][dg] + rank[r];
+            keys_out[pos] = key[r];
+            vals_out[pos] = vals_in[i];
+        }
+    }
+}
+
+struct SortLayout {
+    uint32_t n_blocks;
+    size_t off_keys, off_vals, off_hist, off_totals, total;
+};
+
+SortLayout sort_layout(uint64_t n) {
+    SortLayout L;
+    L.n_blocks = gs_div_up(n, SORT_TILE);
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t r = o;
+        o += (bytes + 255) & ~(size_t)255;
+        return r;
+    };
+    L.off_keys = take(n * sizeof(uint64_t));
+    L.off_vals = take(n * sizeof(int32_t));
+    L.off_hist = take((size_t)RADIX * L.n_blocks * sizeof(uint32_t));
+    L.off_totals = take(RADIX * sizeof(uint32_t));
+    L.total = o;
+    return L;
+}
+
+} // namespace
+
+extern "C" size_t gs_sort_temp_bytes(uint64_t n) { return sort_layout(n).total; }
+
+extern "C" int32_t gs_sort_pairs_u64_i32(
+    uint64_t n, const int64_t *keys_in, const int32_t *vals_in, int64_t *keys_out,
+    int32_t *vals_out, int32_t begin_bit, int32_t end_bit, void *temp, size_t temp_bytes,
+    gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(keys_in && vals_in && keys_out && vals_out, "null pointer");
+    GS_CHECK_ARG(begin_bit >= 0 && end_bit <= 64 && begin_bit <= end_bit, "bad bit range");
+    GS_CHECK_ARG(n < (1ull << 32), "n must be < 2^32");
+    hipStream_t st = (hipStream_t)stream;
+    int passes = (end_bit - begin_bit + RADIX_BITS - 1) / RADIX_BITS;
+    if (passes == 0) {
+        (void)hipMemcpyAsync(keys_out, keys_in, n * sizeof(int64_t), hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(vals_out, vals_in, n * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+        GS_CHECK_LAUNCH();
+        return 0;
+    }
+    SortLayout L = sort_layout(n);
+    if (temp == nullptr || temp_bytes < L.total) {
+        gs_set_error("gs_sort_pairs_u64_i32: temp too small (%zu < %zu)", temp_bytes, L.total);
+        return 1;
+    }
+    char *tp = (char *)temp;
+    uint64_t *tkeys = (uint64_t *)(tp + L.off_keys);
+    int32_t *tvals = (int32_t *)(tp + L.off_vals);
+    uint32_t *hist = (uint32_t *)(tp + L.off_hist);
+    uint32_t *totals = (uint32_t *)(tp + L.off_totals);
+
+    // ping-pong between {temp, out}; the first destination is chosen so the last pass
+    // lands in *_out without ever writing the inputs.
+    const uint64_t *src_k = (const uint64_t *)keys_in;
+    const int32_t *src_v = vals_in;
+    bool to_out = (passes % 2) == 1;
+    for (int p = 0; p < passes; ++p) {
+        DigitSpec d;
+        d.shift = (uint32_t)(begin_bit + p * RADIX_BITS);
+        int bits = end_bit - (int)d.shift;
+        if (bits > RADIX_BITS) bits = RADIX_BITS;
+        d.mask = (1u << bits) - 1u;
+        // int64 keys: when the range includes bit 63 CUB orders them as signed values
+        d.flip = (end_bit == 64 && p == passes - 1) ? (1u << (bits - 1)) : 0u;
+        uint64_t *dst_k = to_out ? (uint64_t *)keys_out : tkeys;
+        int32_t *dst_v = to_out ? vals_out : tvals;
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, src_k, d, L.n_blocks, hist);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, hist, totals);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, src_k, src_v, dst_k,
+                           dst_v, d, L.n_blocks, hist, totals);
+        src_k = dst_k;
+        src_v = dst_v;
+        to_out = !to_out;
+    }
+    GS_CHECK_LAUNCH();
+    return 0;
+}

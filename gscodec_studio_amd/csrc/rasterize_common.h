@@ -1,0 +1,51 @@
+// rasterize_common.h -- argument blocks and wave64 primitives shared by the compositing kernels.
+#pragma once
+
+#include "gs_common.h"
+
+struct RasterArgs {
+    uint32_t C, n_elems, n_isects, channels;
+    const float *means2d;
+    const float *conics;
+    const float *colors;
+    const float *opacities;
+    const float *backgrounds;
+    const uint8_t *masks;
+    uint32_t image_width, image_height, tile_size, tile_width, tile_height;
+    const int32_t *tile_offsets;
+    const int32_t *flatten_ids;
+    float *render_colors;
+    float *render_alphas;
+    int32_t *last_ids;
+};
+
+struct RasterGradArgs {
+    const float *render_alphas;
+    const int32_t *last_ids;
+    const float *v_render_colors;
+    const float *v_render_alphas;
+    float *v_means2d_abs;
+    float *v_means2d;
+    float *v_conics;
+    float *v_colors;
+    float *v_opacities;
+};
+
+// 64-lane sum with DPP row shifts + row broadcasts (GFX9 family).  The total is valid in
+// lane 63 only.  All 64 lanes must be active.
+GS_DEV float wave_reduce_sum_dpp(float v) {
+    // row_shr:1, row_shr:2, row_shr:4, row_shr:8 -> inclusive scan inside each row of 16
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, false));
+    // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+int32_t raster_ref_fwd(const RasterArgs &a, hipStream_t st);
+int32_t raster_ref_bwd(const RasterArgs &a, const RasterGradArgs &ga, hipStream_t st);
+int32_t raster_wave_fwd(const RasterArgs &a, hipStream_t st);
+int32_t raster_wave_bwd(const RasterArgs &a, const RasterGradArgs &ga, hipStream_t st);

@@ -1,0 +1,354 @@
+// sh.hip -- R2: spherical-harmonics colour evaluation, fwd + bwd (gfx950).
+//
+// Replaces gsplat/cuda/csrc/compute_sh_fwd.cu:12-72, compute_sh_bwd.cu:14-95 and the
+// device functions of gsplat/cuda/include/spherical_harmonics.cuh:13-362.
+//
+// Design notes (MI355X):
+//   * This is the largest HBM term of a degree-3 step (192 B of coefficients per
+//     splat).  One lane owns one gaussian and ALL three colour channels, so the
+//     coefficient row is read once with 16-byte loads (the reference reads it from
+//     three different lanes) and the gradient row is written once with 16-byte stores.
+//   * Coefficients shared across cameras are indexed [N,K,3] directly; the reference
+//     materialises a [C,N,K,3] copy and autograd then sums a [C,N,K,3] gradient.  Here
+//     the lane loops over cameras and keeps the K*3 gradient accumulators in VGPRs.
+//   * bwd writes every row of v_coeffs (zeros for culled splats / inactive bands), so
+//     the caller never zero-fills 192 B/splat first.
+//   * The basis is evaluated through the (x+iy)^m recurrence (fC_m, fS_m) and its
+//     gradient uses d fC_m = m (fC_{m-1}, -fS_{m-1}), d fS_m = m (fS_{m-1}, fC_{m-1}).
+//   * The contraction is [1 x K] . [K x 3] with both operands unique per splat: no
+//     operand reuse, so MFMA cannot beat VALU here; kept on VALU.
+#include "gs_common.h"
+
+namespace {
+
+template <int DEG>
+struct ShDim {
+    static constexpr int NB = (DEG + 1) * (DEG + 1);
+};
+
+// Real SH basis values for a UNIT direction (x,y,z); Sloan's fast evaluation constants
+// (spherical_harmonics.cuh:22-96).
+template <int DEG>
+GS_DEV void sh_basis(float x, float y, float z, float *Y) {
+    Y[0] = 0.2820947917738781f;
+    if (DEG < 1) return;
+    Y[1] = -0.48860251190292f * y;
+    Y[2] = 0.48860251190292f * z;
+    Y[3] = -0.48860251190292f * x;
+    if (DEG < 2) return;
+    float z2 = z * z;
+    float c1 = x * x - y * y, s1 = 2.f * x * y;
+    float t0b = -1.092548430592079f * z;
+    Y[4] = 0.5462742152960395f * s1;
+    Y[5] = t0b * y;
+    Y[6] = 0.9461746957575601f * z2 - 0.3153915652525201f;
+    Y[7] = t0b * x;
+    Y[8] = 0.5462742152960395f * c1;
+    if (DEG < 3) return;
+    float c2 = x * c1 - y * s1, s2 = x * s1 + y * c1;
+    float t0c = -2.285228997322329f * z2 + 0.4570457994644658f;
+    float t1b = 1.445305721320277f * z;
+    Y[9] = -0.5900435899266435f * s2;
+    Y[10] = t1b * s1;
+    Y[11] = t0c * y;
+    Y[12] = z * (1.865881662950577f * z2 - 1.119528997770346f);
+    Y[13] = t0c * x;
+    Y[14] = t1b * c1;
+    Y[15] = -0.5900435899266435f * c2;
+    if (DEG < 4) return;
+    float c3 = x * c2 - y * s2, s3 = x * s2 + y * c2;
+    float t0d = z * (-4.683325804901025f * z2 + 2.007139630671868f);
+    float t1c = 3.31161143515146f * z2 - 0.47308734787878f;
+    float t2b = -1.770130769779931f * z;
+    Y[16] = 0.6258357354491763f * s3;
+    Y[17] = t2b * s2;
+    Y[18] = t1c * s1;
+    Y[19] = t0d * y;
+    Y[20] = 1.984313483298443f * z * Y[12] - 1.006230589874905f * Y[6];
+    Y[21] = t0d * x;
+    Y[22] = t1c * c1;
+    Y[23] = t2b * c2;
+    Y[24] = 0.6258357354491763f * c3;
+}
+
+// v_n = sum_k w_k * grad Y_k   (w_k = sum_c coeff[k][c] * v_colour[c]); bands >= 1 only.
+template <int DEG>
+GS_DEV void sh_basis_grad_contract(float x, float y, float z, const float *w, float &gx, float &gy, float &gz) {
+    gx = gy = gz = 0.f;
+    if (DEG < 1) return;
+    const float k1 = 0.48860251190292f;
+    gy += -k1 * w[1];
+    gz += k1 * w[2];
+    gx += -k1 * w[3];
+    if (DEG < 2) return;
+    float z2 = z * z;
+    float c1 = x * x - y * y, s1 = 2.f * x * y;
+    const float k2 = 0.5462742152960395f, k2b = -1.092548430592079f;
+    gx += k2 * 2.f * y * w[4] + k2b * z * w[7] + k2 * 2.f * x * w[8];
+    gy += k2 * 2.f * x * w[4] + k2b * z * w[5] - k2 * 2.f * y * w[8];
+    gz += k2b * y * w[5] + 2.f * 0.9461746957575601f * z * w[6] + k2b * x * w[7];
+    if (DEG < 3) return;
+    float c2 = x * c1 - y * s1, s2 = x * s1 + y * c1;
+    float t0c = -2.285228997322329f * z2 + 0.4570457994644658f;
+    float t0c_z = -2.f * 2.285228997322329f * z;
+    float t1b = 1.445305721320277f * z;
+    const float k3 = -0.5900435899266435f;
+    gx += k3 * 3.f * s1 * w[9] + t1b * 2.f * y * w[10] + t0c * w[13] + t1b * 2.f * x * w[14] + k3 * 3.f * c1 * w[15];
+    gy += k3 * 3.f * c1 * w[9] + t1b * 2.f * x * w[10] + t0c * w[11] - t1b * 2.f * y * w[14] - k3 * 3.f * s1 * w[15];
+    float y12_z = 3.f * 1.865881662950577f * z2 - 1.119528997770346f;
+    gz += 1.445305721320277f * s1 * w[10] + t0c_z * y * w[11] + y12_z * w[12] + t0c_z * x * w[13] +
+          1.445305721320277f * c1 * w[14];
+    if (DEG < 4) return;
+    float t0d = z * (-4.683325804901025f * z2 + 2.007139630671868f);
+    float t0d_z = -3.f * 4.683325804901025f * z2 + 2.007139630671868f;
+    float t1c = 3.31161143515146f * z2 - 0.47308734787878f;
+    float t1c_z = 2.f * 3.31161143515146f * z;
+    float t2b = -1.770130769779931f * z;
+    const float k4 = 0.6258357354491763f;
+    float y12 = z * (1.865881662950577f * z2 - 1.119528997770346f);
+    gx += k4 * 4.f * s2 * w[16] + t2b * 3.f * s1 * w[17] + t1c * 2.f * y * w[18] + t0d * w[21] +
+          t1c * 2.f * x * w[22] + t2b * 3.f * c1 * w[23] + k4 * 4.f * c2 * w[24];
+    gy += k4 * 4.f * c2 * w[16] + t2b * 3.f * c1 * w[17] + t1c * 2.f * x * w[18] + t0d * w[19] -
+          t1c * 2.f * y * w[22] - t2b * 3.f * s1 * w[23] - k4 * 4.f * s2 * w[24];
+    float y20_z = 1.984313483298443f * (y12 + z * y12_z) - 1.006230589874905f * 2.f * 0.9461746957575601f * z;
+    gz += -1.770130769779931f * s2 * w[17] + t1c_z * s1 * w[18] + t0d_z * y * w[19] + y20_z * w[20] +
+          t0d_z * x * w[21] + t1c_z * c1 * w[22] - 1.770130769779931f * c2 * w[23];
+}
+
+// row I/O: VEC => the row base is 16-byte aligned and its length (3K floats) is a
+// multiple of 4, so dwordx4 accesses are legal for every row.
+template <int CNT, bool VEC>
+GS_DEV void load_floats(const float *__restrict__ p, float *dst) {
+    if (VEC) {
+        constexpr int NV = CNT / 4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float4 v = reinterpret_cast<const float4 *>(p)[i];
+            dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = NV * 4; i < CNT; ++i) dst[i] = p[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) dst[i] = p[i];
+    }
+}
+
+// store CNT active floats followed by zeros up to row_len
+template <int CNT, bool VEC>
+GS_DEV void store_row(float *__restrict__ p, const float *src, uint32_t row_len) {
+    if (VEC) {
+        constexpr int NV = CNT / 4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            reinterpret_cast<float4 *>(p)[i] = make_float4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+        constexpr int REM = CNT - NV * 4;
+        uint32_t done = NV * 4;
+        if (REM > 0) {
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < REM; ++i) t[i] = src[NV * 4 + i];
+            reinterpret_cast<float4 *>(p)[NV] = make_float4(t[0], t[1], t[2], t[3]);
+            done += 4;
+        }
+        for (uint32_t i = done; i < row_len; i += 4) reinterpret_cast<float4 *>(p + i)[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) p[i] = src[i];
+        for (uint32_t i = CNT; i < row_len; ++i) p[i] = 0.f;
+    }
+}
+
+template <bool VEC>
+GS_DEV void zero_row(float *__restrict__ p, uint32_t row_len) {
+    if (VEC) {
+        for (uint32_t i = 0; i < row_len; i += 4) reinterpret_cast<float4 *>(p + i)[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        for (uint32_t i = 0; i < row_len; ++i) p[i] = 0.f;
+    }
+}
+
+template <int DEG, bool VEC>
+__global__ void __launch_bounds__(GS_BLOCK) sh_fwd_kernel(
+    uint32_t C, uint32_t N, uint32_t K, const float *__restrict__ dirs,
+    const float *__restrict__ coeffs, int shared, const uint8_t *__restrict__ masks,
+    float *__restrict__ colors) {
+    constexpr int NB = ShDim<DEG>::NB;
+    uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
+    uint32_t c = blockIdx.y;
+    if (n >= N) return;
+    size_t e = (size_t)c * N + n;
+    if (masks != nullptr && !masks[e]) return;
+    float Y[NB];
+    if (DEG >= 1) {
+        float dx = dirs[3 * e], dy = dirs[3 * e + 1], dz = dirs[3 * e + 2];
+        float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
+        sh_basis<DEG>(dx * inv, dy * inv, dz * inv, Y);
+    } else {
+        sh_basis<0>(0.f, 0.f, 1.f, Y);
+    }
+    const float *row = coeffs + (shared ? (size_t)n : e) * K * 3;
+    float cf[NB * 3];
+    load_floats<NB * 3, VEC>(row, cf);
+    float r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        r += Y[k] * cf[3 * k];
+        g += Y[k] * cf[3 * k + 1];
+        b += Y[k] * cf[3 * k + 2];
+    }
+    colors[3 * e] = r;
+    colors[3 * e + 1] = g;
+    colors[3 * e + 2] = b;
+}
+
+// One lane per gaussian; loops over cameras.  SHARED: v_coeffs is [N,K,3] and the lane
+// accumulates over cameras in registers; otherwise [C,N,K,3] rows are written per camera.
+template <int DEG, bool VEC, bool SHARED>
+__global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
+    uint32_t C, uint32_t N, uint32_t K, const float *__restrict__ dirs,
+    const float *__restrict__ coeffs, const uint8_t *__restrict__ masks,
+    const float *__restrict__ v_colors, float *__restrict__ v_coeffs,
+    float *__restrict__ v_dirs) {
+    constexpr int NB = ShDim<DEG>::NB;
+    uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t row_len = K * 3;
+    float acc[NB * 3];
+    if (SHARED) {
+#pragma unroll
+        for (int i = 0; i < NB * 3; ++i) acc[i] = 0.f;
+    }
+    float cf[NB * 3];
+    bool have_cf = false;
+    for (uint32_t c = 0; c < C; ++c) {
+        size_t e = (size_t)c * N + n;
+        bool on = masks == nullptr || masks[e];
+        if (!on) {
+            if (!SHARED) zero_row<VEC>(v_coeffs + e * row_len, row_len);
+            if (v_dirs != nullptr) {
+                v_dirs[3 * e] = 0.f; v_dirs[3 * e + 1] = 0.f; v_dirs[3 * e + 2] = 0.f;
+            }
+            continue;
+        }
+        float vr = v_colors[3 * e], vg = v_colors[3 * e + 1], vb = v_colors[3 * e + 2];
+        float Y[NB];
+        float x = 0.f, y = 0.f, z = 1.f, inv = 1.f;
+        if (DEG >= 1) {
+            float dx = dirs[3 * e], dy = dirs[3 * e + 1], dz = dirs[3 * e + 2];
+            inv = rsqrtf(dx * dx + dy * dy + dz * dz);
+            x = dx * inv; y = dy * inv; z = dz * inv;
+        }
+        sh_basis<DEG>(x, y, z, Y);
+        if (SHARED) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                acc[3 * k] += Y[k] * vr;
+                acc[3 * k + 1] += Y[k] * vg;
+                acc[3 * k + 2] += Y[k] * vb;
+            }
+        } else {
+            float out[NB * 3];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                out[3 * k] = Y[k] * vr;
+                out[3 * k + 1] = Y[k] * vg;
+                out[3 * k + 2] = Y[k] * vb;
+            }
+            store_row<NB * 3, VEC>(v_coeffs + e * row_len, out, row_len);
+        }
+        if (v_dirs != nullptr) {
+            float gx = 0.f, gy = 0.f, gz = 0.f;
+            if (DEG >= 1) {
+                if (!SHARED || !have_cf) {
+                    load_floats<NB * 3, VEC>(coeffs + (SHARED ? (size_t)n : e) * row_len, cf);
+                    have_cf = true;
+                }
+                float w[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) w[k] = cf[3 * k] * vr + cf[3 * k + 1] * vg + cf[3 * k + 2] * vb;
+                float vx, vy, vz;
+                sh_basis_grad_contract<DEG>(x, y, z, w, vx, vy, vz);
+                float dot = vx * x + vy * y + vz * z;
+                gx = (vx - dot * x) * inv;
+                gy = (vy - dot * y) * inv;
+                gz = (vz - dot * z) * inv;
+            }
+            v_dirs[3 * e] = gx; v_dirs[3 * e + 1] = gy; v_dirs[3 * e + 2] = gz;
+        }
+    }
+    if (SHARED) store_row<NB * 3, VEC>(v_coeffs + (size_t)n * row_len, acc, row_len);
+}
+
+bool rows_vectorizable(const void *p, uint32_t K) { return ((uintptr_t)p % 16 == 0) && ((K * 3) % 4 == 0); }
+
+template <int DEG>
+void launch_fwd(bool vec, dim3 grid, hipStream_t st, uint32_t C, uint32_t N, uint32_t K, const float *dirs,
+                const float *coeffs, int shared, const uint8_t *masks, float *colors) {
+    if (vec)
+        hipLaunchKernelGGL((sh_fwd_kernel<DEG, true>), grid, dim3(GS_BLOCK), 0, st, C, N, K, dirs, coeffs, shared, masks, colors);
+    else
+        hipLaunchKernelGGL((sh_fwd_kernel<DEG, false>), grid, dim3(GS_BLOCK), 0, st, C, N, K, dirs, coeffs, shared, masks, colors);
+}
+
+template <int DEG>
+void launch_bwd(bool vec, bool shared, dim3 grid, hipStream_t st, uint32_t C, uint32_t N, uint32_t K,
+                const float *dirs, const float *coeffs, const uint8_t *masks, const float *v_colors,
+                float *v_coeffs, float *v_dirs) {
+#define GS_SH_BWD(V, S)                                                                               \
+    hipLaunchKernelGGL((sh_bwd_kernel<DEG, V, S>), grid, dim3(GS_BLOCK), 0, st, C, N, K, dirs, coeffs, \
+                       masks, v_colors, v_coeffs, v_dirs)
+    if (vec && shared) GS_SH_BWD(true, true);
+    else if (vec) GS_SH_BWD(true, false);
+    else if (shared) GS_SH_BWD(false, true);
+    else GS_SH_BWD(false, false);
+#undef GS_SH_BWD
+}
+
+} // namespace
+
+extern "C" int32_t gs_sh_fwd(
+    uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *dirs, const float *coeffs,
+    int32_t coeffs_shared, const uint8_t *masks, float *colors, gs_stream_t stream) {
+    GS_CHECK_ARG(coeffs && colors, "null pointer");
+    GS_CHECK_ARG(degree <= 4, "degree must be <= 4");
+    GS_CHECK_ARG((degree + 1) * (degree + 1) <= K, "K too small for degree");
+    GS_CHECK_ARG(degree == 0 || dirs != nullptr, "dirs required for degree >= 1");
+    if (C == 0 || N == 0) return 0;
+    dim3 grid(gs_div_up(N, GS_BLOCK), C);
+    hipStream_t st = (hipStream_t)stream;
+    bool vec = rows_vectorizable(coeffs, K);
+    switch (degree) {
+        case 0: launch_fwd<0>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors); break;
+        case 1: launch_fwd<1>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors); break;
+        case 2: launch_fwd<2>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors); break;
+        case 3: launch_fwd<3>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors); break;
+        default: launch_fwd<4>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors); break;
+    }
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_sh_bwd(
+    uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *dirs, const float *coeffs,
+    int32_t coeffs_shared, const uint8_t *masks, const float *v_colors, float *v_coeffs,
+    float *v_dirs, gs_stream_t stream) {
+    GS_CHECK_ARG(coeffs && v_colors && v_coeffs, "null pointer");
+    GS_CHECK_ARG(degree <= 4, "degree must be <= 4");
+    GS_CHECK_ARG((degree + 1) * (degree + 1) <= K, "K too small for degree");
+    GS_CHECK_ARG(degree == 0 || dirs != nullptr, "dirs required for degree >= 1");
+    if (C == 0 || N == 0) return 0;
+    dim3 grid(gs_div_up(N, GS_BLOCK));
+    hipStream_t st = (hipStream_t)stream;
+    bool vec = rows_vectorizable(coeffs, K) && rows_vectorizable(v_coeffs, K);
+    bool shared = coeffs_shared != 0;
+    switch (degree) {
+        case 0: launch_bwd<0>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
+        case 1: launch_bwd<1>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
+        case 2: launch_bwd<2>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
+        case 3: launch_bwd<3>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
+        default: launch_bwd<4>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
+    }
+    GS_CHECK_LAUNCH();
+    return 0;
+}

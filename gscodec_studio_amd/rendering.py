@@ -1,0 +1,252 @@
+"""Render API: ``rasterization()`` with the reference's signature, defaults, return values
+and ``meta`` dictionary (reference ``gsplat/rendering.py:28-582``), orchestrating the five
+HIP stages  project -> SH colour -> tile-intersect + radix sort -> offset-encode ->
+per-tile alpha compositing.
+
+Drop-in contract kept from the reference:
+* ``means2d`` stays an autograd intermediate between the projection Function and the
+  rasterize Function, so ``meta["means2d"].retain_grad()`` / ``.absgrad`` work for the
+  densification strategies (reference strategy/default.py:150, 221-226);
+* ``meta`` keys and dtypes: camera_ids, gaussian_ids, radii, means2d, depths, conics,
+  opacities, tile_width, tile_height, tiles_per_gauss, isect_ids, flatten_ids,
+  isect_offsets, width, height, tile_size, n_cameras.
+
+Differences by design: shared SH coefficients are not expanded to ``[C,N,K,3]`` and
+channel padding is not needed (see _wrapper.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+from typing_extensions import Literal
+
+from ._wrapper import (
+    fully_fused_projection,
+    isect_offset_encode,
+    isect_tiles,
+    rasterize_to_pixels,
+    spherical_harmonics,
+    spherical_harmonics_shared,
+)
+
+
+def rasterization(
+    means: Tensor,  # [N, 3]
+    quats: Tensor,  # [N, 4]
+    scales: Tensor,  # [N, 3]
+    opacities: Tensor,  # [N]
+    colors: Tensor,  # [(C,) N, D] or [(C,) N, K, 3]
+    viewmats: Tensor,  # [C, 4, 4]
+    Ks: Tensor,  # [C, 3, 3]
+    width: int,
+    height: int,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    eps2d: float = 0.3,
+    sh_degree: Optional[int] = None,
+    packed: bool = True,
+    tile_size: int = 16,
+    backgrounds: Optional[Tensor] = None,
+    render_mode: Literal["RGB", "D", "ED", "RGB+D", "RGB+ED"] = "RGB",
+    sparse_grad: bool = False,
+    absgrad: bool = False,
+    rasterize_mode: Literal["classic", "antialiased"] = "classic",
+    channel_chunk: int = 32,
+    distributed: bool = False,
+    camera_model: Literal["pinhole", "ortho", "fisheye"] = "pinhole",
+    covars: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor, Dict]:
+    """Rasterize a set of 3D Gaussians (N) to a batch of image planes (C).
+
+    Same semantics as the reference ``gsplat.rendering.rasterization``.
+
+    Args:
+        means: 3D centres [N,3].  quats: rotations wxyz [N,4] (need not be normalised).
+        scales: [N,3].  opacities: [N].  colors: [(C,)N,D] post-activation features, or SH
+        coefficients [(C,)N,K,3] when ``sh_degree`` is set.  viewmats: world->camera
+        [C,4,4].  Ks: intrinsics [C,3,3].  covars: optional [N,3,3] replacing quats/scales.
+        packed: COO intermediates (memory-efficient for many cameras).  sparse_grad: COO
+        gradients (needs packed).  absgrad: also accumulate |d means2d| into
+        ``meta["means2d"].absgrad``.  rasterize_mode "antialiased": opacity compensation.
+        render_mode: RGB / D / ED / RGB+D / RGB+ED.  distributed: gaussian-sharded
+        multi-GPU mode of the reference (see distributed.py; the camera-sharded data
+        parallel wrapper is ``distributed.rasterization_camera_sharded``).
+
+    Returns:
+        render_colors [C,H,W,X], render_alphas [C,H,W,1], meta dict.
+    """
+    meta: Dict = {}
+
+    N = means.shape[0]
+    C = viewmats.shape[0]
+    device = means.device
+    assert means.shape == (N, 3), means.shape
+    if covars is None:
+        assert quats.shape == (N, 4), quats.shape
+        assert scales.shape == (N, 3), scales.shape
+    else:
+        assert covars.shape == (N, 3, 3), covars.shape
+        quats, scales = None, None
+        # 3x3 matrix -> upper-triangular 6-vector
+        covars = covars[..., [0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]]
+    assert opacities.shape == (N,), opacities.shape
+    assert viewmats.shape == (C, 4, 4), viewmats.shape
+    assert Ks.shape == (C, 3, 3), Ks.shape
+    assert render_mode in ["RGB", "D", "ED", "RGB+D", "RGB+ED"], render_mode
+
+    if sh_degree is None:
+        # post-activation values [N, D] or [C, N, D]
+        assert (colors.dim() == 2 and colors.shape[0] == N) or (
+            colors.dim() == 3 and colors.shape[:2] == (C, N)
+        ), colors.shape
+        if distributed:
+            assert colors.dim() == 2, "Distributed mode only supports per-Gaussian colors."
+    else:
+        # SH coefficients [N, K, 3] or [C, N, K, 3]; partial bands allowed
+        assert (colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3) or (
+            colors.dim() == 4 and colors.shape[:2] == (C, N) and colors.shape[3] == 3
+        ), colors.shape
+        assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
+        if distributed:
+            assert colors.dim() == 3, "Distributed mode only supports per-Gaussian colors."
+
+    if absgrad:
+        assert not distributed, "AbsGrad is not supported in distributed mode."
+
+    if distributed:
+        from . import distributed as D
+
+        world_rank = torch.distributed.get_rank()
+        world_size = torch.distributed.get_world_size()
+        # gaussians are sharded over ranks; gather #gaussians and all cameras
+        N_world = D.all_gather_int32(world_size, N, device=device)
+        C_world = [C] * world_size
+        viewmats, Ks = D.all_gather_tensor_list(world_size, [viewmats, Ks])
+        C = len(viewmats)
+
+    proj_results = fully_fused_projection(
+        means, covars, quats, scales, viewmats, Ks, width, height,
+        eps2d=eps2d, packed=packed, near_plane=near_plane, far_plane=far_plane,
+        radius_clip=radius_clip, sparse_grad=sparse_grad,
+        calc_compensations=(rasterize_mode == "antialiased"), camera_model=camera_model,
+    )
+
+    if packed:
+        camera_ids, gaussian_ids, radii, means2d, depths, conics, compensations = proj_results
+        opacities = opacities[gaussian_ids]  # [nnz]
+    else:
+        radii, means2d, depths, conics, compensations = proj_results
+        opacities = opacities.repeat(C, 1)  # [C, N]
+        camera_ids, gaussian_ids = None, None
+
+    if compensations is not None:
+        opacities = opacities * compensations
+
+    meta.update(
+        {
+            "camera_ids": camera_ids,
+            "gaussian_ids": gaussian_ids,
+            "radii": radii,
+            "means2d": means2d,
+            "depths": depths,
+            "conics": conics,
+            "opacities": opacities,
+        }
+    )
+
+    # colours -> [C, N, D] or [nnz, D]
+    if sh_degree is None:
+        if packed:
+            colors = colors[gaussian_ids] if colors.dim() == 2 else colors[camera_ids, gaussian_ids]
+        else:
+            if colors.dim() == 2:
+                colors = colors.expand(C, -1, -1)
+    else:
+        camtoworlds = torch.inverse(viewmats)  # [C, 4, 4]
+        if packed:
+            dirs = means[gaussian_ids, :] - camtoworlds[camera_ids, :3, 3]  # [nnz, 3]
+            masks = radii > 0
+            shs = colors[gaussian_ids, :, :] if colors.dim() == 3 else colors[camera_ids, gaussian_ids, :, :]
+            colors = spherical_harmonics(sh_degree, dirs, shs, masks=masks)  # [nnz, 3]
+        else:
+            dirs = means[None, :, :] - camtoworlds[:, None, :3, 3]  # [C, N, 3]
+            masks = radii > 0  # [C, N]
+            if colors.dim() == 3:
+                colors = spherical_harmonics_shared(sh_degree, dirs, colors, masks=masks)  # [C, N, 3]
+            else:
+                colors = spherical_harmonics(sh_degree, dirs, colors, masks=masks)  # [C, N, 3]
+        # same convention as the reference (rendering.py:392)
+        colors = torch.clamp_min(colors + 0.5, 0.0)
+
+    if distributed:
+        from . import distributed as D
+
+        (C, radii, means2d, depths, conics, opacities, colors, camera_ids, gaussian_ids) = D.exchange_projected(
+            world_rank, world_size, N, N_world, C_world, packed, radii, means2d, depths, conics, opacities,
+            colors, camera_ids, gaussian_ids,
+        )
+
+    if render_mode in ["RGB+D", "RGB+ED"]:
+        colors = torch.cat((colors, depths[..., None]), dim=-1)
+        if backgrounds is not None:
+            backgrounds = torch.cat([backgrounds, torch.zeros(C, 1, device=backgrounds.device)], dim=-1)
+    elif render_mode in ["D", "ED"]:
+        colors = depths[..., None]
+        if backgrounds is not None:
+            backgrounds = torch.zeros(C, 1, device=backgrounds.device)
+
+    tile_width = math.ceil(width / float(tile_size))
+    tile_height = math.ceil(height / float(tile_size))
+    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
+        means2d, radii, depths, tile_size, tile_width, tile_height,
+        packed=packed, n_cameras=C, camera_ids=camera_ids, gaussian_ids=gaussian_ids,
+    )
+    isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
+
+    meta.update(
+        {
+            "tile_width": tile_width,
+            "tile_height": tile_height,
+            "tiles_per_gauss": tiles_per_gauss,
+            "isect_ids": isect_ids,
+            "flatten_ids": flatten_ids,
+            "isect_offsets": isect_offsets,
+            "width": width,
+            "height": height,
+            "tile_size": tile_size,
+            "n_cameras": C,
+        }
+    )
+
+    if colors.shape[-1] > channel_chunk:
+        n_chunks = (colors.shape[-1] + channel_chunk - 1) // channel_chunk
+        render_colors, render_alphas = [], []
+        for i in range(n_chunks):
+            colors_chunk = colors[..., i * channel_chunk : (i + 1) * channel_chunk]
+            backgrounds_chunk = (
+                backgrounds[..., i * channel_chunk : (i + 1) * channel_chunk] if backgrounds is not None else None
+            )
+            rc_, ra_ = rasterize_to_pixels(
+                means2d, conics, colors_chunk, opacities, width, height, tile_size, isect_offsets, flatten_ids,
+                backgrounds=backgrounds_chunk, packed=packed, absgrad=absgrad,
+            )
+            render_colors.append(rc_)
+            render_alphas.append(ra_)
+        render_colors = torch.cat(render_colors, dim=-1)
+        render_alphas = render_alphas[0]  # discard the rest
+    else:
+        render_colors, render_alphas = rasterize_to_pixels(
+            means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
+            backgrounds=backgrounds, packed=packed, absgrad=absgrad,
+        )
+    if render_mode in ["ED", "RGB+ED"]:
+        # accumulated depth -> expected depth
+        render_colors = torch.cat(
+            [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1
+        )
+
+    return render_colors, render_alphas, meta

@@ -1,0 +1,306 @@
+/*
+ * gsplat_hip.h -- flat C ABI of libgsplat_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the rasterize + quantize hot path of
+ * JasonLSC/GSCodec_Studio (a gsplat 1.4.0 fork).  Every entry point replaces one
+ * pybind11 function of the reference's native module (reference file:line cited
+ * per function, paths relative to the reference root).  Differences from the
+ * reference's native surface, all deliberate:
+ *
+ *   - no torch types: raw device pointers + explicit sizes + a hipStream_t
+ *     (passed as void*), so any host (ctypes, cgo, JNI, a C++ runtime) can bind it;
+ *   - the CALLER owns every buffer, including scratch; the library keeps no
+ *     global device state and never allocates or frees device memory;
+ *   - data-dependent sizes (n_isects, nnz) use a two-call protocol: a *_count
+ *     call leaves the total in caller memory, the caller allocates, then calls
+ *     the *_emit / *_fill entry point;
+ *   - every function returns 0 on success, non-zero on error; the message is
+ *     available (thread-local) from gs_last_error().  Nothing throws or aborts
+ *     across the ABI;
+ *   - all launches are asynchronous on the given stream.
+ *
+ * All floating-point tensors are fp32, contiguous, row-major.  Integer dtypes
+ * match the reference's meta tensors (radii/flatten_ids/offsets/last_ids int32,
+ * isect_ids/camera_ids/gaussian_ids int64, masks uint8/bool).
+ */
+#ifndef GSPLAT_HIP_H
+#define GSPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_ABI_VERSION 1
+
+/* reference: gsplat/cuda/include/bindings.h:34-38 (enum CameraModelType) */
+#define GS_CAMERA_PINHOLE 0
+#define GS_CAMERA_ORTHO 1
+#define GS_CAMERA_FISHEYE 2
+
+/* quantizer modes (reference: gsplat/compression_simulation/ops.py:39-54) */
+#define GS_QUANT_NOISE 0
+#define GS_QUANT_ROUND 1
+
+typedef void *gs_stream_t; /* hipStream_t */
+
+int32_t gs_version(void);
+const char *gs_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * R1  fully fused projection
+ * replaces fully_fused_projection_fwd_tensor
+ *   (gsplat/cuda/csrc/fully_fused_projection_fwd.cu:198-275, kernel 22-196)
+ * Exactly one of {covars} / {quats, scales} is non-NULL.
+ * Outputs for entries with radii == 0 are left untouched (the reference leaves
+ * them uninitialised); compensations (optional) must be zero-filled by the caller.
+ * ---------------------------------------------------------------------- */
+int32_t gs_projection_fwd(
+    uint32_t C, uint32_t N,
+    const float *means,    /* [N,3] */
+    const float *covars,   /* [N,6] triu or NULL */
+    const float *quats,    /* [N,4] wxyz or NULL */
+    const float *scales,   /* [N,3] or NULL */
+    const float *viewmats, /* [C,4,4] world->camera */
+    const float *Ks,       /* [C,3,3] */
+    int32_t image_width, int32_t image_height,
+    float eps2d, float near_plane, float far_plane, float radius_clip,
+    int32_t camera_model,
+    int32_t *radii,       /* [C,N] */
+    float *means2d,       /* [C,N,2] */
+    float *depths,        /* [C,N] */
+    float *conics,        /* [C,N,3] */
+    float *compensations, /* [C,N] or NULL */
+    gs_stream_t stream);
+
+/* replaces fully_fused_projection_bwd_tensor
+ *   (gsplat/cuda/csrc/fully_fused_projection_bwd.cu:265-372, kernel 24-263)
+ * v_means / v_covars / v_quats / v_scales are fully OVERWRITTEN (one thread owns one
+ * gaussian and sums over cameras in registers: no atomics, deterministic).
+ * v_viewmats (optional) is ACCUMULATED with atomics: caller zero-fills it. */
+int32_t gs_projection_bwd(
+    uint32_t C, uint32_t N,
+    const float *means, const float *covars, const float *quats, const float *scales,
+    const float *viewmats, const float *Ks,
+    int32_t image_width, int32_t image_height, float eps2d, int32_t camera_model,
+    const int32_t *radii,        /* [C,N] */
+    const float *conics,         /* [C,N,3] */
+    const float *compensations,  /* [C,N] or NULL */
+    const float *v_means2d,      /* [C,N,2] */
+    const float *v_depths,       /* [C,N] */
+    const float *v_conics,       /* [C,N,3] */
+    const float *v_compensations,/* [C,N] or NULL */
+    float *v_means,   /* [N,3] or NULL */
+    float *v_covars,  /* [N,6] or NULL */
+    float *v_quats,   /* [N,4] or NULL */
+    float *v_scales,  /* [N,3] or NULL */
+    float *v_viewmats,/* [C,4,4] or NULL */
+    gs_stream_t stream);
+
+/* packed (COO) projection, replaces fully_fused_projection_packed_fwd_tensor
+ *   (gsplat/cuda/csrc/fully_fused_projection_packed_fwd.cu:251-399).
+ * Pass 1 (count): block_cnts[C * nblocks] <- #visible per (camera, 256-gaussian block),
+ * nblocks = ceil(N / 256).  The caller turns it into an inclusive prefix sum
+ * (gs_cumsum_i32) and reads nnz = last element.  Pass 2 (fill) writes rows in
+ * (camera, gaussian) order.  NOTE the packed radius formula differs from the unpacked
+ * one exactly as in the reference (packed_fwd.cu:183-186 vs fwd.cu:167-169). */
+int32_t gs_projection_packed_count(
+    uint32_t C, uint32_t N,
+    const float *means, const float *covars, const float *quats, const float *scales,
+    const float *viewmats, const float *Ks,
+    int32_t image_width, int32_t image_height,
+    float eps2d, float near_plane, float far_plane, float radius_clip,
+    int32_t camera_model,
+    int32_t *block_cnts, /* [C * ceil(N/256)] */
+    gs_stream_t stream);
+
+int32_t gs_projection_packed_fill(
+    uint32_t C, uint32_t N,
+    const float *means, const float *covars, const float *quats, const float *scales,
+    const float *viewmats, const float *Ks,
+    int32_t image_width, int32_t image_height,
+    float eps2d, float near_plane, float far_plane, float radius_clip,
+    int32_t camera_model,
+    const int32_t *block_accum, /* inclusive prefix sum of block_cnts */
+    int32_t *indptr,            /* [C+1] */
+    int64_t *camera_ids,        /* [nnz] */
+    int64_t *gaussian_ids,      /* [nnz] */
+    int32_t *radii, float *means2d, float *depths, float *conics,
+    float *compensations,       /* [nnz] or NULL */
+    gs_stream_t stream);
+
+/* replaces fully_fused_projection_packed_bwd_tensor
+ *   (gsplat/cuda/csrc/fully_fused_projection_packed_bwd.cu:318-430).
+ * sparse_grad == 0: dense [N,*] outputs, ACCUMULATED with atomics (caller zero-fills);
+ * sparse_grad != 0: [nnz,*] outputs written directly. */
+int32_t gs_projection_packed_bwd(
+    uint32_t C, uint32_t N, uint32_t nnz,
+    const float *means, const float *covars, const float *quats, const float *scales,
+    const float *viewmats, const float *Ks,
+    int32_t image_width, int32_t image_height, float eps2d, int32_t camera_model,
+    const int64_t *camera_ids, const int64_t *gaussian_ids,
+    const float *conics, const float *compensations,
+    const float *v_means2d, const float *v_depths, const float *v_conics,
+    const float *v_compensations,
+    int32_t sparse_grad,
+    float *v_means, float *v_covars, float *v_quats, float *v_scales, float *v_viewmats,
+    gs_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * R2  spherical harmonics
+ * replaces compute_sh_fwd_tensor / compute_sh_bwd_tensor
+ *   (gsplat/cuda/csrc/compute_sh_fwd.cu:40-72, compute_sh_bwd.cu:53-95,
+ *    gsplat/cuda/include/spherical_harmonics.cuh:13-362)
+ * Elements are laid out [C, N]; coeffs is [C,N,K,3] (coeffs_shared == 0) or
+ * [N,K,3] broadcast over cameras (coeffs_shared != 0) -- the broadcast form avoids
+ * the reference's [C,N,K,3] materialisation (gsplat/cuda/_wrapper.py:72).
+ * masks: optional uint8 [C,N]; colours of masked-out elements are left untouched.
+ * bwd: v_coeffs is fully OVERWRITTEN (zeros for masked / inactive bases),
+ * shape [N,K,3] when coeffs_shared (sum over cameras done in-kernel) else [C,N,K,3].
+ * v_dirs (optional, [C,N,3]) is fully overwritten.
+ * ---------------------------------------------------------------------- */
+int32_t gs_sh_fwd(
+    uint32_t C, uint32_t N, uint32_t K, uint32_t degree,
+    const float *dirs, const float *coeffs, int32_t coeffs_shared,
+    const uint8_t *masks, float *colors, gs_stream_t stream);
+
+int32_t gs_sh_bwd(
+    uint32_t C, uint32_t N, uint32_t K, uint32_t degree,
+    const float *dirs, const float *coeffs, int32_t coeffs_shared,
+    const uint8_t *masks, const float *v_colors,
+    float *v_coeffs, float *v_dirs, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * R3 / R4  tile intersection, 64-bit radix sort, offset encode
+ * replaces isect_tiles_tensor / isect_offset_encode_tensor
+ *   (gsplat/cuda/csrc/isect_tiles.cu:106-306, 356-389)
+ * Protocol: gs_isect_count -> gs_cumsum_i32 (inclusive, int64 out; last element
+ * = n_isects) -> caller allocates -> gs_isect_emit -> gs_sort_pairs_u64_i32 ->
+ * gs_isect_offset_encode.
+ * ---------------------------------------------------------------------- */
+int32_t gs_isect_count(
+    uint32_t n_elems,           /* C*N or nnz */
+    const float *means2d, const int32_t *radii,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+    int32_t *tiles_per_gauss,   /* [n_elems] */
+    gs_stream_t stream);
+
+/* inclusive prefix sum int32 -> int64.  scratch: gs_cumsum_scratch_bytes(n). */
+size_t gs_cumsum_scratch_bytes(uint64_t n);
+int32_t gs_cumsum_i32(
+    uint64_t n, const int32_t *in, int64_t *out,
+    void *scratch, size_t scratch_bytes, gs_stream_t stream);
+/* int32 -> int32 variant (packed projection block counts). */
+int32_t gs_cumsum_i32_i32(
+    uint64_t n, const int32_t *in, int32_t *out,
+    void *scratch, size_t scratch_bytes, gs_stream_t stream);
+
+int32_t gs_isect_emit(
+    uint32_t n_elems, uint32_t N,   /* camera of element i = i / N when camera_ids NULL */
+    const int64_t *camera_ids,      /* [nnz] or NULL */
+    const float *means2d, const int32_t *radii, const float *depths,
+    const int64_t *cum_tiles_per_gauss, /* inclusive */
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+    uint32_t tile_n_bits,
+    int64_t *isect_ids,   /* [n_isects] */
+    int32_t *flatten_ids, /* [n_isects] */
+    gs_stream_t stream);
+
+/* Stable LSD radix sort of (uint64 key, int32 value) pairs on key bits
+ * [begin_bit, end_bit) -- the replacement for cub::DeviceRadixSort::SortPairs
+ * (gsplat/cuda/csrc/isect_tiles.cu:245-299).  Inputs are not modified; the sorted
+ * result is in keys_out / vals_out. */
+size_t gs_sort_temp_bytes(uint64_t n);
+int32_t gs_sort_pairs_u64_i32(
+    uint64_t n,
+    const int64_t *keys_in, const int32_t *vals_in,
+    int64_t *keys_out, int32_t *vals_out,
+    int32_t begin_bit, int32_t end_bit,
+    void *temp, size_t temp_bytes, gs_stream_t stream);
+
+int32_t gs_isect_offset_encode(
+    uint32_t n_isects, const int64_t *isect_ids_sorted,
+    uint32_t C, uint32_t n_tiles, uint32_t tile_n_bits,
+    int32_t *offsets, /* [C, n_tiles]; fully written (zeros when n_isects == 0) */
+    gs_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * R5  per-tile alpha compositing
+ * replaces rasterize_to_pixels_fwd_tensor / rasterize_to_pixels_bwd_tensor
+ *   (gsplat/cuda/csrc/rasterize_to_pixels_fwd.cu:187-352, kernel 16-185;
+ *    gsplat/cuda/csrc/rasterize_to_pixels_bwd.cu:279-489, kernel 17-277)
+ * channels is a runtime value (1..513); no padding is required from the caller.
+ * n_elems = C*N (unpacked) or nnz (packed): size of the per-splat arrays.
+ * bwd outputs are ACCUMULATED with atomics: caller zero-fills them.
+ * ---------------------------------------------------------------------- */
+int32_t gs_rasterize_fwd(
+    uint32_t C, uint32_t n_elems, uint32_t n_isects, uint32_t channels,
+    const float *means2d, const float *conics, const float *colors,
+    const float *opacities,
+    const float *backgrounds, /* [C,channels] or NULL */
+    const uint8_t *masks,     /* [C,tile_h,tile_w] or NULL */
+    uint32_t image_width, uint32_t image_height, uint32_t tile_size,
+    uint32_t tile_width, uint32_t tile_height,
+    const int32_t *tile_offsets, const int32_t *flatten_ids,
+    float *render_colors, /* [C,H,W,channels] */
+    float *render_alphas, /* [C,H,W,1] */
+    int32_t *last_ids,    /* [C,H,W] */
+    gs_stream_t stream);
+
+int32_t gs_rasterize_bwd(
+    uint32_t C, uint32_t n_elems, uint32_t n_isects, uint32_t channels,
+    const float *means2d, const float *conics, const float *colors,
+    const float *opacities, const float *backgrounds, const uint8_t *masks,
+    uint32_t image_width, uint32_t image_height, uint32_t tile_size,
+    uint32_t tile_width, uint32_t tile_height,
+    const int32_t *tile_offsets, const int32_t *flatten_ids,
+    const float *render_alphas, const int32_t *last_ids,
+    const float *v_render_colors, const float *v_render_alphas,
+    float *v_means2d_abs, /* [n_elems,2] or NULL */
+    float *v_means2d,     /* [n_elems,2] */
+    float *v_conics,      /* [n_elems,3] */
+    float *v_colors,      /* [n_elems,channels] */
+    float *v_opacities,   /* [n_elems] */
+    gs_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Q1 / Q2  per-splat quantize / dequantize straight-through estimators
+ * replaces the torch ops of fake_quantize_ste / STE
+ *   (gsplat/compression_simulation/ops.py:39-54, 57-75)
+ * noise: out = clamp(x, lo, hi) + noise * q_step   (noise supplied by the caller so the
+ *        RNG stream stays torch's), bwd: v_x = v_out where lo <= x <= hi else 0.
+ * round: x <- clamp(x, lo, hi) IN PLACE (the reference mutates the parameter),
+ *        out = round_half_even(((x - lo) / (hi - lo)) / q) * q * (hi - lo) + lo,
+ *        q = 1/(2^bits - 1); bwd is the identity (no kernel).
+ * All arithmetic is IEEE fp32 with no contraction, in the reference's op order.
+ * ---------------------------------------------------------------------- */
+int32_t gs_quantize_noise_fwd(
+    uint64_t n, const float *x, const float *noise,
+    float lo, float hi, float q_step, float *out, gs_stream_t stream);
+int32_t gs_quantize_noise_bwd(
+    uint64_t n, const float *x, const float *v_out,
+    float lo, float hi, float *v_x, gs_stream_t stream);
+int32_t gs_quantize_round_fwd(
+    uint64_t n, float *x_inplace, float lo, float hi, float range /* (float)(hi-lo) */,
+    float q_step_norm /* (float)(1/(2^bits-1)) */, float *out, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Unfused public ops (reference: quat_scale_to_covar_preci_{fwd,bwd}.cu,
+ * world_to_cam_{fwd,bwd}.cu, proj_{fwd,bwd}.cu)
+ * ---------------------------------------------------------------------- */
+int32_t gs_quat_scale_to_covar_preci_fwd(
+    uint32_t N, const float *quats, const float *scales, int32_t triu,
+    float *covars /* [N,3,3] or [N,6] or NULL */,
+    float *precis /* same or NULL */, gs_stream_t stream);
+int32_t gs_quat_scale_to_covar_preci_bwd(
+    uint32_t N, const float *quats, const float *scales, int32_t triu,
+    const float *v_covars, const float *v_precis, /* either may be NULL */
+    float *v_quats, float *v_scales,              /* overwritten */
+    gs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_HIP_H */
