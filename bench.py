@@ -1,0 +1,261 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the rasterize hot path on MI355X.
+
+Metric (BASELINE.json): Msplats/s fwd+bwd @1080p, 1M splats.  Workload = BASELINE config 2:
+the reference's load_test_data(scene_grid=3) scene (N = 1,006,065 gaussians), SH degree 3,
+one 1920x1080 camera per GPU, packed=False, near=0.01, far=1e10, radius_clip=0, eps2d=0.3,
+tile 16; a "step" is rasterization() forward + backward of sum(render_colors) (the protocol
+of the reference's profiling/main.py:104-133), inputs resident in HBM.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run): camera-sharded weak scaling -- the
+splats are replicated, rank r renders camera r, and the step ends with the RCCL sum of the
+splat gradients (gscodec_studio_amd.distributed.all_reduce_splat_grads).  value counts
+splat-camera pairs: N_splats * n_gpus / step time.
+
+The JSON line carries two extra objects:
+  roofline      the dominant kernel (largest average time per step among the C-ABI entry
+                points, timed live with HIP events on the launch stream inside the timed
+                region): algorithmic bytes / average
+                duration vs the 8 TB/s HBM peak.
+  cpu_baseline  the CPU oracle (oracle/gs_oracle.c, a port -- kind "port") timed on this host on a
+                bounded sample (scene_grid=1: 111,785 gaussians, same camera / resolution / SH).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scene-grid", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--quantize", action="store_true", help="run the compression-simulation hooks before each render")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scene-grid", type=int, default=1)
+    ap.add_argument("--breakdown", action="store_true", help="print per-entry-point timings to stderr")
+    return ap.parse_args()
+
+
+class CallTimer:
+    """Times C-ABI entry points with HIP events recorded on the stream the kernels are launched on."""
+
+    def __init__(self, backend, only=None):
+        self.B = backend
+        self.only = only
+        self.events = {}
+        self._orig = backend.call
+
+    def __enter__(self):
+        def timed_call(name, *args):
+            if self.only is not None and name not in self.only:
+                return self._orig(name, *args)
+            st = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            r = self._orig(name, *args)
+            e1.record(st)
+            self.events.setdefault(name, []).append((e0, e1))
+            return r
+
+        self.B.call = timed_call
+        # the operator modules hold a reference to the module, not the function, so patching
+        # the attribute is enough
+        return self
+
+    def __exit__(self, *a):
+        self.B.call = self._orig
+
+    def totals_ms(self):
+        torch.cuda.synchronize()
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in self.events.items()}
+
+
+def algorithmic_bytes(stats):
+    """Compulsory HBM bytes per launch of each entry point."""
+    N, V, I, P, T, K = (stats[k] for k in ("N", "V", "I", "P", "T", "K"))
+    return {
+        "gs_projection_fwd": 40 * N + 4 * N + 24 * V,
+        "gs_sh_fwd": (12 + 12 * K) * V + 12 * V,
+        "gs_isect_count": 12 * N + 4 * N,
+        "gs_cumsum_i32": 4 * N + 8 * N,
+        "gs_isect_emit": 24 * V + 12 * I,
+        "gs_sort_pairs_u64_i32": 24 * I,
+        "gs_isect_offset_encode": 8 * I + 4 * T,
+        "gs_rasterize_fwd": 40 * I + 20 * P,
+        "gs_rasterize_bwd": 40 * I + 24 * P + 36 * V,
+        "gs_sh_bwd": (24 + 12 * K) * V + 12 * K * N + 12 * V,
+        "gs_projection_bwd": 92 * V + 40 * N + 4 * N,
+    }
+
+
+def cpu_baseline(args, sh_degree):
+    """Oracle fwd+bwd on a bounded sample; returns the cpu_baseline object."""
+    from gscodec_studio_amd._helper import sh_workload
+    from oracle import gs_oracle as O
+
+    w = sh_workload(scene_grid=args.cpu_scene_grid, width=args.width, height=args.height, n_cameras=1,
+                    sh_degree=sh_degree, device="cpu")
+    a = {k: w[k].numpy() for k in ("means", "quats", "scales", "opacities", "sh", "viewmats", "Ks")}
+    W, H = w["width"], w["height"]
+    t0 = time.perf_counter()
+    rc, ra, m = O.rasterization(a["means"], a["quats"], a["scales"], a["opacities"], a["sh"], a["viewmats"], a["Ks"],
+                                W, H, sh_degree=sh_degree)
+    v_rc = np.ones_like(rc)
+    v_m2, v_cn, v_col, v_op, _ = O.rasterize_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], W, H, 16,
+                                                 m["isect_offsets"], m["flatten_ids"], ra, m["last_ids"], v_rc,
+                                                 np.zeros_like(ra))
+    c2w = np.linalg.inv(a["viewmats"].astype(np.float64)).astype(np.float32)
+    dirs = a["means"][None] - c2w[:, None, :3, 3]
+    O.sh_bwd(sh_degree, dirs, a["sh"][None], v_col, m["radii"] > 0)
+    O.projection_bwd(a["means"], None, a["quats"], a["scales"], a["viewmats"], a["Ks"], W, H, 0.3, "pinhole",
+                     m["radii"], m["conics"], None, v_m2, np.zeros_like(m["depths"]), v_cn, None, need_viewmats=False)
+    dt = time.perf_counter() - t0
+    n = a["means"].shape[0]
+    return {
+        "value": n / dt / 1e6, "unit": "Msplats/s", "cores": int(O.lib().orc_num_threads()), "kind": "port",
+        "sample": f"oracle/gs_oracle.c fwd+bwd, scene_grid={args.cpu_scene_grid} ({n} gaussians, 1/"
+                  f"{args.scene_grid ** 2 // args.cpu_scene_grid ** 2} of the bench scene), same camera, "
+                  f"{W}x{H}, SH deg {sh_degree}; {dt:.1f} s wall, 1 run",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", world_size=world, rank=rank,
+                                device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from gscodec_studio_amd import _backend as B
+    from gscodec_studio_amd import rasterization
+    from gscodec_studio_amd._helper import sh_workload
+    from gscodec_studio_amd.distributed import all_reduce_splat_grads
+
+    B.lib()  # fail loudly if the HIP library is missing
+    w = sh_workload(scene_grid=args.scene_grid, width=args.width, height=args.height, n_cameras=world,
+                    sh_degree=args.sh_degree, device=dev)
+    N = w["N"]
+    params = {k: w[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "sh")}
+    viewmats, Ks = w["viewmats"][rank: rank + 1].contiguous(), w["Ks"][rank: rank + 1].contiguous()
+    sim = None
+    if args.quantize:
+        from gscodec_studio_amd.compression_simulation import CompressionSimulation
+
+        sim = CompressionSimulation(entropy_model_enable=False, entropy_steps={})
+
+    last_meta = {}
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        if sim is not None:
+            q, _ = sim.simulate_compression({"scales": params["scales"], "quats": params["quats"]}, step=0)
+            quats, scales = q["quats"], q["scales"]
+        else:
+            quats, scales = params["quats"], params["scales"]
+        rc, ra, meta = rasterization(params["means"], quats, scales, params["opacities"], params["sh"], viewmats, Ks,
+                                     w["width"], w["height"], sh_degree=args.sh_degree, packed=False)
+        rc.sum().backward()
+        if world > 1:
+            all_reduce_splat_grads(params, world_size=world, average=False)
+        last_meta.update(meta)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+
+    # pass A (untimed): find the dominant entry point
+    with CallTimer(B) as ct:
+        for _ in range(2):
+            step()
+    per_call = {k: float(np.mean(v)) for k, v in ct.totals_ms().items()}
+    calls_per_step = {k: len(v) / 2 for k, v in ct.events.items()}
+    per_step = {k: per_call[k] * calls_per_step[k] for k in per_call}
+    dominant = max(per_step, key=per_step.get)
+    if args.breakdown and rank == 0:
+        for k, v in sorted(per_step.items(), key=lambda kv: -kv[1]):
+            print(f"  {k:32s} {v:8.3f} ms/step", file=sys.stderr)
+
+    # timed region: exactly K steps, only the dominant entry point carries events
+    barrier()
+    with CallTimer(B, only={dominant}) as ct:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+    dom_ms = float(np.mean(ct.totals_ms()[dominant]))
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if rank == 0:
+        meta = last_meta
+        stats = dict(N=N, V=int((meta["radii"] > 0).sum()), I=int(meta["flatten_ids"].numel()),
+                     P=w["width"] * w["height"], T=meta["tile_width"] * meta["tile_height"], K=(args.sh_degree + 1) ** 2)
+        alg = algorithmic_bytes(stats)
+        achieved = alg[dominant] / (dom_ms * 1e-3) / 1e9
+        total_alg = sum(alg.values())
+        out = {
+            "metric": "Msplats/s fwd+bwd @1080p (1M splats)",
+            "value": N * world / (ms_per_step * 1e-3) / 1e6,
+            "unit": "Msplats/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE config 2: load_test_data(scene_grid={args.scene_grid}) -> {N} gaussians, "
+                            f"SH degree {args.sh_degree}, {world}x1 camera {w['width']}x{w['height']}, packed=False, "
+                            f"tile 16, fwd + bwd of sum(render)" + (", quantize hooks on" if args.quantize else ""),
+                "visible": stats["V"], "n_isects": stats["I"], "parallelism": f"camera-sharded dp{world}",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": dom_ms,
+                "algorithmic_bytes": alg[dominant],
+                "whole_step": {"algorithmic_bytes": total_alg, "achieved": total_alg / (ms_per_step * 1e-3) / 1e9,
+                               "frac": total_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "per_entry_point_ms": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, args.sh_degree)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

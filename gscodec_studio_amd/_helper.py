@@ -1,0 +1,99 @@
+"""Synthetic workload generator: counterpart of the reference's ``gsplat/_helper.py:9-55``
+(``load_test_data``) with the randomness made reproducible.
+
+``load_test_data(scene_grid=g)`` tiles the garden crop (111,785 points, shipped as
+``assets/garden_crop.npz``, derived data of the reference's assets/test_garden.npz) on a g x g
+grid => N = g^2 * 111,785 gaussians, and draws scales ~ U(0, 0.02)^3, quats = normalize(N(0,1)^4),
+opacities ~ U(0,1).  The reference draws them from the global RNG unseeded; here a CPU
+generator with an explicit seed is used, so CPU (oracle) and GPU runs see identical inputs.
+``sh_workload`` adds degree-3 SH coefficients (BASELINE config 2).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_ASSET = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "garden_crop.npz")
+SH_C0 = 0.2820947917738781
+
+
+def load_test_data(
+    data_path: Optional[str] = None,
+    device="cuda",
+    scene_crop: Tuple[float, float, float, float, float, float] = (-2, -2, -2, 2, 2, 2),
+    scene_grid: int = 1,
+    seed: int = 42,
+):
+    """Returns (means, quats, scales, opacities, colors, viewmats, Ks, width, height)."""
+    assert scene_grid % 2 == 1, "scene_grid must be odd"
+    data = np.load(data_path or _ASSET)
+    height, width = int(data["height"]), int(data["width"])
+    viewmats = torch.from_numpy(data["viewmats"]).float()
+    Ks = torch.from_numpy(data["Ks"]).float()
+    means = torch.from_numpy(data["means3d"]).float()
+    colors = torch.from_numpy(data["colors"] / 255.0).float()
+
+    aabb = torch.tensor(scene_crop, dtype=torch.float32)
+    edges = aabb[3:] - aabb[:3]
+    sel = ((means >= aabb[:3]) & (means <= aabb[3:])).all(dim=-1)
+    means, colors = means[sel], colors[sel]
+
+    r = scene_grid
+    gx, gy = torch.meshgrid(torch.arange(-(r // 2), r // 2 + 1), torch.arange(-(r // 2), r // 2 + 1), indexing="ij")
+    grid = torch.stack([gx, gy, torch.zeros_like(gx)], dim=-1).reshape(-1, 3).float()
+    means = (means[None, :, :] + grid[:, None, :] * edges[None, None, :]).reshape(-1, 3)
+    colors = colors.repeat(r**2, 1)
+
+    N = len(means)
+    g = torch.Generator().manual_seed(seed)
+    scales = torch.rand((N, 3), generator=g) * 0.02
+    quats = F.normalize(torch.randn((N, 4), generator=g), dim=-1)
+    opacities = torch.rand((N,), generator=g)
+    out = (means, quats, scales, opacities, colors, viewmats, Ks)
+    out = tuple(t.contiguous().to(device) for t in out)
+    return out + (width, height)
+
+
+def rescale_intrinsics(Ks: torch.Tensor, width: int, height: int, new_width: int, new_height: int) -> torch.Tensor:
+    """profiling/main.py:85-87 of the reference: scale K rows to the new resolution."""
+    Ks = Ks.clone()
+    Ks[..., 0, :] *= new_width / width
+    Ks[..., 1, :] *= new_height / height
+    return Ks
+
+
+def sh_workload(scene_grid: int = 3, width: int = 1920, height: int = 1080, n_cameras: int = 1, sh_degree: int = 3,
+                device="cuda", seed: int = 42) -> Dict:
+    """BASELINE.json config 2: scene_grid=3 -> N = 1,006,065 gaussians, SH degree 3, 1080p.
+
+    Cameras: the fixture's 3 cameras, cycled when n_cameras > 3 with a small seeded yaw so that
+    every camera of a multi-GPU batch is distinct.
+    """
+    means, quats, scales, opacities, rgb, viewmats, Ks, w0, h0 = load_test_data(device="cpu", scene_grid=scene_grid, seed=seed)
+    Ks = rescale_intrinsics(Ks, w0, h0, width, height)
+    K = (sh_degree + 1) ** 2
+    N = means.shape[0]
+    g = torch.Generator().manual_seed(seed + 1)
+    sh = torch.empty((N, K, 3))
+    sh[:, 0] = (rgb - 0.5) / SH_C0
+    if K > 1:
+        sh[:, 1:] = torch.randn((N, K - 1, 3), generator=g) * 0.05
+    vm, kk = [], []
+    for i in range(n_cameras):
+        V = viewmats[i % 3].clone()
+        if i >= 3:
+            a = 0.05 * (i // 3) * (1 if i % 2 else -1)
+            c, s = float(np.cos(a)), float(np.sin(a))
+            Rz = torch.tensor([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=torch.float32)
+            V = V @ Rz
+        vm.append(V)
+        kk.append(Ks[i % 3])
+    d = dict(means=means, quats=quats, scales=scales, opacities=opacities, sh=sh, rgb=rgb,
+             viewmats=torch.stack(vm), Ks=torch.stack(kk))
+    d = {k: v.contiguous().to(device) for k, v in d.items()}
+    d.update(width=width, height=height, sh_degree=sh_degree, N=N)
+    return d

@@ -580,10 +580,12 @@ class _RasterizeToPixels(torch.autograd.Function):
         m8 = masks.view(torch.uint8) if masks is not None else None
         assert isect_offsets.dtype == torch.int32 and flatten_ids.dtype == torch.int32
         with _device_of(means2d):
+            sb = B.query("gs_rasterize_scratch_bytes", C * tile_height * tile_width)
+            scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
             B.call("gs_rasterize_fwd", C, n_elems, n_isects, channels, B.ptr(means2d), B.ptr(conics), B.ptr(colors),
                    B.ptr(opacities), B.ptr(backgrounds), B.ptr(m8), width, height, tile_size, tile_width,
                    tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_colors),
-                   B.ptr(render_alphas), B.ptr(last_ids), _stream(means2d))
+                   B.ptr(render_alphas), B.ptr(last_ids), B.ptr(scratch), sb, _stream(means2d))
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids,
                               render_alphas, last_ids)
         ctx.width, ctx.height, ctx.tile_size, ctx.absgrad = width, height, tile_size, absgrad
@@ -607,11 +609,14 @@ class _RasterizeToPixels(torch.autograd.Function):
         v_means2d_abs = torch.zeros_like(means2d) if ctx.absgrad else None
         m8 = masks.view(torch.uint8) if masks is not None else None
         with _device_of(means2d):
+            sb = B.query("gs_rasterize_scratch_bytes", C * tile_height * tile_width)
+            scratch = torch.empty(sb, dtype=torch.uint8, device=means2d.device)
             B.call("gs_rasterize_bwd", C, n_elems, n_isects, channels, B.ptr(means2d), B.ptr(conics), B.ptr(colors),
                    B.ptr(opacities), B.ptr(backgrounds), B.ptr(m8), ctx.width, ctx.height, ctx.tile_size,
                    tile_width, tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_alphas),
                    B.ptr(last_ids), B.ptr(v_render_colors), B.ptr(v_render_alphas), B.ptr(v_means2d_abs),
-                   B.ptr(v_means2d), B.ptr(v_conics), B.ptr(v_colors), B.ptr(v_opacities), _stream(means2d))
+                   B.ptr(v_means2d), B.ptr(v_conics), B.ptr(v_colors), B.ptr(v_opacities), B.ptr(scratch), sb,
+                   _stream(means2d))
         if ctx.absgrad:
             means2d.absgrad = v_means2d_abs
         if ctx.needs_input_grad[4]:

@@ -1,4 +1,637 @@
-// TEMPORARY stub: wave-per-tile kernels not written yet
+// rasterize.hip -- R5: per-tile front-to-back alpha compositing, fwd + bwd, wave-per-tile
+// kernels for gfx950 (the default implementation; rasterize_ref.hip is the baseline).
+//
+// Replaces gsplat/cuda/csrc/rasterize_to_pixels_fwd.cu:16-185 and
+// rasterize_to_pixels_bwd.cu:17-277.  Same per-pixel arithmetic and decisions
+// (alpha = min(0.999, o * exp(-sigma)); skip sigma < 0 or alpha < 1/255; exclusive stop when
+// T (1 - alpha) <= 1e-4; last_ids; alpha-clamp gradient gate), different mapping:
+//
+//   * ONE WAVE64 OWNS ONE 16x16 TILE; lane (lx, ly) of an 8x8 grid owns FOUR pixels, one in
+//     each 8x8 quadrant.  No workgroup barriers (the reference's 256-thread block needs two
+//     __syncthreads per 256 splats); a splat record is fetched from LDS once per 256 pixel
+//     evaluations (register blocking over pixels: with one pixel per lane the broadcast
+//     ds_read_b128 traffic alone would saturate the LDS pipe); the four pixels give four
+//     independent dependency chains per lane, and in the backward the cross-lane reduction
+//     is paid once per (tile, splat) on partial sums of 4 pixels.
+//   * LDS-STAGED, COMPACTED SPLAT LISTS: each lane gathers one splat of the tile's sorted
+//     list (flatten_ids -> means2d / conics / opacities / colours) and converts it to what the
+//     inner loop wants: the conic pre-scaled by -log2(e)/2 so that
+//         alpha = exp2(dx (a' dx + b' dy) + c' dy^2 + log2 o)      (5 FMA + v_exp_f32).
+//     While a lane holds its splat it computes the axis-aligned extent of the
+//     { alpha >= 1/255 } ellipse (half extents sqrt(2 ln(255 o) Sigma_xx), Sigma = conic^-1) and
+//     tests it against the tile's live pixel rectangle; a __ballot + mbcnt prefix compacts the
+//     survivors, in order, into the LDS record array.  Splats whose 3-sigma bbox touches the
+//     tile but whose visible ellipse does not are never looked at again.  Culling is
+//     conservative (margins below), hence exact: a culled splat has alpha < 1/255 at every
+//     pixel of the tile, which the reference skips too.  The next batch's gathers are issued
+//     before the current batch is processed (software prefetch), and inside a batch the next
+//     record is read while the current one is evaluated.
+//   * Tiles are walked heaviest-first (tile_order, built by tile_order_kernel): the longest
+//     list bounds the kernel's critical path (one wave walks it serially), so those waves must
+//     start first, spread over all SIMDs, and run at raised priority (s_setprio).
+//   * Backward, per (pixel, splat) with the running transmittance T and
+//         D = sum_k colour_k v_out_k,   B = sum_{splats behind} fac D   (a scalar),
+//     v_alpha = D T + (T_final (v_alpha_out - bg . v_out) - B) / (1 - alpha) -- the reference's
+//     per-channel "buffer" vector (rasterize_to_pixels_bwd.cu:203-241) collapses to the scalar
+//     B, so the per-pixel state does not grow with the channel count.  Every lane accumulates
+//     over its pixels the moments
+//       S0 = sum v_sigma, Sx = sum v_sigma dx, Sy, Sxx, Sxy, Syy   and   C_k = sum fac v_out_k;
+//     one DPP reduction per value per (tile, splat), then
+//       v_xy = (a Sx + b Sy, b Sx + c Sy), v_conic = (Sxx/2, Sxy, Syy/2), v_opacity = -S0 / o,
+//     v_colour = C: algebraically the reference's formulas (bwd.cu:221-236) with the per-pixel
+//     conic products hoisted out of the pixel loop.
+//
+// Channel counts: 1..4 use 4 pixels per lane with colours in the LDS record; 5..32 use one
+// quadrant per wave (NQ = 1) with colours read from global memory at wave-uniform addresses;
+// more than 32 channels: forward in exact chunks of 32, backward in ONE pass of the generic
+// kernel (v_out re-read per splat) so that v_alpha -- and therefore absgrad -- sees every
+// channel, as the reference's single CDIM-templated kernel does.
+#include "gs_common.h"
 #include "rasterize_common.h"
-int32_t raster_wave_fwd(const RasterArgs &a, hipStream_t st) { return raster_ref_fwd(a, st); }
-int32_t raster_wave_bwd(const RasterArgs &a, const RasterGradArgs &ga, hipStream_t st) { return raster_ref_bwd(a, ga, st); }
+
+#include <cstdlib>
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float ALPHA_MIN = 1.f / 255.f;
+constexpr float LOG2_255 = 7.994353436858858f;
+constexpr int HEAVY_TILE = 1024; // list length from which a wave raises its priority
+
+struct SplatRaw {
+    int32_t g;
+    float mx, my, ca, cb, cc, opac;
+};
+
+GS_DEV SplatRaw gather_splat(const RasterArgs &a, int32_t idx, bool in_range) {
+    SplatRaw s;
+    s.g = 0;
+    s.mx = s.my = s.ca = s.cb = s.cc = 0.f;
+    s.opac = 0.f;
+    if (in_range) {
+        s.g = a.flatten_ids[idx];
+        float2 xy = reinterpret_cast<const float2 *>(a.means2d)[s.g];
+        const float *cn = a.conics + 3 * (size_t)s.g;
+        s.mx = xy.x; s.my = xy.y;
+        s.ca = cn[0]; s.cb = cn[1]; s.cc = cn[2];
+        s.opac = a.opacities[s.g];
+    }
+    return s;
+}
+
+// Axis-aligned half extents of { alpha >= 1/255 } for this splat; false when the splat
+// cannot contribute anywhere (opacity below 1/255, zero, negative or NaN).
+GS_DEV bool splat_extent(const SplatRaw &s, float &hx, float &hy) {
+    hx = hy = 0.f;
+    if (!(s.opac > 0.f)) return false;
+    float t = (__log2f(s.opac) + LOG2_255) * LN2; // ln(255 o): alpha >= 1/255 <=> sigma <= t
+    if (!(t > -1e-3f)) return false;
+    t = t * 1.001f + 1e-3f;
+    float det = s.ca * s.cc - s.cb * s.cb;
+    if (det > 0.f && s.ca > 0.f && s.cc > 0.f) {
+        float inv = 1.f / det;
+        hx = sqrtf(2.f * t * s.cc * inv) * 1.01f + 0.25f; // margins: +1% and +0.25 px
+        hy = sqrtf(2.f * t * s.ca * inv) * 1.01f + 0.25f;
+    } else {
+        hx = hy = 3.0e38f; // degenerate conic: never cull
+    }
+    return true;
+}
+
+struct TileGeom {
+    uint32_t lin, cam, tile_id;
+    int32_t range_start, range_end;
+    uint32_t px0, py0;
+};
+
+GS_DEV TileGeom tile_geom(const RasterArgs &a, const int32_t *__restrict__ order, uint32_t slot) {
+    TileGeom g;
+    const uint32_t tiles = a.tile_width * a.tile_height;
+    g.lin = order != nullptr ? (uint32_t)order[slot] : slot;
+    g.cam = g.lin / tiles;
+    g.tile_id = g.lin % tiles;
+    g.range_start = a.tile_offsets[g.lin];
+    g.range_end = (g.lin + 1 == a.C * tiles) ? (int32_t)a.n_isects : a.tile_offsets[g.lin + 1];
+    g.px0 = (g.tile_id % a.tile_width) * a.tile_size;
+    g.py0 = (g.tile_id / a.tile_width) * a.tile_size;
+    return g;
+}
+
+// Pixel rectangle (centres) covered by this wave: the tile (NQ == 4) or one quadrant,
+// clipped to the tile size and the image.  Wave-uniform.
+struct Rect {
+    float x0, x1, y0, y1;
+    bool empty;
+};
+
+template <int NQ>
+GS_DEV Rect wave_rect(const RasterArgs &a, const TileGeom &tg, uint32_t q_first) {
+    uint32_t ox0 = (NQ == 4) ? 0u : 8u * (q_first & 1u), oy0 = (NQ == 4) ? 0u : 8u * (q_first >> 1);
+    uint32_t ox1 = (NQ == 4) ? 16u : ox0 + 8u, oy1 = (NQ == 4) ? 16u : oy0 + 8u;
+    ox1 = min(ox1, a.tile_size);
+    oy1 = min(oy1, a.tile_size);
+    uint32_t X0 = tg.px0 + ox0, Y0 = tg.py0 + oy0;
+    uint32_t X1 = min(tg.px0 + ox1, a.image_width), Y1 = min(tg.py0 + oy1, a.image_height);
+    Rect r;
+    r.empty = (ox0 >= ox1) || (oy0 >= oy1) || X0 >= X1 || Y0 >= Y1;
+    r.x0 = (float)X0 + 0.5f;
+    r.y0 = (float)Y0 + 0.5f;
+    r.x1 = (float)X1 - 0.5f;
+    r.y1 = (float)Y1 - 0.5f;
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// forward
+//   NQ   : pixels per lane (4: whole tile, one pixel per quadrant; 1: quadrant = blockIdx.y)
+//   CDIM : channels of this launch; COLOR_LDS: colours travel in the LDS record (CDIM <= 4)
+// record: R0 = (mx, my, a', b')  R1 = (c', log2 o, col0, col1)  R2 = (col2, col3, idx, g)
+// ---------------------------------------------------------------------------
+template <int NQ, int CDIM, bool COLOR_LDS>
+__global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, const int32_t *__restrict__ order, uint32_t cnt, uint32_t ch_off) {
+    constexpr int REC = 3;
+    __shared__ float4 s_rec[(GS_WAVE + 1) * REC];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    const TileGeom tg = tile_geom(a, order, blockIdx.x);
+    const uint32_t q_first = (NQ == 4) ? 0u : blockIdx.y;
+    const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels + ch_off : nullptr;
+
+    bool inside[NQ];
+    float px[NQ], py[NQ];
+    size_t pix[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const uint32_t q = q_first + i;
+        const uint32_t ox = lx + 8u * (q & 1u), oy = ly + 8u * (q >> 1);
+        const uint32_t x = tg.px0 + ox, y = tg.py0 + oy;
+        inside[i] = ox < a.tile_size && oy < a.tile_size && x < a.image_width && y < a.image_height;
+        px[i] = (float)x + 0.5f;
+        py[i] = (float)y + 0.5f;
+        pix[i] = ((size_t)tg.cam * a.image_height + y) * a.image_width + x;
+    }
+
+    if (a.masks != nullptr && !a.masks[tg.lin]) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+            if (inside[i])
+                for (uint32_t k = 0; k < cnt; ++k) a.render_colors[pix[i] * a.channels + ch_off + k] = bg ? bg[k] : 0.f;
+        return;
+    }
+
+    float T[NQ], out[NQ][CDIM];
+    int32_t cur[NQ];
+    bool done[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        T[i] = 1.f;
+        cur[i] = 0;
+        done[i] = !inside[i];
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) out[i][k] = 0.f;
+    }
+
+    const Rect rect = wave_rect<NQ>(a, tg, q_first);
+    const int32_t n = rect.empty ? 0 : tg.range_end - tg.range_start;
+    const int32_t num_batches = (n + GS_WAVE - 1) / GS_WAVE;
+    if (n >= HEAVY_TILE) __builtin_amdgcn_s_setprio(2);
+
+    SplatRaw nxt = gather_splat(a, tg.range_start + (int32_t)lane, (int32_t)lane < n);
+    float ncol[COLOR_LDS ? CDIM : 1];
+    if (COLOR_LDS) {
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k)
+            ncol[k] = ((int32_t)lane < n && (uint32_t)k < cnt) ? a.colors[(size_t)nxt.g * a.channels + ch_off + k] : 0.f;
+    }
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    for (int32_t b = 0; b < num_batches; ++b) {
+        const int32_t batch_start = tg.range_start + b * GS_WAVE;
+        // ---- cull + compact the prefetched splats into LDS
+        SplatRaw s = nxt;
+        float hx, hy;
+        const bool have = (int32_t)(b * GS_WAVE + lane) < n;
+        const bool live = have && splat_extent(s, hx, hy) && (s.mx + hx >= rect.x0) && (s.mx - hx <= rect.x1) &&
+                          (s.my + hy >= rect.y0) && (s.my - hy <= rect.y1);
+        const unsigned long long lm = __ballot(live);
+        const int count = __popcll(lm);
+        if (live) {
+            const int slot = __popcll(lm & lt_mask);
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+            if (COLOR_LDS) {
+                c0 = ncol[0];
+                if (CDIM > 1) c1 = ncol[CDIM > 1 ? 1 : 0];
+                if (CDIM > 2) c2 = ncol[CDIM > 2 ? 2 : 0];
+                if (CDIM > 3) c3 = ncol[CDIM > 3 ? 3 : 0];
+            }
+            s_rec[slot * REC + 0] = make_float4(s.mx, s.my, -0.5f * LOG2E * s.ca, -LOG2E * s.cb);
+            s_rec[slot * REC + 1] = make_float4(-0.5f * LOG2E * s.cc, __log2f(s.opac), c0, c1);
+            s_rec[slot * REC + 2] = make_float4(c2, c3, __int_as_float(batch_start + (int32_t)lane), __int_as_float(s.g));
+        }
+        // ---- prefetch the next batch
+        if (b + 1 < num_batches) {
+            const int32_t li = (b + 1) * GS_WAVE + (int32_t)lane;
+            nxt = gather_splat(a, tg.range_start + li, li < n);
+            if (COLOR_LDS) {
+#pragma unroll
+                for (int k = 0; k < CDIM; ++k)
+                    ncol[k] = (li < n && (uint32_t)k < cnt) ? a.colors[(size_t)nxt.g * a.channels + ch_off + k] : 0.f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- walk the compacted records; record j+1 is read while j is evaluated
+        float4 r0 = s_rec[0], r1 = s_rec[1], r2 = s_rec[2];
+        for (int j = 0; j < count; ++j) {
+            const float4 c0 = r0, c1 = r1, c2 = r2;
+            r0 = s_rec[(j + 1) * REC + 0]; // slot `count` may be stale: never used
+            r1 = s_rec[(j + 1) * REC + 1];
+            r2 = s_rec[(j + 1) * REC + 2];
+            float col[CDIM];
+            if (COLOR_LDS) {
+                col[0] = c1.z;
+                if (CDIM > 1) col[CDIM > 1 ? 1 : 0] = c1.w;
+                if (CDIM > 2) col[CDIM > 2 ? 2 : 0] = c2.x;
+                if (CDIM > 3) col[CDIM > 3 ? 3 : 0] = c2.y;
+            } else {
+                const float *cp = a.colors + (size_t)__float_as_int(c2.w) * a.channels + ch_off;
+#pragma unroll
+                for (int k = 0; k < CDIM; ++k) col[k] = (uint32_t)k < cnt ? cp[k] : 0.f;
+            }
+            const int32_t idx = __float_as_int(c2.z);
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const float dx = c0.x - px[i], dy = c0.y - py[i];
+                const float power = dx * (c0.z * dx + c0.w * dy) + c1.x * dy * dy; // = -sigma log2(e)
+                const float alpha = fminf(0.999f, __builtin_amdgcn_exp2f(power + c1.y));
+                bool valid = !done[i] && !(power > 0.f) && (alpha >= ALPHA_MIN);
+                const float next_T = T[i] - T[i] * alpha;
+                const bool stop = valid && next_T <= 1e-4f;
+                done[i] = done[i] || stop;
+                valid = valid && !stop;
+                const float vis = valid ? alpha * T[i] : 0.f;
+#pragma unroll
+                for (int k = 0; k < CDIM; ++k) out[i][k] += col[k] * vis;
+                T[i] = valid ? next_T : T[i];
+                cur[i] = valid ? idx : cur[i];
+            }
+        }
+        // ---- early exit when every pixel of the wave is finished
+        bool all_done = true;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) all_done = all_done && done[i];
+        if (__all(all_done)) break;
+        __builtin_amdgcn_wave_barrier();
+    }
+
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        if (!inside[i]) continue;
+        a.render_alphas[pix[i]] = 1.f - T[i];
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k)
+            if ((uint32_t)k < cnt)
+                a.render_colors[pix[i] * a.channels + ch_off + k] = bg ? out[i][k] + T[i] * bg[k] : out[i][k];
+        a.last_ids[pix[i]] = cur[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward
+//   CMODE: 0 = colours in the LDS record (CDIM <= 4, v_out in registers)
+//          1 = colours from global, v_out in registers (CDIM <= 32)
+//          2 = any channel count: colours and v_out from global per splat (CDIM unused)
+// record: R0, R1 as forward; R2 = (col2, col3, idx, g); R3 = (a, b, c, o)
+// ---------------------------------------------------------------------------
+template <int NQ, int CDIM, int CMODE, bool ABS>
+__global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, RasterGradArgs ga, const int32_t *__restrict__ order, uint32_t cnt, uint32_t ch_off, int use_v_alpha) {
+    constexpr int REC = 4;
+    constexpr int CR = (CMODE == 2) ? 1 : CDIM; // registers for v_out / colour sums
+    __shared__ float4 s_rec[(GS_WAVE + 1) * REC];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    const TileGeom tg = tile_geom(a, order, blockIdx.x);
+    if (a.masks != nullptr && !a.masks[tg.lin]) return;
+    const uint32_t q_first = (NQ == 4) ? 0u : blockIdx.y;
+    const Rect rect = wave_rect<NQ>(a, tg, q_first);
+    if (rect.empty || tg.range_end <= tg.range_start) return;
+
+    bool inside[NQ];
+    float px[NQ], py[NQ], T[NQ], Tw[NQ], Bq[NQ], vc[NQ][CR];
+    int32_t bin_final[NQ];
+    size_t pixv[NQ];
+    const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels + ch_off : nullptr;
+    int32_t bin_max = -1;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const uint32_t q = q_first + i;
+        const uint32_t ox = lx + 8u * (q & 1u), oy = ly + 8u * (q >> 1);
+        const uint32_t x = tg.px0 + ox, y = tg.py0 + oy;
+        inside[i] = ox < a.tile_size && oy < a.tile_size && x < a.image_width && y < a.image_height;
+        px[i] = (float)x + 0.5f;
+        py[i] = (float)y + 0.5f;
+        const size_t pix = inside[i] ? ((size_t)tg.cam * a.image_height + y) * a.image_width + x : 0;
+        pixv[i] = pix * a.channels + ch_off;
+        const float T_final = inside[i] ? 1.f - ga.render_alphas[pix] : 1.f;
+        T[i] = T_final;
+        Bq[i] = 0.f;
+        float bg_dot = 0.f;
+        if (CMODE != 2) {
+#pragma unroll
+            for (int k = 0; k < CR; ++k) {
+                vc[i][k] = (inside[i] && (uint32_t)k < cnt) ? ga.v_render_colors[pixv[i] + k] : 0.f;
+                if (bg != nullptr && (uint32_t)k < cnt) bg_dot += bg[k] * vc[i][k];
+            }
+        } else {
+            vc[i][0] = 0.f;
+            if (bg != nullptr && inside[i])
+                for (uint32_t k = 0; k < cnt; ++k) bg_dot += bg[k] * ga.v_render_colors[pixv[i] + k];
+        }
+        const float v_a = (inside[i] && use_v_alpha) ? ga.v_render_alphas[pix] : 0.f;
+        Tw[i] = T_final * (v_a - bg_dot);
+        bin_final[i] = inside[i] ? ga.last_ids[pix] : -1; // never matches
+        bin_max = max(bin_max, bin_final[i]);
+    }
+    bin_max = wave_max_i32(bin_max);
+    if (bin_max < tg.range_start) return; // nothing was composited in this wave's pixels
+    // nothing behind bin_max contributes: start there and walk back to front
+    const int32_t first = min(tg.range_end - 1, bin_max);
+    const int32_t total = first - tg.range_start + 1;
+    const int32_t num_batches = (total + GS_WAVE - 1) / GS_WAVE;
+    if (total >= HEAVY_TILE) __builtin_amdgcn_s_setprio(2);
+
+    SplatRaw nxt = gather_splat(a, first - (int32_t)lane, first - (int32_t)lane >= tg.range_start);
+    float ncol[CMODE == 0 ? CDIM : 1];
+    if (CMODE == 0) {
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k)
+            ncol[k] = (first - (int32_t)lane >= tg.range_start && (uint32_t)k < cnt)
+                          ? a.colors[(size_t)nxt.g * a.channels + ch_off + k] : 0.f;
+    }
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    for (int32_t b = 0; b < num_batches; ++b) {
+        const int32_t batch_end = first - b * GS_WAVE; // lane l holds list index batch_end - l
+        SplatRaw s = nxt;
+        float hx, hy;
+        const int32_t my_idx = batch_end - (int32_t)lane;
+        const bool live = (my_idx >= tg.range_start) && splat_extent(s, hx, hy) && (s.mx + hx >= rect.x0) &&
+                          (s.mx - hx <= rect.x1) && (s.my + hy >= rect.y0) && (s.my - hy <= rect.y1);
+        const unsigned long long lm = __ballot(live);
+        const int count = __popcll(lm);
+        if (live) {
+            const int slot = __popcll(lm & lt_mask);
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+            if (CMODE == 0) {
+                c0 = ncol[0];
+                if (CDIM > 1) c1 = ncol[CDIM > 1 ? 1 : 0];
+                if (CDIM > 2) c2 = ncol[CDIM > 2 ? 2 : 0];
+                if (CDIM > 3) c3 = ncol[CDIM > 3 ? 3 : 0];
+            }
+            s_rec[slot * REC + 0] = make_float4(s.mx, s.my, -0.5f * LOG2E * s.ca, -LOG2E * s.cb);
+            s_rec[slot * REC + 1] = make_float4(-0.5f * LOG2E * s.cc, __log2f(s.opac), c0, c1);
+            s_rec[slot * REC + 2] = make_float4(c2, c3, __int_as_float(my_idx), __int_as_float(s.g));
+            s_rec[slot * REC + 3] = make_float4(s.ca, s.cb, s.cc, s.opac);
+        }
+        if (b + 1 < num_batches) {
+            const int32_t ni = first - (b + 1) * GS_WAVE - (int32_t)lane;
+            nxt = gather_splat(a, ni, ni >= tg.range_start);
+            if (CMODE == 0) {
+#pragma unroll
+                for (int k = 0; k < CDIM; ++k)
+                    ncol[k] = (ni >= tg.range_start && (uint32_t)k < cnt) ? a.colors[(size_t)nxt.g * a.channels + ch_off + k] : 0.f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        float4 r0 = s_rec[0], r1 = s_rec[1], r2 = s_rec[2], r3 = s_rec[3];
+        for (int j = 0; j < count; ++j) {
+            const float4 c0 = r0, c1 = r1, c2 = r2, c3 = r3;
+            r0 = s_rec[(j + 1) * REC + 0];
+            r1 = s_rec[(j + 1) * REC + 1];
+            r2 = s_rec[(j + 1) * REC + 2];
+            r3 = s_rec[(j + 1) * REC + 3];
+            const int32_t idx = __float_as_int(c2.z);
+            const int32_t g = __float_as_int(c2.w);
+            const float *cp = a.colors + (size_t)g * a.channels + ch_off; // wave-uniform
+            float col[CR];
+            if (CMODE == 0) {
+                col[0] = c1.z;
+                if (CDIM > 1) col[CDIM > 1 ? 1 : 0] = c1.w;
+                if (CDIM > 2) col[CDIM > 2 ? 2 : 0] = c2.x;
+                if (CDIM > 3) col[CDIM > 3 ? 3 : 0] = c2.y;
+            } else if (CMODE == 1) {
+#pragma unroll
+                for (int k = 0; k < CR; ++k) col[k] = (uint32_t)k < cnt ? cp[k] : 0.f;
+            }
+            float S0 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Ax = 0.f, Ay = 0.f;
+            float Cs[CR];
+#pragma unroll
+            for (int k = 0; k < CR; ++k) Cs[k] = 0.f;
+            float facs[NQ];
+            bool any_valid = false;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const float dx = c0.x - px[i], dy = c0.y - py[i];
+                const float power = dx * (c0.z * dx + c0.w * dy) + c1.x * dy * dy;
+                const float araw = __builtin_amdgcn_exp2f(power + c1.y); // = o exp(-sigma)
+                const float alpha = fminf(0.999f, araw);
+                const bool valid = (idx <= bin_final[i]) && !(power > 0.f) && (alpha >= ALPHA_MIN);
+                any_valid |= valid;
+                const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+                const float Tn = T[i] * ra;
+                const float facv = valid ? alpha * Tn : 0.f;
+                float D = 0.f;
+                if (CMODE == 2) {
+                    if (valid)
+                        for (uint32_t k = 0; k < cnt; ++k) D += cp[k] * ga.v_render_colors[pixv[i] + k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CR; ++k) {
+                        D += col[k] * vc[i][k];
+                        Cs[k] += facv * vc[i][k];
+                    }
+                }
+                facs[i] = facv;
+                const float v_alpha = D * Tn + (Tw[i] - Bq[i]) * ra;
+                // gradient gate: nothing for conic / xy / opacity when o * vis > 0.999
+                const float v_sigma = (valid && araw <= 0.999f) ? -araw * v_alpha : 0.f;
+                Bq[i] += facv * D;
+                T[i] = valid ? Tn : T[i];
+                const float sdx = v_sigma * dx, sdy = v_sigma * dy;
+                S0 += v_sigma;
+                Sx += sdx;
+                Sy += sdy;
+                Sxx += sdx * dx;
+                Sxy += sdx * dy;
+                Syy += sdy * dy;
+                if (ABS) {
+                    Ax += fabsf(c3.x * sdx + c3.y * sdy);
+                    Ay += fabsf(c3.y * sdx + c3.z * sdy);
+                }
+            }
+            if (!__any(any_valid)) continue;
+            float *vcol = ga.v_colors + (size_t)g * a.channels + ch_off;
+            if (CMODE == 2) {
+                // any channel count: one reduction + atomic per channel
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    float c = 0.f;
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) c += facs[i] * (inside[i] ? ga.v_render_colors[pixv[i] + k] : 0.f);
+                    c = wave_reduce_sum_dpp(c);
+                    if (lane == GS_WAVE - 1) unsafeAtomicAdd(vcol + k, c);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CR; ++k) Cs[k] = wave_reduce_sum_dpp(Cs[k]);
+            }
+            S0 = wave_reduce_sum_dpp(S0);
+            Sx = wave_reduce_sum_dpp(Sx);
+            Sy = wave_reduce_sum_dpp(Sy);
+            Sxx = wave_reduce_sum_dpp(Sxx);
+            Sxy = wave_reduce_sum_dpp(Sxy);
+            Syy = wave_reduce_sum_dpp(Syy);
+            if (ABS) {
+                Ax = wave_reduce_sum_dpp(Ax);
+                Ay = wave_reduce_sum_dpp(Ay);
+            }
+            if (lane == GS_WAVE - 1) {
+                if (CMODE != 2) {
+#pragma unroll
+                    for (int k = 0; k < CR; ++k)
+                        if ((uint32_t)k < cnt) unsafeAtomicAdd(vcol + k, Cs[k]);
+                }
+                unsafeAtomicAdd(ga.v_means2d + 2 * (size_t)g, c3.x * Sx + c3.y * Sy);
+                unsafeAtomicAdd(ga.v_means2d + 2 * (size_t)g + 1, c3.y * Sx + c3.z * Sy);
+                unsafeAtomicAdd(ga.v_conics + 3 * (size_t)g, 0.5f * Sxx);
+                unsafeAtomicAdd(ga.v_conics + 3 * (size_t)g + 1, Sxy);
+                unsafeAtomicAdd(ga.v_conics + 3 * (size_t)g + 2, 0.5f * Syy);
+                unsafeAtomicAdd(ga.v_opacities + g, -S0 / c3.w);
+                if (ABS) {
+                    unsafeAtomicAdd(ga.v_means2d_abs + 2 * (size_t)g, Ax);
+                    unsafeAtomicAdd(ga.v_means2d_abs + 2 * (size_t)g + 1, Ay);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// heaviest-first tile order (approximate: 64 length classes, 4 per octave), one workgroup.
+// Only scheduling depends on it, never results.
+// ---------------------------------------------------------------------------
+GS_DEV uint32_t length_class(uint32_t len) {
+    if (len < 4) return len; // 0..3
+    uint32_t msb = 31u - (uint32_t)__clz((int)len);
+    uint32_t c = 4u * (msb - 1u) + ((len >> (msb - 2u)) & 3u); // len 4 -> 4
+    return min(c, 63u);
+}
+
+__global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t n_tiles_all, uint32_t n_isects,
+                                                          const int32_t *__restrict__ offsets,
+                                                          int32_t *__restrict__ order) {
+    __shared__ uint32_t s_cnt[64];
+    __shared__ uint32_t s_base[64];
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_tiles_all; i += blockDim.x) {
+        int32_t e = (i + 1 == n_tiles_all) ? (int32_t)n_isects : offsets[i + 1];
+        atomicAdd(&s_cnt[length_class((uint32_t)max(0, e - offsets[i]))], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int c = 63; c >= 0; --c) { // heaviest class first
+            s_base[c] = run;
+            run += s_cnt[c];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_tiles_all; i += blockDim.x) {
+        int32_t e = (i + 1 == n_tiles_all) ? (int32_t)n_isects : offsets[i + 1];
+        uint32_t pos = atomicAdd(&s_base[length_class((uint32_t)max(0, e - offsets[i]))], 1u);
+        order[pos] = (int32_t)i;
+    }
+}
+
+template <int NQ, int CDIM, bool COLOR_LDS>
+void launch_fwd(const RasterArgs &a, const int32_t *order, uint32_t cnt, uint32_t off, hipStream_t st) {
+    dim3 grid(a.C * a.tile_width * a.tile_height, NQ == 4 ? 1 : 4);
+    hipLaunchKernelGGL((raster_wave_fwd_kernel<NQ, CDIM, COLOR_LDS>), grid, dim3(GS_WAVE), 0, st, a, order, cnt, off);
+}
+
+template <int NQ, int CDIM, int CMODE>
+void launch_bwd(const RasterArgs &a, const RasterGradArgs &ga, const int32_t *order, uint32_t cnt, uint32_t off, int use_va, hipStream_t st) {
+    dim3 grid(a.C * a.tile_width * a.tile_height, NQ == 4 ? 1 : 4);
+    if (ga.v_means2d_abs != nullptr)
+        hipLaunchKernelGGL((raster_wave_bwd_kernel<NQ, CDIM, CMODE, true>), grid, dim3(GS_WAVE), 0, st, a, ga, order, cnt, off, use_va);
+    else
+        hipLaunchKernelGGL((raster_wave_bwd_kernel<NQ, CDIM, CMODE, false>), grid, dim3(GS_WAVE), 0, st, a, ga, order, cnt, off, use_va);
+}
+
+} // namespace
+
+size_t raster_wave_scratch_bytes(uint32_t n_tiles_all) { return (size_t)n_tiles_all * sizeof(int32_t); }
+
+// Build the heaviest-first order into `scratch` (when given and the tile count fits one
+// workgroup's LDS); returns the order pointer or nullptr (natural order).
+static const int32_t *build_order(const RasterArgs &a, void *scratch, size_t scratch_bytes, hipStream_t st) {
+    const uint32_t n = a.C * a.tile_width * a.tile_height;
+    const char *e = getenv("GS_RASTER_ORDER"); // measured: no effect on MI355X (all waves resident); opt-in
+    if (e == nullptr || e[0] != '1') return nullptr;
+    if (scratch == nullptr || scratch_bytes < raster_wave_scratch_bytes(n) || n < 1024) return nullptr;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, n, a.n_isects, a.tile_offsets, (int32_t *)scratch);
+    return (const int32_t *)scratch;
+}
+
+int32_t raster_wave_fwd(const RasterArgs &a, void *scratch, size_t scratch_bytes, hipStream_t st) {
+    const int32_t *order = build_order(a, scratch, scratch_bytes, st);
+    // One quadrant per wave (NQ = 1) by default: the kernel is bound by the serial walk of the
+    // longest tile list, and four quadrant waves walk it 2.6x faster than one tile wave
+    // (measured, profiles/round1_notes.md).  GS_RASTER_NQ_FWD=4 selects 4 pixels per lane.
+    const char *enq = getenv("GS_RASTER_NQ_FWD");
+    const bool nq4 = enq != nullptr && enq[0] == '4';
+    if (a.channels <= 4) {
+        switch (a.channels) {
+            case 1: if (nq4) launch_fwd<4, 1, true>(a, order, 1, 0, st); else launch_fwd<1, 1, true>(a, order, 1, 0, st); break;
+            case 2: if (nq4) launch_fwd<4, 2, true>(a, order, 2, 0, st); else launch_fwd<1, 2, true>(a, order, 2, 0, st); break;
+            case 3: if (nq4) launch_fwd<4, 3, true>(a, order, 3, 0, st); else launch_fwd<1, 3, true>(a, order, 3, 0, st); break;
+            default: if (nq4) launch_fwd<4, 4, true>(a, order, 4, 0, st); else launch_fwd<1, 4, true>(a, order, 4, 0, st); break;
+        }
+        return 0;
+    }
+    for (uint32_t off = 0; off < a.channels; off += 32) {
+        uint32_t cnt = min(32u, a.channels - off);
+        if (cnt <= 8) launch_fwd<1, 8, false>(a, order, cnt, off, st);
+        else if (cnt <= 16) launch_fwd<1, 16, false>(a, order, cnt, off, st);
+        else launch_fwd<1, 32, false>(a, order, cnt, off, st);
+    }
+    return 0;
+}
+
+int32_t raster_wave_bwd(const RasterArgs &a, const RasterGradArgs &ga, void *scratch, size_t scratch_bytes, hipStream_t st) {
+    const int32_t *order = build_order(a, scratch, scratch_bytes, st);
+    const int use_va = ga.v_render_alphas != nullptr;
+    const uint32_t c = a.channels;
+    const char *enq = getenv("GS_RASTER_NQ_BWD");
+    const bool nq4 = enq != nullptr && enq[0] == '4';
+    if (c <= 4) {
+        switch (c) {
+            case 1: if (nq4) launch_bwd<4, 1, 0>(a, ga, order, 1, 0, use_va, st); else launch_bwd<1, 1, 0>(a, ga, order, 1, 0, use_va, st); break;
+            case 2: if (nq4) launch_bwd<4, 2, 0>(a, ga, order, 2, 0, use_va, st); else launch_bwd<1, 2, 0>(a, ga, order, 2, 0, use_va, st); break;
+            case 3: if (nq4) launch_bwd<4, 3, 0>(a, ga, order, 3, 0, use_va, st); else launch_bwd<1, 3, 0>(a, ga, order, 3, 0, use_va, st); break;
+            default: if (nq4) launch_bwd<4, 4, 0>(a, ga, order, 4, 0, use_va, st); else launch_bwd<1, 4, 0>(a, ga, order, 4, 0, use_va, st); break;
+        }
+    } else if (c <= 8) {
+        launch_bwd<1, 8, 1>(a, ga, order, c, 0, use_va, st);
+    } else if (c <= 16) {
+        launch_bwd<1, 16, 1>(a, ga, order, c, 0, use_va, st);
+    } else if (c <= 32) {
+        launch_bwd<1, 32, 1>(a, ga, order, c, 0, use_va, st);
+    } else {
+        launch_bwd<1, 1, 2>(a, ga, order, c, 0, use_va, st);
+    }
+    return 0;
+}

@@ -234,7 +234,10 @@ int32_t gs_isect_offset_encode(
  * channels is a runtime value (1..513); no padding is required from the caller.
  * n_elems = C*N (unpacked) or nnz (packed): size of the per-splat arrays.
  * bwd outputs are ACCUMULATED with atomics: caller zero-fills them.
+ * scratch (optional, gs_rasterize_scratch_bytes(C * tile_width * tile_height) bytes, contents
+ * need not be preserved between calls): lets the kernels walk the tiles heaviest-first.
  * ---------------------------------------------------------------------- */
+size_t gs_rasterize_scratch_bytes(uint32_t n_tiles_all);
 int32_t gs_rasterize_fwd(
     uint32_t C, uint32_t n_elems, uint32_t n_isects, uint32_t channels,
     const float *means2d, const float *conics, const float *colors,
@@ -247,6 +250,7 @@ int32_t gs_rasterize_fwd(
     float *render_colors, /* [C,H,W,channels] */
     float *render_alphas, /* [C,H,W,1] */
     int32_t *last_ids,    /* [C,H,W] */
+    void *scratch, size_t scratch_bytes,
     gs_stream_t stream);
 
 int32_t gs_rasterize_bwd(
@@ -263,6 +267,7 @@ int32_t gs_rasterize_bwd(
     float *v_conics,      /* [n_elems,3] */
     float *v_colors,      /* [n_elems,channels] */
     float *v_opacities,   /* [n_elems] */
+    void *scratch, size_t scratch_bytes,
     gs_stream_t stream);
 
 /* ------------------------------------------------------------------------

@@ -1,0 +1,352 @@
+"""GPU parity tests of the individual HIP stages against the CPU oracle and the golden
+vectors produced by the reference (tests/golden/make_golden.py).  Test recipes follow the
+reference's tests/test_basic.py (cited per test).  All calls go through the C ABI.
+
+Bars (BASELINE.json north_star): tile/bin indices bit-exact; fp32 results within 1e-4
+relative (plus an absolute floor for values near zero), tolerances written per assert.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from util import N, T, assert_close, garden, golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gs_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import gscodec_studio_amd as g
+
+    return g
+
+
+# ---------------------------------------------------------------------------
+# projection  (reference tests/test_basic.py:176-279)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("camera_model", ["pinhole", "ortho", "fisheye"])
+@pytest.mark.parametrize("calc_compensations", [False, True])
+def test_projection_vs_golden_and_oracle(ops, camera_model, calc_compensations):
+    gd = golden("projection.npz")
+    tag = f"{camera_model}_{int(calc_compensations)}"
+    W, H = int(gd["width"]), int(gd["height"])
+    means, quats, scales = T(gd["means"], True), T(gd["quats"], True), T(gd["scales"], True)
+    viewmats, Ks = T(gd["viewmats"], True), T(gd["Ks"])
+    radii, means2d, depths, conics, comps = ops.fully_fused_projection(
+        means, None, quats, scales, viewmats, Ks, W, H, calc_compensations=calc_compensations,
+        camera_model=camera_model)
+    r_ref = gd[f"{tag}_radii"]
+    r = N(radii)
+    # reference test allows +-1 on radii (fast-math); against the reference's torch path we are exact here
+    assert np.abs(r - r_ref).max() <= 1
+    assert (r == r_ref).mean() > 0.999
+    valid = (r > 0) & (r_ref > 0)
+    assert_close(N(means2d)[valid], gd[f"{tag}_means2d"][valid], 1e-4, 1e-4, "means2d")
+    assert_close(N(depths)[valid], gd[f"{tag}_depths"][valid], 1e-4, 1e-5, "depths")
+    assert_close(N(conics)[valid], gd[f"{tag}_conics"][valid], 3e-4, 1e-5, "conics")
+    if calc_compensations:
+        assert_close(N(comps)[valid], gd[f"{tag}_comp"][valid], 1e-4, 1e-3, "compensations")
+    else:
+        assert comps is None
+
+    # backward with the golden cotangents, masked by the reference's validity
+    vmask = torch.as_tensor(r_ref > 0, device=means.device)
+    loss = (means2d * T(gd["v_means2d"]) * vmask[..., None]).sum() + (depths * T(gd["v_depths"]) * vmask).sum() + \
+           (conics * T(gd["v_conics"]) * vmask[..., None]).sum()
+    if calc_compensations:
+        loss = loss + (comps * T(gd["v_comp"]) * vmask).sum()
+    g_m, g_q, g_s, g_v = torch.autograd.grad(loss, (means, quats, scales, viewmats))
+    for name, got, ref in (("v_means", g_m, gd[f"{tag}_v_means"]), ("v_quats", g_q, gd[f"{tag}_v_quats"]),
+                           ("v_scales", g_s, gd[f"{tag}_v_scales"]), ("v_viewmats", g_v, gd[f"{tag}_v_viewmats"])):
+        # fp32 chains with cancellation: compare in relative L2 (1e-3) and elementwise with a scale-aware floor
+        assert rel_l2(N(got), ref) < 2e-3, (name, rel_l2(N(got), ref))
+        assert_close(N(got), ref, 5e-3, 5e-3 * np.abs(ref).max(), name)
+
+
+def test_projection_covars_path_and_radius_clip(ops):
+    fx = garden(1500, scale_mult=3.0)
+    means, quats, scales = T(fx["means"]), T(fx["quats"]), T(fx["scales"])
+    viewmats, Ks = T(fx["viewmats"]), T(fx["Ks"])
+    W, H = fx["width"], fx["height"]
+    covars, _ = ops.quat_scale_to_covar_preci(quats, scales, compute_preci=False, triu=True)
+    covars = covars.detach().requires_grad_(True)
+    out_q = ops.fully_fused_projection(means, None, quats, scales, viewmats, Ks, W, H, radius_clip=3.0, near_plane=0.2,
+                                       far_plane=6.0)
+    out_c = ops.fully_fused_projection(means, covars, None, None, viewmats, Ks, W, H, radius_clip=3.0, near_plane=0.2,
+                                       far_plane=6.0)
+    assert (N(out_q[0]) == N(out_c[0])).mean() > 0.999
+    valid = (N(out_q[0]) > 0) & (N(out_c[0]) > 0)
+    for a, b in zip(out_q[1:4], out_c[1:4]):
+        assert_close(N(a)[valid], N(b)[valid], 1e-4, 1e-4, "quat/scale vs covars")
+    # oracle agreement incl. clip planes and radius_clip
+    o = O.projection_fwd(fx["means"], None, fx["quats"], fx["scales"], fx["viewmats"], fx["Ks"], W, H,
+                         near_plane=0.2, far_plane=6.0, radius_clip=3.0)
+    assert (N(out_q[0]) == o[0]).mean() > 0.999
+    assert ((N(out_q[0]) > 0) & (N(out_q[0]) <= 3)).sum() == 0
+    # v_covars path
+    v = torch.randn_like(out_c[3])
+    (g_c,) = torch.autograd.grad((out_c[3] * v * (out_c[0] > 0)[..., None]).sum(), covars)
+    vm2 = np.zeros(N(out_c[1]).shape, np.float32)
+    vd = np.zeros(N(out_c[2]).shape, np.float32)
+    vc = N(v) * (N(out_c[0]) > 0)[..., None]
+    o_b = O.projection_bwd(fx["means"], N(covars), None, None, fx["viewmats"], fx["Ks"], W, H, 0.3, "pinhole",
+                           N(out_c[0]), N(out_c[3]), None, vm2, vd, vc, None)
+    assert rel_l2(N(g_c), o_b[1]) < 2e-3
+
+
+def test_quat_scale_to_covar_preci(ops):
+    """reference tests/test_basic.py:52-88"""
+    fx = garden(500)
+    quats, scales = T(fx["quats"], True), T(fx["scales"] * 50 + 0.05, True)
+    for triu in (False, True):
+        covars, precis = ops.quat_scale_to_covar_preci(quats, scales, triu=triu)
+        q, s = quats.detach().cpu().double(), scales.detach().cpu().double()
+        qn = q / q.norm(dim=-1, keepdim=True)
+        w, x, y, z = qn.unbind(-1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z),
+                         1 - 2 * (x * x + z * z), 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x),
+                         1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+        M = R * s[:, None, :]
+        cov = M @ M.transpose(1, 2)
+        P = R / s[:, None, :]
+        pre = P @ P.transpose(1, 2)
+        if triu:
+            idx = ([0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2])
+            cov, pre = cov[:, idx[0], idx[1]], pre[:, idx[0], idx[1]]
+        assert_close(N(covars), cov.numpy(), 1e-4, 1e-6, "covars")
+        assert_close(N(precis), pre.numpy(), 1e-3, 1e-3, "precis")
+        vc, vp = torch.randn_like(covars), torch.randn_like(precis) * 1e-3
+        g_q, g_s = torch.autograd.grad((covars * vc).sum() + (precis * vp).sum(), (quats, scales))
+        qd, sd = q.clone().requires_grad_(True), s.clone().requires_grad_(True)
+        qn = qd / qd.norm(dim=-1, keepdim=True)
+        w, x, y, z = qn.unbind(-1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z),
+                         1 - 2 * (x * x + z * z), 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x),
+                         1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+        M = R * sd[:, None, :]
+        cov = M @ M.transpose(1, 2)
+        P = R / sd[:, None, :]
+        pre = P @ P.transpose(1, 2)
+        if triu:
+            cov, pre = cov[:, idx[0], idx[1]], pre[:, idx[0], idx[1]]
+        r_q, r_s = torch.autograd.grad((cov * vc.cpu().double()).sum() + (pre * vp.cpu().double()).sum(), (qd, sd))
+        assert rel_l2(N(g_q), r_q.numpy()) < 1e-3
+        assert rel_l2(N(g_s), r_s.numpy()) < 1e-3
+
+
+# ---------------------------------------------------------------------------
+# spherical harmonics  (reference tests/test_basic.py:579-607, tol 1e-4)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("sh_degree", [0, 1, 2, 3, 4])
+def test_sh_vs_golden(ops, sh_degree):
+    gd = golden("sh.npz")
+    coeffs, dirs = T(gd["coeffs"], True), T(gd["dirs"], True)
+    colors = ops.spherical_harmonics(sh_degree, dirs, coeffs)
+    assert_close(N(colors), gd[f"deg{sh_degree}_colors"], 1e-4, 1e-4, "colors")
+    g_c, g_d = torch.autograd.grad((colors * T(gd["v_colors"])).sum(), (coeffs, dirs), allow_unused=True)
+    assert_close(N(g_c), gd[f"deg{sh_degree}_v_coeffs"], 1e-4, 1e-4, "v_coeffs")
+    if sh_degree > 0:
+        assert_close(N(g_d), gd[f"deg{sh_degree}_v_dirs"], 1e-4, 1e-4, "v_dirs")
+
+
+@pytest.mark.parametrize("K", [16, 25, 9])
+def test_sh_masks_shared_and_partial_bands(ops, K):
+    rs = np.random.RandomState(1)
+    C, Ng, deg = 3, 777, 2
+    dirs = rs.randn(C, Ng, 3).astype(np.float32)
+    coeffs = rs.randn(Ng, K, 3).astype(np.float32)
+    masks = rs.rand(C, Ng) > 0.4
+    v = rs.randn(C, Ng, 3).astype(np.float32)
+    d_t, c_t = T(dirs, True), T(coeffs, True)
+    col = ops.spherical_harmonics_shared(deg, d_t, c_t, masks=T(masks))
+    g_c, g_d = torch.autograd.grad((col * T(v) * T(masks)[..., None]).sum(), (c_t, d_t))
+    # oracle on the materialised [C,N,K,3] form (what the reference does)
+    cexp = np.ascontiguousarray(np.broadcast_to(coeffs[None], (C, Ng, K, 3)))
+    o_col = O.sh_fwd(deg, dirs, cexp, masks)
+    o_vc, o_vd = O.sh_bwd(deg, dirs, cexp, v * masks[..., None], masks)
+    assert_close(N(col)[masks], o_col[masks], 1e-4, 1e-5, "colors (masked)")
+    assert_close(N(g_c), o_vc.sum(0), 1e-4, 1e-5, "v_coeffs summed over cameras")
+    assert_close(N(g_d), o_vd, 1e-4, 1e-5, "v_dirs")
+    # inactive bands of the gradient are exactly zero
+    assert (N(g_c)[:, (deg + 1) ** 2:] == 0).all()
+    # generic (non-shared) entry point on the expanded tensor gives the same numbers
+    c2 = T(cexp, True)
+    col2 = ops.spherical_harmonics(deg, T(dirs), c2, masks=T(masks))
+    assert_close(N(col2)[masks], N(col)[masks], 0, 0, "shared vs expanded")
+    (g_c2,) = torch.autograd.grad((col2 * T(v) * T(masks)[..., None]).sum(), (c2,))
+    assert_close(N(g_c2), o_vc, 1e-4, 1e-5, "v_coeffs per camera")
+
+
+# ---------------------------------------------------------------------------
+# tile intersection + sort + offsets: BIT EXACT  (reference tests/test_basic.py:442-472)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_isect_bit_exact_vs_reference_golden(ops, case):
+    gd = golden("isect.npz")
+    means2d, radii, depths = T(gd[f"{case}_means2d"]), T(gd[f"{case}_radii"]), T(gd[f"{case}_depths"])
+    ts, tw, th = int(gd[f"{case}_tile_size"]), int(gd[f"{case}_tile_width"]), int(gd[f"{case}_tile_height"])
+    C = means2d.shape[0]
+    tpg, ids, flat = ops.isect_tiles(means2d, radii, depths, ts, tw, th)
+    offs = ops.isect_offset_encode(ids, C, tw, th)
+    assert tpg.dtype == torch.int32 and ids.dtype == torch.int64 and flat.dtype == torch.int32 and offs.dtype == torch.int32
+    assert np.array_equal(N(tpg), gd[f"{case}_tiles_per_gauss"])
+    assert np.array_equal(N(ids), gd[f"{case}_isect_ids"])
+    assert np.array_equal(N(flat), gd[f"{case}_flatten_ids"])
+    assert np.array_equal(N(offs), gd[f"{case}_isect_offsets"])
+    if case == "a":
+        _, ids_u, flat_u = ops.isect_tiles(means2d, radii, depths, ts, tw, th, sort=False)
+        assert np.array_equal(N(ids_u), gd["a_isect_ids_unsorted"])
+        assert np.array_equal(N(flat_u), gd["a_flatten_ids_unsorted"])
+
+
+def test_isect_packed_and_empty(ops):
+    gd = golden("isect.npz")
+    m, r, d = gd["b_means2d"], gd["b_radii"], gd["b_depths"]
+    C, Ng = r.shape
+    ts, tw, th = 16, int(gd["b_tile_width"]), int(gd["b_tile_height"])
+    cam, gau = np.nonzero(r > 0)
+    tpg, ids, flat = ops.isect_tiles(T(m[cam, gau]), T(r[cam, gau]), T(d[cam, gau]), ts, tw, th, packed=True,
+                                     n_cameras=C, camera_ids=T(cam.astype(np.int64)), gaussian_ids=T(gau.astype(np.int64)))
+    o_tpg, o_ids, o_flat = O.isect_tiles(m[cam, gau], r[cam, gau], d[cam, gau], ts, tw, th, n_cameras=C,
+                                         camera_ids=cam.astype(np.int64))
+    assert np.array_equal(N(tpg), o_tpg) and np.array_equal(N(ids), o_ids) and np.array_equal(N(flat), o_flat)
+    # same ids as the unpacked run (flatten ids differ by construction)
+    assert np.array_equal(N(ids), gd["b_isect_ids"])
+    # nothing visible -> empty lists, zero offsets
+    z = torch.zeros((2, 10), dtype=torch.int32, device=T(m).device)
+    tpg, ids, flat = ops.isect_tiles(torch.zeros((2, 10, 2), device=z.device), z, torch.ones((2, 10), device=z.device), 16, 4, 4)
+    assert ids.numel() == 0 and flat.numel() == 0 and int(tpg.sum()) == 0
+    offs = ops.isect_offset_encode(ids, 2, 4, 4)
+    assert int(offs.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("n,end_bit", [(1, 40), (63, 46), (4096, 46), (4097, 33), (200_003, 46), (1_000_000, 64), (300_000, 8)])
+def test_radix_sort_stable_bit_exact(ops, n, end_bit):
+    from gscodec_studio_amd import _backend as B
+
+    rs = np.random.RandomState(n % 1000)
+    # few distinct keys -> many ties -> stability is actually exercised
+    keys = rs.randint(0, 1 << 20, size=n).astype(np.int64) << 12
+    keys |= rs.randint(0, 4, size=n).astype(np.int64) << 44
+    if end_bit == 64:
+        keys |= rs.randint(0, 2, size=n).astype(np.int64) << 63  # negative int64 keys
+    vals = np.arange(n, dtype=np.int32)
+    k_t, v_t = T(keys), T(vals)
+    ko, vo = torch.empty_like(k_t), torch.empty_like(v_t)
+    tb = B.query("gs_sort_temp_bytes", n)
+    temp = torch.empty(tb, dtype=torch.uint8, device=k_t.device)
+    B.call("gs_sort_pairs_u64_i32", n, B.ptr(k_t), B.ptr(v_t), B.ptr(ko), B.ptr(vo), 0, end_bit, B.ptr(temp), tb,
+           torch.cuda.current_stream().cuda_stream)
+    ek, ev = O.sort_pairs(keys, vals, end_bit)
+    assert np.array_equal(N(k_t), keys), "inputs must not be modified"
+    assert np.array_equal(N(ko), ek)
+    assert np.array_equal(N(vo), ev)
+    # independent check: numpy stable sort on the masked (signed when 64 bits) key
+    mk = keys if end_bit == 64 else (keys & ((1 << end_bit) - 1))
+    order = np.argsort(mk, kind="stable")
+    assert np.array_equal(N(vo), vals[order])
+
+
+def test_cumsum_matches_numpy(ops):
+    from gscodec_studio_amd import _backend as B
+
+    for n in (1, 255, 2048, 2049, 1_000_003):
+        x = np.random.RandomState(n % 97).randint(0, 50, size=n).astype(np.int32)
+        x_t = T(x)
+        out = torch.empty(n, dtype=torch.int64, device=x_t.device)
+        sb = B.query("gs_cumsum_scratch_bytes", n)
+        scratch = torch.empty(sb, dtype=torch.uint8, device=x_t.device)
+        B.call("gs_cumsum_i32", n, B.ptr(x_t), B.ptr(out), B.ptr(scratch), sb, torch.cuda.current_stream().cuda_stream)
+        assert np.array_equal(N(out), np.cumsum(x.astype(np.int64)))
+
+
+# ---------------------------------------------------------------------------
+# compositing  (reference tests/test_basic.py:475-576)
+# ---------------------------------------------------------------------------
+def _raster_case(n=3000, scale_mult=6.0, cams=2, channels=3, seed=0, opac_boost=False):
+    fx = garden(n, scale_mult=scale_mult)
+    W, H = fx["width"], fx["height"]
+    radii, means2d, depths, conics, _ = O.projection_fwd(fx["means"], None, fx["quats"], fx["scales"],
+                                                         fx["viewmats"][:cams], fx["Ks"][:cams], W, H)
+    rs = np.random.RandomState(seed)
+    C = cams
+    opac = np.broadcast_to(fx["opacities"][None], (C, n)).copy()
+    if opac_boost:
+        opac = np.clip(opac * 3.0, 0, 1).astype(np.float32)  # saturate pixels -> early termination + alpha clamp
+    colors = rs.rand(C, n, channels).astype(np.float32)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    tpg, ids, flat = O.isect_tiles(means2d, radii, depths, 16, tw, th)
+    offs = O.isect_offset_encode(ids, C, tw, th)
+    return dict(means2d=means2d, conics=conics, colors=colors, opacities=opac, W=W, H=H, offs=offs, flat=flat, C=C)
+
+
+@pytest.mark.parametrize("channels", [3, 1, 4, 7, 32, 40])
+@pytest.mark.parametrize("impl", ["default", "ref"])
+def test_rasterize_fwd_bwd_vs_oracle(ops, channels, impl, monkeypatch):
+    if impl == "ref":
+        if channels > 32:
+            pytest.skip("the baseline kernels chunk > 32 channels (absgrad then differs by construction)")
+        monkeypatch.setenv("GS_RASTER_IMPL", "ref")
+    else:
+        monkeypatch.delenv("GS_RASTER_IMPL", raising=False)
+    c = _raster_case(n=2500 if channels > 8 else 4000, channels=channels, opac_boost=(channels == 3))
+    rs = np.random.RandomState(5)
+    bg = rs.rand(c["C"], channels).astype(np.float32)
+    o_rc, o_ra, o_li, bl = O.rasterize_fwd(c["means2d"], c["conics"], c["colors"], c["opacities"], c["W"], c["H"], 16,
+                                           c["offs"], c["flat"], backgrounds=bg, return_borderline=True)
+    m2, cn, col, op = T(c["means2d"], True), T(c["conics"], True), T(c["colors"], True), T(c["opacities"], True)
+    bg_t = T(bg, True)
+    rc, ra = ops.rasterize_to_pixels(m2, cn, col, op, c["W"], c["H"], 16, T(c["offs"]), T(c["flat"]), backgrounds=bg_t,
+                                     absgrad=True)
+    ok = bl == 0  # pixels whose threshold decisions are not within a few ulp of flipping
+    assert ok.mean() > 0.995
+    assert_close(N(rc)[ok], o_rc[ok], 1e-4, 2e-5, "render_colors", max_bad_frac=2e-5)
+    assert_close(N(ra)[ok], o_ra[ok], 1e-4, 2e-5, "render_alphas", max_bad_frac=2e-5)
+
+    v_rc = rs.randn(*o_rc.shape).astype(np.float32) * ok[..., None]
+    v_ra = rs.randn(*o_ra.shape).astype(np.float32) * ok[..., None]
+    loss = (rc * T(v_rc)).sum() + (ra * T(v_ra)).sum()
+    g_m2, g_cn, g_col, g_op, g_bg = torch.autograd.grad(loss, (m2, cn, col, op, bg_t))
+    # oracle backward from the oracle's own forward state
+    o = O.rasterize_bwd(c["means2d"], c["conics"], c["colors"], c["opacities"], c["W"], c["H"], 16, c["offs"],
+                        c["flat"], o_ra, o_li, v_rc, v_ra, backgrounds=bg, absgrad=True)
+    for name, got, ref in (("v_means2d", g_m2, o[0]), ("v_conics", g_cn, o[1]), ("v_colors", g_col, o[2]),
+                           ("v_opacities", g_op, o[3]), ("absgrad", m2.absgrad, o[4])):
+        assert rel_l2(N(got), ref) < 2e-4, (name, rel_l2(N(got), ref))
+        assert_close(N(got), ref, 1e-3, 1e-4 * np.abs(ref).max(), name, max_bad_frac=1e-4)
+    o_vbg = (v_rc * (1.0 - o_ra)).sum(axis=(1, 2))
+    assert_close(N(g_bg), o_vbg, 1e-3, 1e-3, "v_backgrounds")
+
+
+def test_rasterize_masks_tilesize_and_last_ids(ops):
+    c = _raster_case(n=2000, cams=1, channels=3)
+    th, tw = c["offs"].shape[1:]
+    rs = np.random.RandomState(2)
+    masks = rs.rand(1, th, tw) > 0.3
+    o_rc, o_ra, o_li = O.rasterize_fwd(c["means2d"], c["conics"], c["colors"], c["opacities"], c["W"], c["H"], 16,
+                                       c["offs"], c["flat"], masks=masks)
+    rc, ra = ops.rasterize_to_pixels(T(c["means2d"]), T(c["conics"]), T(c["colors"]), T(c["opacities"]), c["W"], c["H"],
+                                     16, T(c["offs"]), T(c["flat"]), masks=T(masks))
+    pm = np.repeat(np.repeat(masks, 16, 1), 16, 2)[:, :c["H"], :c["W"]]
+    assert_close(N(rc)[pm], o_rc[pm], 1e-4, 2e-5, "masked render (kept tiles)", max_bad_frac=1e-4)
+    assert (N(rc)[~pm] == 0).all()
+    # small tiles
+    fx = garden(1500, scale_mult=6.0)
+    W, H = 160, 100
+    Ks = fx["Ks"][:1].copy()
+    Ks[:, 0] *= W / fx["width"]
+    Ks[:, 1] *= H / fx["height"]
+    radii, means2d, depths, conics, _ = O.projection_fwd(fx["means"], None, fx["quats"], fx["scales"], fx["viewmats"][:1], Ks, W, H)
+    for ts in (4, 8, 13):
+        tw, th = math.ceil(W / ts), math.ceil(H / ts)
+        tpg, ids, flat = O.isect_tiles(means2d, radii, depths, ts, tw, th)
+        offs = O.isect_offset_encode(ids, 1, tw, th)
+        cols = rs.rand(1, 1500, 3).astype(np.float32)
+        op = fx["opacities"][None].copy()
+        o_rc, o_ra, o_li, bl = O.rasterize_fwd(means2d, conics, cols, op, W, H, ts, offs, flat, return_borderline=True)
+        rc, ra = ops.rasterize_to_pixels(T(means2d), T(conics), T(cols), T(op), W, H, ts, T(offs), T(flat))
+        assert_close(N(rc)[bl == 0], o_rc[bl == 0], 1e-4, 2e-5, f"tile {ts}", max_bad_frac=1e-4)

@@ -1,0 +1,113 @@
+"""GPU parity of the quantize/dequantize STE kernels: BIT EXACT against the golden vectors
+produced by the reference's gsplat/compression_simulation/ops.py (CPU) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from util import N, T, golden
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gs_oracle as O  # noqa: E402
+
+BOUNDS = ["scales", "quats", "opacities", "sh0", "stg_opacities", "stg_colors", "features"]
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("name", BOUNDS)
+@pytest.mark.parametrize("bits", [8, 4])
+def test_round_ste_bit_exact(name, bits):
+    from gscodec_studio_amd.compression_simulation import STE, fake_quantize_ste
+
+    gd = golden("quantize.npz")
+    lo, hi = gd[f"{name}_bounds"]
+    lo, hi = (int(lo) if float(lo).is_integer() else float(lo)), (int(hi) if float(hi).is_integer() else float(hi))
+    param = torch.nn.Parameter(T(gd[f"{name}_x"]))
+    out = fake_quantize_ste(param, lo, hi, bits, "round")
+    assert bits_equal(N(out["output_value"]), gd[f"{name}_round{bits}_out"])
+    # the parameter itself was clamped in place (reference ops.py:63)
+    assert bits_equal(N(param), gd[f"{name}_round{bits}_x_after"])
+    assert out["q_step"] == (hi - lo) / (2**bits - 1)
+    # identity gradient everywhere, including clamped elements
+    v = torch.randn_like(param)
+    (g,) = torch.autograd.grad((out["output_value"] * v).sum(), param)
+    assert torch.equal(g, v)
+
+
+@pytest.mark.parametrize("name", BOUNDS)
+@pytest.mark.parametrize("bits", [8, 4])
+def test_noise_kernels_bit_exact(name, bits):
+    from gscodec_studio_amd import _backend as B
+
+    gd = golden("quantize.npz")
+    lo, hi = (float(v) for v in gd[f"{name}_bounds"])
+    x, noise = T(gd[f"{name}_x"]), T(gd[f"{name}_noise{bits}_noise"])
+    q_step = float(gd[f"{name}_noise{bits}_q_step"])
+    out = torch.empty_like(x)
+    st = torch.cuda.current_stream().cuda_stream
+    B.call("gs_quantize_noise_fwd", x.numel(), B.ptr(x), B.ptr(noise), O.f32(lo), O.f32(hi), O.f32(q_step), B.ptr(out), st)
+    assert bits_equal(N(out), gd[f"{name}_noise{bits}_out"])
+    v_out = T(gd[f"{name}_noise{bits}_v_out"])
+    v_x = torch.empty_like(x)
+    B.call("gs_quantize_noise_bwd", x.numel(), B.ptr(x), B.ptr(v_out), O.f32(lo), O.f32(hi), B.ptr(v_x), st)
+    assert bits_equal(N(v_x), gd[f"{name}_noise{bits}_v_x"])
+
+
+def test_noise_autograd_and_rng_stream():
+    """fake_quantize_ste("noise") consumes the device generator exactly like the reference's
+    torch.empty_like(x).uniform_(-0.5, 0.5) and masks gradients outside [lo, hi]."""
+    from gscodec_studio_amd.compression_simulation import fake_quantize_ste
+
+    x = (torch.rand(100_003, device="cuda:0") * 4 - 2).requires_grad_(True)
+    torch.manual_seed(99)
+    out = fake_quantize_ste(x, -1, 1, 8)  # default q_type == "noise"
+    torch.manual_seed(99)
+    noise = torch.empty_like(x).uniform_(-0.5, 0.5)
+    q = 2 / 255
+    expect = O.quant_noise_fwd(N(x), N(noise), -1, 1, q)
+    assert bits_equal(N(out["output_value"]), expect)
+    (g,) = torch.autograd.grad(out["output_value"].sum(), x)
+    assert torch.equal(g, ((x >= -1) & (x <= 1)).float())
+    with pytest.raises(UnboundLocalError):
+        fake_quantize_ste(x, -1, 1, 8, "vq")
+
+
+def test_compression_simulation_hooks():
+    from gscodec_studio_amd.compression_simulation import CompressionSimulation, STGCompressionSimulation
+
+    n = 5000
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    splats = {
+        "means": torch.randn(n, 3, device="cuda:0", generator=g), "scales": torch.randn(n, 3, device="cuda:0", generator=g) * 3 - 4,
+        "quats": torch.randn(n, 4, device="cuda:0", generator=g), "opacities": torch.randn(n, device="cuda:0", generator=g) * 5,
+        "sh0": torch.randn(n, 1, 3, device="cuda:0", generator=g), "shN": torch.randn(n, 15, 3, device="cuda:0", generator=g),
+    }
+    splats = {k: torch.nn.Parameter(v) for k, v in splats.items()}
+    before = {k: v.detach().clone() for k, v in splats.items()}
+    sim = CompressionSimulation(entropy_model_enable=False, entropy_steps={k: -1 for k in splats})
+    new, bits = sim.simulate_compression(splats, step=100)
+    assert set(new) == set(splats) and all(v is None for v in bits.values())
+    assert torch.equal(new["means"], before["means"]) and new["means"] is not splats["means"]
+    assert new["shN"] is splats["shN"]
+    for k, (lo, hi) in dict(scales=(-10, 2), quats=(-1, 1), opacities=(-15, 15), sh0=(-2, 4)).items():
+        q = (hi - lo) / 255
+        err = (new[k] - before[k].clamp(lo, hi)).abs().max()
+        assert float(err) <= q / 2 * 1.0001, k  # uniform noise of +- q/2 around the clamped value
+        assert torch.equal(splats[k].detach(), before[k])  # noise mode leaves the parameter alone
+    # dynamic variant, round mode: parameters ARE clamped in place
+    names = ("means", "scales", "quats", "opacities", "trbf_center", "trbf_scale", "motion", "omega", "colors",
+             "features_dir", "features_time")
+    dims = (3, 3, 4, 1, 1, 1, 9, 4, 3, 3, 3)
+    dyn = {k: torch.nn.Parameter(torch.randn(n, d, device="cuda:0", generator=g) * 6) for k, d in zip(names, dims)}
+    sim2 = STGCompressionSimulation(quantization_sim_type="round", entropy_steps={})
+    new2, _ = sim2.simulate_compression(dyn, step=0)
+    for k, (lo, hi) in dict(scales=(-10, 2), quats=(-1, 1), opacities=(-7, 7), colors=(-7.5, 7.5),
+                            features_dir=(-10, 10), features_time=(-10, 10)).items():
+        assert float(dyn[k].min()) >= lo and float(dyn[k].max()) <= hi
+        lv = (new2[k] - lo) / ((hi - lo) / 255)
+        assert float((lv - lv.round()).abs().max()) < 1e-3
+    with pytest.raises(NotImplementedError):
+        CompressionSimulation(entropy_model_enable=True, entropy_steps={})

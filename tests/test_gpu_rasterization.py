@@ -1,0 +1,198 @@
+"""End-to-end GPU parity of rasterization() against the CPU oracle (the reference's
+tests/test_rasterization.py:17-89 compares rasterization() with its torch twin the same way),
+plus size-independent properties at BASELINE config-2 size."""
+import numpy as np
+import pytest
+import torch
+
+from util import N, T, assert_close, garden, garden_sh, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gs_oracle as O  # noqa: E402
+
+
+def _inputs(n=3000, scale_mult=5.0, cams=2, sh_degree=3):
+    fx = garden(n, scale_mult=scale_mult)
+    d = dict(means=fx["means"], quats=fx["quats"], scales=fx["scales"], opacities=fx["opacities"],
+             viewmats=fx["viewmats"][:cams], Ks=fx["Ks"][:cams], W=fx["width"], H=fx["height"])
+    d["colors"] = garden_sh(fx["rgb"], K=16) if sh_degree is not None else fx["rgb"]
+    return d
+
+
+@pytest.mark.parametrize("sh_degree", [None, 3])
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("render_mode", ["RGB", "RGB+D", "D", "RGB+ED"])
+def test_rasterization_vs_oracle(sh_degree, packed, render_mode):
+    from gscodec_studio_amd import rasterization
+
+    d = _inputs(sh_degree=sh_degree)
+    rc, ra, meta = rasterization(T(d["means"]), T(d["quats"]), T(d["scales"]), T(d["opacities"]), T(d["colors"]),
+                                 T(d["viewmats"]), T(d["Ks"]), d["W"], d["H"], sh_degree=sh_degree, packed=packed,
+                                 render_mode=render_mode)
+    o_rc, o_ra, om = O.rasterization(d["means"], d["quats"], d["scales"], d["opacities"], d["colors"], d["viewmats"],
+                                     d["Ks"], d["W"], d["H"], sh_degree=sh_degree)
+    C = d["viewmats"].shape[0]
+    assert rc.shape[:3] == (C, d["H"], d["W"]) and ra.shape == (C, d["H"], d["W"], 1)
+    for k in ("camera_ids", "gaussian_ids", "radii", "means2d", "depths", "conics", "opacities", "tile_width",
+              "tile_height", "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets", "width", "height",
+              "tile_size", "n_cameras"):
+        assert k in meta, k
+    if not packed:
+        assert meta["camera_ids"] is None and meta["gaussian_ids"] is None
+        # integer meta: exact where the projection agrees (it does on >99.9% of splats)
+        same = N(meta["radii"]) == om["radii"]
+        assert same.mean() > 0.999
+    else:
+        assert meta["camera_ids"].dtype == torch.int64 and meta["gaussian_ids"].dtype == torch.int64
+    # depth channel of the oracle (channel = camera-space z of each splat)
+    if render_mode != "RGB":
+        cols = om["colors"]
+        dep = om["depths"][..., None]
+        cols = dep if render_mode == "D" else np.concatenate([cols, dep], -1)
+        o_rc, o_ra, _ = O.rasterize_fwd(om["means2d"], om["conics"], cols, om["opacities"], d["W"], d["H"], 16,
+                                        om["isect_offsets"], om["flatten_ids"])
+        if render_mode == "RGB+ED":
+            o_rc = np.concatenate([o_rc[..., :-1], o_rc[..., -1:] / np.clip(o_ra, 1e-10, None)], -1)
+    assert_close(N(ra), o_ra, 1e-4, 5e-5, "alphas", max_bad_frac=2e-4)
+    assert_close(N(rc), o_rc, 1e-4, 5e-5, "colors", max_bad_frac=2e-4)
+
+
+def test_rasterization_backward_vs_oracle_chain():
+    """Full chain gradient (quantizer-free): d(sum of weighted render)/d(params) on the GPU vs the
+    oracle stage VJPs chained by hand."""
+    from gscodec_studio_amd import rasterization
+
+    d = _inputs(n=2500, cams=2, sh_degree=3)
+    P = {k: T(d[k], True) for k in ("means", "quats", "scales", "opacities", "colors")}
+    rc, ra, meta = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], T(d["viewmats"]),
+                                 T(d["Ks"]), d["W"], d["H"], sh_degree=3, packed=False, absgrad=True)
+    meta["means2d"].retain_grad()  # DefaultStrategy contract (reference strategy/default.py:150)
+    rs = np.random.RandomState(11)
+    o_rc, o_ra, om = O.rasterization(d["means"], d["quats"], d["scales"], d["opacities"], d["colors"], d["viewmats"],
+                                     d["Ks"], d["W"], d["H"], sh_degree=3)
+    _, _, _, bl = O.rasterize_fwd(om["means2d"], om["conics"], om["colors"], om["opacities"], d["W"], d["H"], 16,
+                                  om["isect_offsets"], om["flatten_ids"], return_borderline=True)
+    v_rc = rs.randn(*o_rc.shape).astype(np.float32) * (bl == 0)[..., None]
+    v_ra = rs.randn(*o_ra.shape).astype(np.float32) * (bl == 0)[..., None]
+    ((rc * T(v_rc)).sum() + (ra * T(v_ra)).sum()).backward()
+    assert meta["means2d"].grad is not None and meta["means2d"].absgrad is not None
+
+    # oracle chain
+    C, Ng = om["radii"].shape
+    v_m2, v_cn, v_col, v_op, _ = O.rasterize_bwd(om["means2d"], om["conics"], om["colors"], om["opacities"], d["W"],
+                                                 d["H"], 16, om["isect_offsets"], om["flatten_ids"], o_ra,
+                                                 om["last_ids"], v_rc, v_ra)
+    assert rel_l2(N(meta["means2d"].grad), v_m2) < 5e-4
+    c2w = np.linalg.inv(d["viewmats"].astype(np.float64)).astype(np.float32)
+    dirs = d["means"][None] - c2w[:, None, :3, 3]
+    sh_raw = O.sh_fwd(3, dirs, np.ascontiguousarray(np.broadcast_to(d["colors"][None], (C,) + d["colors"].shape)), om["radii"] > 0)
+    v_sh_out = v_col * ((sh_raw + 0.5) > 0)  # clamp_min(x + 0.5, 0)
+    v_coeffs, v_dirs = O.sh_bwd(3, dirs, np.ascontiguousarray(np.broadcast_to(d["colors"][None], (C,) + d["colors"].shape)),
+                                v_sh_out, om["radii"] > 0)
+    vm, _, vq, vs, _ = O.projection_bwd(d["means"], None, d["quats"], d["scales"], d["viewmats"], d["Ks"], d["W"], d["H"],
+                                        0.3, "pinhole", om["radii"], om["conics"], None, v_m2,
+                                        np.zeros_like(om["depths"]), v_cn, None, need_viewmats=False)
+    vm = vm + v_dirs.sum(0)
+    for name, ref in (("means", vm), ("quats", vq), ("scales", vs), ("opacities", v_op.sum(0)), ("colors", v_coeffs.sum(0))):
+        got = N(P[name].grad)
+        assert rel_l2(got, ref) < 2e-3, (name, rel_l2(got, ref))
+
+
+def test_rasterization_antialiased_fisheye_covars_backgrounds():
+    from gscodec_studio_amd import rasterization
+
+    d = _inputs(n=2000, cams=1, sh_degree=None)
+    bg = np.array([[0.2, 0.5, 0.9]], np.float32)
+    rc, ra, meta = rasterization(T(d["means"]), T(d["quats"]), T(d["scales"]), T(d["opacities"]), T(d["colors"]),
+                                 T(d["viewmats"]), T(d["Ks"]), d["W"], d["H"], packed=False, backgrounds=T(bg),
+                                 rasterize_mode="antialiased", camera_model="fisheye")
+    o_rc, o_ra, om = O.rasterization(d["means"], d["quats"], d["scales"], d["opacities"], d["colors"], d["viewmats"],
+                                     d["Ks"], d["W"], d["H"], backgrounds=bg, camera_model="fisheye", antialiased=True)
+    assert_close(N(rc), o_rc, 1e-4, 5e-5, "fisheye/antialiased colors", max_bad_frac=5e-4)
+    assert_close(N(meta["opacities"]), om["opacities"] * (om["radii"] > 0), 1e-3, 1e-3, "compensated opacities")
+    # covars instead of quats/scales
+    from gscodec_studio_amd import quat_scale_to_covar_preci
+
+    cov, _ = quat_scale_to_covar_preci(T(d["quats"]), T(d["scales"]), compute_preci=False)
+    rc2, _, _ = rasterization(T(d["means"]), None, None, T(d["opacities"]), T(d["colors"]), T(d["viewmats"]), T(d["Ks"]),
+                              d["W"], d["H"], packed=False, covars=cov)
+    rc3, _, _ = rasterization(T(d["means"]), T(d["quats"]), T(d["scales"]), T(d["opacities"]), T(d["colors"]),
+                              T(d["viewmats"]), T(d["Ks"]), d["W"], d["H"], packed=False)
+    assert_close(N(rc2), N(rc3), 1e-3, 1e-4, "covars path", max_bad_frac=1e-3)
+
+
+def test_packed_equals_unpacked_and_sparse_grad():
+    """reference tests/test_basic.py:282-439"""
+    from gscodec_studio_amd import fully_fused_projection
+
+    fx = garden(3000, scale_mult=4.0)
+    args = (T(fx["viewmats"]), T(fx["Ks"]), fx["width"], fx["height"])
+    m, q, s = T(fx["means"], True), T(fx["quats"], True), T(fx["scales"], True)
+    radii, means2d, depths, conics, _ = fully_fused_projection(m, None, q, s, *args, packed=False)
+    cam, gau, radii_p, means2d_p, depths_p, conics_p, _ = fully_fused_projection(m, None, q, s, *args, packed=True)
+    cam_n, gau_n = N(cam), N(gau)
+    # rows sorted by (camera, gaussian)
+    key = cam_n * 10**7 + gau_n
+    assert (np.diff(key) > 0).all()
+    dense_r = np.zeros(N(radii).shape, np.int32)
+    dense_r[cam_n, gau_n] = N(radii_p)
+    sel = (N(radii) > 0) & (dense_r > 0)
+    assert np.abs(dense_r - N(radii))[sel].max() <= 1  # the two radius formulas
+    assert sel.sum() > 0.98 * (N(radii) > 0).sum()
+    both = sel[cam_n, gau_n]
+    assert_close(N(means2d_p)[both], N(means2d)[cam_n, gau_n][both], 1e-4, 2e-4, "packed means2d")
+    assert_close(N(conics_p)[both], N(conics)[cam_n, gau_n][both], 3e-4, 1e-5, "packed conics")
+    v2, vd, vc = torch.randn_like(means2d_p), torch.randn_like(depths_p), torch.randn_like(conics_p)
+    loss_p = (means2d_p * v2).sum() + (depths_p * vd).sum() + (conics_p * vc).sum()
+    g_p = torch.autograd.grad(loss_p, (m, q, s), retain_graph=True)
+    V2, VD, VC = torch.zeros_like(means2d), torch.zeros_like(depths), torch.zeros_like(conics)
+    V2[cam, gau], VD[cam, gau], VC[cam, gau] = v2, vd, vc
+    keep = (radii > 0)
+    loss_u = (means2d * V2 * keep[..., None]).sum() + (depths * VD * keep).sum() + (conics * VC * keep[..., None]).sum()
+    g_u = torch.autograd.grad(loss_u, (m, q, s))
+    only_p = torch.ones(len(cam_n), dtype=torch.bool, device=cam.device)
+    only_p[torch.as_tensor(both, device=cam.device)] = False
+    if int(only_p.sum()) == 0:
+        for a, b in zip(g_p, g_u):
+            assert rel_l2(N(a), N(b)) < 1e-4
+    # sparse grads densify to the dense ones
+    out = fully_fused_projection(m, None, q, s, *args, packed=True, sparse_grad=True)
+    loss_s = (out[3] * v2).sum() + (out[4] * vd).sum() + (out[5] * vc).sum()
+    g_s = torch.autograd.grad(loss_s, (m, q, s))
+    for a, b in zip(g_s, g_p):
+        assert a.is_sparse
+        assert rel_l2(N(a.to_dense()), N(b)) < 1e-5
+
+
+def test_full_size_properties():
+    """BASELINE config 2 size (1,006,065 gaussians, SH deg 3, 1080p): size-independent checks."""
+    from gscodec_studio_amd import rasterization
+    from gscodec_studio_amd._helper import sh_workload
+
+    w = sh_workload(scene_grid=3, device="cuda:0")
+    P = {k: w[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "sh")}
+    rc, ra, meta = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["sh"], w["viewmats"], w["Ks"],
+                                 w["width"], w["height"], sh_degree=3, packed=False)
+    ids, flat, offs = meta["isect_ids"], meta["flatten_ids"], meta["isect_offsets"]
+    n_isects = ids.numel()
+    assert w["N"] == 1006065
+    # sortedness of the 64-bit keys; every flatten id refers to a visible splat; counts add up
+    assert bool((ids[1:] >= ids[:-1]).all())
+    assert int(meta["tiles_per_gauss"].sum()) == n_isects
+    assert bool((meta["radii"].flatten()[flat.long()] > 0).all())
+    # offsets: monotone, consistent with the tile id stored in the keys
+    o = offs.flatten().long()
+    assert bool((o[1:] >= o[:-1]).all()) and int(o[0]) == 0
+    tile_of = ((ids >> 32) & ((1 << 13) - 1)).long()
+    counts = torch.bincount(tile_of, minlength=o.numel())
+    assert torch.equal(torch.cat([o[1:], o.new_tensor([n_isects])]) - o, counts)
+    # image sanity: alpha in [0,1], colours finite and >= 0 (clamp_min(sh + 0.5, 0) inputs)
+    assert float(ra.min()) >= 0 and float(ra.max()) <= 1.0 and bool(torch.isfinite(rc).all()) and float(rc.min()) >= 0
+    # linearity of compositing in the colours: render(2*sh0-shifted colours) -- use the gradient instead:
+    (rc.sum()).backward()
+    for k, p in P.items():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+    # d(sum render)/d(sh0 coefficient) = SH_C0 * sum_pixels(weight) >= 0 for unclamped colours
+    vis = (meta["radii"][0] > 0)
+    assert float(P["sh"].grad[~vis].abs().max()) == 0.0  # culled splats get exactly zero gradient
