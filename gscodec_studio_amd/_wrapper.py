@@ -580,21 +580,24 @@ class _RasterizeToPixels(torch.autograd.Function):
         m8 = masks.view(torch.uint8) if masks is not None else None
         assert isect_offsets.dtype == torch.int32 and flatten_ids.dtype == torch.int32
         with _device_of(means2d):
-            sb = B.query("gs_rasterize_scratch_bytes", C * tile_height * tile_width)
+            sb = B.query("gs_rasterize_scratch_bytes", C * tile_height * tile_width, n_isects, channels)
             scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
             B.call("gs_rasterize_fwd", C, n_elems, n_isects, channels, B.ptr(means2d), B.ptr(conics), B.ptr(colors),
                    B.ptr(opacities), B.ptr(backgrounds), B.ptr(m8), width, height, tile_size, tile_width,
                    tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_colors),
                    B.ptr(render_alphas), B.ptr(last_ids), B.ptr(scratch), sb, _stream(means2d))
+        # scratch carries the forward checkpoints of the depth-segmented backward
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids,
-                              render_alphas, last_ids)
+                              render_alphas, last_ids, scratch)
+        ctx.render_colors = render_colors.detach()
         ctx.width, ctx.height, ctx.tile_size, ctx.absgrad = width, height, tile_size, absgrad
         return render_colors, render_alphas
 
     @staticmethod
     def backward(ctx, v_render_colors: Tensor, v_render_alphas: Tensor):
         (means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas,
-         last_ids) = ctx.saved_tensors
+         last_ids, scratch) = ctx.saved_tensors
+        render_colors = ctx.render_colors
         C, tile_height, tile_width = isect_offsets.shape
         channels = colors.shape[-1]
         n_elems = opacities.numel()
@@ -609,12 +612,11 @@ class _RasterizeToPixels(torch.autograd.Function):
         v_means2d_abs = torch.zeros_like(means2d) if ctx.absgrad else None
         m8 = masks.view(torch.uint8) if masks is not None else None
         with _device_of(means2d):
-            sb = B.query("gs_rasterize_scratch_bytes", C * tile_height * tile_width)
-            scratch = torch.empty(sb, dtype=torch.uint8, device=means2d.device)
+            sb = scratch.numel()
             B.call("gs_rasterize_bwd", C, n_elems, n_isects, channels, B.ptr(means2d), B.ptr(conics), B.ptr(colors),
                    B.ptr(opacities), B.ptr(backgrounds), B.ptr(m8), ctx.width, ctx.height, ctx.tile_size,
-                   tile_width, tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_alphas),
-                   B.ptr(last_ids), B.ptr(v_render_colors), B.ptr(v_render_alphas), B.ptr(v_means2d_abs),
+                   tile_width, tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_colors),
+                   B.ptr(render_alphas), B.ptr(last_ids), B.ptr(v_render_colors), B.ptr(v_render_alphas), B.ptr(v_means2d_abs),
                    B.ptr(v_means2d), B.ptr(v_conics), B.ptr(v_colors), B.ptr(v_opacities), B.ptr(scratch), sb,
                    _stream(means2d))
         if ctx.absgrad:

@@ -43,7 +43,9 @@ static int32_t check_raster_args(const RasterArgs &a) {
     return 0;
 }
 
-extern "C" size_t gs_rasterize_scratch_bytes(uint32_t n_tiles_all) { return raster_wave_scratch_bytes(n_tiles_all); }
+extern "C" size_t gs_rasterize_scratch_bytes(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels) {
+    return raster_wave_scratch_bytes(n_tiles_all, n_isects, channels);
+}
 
 extern "C" int32_t gs_rasterize_fwd(
     uint32_t C, uint32_t n_elems, uint32_t n_isects, uint32_t channels, const float *means2d,
@@ -70,8 +72,8 @@ extern "C" int32_t gs_rasterize_bwd(
     const float *conics, const float *colors, const float *opacities, const float *backgrounds,
     const uint8_t *masks, uint32_t image_width, uint32_t image_height, uint32_t tile_size,
     uint32_t tile_width, uint32_t tile_height, const int32_t *tile_offsets,
-    const int32_t *flatten_ids, const float *render_alphas, const int32_t *last_ids,
-    const float *v_render_colors, const float *v_render_alphas, float *v_means2d_abs,
+    const int32_t *flatten_ids, const float *render_colors, const float *render_alphas,
+    const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas, float *v_means2d_abs,
     float *v_means2d, float *v_conics, float *v_colors, float *v_opacities, void *scratch,
     size_t scratch_bytes, gs_stream_t stream) {
     GS_CHECK_ARG(render_alphas && last_ids && v_render_colors && tile_offsets, "null pointer");
@@ -85,7 +87,7 @@ extern "C" int32_t gs_rasterize_bwd(
                          v_means2d, v_conics, v_colors, v_opacities};
     if (int32_t rc = check_raster_args(a)) return rc;
     if (C == 0 || image_width == 0 || image_height == 0 || n_isects == 0) return 0;
-    int32_t rc = use_ref_raster() ? raster_ref_bwd(a, ga, (hipStream_t)stream) : raster_wave_bwd(a, ga, scratch, scratch_bytes, (hipStream_t)stream);
+    int32_t rc = use_ref_raster() ? raster_ref_bwd(a, ga, (hipStream_t)stream) : raster_wave_bwd(a, ga, render_colors, scratch, scratch_bytes, (hipStream_t)stream);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;

@@ -148,8 +148,10 @@ GS_DEV Rect wave_rect(const RasterArgs &a, const TileGeom &tg, uint32_t q_first)
 //   CDIM : channels of this launch; COLOR_LDS: colours travel in the LDS record (CDIM <= 4)
 // record: R0 = (mx, my, a', b')  R1 = (c', log2 o, col0, col1)  R2 = (col2, col3, idx, g)
 // ---------------------------------------------------------------------------
-template <int NQ, int CDIM, bool COLOR_LDS>
-__global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, const int32_t *__restrict__ order, uint32_t cnt, uint32_t ch_off) {
+// CKPT: write per-pixel checkpoints (T, accumulated colour) "before list entry b" for every
+// b = k * seg strictly inside the tile's range, planar: ckpt[k][c][256] with c = 0 (T), 1..CDIM.
+template <int NQ, int CDIM, bool COLOR_LDS, bool CKPT>
+__global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, const int32_t *__restrict__ order, uint32_t cnt, uint32_t ch_off, float *__restrict__ ckpt, int32_t seg) {
     constexpr int REC = 3;
     __shared__ float4 s_rec[(GS_WAVE + 1) * REC];
     const uint32_t lane = threadIdx.x;
@@ -205,6 +207,18 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
             ncol[k] = ((int32_t)lane < n && (uint32_t)k < cnt) ? a.colors[(size_t)nxt.g * a.channels + ch_off + k] : 0.f;
     }
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // next checkpoint boundary strictly inside (range_start, range_end)
+    int32_t next_b = CKPT ? (tg.range_start / seg + 1) * seg : 0x7fffffff;
+    auto store_ckpt = [&](int32_t bidx) {
+        float *base = ckpt + (size_t)(bidx / seg) * (CDIM + 1) * 256;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const uint32_t p = (q_first + i) * 64u + lane;
+            base[p] = T[i];
+#pragma unroll
+            for (int k = 0; k < CDIM; ++k) base[(k + 1) * 256 + p] = out[i][k];
+        }
+    };
 
     for (int32_t b = 0; b < num_batches; ++b) {
         const int32_t batch_start = tg.range_start + b * GS_WAVE;
@@ -260,6 +274,12 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
                 for (int k = 0; k < CDIM; ++k) col[k] = (uint32_t)k < cnt ? cp[k] : 0.f;
             }
             const int32_t idx = __float_as_int(c2.z);
+            if (CKPT) {
+                while (idx >= next_b && next_b < tg.range_end) { // wave-uniform
+                    store_ckpt(next_b);
+                    next_b += seg;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const float dx = c0.x - px[i], dy = c0.y - py[i];
@@ -285,6 +305,13 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
         __builtin_amdgcn_wave_barrier();
     }
 
+    if (CKPT && !rect.empty) {
+        // boundaries after the last live record (or after an early exit) carry the final state
+        while (next_b < tg.range_end) {
+            store_ckpt(next_b);
+            next_b += seg;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         if (!inside[i]) continue;
@@ -304,18 +331,43 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
 //          2 = any channel count: colours and v_out from global per splat (CDIM unused)
 // record: R0, R1 as forward; R2 = (col2, col3, idx, g); R3 = (a, b, c, o)
 // ---------------------------------------------------------------------------
-template <int NQ, int CDIM, int CMODE, bool ABS>
-__global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, RasterGradArgs ga, const int32_t *__restrict__ order, uint32_t cnt, uint32_t ch_off, int use_v_alpha) {
+// SEG: blockIdx.x indexes a work item (tile, k): the list entries [k*seg, (k+1)*seg) of that
+// tile.  The state at the item's far end comes from the forward's checkpoint k+1
+// (T, accumulated colour) and the final render: B = v_out . (colour_final - colour_ckpt).
+struct SegArgs {
+    const uint2 *items;      // (tile, k)
+    const uint32_t *n_items; // device counter
+    const float *ckpt;       // [k][CDIM+1][256]
+    const float *render_colors;
+    int32_t seg;
+};
+
+template <int NQ, int CDIM, int CMODE, bool ABS, bool SEG>
+__global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, RasterGradArgs ga, const int32_t *__restrict__ order, uint32_t cnt, uint32_t ch_off, int use_v_alpha, SegArgs sg) {
     constexpr int REC = 4;
     constexpr int CR = (CMODE == 2) ? 1 : CDIM; // registers for v_out / colour sums
     __shared__ float4 s_rec[(GS_WAVE + 1) * REC];
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-    const TileGeom tg = tile_geom(a, order, blockIdx.x);
+    uint32_t slot = blockIdx.x;
+    int32_t seg_k = 0;
+    if (SEG) {
+        if (blockIdx.x >= *sg.n_items) return;
+        const uint2 it = sg.items[blockIdx.x];
+        slot = it.x;
+        seg_k = (int32_t)it.y;
+    }
+    TileGeom tg = tile_geom(a, SEG ? nullptr : order, slot);
     if (a.masks != nullptr && !a.masks[tg.lin]) return;
     const uint32_t q_first = (NQ == 4) ? 0u : blockIdx.y;
     const Rect rect = wave_rect<NQ>(a, tg, q_first);
     if (rect.empty || tg.range_end <= tg.range_start) return;
+    const int32_t tile_end = tg.range_end;
+    if (SEG) {
+        tg.range_start = max(tg.range_start, seg_k * sg.seg);
+        tg.range_end = min(tg.range_end, (seg_k + 1) * sg.seg);
+    }
+    const bool from_ckpt = SEG && tg.range_end < tile_end;
 
     bool inside[NQ];
     float px[NQ], py[NQ], T[NQ], Tw[NQ], Bq[NQ], vc[NQ][CR];
@@ -352,6 +404,22 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
         Tw[i] = T_final * (v_a - bg_dot);
         bin_final[i] = inside[i] ? ga.last_ids[pix] : -1; // never matches
         bin_max = max(bin_max, bin_final[i]);
+        if (SEG && CMODE == 0) {
+            if (from_ckpt && inside[i]) {
+                const float *cb = sg.ckpt + (size_t)(seg_k + 1) * (CDIM + 1) * 256 + q * 64u + lane;
+                T[i] = cb[0];
+                float bsum = 0.f;
+#pragma unroll
+                for (int k = 0; k < CR; ++k) {
+                    if ((uint32_t)k < cnt) {
+                        float fin = sg.render_colors[pixv[i] + k];
+                        if (bg != nullptr) fin -= T_final * bg[k];
+                        bsum += vc[i][k] * (fin - cb[(k + 1) * 256]);
+                    }
+                }
+                Bq[i] = bsum;
+            }
+        }
     }
     bin_max = wave_max_i32(bin_max);
     if (bin_max < tg.range_start) return; // nothing was composited in this wave's pixels
@@ -557,37 +625,121 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t n_tiles_all, 
 }
 
 template <int NQ, int CDIM, bool COLOR_LDS>
-void launch_fwd(const RasterArgs &a, const int32_t *order, uint32_t cnt, uint32_t off, hipStream_t st) {
+void launch_fwd(const RasterArgs &a, const int32_t *order, uint32_t cnt, uint32_t off, float *ckpt, int32_t seg, hipStream_t st) {
     dim3 grid(a.C * a.tile_width * a.tile_height, NQ == 4 ? 1 : 4);
-    hipLaunchKernelGGL((raster_wave_fwd_kernel<NQ, CDIM, COLOR_LDS>), grid, dim3(GS_WAVE), 0, st, a, order, cnt, off);
+    if (ckpt != nullptr)
+        hipLaunchKernelGGL((raster_wave_fwd_kernel<NQ, CDIM, COLOR_LDS, true>), grid, dim3(GS_WAVE), 0, st, a, order, cnt, off, ckpt, seg);
+    else
+        hipLaunchKernelGGL((raster_wave_fwd_kernel<NQ, CDIM, COLOR_LDS, false>), grid, dim3(GS_WAVE), 0, st, a, order, cnt, off, ckpt, seg);
 }
 
 template <int NQ, int CDIM, int CMODE>
 void launch_bwd(const RasterArgs &a, const RasterGradArgs &ga, const int32_t *order, uint32_t cnt, uint32_t off, int use_va, hipStream_t st) {
     dim3 grid(a.C * a.tile_width * a.tile_height, NQ == 4 ? 1 : 4);
+    SegArgs sg = {nullptr, nullptr, nullptr, nullptr, 0};
     if (ga.v_means2d_abs != nullptr)
-        hipLaunchKernelGGL((raster_wave_bwd_kernel<NQ, CDIM, CMODE, true>), grid, dim3(GS_WAVE), 0, st, a, ga, order, cnt, off, use_va);
+        hipLaunchKernelGGL((raster_wave_bwd_kernel<NQ, CDIM, CMODE, true, false>), grid, dim3(GS_WAVE), 0, st, a, ga, order, cnt, off, use_va, sg);
     else
-        hipLaunchKernelGGL((raster_wave_bwd_kernel<NQ, CDIM, CMODE, false>), grid, dim3(GS_WAVE), 0, st, a, ga, order, cnt, off, use_va);
+        hipLaunchKernelGGL((raster_wave_bwd_kernel<NQ, CDIM, CMODE, false, false>), grid, dim3(GS_WAVE), 0, st, a, ga, order, cnt, off, use_va, sg);
+}
+
+// segmented launch: one wave per (tile, segment) item, 4 pixels per lane
+template <int CDIM>
+void launch_bwd_seg(const RasterArgs &a, const RasterGradArgs &ga, uint32_t max_items, int use_va, const SegArgs &sg, hipStream_t st) {
+    dim3 grid(max_items, 1);
+    if (ga.v_means2d_abs != nullptr)
+        hipLaunchKernelGGL((raster_wave_bwd_kernel<4, CDIM, 0, true, true>), grid, dim3(GS_WAVE), 0, st, a, ga, (const int32_t *)nullptr, (uint32_t)CDIM, 0u, use_va, sg);
+    else
+        hipLaunchKernelGGL((raster_wave_bwd_kernel<4, CDIM, 0, false, true>), grid, dim3(GS_WAVE), 0, st, a, ga, (const int32_t *)nullptr, (uint32_t)CDIM, 0u, use_va, sg);
+}
+
+// (tile, k) items: every global segment [k*seg, (k+1)*seg) that intersects a tile's range
+__global__ void __launch_bounds__(GS_BLOCK) seg_items_kernel(uint32_t n_tiles_all, uint32_t n_isects, const int32_t *__restrict__ offsets,
+                                                             int32_t seg, uint32_t *__restrict__ counter, uint2 *__restrict__ items) {
+    uint32_t t = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (t >= n_tiles_all) return;
+    int32_t rs = offsets[t];
+    int32_t re = (t + 1 == n_tiles_all) ? (int32_t)n_isects : offsets[t + 1];
+    if (re <= rs) return;
+    int32_t k0 = rs / seg, k1 = (re - 1) / seg;
+    uint32_t base = atomicAdd(counter, (uint32_t)(k1 - k0 + 1));
+    for (int32_t k = k0; k <= k1; ++k) items[base + (uint32_t)(k - k0)] = make_uint2(t, (uint32_t)k);
 }
 
 } // namespace
 
-size_t raster_wave_scratch_bytes(uint32_t n_tiles_all) { return (size_t)n_tiles_all * sizeof(int32_t); }
+// ---------------------------------------------------------------------------
+// host side
+// scratch layout (the SAME buffer must be handed to gs_rasterize_fwd and to the matching
+// gs_rasterize_bwd; its contents must be preserved in between):
+//   [0, 256)                      item counter (uint32) + padding
+//   [256, 256 + items)            (tile, k) work items of the segmented backward (uint2)
+//   [.., .. + order)              optional heaviest-first tile order (int32)
+//   [.., .. + ckpt)               forward checkpoints, (n_isects / seg + 2) x (channels + 1) x 256 floats
+// ---------------------------------------------------------------------------
+namespace {
 
-// Build the heaviest-first order into `scratch` (when given and the tile count fits one
-// workgroup's LDS); returns the order pointer or nullptr (natural order).
+// Segment length of the depth-segmented backward: 128 list entries (measured best on MI355X:
+// 512 -> 1.14 ms, 256 -> 0.97 ms, 128 -> 0.89 ms at config 2), doubled until the checkpoint
+// array stays below 65536 boundaries (256 MB for RGB).  GS_RASTER_SEG overrides; 0 disables.
+int32_t seg_len(uint32_t n_isects) {
+    const char *e = getenv("GS_RASTER_SEG");
+    if (e != nullptr) {
+        int v = atoi(e);
+        if (v <= 0) return 0;
+        return ((v + 63) / 64) * 64;
+    }
+    int32_t v = 128;
+    while ((uint64_t)n_isects / (uint32_t)v > 65536u) v *= 2;
+    return v;
+}
+
+struct ScratchLayout {
+    size_t off_items, off_order, off_ckpt, total;
+    uint32_t max_items;
+};
+
+ScratchLayout scratch_layout(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels) {
+    ScratchLayout L;
+    const int32_t seg = seg_len(n_isects);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t o = 256;
+    L.max_items = n_tiles_all + (seg > 0 ? n_isects / (uint32_t)seg : 0) + 1;
+    L.off_items = o;
+    o += up((size_t)L.max_items * sizeof(uint2));
+    L.off_order = o;
+    o += up((size_t)n_tiles_all * sizeof(int32_t));
+    L.off_ckpt = o;
+    if (seg > 0 && channels <= 4) o += up(((size_t)n_isects / seg + 2) * (channels + 1) * 256 * sizeof(float));
+    L.total = o;
+    return L;
+}
+
+} // namespace
+
+size_t raster_wave_scratch_bytes(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels) {
+    return scratch_layout(n_tiles_all, n_isects, channels).total;
+}
+
+// Build the heaviest-first order (opt-in); returns the order pointer or nullptr (natural order).
 static const int32_t *build_order(const RasterArgs &a, void *scratch, size_t scratch_bytes, hipStream_t st) {
     const uint32_t n = a.C * a.tile_width * a.tile_height;
     const char *e = getenv("GS_RASTER_ORDER"); // measured: no effect on MI355X (all waves resident); opt-in
     if (e == nullptr || e[0] != '1') return nullptr;
-    if (scratch == nullptr || scratch_bytes < raster_wave_scratch_bytes(n) || n < 1024) return nullptr;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, n, a.n_isects, a.tile_offsets, (int32_t *)scratch);
-    return (const int32_t *)scratch;
+    ScratchLayout L = scratch_layout(n, a.n_isects, a.channels);
+    if (scratch == nullptr || scratch_bytes < L.total || n < 1024) return nullptr;
+    int32_t *order = (int32_t *)((char *)scratch + L.off_order);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, n, a.n_isects, a.tile_offsets, order);
+    return order;
 }
 
 int32_t raster_wave_fwd(const RasterArgs &a, void *scratch, size_t scratch_bytes, hipStream_t st) {
     const int32_t *order = build_order(a, scratch, scratch_bytes, st);
+    const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;
+    const ScratchLayout L = scratch_layout(n_tiles_all, a.n_isects, a.channels);
+    const int32_t seg = seg_len(a.n_isects);
+    float *ckpt = nullptr;
+    if (seg > 0 && a.channels <= 4 && scratch != nullptr && scratch_bytes >= L.total) ckpt = (float *)((char *)scratch + L.off_ckpt);
     // One quadrant per wave (NQ = 1) by default: the kernel is bound by the serial walk of the
     // longest tile list, and four quadrant waves walk it 2.6x faster than one tile wave
     // (measured, profiles/round1_notes.md).  GS_RASTER_NQ_FWD=4 selects 4 pixels per lane.
@@ -595,26 +747,50 @@ int32_t raster_wave_fwd(const RasterArgs &a, void *scratch, size_t scratch_bytes
     const bool nq4 = enq != nullptr && enq[0] == '4';
     if (a.channels <= 4) {
         switch (a.channels) {
-            case 1: if (nq4) launch_fwd<4, 1, true>(a, order, 1, 0, st); else launch_fwd<1, 1, true>(a, order, 1, 0, st); break;
-            case 2: if (nq4) launch_fwd<4, 2, true>(a, order, 2, 0, st); else launch_fwd<1, 2, true>(a, order, 2, 0, st); break;
-            case 3: if (nq4) launch_fwd<4, 3, true>(a, order, 3, 0, st); else launch_fwd<1, 3, true>(a, order, 3, 0, st); break;
-            default: if (nq4) launch_fwd<4, 4, true>(a, order, 4, 0, st); else launch_fwd<1, 4, true>(a, order, 4, 0, st); break;
+            case 1: if (nq4) launch_fwd<4, 1, true>(a, order, 1, 0, ckpt, seg, st); else launch_fwd<1, 1, true>(a, order, 1, 0, ckpt, seg, st); break;
+            case 2: if (nq4) launch_fwd<4, 2, true>(a, order, 2, 0, ckpt, seg, st); else launch_fwd<1, 2, true>(a, order, 2, 0, ckpt, seg, st); break;
+            case 3: if (nq4) launch_fwd<4, 3, true>(a, order, 3, 0, ckpt, seg, st); else launch_fwd<1, 3, true>(a, order, 3, 0, ckpt, seg, st); break;
+            default: if (nq4) launch_fwd<4, 4, true>(a, order, 4, 0, ckpt, seg, st); else launch_fwd<1, 4, true>(a, order, 4, 0, ckpt, seg, st); break;
         }
         return 0;
     }
     for (uint32_t off = 0; off < a.channels; off += 32) {
         uint32_t cnt = min(32u, a.channels - off);
-        if (cnt <= 8) launch_fwd<1, 8, false>(a, order, cnt, off, st);
-        else if (cnt <= 16) launch_fwd<1, 16, false>(a, order, cnt, off, st);
-        else launch_fwd<1, 32, false>(a, order, cnt, off, st);
+        if (cnt <= 8) launch_fwd<1, 8, false>(a, order, cnt, off, nullptr, 0, st);
+        else if (cnt <= 16) launch_fwd<1, 16, false>(a, order, cnt, off, nullptr, 0, st);
+        else launch_fwd<1, 32, false>(a, order, cnt, off, nullptr, 0, st);
     }
     return 0;
 }
 
-int32_t raster_wave_bwd(const RasterArgs &a, const RasterGradArgs &ga, void *scratch, size_t scratch_bytes, hipStream_t st) {
-    const int32_t *order = build_order(a, scratch, scratch_bytes, st);
+int32_t raster_wave_bwd(const RasterArgs &a, const RasterGradArgs &ga, const float *render_colors, void *scratch,
+                        size_t scratch_bytes, hipStream_t st) {
     const int use_va = ga.v_render_alphas != nullptr;
     const uint32_t c = a.channels;
+    const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;
+    const ScratchLayout L = scratch_layout(n_tiles_all, a.n_isects, a.channels);
+    const int32_t seg = seg_len(a.n_isects);
+    // Depth-segmented backward: needs the forward's checkpoints (same scratch) and the render.
+    if (seg > 0 && c <= 4 && scratch != nullptr && scratch_bytes >= L.total && render_colors != nullptr) {
+        uint32_t *counter = (uint32_t *)scratch;
+        uint2 *items = (uint2 *)((char *)scratch + L.off_items);
+        hipError_t e = hipMemsetAsync(counter, 0, sizeof(uint32_t), st);
+        if (e != hipSuccess) {
+            gs_set_error("gs_rasterize_bwd: memset failed: %s", hipGetErrorString(e));
+            return 2;
+        }
+        hipLaunchKernelGGL(seg_items_kernel, dim3(gs_div_up(n_tiles_all, GS_BLOCK)), dim3(GS_BLOCK), 0, st, n_tiles_all,
+                           a.n_isects, a.tile_offsets, seg, counter, items);
+        SegArgs sg = {items, counter, (const float *)((char *)scratch + L.off_ckpt), render_colors, seg};
+        switch (c) {
+            case 1: launch_bwd_seg<1>(a, ga, L.max_items, use_va, sg, st); break;
+            case 2: launch_bwd_seg<2>(a, ga, L.max_items, use_va, sg, st); break;
+            case 3: launch_bwd_seg<3>(a, ga, L.max_items, use_va, sg, st); break;
+            default: launch_bwd_seg<4>(a, ga, L.max_items, use_va, sg, st); break;
+        }
+        return 0;
+    }
+    const int32_t *order = build_order(a, scratch, scratch_bytes, st);
     const char *enq = getenv("GS_RASTER_NQ_BWD");
     const bool nq4 = enq != nullptr && enq[0] == '4';
     if (c <= 4) {

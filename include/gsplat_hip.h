@@ -234,10 +234,14 @@ int32_t gs_isect_offset_encode(
  * channels is a runtime value (1..513); no padding is required from the caller.
  * n_elems = C*N (unpacked) or nnz (packed): size of the per-splat arrays.
  * bwd outputs are ACCUMULATED with atomics: caller zero-fills them.
- * scratch (optional, gs_rasterize_scratch_bytes(C * tile_width * tile_height) bytes, contents
- * need not be preserved between calls): lets the kernels walk the tiles heaviest-first.
+ * scratch (optional, gs_rasterize_scratch_bytes(C * tile_width * tile_height, n_isects, channels)
+ * bytes): the forward stores per-pixel checkpoints (transmittance, accumulated colour) at fixed
+ * list-index boundaries in it; when the SAME buffer (contents preserved) and the forward's
+ * render_colors are handed to gs_rasterize_bwd, the backward runs depth-segmented (one wave per
+ * (tile, segment), no serial walk of long lists).  Without them it falls back to one wave per
+ * quadrant.  Results are the same up to fp32 rounding.
  * ---------------------------------------------------------------------- */
-size_t gs_rasterize_scratch_bytes(uint32_t n_tiles_all);
+size_t gs_rasterize_scratch_bytes(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels);
 int32_t gs_rasterize_fwd(
     uint32_t C, uint32_t n_elems, uint32_t n_isects, uint32_t channels,
     const float *means2d, const float *conics, const float *colors,
@@ -260,6 +264,7 @@ int32_t gs_rasterize_bwd(
     uint32_t image_width, uint32_t image_height, uint32_t tile_size,
     uint32_t tile_width, uint32_t tile_height,
     const int32_t *tile_offsets, const int32_t *flatten_ids,
+    const float *render_colors, /* forward output, or NULL (disables the segmented path) */
     const float *render_alphas, const int32_t *last_ids,
     const float *v_render_colors, const float *v_render_alphas,
     float *v_means2d_abs, /* [n_elems,2] or NULL */
