@@ -85,8 +85,10 @@ class _AllGatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, data: Tensor) -> Tensor:
         world = dist.get_world_size()
-        out = data.new_empty((world,) + tuple(data.shape))
+        # concatenated form [world * N, ...] (accepted by both RCCL and gloo)
+        out = data.new_empty((world * data.shape[0],) + tuple(data.shape[1:]))
         dist.all_gather_into_tensor(out, data.contiguous())
+        ctx.rows = data.shape[0]
         return out
 
     @staticmethod
@@ -94,7 +96,8 @@ class _AllGatherRows(torch.autograd.Function):
         # d/d(local) = sum over ranks of their gradient for my slab
         v = v_out.contiguous().clone()
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        return v[dist.get_rank()]
+        r = dist.get_rank()
+        return v[r * ctx.rows : (r + 1) * ctx.rows]
 
 
 # ---------------------------------------------------------------------------
@@ -151,7 +154,7 @@ def all_gather_tensor_list(world_size: int, tensor_list: List[Tensor]) -> List[T
     if data.requires_grad:
         gathered = _AllGatherRows.apply(data)
     else:
-        gathered = data.new_empty((world_size,) + tuple(data.shape))
+        gathered = data.new_empty((world_size * N,) + tuple(data.shape[1:]))
         dist.all_gather_into_tensor(gathered, data.contiguous())
     gathered = gathered.reshape(world_size * N, -1)
     outs = torch.split(gathered, sizes, dim=-1)
@@ -212,8 +215,11 @@ def exchange_projected(
         cnts_t = torch.stack(cnts)
         cam_off = torch.tensor([0] + C_world[:-1], device=device, dtype=camera_ids.dtype).cumsum(0)
         camera_ids = camera_ids - cam_off.repeat_interleave(cnts_t)
-        g_off = torch.tensor([0] + N_world[:-1], device=device, dtype=gaussian_ids.dtype).cumsum(0)
-        gaussian_ids = gaussian_ids + g_off.repeat_interleave(cnts_t)
+        # NOTE (deliberate fix): the reference adds the offset of the DESTINATION
+        # rank here (rendering.py:428-436: offsets.repeat_interleave(cnts)), which makes ids of
+        # different source ranks collide; a local id becomes global by adding the offset of the
+        # rank that OWNS the gaussian, i.e. this (source) rank.
+        gaussian_ids = gaussian_ids + int(sum(N_world[:world_rank]))
         camera_ids, gaussian_ids = all_to_all_tensor_list(
             world_size, [camera_ids, gaussian_ids], cnts, output_splits=collected_splits
         )

@@ -1,0 +1,146 @@
+"""CPU, world_size 2, gloo: the multi-GPU layer (collectives of the reference's
+tests/_test_distributed.py:13-107, the gaussian-sharded exchange and the splat-gradient
+reduction of the camera-sharded data-parallel path)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn_name):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        globals()[fn_name](rank, world)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run(fn_name, world=2):
+    mp.spawn(_worker, args=(world, _free_port(), fn_name), nprocs=world, join=True)
+
+
+# --------------------------------------------------------------------------- collectives
+def _collectives(rank, world):
+    from gscodec_studio_amd import distributed as D
+
+    dev = torch.device("cpu")
+    # all_gather_int32 (reference _test_distributed.py:13-28)
+    assert D.all_gather_int32(world, rank + 10, device=dev) == [10, 11]
+    got = D.all_gather_int32(world, torch.tensor(rank + 10, dtype=torch.int32))
+    assert [int(t) for t in got] == [10, 11]
+    # all_to_all_int32 (30-47)
+    vals = [rank * 2 + 0, rank * 2 + 1]
+    assert D.all_to_all_int32(world, vals, device=dev) == [0 + rank, 2 + rank]
+    # all_gather_tensor_list (49-75), with gradients
+    a = torch.full((2, 3), float(rank), requires_grad=True)
+    b = torch.full((2,), float(rank) + 0.5)
+    ga, gb = D.all_gather_tensor_list(world, [a, b])
+    assert ga.shape == (4, 3) and gb.shape == (4,)
+    assert torch.equal(ga[:2], torch.zeros(2, 3)) and torch.equal(ga[2:], torch.ones(2, 3))
+    (ga * (rank + 1)).sum().backward()
+    assert torch.allclose(a.grad, torch.full((2, 3), 3.0))  # (1 + 2): every rank used my slab
+    # all_to_all_tensor_list (77-107): the docstring example of the reference
+    if rank == 0:
+        tl, splits = [torch.tensor([1., 2., 3.], requires_grad=True), torch.tensor([4., 5., 6.])], [2, 1]
+    else:
+        tl, splits = [torch.tensor([7., 8.], requires_grad=True), torch.tensor([9., 10.])], [1, 1]
+    x, y = D.all_to_all_tensor_list(world, tl, splits)
+    if rank == 0:
+        assert x.tolist() == [1, 2, 7] and y.tolist() == [4, 5, 9]
+    else:
+        assert x.tolist() == [3, 8] and y.tolist() == [6, 10]
+    (x * (10.0 ** rank)).sum().backward()
+    if rank == 0:
+        assert tl[0].grad.tolist() == [1, 1, 10]
+    else:
+        assert tl[0].grad.tolist() == [1, 10]
+
+
+def test_collectives_world2():
+    _run("_collectives")
+
+
+# --------------------------------------------------------------------------- gaussian-sharded exchange
+def _exchange(rank, world):
+    from gscodec_studio_amd import distributed as D
+
+    # 2 ranks, N_world = [3, 5] gaussians, 1 camera each -> C_total = 2
+    N_world, C_world = [3, 5], [1, 1]
+    N = N_world[rank]
+    C = 2
+    off = sum(N_world[:rank])
+    # value of element (c, n_global) = 100 * c + n_global  -> easy to verify after the exchange
+    base = (100 * torch.arange(C)[:, None] + (off + torch.arange(N))[None, :]).float()
+    radii = base.to(torch.int32) + 1
+    means2d = torch.stack([base, -base], -1)
+    depths, conics, opac, colors = base + 0.25, base[..., None].repeat(1, 1, 3), base + 0.5, base[..., None].repeat(1, 1, 3) * 2
+    out = D.exchange_projected(rank, world, N, N_world, C_world, False, radii, means2d, depths, conics, opac, colors, None, None)
+    C_local, r2, m2, d2, c2, o2, col2, cam, gau = out
+    assert C_local == 1 and cam is None and gau is None
+    expect = (100 * rank + torch.arange(sum(N_world))).float()[None]
+    assert torch.equal(r2, expect.to(torch.int32) + 1)
+    assert torch.equal(m2[..., 0], expect) and torch.equal(d2, expect + 0.25) and torch.equal(col2[..., 2], expect * 2)
+    # packed: rank r sees gaussians visible in both cameras, ids local -> global
+    cam_ids = torch.tensor([0, 0, 1], dtype=torch.int64)
+    gau_ids = torch.tensor([0, 2, 1], dtype=torch.int64)
+    vals = (1000 * rank + 100 * cam_ids + gau_ids).float()
+    out = D.exchange_projected(rank, world, N, N_world, C_world, True, (vals + 1).to(torch.int32), torch.stack([vals, vals], -1),
+                               vals, vals[:, None].repeat(1, 3), vals, vals[:, None].repeat(1, 3), cam_ids, gau_ids)
+    C_local, r2, m2, d2, c2, o2, col2, cam, gau = out
+    assert (cam == 0).all()  # local camera index on every rank
+    if rank == 0:   # receives camera-0 rows of rank 0 (2 rows) and of rank 1 (2 rows)
+        assert d2.tolist() == [0., 2., 1000., 1002.] and gau.tolist() == [0, 2, 3, 5]
+    else:           # camera-1 rows
+        assert d2.tolist() == [101., 1101.] and gau.tolist() == [1, 4]
+
+
+def test_gaussian_sharded_exchange_world2():
+    _run("_exchange")
+
+
+# --------------------------------------------------------------------------- gradient reduction
+def _grad_reduce(rank, world):
+    from gscodec_studio_amd import distributed as D
+
+    torch.manual_seed(0)
+    params = {"means": torch.nn.Parameter(torch.randn(7, 3)), "sh": torch.nn.Parameter(torch.randn(7, 4, 3)),
+              "frozen": torch.nn.Parameter(torch.randn(2), requires_grad=False), "nograd": torch.nn.Parameter(torch.randn(5))}
+    g = {k: torch.full_like(v, float(rank + 1)) for k, v in params.items()}
+    params["means"].grad = g["means"].clone()
+    params["sh"].grad = g["sh"].clone()
+    D.all_reduce_splat_grads(params, average=False)
+    assert torch.equal(params["means"].grad, torch.full((7, 3), 3.0))
+    assert torch.equal(params["sh"].grad, torch.full((7, 4, 3), 3.0))
+    assert torch.equal(params["nograd"].grad, torch.zeros(5))  # missing grads count as zeros on every rank
+    assert params["frozen"].grad is None
+    params["means"].grad = g["means"].clone()
+    D.all_reduce_splat_grads([params["means"]], average=True, algorithm="all_reduce")
+    assert torch.allclose(params["means"].grad, torch.full((7, 3), 1.5))
+    # camera-sharded equivalence on a toy differentiable "renderer": sum over ALL cameras of f(c, theta)
+    theta = torch.nn.Parameter(torch.arange(6, dtype=torch.float32).reshape(3, 2))
+    cams = torch.arange(1, 5, dtype=torch.float32)  # 4 cameras
+    mine = D.shard_cameras(4, rank, world)
+    loss = sum(((theta * cams[c]) ** 2).sum() for c in mine)
+    loss.backward()
+    D.all_reduce_splat_grads([theta], average=False)
+    full = torch.arange(6, dtype=torch.float32).reshape(3, 2).requires_grad_(True)
+    sum(((full * c) ** 2).sum() for c in cams).backward()
+    assert torch.allclose(theta.grad, full.grad)
+
+
+def test_splat_grad_reduction_world2():
+    _run("_grad_reduce")

@@ -1,0 +1,94 @@
+"""CPU: host-side logic that needs no kernel -- argument validation of rasterization()
+(reference rendering.py:229-277), the simulation hook tables (reference simulation.py:30-59,
+527-571), the workload generator and the camera sharding helpers."""
+import numpy as np
+import pytest
+import torch
+
+import gscodec_studio_amd as g
+
+
+def _args(N=10, C=2):
+    return dict(means=torch.randn(N, 3), quats=torch.randn(N, 4), scales=torch.rand(N, 3), opacities=torch.rand(N),
+                colors=torch.rand(N, 3), viewmats=torch.eye(4).repeat(C, 1, 1), Ks=torch.eye(3).repeat(C, 1, 1),
+                width=32, height=32)
+
+
+@pytest.mark.parametrize("mutate,exc", [
+    (lambda a: a.update(means=torch.randn(10, 2)), AssertionError),
+    (lambda a: a.update(quats=torch.randn(10, 3)), AssertionError),
+    (lambda a: a.update(opacities=torch.rand(10, 1)), AssertionError),
+    (lambda a: a.update(viewmats=torch.eye(4)), AssertionError),
+    (lambda a: a.update(Ks=torch.eye(3).repeat(3, 1, 1)), AssertionError),
+    (lambda a: a.update(colors=torch.rand(9, 3)), AssertionError),
+])
+def test_rasterization_shape_validation(mutate, exc):
+    a = _args()
+    mutate(a)
+    with pytest.raises(exc):
+        g.rasterization(**a)
+
+
+def test_rasterization_mode_validation():
+    a = _args()
+    with pytest.raises(AssertionError):
+        g.rasterization(**a, render_mode="XYZ")
+    a["colors"] = torch.rand(10, 4, 3)
+    with pytest.raises(AssertionError):  # (sh_degree + 1)^2 <= K
+        g.rasterization(**a, sh_degree=2)
+    a = _args()
+    with pytest.raises(AssertionError, match="sparse_grad"):
+        g.fully_fused_projection(a["means"], None, a["quats"], a["scales"], a["viewmats"], a["Ks"], 32, 32, packed=False, sparse_grad=True)
+    with pytest.raises(ValueError, match="Unsupported number of color channels"):
+        g.rasterize_to_pixels(torch.zeros(1, 4, 2), torch.zeros(1, 4, 3), torch.zeros(1, 4, 600), torch.zeros(1, 4), 16, 16, 16,
+                              torch.zeros(1, 1, 1, dtype=torch.int32), torch.zeros(0, dtype=torch.int32))
+    with pytest.raises(AssertionError, match="Assert Failed"):
+        g.rasterize_to_pixels(torch.zeros(1, 4, 2), torch.zeros(1, 4, 3), torch.zeros(1, 4, 3), torch.zeros(1, 4), 64, 16, 16,
+                              torch.zeros(1, 1, 1, dtype=torch.int32), torch.zeros(0, dtype=torch.int32))
+
+
+def test_simulation_tables_match_reference():
+    from gscodec_studio_amd.compression_simulation import CompressionSimulation, STGCompressionSimulation
+
+    s = CompressionSimulation(entropy_model_enable=False, entropy_steps={})
+    assert s.simulation_option == {"means": False, "scales": True, "quats": True, "opacities": True, "sh0": True, "shN": True}
+    assert s.bds["scales"] == [-10, 2] and s.bds["quats"] == [-1, 1] and s.bds["opacities"] == [-15, 15] and s.bds["sh0"] == [-2, 4]
+    assert all(s.q_bitwidth[k] == 8 for k in ("scales", "quats", "opacities", "sh0"))
+    d = STGCompressionSimulation(quantization_sim_type="round", entropy_steps={})
+    assert d.bds["opacities"] == [-7, 7] and d.bds["colors"] == [-7.5, 7.5] and d.bds["features_dir"] == [-10, 10]
+    assert [k for k, v in d.simulation_option.items() if v] == ["scales", "quats", "opacities", "colors", "features_dir", "features_time"]
+    with pytest.raises(NotImplementedError):
+        STGCompressionSimulation(quantization_sim_type="round", entropy_model_enable=True)
+    # attributes that are not simulated come back as a fresh tensor (param + 0.), simulated ones need the GPU
+    p = torch.nn.Parameter(torch.randn(5, 3))
+    new, bits = s.simulate_compression({"means": p}, step=0)
+    assert new["means"] is not p and torch.equal(new["means"], p) and bits["means"] is None
+
+
+def test_workload_generator_is_deterministic_and_sized():
+    from gscodec_studio_amd._helper import load_test_data, rescale_intrinsics, sh_workload
+
+    a = load_test_data(device="cpu", scene_grid=1)
+    b = load_test_data(device="cpu", scene_grid=1)
+    assert a[0].shape == (111785, 3)
+    for x, y in zip(a[:7], b[:7]):
+        assert torch.equal(x, y)
+    assert a[7:] == (648, 420)
+    assert float(a[2].max()) <= 0.02 and float(a[3].max()) <= 1.0
+    assert torch.allclose(a[1].norm(dim=-1), torch.ones(111785), atol=1e-5)
+    K = rescale_intrinsics(a[6], 648, 420, 1920, 1080)
+    assert torch.allclose(K[:, 0, 0], a[6][:, 0, 0] * 1920 / 648)
+    w = sh_workload(scene_grid=1, n_cameras=5, device="cpu")
+    assert w["sh"].shape == (111785, 16, 3) and w["viewmats"].shape == (5, 4, 4)
+    assert not torch.equal(w["viewmats"][3], w["viewmats"][0])  # cameras beyond the fixture's 3 are distinct
+    R = w["viewmats"][4, :3, :3]
+    assert torch.allclose(R @ R.T, torch.eye(3), atol=1e-5)
+
+
+def test_camera_sharding():
+    from gscodec_studio_amd.distributed import shard_cameras
+
+    assert shard_cameras(8, 3, 8) == [3]
+    assert shard_cameras(8, 1, 4) == [1, 5]
+    got = sorted(sum((shard_cameras(10, r, 4) for r in range(4)), []))
+    assert got == list(range(10))
