@@ -58,7 +58,7 @@ extern "C" int32_t gs_rasterize_fwd(
     GS_CHECK_ARG(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids), "null pointer");
     RasterArgs a = {C, n_elems, n_isects, channels, means2d, conics, colors, opacities, backgrounds, masks,
                     image_width, image_height, tile_size, tile_width, tile_height, tile_offsets, flatten_ids,
-                    render_colors, render_alphas, last_ids};
+                    render_colors, render_alphas, last_ids, 0u};
     if (int32_t rc = check_raster_args(a)) return rc;
     if (C == 0 || image_width == 0 || image_height == 0) return 0;
     int32_t rc = use_ref_raster() ? raster_ref_fwd(a, (hipStream_t)stream) : raster_wave_fwd(a, scratch, scratch_bytes, (hipStream_t)stream);
@@ -82,7 +82,7 @@ extern "C" int32_t gs_rasterize_bwd(
                  "null pointer");
     RasterArgs a = {C, n_elems, n_isects, channels, means2d, conics, colors, opacities, backgrounds, masks,
                     image_width, image_height, tile_size, tile_width, tile_height, tile_offsets, flatten_ids,
-                    nullptr, nullptr, nullptr};
+                    nullptr, nullptr, nullptr, 0u};
     RasterGradArgs ga = {render_alphas, last_ids, v_render_colors, v_render_alphas, v_means2d_abs,
                          v_means2d, v_conics, v_colors, v_opacities};
     if (int32_t rc = check_raster_args(a)) return rc;

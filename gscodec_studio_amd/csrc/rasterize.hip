@@ -48,6 +48,7 @@
 // channel, as the reference's single CDIM-templated kernel does.
 #include "gs_common.h"
 #include "rasterize_common.h"
+#include "dpp_reduce.h"
 
 #include <cstdlib>
 
@@ -97,6 +98,21 @@ GS_DEV bool splat_extent(const SplatRaw &s, float &hx, float &hy) {
         hx = hy = 3.0e38f; // degenerate conic: never cull
     }
     return true;
+}
+
+// XCD-aware work-item remap (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroup b runs on
+// XCD b % 8).  Consecutive virtual items (neighbouring tiles, which share most of their splats)
+// are given to the SAME XCD, so their gathers hit that XCD's L2 instead of re-fetching the
+// splat from the fabric on all 8.  Bijective for any M.  Placement only affects speed.
+// `group` > 0: XCD x owns every 8th group of `group` consecutive virtual items (locality inside a
+// group, load spread over the whole image: the heavy tiles are spatially clustered, so giving one
+// XCD a contiguous 1/8 of the image costs more in imbalance than it saves in traffic -- measured).
+GS_DEV uint32_t xcd_remap(uint32_t b, uint32_t M, uint32_t group) {
+    if (group == 0u) return b;
+    const uint32_t full = (M / (8u * group)) * (8u * group); // items covered by complete rounds
+    if (b >= full) return b;                                  // ragged tail: identity
+    const uint32_t x = b & 7u, i = b >> 3;                    // i-th item of XCD x
+    return ((i / group) * 8u + x) * group + (i % group);
 }
 
 struct TileGeom {
@@ -156,8 +172,9 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
     __shared__ float4 s_rec[(GS_WAVE + 1) * REC];
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-    const TileGeom tg = tile_geom(a, order, blockIdx.x);
-    const uint32_t q_first = (NQ == 4) ? 0u : blockIdx.y;
+    const uint32_t vitem = xcd_remap(blockIdx.x, gridDim.x, a.xcd_group);
+    const TileGeom tg = tile_geom(a, order, (NQ == 4) ? vitem : (vitem >> 2));
+    const uint32_t q_first = (NQ == 4) ? 0u : (vitem & 3u);
     const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels + ch_off : nullptr;
 
     bool inside[NQ];
@@ -349,17 +366,22 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
     __shared__ float4 s_rec[(GS_WAVE + 1) * REC];
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-    uint32_t slot = blockIdx.x;
+    uint32_t n_work = gridDim.x;
+    if (SEG) {
+        n_work = *sg.n_items; // the grid is an upper bound
+        if (blockIdx.x >= n_work) return;
+    }
+    const uint32_t vitem = xcd_remap(blockIdx.x, n_work, a.xcd_group);
+    uint32_t slot = (NQ == 4) ? vitem : (vitem >> 2);
     int32_t seg_k = 0;
     if (SEG) {
-        if (blockIdx.x >= *sg.n_items) return;
-        const uint2 it = sg.items[blockIdx.x];
+        const uint2 it = sg.items[vitem];
         slot = it.x;
         seg_k = (int32_t)it.y;
     }
     TileGeom tg = tile_geom(a, SEG ? nullptr : order, slot);
     if (a.masks != nullptr && !a.masks[tg.lin]) return;
-    const uint32_t q_first = (NQ == 4) ? 0u : blockIdx.y;
+    const uint32_t q_first = (NQ == 4) ? 0u : (vitem & 3u);
     const Rect rect = wave_rect<NQ>(a, tg, q_first);
     if (rect.empty || tg.range_end <= tg.range_start) return;
     const int32_t tile_end = tg.range_end;
@@ -626,7 +648,7 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t n_tiles_all, 
 
 template <int NQ, int CDIM, bool COLOR_LDS>
 void launch_fwd(const RasterArgs &a, const int32_t *order, uint32_t cnt, uint32_t off, float *ckpt, int32_t seg, hipStream_t st) {
-    dim3 grid(a.C * a.tile_width * a.tile_height, NQ == 4 ? 1 : 4);
+    dim3 grid(a.C * a.tile_width * a.tile_height * (NQ == 4 ? 1 : 4));
     if (ckpt != nullptr)
         hipLaunchKernelGGL((raster_wave_fwd_kernel<NQ, CDIM, COLOR_LDS, true>), grid, dim3(GS_WAVE), 0, st, a, order, cnt, off, ckpt, seg);
     else
@@ -635,7 +657,7 @@ void launch_fwd(const RasterArgs &a, const int32_t *order, uint32_t cnt, uint32_
 
 template <int NQ, int CDIM, int CMODE>
 void launch_bwd(const RasterArgs &a, const RasterGradArgs &ga, const int32_t *order, uint32_t cnt, uint32_t off, int use_va, hipStream_t st) {
-    dim3 grid(a.C * a.tile_width * a.tile_height, NQ == 4 ? 1 : 4);
+    dim3 grid(a.C * a.tile_width * a.tile_height * (NQ == 4 ? 1 : 4));
     SegArgs sg = {nullptr, nullptr, nullptr, nullptr, 0};
     if (ga.v_means2d_abs != nullptr)
         hipLaunchKernelGGL((raster_wave_bwd_kernel<NQ, CDIM, CMODE, true, false>), grid, dim3(GS_WAVE), 0, st, a, ga, order, cnt, off, use_va, sg);
@@ -643,14 +665,228 @@ void launch_bwd(const RasterArgs &a, const RasterGradArgs &ga, const int32_t *or
         hipLaunchKernelGGL((raster_wave_bwd_kernel<NQ, CDIM, CMODE, false, false>), grid, dim3(GS_WAVE), 0, st, a, ga, order, cnt, off, use_va, sg);
 }
 
+// ---------------------------------------------------------------------------
+// Fast segmented backward for 1..4 channels (the hot case): one wave per (tile, segment) item,
+// 4 pixels per lane.  Differences from the generic kernel above:
+//   * no compaction: every lane stages its list entry at slot = lane, and FOUR ballots (one per
+//     8x8 quadrant, ellipse-extent test against that quadrant) give four 64-bit SGPR masks.  The
+//     walk iterates over the set bits of their union (s_ff1) and enters a quadrant's pixel code
+//     through a scalar branch -- segments bound the critical path, so throughput is what
+//     counts here, and a splat typically touches ~2 of the 4 quadrants;
+//   * the 6 + CDIM (+2) per-splat sums are reduced by hand-scheduled interleaved v_add_f32_dpp
+//     chains (dpp_reduce.h): 6 instructions per value, no moves, no hazards.
+// record: R0 = (mx, my, a', b')  R1 = (c', log2 o, col0, col1)  R2 = (col2, col3, a, b)  R3 = (c, o, g, -)
+// ---------------------------------------------------------------------------
+template <int CDIM, bool ABS>
+__global__ void __launch_bounds__(GS_WAVE) raster_seg_bwd_kernel(RasterArgs a, RasterGradArgs ga, int use_v_alpha, SegArgs sg) {
+    constexpr int REC = 4;
+    __shared__ float4 s_rec[GS_WAVE * REC];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    const uint32_t n_work = *sg.n_items; // the grid is an upper bound
+    if (blockIdx.x >= n_work) return;
+    const uint2 it = sg.items[xcd_remap(blockIdx.x, n_work, a.xcd_group)];
+    const int32_t seg_k = (int32_t)it.y;
+    TileGeom tg = tile_geom(a, nullptr, it.x);
+    if (a.masks != nullptr && !a.masks[tg.lin]) return;
+    const int32_t tile_end = tg.range_end;
+    tg.range_start = max(tg.range_start, seg_k * sg.seg);
+    tg.range_end = min(tg.range_end, (seg_k + 1) * sg.seg);
+    const bool from_ckpt = tg.range_end < tile_end;
+
+    bool inside[4];
+    float px[4], py[4], T[4], Tw[4], Bq[4], vc[4][CDIM];
+    int32_t bin_final[4], q_bin_max[4];
+    float qx0[4], qx1[4], qy0[4], qy1[4];
+    unsigned q_live = 0;
+    const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t ox = lx + 8u * (i & 1), oy = ly + 8u * (i >> 1);
+        const uint32_t x = tg.px0 + ox, y = tg.py0 + oy;
+        inside[i] = ox < a.tile_size && oy < a.tile_size && x < a.image_width && y < a.image_height;
+        px[i] = (float)x + 0.5f;
+        py[i] = (float)y + 0.5f;
+        const size_t pix = inside[i] ? ((size_t)tg.cam * a.image_height + y) * a.image_width + x : 0;
+        const float T_final = inside[i] ? 1.f - ga.render_alphas[pix] : 1.f;
+        T[i] = T_final;
+        Bq[i] = 0.f;
+        float bg_dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) {
+            vc[i][k] = inside[i] ? ga.v_render_colors[pix * CDIM + k] : 0.f;
+            if (bg != nullptr) bg_dot += bg[k] * vc[i][k];
+        }
+        const float v_a = (inside[i] && use_v_alpha) ? ga.v_render_alphas[pix] : 0.f;
+        Tw[i] = T_final * (v_a - bg_dot);
+        bin_final[i] = inside[i] ? ga.last_ids[pix] : -1;
+        if (from_ckpt && inside[i]) {
+            const float *cb = sg.ckpt + (size_t)(seg_k + 1) * (CDIM + 1) * 256 + i * 64 + lane;
+            T[i] = cb[0];
+            float bsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < CDIM; ++k) {
+                float fin = sg.render_colors[pix * CDIM + k];
+                if (bg != nullptr) fin -= T_final * bg[k];
+                bsum += vc[i][k] * (fin - cb[(k + 1) * 256]);
+            }
+            Bq[i] = bsum;
+        }
+        q_bin_max[i] = __builtin_amdgcn_readfirstlane(wave_max_i32(bin_final[i])); // make it an SGPR
+        if (q_bin_max[i] >= tg.range_start) q_live |= 1u << i;
+        // quadrant rectangle (pixel centres), clipped to tile size and image
+        const float X0 = (float)(tg.px0 + 8u * (i & 1)) + 0.5f, Y0 = (float)(tg.py0 + 8u * (i >> 1)) + 0.5f;
+        qx0[i] = X0;
+        qy0[i] = Y0;
+        qx1[i] = fminf(X0 + 7.f, fminf((float)(tg.px0 + a.tile_size) - 0.5f, (float)a.image_width - 0.5f));
+        qy1[i] = fminf(Y0 + 7.f, fminf((float)(tg.py0 + a.tile_size) - 0.5f, (float)a.image_height - 0.5f));
+    }
+    if (q_live == 0u) return; // nothing composited in this segment for any pixel
+    int32_t bin_max = max(max(q_bin_max[0], q_bin_max[1]), max(q_bin_max[2], q_bin_max[3]));
+    const int32_t first = min(tg.range_end - 1, bin_max);
+    const int32_t total = first - tg.range_start + 1;
+    const int32_t num_batches = (total + GS_WAVE - 1) / GS_WAVE;
+
+    auto fetch = [&](int32_t idx, SplatRaw &s, float *col) {
+        const bool ok = idx >= tg.range_start;
+        s = gather_splat(a, idx, ok);
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) col[k] = ok ? a.colors[(size_t)s.g * CDIM + k] : 0.f;
+    };
+    SplatRaw nxt;
+    float ncol[CDIM];
+    fetch(first - (int32_t)lane, nxt, ncol);
+
+    for (int32_t b = 0; b < num_batches; ++b) {
+        const int32_t batch_end = first - b * GS_WAVE; // slot t holds list index batch_end - t
+        const SplatRaw s = nxt;
+        float hx, hy;
+        const int32_t my_idx = batch_end - (int32_t)lane;
+        const bool live = (my_idx >= tg.range_start) && splat_extent(s, hx, hy);
+        unsigned long long qm[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool touch = live && (my_idx <= q_bin_max[i]) && (s.mx + hx >= qx0[i]) && (s.mx - hx <= qx1[i]) &&
+                               (s.my + hy >= qy0[i]) && (s.my - hy <= qy1[i]);
+            qm[i] = ((q_live >> i) & 1u) ? __ballot(touch) : 0ull;
+        }
+        {
+            float c0 = ncol[0], c1 = 0.f, c2 = 0.f, c3 = 0.f;
+            if (CDIM > 1) c1 = ncol[CDIM > 1 ? 1 : 0];
+            if (CDIM > 2) c2 = ncol[CDIM > 2 ? 2 : 0];
+            if (CDIM > 3) c3 = ncol[CDIM > 3 ? 3 : 0];
+            s_rec[lane * REC + 0] = make_float4(s.mx, s.my, -0.5f * LOG2E * s.ca, -LOG2E * s.cb);
+            s_rec[lane * REC + 1] = make_float4(-0.5f * LOG2E * s.cc, __log2f(s.opac), c0, c1);
+            s_rec[lane * REC + 2] = make_float4(c2, c3, s.ca, s.cb);
+            s_rec[lane * REC + 3] = make_float4(s.cc, s.opac, __int_as_float(s.g), 0.f);
+        }
+        if (b + 1 < num_batches) fetch(first - (b + 1) * GS_WAVE - (int32_t)lane, nxt, ncol);
+        __builtin_amdgcn_wave_barrier();
+
+        unsigned long long any = qm[0] | qm[1] | qm[2] | qm[3];
+        while (any) {
+            const int t = __builtin_ctzll(any);
+            any &= any - 1;
+            const float4 r0 = s_rec[t * REC + 0];
+            const float4 r1 = s_rec[t * REC + 1];
+            const float4 r2 = s_rec[t * REC + 2];
+            const float4 r3 = s_rec[t * REC + 3];
+            float col[CDIM];
+            col[0] = r1.z;
+            if (CDIM > 1) col[CDIM > 1 ? 1 : 0] = r1.w;
+            if (CDIM > 2) col[CDIM > 2 ? 2 : 0] = r2.x;
+            if (CDIM > 3) col[CDIM > 3 ? 3 : 0] = r2.y;
+            const int32_t idx = batch_end - t;
+            float S0 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Ax = 0.f, Ay = 0.f;
+            float Cs[CDIM];
+#pragma unroll
+            for (int k = 0; k < CDIM; ++k) Cs[k] = 0.f;
+            bool any_valid = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!((qm[i] >> t) & 1ull)) continue; // wave-uniform (scalar) branch
+                const float dx = r0.x - px[i], dy = r0.y - py[i];
+                const float power = dx * (r0.z * dx + r0.w * dy) + r1.x * dy * dy;
+                const float araw = __builtin_amdgcn_exp2f(power + r1.y); // = o exp(-sigma)
+                const float alpha = fminf(0.999f, araw);
+                const bool valid = (idx <= bin_final[i]) && !(power > 0.f) && (alpha >= ALPHA_MIN);
+                any_valid |= valid;
+                const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+                const float Tn = T[i] * ra;
+                const float facv = valid ? alpha * Tn : 0.f;
+                float D = 0.f;
+#pragma unroll
+                for (int k = 0; k < CDIM; ++k) {
+                    D += col[k] * vc[i][k];
+                    Cs[k] += facv * vc[i][k];
+                }
+                const float v_alpha = D * Tn + (Tw[i] - Bq[i]) * ra;
+                const float v_sigma = (valid && araw <= 0.999f) ? -araw * v_alpha : 0.f;
+                Bq[i] += facv * D;
+                T[i] = valid ? Tn : T[i];
+                const float sdx = v_sigma * dx, sdy = v_sigma * dy;
+                S0 += v_sigma;
+                Sx += sdx;
+                Sy += sdy;
+                Sxx += sdx * dx;
+                Sxy += sdx * dy;
+                Syy += sdy * dy;
+                if (ABS) {
+                    Ax += fabsf(r2.z * sdx + r2.w * sdy);
+                    Ay += fabsf(r2.w * sdx + r3.x * sdy);
+                }
+            }
+            if (!__any(any_valid)) continue;
+            wave_reduce_sum_6(S0, Sx, Sy, Sxx, Sxy, Syy);
+            if (ABS) {
+                if (CDIM == 1) wave_reduce_sum_3(Cs[0], Ax, Ay);
+                else if (CDIM == 2) wave_reduce_sum_4(Cs[0], Cs[CDIM > 1 ? 1 : 0], Ax, Ay);
+                else if (CDIM == 3) wave_reduce_sum_5(Cs[0], Cs[CDIM > 1 ? 1 : 0], Cs[CDIM > 2 ? 2 : 0], Ax, Ay);
+                else wave_reduce_sum_6(Cs[0], Cs[CDIM > 1 ? 1 : 0], Cs[CDIM > 2 ? 2 : 0], Cs[CDIM > 3 ? 3 : 0], Ax, Ay);
+            } else {
+                if (CDIM == 1) wave_reduce_sum_1(Cs[0]);
+                else if (CDIM == 2) wave_reduce_sum_2(Cs[0], Cs[CDIM > 1 ? 1 : 0]);
+                else if (CDIM == 3) wave_reduce_sum_3(Cs[0], Cs[CDIM > 1 ? 1 : 0], Cs[CDIM > 2 ? 2 : 0]);
+                else wave_reduce_sum_4(Cs[0], Cs[CDIM > 1 ? 1 : 0], Cs[CDIM > 2 ? 2 : 0], Cs[CDIM > 3 ? 3 : 0]);
+            }
+            if (lane == GS_WAVE - 1) {
+                const size_t g = (size_t)__float_as_int(r3.z);
+                float *vcol = ga.v_colors + g * CDIM;
+#pragma unroll
+                for (int k = 0; k < CDIM; ++k) unsafeAtomicAdd(vcol + k, Cs[k]);
+                const float ca = r2.z, cb = r2.w, cc = r3.x;
+                unsafeAtomicAdd(ga.v_means2d + 2 * g, ca * Sx + cb * Sy);
+                unsafeAtomicAdd(ga.v_means2d + 2 * g + 1, cb * Sx + cc * Sy);
+                unsafeAtomicAdd(ga.v_conics + 3 * g, 0.5f * Sxx);
+                unsafeAtomicAdd(ga.v_conics + 3 * g + 1, Sxy);
+                unsafeAtomicAdd(ga.v_conics + 3 * g + 2, 0.5f * Syy);
+                unsafeAtomicAdd(ga.v_opacities + g, -S0 / r3.y);
+                if (ABS) {
+                    unsafeAtomicAdd(ga.v_means2d_abs + 2 * g, Ax);
+                    unsafeAtomicAdd(ga.v_means2d_abs + 2 * g + 1, Ay);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // segmented launch: one wave per (tile, segment) item, 4 pixels per lane
 template <int CDIM>
 void launch_bwd_seg(const RasterArgs &a, const RasterGradArgs &ga, uint32_t max_items, int use_va, const SegArgs &sg, hipStream_t st) {
     dim3 grid(max_items, 1);
+    const char *e = getenv("GS_RASTER_SEG_KERNEL"); // "generic" selects the compacting generic kernel (A/B)
+    if (e != nullptr && e[0] == 'g') {
+        if (ga.v_means2d_abs != nullptr)
+            hipLaunchKernelGGL((raster_wave_bwd_kernel<4, CDIM, 0, true, true>), grid, dim3(GS_WAVE), 0, st, a, ga, (const int32_t *)nullptr, (uint32_t)CDIM, 0u, use_va, sg);
+        else
+            hipLaunchKernelGGL((raster_wave_bwd_kernel<4, CDIM, 0, false, true>), grid, dim3(GS_WAVE), 0, st, a, ga, (const int32_t *)nullptr, (uint32_t)CDIM, 0u, use_va, sg);
+        return;
+    }
     if (ga.v_means2d_abs != nullptr)
-        hipLaunchKernelGGL((raster_wave_bwd_kernel<4, CDIM, 0, true, true>), grid, dim3(GS_WAVE), 0, st, a, ga, (const int32_t *)nullptr, (uint32_t)CDIM, 0u, use_va, sg);
+        hipLaunchKernelGGL((raster_seg_bwd_kernel<CDIM, true>), grid, dim3(GS_WAVE), 0, st, a, ga, use_va, sg);
     else
-        hipLaunchKernelGGL((raster_wave_bwd_kernel<4, CDIM, 0, false, true>), grid, dim3(GS_WAVE), 0, st, a, ga, (const int32_t *)nullptr, (uint32_t)CDIM, 0u, use_va, sg);
+        hipLaunchKernelGGL((raster_seg_bwd_kernel<CDIM, false>), grid, dim3(GS_WAVE), 0, st, a, ga, use_va, sg);
 }
 
 // (tile, k) items: every global segment [k*seg, (k+1)*seg) that intersects a tile's range
@@ -733,7 +969,14 @@ static const int32_t *build_order(const RasterArgs &a, void *scratch, size_t scr
     return order;
 }
 
-int32_t raster_wave_fwd(const RasterArgs &a, void *scratch, size_t scratch_bytes, hipStream_t st) {
+static uint32_t xcd_group_env(const char *name, uint32_t dflt) {
+    const char *e = getenv(name);
+    return e ? (uint32_t)atoi(e) : dflt;
+}
+
+int32_t raster_wave_fwd(const RasterArgs &a_in, void *scratch, size_t scratch_bytes, hipStream_t st) {
+    RasterArgs a = a_in;
+    a.xcd_group = xcd_group_env("GS_RASTER_XCD_FWD", 64u); // 16 tiles x 4 quadrants (sweep: profiles/round1_notes.md)
     const int32_t *order = build_order(a, scratch, scratch_bytes, st);
     const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;
     const ScratchLayout L = scratch_layout(n_tiles_all, a.n_isects, a.channels);
@@ -763,8 +1006,10 @@ int32_t raster_wave_fwd(const RasterArgs &a, void *scratch, size_t scratch_bytes
     return 0;
 }
 
-int32_t raster_wave_bwd(const RasterArgs &a, const RasterGradArgs &ga, const float *render_colors, void *scratch,
+int32_t raster_wave_bwd(const RasterArgs &a_in, const RasterGradArgs &ga, const float *render_colors, void *scratch,
                         size_t scratch_bytes, hipStream_t st) {
+    RasterArgs a = a_in;
+    a.xcd_group = xcd_group_env("GS_RASTER_XCD_BWD", 16u);
     const int use_va = ga.v_render_alphas != nullptr;
     const uint32_t c = a.channels;
     const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;

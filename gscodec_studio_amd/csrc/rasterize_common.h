@@ -17,6 +17,7 @@ struct RasterArgs {
     float *render_colors;
     float *render_alphas;
     int32_t *last_ids;
+    uint32_t xcd_group; // XCD-aware work-item grouping (0 = off), set by the dispatcher
 };
 
 struct RasterGradArgs {
