@@ -604,21 +604,31 @@ class _RasterizeToPixels(torch.autograd.Function):
         n_isects = flatten_ids.shape[0]
         v_render_colors = _f32c(v_render_colors)
         v_render_alphas = _f32c(v_render_alphas)
-        # accumulated with atomics -> zero-filled
-        v_means2d = torch.zeros_like(means2d)
-        v_conics = torch.zeros_like(conics)
-        v_colors = torch.zeros_like(colors)
-        v_opacities = torch.zeros_like(opacities)
-        v_means2d_abs = torch.zeros_like(means2d) if ctx.absgrad else None
+        # accumulated with atomics -> zero-filled.  Up to 4 channels: ONE packed [n_elems,16] buffer
+        # (64-byte row per splat: vx vy | ca cb cc | o | c0..c3 | ax ay) so that a splat's whole
+        # gradient is one L2 request; the tensors handed to autograd are views of it.
+        packed = channels <= 4
+        if packed:
+            P = torch.zeros(opacities.shape + (16,), dtype=torch.float32, device=means2d.device)
+            v_means2d, v_conics, v_opacities = P[..., 0:2], P[..., 2:5], P[..., 5]
+            v_colors = P[..., 6:6 + channels]
+            v_means2d_abs = P[..., 10:12] if ctx.absgrad else None
+            out_ptrs = (B.ptr(P) if ctx.absgrad else None, B.ptr(P), None, None, None)
+        else:
+            v_means2d = torch.zeros_like(means2d)
+            v_conics = torch.zeros_like(conics)
+            v_colors = torch.zeros_like(colors)
+            v_opacities = torch.zeros_like(opacities)
+            v_means2d_abs = torch.zeros_like(means2d) if ctx.absgrad else None
+            out_ptrs = (B.ptr(v_means2d_abs), B.ptr(v_means2d), B.ptr(v_conics), B.ptr(v_colors), B.ptr(v_opacities))
         m8 = masks.view(torch.uint8) if masks is not None else None
         with _device_of(means2d):
             sb = scratch.numel()
             B.call("gs_rasterize_bwd", C, n_elems, n_isects, channels, B.ptr(means2d), B.ptr(conics), B.ptr(colors),
                    B.ptr(opacities), B.ptr(backgrounds), B.ptr(m8), ctx.width, ctx.height, ctx.tile_size,
                    tile_width, tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_colors),
-                   B.ptr(render_alphas), B.ptr(last_ids), B.ptr(v_render_colors), B.ptr(v_render_alphas), B.ptr(v_means2d_abs),
-                   B.ptr(v_means2d), B.ptr(v_conics), B.ptr(v_colors), B.ptr(v_opacities), B.ptr(scratch), sb,
-                   _stream(means2d))
+                   B.ptr(render_alphas), B.ptr(last_ids), B.ptr(v_render_colors), B.ptr(v_render_alphas), *out_ptrs,
+                   int(packed), B.ptr(scratch), sb, _stream(means2d))
         if ctx.absgrad:
             means2d.absgrad = v_means2d_abs
         if ctx.needs_input_grad[4]:

@@ -74,17 +74,28 @@ extern "C" int32_t gs_rasterize_bwd(
     uint32_t tile_width, uint32_t tile_height, const int32_t *tile_offsets,
     const int32_t *flatten_ids, const float *render_colors, const float *render_alphas,
     const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas, float *v_means2d_abs,
-    float *v_means2d, float *v_conics, float *v_colors, float *v_opacities, void *scratch,
-    size_t scratch_bytes, gs_stream_t stream) {
+    float *v_means2d, float *v_conics, float *v_colors, float *v_opacities, int32_t packed16,
+    void *scratch, size_t scratch_bytes, gs_stream_t stream) {
     GS_CHECK_ARG(render_alphas && last_ids && v_render_colors && tile_offsets, "null pointer");
-    GS_CHECK_ARG(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids && v_means2d &&
-                                   v_conics && v_colors && v_opacities),
+    GS_CHECK_ARG(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids && v_means2d),
                  "null pointer");
+    GS_CHECK_ARG(n_isects == 0 || packed16 || (v_conics && v_colors && v_opacities), "null pointer");
+    GS_CHECK_ARG(!packed16 || channels <= 4, "packed16 gradients need channels <= 4");
     RasterArgs a = {C, n_elems, n_isects, channels, means2d, conics, colors, opacities, backgrounds, masks,
                     image_width, image_height, tile_size, tile_width, tile_height, tile_offsets, flatten_ids,
                     nullptr, nullptr, nullptr, 0u};
     RasterGradArgs ga = {render_alphas, last_ids, v_render_colors, v_render_alphas, v_means2d_abs,
-                         v_means2d, v_conics, v_colors, v_opacities};
+                         v_means2d, v_conics, v_colors, v_opacities, 2u, 2u, 3u, channels, 1u, 0u};
+    if (packed16) {
+        float *P = v_means2d; // [n_elems,16]: vx vy | ca cb cc | o | c0 c1 c2 c3 | ax ay | pad
+        ga.v_means2d = P;
+        ga.v_conics = P + 2;
+        ga.v_opacities = P + 5;
+        ga.v_colors = P + 6;
+        ga.v_means2d_abs = v_means2d_abs != nullptr ? P + 10 : nullptr;
+        ga.s_abs = ga.s_xy = ga.s_conic = ga.s_color = ga.s_opac = 16u;
+        ga.packed = 1u;
+    }
     if (int32_t rc = check_raster_args(a)) return rc;
     if (C == 0 || image_width == 0 || image_height == 0 || n_isects == 0) return 0;
     int32_t rc = use_ref_raster() ? raster_ref_bwd(a, ga, (hipStream_t)stream) : raster_wave_bwd(a, ga, render_colors, scratch, scratch_bytes, (hipStream_t)stream);

@@ -108,6 +108,7 @@ GS_DEV bool splat_extent(const SplatRaw &s, float &hx, float &hy) {
 // group, load spread over the whole image: the heavy tiles are spatially clustered, so giving one
 // XCD a contiguous 1/8 of the image costs more in imbalance than it saves in traffic -- measured).
 GS_DEV uint32_t xcd_remap(uint32_t b, uint32_t M, uint32_t group) {
+    group &= 0x7fffffffu;
     if (group == 0u) return b;
     const uint32_t full = (M / (8u * group)) * (8u * group); // items covered by complete rounds
     if (b >= full) return b;                                  // ragged tail: identity
@@ -562,7 +563,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
                 }
             }
             if (!__any(any_valid)) continue;
-            float *vcol = ga.v_colors + (size_t)g * a.channels + ch_off;
+            float *vcol = ga.v_colors + (size_t)g * ga.s_color + ch_off;
             if (CMODE == 2) {
                 // any channel count: one reduction + atomic per channel
                 for (uint32_t k = 0; k < cnt; ++k) {
@@ -592,15 +593,15 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
                     for (int k = 0; k < CR; ++k)
                         if ((uint32_t)k < cnt) unsafeAtomicAdd(vcol + k, Cs[k]);
                 }
-                unsafeAtomicAdd(ga.v_means2d + 2 * (size_t)g, c3.x * Sx + c3.y * Sy);
-                unsafeAtomicAdd(ga.v_means2d + 2 * (size_t)g + 1, c3.y * Sx + c3.z * Sy);
-                unsafeAtomicAdd(ga.v_conics + 3 * (size_t)g, 0.5f * Sxx);
-                unsafeAtomicAdd(ga.v_conics + 3 * (size_t)g + 1, Sxy);
-                unsafeAtomicAdd(ga.v_conics + 3 * (size_t)g + 2, 0.5f * Syy);
-                unsafeAtomicAdd(ga.v_opacities + g, -S0 / c3.w);
+                unsafeAtomicAdd(ga.v_means2d + ga.s_xy * (size_t)g, c3.x * Sx + c3.y * Sy);
+                unsafeAtomicAdd(ga.v_means2d + ga.s_xy * (size_t)g + 1, c3.y * Sx + c3.z * Sy);
+                unsafeAtomicAdd(ga.v_conics + ga.s_conic * (size_t)g, 0.5f * Sxx);
+                unsafeAtomicAdd(ga.v_conics + ga.s_conic * (size_t)g + 1, Sxy);
+                unsafeAtomicAdd(ga.v_conics + ga.s_conic * (size_t)g + 2, 0.5f * Syy);
+                unsafeAtomicAdd(ga.v_opacities + ga.s_opac * g, -S0 / c3.w);
                 if (ABS) {
-                    unsafeAtomicAdd(ga.v_means2d_abs + 2 * (size_t)g, Ax);
-                    unsafeAtomicAdd(ga.v_means2d_abs + 2 * (size_t)g + 1, Ay);
+                    unsafeAtomicAdd(ga.v_means2d_abs + ga.s_abs * (size_t)g, Ax);
+                    unsafeAtomicAdd(ga.v_means2d_abs + ga.s_abs * (size_t)g + 1, Ay);
                 }
             }
         }
@@ -678,9 +679,11 @@ void launch_bwd(const RasterArgs &a, const RasterGradArgs &ga, const int32_t *or
 // record: R0 = (mx, my, a', b')  R1 = (c', log2 o, col0, col1)  R2 = (col2, col3, a, b)  R3 = (c, o, g, -)
 // ---------------------------------------------------------------------------
 template <int CDIM, bool ABS>
-__global__ void __launch_bounds__(GS_WAVE) raster_seg_bwd_kernel(RasterArgs a, RasterGradArgs ga, int use_v_alpha, SegArgs sg) {
+__global__ void __launch_bounds__(GS_WAVE, 5) raster_seg_bwd_kernel(RasterArgs a, RasterGradArgs ga, int use_v_alpha, SegArgs sg) {
     constexpr int REC = 4;
+    constexpr int ACC = 3; // float4 per accumulator slot: (Sx', Sy', Sxx, Sxy) (Syy, S0, C0, C1) (C2, C3, Ax, Ay)
     __shared__ float4 s_rec[GS_WAVE * REC];
+    __shared__ float4 s_acc[GS_WAVE * ACC];
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const uint32_t n_work = *sg.n_items; // the grid is an upper bound
@@ -694,8 +697,23 @@ __global__ void __launch_bounds__(GS_WAVE) raster_seg_bwd_kernel(RasterArgs a, R
     tg.range_end = min(tg.range_end, (seg_k + 1) * sg.seg);
     const bool from_ckpt = tg.range_end < tile_end;
 
+    // issue the first batch's gathers before anything else: their latency overlaps the pixel-state
+    // loads below.  The walk starts at the segment's far end; entries behind every pixel's
+    // last_ids are dropped by the per-quadrant test (idx <= q_bin_max).
+    const int32_t first = tg.range_end - 1;
+    auto fetch = [&](int32_t idx, SplatRaw &s, float *col) {
+        const bool ok = idx >= tg.range_start;
+        s = gather_splat(a, idx, ok);
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) col[k] = ok ? a.colors[(size_t)s.g * CDIM + k] : 0.f;
+    };
+    SplatRaw nxt;
+    float ncol[CDIM];
+    fetch(first - (int32_t)lane, nxt, ncol);
+
     bool inside[4];
-    float px[4], py[4], T[4], Tw[4], Bq[4], vc[4][CDIM];
+    float T[4], Wq[4], vc[4][CDIM]; // Wq = T_final (v_alpha_out - bg . v_out) - B  (the only way Tw and B are used)
+    const float px0 = (float)(tg.px0 + lx) + 0.5f, py0 = (float)(tg.py0 + ly) + 0.5f; // quadrant i: + 8 (i&1), + 8 (i>>1)
     int32_t bin_final[4], q_bin_max[4];
     float qx0[4], qx1[4], qy0[4], qy1[4];
     unsigned q_live = 0;
@@ -705,12 +723,9 @@ __global__ void __launch_bounds__(GS_WAVE) raster_seg_bwd_kernel(RasterArgs a, R
         const uint32_t ox = lx + 8u * (i & 1), oy = ly + 8u * (i >> 1);
         const uint32_t x = tg.px0 + ox, y = tg.py0 + oy;
         inside[i] = ox < a.tile_size && oy < a.tile_size && x < a.image_width && y < a.image_height;
-        px[i] = (float)x + 0.5f;
-        py[i] = (float)y + 0.5f;
         const size_t pix = inside[i] ? ((size_t)tg.cam * a.image_height + y) * a.image_width + x : 0;
         const float T_final = inside[i] ? 1.f - ga.render_alphas[pix] : 1.f;
         T[i] = T_final;
-        Bq[i] = 0.f;
         float bg_dot = 0.f;
 #pragma unroll
         for (int k = 0; k < CDIM; ++k) {
@@ -718,7 +733,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_seg_bwd_kernel(RasterArgs a, R
             if (bg != nullptr) bg_dot += bg[k] * vc[i][k];
         }
         const float v_a = (inside[i] && use_v_alpha) ? ga.v_render_alphas[pix] : 0.f;
-        Tw[i] = T_final * (v_a - bg_dot);
+        Wq[i] = T_final * (v_a - bg_dot);
         bin_final[i] = inside[i] ? ga.last_ids[pix] : -1;
         if (from_ckpt && inside[i]) {
             const float *cb = sg.ckpt + (size_t)(seg_k + 1) * (CDIM + 1) * 256 + i * 64 + lane;
@@ -730,40 +745,30 @@ __global__ void __launch_bounds__(GS_WAVE) raster_seg_bwd_kernel(RasterArgs a, R
                 if (bg != nullptr) fin -= T_final * bg[k];
                 bsum += vc[i][k] * (fin - cb[(k + 1) * 256]);
             }
-            Bq[i] = bsum;
+            Wq[i] -= bsum;
         }
         q_bin_max[i] = __builtin_amdgcn_readfirstlane(wave_max_i32(bin_final[i])); // make it an SGPR
         if (q_bin_max[i] >= tg.range_start) q_live |= 1u << i;
         // quadrant rectangle (pixel centres), clipped to tile size and image
         const float X0 = (float)(tg.px0 + 8u * (i & 1)) + 0.5f, Y0 = (float)(tg.py0 + 8u * (i >> 1)) + 0.5f;
-        qx0[i] = X0;
-        qy0[i] = Y0;
-        qx1[i] = fminf(X0 + 7.f, fminf((float)(tg.px0 + a.tile_size) - 0.5f, (float)a.image_width - 0.5f));
-        qy1[i] = fminf(Y0 + 7.f, fminf((float)(tg.py0 + a.tile_size) - 0.5f, (float)a.image_height - 0.5f));
+        auto sgpr = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
+        qx0[i] = sgpr(X0);
+        qy0[i] = sgpr(Y0);
+        qx1[i] = sgpr(fminf(X0 + 7.f, fminf((float)(tg.px0 + a.tile_size) - 0.5f, (float)a.image_width - 0.5f)));
+        qy1[i] = sgpr(fminf(Y0 + 7.f, fminf((float)(tg.py0 + a.tile_size) - 0.5f, (float)a.image_height - 0.5f)));
     }
     if (q_live == 0u) return; // nothing composited in this segment for any pixel
-    int32_t bin_max = max(max(q_bin_max[0], q_bin_max[1]), max(q_bin_max[2], q_bin_max[3]));
-    const int32_t first = min(tg.range_end - 1, bin_max);
     const int32_t total = first - tg.range_start + 1;
     const int32_t num_batches = (total + GS_WAVE - 1) / GS_WAVE;
 
-    auto fetch = [&](int32_t idx, SplatRaw &s, float *col) {
-        const bool ok = idx >= tg.range_start;
-        s = gather_splat(a, idx, ok);
-#pragma unroll
-        for (int k = 0; k < CDIM; ++k) col[k] = ok ? a.colors[(size_t)s.g * CDIM + k] : 0.f;
-    };
-    SplatRaw nxt;
-    float ncol[CDIM];
-    fetch(first - (int32_t)lane, nxt, ncol);
-
     for (int32_t b = 0; b < num_batches; ++b) {
         const int32_t batch_end = first - b * GS_WAVE; // slot t holds list index batch_end - t
+        unsigned long long qm[4];
+        {
         const SplatRaw s = nxt;
         float hx, hy;
         const int32_t my_idx = batch_end - (int32_t)lane;
         const bool live = (my_idx >= tg.range_start) && splat_extent(s, hx, hy);
-        unsigned long long qm[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool touch = live && (my_idx <= q_bin_max[i]) && (s.mx + hx >= qx0[i]) && (s.mx - hx <= qx1[i]) &&
@@ -780,17 +785,25 @@ __global__ void __launch_bounds__(GS_WAVE) raster_seg_bwd_kernel(RasterArgs a, R
             s_rec[lane * REC + 2] = make_float4(c2, c3, s.ca, s.cb);
             s_rec[lane * REC + 3] = make_float4(s.cc, s.opac, __int_as_float(s.g), 0.f);
         }
+        }
         if (b + 1 < num_batches) fetch(first - (b + 1) * GS_WAVE - (int32_t)lane, nxt, ncol);
         __builtin_amdgcn_wave_barrier();
 
         unsigned long long any = qm[0] | qm[1] | qm[2] | qm[3];
+        unsigned long long touched = 0ull; // slots whose sums were stored this batch
+        // software pipeline: the next record is read from LDS while the current one is processed
+        int tn = any ? __builtin_ctzll(any) : 0;
+        float4 n0 = s_rec[tn * REC + 0], n1 = s_rec[tn * REC + 1], n2 = s_rec[tn * REC + 2];
+        float4 n3 = ABS ? s_rec[tn * REC + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
         while (any) {
-            const int t = __builtin_ctzll(any);
+            const int t = tn;
             any &= any - 1;
-            const float4 r0 = s_rec[t * REC + 0];
-            const float4 r1 = s_rec[t * REC + 1];
-            const float4 r2 = s_rec[t * REC + 2];
-            const float4 r3 = s_rec[t * REC + 3];
+            const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+            tn = any ? __builtin_ctzll(any) : 0;
+            n0 = s_rec[tn * REC + 0];
+            n1 = s_rec[tn * REC + 1];
+            n2 = s_rec[tn * REC + 2];
+            if (ABS) n3 = s_rec[tn * REC + 3];
             float col[CDIM];
             col[0] = r1.z;
             if (CDIM > 1) col[CDIM > 1 ? 1 : 0] = r1.w;
@@ -805,7 +818,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_seg_bwd_kernel(RasterArgs a, R
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (!((qm[i] >> t) & 1ull)) continue; // wave-uniform (scalar) branch
-                const float dx = r0.x - px[i], dy = r0.y - py[i];
+                const float dx = r0.x - (px0 + 8.f * (float)(i & 1)), dy = r0.y - (py0 + 8.f * (float)(i >> 1));
                 const float power = dx * (r0.z * dx + r0.w * dy) + r1.x * dy * dy;
                 const float araw = __builtin_amdgcn_exp2f(power + r1.y); // = o exp(-sigma)
                 const float alpha = fminf(0.999f, araw);
@@ -820,9 +833,9 @@ __global__ void __launch_bounds__(GS_WAVE) raster_seg_bwd_kernel(RasterArgs a, R
                     D += col[k] * vc[i][k];
                     Cs[k] += facv * vc[i][k];
                 }
-                const float v_alpha = D * Tn + (Tw[i] - Bq[i]) * ra;
+                const float v_alpha = D * Tn + Wq[i] * ra;
                 const float v_sigma = (valid && araw <= 0.999f) ? -araw * v_alpha : 0.f;
-                Bq[i] += facv * D;
+                Wq[i] -= facv * D;
                 T[i] = valid ? Tn : T[i];
                 const float sdx = v_sigma * dx, sdy = v_sigma * dy;
                 S0 += v_sigma;
@@ -837,34 +850,76 @@ __global__ void __launch_bounds__(GS_WAVE) raster_seg_bwd_kernel(RasterArgs a, R
                 }
             }
             if (!__any(any_valid)) continue;
-            wave_reduce_sum_6(S0, Sx, Sy, Sxx, Sxy, Syy);
+            // 8 values through the permlane butterfly (20 VALU), the rest through plain DPP chains.
+            // slot floats: [Sx, Sy | Sxx, Sxy | Syy, S0 | C0, C1 | C2, C3, Ax, Ay]
+            float lo, hi;
+            const float C1v = CDIM > 1 ? Cs[CDIM > 1 ? 1 : 0] : 0.f;
+            wave_reduce_sum_8_butterfly(Sx, Syy, Sxx, Cs[0], Sy, S0, Sxy, C1v, lo, hi);
+            float C2v = CDIM > 2 ? Cs[CDIM > 2 ? 2 : 0] : 0.f, C3v = CDIM > 3 ? Cs[CDIM > 3 ? 3 : 0] : 0.f;
             if (ABS) {
-                if (CDIM == 1) wave_reduce_sum_3(Cs[0], Ax, Ay);
-                else if (CDIM == 2) wave_reduce_sum_4(Cs[0], Cs[CDIM > 1 ? 1 : 0], Ax, Ay);
-                else if (CDIM == 3) wave_reduce_sum_5(Cs[0], Cs[CDIM > 1 ? 1 : 0], Cs[CDIM > 2 ? 2 : 0], Ax, Ay);
-                else wave_reduce_sum_6(Cs[0], Cs[CDIM > 1 ? 1 : 0], Cs[CDIM > 2 ? 2 : 0], Cs[CDIM > 3 ? 3 : 0], Ax, Ay);
+                if (CDIM > 3) wave_reduce_sum_4(C2v, C3v, Ax, Ay);
+                else if (CDIM > 2) wave_reduce_sum_3(C2v, Ax, Ay);
+                else wave_reduce_sum_2(Ax, Ay);
             } else {
-                if (CDIM == 1) wave_reduce_sum_1(Cs[0]);
-                else if (CDIM == 2) wave_reduce_sum_2(Cs[0], Cs[CDIM > 1 ? 1 : 0]);
-                else if (CDIM == 3) wave_reduce_sum_3(Cs[0], Cs[CDIM > 1 ? 1 : 0], Cs[CDIM > 2 ? 2 : 0]);
-                else wave_reduce_sum_4(Cs[0], Cs[CDIM > 1 ? 1 : 0], Cs[CDIM > 2 ? 2 : 0], Cs[CDIM > 3 ? 3 : 0]);
+                if (CDIM > 3) wave_reduce_sum_2(C2v, C3v);
+                else if (CDIM > 2) wave_reduce_sum_1(C2v);
             }
-            if (lane == GS_WAVE - 1) {
-                const size_t g = (size_t)__float_as_int(r3.z);
-                float *vcol = ga.v_colors + g * CDIM;
-#pragma unroll
-                for (int k = 0; k < CDIM; ++k) unsafeAtomicAdd(vcol + k, Cs[k]);
-                const float ca = r2.z, cb = r2.w, cc = r3.x;
-                unsafeAtomicAdd(ga.v_means2d + 2 * g, ca * Sx + cb * Sy);
-                unsafeAtomicAdd(ga.v_means2d + 2 * g + 1, cb * Sx + cc * Sy);
-                unsafeAtomicAdd(ga.v_conics + 3 * g, 0.5f * Sxx);
-                unsafeAtomicAdd(ga.v_conics + 3 * g + 1, Sxy);
-                unsafeAtomicAdd(ga.v_conics + 3 * g + 2, 0.5f * Syy);
-                unsafeAtomicAdd(ga.v_opacities + g, -S0 / r3.y);
-                if (ABS) {
-                    unsafeAtomicAdd(ga.v_means2d_abs + 2 * g, Ax);
-                    unsafeAtomicAdd(ga.v_means2d_abs + 2 * g + 1, Ay);
+            // park the totals in LDS; the atomics are issued once per batch by the lane that staged
+            // the splat (full-width atomic instructions instead of 9 one-lane instructions per splat)
+            touched |= 1ull << t;
+            float *acc = reinterpret_cast<float *>(&s_acc[t * ACC]);
+            if ((lane & 15u) == 15u) {
+                const uint32_t row = lane >> 4; // rows 0..3 hold (v0,v4) (v2,v6) (v1,v5) (v3,v7)
+                reinterpret_cast<float2 *>(acc)[row] = make_float2(lo, hi);
+            }
+            if (lane == GS_WAVE - 1) s_acc[t * ACC + 2] = make_float4(C2v, C3v, Ax, Ay);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (ga.packed) {
+            // Packed gradient rows [n_elems,16]: finalise per slot in LDS, then issue the atomics with
+            // lane = (slot, component): the <= 12 components of a splat go out as ONE request to ONE
+            // 64-byte line instead of 9-11 requests to 4 arrays (atomics were 27% of this kernel).
+            if ((touched >> lane) & 1ull) {
+                const float4 a0 = s_acc[lane * ACC + 0], a1 = s_acc[lane * ACC + 1];
+                const float4 e2 = s_rec[lane * REC + 2], e3 = s_rec[lane * REC + 3];
+                const float e_ca = e2.z, e_cb = e2.w, e_cc = e3.x, e_op = e3.y;
+                // row layout: vx vy | ca cb cc | o | c0 c1 c2 c3 | ax ay   (a2 already holds c2 c3 ax ay)
+                s_acc[lane * ACC + 0] = make_float4(e_ca * a0.x + e_cb * a0.y, e_cb * a0.x + e_cc * a0.y, 0.5f * a0.z, a0.w);
+                s_acc[lane * ACC + 1] = make_float4(0.5f * a1.x, -a1.y / e_op, a1.z, a1.w);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t sub = lane / 12u, comp = lane % 12u; // 5 slots x 12 components per instruction
+            const bool comp_on = lane < 60u && (comp < 6u + (uint32_t)CDIM || (ABS && comp >= 10u));
+            const float *accf = reinterpret_cast<const float *>(s_acc);
+#pragma unroll 1
+            for (uint32_t grp = 0; grp < 13u; ++grp) {
+                if (((touched >> (grp * 5u)) & 0x1full) == 0ull) continue; // wave-uniform
+                const uint32_t slot = grp * 5u + sub;
+                if (comp_on && slot < 64u && ((touched >> slot) & 1ull)) {
+                    const uint32_t g = (uint32_t)__float_as_int(s_rec[slot * REC + 3].z);
+                    unsafeAtomicAdd(ga.v_means2d + (size_t)g * 16u + comp, accf[slot * (ACC * 4) + comp]);
                 }
+            }
+        } else if ((touched >> lane) & 1ull) {
+            const float4 a0 = s_acc[lane * ACC + 0], a1 = s_acc[lane * ACC + 1], a2 = s_acc[lane * ACC + 2];
+            // this lane staged slot `lane`: its raw conic / opacity / id are still in the record
+            const float4 e2 = s_rec[lane * REC + 2], e3 = s_rec[lane * REC + 3];
+            const size_t g = (size_t)__float_as_int(e3.z);
+            const float e_ca = e2.z, e_cb = e2.w, e_cc = e3.x, e_op = e3.y;
+            float *vcol = ga.v_colors + g * CDIM;
+            unsafeAtomicAdd(vcol, a1.z);
+            if (CDIM > 1) unsafeAtomicAdd(vcol + 1, a1.w);
+            if (CDIM > 2) unsafeAtomicAdd(vcol + 2, a2.x);
+            if (CDIM > 3) unsafeAtomicAdd(vcol + 3, a2.y);
+            unsafeAtomicAdd(ga.v_means2d + ga.s_xy * g, e_ca * a0.x + e_cb * a0.y);
+            unsafeAtomicAdd(ga.v_means2d + ga.s_xy * g + 1, e_cb * a0.x + e_cc * a0.y);
+            unsafeAtomicAdd(ga.v_conics + ga.s_conic * g, 0.5f * a0.z);
+            unsafeAtomicAdd(ga.v_conics + ga.s_conic * g + 1, a0.w);
+            unsafeAtomicAdd(ga.v_conics + ga.s_conic * g + 2, 0.5f * a1.x);
+            unsafeAtomicAdd(ga.v_opacities + ga.s_opac * g, -a1.y / e_op);
+            if (ABS) {
+                unsafeAtomicAdd(ga.v_means2d_abs + ga.s_abs * g, a2.z);
+                unsafeAtomicAdd(ga.v_means2d_abs + ga.s_abs * g + 1, a2.w);
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -30,6 +30,10 @@ struct RasterGradArgs {
     float *v_conics;
     float *v_colors;
     float *v_opacities;
+    // row strides (in floats) of the five gradient arrays.  Separate tensors: 2, 2, 3, channels, 1.
+    // Packed mode (one 64-byte row per splat: [vx vy | ca cb cc | o | c0..c3 | ax ay | pad]): all 16.
+    uint32_t s_abs, s_xy, s_conic, s_color, s_opac;
+    uint32_t packed; // 1: the pointers above alias one [n_elems,16] buffer
 };
 
 // 64-lane sum with DPP row shifts + row broadcasts (GFX9 family).  The total is valid in

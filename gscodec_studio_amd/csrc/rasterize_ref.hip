@@ -220,20 +220,20 @@ __global__ void __launch_bounds__(GS_BLOCK) raster_ref_bwd_kernel(RasterArgs a, 
             }
             if (lane == GS_WAVE - 1) {
                 const size_t g = (size_t)s_id[t];
-                float *vc = ga.v_colors + g * a.channels + ch_off;
+                float *vc = ga.v_colors + g * ga.s_color + ch_off;
 #pragma unroll
                 for (int k = 0; k < CDIM; ++k)
                     if ((uint32_t)k < cnt) unsafeAtomicAdd(vc + k, v_rgb[k]);
-                unsafeAtomicAdd(ga.v_conics + 3 * g, v_ca);
-                unsafeAtomicAdd(ga.v_conics + 3 * g + 1, v_cb);
-                unsafeAtomicAdd(ga.v_conics + 3 * g + 2, v_cc);
-                unsafeAtomicAdd(ga.v_means2d + 2 * g, v_x);
-                unsafeAtomicAdd(ga.v_means2d + 2 * g + 1, v_y);
+                unsafeAtomicAdd(ga.v_conics + ga.s_conic * g, v_ca);
+                unsafeAtomicAdd(ga.v_conics + ga.s_conic * g + 1, v_cb);
+                unsafeAtomicAdd(ga.v_conics + ga.s_conic * g + 2, v_cc);
+                unsafeAtomicAdd(ga.v_means2d + ga.s_xy * g, v_x);
+                unsafeAtomicAdd(ga.v_means2d + ga.s_xy * g + 1, v_y);
                 if (ga.v_means2d_abs != nullptr) {
-                    unsafeAtomicAdd(ga.v_means2d_abs + 2 * g, v_ax);
-                    unsafeAtomicAdd(ga.v_means2d_abs + 2 * g + 1, v_ay);
+                    unsafeAtomicAdd(ga.v_means2d_abs + ga.s_abs * g, v_ax);
+                    unsafeAtomicAdd(ga.v_means2d_abs + ga.s_abs * g + 1, v_ay);
                 }
-                unsafeAtomicAdd(ga.v_opacities + g, v_o);
+                unsafeAtomicAdd(ga.v_opacities + ga.s_opac * g, v_o);
             }
         }
     }

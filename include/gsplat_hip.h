@@ -272,6 +272,11 @@ int32_t gs_rasterize_bwd(
     float *v_conics,      /* [n_elems,3] */
     float *v_colors,      /* [n_elems,channels] */
     float *v_opacities,   /* [n_elems] */
+    int32_t packed16,     /* != 0: v_means2d is ONE zero-filled [n_elems,16] buffer receiving every gradient,
+                             row = [vx vy | ca cb cc | o | c0 c1 c2 c3 | ax ay | 4 pad]; v_conics / v_colors /
+                             v_opacities are ignored, v_means2d_abs only selects absgrad (non-NULL).
+                             One 64-byte row per splat lets the kernels add a whole splat's gradient with
+                             a single L2 request.  Requires channels <= 4. */
     void *scratch, size_t scratch_bytes,
     gs_stream_t stream);
 
