@@ -200,12 +200,13 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
         return;
     }
 
-    float T[NQ], out[NQ][CDIM];
+    float T[NQ], Tkeep[NQ], out[NQ][CDIM];
     int32_t cur[NQ];
     bool done[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         T[i] = 1.f;
+        Tkeep[i] = 1.f;
         cur[i] = 0;
         done[i] = !inside[i];
 #pragma unroll
@@ -214,36 +215,47 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
 
     const Rect rect = wave_rect<NQ>(a, tg, q_first);
     const int32_t n = rect.empty ? 0 : tg.range_end - tg.range_start;
-    const int32_t num_batches = (n + GS_WAVE - 1) / GS_WAVE;
+    // Batches are aligned to multiples of 64 of the GLOBAL list index (the first one is partial), so
+    // that a checkpoint boundary (a multiple of seg, itself a multiple of 64) always coincides with
+    // a batch start: no per-record boundary test inside the hot loop.
+    const int32_t base0 = tg.range_start & ~(GS_WAVE - 1);
+    const int32_t num_batches = n > 0 ? (tg.range_end - base0 + GS_WAVE - 1) / GS_WAVE : 0;
     if (n >= HEAVY_TILE) __builtin_amdgcn_s_setprio(2);
+    auto in_range = [&](int32_t idx) { return idx >= tg.range_start && idx < tg.range_end && n > 0; };
 
-    SplatRaw nxt = gather_splat(a, tg.range_start + (int32_t)lane, (int32_t)lane < n);
+    SplatRaw nxt = gather_splat(a, base0 + (int32_t)lane, in_range(base0 + (int32_t)lane));
     float ncol[COLOR_LDS ? CDIM : 1];
     if (COLOR_LDS) {
 #pragma unroll
         for (int k = 0; k < CDIM; ++k)
-            ncol[k] = ((int32_t)lane < n && (uint32_t)k < cnt) ? a.colors[(size_t)nxt.g * a.channels + ch_off + k] : 0.f;
+            ncol[k] = (in_range(base0 + (int32_t)lane) && (uint32_t)k < cnt) ? a.colors[(size_t)nxt.g * a.channels + ch_off + k] : 0.f;
     }
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    // next checkpoint boundary strictly inside (range_start, range_end)
+    // next checkpoint boundary strictly inside (range_start, range_end), and its slot
     int32_t next_b = CKPT ? (tg.range_start / seg + 1) * seg : 0x7fffffff;
-    auto store_ckpt = [&](int32_t bidx) {
-        float *base = ckpt + (size_t)(bidx / seg) * (CDIM + 1) * 256;
+    int32_t next_k = CKPT ? next_b / seg : 0;
+    auto store_ckpt = [&]() {
+        float *base = ckpt + (size_t)next_k * (CDIM + 1) * 256;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const uint32_t p = (q_first + i) * 64u + lane;
-            base[p] = T[i];
+            base[p] = done[i] ? Tkeep[i] : T[i];
 #pragma unroll
             for (int k = 0; k < CDIM; ++k) base[(k + 1) * 256 + p] = out[i][k];
         }
     };
 
     for (int32_t b = 0; b < num_batches; ++b) {
-        const int32_t batch_start = tg.range_start + b * GS_WAVE;
+        const int32_t batch_start = base0 + b * GS_WAVE;
+        if (CKPT && batch_start == next_b && next_b < tg.range_end) { // state before list entry next_b
+            store_ckpt();
+            next_b += seg;
+            next_k += 1;
+        }
         // ---- cull + compact the prefetched splats into LDS
         SplatRaw s = nxt;
         float hx, hy;
-        const bool have = (int32_t)(b * GS_WAVE + lane) < n;
+        const bool have = in_range(batch_start + (int32_t)lane);
         const bool live = have && splat_extent(s, hx, hy) && (s.mx + hx >= rect.x0) && (s.mx - hx <= rect.x1) &&
                           (s.my + hy >= rect.y0) && (s.my - hy <= rect.y1);
         const unsigned long long lm = __ballot(live);
@@ -263,23 +275,21 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
         }
         // ---- prefetch the next batch
         if (b + 1 < num_batches) {
-            const int32_t li = (b + 1) * GS_WAVE + (int32_t)lane;
-            nxt = gather_splat(a, tg.range_start + li, li < n);
+            const int32_t ni = batch_start + GS_WAVE + (int32_t)lane;
+            nxt = gather_splat(a, ni, in_range(ni));
             if (COLOR_LDS) {
 #pragma unroll
                 for (int k = 0; k < CDIM; ++k)
-                    ncol[k] = (li < n && (uint32_t)k < cnt) ? a.colors[(size_t)nxt.g * a.channels + ch_off + k] : 0.f;
+                    ncol[k] = (in_range(ni) && (uint32_t)k < cnt) ? a.colors[(size_t)nxt.g * a.channels + ch_off + k] : 0.f;
             }
         }
         __builtin_amdgcn_wave_barrier();
 
-        // ---- walk the compacted records; record j+1 is read while j is evaluated
-        float4 r0 = s_rec[0], r1 = s_rec[1], r2 = s_rec[2];
-        for (int j = 0; j < count; ++j) {
-            const float4 c0 = r0, c1 = r1, c2 = r2;
-            r0 = s_rec[(j + 1) * REC + 0]; // slot `count` may be stale: never used
-            r1 = s_rec[(j + 1) * REC + 1];
-            r2 = s_rec[(j + 1) * REC + 2];
+        // ---- walk the compacted records, two per iteration.  The only loop-carried dependency
+        // is ONE fma per record (T <- T - T a): a finished pixel keeps multiplying (its
+        // contributions are masked by `done`, its final transmittance is parked in Tkeep), so the
+        // alpha evaluation of the next records overlaps the composite of the current one.
+        auto composite = [&](const float4 &c0, const float4 &c1, const float4 &c2, bool rec_ok) {
             float col[CDIM];
             if (COLOR_LDS) {
                 col[0] = c1.z;
@@ -289,30 +299,40 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
             } else {
                 const float *cp = a.colors + (size_t)__float_as_int(c2.w) * a.channels + ch_off;
 #pragma unroll
-                for (int k = 0; k < CDIM; ++k) col[k] = (uint32_t)k < cnt ? cp[k] : 0.f;
+                for (int k = 0; k < CDIM; ++k) col[k] = ((uint32_t)k < cnt && rec_ok) ? cp[k] : 0.f;
             }
             const int32_t idx = __float_as_int(c2.z);
-            if (CKPT) {
-                while (idx >= next_b && next_b < tg.range_end) { // wave-uniform
-                    store_ckpt(next_b);
-                    next_b += seg;
-                }
-            }
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const float dx = c0.x - px[i], dy = c0.y - py[i];
                 const float power = dx * (c0.z * dx + c0.w * dy) + c1.x * dy * dy; // = -sigma log2(e)
                 const float alpha = fminf(0.999f, __builtin_amdgcn_exp2f(power + c1.y));
-                bool valid = !done[i] && !(power > 0.f) && (alpha >= ALPHA_MIN);
-                const float next_T = T[i] - T[i] * alpha;
-                const bool stop = valid && next_T <= 1e-4f;
-                done[i] = done[i] || stop;
-                valid = valid && !stop;
-                const float vis = valid ? alpha * T[i] : 0.f;
+                const bool ok = rec_ok && !(power > 0.f) && (alpha >= ALPHA_MIN);
+                const float a_eff = ok ? alpha : 0.f;
+                const float Tj = T[i];
+                const float next_T = Tj - Tj * a_eff;         // the loop-carried chain
+                const bool stop = ok && (next_T <= 1e-4f);    // exclusive stop
+                const bool live = !done[i] && !stop;          // this record is composited
+                Tkeep[i] = done[i] ? Tkeep[i] : Tj;           // transmittance before the stopping splat
+                const float vis = live ? a_eff * Tj : 0.f;
 #pragma unroll
                 for (int k = 0; k < CDIM; ++k) out[i][k] += col[k] * vis;
-                T[i] = valid ? next_T : T[i];
-                cur[i] = valid ? idx : cur[i];
+                cur[i] = (live && ok) ? idx : cur[i];
+                done[i] = done[i] || stop;
+                T[i] = next_T;
+            }
+        };
+        {
+            int j = 0;
+            for (; j + 1 < count; j += 2) {
+                const float4 a0 = s_rec[j * REC + 0], a1 = s_rec[j * REC + 1], a2 = s_rec[j * REC + 2];
+                const float4 b0 = s_rec[j * REC + 3], b1 = s_rec[j * REC + 4], b2 = s_rec[j * REC + 5];
+                composite(a0, a1, a2, true);
+                composite(b0, b1, b2, true);
+            }
+            if (j < count) {
+                const float4 a0 = s_rec[j * REC + 0], a1 = s_rec[j * REC + 1], a2 = s_rec[j * REC + 2];
+                composite(a0, a1, a2, true);
             }
         }
         // ---- early exit when every pixel of the wave is finished
@@ -326,18 +346,20 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
     if (CKPT && !rect.empty) {
         // boundaries after the last live record (or after an early exit) carry the final state
         while (next_b < tg.range_end) {
-            store_ckpt(next_b);
+            store_ckpt();
             next_b += seg;
+            next_k += 1;
         }
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         if (!inside[i]) continue;
-        a.render_alphas[pix[i]] = 1.f - T[i];
+        const float Tf = done[i] ? Tkeep[i] : T[i];
+        a.render_alphas[pix[i]] = 1.f - Tf;
 #pragma unroll
         for (int k = 0; k < CDIM; ++k)
             if ((uint32_t)k < cnt)
-                a.render_colors[pix[i] * a.channels + ch_off + k] = bg ? out[i][k] + T[i] * bg[k] : out[i][k];
+                a.render_colors[pix[i] * a.channels + ch_off + k] = bg ? out[i][k] + Tf * bg[k] : out[i][k];
         a.last_ids[pix[i]] = cur[i];
     }
 }
