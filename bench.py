@@ -226,7 +226,7 @@ def main():
         stats = dict(N=N, V=int((meta["radii"] > 0).sum()), I=int(meta["flatten_ids"].numel()),
                      P=w["width"] * w["height"], T=meta["tile_width"] * meta["tile_height"], K=(args.sh_degree + 1) ** 2)
         alg = algorithmic_bytes(stats)
-        achieved = alg[dominant] / (dom_ms * 1e-3) / 1e9
+        achieved = alg.get(dominant, 0) / (dom_ms * 1e-3) / 1e9
         total_alg = sum(alg.values())
         out = {
             "metric": "Msplats/s fwd+bwd @1080p (1M splats)",
@@ -243,7 +243,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": dom_ms,
-                "algorithmic_bytes": alg[dominant],
+                "algorithmic_bytes": alg.get(dominant, 0),
                 "whole_step": {"algorithmic_bytes": total_alg, "achieved": total_alg / (ms_per_step * 1e-3) / 1e9,
                                "frac": total_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "per_entry_point_ms": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},

@@ -459,31 +459,44 @@ def isect_tiles(
     assert tile_n_bits + cam_n_bits <= 32, "tile_n_bits + cam_n_bits must be <= 32"
 
     tiles_per_gauss = torch.empty(radii.shape, dtype=torch.int32, device=dev)
+
+    def _sort(n, keys, vals, begin_bit, end_bit):
+        ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+        tb = B.query("gs_sort_temp_bytes", n)
+        temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+        B.call("gs_sort_pairs_u64_i32", n, B.ptr(keys), B.ptr(vals), B.ptr(ko), B.ptr(vo), begin_bit, end_bit,
+               B.ptr(temp), tb, st)
+        return ko, vo
+
     with _device_of(means2d):
         n_isects = 0
         cum = None
+        perm = None
         if n_elems > 0:
             B.call("gs_isect_count", n_elems, B.ptr(means2d), B.ptr(radii), tile_size, tile_width, tile_height,
                    B.ptr(tiles_per_gauss), st)
+            counts = tiles_per_gauss
+            if sort:
+                # splat-level depth pre-sort: afterwards only the (camera, tile) bits need sorting
+                dkeys = torch.empty(n_elems, dtype=torch.int64, device=dev)
+                dvals = torch.empty(n_elems, dtype=torch.int32, device=dev)
+                B.call("gs_isect_depth_keys", n_elems, B.ptr(radii), B.ptr(depths), B.ptr(dkeys), B.ptr(dvals), st)
+                _, perm = _sort(n_elems, dkeys, dvals, 32, 64)
+                counts = torch.empty(n_elems, dtype=torch.int32, device=dev)
+                B.call("gs_gather_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(perm), B.ptr(counts), st)
             cum = torch.empty(n_elems, dtype=torch.int64, device=dev)
             sb = B.query("gs_cumsum_scratch_bytes", n_elems)
             scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
-            B.call("gs_cumsum_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(cum), B.ptr(scratch), sb, st)
+            B.call("gs_cumsum_i32", n_elems, B.ptr(counts), B.ptr(cum), B.ptr(scratch), sb, st)
             n_isects = int(cum[-1].item())  # the one host sync (isect_tiles.cu:200)
         isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
         flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
         if n_isects > 0:
-            B.call("gs_isect_emit", n_elems, max(N, 1), B.ptr(camera_ids), B.ptr(means2d), B.ptr(radii),
+            B.call("gs_isect_emit", n_elems, max(N, 1), B.ptr(perm), B.ptr(camera_ids), B.ptr(means2d), B.ptr(radii),
                    B.ptr(depths), B.ptr(cum), tile_size, tile_width, tile_height, tile_n_bits, B.ptr(isect_ids),
                    B.ptr(flatten_ids), st)
             if sort:
-                ids_sorted = torch.empty_like(isect_ids)
-                flat_sorted = torch.empty_like(flatten_ids)
-                tb = B.query("gs_sort_temp_bytes", n_isects)
-                temp = torch.empty(tb, dtype=torch.uint8, device=dev)
-                B.call("gs_sort_pairs_u64_i32", n_isects, B.ptr(isect_ids), B.ptr(flatten_ids), B.ptr(ids_sorted),
-                       B.ptr(flat_sorted), 0, 32 + tile_n_bits + cam_n_bits, B.ptr(temp), tb, st)
-                isect_ids, flatten_ids = ids_sorted, flat_sorted
+                isect_ids, flatten_ids = _sort(n_isects, isect_ids, flatten_ids, 32, 32 + tile_n_bits + cam_n_bits)
     return tiles_per_gauss, isect_ids, flatten_ids
 
 

@@ -44,14 +44,35 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_count_kernel(
     tiles_per_gauss[i] = cnt;
 }
 
+// Depth keys for the splat-level pre-sort: (float_bits(depth) << 32) | element for visible
+// elements, a maximal positive key for culled ones (they sort last and emit nothing).
+__global__ void __launch_bounds__(GS_BLOCK) isect_depth_keys_kernel(
+    uint32_t n_elems, const int32_t *__restrict__ radii, const float *__restrict__ depths,
+    int64_t *__restrict__ keys, int32_t *__restrict__ vals) {
+    uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (i >= n_elems) return;
+    uint32_t d = radii[i] > 0 ? (uint32_t)__float_as_int(depths[i]) & 0x7fffffffu : 0x7fffffffu;
+    keys[i] = (int64_t)(((uint64_t)d << 32) | (uint64_t)i);
+    vals[i] = (int32_t)i;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) gather_i32_kernel(
+    uint32_t n, const int32_t *__restrict__ src, const int32_t *__restrict__ idx, int32_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+
 __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
-    uint32_t n_elems, uint32_t N, const int64_t *__restrict__ camera_ids,
+    uint32_t n_elems, uint32_t N, const int32_t *__restrict__ perm, const int64_t *__restrict__ camera_ids,
     const float *__restrict__ means2d, const int32_t *__restrict__ radii,
     const float *__restrict__ depths, const int64_t *__restrict__ cum_tiles,
     float tile_size, int32_t tw, int32_t th, uint32_t tile_n_bits,
     int64_t *__restrict__ isect_ids, int32_t *__restrict__ flatten_ids) {
-    uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x;
-    if (i >= n_elems) return;
+    // `pos` = position in the emission order (identity, or depth-sorted when perm is given);
+    // `i` = the element it refers to.  cum_tiles is indexed by position.
+    uint32_t pos = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (pos >= n_elems) return;
+    uint32_t i = perm != nullptr ? (uint32_t)perm[pos] : pos;
     int32_t r = radii[i];
     if (r <= 0) return;
     float2 m = reinterpret_cast<const float2 *>(means2d)[i];
@@ -61,7 +82,7 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
     // raw IEEE bits of the (positive) depth, sign-extended like the reference's
     // (int64_t)*(int32_t*)&depth  (isect_tiles.cu:91)
     int64_t depth_enc = (int64_t)__float_as_int(depths[i]);
-    int64_t cur = (i == 0) ? 0 : cum_tiles[i - 1];
+    int64_t cur = (pos == 0) ? 0 : cum_tiles[pos - 1];
     for (int32_t y = b.y0; y < b.y1; ++y) {
         for (int32_t x = b.x0; x < b.x1; ++x) {
             int64_t tile_id = (int64_t)y * tw + x;
@@ -238,8 +259,26 @@ extern "C" int32_t gs_cumsum_i32_i32(
     return 0;
 }
 
+extern "C" int32_t gs_isect_depth_keys(
+    uint32_t n_elems, const int32_t *radii, const float *depths, int64_t *keys, int32_t *vals, gs_stream_t stream) {
+    if (n_elems == 0) return 0;
+    GS_CHECK_ARG(radii && depths && keys && vals, "null pointer");
+    hipLaunchKernelGGL(isect_depth_keys_kernel, dim3(gs_div_up(n_elems, GS_BLOCK)), dim3(GS_BLOCK), 0,
+                       (hipStream_t)stream, n_elems, radii, depths, keys, vals);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_gather_i32(uint32_t n, const int32_t *src, const int32_t *idx, int32_t *out, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(src && idx && out, "null pointer");
+    hipLaunchKernelGGL(gather_i32_kernel, dim3(gs_div_up(n, GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream, n, src, idx, out);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int32_t gs_isect_emit(
-    uint32_t n_elems, uint32_t N, const int64_t *camera_ids, const float *means2d,
+    uint32_t n_elems, uint32_t N, const int32_t *perm, const int64_t *camera_ids, const float *means2d,
     const int32_t *radii, const float *depths, const int64_t *cum_tiles_per_gauss,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits,
     int64_t *isect_ids, int32_t *flatten_ids, gs_stream_t stream) {
@@ -248,7 +287,7 @@ extern "C" int32_t gs_isect_emit(
     GS_CHECK_ARG(camera_ids != nullptr || N > 0, "N must be > 0 when camera_ids is NULL");
     GS_CHECK_ARG(tile_n_bits < 32, "tile_n_bits must be < 32");
     hipLaunchKernelGGL(isect_emit_kernel, dim3(gs_div_up(n_elems, GS_BLOCK)), dim3(GS_BLOCK), 0,
-                       (hipStream_t)stream, n_elems, N, camera_ids, means2d, radii, depths,
+                       (hipStream_t)stream, n_elems, N, perm, camera_ids, means2d, radii, depths,
                        cum_tiles_per_gauss, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
                        tile_n_bits, isect_ids, flatten_ids);
     GS_CHECK_LAUNCH();

@@ -33,6 +33,26 @@ from ._wrapper import (
 )
 
 
+def _camera_centers(viewmats: Tensor) -> Tensor:
+    """Camera positions in world space, ``inverse(viewmats)[:, :3, 3]``, in closed form.
+
+    The reference calls ``torch.inverse(viewmats)`` (rendering.py:370); on ROCm that goes through
+    a batched LU with a host-side status check, i.e. a device synchronisation of ~0.5 ms in the
+    middle of every step (measured: tools/cpu_prof.py).  For an affine world->camera matrix
+    [[A, t], [0, 1]] the inverse's translation is -A^-1 t, and A^-1 = adj(A) / det(A) is three
+    cross products -- a handful of tiny asynchronous kernels, differentiable through autograd.
+    """
+    A = viewmats[:, :3, :3]
+    t = viewmats[:, :3, 3]
+    c0, c1, c2 = A[:, :, 0], A[:, :, 1], A[:, :, 2]
+    r0 = torch.linalg.cross(c1, c2)
+    r1 = torch.linalg.cross(c2, c0)
+    r2 = torch.linalg.cross(c0, c1)
+    det = (c0 * r0).sum(-1, keepdim=True)
+    inv_t = torch.stack([(r0 * t).sum(-1), (r1 * t).sum(-1), (r2 * t).sum(-1)], dim=-1) / det
+    return -inv_t
+
+
 def rasterization(
     means: Tensor,  # [N, 3]
     quats: Tensor,  # [N, 4]
@@ -166,14 +186,14 @@ def rasterization(
             if colors.dim() == 2:
                 colors = colors.expand(C, -1, -1)
     else:
-        camtoworlds = torch.inverse(viewmats)  # [C, 4, 4]
+        campos = _camera_centers(viewmats)  # [C, 3] == inverse(viewmats)[:, :3, 3]
         if packed:
-            dirs = means[gaussian_ids, :] - camtoworlds[camera_ids, :3, 3]  # [nnz, 3]
+            dirs = means[gaussian_ids, :] - campos[camera_ids]  # [nnz, 3]
             masks = radii > 0
             shs = colors[gaussian_ids, :, :] if colors.dim() == 3 else colors[camera_ids, gaussian_ids, :, :]
             colors = spherical_harmonics(sh_degree, dirs, shs, masks=masks)  # [nnz, 3]
         else:
-            dirs = means[None, :, :] - camtoworlds[:, None, :3, 3]  # [C, N, 3]
+            dirs = means[None, :, :] - campos[:, None, :]  # [C, N, 3]
             masks = radii > 0  # [C, N]
             if colors.dim() == 3:
                 colors = spherical_harmonics_shared(sh_degree, dirs, colors, masks=masks)  # [C, N, 3]

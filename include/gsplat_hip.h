@@ -197,11 +197,25 @@ int32_t gs_cumsum_i32_i32(
     uint64_t n, const int32_t *in, int32_t *out,
     void *scratch, size_t scratch_bytes, gs_stream_t stream);
 
+/* Splat-level depth pre-sort (an optimisation of the sorted path, results identical):
+ * keys[i] = float_bits(depth_i) << 32 | i for visible elements, a maximal key for culled ones.
+ * Sorting them (gs_sort_pairs_u64_i32, bits [32,64)) gives a permutation `perm` in (depth, index)
+ * order; emitting the intersections in that order (gs_isect_emit with perm, cum_tiles being the
+ * prefix sum of gs_gather_i32(tiles_per_gauss, perm)) leaves only the (camera, tile) bits
+ * [32, 32+tile_bits+cam_bits) to be sorted afterwards -- 2 radix passes over the n_isects pairs
+ * instead of 6 -- and, the radix sort being stable, yields exactly the order of a full-key sort
+ * of the reference's emission order (ties: ascending flatten id). */
+int32_t gs_isect_depth_keys(
+    uint32_t n_elems, const int32_t *radii, const float *depths,
+    int64_t *keys, int32_t *vals, gs_stream_t stream);
+int32_t gs_gather_i32(uint32_t n, const int32_t *src, const int32_t *idx, int32_t *out, gs_stream_t stream);
+
 int32_t gs_isect_emit(
     uint32_t n_elems, uint32_t N,   /* camera of element i = i / N when camera_ids NULL */
+    const int32_t *perm,            /* [n_elems] emission order or NULL (identity) */
     const int64_t *camera_ids,      /* [nnz] or NULL */
     const float *means2d, const int32_t *radii, const float *depths,
-    const int64_t *cum_tiles_per_gauss, /* inclusive */
+    const int64_t *cum_tiles_per_gauss, /* inclusive, indexed by emission position */
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
     uint32_t tile_n_bits,
     int64_t *isect_ids,   /* [n_isects] */
