@@ -34,6 +34,26 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# PMC traffic (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 correction applied)
+# measured for this workload and committed under profiles/; bench.py cannot run rocprof on itself.
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+KERNEL_OF_ENTRY = {"gs_rasterize_bwd": "raster_seg_bwd_kernel", "gs_rasterize_fwd": "raster_wave_fwd_kernel",
+                   "gs_sh_view_bwd": "sh_bwd_kernel", "gs_sort_pairs_u64_i32": "sort_scatter_kernel"}
+
+
+def measured_traffic(entry, workload_key):
+    """HBM bytes per launch of the kernel behind `entry` from the committed PMC summary, or None."""
+    try:
+        d = json.load(open(TRAFFIC_JSON))
+        if d.get("workload_key") != workload_key:
+            return None
+        frag = KERNEL_OF_ENTRY.get(entry)
+        for name, v in d["kernels"].items():
+            if frag and frag in name:
+                return v["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def parse():
@@ -92,6 +112,10 @@ def algorithmic_bytes(stats):
     return {
         "gs_projection_fwd": 40 * N + 4 * N + 24 * V,
         "gs_sh_fwd": (12 + 12 * K) * V + 12 * V,
+        "gs_sh_view_fwd": (12 + 12 * K) * V + 12 * V + 4 * N,
+        "gs_sh_view_bwd": (24 + 12 * K) * V + 12 * K * N + 12 * V + 12 * N,
+        "gs_isect_depth_keys": 8 * N + 12 * N,
+        "gs_gather_i32": 12 * N,
         "gs_isect_count": 12 * N + 4 * N,
         "gs_cumsum_i32": 4 * N + 8 * N,
         "gs_isect_emit": 24 * V + 12 * I,
@@ -242,7 +266,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": dom_ms,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": measured_traffic(dominant, f"grid{args.scene_grid}_{w['width']}x{w['height']}_sh{args.sh_degree}"),
+                "kernel_ms": dom_ms,
                 "algorithmic_bytes": alg.get(dominant, 0),
                 "whole_step": {"algorithmic_bytes": total_alg, "achieved": total_alg / (ms_per_step * 1e-3) / 1e9,
                                "frac": total_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -113,6 +113,80 @@ def spherical_harmonics_shared(
     return _SphericalHarmonics.apply(degrees_to_use, dirs.contiguous(), coeffs.contiguous(), masks, True)
 
 
+def _row_strided(t: Tensor, width: int):
+    """(tensor, row_stride) for a [..., width] gradient that is either contiguous or a column
+    slice of a wider row-major buffer (e.g. the packed [n_elems,16] compositing gradients): such
+    views are consumed in place by the kernels instead of being copied by ``.contiguous()``."""
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32 tensor, got {t.dtype}")
+    if t.is_contiguous():
+        return t, width
+    if t.dim() >= 2 and t.shape[-1] == width and t.stride(-1) == 1:
+        rs = t.stride(-2)
+        expect = rs
+        ok = True
+        for d in range(t.dim() - 2, -1, -1):
+            if t.shape[d] != 1 and t.stride(d) != expect:
+                ok = False
+                break
+            expect *= t.shape[d]
+        if ok and rs >= width:
+            return t, rs
+    return t.contiguous(), width
+
+
+def spherical_harmonics_view(
+    degrees_to_use: int,
+    means: Tensor,  # [N, 3]
+    campos: Tensor,  # [C, 3] camera centres in world space
+    coeffs: Tensor,  # [N, K, 3] shared by all cameras
+    radii: Optional[Tensor] = None,  # [C, N] int32: evaluate only where radii > 0
+) -> Tensor:
+    """Fused colour evaluation used by ``rasterization``:
+    ``clamp_min(spherical_harmonics(deg, means[None] - campos[:, None], coeffs, radii > 0) + 0.5, 0)``
+    (reference rendering.py:372-392) in ONE kernel each way -- no ``dirs`` / mask / clamp
+    tensors, and the backward writes ``v_means`` (summed over cameras) directly."""
+    C, N = campos.shape[0], means.shape[0]
+    assert means.shape == (N, 3) and campos.shape == (C, 3), (means.shape, campos.shape)
+    assert coeffs.dim() == 3 and coeffs.shape[0] == N and coeffs.shape[2] == 3, coeffs.shape
+    assert (degrees_to_use + 1) ** 2 <= coeffs.shape[-2], coeffs.shape
+    if radii is not None:
+        assert radii.shape == (C, N) and radii.dtype == torch.int32, (radii.shape, radii.dtype)
+    return _SphericalHarmonicsView.apply(degrees_to_use, means.contiguous(), campos.contiguous(), coeffs.contiguous(),
+                                         radii.contiguous() if radii is not None else None)
+
+
+class _SphericalHarmonicsView(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sh_degree, means, campos, coeffs, radii):
+        _require_gpu(coeffs, "spherical_harmonics_view")
+        means, campos, coeffs = _f32c(means), _f32c(campos), _f32c(coeffs)
+        C, N, K = campos.shape[0], means.shape[0], coeffs.shape[1]
+        colors = torch.empty((C, N, 3), dtype=torch.float32, device=means.device)
+        with _device_of(means):
+            B.call("gs_sh_view_fwd", C, N, K, sh_degree, B.ptr(means), B.ptr(campos), B.ptr(coeffs), B.ptr(radii),
+                   B.ptr(colors), _stream(means))
+        ctx.save_for_backward(means, campos, coeffs, radii, colors)
+        ctx.sh_degree = sh_degree
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        means, campos, coeffs, radii, colors = ctx.saved_tensors
+        C, N, K = campos.shape[0], means.shape[0], coeffs.shape[1]
+        v_colors, vstride = _row_strided(v_colors, 3)
+        v_coeffs = torch.empty_like(coeffs)
+        v_means = torch.empty_like(means) if ctx.needs_input_grad[1] else None
+        with _device_of(means):
+            B.call("gs_sh_view_bwd", C, N, K, ctx.sh_degree, B.ptr(means), B.ptr(campos), B.ptr(coeffs), B.ptr(radii),
+                   B.ptr(colors), B.ptr(v_colors), vstride, B.ptr(v_coeffs), B.ptr(v_means), _stream(means))
+        if not ctx.needs_input_grad[3]:
+            v_coeffs = None
+        # campos (camera poses) gets no gradient on this path; rasterization() takes the unfused
+        # route when viewmats require grad.
+        return None, v_means, None, v_coeffs, None
+
+
 class _SphericalHarmonics(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sh_degree: int, dirs: Tensor, coeffs: Tensor, masks: Optional[Tensor],
@@ -297,7 +371,8 @@ class _FullyFusedProjection(torch.autograd.Function):
         means, covars, quats, scales, viewmats, Ks, radii, conics, compensations = ctx.saved_tensors
         C, N = viewmats.shape[0], means.shape[0]
         dev = means.device
-        v_means2d, v_depths, v_conics = _f32c(v_means2d), _f32c(v_depths), _f32c(v_conics)
+        (v_means2d, s_m2), (v_conics, s_cn) = _row_strided(v_means2d, 2), _row_strided(v_conics, 3)
+        v_depths = _f32c(v_depths)
         v_compensations = _f32c(v_compensations) if v_compensations is not None else None
         need = ctx.needs_input_grad
         # rows are fully written by the kernel -> empty, not zeros
@@ -311,7 +386,7 @@ class _FullyFusedProjection(torch.autograd.Function):
                    B.ptr(viewmats), B.ptr(Ks), int(ctx.width), int(ctx.height), float(ctx.eps2d), ctx.cm,
                    B.ptr(radii), B.ptr(conics), B.ptr(compensations), B.ptr(v_means2d), B.ptr(v_depths),
                    B.ptr(v_conics), B.ptr(v_compensations), B.ptr(v_means), B.ptr(v_covars), B.ptr(v_quats),
-                   B.ptr(v_scales), B.ptr(v_viewmats), _stream(means))
+                   B.ptr(v_scales), B.ptr(v_viewmats), s_m2, s_cn, _stream(means))
         return (v_means, v_covars, v_quats, v_scales, v_viewmats) + (None,) * 9
 
 

@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
     const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
     const float *__restrict__ v_conics, const float *__restrict__ v_compensations,
     float *__restrict__ v_means, float *__restrict__ v_covars, float *__restrict__ v_quats,
-    float *__restrict__ v_scales, float *__restrict__ v_viewmats) {
+    float *__restrict__ v_scales, float *__restrict__ v_viewmats, uint32_t s_m2, uint32_t s_cn) {
     __shared__ float s_view[GS_BLOCK / GS_WAVE][12];
     uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
     bool in_range = n < N;
@@ -467,8 +467,8 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
                 cam, px, py, pz, S, W, H, eps2d, camera_model,
                 conics[3 * idx], conics[3 * idx + 1], conics[3 * idx + 2],
                 has_comp ? compensations[idx] : 0.f, has_comp ? v_compensations[idx] : 0.f, has_comp,
-                v_means2d[2 * idx], v_means2d[2 * idx + 1], v_depths[idx],
-                v_conics[3 * idx], v_conics[3 * idx + 1], v_conics[3 * idx + 2], g);
+                v_means2d[s_m2 * idx], v_means2d[s_m2 * idx + 1], v_depths[idx],
+                v_conics[s_cn * idx], v_conics[s_cn * idx + 1], v_conics[s_cn * idx + 2], g);
             any = true;
         }
         if (NEED_VIEW) {
@@ -703,9 +703,11 @@ extern "C" int32_t gs_projection_bwd(
     int32_t image_height, float eps2d, int32_t camera_model, const int32_t *radii,
     const float *conics, const float *compensations, const float *v_means2d,
     const float *v_depths, const float *v_conics, const float *v_compensations, float *v_means,
-    float *v_covars, float *v_quats, float *v_scales, float *v_viewmats, gs_stream_t stream) {
+    float *v_covars, float *v_quats, float *v_scales, float *v_viewmats, uint32_t v_means2d_stride,
+    uint32_t v_conics_stride, gs_stream_t stream) {
     GS_CHECK_ARG(means && viewmats && Ks && radii && conics && v_means2d && v_depths && v_conics,
                  "null pointer");
+    GS_CHECK_ARG(v_means2d_stride >= 2 && v_conics_stride >= 3, "bad gradient row strides");
     GS_CHECK_ARG((covars != nullptr) != (quats != nullptr && scales != nullptr),
                  "exactly one of covars / (quats, scales) must be given");
     GS_CHECK_ARG((v_compensations == nullptr) || (compensations != nullptr),
@@ -716,12 +718,14 @@ extern "C" int32_t gs_projection_bwd(
         hipLaunchKernelGGL(projection_bwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
                            means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
                            camera_model, radii, conics, compensations, v_means2d, v_depths, v_conics,
-                           v_compensations, v_means, v_covars, v_quats, v_scales, v_viewmats);
+                           v_compensations, v_means, v_covars, v_quats, v_scales, v_viewmats, v_means2d_stride,
+                           v_conics_stride);
     } else {
         hipLaunchKernelGGL(projection_bwd_kernel<false>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
                            means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
                            camera_model, radii, conics, compensations, v_means2d, v_depths, v_conics,
-                           v_compensations, v_means, v_covars, v_quats, v_scales, v_viewmats);
+                           v_compensations, v_means, v_covars, v_quats, v_scales, v_viewmats, v_means2d_stride,
+                           v_conics_stride);
     }
     GS_CHECK_LAUNCH();
     return 0;

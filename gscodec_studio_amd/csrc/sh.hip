@@ -168,20 +168,47 @@ GS_DEV void zero_row(float *__restrict__ p, uint32_t row_len) {
     }
 }
 
+// "View" mode (used by rasterization()): directions are means[n] - campos[c] computed in-kernel,
+// the mask is radii[c,n] > 0 and the output is clamp_min(colour + 0.5, 0) -- i.e. the torch ops
+// around the reference's spherical_harmonics call (rendering.py:372-392) are fused in.
+struct ShView {
+    const float *means;   // [N,3] or nullptr (then `dirs` is used)
+    const float *campos;  // [C,3]
+    const int32_t *radii; // [C,N] or nullptr
+    int clamp_half;       // colour = max(colour + 0.5, 0)
+};
+
+GS_DEV bool sh_active(const uint8_t *masks, const ShView &v, size_t e) {
+    if (masks != nullptr) return masks[e] != 0;
+    if (v.radii != nullptr) return v.radii[e] > 0;
+    return true;
+}
+
+GS_DEV void sh_dir(const float *dirs, const ShView &v, uint32_t c, uint32_t n, size_t e, float &dx, float &dy, float &dz) {
+    if (v.means != nullptr) {
+        dx = v.means[3 * (size_t)n] - v.campos[3 * c];
+        dy = v.means[3 * (size_t)n + 1] - v.campos[3 * c + 1];
+        dz = v.means[3 * (size_t)n + 2] - v.campos[3 * c + 2];
+    } else {
+        dx = dirs[3 * e]; dy = dirs[3 * e + 1]; dz = dirs[3 * e + 2];
+    }
+}
+
 template <int DEG, bool VEC>
 __global__ void __launch_bounds__(GS_BLOCK) sh_fwd_kernel(
     uint32_t C, uint32_t N, uint32_t K, const float *__restrict__ dirs,
     const float *__restrict__ coeffs, int shared, const uint8_t *__restrict__ masks,
-    float *__restrict__ colors) {
+    float *__restrict__ colors, ShView view) {
     constexpr int NB = ShDim<DEG>::NB;
     uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
     uint32_t c = blockIdx.y;
     if (n >= N) return;
     size_t e = (size_t)c * N + n;
-    if (masks != nullptr && !masks[e]) return;
+    if (!sh_active(masks, view, e)) return;
     float Y[NB];
     if (DEG >= 1) {
-        float dx = dirs[3 * e], dy = dirs[3 * e + 1], dz = dirs[3 * e + 2];
+        float dx, dy, dz;
+        sh_dir(dirs, view, c, n, e, dx, dy, dz);
         float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
         sh_basis<DEG>(dx * inv, dy * inv, dz * inv, Y);
     } else {
@@ -197,6 +224,11 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_fwd_kernel(
         g += Y[k] * cf[3 * k + 1];
         b += Y[k] * cf[3 * k + 2];
     }
+    if (view.clamp_half) {
+        r = fmaxf(r + 0.5f, 0.f);
+        g = fmaxf(g + 0.5f, 0.f);
+        b = fmaxf(b + 0.5f, 0.f);
+    }
     colors[3 * e] = r;
     colors[3 * e + 1] = g;
     colors[3 * e + 2] = b;
@@ -209,10 +241,12 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
     uint32_t C, uint32_t N, uint32_t K, const float *__restrict__ dirs,
     const float *__restrict__ coeffs, const uint8_t *__restrict__ masks,
     const float *__restrict__ v_colors, float *__restrict__ v_coeffs,
-    float *__restrict__ v_dirs) {
+    float *__restrict__ v_dirs, ShView view, const float *__restrict__ colors_out, uint32_t v_colors_stride,
+    float *__restrict__ v_means) {
     constexpr int NB = ShDim<DEG>::NB;
     uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
     if (n >= N) return;
+    float vmx = 0.f, vmy = 0.f, vmz = 0.f; // view mode: d/d means = sum over cameras of d/d dirs
     const uint32_t row_len = K * 3;
     float acc[NB * 3];
     if (SHARED) {
@@ -223,7 +257,7 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
     bool have_cf = false;
     for (uint32_t c = 0; c < C; ++c) {
         size_t e = (size_t)c * N + n;
-        bool on = masks == nullptr || masks[e];
+        bool on = sh_active(masks, view, e);
         if (!on) {
             if (!SHARED) zero_row<VEC>(v_coeffs + e * row_len, row_len);
             if (v_dirs != nullptr) {
@@ -231,11 +265,18 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
             }
             continue;
         }
-        float vr = v_colors[3 * e], vg = v_colors[3 * e + 1], vb = v_colors[3 * e + 2];
+        const float *vcp = v_colors + e * v_colors_stride;
+        float vr = vcp[0], vg = vcp[1], vb = vcp[2];
+        if (view.clamp_half) { // gradient of clamp_min(colour + 0.5, 0): passes where the output is > 0
+            if (!(colors_out[3 * e] > 0.f)) vr = 0.f;
+            if (!(colors_out[3 * e + 1] > 0.f)) vg = 0.f;
+            if (!(colors_out[3 * e + 2] > 0.f)) vb = 0.f;
+        }
         float Y[NB];
         float x = 0.f, y = 0.f, z = 1.f, inv = 1.f;
         if (DEG >= 1) {
-            float dx = dirs[3 * e], dy = dirs[3 * e + 1], dz = dirs[3 * e + 2];
+            float dx, dy, dz;
+            sh_dir(dirs, view, c, n, e, dx, dy, dz);
             inv = rsqrtf(dx * dx + dy * dy + dz * dz);
             x = dx * inv; y = dy * inv; z = dz * inv;
         }
@@ -257,7 +298,7 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
             }
             store_row<NB * 3, VEC>(v_coeffs + e * row_len, out, row_len);
         }
-        if (v_dirs != nullptr) {
+        if (v_dirs != nullptr || v_means != nullptr) {
             float gx = 0.f, gy = 0.f, gz = 0.f;
             if (DEG >= 1) {
                 if (!SHARED || !have_cf) {
@@ -274,30 +315,36 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
                 gy = (vy - dot * y) * inv;
                 gz = (vz - dot * z) * inv;
             }
-            v_dirs[3 * e] = gx; v_dirs[3 * e + 1] = gy; v_dirs[3 * e + 2] = gz;
+            if (v_dirs != nullptr) {
+                v_dirs[3 * e] = gx; v_dirs[3 * e + 1] = gy; v_dirs[3 * e + 2] = gz;
+            }
+            vmx += gx; vmy += gy; vmz += gz;
         }
     }
     if (SHARED) store_row<NB * 3, VEC>(v_coeffs + (size_t)n * row_len, acc, row_len);
+    if (v_means != nullptr) {
+        v_means[3 * (size_t)n] = vmx; v_means[3 * (size_t)n + 1] = vmy; v_means[3 * (size_t)n + 2] = vmz;
+    }
 }
 
 bool rows_vectorizable(const void *p, uint32_t K) { return ((uintptr_t)p % 16 == 0) && ((K * 3) % 4 == 0); }
 
 template <int DEG>
 void launch_fwd(bool vec, dim3 grid, hipStream_t st, uint32_t C, uint32_t N, uint32_t K, const float *dirs,
-                const float *coeffs, int shared, const uint8_t *masks, float *colors) {
+                const float *coeffs, int shared, const uint8_t *masks, float *colors, ShView view) {
     if (vec)
-        hipLaunchKernelGGL((sh_fwd_kernel<DEG, true>), grid, dim3(GS_BLOCK), 0, st, C, N, K, dirs, coeffs, shared, masks, colors);
+        hipLaunchKernelGGL((sh_fwd_kernel<DEG, true>), grid, dim3(GS_BLOCK), 0, st, C, N, K, dirs, coeffs, shared, masks, colors, view);
     else
-        hipLaunchKernelGGL((sh_fwd_kernel<DEG, false>), grid, dim3(GS_BLOCK), 0, st, C, N, K, dirs, coeffs, shared, masks, colors);
+        hipLaunchKernelGGL((sh_fwd_kernel<DEG, false>), grid, dim3(GS_BLOCK), 0, st, C, N, K, dirs, coeffs, shared, masks, colors, view);
 }
 
 template <int DEG>
 void launch_bwd(bool vec, bool shared, dim3 grid, hipStream_t st, uint32_t C, uint32_t N, uint32_t K,
                 const float *dirs, const float *coeffs, const uint8_t *masks, const float *v_colors,
-                float *v_coeffs, float *v_dirs) {
+                float *v_coeffs, float *v_dirs, ShView view, const float *colors_out, uint32_t vstride, float *v_means) {
 #define GS_SH_BWD(V, S)                                                                               \
     hipLaunchKernelGGL((sh_bwd_kernel<DEG, V, S>), grid, dim3(GS_BLOCK), 0, st, C, N, K, dirs, coeffs, \
-                       masks, v_colors, v_coeffs, v_dirs)
+                       masks, v_colors, v_coeffs, v_dirs, view, colors_out, vstride, v_means)
     if (vec && shared) GS_SH_BWD(true, true);
     else if (vec) GS_SH_BWD(true, false);
     else if (shared) GS_SH_BWD(false, true);
@@ -318,12 +365,35 @@ extern "C" int32_t gs_sh_fwd(
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K);
+    ShView view = {nullptr, nullptr, nullptr, 0};
     switch (degree) {
-        case 0: launch_fwd<0>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors); break;
-        case 1: launch_fwd<1>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors); break;
-        case 2: launch_fwd<2>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors); break;
-        case 3: launch_fwd<3>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors); break;
-        default: launch_fwd<4>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors); break;
+        case 0: launch_fwd<0>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
+        case 1: launch_fwd<1>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
+        case 2: launch_fwd<2>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
+        case 3: launch_fwd<3>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
+        default: launch_fwd<4>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
+    }
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_sh_view_fwd(
+    uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos,
+    const float *coeffs, const int32_t *radii, float *colors, gs_stream_t stream) {
+    GS_CHECK_ARG(means && campos && coeffs && colors, "null pointer");
+    GS_CHECK_ARG(degree <= 4, "degree must be <= 4");
+    GS_CHECK_ARG((degree + 1) * (degree + 1) <= K, "K too small for degree");
+    if (C == 0 || N == 0) return 0;
+    dim3 grid(gs_div_up(N, GS_BLOCK), C);
+    hipStream_t st = (hipStream_t)stream;
+    bool vec = rows_vectorizable(coeffs, K);
+    ShView view = {means, campos, radii, 1};
+    switch (degree) {
+        case 0: launch_fwd<0>(vec, grid, st, C, N, K, nullptr, coeffs, 1, nullptr, colors, view); break;
+        case 1: launch_fwd<1>(vec, grid, st, C, N, K, nullptr, coeffs, 1, nullptr, colors, view); break;
+        case 2: launch_fwd<2>(vec, grid, st, C, N, K, nullptr, coeffs, 1, nullptr, colors, view); break;
+        case 3: launch_fwd<3>(vec, grid, st, C, N, K, nullptr, coeffs, 1, nullptr, colors, view); break;
+        default: launch_fwd<4>(vec, grid, st, C, N, K, nullptr, coeffs, 1, nullptr, colors, view); break;
     }
     GS_CHECK_LAUNCH();
     return 0;
@@ -342,12 +412,37 @@ extern "C" int32_t gs_sh_bwd(
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K) && rows_vectorizable(v_coeffs, K);
     bool shared = coeffs_shared != 0;
+    ShView view = {nullptr, nullptr, nullptr, 0};
     switch (degree) {
-        case 0: launch_bwd<0>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
-        case 1: launch_bwd<1>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
-        case 2: launch_bwd<2>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
-        case 3: launch_bwd<3>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
-        default: launch_bwd<4>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
+        case 0: launch_bwd<0>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
+        case 1: launch_bwd<1>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
+        case 2: launch_bwd<2>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
+        case 3: launch_bwd<3>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
+        default: launch_bwd<4>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
+    }
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_sh_view_bwd(
+    uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos,
+    const float *coeffs, const int32_t *radii, const float *colors_out, const float *v_colors,
+    uint32_t v_colors_stride, float *v_coeffs, float *v_means, gs_stream_t stream) {
+    GS_CHECK_ARG(means && campos && coeffs && colors_out && v_colors && v_coeffs, "null pointer");
+    GS_CHECK_ARG(degree <= 4, "degree must be <= 4");
+    GS_CHECK_ARG((degree + 1) * (degree + 1) <= K, "K too small for degree");
+    GS_CHECK_ARG(v_colors_stride >= 3, "v_colors_stride must be >= 3");
+    if (C == 0 || N == 0) return 0;
+    dim3 grid(gs_div_up(N, GS_BLOCK));
+    hipStream_t st = (hipStream_t)stream;
+    bool vec = rows_vectorizable(coeffs, K) && rows_vectorizable(v_coeffs, K);
+    ShView view = {means, campos, radii, 1};
+    switch (degree) {
+        case 0: launch_bwd<0>(vec, true, grid, st, C, N, K, nullptr, coeffs, nullptr, v_colors, v_coeffs, nullptr, view, colors_out, v_colors_stride, v_means); break;
+        case 1: launch_bwd<1>(vec, true, grid, st, C, N, K, nullptr, coeffs, nullptr, v_colors, v_coeffs, nullptr, view, colors_out, v_colors_stride, v_means); break;
+        case 2: launch_bwd<2>(vec, true, grid, st, C, N, K, nullptr, coeffs, nullptr, v_colors, v_coeffs, nullptr, view, colors_out, v_colors_stride, v_means); break;
+        case 3: launch_bwd<3>(vec, true, grid, st, C, N, K, nullptr, coeffs, nullptr, v_colors, v_coeffs, nullptr, view, colors_out, v_colors_stride, v_means); break;
+        default: launch_bwd<4>(vec, true, grid, st, C, N, K, nullptr, coeffs, nullptr, v_colors, v_coeffs, nullptr, view, colors_out, v_colors_stride, v_means); break;
     }
     GS_CHECK_LAUNCH();
     return 0;

@@ -30,6 +30,7 @@ from ._wrapper import (
     rasterize_to_pixels,
     spherical_harmonics,
     spherical_harmonics_shared,
+    spherical_harmonics_view,
 )
 
 
@@ -187,20 +188,27 @@ def rasterization(
                 colors = colors.expand(C, -1, -1)
     else:
         campos = _camera_centers(viewmats)  # [C, 3] == inverse(viewmats)[:, :3, 3]
+        fused_sh = False
         if packed:
             dirs = means[gaussian_ids, :] - campos[camera_ids]  # [nnz, 3]
             masks = radii > 0
             shs = colors[gaussian_ids, :, :] if colors.dim() == 3 else colors[camera_ids, gaussian_ids, :, :]
             colors = spherical_harmonics(sh_degree, dirs, shs, masks=masks)  # [nnz, 3]
         else:
-            dirs = means[None, :, :] - campos[:, None, :]  # [C, N, 3]
-            masks = radii > 0  # [C, N]
-            if colors.dim() == 3:
-                colors = spherical_harmonics_shared(sh_degree, dirs, colors, masks=masks)  # [C, N, 3]
+            if colors.dim() == 3 and not campos.requires_grad:
+                # fused: dirs, mask, SH and clamp_min(. + 0.5, 0) in one kernel each way
+                colors = spherical_harmonics_view(sh_degree, means, campos, colors, radii)  # [C, N, 3]
+                fused_sh = True
             else:
-                colors = spherical_harmonics(sh_degree, dirs, colors, masks=masks)  # [C, N, 3]
+                dirs = means[None, :, :] - campos[:, None, :]  # [C, N, 3]
+                masks = radii > 0  # [C, N]
+                if colors.dim() == 3:
+                    colors = spherical_harmonics_shared(sh_degree, dirs, colors, masks=masks)  # [C, N, 3]
+                else:
+                    colors = spherical_harmonics(sh_degree, dirs, colors, masks=masks)  # [C, N, 3]
         # same convention as the reference (rendering.py:392)
-        colors = torch.clamp_min(colors + 0.5, 0.0)
+        if not fused_sh:
+            colors = torch.clamp_min(colors + 0.5, 0.0)
 
     if distributed:
         from . import distributed as D

@@ -97,6 +97,8 @@ int32_t gs_projection_bwd(
     float *v_quats,   /* [N,4] or NULL */
     float *v_scales,  /* [N,3] or NULL */
     float *v_viewmats,/* [C,4,4] or NULL */
+    uint32_t v_means2d_stride, /* row stride of v_means2d in floats: 2, or 16 for the packed compositing rows */
+    uint32_t v_conics_stride,  /* row stride of v_conics in floats: 3, or 16 */
     gs_stream_t stream);
 
 /* packed (COO) projection, replaces fully_fused_projection_packed_fwd_tensor
@@ -171,6 +173,24 @@ int32_t gs_sh_bwd(
     const float *dirs, const float *coeffs, int32_t coeffs_shared,
     const uint8_t *masks, const float *v_colors,
     float *v_coeffs, float *v_dirs, gs_stream_t stream);
+
+/* Fused "view" form used by rasterization() for coefficients shared by all cameras: the torch
+ * ops around the reference's spherical_harmonics call (gsplat/rendering.py:372-392) are folded in:
+ *   dirs = means[n] - campos[c]   (campos = inverse(viewmats)[:, :3, 3], [C,3])
+ *   mask = radii[c,n] > 0         (radii may be NULL: no mask)
+ *   colors = max(SH + 0.5, 0)
+ * bwd: colors_out is the forward output (gradient of the clamp); v_colors may be a strided view
+ * (row stride v_colors_stride floats, e.g. 16 for the packed compositing gradient rows);
+ * v_coeffs [N,K,3] and v_means [N,3] (= sum over cameras of d/d dirs; may be NULL) are OVERWRITTEN. */
+int32_t gs_sh_view_fwd(
+    uint32_t C, uint32_t N, uint32_t K, uint32_t degree,
+    const float *means, const float *campos, const float *coeffs, const int32_t *radii,
+    float *colors, gs_stream_t stream);
+int32_t gs_sh_view_bwd(
+    uint32_t C, uint32_t N, uint32_t K, uint32_t degree,
+    const float *means, const float *campos, const float *coeffs, const int32_t *radii,
+    const float *colors_out, const float *v_colors, uint32_t v_colors_stride,
+    float *v_coeffs, float *v_means, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * R3 / R4  tile intersection, 64-bit radix sort, offset encode
