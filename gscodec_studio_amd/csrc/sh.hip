@@ -377,6 +377,33 @@ extern "C" int32_t gs_sh_fwd(
     return 0;
 }
 
+// camera centres: -A^-1 t of the affine world->camera matrix [[A, t], [0, 1]] (adjugate form)
+__global__ void camera_centers_kernel(uint32_t C, const float *__restrict__ viewmats, float *__restrict__ out) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float *V = viewmats + 16 * c;
+    float a00 = V[0], a01 = V[1], a02 = V[2], t0 = V[3];
+    float a10 = V[4], a11 = V[5], a12 = V[6], t1 = V[7];
+    float a20 = V[8], a21 = V[9], a22 = V[10], t2 = V[11];
+    // rows of adj(A) = cross products of the columns of A
+    float r00 = a11 * a22 - a21 * a12, r01 = a21 * a02 - a01 * a22, r02 = a01 * a12 - a11 * a02;
+    float r10 = a12 * a20 - a22 * a10, r11 = a22 * a00 - a02 * a20, r12 = a02 * a10 - a12 * a00;
+    float r20 = a10 * a21 - a20 * a11, r21 = a20 * a01 - a00 * a21, r22 = a00 * a11 - a10 * a01;
+    float det = a00 * r00 + a10 * r01 + a20 * r02;
+    float inv = 1.f / det;
+    out[3 * c] = -(r00 * t0 + r01 * t1 + r02 * t2) * inv;
+    out[3 * c + 1] = -(r10 * t0 + r11 * t1 + r12 * t2) * inv;
+    out[3 * c + 2] = -(r20 * t0 + r21 * t1 + r22 * t2) * inv;
+}
+
+extern "C" int32_t gs_camera_centers(uint32_t C, const float *viewmats, float *campos, gs_stream_t stream) {
+    if (C == 0) return 0;
+    GS_CHECK_ARG(viewmats && campos, "null pointer");
+    hipLaunchKernelGGL(camera_centers_kernel, dim3(gs_div_up(C, 64)), dim3(64), 0, (hipStream_t)stream, C, viewmats, campos);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int32_t gs_sh_view_fwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos,
     const float *coeffs, const int32_t *radii, float *colors, gs_stream_t stream) {

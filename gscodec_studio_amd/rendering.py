@@ -43,6 +43,14 @@ def _camera_centers(viewmats: Tensor) -> Tensor:
     [[A, t], [0, 1]] the inverse's translation is -A^-1 t, and A^-1 = adj(A) / det(A) is three
     cross products -- a handful of tiny asynchronous kernels, differentiable through autograd.
     """
+    if viewmats.is_cuda and not viewmats.requires_grad:
+        from . import _backend as B
+
+        vm = viewmats.contiguous()
+        out = torch.empty((vm.shape[0], 3), dtype=torch.float32, device=vm.device)
+        with torch.cuda.device(vm.device):
+            B.call("gs_camera_centers", vm.shape[0], B.ptr(vm), B.ptr(out), torch.cuda.current_stream(vm.device).cuda_stream)
+        return out
     A = viewmats[:, :3, :3]
     t = viewmats[:, :3, 3]
     c0, c1, c2 = A[:, :, 0], A[:, :, 1], A[:, :, 2]

@@ -182,6 +182,9 @@ int32_t gs_sh_bwd(
  * bwd: colors_out is the forward output (gradient of the clamp); v_colors may be a strided view
  * (row stride v_colors_stride floats, e.g. 16 for the packed compositing gradient rows);
  * v_coeffs [N,K,3] and v_means [N,3] (= sum over cameras of d/d dirs; may be NULL) are OVERWRITTEN. */
+/* campos[c] = inverse(viewmats[c])[:3, 3] for affine world->camera matrices, closed form
+ * (replaces torch.inverse(viewmats) of gsplat/rendering.py:370, which host-synchronises on ROCm). */
+int32_t gs_camera_centers(uint32_t C, const float *viewmats, float *campos, gs_stream_t stream);
 int32_t gs_sh_view_fwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree,
     const float *means, const float *campos, const float *coeffs, const int32_t *radii,
