@@ -193,11 +193,20 @@ GS_DEV Rect wave_rect(const RasterArgs &a, const TileGeom &tg, uint32_t q_first)
 // ---------------------------------------------------------------------------
 // CKPT: write per-pixel checkpoints (T, accumulated colour) "before list entry b" for every
 // b = k * seg strictly inside the tile's range, planar: ckpt[k][c][256] with c = 0 (T), 1..CDIM.
+#ifdef GS_ABL
+__device__ unsigned long long g_abl_stats[16];
+__device__ unsigned long long g_abl_wave[65536 * 4];
+#endif
 template <int NQ, int CDIM, bool COLOR_LDS, bool CKPT>
 __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, const int32_t *__restrict__ order, uint32_t cnt, uint32_t ch_off, float *__restrict__ ckpt, int32_t seg) {
     constexpr int REC = 3;
     __shared__ float4 s_rec[(GS_WAVE + 1) * REC];
     const uint32_t lane = threadIdx.x;
+#if defined(GS_ABL) && GS_ABL == 9
+    const unsigned long long abl_t0 = wall_clock64();
+    const unsigned long long abl_c0 = clock64();
+    unsigned abl_evals = 0;
+#endif
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const uint32_t vitem = xcd_remap(blockIdx.x, gridDim.x, a.xcd_group);
     const TileGeom tg = tile_geom(a, order, (NQ == 4) ? vitem : (vitem >> 2));
@@ -246,7 +255,9 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
     // a batch start: no per-record boundary test inside the hot loop.
     const int32_t base0 = tg.range_start & ~(GS_WAVE - 1);
     const int32_t num_batches = n > 0 ? (tg.range_end - base0 + GS_WAVE - 1) / GS_WAVE : 0;
-    if (n >= HEAVY_TILE) __builtin_amdgcn_s_setprio(2);
+    if (n >= 4 * HEAVY_TILE) __builtin_amdgcn_s_setprio(3);
+    else if (n >= 2 * HEAVY_TILE) __builtin_amdgcn_s_setprio(2);
+    else if (n >= HEAVY_TILE) __builtin_amdgcn_s_setprio(1);
     auto in_range = [&](int32_t idx) { return idx >= tg.range_start && idx < tg.range_end && n > 0; };
 
     SplatRaw nxt = gather_splat(a, base0 + (int32_t)lane, in_range(base0 + (int32_t)lane));
@@ -285,6 +296,9 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
         const bool live = have && cull_prepare(s, cs) && rect_touch(s, cs, rect.x0, rect.x1, rect.y0, rect.y1);
         const unsigned long long lm = __ballot(live);
         const int count = __popcll(lm);
+#if defined(GS_ABL) && GS_ABL == 9
+        abl_evals += count;
+#endif
         if (live) {
             const int slot = __popcll(lm & lt_mask);
             float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
@@ -387,6 +401,296 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
                 a.render_colors[pix[i] * a.channels + ch_off + k] = bg ? out[i][k] + Tf * bg[k] : out[i][k];
         a.last_ids[pix[i]] = cur[i];
     }
+#if defined(GS_ABL) && GS_ABL == 9
+    if (lane == 0 && blockIdx.x < 65536u) {
+        const unsigned long long t1 = wall_clock64();
+        g_abl_wave[blockIdx.x * 4 + 0] = abl_t0;
+        g_abl_wave[blockIdx.x * 4 + 1] = t1;
+        g_abl_wave[blockIdx.x * 4 + 2] = ((unsigned long long)(tg.range_end - tg.range_start) << 32) | abl_evals;
+        g_abl_wave[blockIdx.x * 4 + 3] = (clock64() - abl_c0) << 24;
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// Forward for 1..4 channels (the hot case, default): ONE 256-THREAD WORKGROUP PER TILE, wave q
+// composites quadrant q, and the four waves STAGE COOPERATIVELY: per batch of 256 list entries
+// every thread gathers ONE entry, tests it exactly against all four quadrant rectangles
+// (rect_touch) and writes its record once; four ballots per wave give one 64-bit mask per
+// (64-entry sub-batch, quadrant).  After one barrier, wave q walks the set bits of "its" four
+// masks (s_ff1 on SGPRs) and reads the records as LDS broadcasts.
+// Why (measured with per-wave timestamps, tools/abl_run.py): with one independent wave per
+// quadrant the kernel's duration was the life of the heaviest waves (list 5-6k entries, 311 us of
+// a 320 us kernel), and ~60% of that was the exposed latency of the two dependent gathers
+// (flatten_ids -> splat) once per 64 entries, because culling leaves only ~15 records to
+// evaluate per batch.  Here a heavy tile takes 4x fewer, 4x larger batches, the gathers are
+// prefetched two levels deep (ids two batches ahead, splat data one batch ahead) and are hidden
+// behind ~60 record evaluations, and every entry is gathered once per tile instead of four times.
+// LDS is double-buffered so that one __syncthreads per batch suffices.
+// Sub-batches are aligned to multiples of 64 of the GLOBAL list index, so a checkpoint boundary
+// (multiple of seg) always coincides with a sub-batch start.
+// ---------------------------------------------------------------------------
+template <int CDIM, bool CKPT>
+__global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, const int32_t *__restrict__ order, float *__restrict__ ckpt, int32_t seg) {
+    constexpr int REC = 3;
+    constexpr int BATCH = 256;
+    __shared__ float4 s_rec[2][BATCH * REC];
+    __shared__ unsigned long long s_mask[2][4][4]; // [buffer][sub-batch (= staging wave)][quadrant]
+    __shared__ uint32_t s_done[2][4];              // [buffer][quadrant]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6); // staging sub-batch AND composited quadrant
+#if defined(GS_ABL) && GS_ABL == 9
+    const unsigned long long abl_t0 = wall_clock64();
+    const unsigned long long abl_c0 = clock64();
+    unsigned abl_evals = 0;
+    unsigned long long abl_bar = 0;
+#endif
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    const TileGeom tg = tile_geom(a, order, xcd_remap(blockIdx.x, gridDim.x, a.xcd_group));
+    const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels : nullptr;
+
+    const uint32_t ox = lx + 8u * (w & 1u), oy = ly + 8u * (w >> 1);
+    const uint32_t x = tg.px0 + ox, y = tg.py0 + oy;
+    const bool inside = ox < a.tile_size && oy < a.tile_size && x < a.image_width && y < a.image_height;
+    const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+    const size_t pix = ((size_t)tg.cam * a.image_height + y) * a.image_width + x;
+
+    if (a.masks != nullptr && !a.masks[tg.lin]) {
+        if (inside) {
+#pragma unroll
+            for (int k = 0; k < CDIM; ++k) a.render_colors[pix * CDIM + k] = bg ? bg[k] : 0.f;
+        }
+        return;
+    }
+
+    float qx0[4], qx1[4], qy0[4], qy1[4];
+    bool qdone[4]; // block-uniform: quadrant finished (or empty)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const Rect r = wave_rect<1>(a, tg, (uint32_t)q);
+        qx0[q] = r.x0; qx1[q] = r.x1; qy0[q] = r.y0; qy1[q] = r.y1;
+        qdone[q] = r.empty;
+    }
+
+    float T = 1.f, Tkeep = 1.f, out[CDIM];
+    int32_t cur = 0;
+    bool done = !inside;
+#pragma unroll
+    for (int k = 0; k < CDIM; ++k) out[k] = 0.f;
+
+    const int32_t n = tg.range_end - tg.range_start;
+    const int32_t base0 = tg.range_start & ~(GS_WAVE - 1);
+    const int32_t num_batches = n > 0 ? (tg.range_end - base0 + BATCH - 1) / BATCH : 0;
+    // graded issue priority: the longest lists bound the kernel, they must win arbitration on their SIMD
+    if (n >= 4 * HEAVY_TILE) __builtin_amdgcn_s_setprio(3);
+    else if (n >= 2 * HEAVY_TILE) __builtin_amdgcn_s_setprio(2);
+    else if (n >= HEAVY_TILE) __builtin_amdgcn_s_setprio(1);
+    auto in_range = [&](int32_t idx) { return idx >= tg.range_start && idx < tg.range_end; };
+    auto load_id = [&](int32_t idx) { return in_range(idx) ? a.flatten_ids[idx] : -1; };
+    struct Staged {
+        SplatRaw s;
+        float col[CDIM];
+    };
+    auto gather = [&](int32_t g, Staged &o) {
+        o.s.g = 0;
+        o.s.mx = o.s.my = o.s.ca = o.s.cb = o.s.cc = o.s.opac = 0.f;
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) o.col[k] = 0.f;
+        if (g >= 0) {
+            o.s.g = g;
+            const float2 xy = reinterpret_cast<const float2 *>(a.means2d)[g];
+            const float *cn = a.conics + 3 * (size_t)g;
+            o.s.mx = xy.x; o.s.my = xy.y;
+            o.s.ca = cn[0]; o.s.cb = cn[1]; o.s.cc = cn[2];
+            o.s.opac = a.opacities[g];
+#pragma unroll
+            for (int k = 0; k < CDIM; ++k) o.col[k] = a.colors[(size_t)g * CDIM + k];
+        }
+    };
+    int32_t id_cur = load_id(base0 + (int32_t)tid);
+    int32_t id_nxt = load_id(base0 + BATCH + (int32_t)tid);
+    Staged nxt;
+    gather(id_cur, nxt);
+
+    int32_t next_b = CKPT ? (tg.range_start / seg + 1) * seg : 0x7fffffff;
+    int32_t next_k = CKPT ? next_b / seg : 0;
+    auto store_ckpt = [&]() {
+        float *base = ckpt + (size_t)next_k * (CDIM + 1) * 256;
+        const uint32_t p = w * 64u + lane;
+        base[p] = done ? Tkeep : T;
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) base[(k + 1) * 256 + p] = out[k];
+    };
+
+    for (int32_t b = 0; b < num_batches; ++b) {
+        const uint32_t buf = (uint32_t)b & 1u;
+        const int32_t batch_start = base0 + b * BATCH;
+        // ---- stage: exact cull of my entry against the four quadrants
+        {
+            const Staged st = nxt;
+            const bool have = id_cur >= 0;
+            CullSplat cs;
+            const bool live = have && cull_prepare(st.s, cs);
+            unsigned long long m[4];
+            bool any_touch = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool touch = live && !qdone[q] && rect_touch(st.s, cs, qx0[q], qx1[q], qy0[q], qy1[q]);
+                any_touch |= touch;
+                m[q] = __ballot(touch);
+            }
+            if (any_touch) {
+                float c0 = st.col[0], c1 = 0.f, c2 = 0.f, c3 = 0.f;
+                if (CDIM > 1) c1 = st.col[CDIM > 1 ? 1 : 0];
+                if (CDIM > 2) c2 = st.col[CDIM > 2 ? 2 : 0];
+                if (CDIM > 3) c3 = st.col[CDIM > 3 ? 3 : 0];
+                float4 *r = &s_rec[buf][tid * REC];
+                r[0] = make_float4(st.s.mx, st.s.my, -0.5f * LOG2E * st.s.ca, -LOG2E * st.s.cb);
+                r[1] = make_float4(-0.5f * LOG2E * st.s.cc, __log2f(st.s.opac), c0, c1);
+                if (CDIM > 2) r[2] = make_float4(c2, c3, 0.f, 0.f);
+            }
+            const bool wave_done = __all(done); // evaluated by all 64 lanes, before the branch
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s_mask[buf][w][q] = m[q];
+                s_done[buf][w] = wave_done ? 1u : 0u;
+            }
+        }
+        // ---- prefetch: splat data of the next batch (its ids are already here), ids of the one after
+        id_cur = id_nxt;
+        if (b + 1 < num_batches) gather(id_cur, nxt);
+        id_nxt = (b + 2 < num_batches) ? load_id(batch_start + 2 * BATCH + (int32_t)tid) : -1;
+        // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the gathers just issued
+#if defined(GS_ABL) && GS_ABL == 9
+        const unsigned long long abl_b0 = clock64();
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if defined(GS_ABL) && GS_ABL == 9
+        abl_bar += clock64() - abl_b0;
+#endif
+        {
+            const uint32_t d0 = s_done[buf][0], d1 = s_done[buf][1], d2 = s_done[buf][2], d3 = s_done[buf][3];
+            if (d0 & d1 & d2 & d3) break; // every pixel of the tile is finished (block-uniform)
+            qdone[0] = qdone[0] || d0; qdone[1] = qdone[1] || d1; qdone[2] = qdone[2] || d2; qdone[3] = qdone[3] || d3;
+        }
+        // ---- composite my quadrant over the four sub-batches
+#pragma unroll 1
+        for (int sub = 0; sub < 4; ++sub) {
+            const int32_t sb_start = batch_start + sub * GS_WAVE;
+            if (sb_start >= tg.range_end) break;
+            if (CKPT && sb_start == next_b && next_b < tg.range_end) { // state before list entry next_b
+                store_ckpt();
+                next_b += seg;
+                next_k += 1;
+            }
+            unsigned long long m = s_mask[buf][sub][w];
+            m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) |
+                (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)m); // (the builtin returns int: no sign extension)
+            if (m == 0ull) continue;
+#if defined(GS_ABL) && GS_ABL == 9
+            abl_evals += __popcll(m);
+#endif
+            const float4 *rec = &s_rec[buf][sub * GS_WAVE * REC];
+            // FOUR records per iteration, in one basic block: a lone wave issues one instruction per
+            // ~5 cycles and a record is a ~25-deep dependent chain, so one record at a time costs
+            // ~390 cycles (measured) against ~40 instructions x 5 cycles of issue.  The four alpha
+            // evaluations are independent; only T <- T - T a (one fma) is carried from record to record.
+            // The next group's records are read from LDS while this group is evaluated.
+            constexpr int G = 4;
+            int tt[G];
+            bool vv[G];
+            float4 q0[G], q1[G], q2[G];
+            auto take = [&]() { // pop up to G set bits (wave-uniform); exhausted slots alias slot tt[0], masked by vv
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    vv[g] = m != 0ull;
+                    tt[g] = vv[g] ? __builtin_ctzll(m) : (g ? tt[0] : 0);
+                    m &= m - 1;
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    q0[g] = rec[tt[g] * REC + 0];
+                    q1[g] = rec[tt[g] * REC + 1];
+                    if (CDIM > 2) q2[g] = rec[tt[g] * REC + 2];
+                }
+            };
+            take();
+            while (vv[0]) {
+                float4 c0[G], c1[G], c2[G];
+                int32_t idx[G];
+                bool rv[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    c0[g] = q0[g]; c1[g] = q1[g];
+                    if (CDIM > 2) c2[g] = q2[g];
+                    idx[g] = sb_start + tt[g];
+                    rv[g] = vv[g];
+                }
+                take(); // prefetch the next group
+                float a_eff[G];
+                bool ok[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float dx = c0[g].x - px, dy = c0[g].y - py;
+                    const float power = dx * (c0[g].z * dx + c0[g].w * dy) + c1[g].x * dy * dy; // = -sigma log2(e)
+                    const float alpha = fminf(0.999f, __builtin_amdgcn_exp2f(power + c1[g].y));
+                    ok[g] = rv[g] && !(power > 0.f) && (alpha >= ALPHA_MIN);
+                    a_eff[g] = ok[g] ? alpha : 0.f;
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float Tj = T;
+                    const float next_T = Tj - Tj * a_eff[g];      // the loop-carried chain: one fma
+                    const bool stop = ok[g] && (next_T <= 1e-4f); // exclusive stop
+                    const bool live = !done && !stop;             // this record is composited
+                    Tkeep = done ? Tkeep : Tj;                    // transmittance before the stopping splat
+                    const float vis = live ? a_eff[g] * Tj : 0.f;
+                    out[0] += c1[g].z * vis;
+                    if (CDIM > 1) out[CDIM > 1 ? 1 : 0] += c1[g].w * vis;
+                    if (CDIM > 2) out[CDIM > 2 ? 2 : 0] += c2[g].x * vis;
+                    if (CDIM > 3) out[CDIM > 3 ? 3 : 0] += c2[g].y * vis;
+                    cur = (live && ok[g]) ? idx[g] : cur;
+                    done = done || stop;
+                    T = next_T;
+                }
+            }
+            if (__all(done)) break;
+        }
+    }
+
+    if (CKPT && n > 0) {
+        // boundaries after the last composited record (or after an early exit) carry the final state
+        while (next_b < tg.range_end) {
+            store_ckpt();
+            next_b += seg;
+            next_k += 1;
+        }
+    }
+    if (inside) {
+        const float Tf = done ? Tkeep : T;
+        a.render_alphas[pix] = 1.f - Tf;
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) a.render_colors[pix * CDIM + k] = bg ? out[k] + Tf * bg[k] : out[k];
+        a.last_ids[pix] = cur;
+    }
+#if defined(GS_ABL) && GS_ABL == 9
+    if (lane == 0 && blockIdx.x * 4 + w < 65536u) {
+        const uint32_t slot = blockIdx.x * 4 + w;
+        g_abl_wave[slot * 4 + 0] = abl_t0;
+        g_abl_wave[slot * 4 + 1] = wall_clock64();
+        g_abl_wave[slot * 4 + 2] = ((unsigned long long)n << 32) | abl_evals;
+        g_abl_wave[slot * 4 + 3] = ((clock64() - abl_c0) << 24) | (abl_bar >> 8 & 0xffffffull);
+    }
+#endif
+}
+
+template <int CDIM>
+void launch_tile_fwd(const RasterArgs &a, const int32_t *order, float *ckpt, int32_t seg, hipStream_t st) {
+    dim3 grid(a.C * a.tile_width * a.tile_height);
+    if (ckpt != nullptr)
+        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true>), grid, dim3(256), 0, st, a, order, ckpt, seg);
+    else
+        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, false>), grid, dim3(256), 0, st, a, order, ckpt, seg);
 }
 
 // ---------------------------------------------------------------------------
@@ -724,9 +1028,6 @@ void launch_bwd(const RasterArgs &a, const RasterGradArgs &ga, const int32_t *or
 //     chains (dpp_reduce.h): 6 instructions per value, no moves, no hazards.
 // record: R0 = (mx, my, a', b')  R1 = (c', log2 o, col0, col1)  R2 = (col2, col3, a, b)  R3 = (c, o, g, -)
 // ---------------------------------------------------------------------------
-#ifdef GS_ABL
-__device__ unsigned long long g_abl_stats[8];
-#endif
 #ifndef GS_SEG_WAVES
 #define GS_SEG_WAVES 5
 #endif
@@ -1105,8 +1406,11 @@ ScratchLayout scratch_layout(uint32_t n_tiles_all, uint32_t n_isects, uint32_t c
 } // namespace
 
 #ifdef GS_ABL
+extern "C" void gs_debug_abl_waves(unsigned long long *out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_abl_wave), sizeof(unsigned long long) * 65536 * 4);
+}
 extern "C" void gs_debug_abl_stats(unsigned long long *out) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_abl_stats), sizeof(unsigned long long) * 8);
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_abl_stats), sizeof(unsigned long long) * 16);
 }
 #endif
 
@@ -1133,6 +1437,12 @@ static uint32_t xcd_group_env(const char *name, uint32_t dflt) {
 
 int32_t raster_wave_fwd(const RasterArgs &a_in, void *scratch, size_t scratch_bytes, hipStream_t st) {
     RasterArgs a = a_in;
+#if defined(GS_ABL) && GS_ABL == 9
+    {
+        static unsigned long long init[8] = {0ull, ~0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_abl_stats), init, sizeof(init), 8 * sizeof(unsigned long long), hipMemcpyHostToDevice, st);
+    }
+#endif
     a.xcd_group = xcd_group_env("GS_RASTER_XCD_FWD", 64u); // 16 tiles x 4 quadrants (sweep: profiles/round1_notes.md)
     const int32_t *order = build_order(a, scratch, scratch_bytes, st);
     const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;
@@ -1145,6 +1455,17 @@ int32_t raster_wave_fwd(const RasterArgs &a_in, void *scratch, size_t scratch_by
     // (measured, profiles/round1_notes.md).  GS_RASTER_NQ_FWD=4 selects 4 pixels per lane.
     const char *enq = getenv("GS_RASTER_NQ_FWD");
     const bool nq4 = enq != nullptr && enq[0] == '4';
+    const char *efw = getenv("GS_RASTER_FWD"); // "wave": independent quadrant waves (previous default, A/B)
+    if (a.channels <= 4 && !nq4 && !(efw != nullptr && efw[0] == 'w')) {
+        a.xcd_group = xcd_group_env("GS_RASTER_XCD_FWD", 64u) / 4u; // groups of 16 tiles per XCD
+        switch (a.channels) {
+            case 1: launch_tile_fwd<1>(a, order, ckpt, seg, st); break;
+            case 2: launch_tile_fwd<2>(a, order, ckpt, seg, st); break;
+            case 3: launch_tile_fwd<3>(a, order, ckpt, seg, st); break;
+            default: launch_tile_fwd<4>(a, order, ckpt, seg, st); break;
+        }
+        return 0;
+    }
     if (a.channels <= 4) {
         switch (a.channels) {
             case 1: if (nq4) launch_fwd<4, 1, true>(a, order, 1, 0, ckpt, seg, st); else launch_fwd<1, 1, true>(a, order, 1, 0, ckpt, seg, st); break;
