@@ -3,8 +3,10 @@
 Mirrors ``CompressionSimulation`` (reference simulation.py:14-348) and
 ``STGCompressionSimulation`` (508-780): which attributes are fake-quantized, their bounds
 and bit widths, and the ``simulate_compression(splats, step) -> (new_splats, esti_bits)``
-contract.  Entropy models (factorized prior / hash-grid Gaussian model) are outside this
-hot path: constructing with ``entropy_model_enable=True`` raises NotImplementedError.
+contract.  ``entropy_model_enable=True`` with the factorized prior attaches the fused bits
+estimator (entropy_model.py, reference wiring simulation.py:87-149, 247-316, 576-608); the
+hash-grid Gaussian model needs the reference's CUDA-only ``_gridencoder`` and raises
+NotImplementedError.
 """
 from __future__ import annotations
 
@@ -14,6 +16,7 @@ import torch
 from torch import Tensor
 from typing_extensions import Literal
 
+from .entropy_model import Entropy_factorized_optimized_refactor
 from .ops import fake_quantize_ste
 
 
@@ -23,14 +26,38 @@ class _SimulationBase:
     bds: Dict[str, Optional[list]]
     q_type: Optional[str]
 
-    def _check_entropy(self, enable: bool) -> None:
-        if enable:
-            raise NotImplementedError(
-                "entropy models (bits estimators) are not part of the MI355X hot path yet "
-                "(SURVEY.md section 8f rank 1); construct with entropy_model_enable=False"
-            )
+    entropy_model_enable: bool = False
+    entropy_model_option: Dict[str, bool] = {}
+    entropy_models: Dict[str, Optional[torch.nn.Module]] = {}
 
-    def _quantize(self, name: str, param: Tensor) -> Tuple[Tensor, None]:
+    def _setup_entropy(self, enable: bool, model_type: str, specs: Dict[str, Optional[dict]]) -> None:
+        """Factorized-prior models + their Adam optimizers (reference simulation.py:87-149, 576-608).
+        ``specs``: attribute -> constructor kwargs (None: no model)."""
+        self.entropy_model_enable = bool(enable)
+        if not enable:
+            return
+        if model_type != "factorized_model":
+            raise NotImplementedError(
+                f"entropy_model_type={model_type!r}: only the factorized prior is built (the hash-grid Gaussian "
+                "model depends on the reference's CUDA-only _gridencoder extension)")
+        if self.entropy_steps is None:
+            raise ValueError("entropy_model_enable=True needs entropy_steps")
+        for name in list(self.entropy_model_option):  # turn off if entropy step < 0 (simulation.py:70-73)
+            if self.entropy_steps.get(name, -1) < 0:
+                self.entropy_model_option[name] = False
+        self.entropy_models = {k: (Entropy_factorized_optimized_refactor(**kw).to(self.device) if kw is not None else None)
+                               for k, kw in specs.items()}
+        positive = [k for k, v in self.entropy_steps.items() if v > 0]
+        self.entropy_min_step = self.entropy_steps[min(positive, key=lambda k: self.entropy_steps[k])] if positive else 0
+        self.entropy_model_optimizers, self.entropy_model_schedulers = {}, {}
+        for k, m in self.entropy_models.items():
+            self.entropy_model_optimizers[k] = None if m is None else torch.optim.Adam(
+                [{"params": p, "lr": 1e-4, "name": n} for n, p in m.named_parameters()])
+            self.entropy_model_schedulers[k] = None
+
+    def _quantize(self, name: str, param: Tensor, step: int = 0, as_channels=None) -> Tuple[Tensor, Optional[Tensor]]:
+        """fake-quantize ``param``; past ``entropy_steps[name]`` also estimate its bits.
+        ``as_channels``: reshape of the quantized value to the model's [N, C] input (and back)."""
         lo, hi = self.bds[name]
         # both sides of the reference's `step < 10_000` branch select 8 bits
         # (simulation.py:242-245): the schedule is a no-op and q_bitwidth[name] is used.
@@ -39,7 +66,12 @@ class _SimulationBase:
             out = fake_quantize_ste(param, lo, hi, bits)  # default q_type="noise"
         else:
             out = fake_quantize_ste(param, lo, hi, bits, self.q_type)
-        return out["output_value"], None
+        value = out["output_value"]
+        if (self.entropy_model_enable and self.entropy_model_option.get(name, False)
+                and step > self.entropy_steps[name] and self.entropy_models.get(name) is not None):
+            x = value if as_channels is None else as_channels(value)
+            return value, self.entropy_models[name](x, out["q_step"])
+        return value, None
 
     def simulate_compression(self, splats: Dict[str, Tensor], step: int):
         """Returns (new_splats, esti_bits_dict); un-simulated attributes come back as ``p + 0.``"""
@@ -49,7 +81,7 @@ class _SimulationBase:
                 fn = getattr(self, f"simulate_compression_{name}", None)
                 if fn is None:
                     raise NotImplementedError(f"no simulate function for {name}")
-                new_splats[name], esti_bits[name] = fn(splats[name], step)
+                new_splats[name], esti_bits[name] = fn(splats[name], step)[:2]
             else:
                 new_splats[name] = splats[name] + 0.0
                 esti_bits[name] = None
@@ -65,26 +97,33 @@ class CompressionSimulation(_SimulationBase):
                  entropy_model_type: Literal["factorized_model", "gaussian_model"] = "factorized_model",
                  entropy_steps: Optional[Dict[str, int]] = None, device=None, ada_mask_opt: bool = False,
                  ada_mask_step: int = 10_000, ada_mask_strategy: Optional[str] = "learnable", **kwargs) -> None:
-        self._check_entropy(entropy_model_enable)
         if ada_mask_opt:
             raise NotImplementedError("learnable shN mask (ada_mask_opt) is outside the hot path")
-        self.entropy_model_enable = False
         self.entropy_model_type = entropy_model_type
         self.entropy_steps = entropy_steps
         self.device = device
         self.q_type = None
+        self.entropy_model_option = {"means": False, "scales": True, "quats": True, "opacities": False, "sh0": True,
+                                     "shN": False}
+        self._setup_entropy(entropy_model_enable, entropy_model_type, {
+            "means": None, "scales": dict(channel=3, filters=(3, 3)), "quats": dict(channel=4), "opacities": None,
+            "sh0": dict(channel=3, filters=(3, 3)), "shN": None})
         self.simulation_option = {"means": False, "scales": True, "quats": True, "opacities": True, "sh0": True,
                                   "shN": True}
         self.q_bitwidth = {"means": None, "scales": 8, "quats": 8, "opacities": 8, "sh0": 8, "shN": None}
         self.bds = {"means": None, "scales": [-10, 2], "quats": [-1, 1], "opacities": [-15, 15], "sh0": [-2, 4],
                     "shN": None}
 
-    def simulate_compression_scales(self, param, step): return self._quantize("scales", param)
-    def simulate_compression_quats(self, param, step): return self._quantize("quats", param)
-    def simulate_compression_opacities(self, param, step): return self._quantize("opacities", param)
-    def simulate_compression_sh0(self, param, step): return self._quantize("sh0", param)
+    def simulate_compression_scales(self, param, step, *_): return self._quantize("scales", param, step)
+    def simulate_compression_quats(self, param, step, *_): return self._quantize("quats", param, step)
 
-    def simulate_compression_shN(self, param, step):
+    def simulate_compression_opacities(self, param, step, *_):  # [N] -> [N, 1] for the model (simulation.py:289-296)
+        return self._quantize("opacities", param, step, lambda v: v.unsqueeze(1))
+
+    def simulate_compression_sh0(self, param, step, *_):  # [N, 1, 3] -> [N, 3] (simulation.py:308-314)
+        return self._quantize("sh0", param, step, lambda v: v.squeeze(1))
+
+    def simulate_compression_shN(self, param, step, *_):
         return param, None  # reference simulation.py:319-324 without the optional mask
 
 
@@ -95,12 +134,12 @@ class STGCompressionSimulation(_SimulationBase):
     def __init__(self, quantization_sim_type: Optional[Literal["round", "noise", "vq"]] = None,
                  entropy_model_enable: bool = False, entropy_steps: Optional[Dict[str, int]] = None, device=None,
                  ada_mask_opt: bool = False, ada_mask_step: int = 10_000, **kwargs) -> None:
-        self._check_entropy(entropy_model_enable)
         self.quantization_sim_type = quantization_sim_type
         self.q_type = quantization_sim_type
-        self.entropy_model_enable = False
         self.entropy_steps = entropy_steps
         self.device = device
+        self.entropy_model_option = {"means": False, "scales": True, "quats": True, "opacities": False, "colors": True,
+                                     "features_dir": True, "features_time": True}
         self.simulation_option = {
             "means": False, "scales": True, "quats": True, "opacities": True, "trbf_center": False,
             "trbf_scale": False, "motion": False, "omega": False, "colors": True, "features_dir": True,
@@ -115,15 +154,17 @@ class STGCompressionSimulation(_SimulationBase):
             "trbf_scale": None, "motion": None, "omega": None, "colors": [-7.5, 7.5], "features_dir": [-10, 10],
             "features_time": [-10, 10],
         }
+        self._setup_entropy(entropy_model_enable, "factorized_model", {  # reference simulation.py:587-596
+            "means": None, "scales": dict(channel=3), "quats": dict(channel=4), "opacities": None,
+            "colors": dict(channel=3, filters=(3, 3)), "features_dir": dict(channel=3, filters=(3, 3)),
+            "features_time": dict(channel=3, filters=(3, 3))})
 
-    def _quantize(self, name, param):
-        lo, hi = self.bds[name]
-        out = fake_quantize_ste(param, lo, hi, self.q_bitwidth[name], self.q_type)
-        return out["output_value"], None
+    def simulate_compression_scales(self, param, step, *_): return self._quantize("scales", param, step)
+    def simulate_compression_quats(self, param, step, *_): return self._quantize("quats", param, step)
 
-    def simulate_compression_scales(self, param, step): return self._quantize("scales", param)
-    def simulate_compression_quats(self, param, step): return self._quantize("quats", param)
-    def simulate_compression_opacities(self, param, step): return self._quantize("opacities", param)
-    def simulate_compression_colors(self, param, step): return self._quantize("colors", param)
-    def simulate_compression_features_dir(self, param, step): return self._quantize("features_dir", param)
-    def simulate_compression_features_time(self, param, step): return self._quantize("features_time", param)
+    def simulate_compression_opacities(self, param, step, *_):
+        return self._quantize("opacities", param, step, lambda v: v.unsqueeze(1))
+
+    def simulate_compression_colors(self, param, step, *_): return self._quantize("colors", param, step)
+    def simulate_compression_features_dir(self, param, step, *_): return self._quantize("features_dir", param, step)
+    def simulate_compression_features_time(self, param, step, *_): return self._quantize("features_time", param, step)

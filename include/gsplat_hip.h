@@ -339,6 +339,32 @@ int32_t gs_quantize_round_fwd(
     float q_step_norm /* (float)(1/(2^bits-1)) */, float *out, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Factorized-prior bits estimator (the rate term behind the quantize hooks).
+ * Replaces Entropy_factorized_optimized_refactor.forward
+ * (gsplat/compression_simulation/entropy_model.py:195-254) and the autograd graph torch builds from
+ * it: bits[n,c] = -log2(max(bound, |sigmoid(s u) - sigmoid(s l)|)), l/u = f_p(x[n,c] -/+ half_q[c]),
+ * f_p a 1 -> W -> .. -> W -> 1 MLP (hidden_layers x hidden_width; reference: filters=(3,3) or (3,3,3))
+ * with softplus'd matrices and tanh-gated residual nonlinearity (229-238), s = -sign(l+u) (247),
+ * LowerBound gradient rule (355-357).  The parameter set of element (n,c) follows the reference's
+ * 32-way reshape: p = (32 c + n / chunk) % channels, chunk = (n_rows + 32 - n_rows % 32) / 32.
+ * params [channels, P] raw (un-transformed) parameters, per set and per layer [matrix row-major |
+ * bias | factor], the last layer without factor; P = gs_entropy_factorized_params_per_channel().
+ * x, bits, v_bits, v_x: [n_rows, channels] row-major.  half_q: [channels] device floats (= Q/2).
+ * bwd: v_x is overwritten; v_params [replicas, channels, P] is ACCUMULATED with atomics (zero-fill first)
+ * and the caller sums it over the leading axis -- workgroups spread over the replicas because
+ * same-address device-scope float atomics serialise (replicas = 1 is valid, 32 is what the wrapper uses).
+ * hidden_layers, hidden_width in 1..4 (uniform width), channels in 1..32; anything else: status 1. */
+uint32_t gs_entropy_factorized_params_per_channel(uint32_t hidden_layers, uint32_t hidden_width);
+int32_t gs_entropy_factorized_fwd(
+    uint64_t n_rows, uint32_t channels, uint32_t hidden_layers, uint32_t hidden_width,
+    const float *x, const float *half_q, const float *params, float likelihood_bound,
+    float *bits, gs_stream_t stream);
+int32_t gs_entropy_factorized_bwd(
+    uint64_t n_rows, uint32_t channels, uint32_t hidden_layers, uint32_t hidden_width,
+    const float *x, const float *half_q, const float *params, float likelihood_bound,
+    const float *v_bits, float *v_x, float *v_params, uint32_t replicas, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Unfused public ops (reference: quat_scale_to_covar_preci_{fwd,bwd}.cu,
  * world_to_cam_{fwd,bwd}.cu, proj_{fwd,bwd}.cu)
  * ---------------------------------------------------------------------- */

@@ -1,0 +1,127 @@
+"""CPU tests of the bits-estimator oracle against the golden vectors recorded from the reference's
+Entropy_factorized_optimized_refactor (tests/golden/make_golden_entropy.py), and of the host-side
+module (parameter names/shapes, packed layout, wiring) -- no GPU compute."""
+import numpy as np
+import pytest
+import torch
+
+from util import golden
+
+from oracle import entropy_oracle as EO
+
+CASES = ["scales", "quats", "opacities", "sh0_qvec", "wide", "deep", "narrow"]
+
+
+def load_case(gd, name):
+    n_layers = len(gd[f"{name}.filters"]) + 1
+    mats = [gd[f"{name}.mat{i}"] for i in range(n_layers)]
+    biases = [gd[f"{name}.bias{i}"] for i in range(n_layers)]
+    factors = [gd[f"{name}.factor{i}"] for i in range(n_layers - 1)]
+    return mats, biases, factors
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_reference(name):
+    gd = golden("entropy.npz")
+    mats, biases, factors = load_case(gd, name)
+    x, q, vb = gd[f"{name}.x"], gd[f"{name}.q"], gd[f"{name}.v_bits"]
+    bits = EO.factorized_bits_fwd(x, q, mats, biases, factors)
+    ref = gd[f"{name}.bits"]
+    # the reference itself is fp32 and loses up to ~3e-3 bits to sigmoid cancellation (measured against float64)
+    assert np.all(np.abs(bits - ref) <= 4e-3 + 2e-4 * np.abs(ref))
+    gx, gm, gb, gf = EO.factorized_bits_bwd(x, q, mats, biases, factors, vb)
+    rx = gd[f"{name}.v_x"]
+    assert (np.abs(gx - rx) > 5e-3 * (np.abs(rx) + np.abs(rx).mean())).mean() < 0.01
+    for i in range(len(mats)):
+        for got, key in ((gm[i], f"v_mat{i}"), (gb[i], f"v_bias{i}")):
+            r = gd[f"{name}.{key}"]
+            assert np.abs(got - r).max() <= 5e-3 * np.abs(r).max()
+    for i in range(len(factors)):
+        r = gd[f"{name}.v_factor{i}"]
+        assert np.abs(gf[i] - r).max() <= 5e-3 * np.abs(r).max()
+
+
+def test_oracle_channel_mapping_is_the_reference_quirk():
+    """p(n, c) = (32 c + n // chunk) % C: with the straightforward mapping p = c the oracle must NOT match."""
+    gd = golden("entropy.npz")
+    name = "quats"
+    mats, biases, factors = load_case(gd, name)
+    x, q = gd[f"{name}.x"], gd[f"{name}.q"]
+    N_, C = x.shape
+    assert EO.chunk_len(1024) == 33 and EO.chunk_len(1000) == 32 and EO.chunk_len(31) == 1
+    n_idx, c_idx = np.meshgrid(np.arange(N_), np.arange(C), indexing="ij")
+    p = EO.param_channel(n_idx, c_idx, N_, C)
+    assert np.array_equal(p[:, 0], (np.arange(N_) // 33) % 4) and np.array_equal(p[:, 0], p[:, 3])  # C = 4: position only
+    # permuting the parameter sets changes the result => the mapping matters and is pinned by the golden bits
+    perm = [1, 2, 3, 0]
+    bits = EO.factorized_bits_fwd(x, q, [m[perm] for m in mats], [b[perm] for b in biases], [f[perm] for f in factors])
+    assert np.abs(bits - gd[f"{name}.bits"]).max() > 0.05
+
+
+def test_oracle_gradient_matches_finite_differences():
+    gd = golden("entropy.npz")
+    name = "wide"
+    mats, biases, factors = load_case(gd, name)
+    x, q = gd[f"{name}.x"].astype(np.float64), gd[f"{name}.q"]
+    vb = gd[f"{name}.v_bits"].astype(np.float64)
+    gx, gm, gb, gf = EO.factorized_bits_bwd(x, q, mats, biases, factors, vb)
+    f = lambda xx, mm: float((EO.factorized_bits_fwd(xx, q, mm, biases, factors) * vb).sum())  # noqa: E731
+    eps = 1e-6
+    for (n, c) in [(10, 0), (50, 1), (95, 0)]:
+        xp, xm = x.copy(), x.copy()
+        xp[n, c] += eps
+        xm[n, c] -= eps
+        fd = (f(xp, mats) - f(xm, mats)) / (2 * eps)
+        assert abs(fd - gx[n, c]) <= 1e-4 * (abs(fd) + 1e-3)
+    m1 = [m.astype(np.float64).copy() for m in mats]
+    for idx in [(0, 1, 0), (1, 0, 1)]:
+        mp = [m.copy() for m in m1]
+        mm_ = [m.copy() for m in m1]
+        mp[1][idx] += eps
+        mm_[1][idx] -= eps
+        fd = (f(x, mp) - f(x, mm_)) / (2 * eps)
+        assert abs(fd - gm[1][idx]) <= 1e-4 * (abs(fd) + 1e-3)
+
+
+def test_module_matches_reference_parameter_layout():
+    from gscodec_studio_amd.compression_simulation import Entropy_factorized_optimized_refactor as M
+
+    m = M(channel=4)  # default filters (3, 3, 3)
+    names = [n for n, _ in m.named_parameters()]
+    assert names == [f"_matrices.{i}" for i in range(4)] + [f"_bias.{i}" for i in range(4)] + [f"_factor.{i}" for i in range(3)]
+    assert [tuple(p.shape) for p in m._matrices] == [(4, 3, 1), (4, 3, 3), (4, 3, 3), (4, 1, 3)]
+    assert [tuple(p.shape) for p in m._bias] == [(4, 3, 1), (4, 3, 1), (4, 3, 1), (4, 1, 1)]
+    assert [tuple(p.shape) for p in m._factor] == [(4, 3, 1)] * 3
+    scale = 10.0 ** (1.0 / 4)
+    assert np.allclose(m._matrices[1].detach().numpy(), np.log(np.expm1(1.0 / scale / 3)))
+    assert float(m._factor[0].abs().max()) == 0.0 and float(m._bias[0].abs().max()) <= 0.5
+    assert set(m.state_dict().keys()) >= {"filters_len", "factor_len", "likelihood_lower_bound.bound"}
+    packed = m.packed_parameters()
+    assert packed.shape == (4, 43)
+    # layout: layer 0 = [matrix (3) | bias (3) | factor (3)], then 2 x [9 | 3 | 3], last [3 | 1]
+    assert torch.equal(packed[:, 0:3], m._matrices[0].reshape(4, 3)) and torch.equal(packed[:, 3:6], m._bias[0].reshape(4, 3))
+    assert torch.equal(packed[:, 9:18], m._matrices[1].reshape(4, 9)) and torch.equal(packed[:, 39:42], m._matrices[3].reshape(4, 3))
+    packed.sum().backward()
+    assert all(p.grad is not None for p in m.parameters())
+    with pytest.raises(NotImplementedError):
+        M(channel=3, filters=(3, 2))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(8, 4), 0.1)  # CPU tensors: no fallback
+
+
+def test_simulation_wiring_without_compute():
+    from gscodec_studio_amd.compression_simulation import CompressionSimulation, STGCompressionSimulation
+
+    steps = {"means": -1, "scales": 10_000, "quats": 10_000, "opacities": -1, "sh0": 20_000, "shN": -1}
+    sim = CompressionSimulation(entropy_model_enable=True, entropy_steps=steps, device="cpu")
+    assert sim.entropy_model_option == {"means": False, "scales": True, "quats": True, "opacities": False, "sh0": True, "shN": False}
+    assert sim.entropy_min_step == 10_000
+    assert sim.entropy_models["scales"].filters == (3, 3) and sim.entropy_models["quats"].filters == (3, 3, 3)
+    assert sim.entropy_models["opacities"] is None and sim.entropy_model_optimizers["opacities"] is None
+    opt = sim.entropy_model_optimizers["sh0"]
+    assert isinstance(opt, torch.optim.Adam) and len(opt.param_groups) == 8 and opt.param_groups[0]["lr"] == 1e-4
+    with pytest.raises(NotImplementedError):
+        CompressionSimulation(entropy_model_enable=True, entropy_model_type="gaussian_model", entropy_steps=steps)
+    stg_steps = {"means": -1, "scales": 5, "quats": 5, "opacities": -1, "colors": 5, "features_dir": 5, "features_time": 5}
+    stg = STGCompressionSimulation("round", entropy_model_enable=True, entropy_steps=stg_steps, device="cpu")
+    assert stg.entropy_models["scales"].filters == (3, 3, 3) and stg.entropy_models["colors"].filters == (3, 3)

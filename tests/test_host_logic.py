@@ -57,8 +57,10 @@ def test_simulation_tables_match_reference():
     d = STGCompressionSimulation(quantization_sim_type="round", entropy_steps={})
     assert d.bds["opacities"] == [-7, 7] and d.bds["colors"] == [-7.5, 7.5] and d.bds["features_dir"] == [-10, 10]
     assert [k for k, v in d.simulation_option.items() if v] == ["scales", "quats", "opacities", "colors", "features_dir", "features_time"]
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):  # entropy models need their step table (wiring is tested in test_entropy_cpu.py)
         STGCompressionSimulation(quantization_sim_type="round", entropy_model_enable=True)
+    with pytest.raises(NotImplementedError):  # the hash-grid Gaussian model needs the reference's CUDA-only extension
+        CompressionSimulation(entropy_model_enable=True, entropy_model_type="gaussian_model", entropy_steps={"scales": 1})
     # attributes that are not simulated come back as a fresh tensor (param + 0.), simulated ones need the GPU
     p = torch.nn.Parameter(torch.randn(5, 3))
     new, bits = s.simulate_compression({"means": p}, step=0)

@@ -1,0 +1,78 @@
+"""Timing of the fused bits estimator at the compression-simulation sizes (N = 1,006,065 splats:
+scales [N,3], quats [N,4], sh0 [N,3]) against an eager-torch formulation of the same arithmetic
+(the structure of the reference's Entropy_factorized_optimized_refactor.forward: cat, 64-fold
+parameter tiling, bmm/add/tanh chain) on the same GPU.  Prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gscodec_studio_amd.compression_simulation import Entropy_factorized_optimized_refactor as M  # noqa: E402
+
+
+def eager_bits(m, x, q):
+    C = m.channel
+    xt = x.t().unsqueeze(1)
+    st = torch.cat([xt - 0.5 * q, xt + 0.5 * q], dim=0)
+    z = 32 - st.shape[-1] % 32
+    lg = torch.cat([st, torch.zeros(*st.shape[:2], z, device=x.device)], dim=-1)
+    CC, _, NN = lg.shape
+    lg = lg.view(32 * CC, 1, NN // 32)
+    for i in range(len(m._matrices)):
+        lg = torch.bmm(F.softplus(m._matrices[i]).repeat(64, 1, 1), lg) + m._bias[i].repeat(64, 1, 1)
+        if i < len(m._factor):
+            lg = lg + torch.tanh(m._factor[i].repeat(64, 1, 1)) * torch.tanh(lg)
+    lg = lg.view(CC, 1, NN)[..., : NN - z]
+    lo, up = lg[:C], lg[C:]
+    s = -(lo + up).sign()
+    lik = torch.abs(torch.sigmoid(s * up) - torch.sigmoid(s * lo)).clamp_min(1e-6)
+    return (-torch.log2(lik)).permute(2, 1, 0).squeeze(1)
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def main():
+    n = 1_006_065
+    res = {}
+    for name, C, filters, q in [("scales", 3, (3, 3), 12 / 255), ("quats", 4, (3, 3, 3), 2 / 255), ("sh0", 3, (3, 3), 6 / 255)]:
+        m = M(channel=C, filters=filters).cuda()
+        x = torch.randn(n, C, device="cuda", requires_grad=True)
+        v = torch.randn(n, C, device="cuda")
+
+        def fwd():
+            return m(x, q)
+
+        def fwd_bwd():
+            x.grad = None
+            m(x, q).backward(v)
+
+        def eager_fwd_bwd():
+            x.grad = None
+            eager_bits(m, x, q).backward(v)
+
+        with torch.no_grad():
+            t_f = timeit(fwd)
+            t_ef = timeit(lambda: eager_bits(m, x, q), 5)
+        t_fb = timeit(fwd_bwd)
+        t_efb = timeit(eager_fwd_bwd, 5)
+        el = n * C
+        res[name] = {"fwd_ms": round(t_f, 4), "fwd_bwd_ms": round(t_fb, 4), "eager_fwd_ms": round(t_ef, 3), "eager_fwd_bwd_ms": round(t_efb, 3),
+                     "fwd_GBps": round(8 * el / t_f / 1e6, 1), "fwd_bwd_GBps_algorithmic": round((8 + 12) * el / t_fb / 1e6, 1)}
+    print(json.dumps({"workload": "factorized bits estimator, N=1006065", "results": res}))
+
+
+if __name__ == "__main__":
+    main()
