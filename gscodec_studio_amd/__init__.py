@@ -8,15 +8,20 @@ from ._wrapper import (
     fully_fused_projection,
     isect_offset_encode,
     isect_tiles,
+    persp_proj,
+    proj,
     quat_scale_to_covar_preci,
+    rasterize_to_indices_in_range,
     rasterize_to_pixels,
     spherical_harmonics,
     spherical_harmonics_shared,
+    world_to_cam,
 )
 from .rendering import rasterization
 from .version import __version__
 
 __all__ = [
     "rasterization", "fully_fused_projection", "spherical_harmonics", "spherical_harmonics_shared",
-    "isect_tiles", "isect_offset_encode", "rasterize_to_pixels", "quat_scale_to_covar_preci", "__version__",
+    "isect_tiles", "isect_offset_encode", "rasterize_to_pixels", "quat_scale_to_covar_preci", "proj", "persp_proj",
+    "world_to_cam", "rasterize_to_indices_in_range", "__version__",
 ]

@@ -227,6 +227,170 @@ class _SphericalHarmonics(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------
+# unfused public ops: world_to_cam, proj / persp_proj, rasterize_to_indices_in_range
+# (reference _wrapper.py:118-200, 571-643, 709-772)
+# ---------------------------------------------------------------------------
+_CAMERA_MODELS = {"pinhole": 0, "ortho": 1, "fisheye": 2}
+
+
+def world_to_cam(
+    means: Tensor,  # [N, 3]
+    covars: Tensor,  # [N, 3, 3]
+    viewmats: Tensor,  # [C, 4, 4]
+) -> Tuple[Tensor, Tensor]:
+    """Transforms Gaussians from world to camera coordinate system.
+
+    Returns (means_c [C, N, 3], covars_c [C, N, 3, 3])."""
+    C = viewmats.size(0)
+    N = means.size(0)
+    assert means.size() == (N, 3), means.size()
+    assert covars.size() == (N, 3, 3), covars.size()
+    assert viewmats.size() == (C, 4, 4), viewmats.size()
+    return _WorldToCam.apply(means.contiguous(), covars.contiguous(), viewmats.contiguous())
+
+
+class _WorldToCam(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, covars, viewmats):
+        _require_gpu(means, "world_to_cam")
+        means, covars, viewmats = _f32c(means), _f32c(covars), _f32c(viewmats)
+        C, N = viewmats.shape[0], means.shape[0]
+        means_c = torch.empty((C, N, 3), device=means.device)
+        covars_c = torch.empty((C, N, 3, 3), device=means.device)
+        with _device_of(means):
+            B.call("gs_world_to_cam_fwd", C, N, B.ptr(means), B.ptr(covars), B.ptr(viewmats), B.ptr(means_c),
+                   B.ptr(covars_c), _stream(means))
+        ctx.save_for_backward(means, covars, viewmats)
+        return means_c, covars_c
+
+    @staticmethod
+    def backward(ctx, v_means_c, v_covars_c):
+        means, covars, viewmats = ctx.saved_tensors
+        C, N = viewmats.shape[0], means.shape[0]
+        need = ctx.needs_input_grad
+        v_means = torch.empty_like(means) if need[0] else None
+        v_covars = torch.empty_like(covars) if need[1] else None
+        v_viewmats = torch.zeros_like(viewmats) if need[2] else None
+        with _device_of(means):
+            B.call("gs_world_to_cam_bwd", C, N, B.ptr(means), B.ptr(covars), B.ptr(viewmats),
+                   B.ptr(_f32c(v_means_c)) if v_means_c is not None else None,
+                   B.ptr(_f32c(v_covars_c)) if v_covars_c is not None else None,
+                   B.ptr(v_means), B.ptr(v_covars), B.ptr(v_viewmats), _stream(means))
+        return v_means, v_covars, v_viewmats
+
+
+def proj(
+    means: Tensor,  # [C, N, 3]
+    covars: Tensor,  # [C, N, 3, 3]
+    Ks: Tensor,  # [C, 3, 3]
+    width: int,
+    height: int,
+    camera_model: Literal["pinhole", "ortho", "fisheye"] = "pinhole",
+) -> Tuple[Tensor, Tensor]:
+    """Projection of Gaussians (perspective, orthographic or fisheye).
+
+    Returns (means2d [C, N, 2], covars2d [C, N, 2, 2])."""
+    C, N, _ = means.shape
+    assert means.shape == (C, N, 3), means.size()
+    assert covars.shape == (C, N, 3, 3), covars.size()
+    assert Ks.shape == (C, 3, 3), Ks.size()
+    assert camera_model in _CAMERA_MODELS, camera_model
+    return _Proj.apply(means.contiguous(), covars.contiguous(), Ks.contiguous(), width, height, camera_model)
+
+
+def persp_proj(means: Tensor, covars: Tensor, Ks: Tensor, width: int, height: int) -> Tuple[Tensor, Tensor]:
+    """DEPRECATED (as in the reference, _wrapper.py:118-139): use ``proj`` with camera_model="pinhole"."""
+    import warnings
+
+    warnings.warn("persp_proj is deprecated and will be removed in a future release. Use proj with ortho=False instead.",
+                  DeprecationWarning)
+    return proj(means, covars, Ks, width, height, "pinhole")
+
+
+class _Proj(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, covars, Ks, width, height, camera_model):
+        _require_gpu(means, "proj")
+        means, covars, Ks = _f32c(means), _f32c(covars), _f32c(Ks)
+        C, N = means.shape[0], means.shape[1]
+        means2d = torch.empty((C, N, 2), device=means.device)
+        covars2d = torch.empty((C, N, 2, 2), device=means.device)
+        with _device_of(means):
+            B.call("gs_proj_fwd", C, N, B.ptr(means), B.ptr(covars), B.ptr(Ks), int(width), int(height),
+                   _CAMERA_MODELS[camera_model], B.ptr(means2d), B.ptr(covars2d), _stream(means))
+        ctx.save_for_backward(means, covars, Ks)
+        ctx.cfg = (int(width), int(height), _CAMERA_MODELS[camera_model])
+        return means2d, covars2d
+
+    @staticmethod
+    def backward(ctx, v_means2d, v_covars2d):
+        means, covars, Ks = ctx.saved_tensors
+        width, height, model = ctx.cfg
+        C, N = means.shape[0], means.shape[1]
+        v_means2d = _f32c(v_means2d) if v_means2d is not None else torch.zeros((C, N, 2), device=means.device)
+        v_covars2d = _f32c(v_covars2d) if v_covars2d is not None else torch.zeros((C, N, 2, 2), device=means.device)
+        v_means = torch.empty_like(means)
+        v_covars = torch.empty_like(covars)
+        with _device_of(means):
+            B.call("gs_proj_bwd", C, N, B.ptr(means), B.ptr(covars), B.ptr(Ks), width, height, model, B.ptr(v_means2d),
+                   B.ptr(v_covars2d), B.ptr(v_means), B.ptr(v_covars), _stream(means))
+        return v_means, v_covars, None, None, None, None
+
+
+@torch.no_grad()
+def rasterize_to_indices_in_range(
+    range_start: int,
+    range_end: int,
+    transmittances: Tensor,  # [C, image_height, image_width]
+    means2d: Tensor,  # [C, N, 2]
+    conics: Tensor,  # [C, N, 3]
+    opacities: Tensor,  # [C, N]
+    image_width: int,
+    image_height: int,
+    tile_size: int,
+    isect_offsets: Tensor,  # [C, tile_height, tile_width]
+    flatten_ids: Tensor,  # [n_isects]
+) -> Tuple[Tensor, Tensor, Tensor]:
+    """Rasterizes the list batches ``[range_start, range_end)`` (one batch = tile_size^2 sorted entries per
+    tile) and returns only the indices: (gaussian_ids, pixel_ids, camera_ids), flattened [M] int64."""
+    C, N, _ = means2d.shape
+    assert conics.shape == (C, N, 3), conics.shape
+    assert opacities.shape == (C, N), opacities.shape
+    assert isect_offsets.shape[0] == C, isect_offsets.shape
+    tile_height, tile_width = isect_offsets.shape[1:3]
+    assert tile_height * tile_size >= image_height, f"Assert Failed: {tile_height} * {tile_size} >= {image_height}"
+    assert tile_width * tile_size >= image_width, f"Assert Failed: {tile_width} * {tile_size} >= {image_width}"
+    _require_gpu(means2d, "rasterize_to_indices_in_range")
+    dev = means2d.device
+    n_isects = int(flatten_ids.shape[0])
+    empty = torch.empty((0,), dtype=torch.int64, device=dev)
+    if n_isects == 0:
+        return empty, empty.clone(), empty.clone()
+    # saturate like the reference's uint32 arguments (callers pass e.g. 1e10 for "everything")
+    rs = int(min(max(range_start, 0), 0xFFFFFFFF))
+    re = int(min(max(range_end, 0), 0xFFFFFFFF))
+    trans = _f32c(transmittances)
+    means2d, conics, opacities = _f32c(means2d), _f32c(conics), _f32c(opacities)
+    offsets = isect_offsets.contiguous().to(torch.int32)
+    flat = flatten_ids.contiguous().to(torch.int32)
+    cnts = torch.zeros((C * image_height * image_width,), dtype=torch.int32, device=dev)
+    common = (rs, re, C, N, n_isects, B.ptr(means2d), B.ptr(conics), B.ptr(opacities), int(image_width), int(image_height),
+              int(tile_size), int(tile_width), int(tile_height), B.ptr(offsets), B.ptr(flat), B.ptr(trans))
+    with _device_of(means2d):
+        B.call("gs_rasterize_indices_count", *common, B.ptr(cnts), _stream(means2d))
+        cumsum = torch.cumsum(cnts, 0, dtype=torch.int32)
+        n_elems = int(cumsum[-1].item())
+        starts = (cumsum - cnts).contiguous()
+        gaussian_ids = torch.empty((n_elems,), dtype=torch.int64, device=dev)
+        pixel_ids = torch.empty((n_elems,), dtype=torch.int64, device=dev)
+        if n_elems:
+            B.call("gs_rasterize_indices_fill", *common, B.ptr(starts), B.ptr(gaussian_ids), B.ptr(pixel_ids), _stream(means2d))
+    out_pixel_ids = pixel_ids % (image_width * image_height)
+    out_camera_ids = pixel_ids // (image_width * image_height)
+    return gaussian_ids, out_pixel_ids, out_camera_ids
+
+
+# ---------------------------------------------------------------------------
 # quat/scale -> covar/preci  (reference _wrapper.py:76-115, 646-706)
 # ---------------------------------------------------------------------------
 def quat_scale_to_covar_preci(

@@ -14,27 +14,9 @@
 //     in SGPRs.
 //   * All maths are written on symmetric 2x2 / 3x3 forms (6 / 3 scalars), row-major.
 #include "gs_common.h"
+#include "proj_models.h"
 
 namespace {
-
-struct Camera {
-    Mat3 W;       // world->camera rotation
-    float tx, ty, tz;
-    float fx, fy, cx, cy;
-};
-
-GS_DEV Camera load_camera(const float *__restrict__ viewmats, const float *__restrict__ Ks, uint32_t c) {
-    const float *V = viewmats + 16 * c;
-    const float *K = Ks + 9 * c;
-    Camera cam;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) cam.W.m[i][j] = V[4 * i + j];
-    cam.tx = V[3]; cam.ty = V[7]; cam.tz = V[11];
-    cam.fx = K[0]; cam.cx = K[2]; cam.fy = K[4]; cam.cy = K[5];
-    return cam;
-}
 
 GS_DEV Sym3 load_covar(
     const float *__restrict__ covars, const float *__restrict__ quats,
@@ -48,73 +30,6 @@ GS_DEV Sym3 load_covar(
     const float *s = scales + 3 * (size_t)n;
     Mat3 R = quat_to_rotmat(q[0], q[1], q[2], q[3]);
     return covar_from_rot_scale(R, s[0], s[1], s[2]);
-}
-
-// 2x3 Jacobian of the camera model at pc, plus the projected mean.
-struct Jac {
-    float j00, j01, j02, j10, j11, j12;
-};
-
-// pinhole: gsplat/cuda/include/proj.cuh:80-119 (the x/z, y/z clamp only affects J)
-GS_DEV void pinhole_jac(const Camera &cam, float x, float y, float z, int W, int H,
-                        Jac &J, float &mx, float &my, float &txc, float &tyc) {
-    float tan_fovx = 0.5f * W / cam.fx;
-    float tan_fovy = 0.5f * H / cam.fy;
-    float lim_x_pos = (W - cam.cx) / cam.fx + 0.3f * tan_fovx;
-    float lim_x_neg = cam.cx / cam.fx + 0.3f * tan_fovx;
-    float lim_y_pos = (H - cam.cy) / cam.fy + 0.3f * tan_fovy;
-    float lim_y_neg = cam.cy / cam.fy + 0.3f * tan_fovy;
-    float rz = 1.f / z;
-    float rz2 = rz * rz;
-    txc = z * fminf(lim_x_pos, fmaxf(-lim_x_neg, x * rz));
-    tyc = z * fminf(lim_y_pos, fmaxf(-lim_y_neg, y * rz));
-    J.j00 = cam.fx * rz; J.j01 = 0.f;         J.j02 = -cam.fx * txc * rz2;
-    J.j10 = 0.f;         J.j11 = cam.fy * rz; J.j12 = -cam.fy * tyc * rz2;
-    mx = cam.fx * x * rz + cam.cx;
-    my = cam.fy * y * rz + cam.cy;
-}
-
-// orthographic: proj.cuh:9-37
-GS_DEV void ortho_jac(const Camera &cam, float x, float y, Jac &J, float &mx, float &my) {
-    J.j00 = cam.fx; J.j01 = 0.f; J.j02 = 0.f;
-    J.j10 = 0.f; J.j11 = cam.fy; J.j12 = 0.f;
-    mx = cam.fx * x + cam.cx;
-    my = cam.fy * y + cam.cy;
-}
-
-// fisheye (equidistant): proj.cuh:202-243
-struct FisheyeTerms {
-    float x2, y2, xy, r2, rho, inv_rho, len, theta, a, b;
-};
-
-GS_DEV FisheyeTerms fisheye_terms(float x, float y, float z) {
-    const float eps = 0.0000001f;
-    FisheyeTerms t;
-    t.x2 = x * x + eps;
-    t.y2 = y * y;
-    t.xy = x * y;
-    t.r2 = t.x2 + t.y2;
-    t.rho = t.r2 + z * z;
-    t.inv_rho = 1.f / t.rho;
-    t.len = sqrtf(x * x + y * y) + eps;
-    t.theta = atan2f(t.len, z);
-    t.b = t.theta / t.len / t.r2;
-    t.a = z * t.inv_rho / t.r2;
-    return t;
-}
-
-GS_DEV void fisheye_jac(const Camera &cam, float x, float y, float z, Jac &J, float &mx, float &my) {
-    const float eps = 0.0000001f;
-    FisheyeTerms t = fisheye_terms(x, y, z);
-    float theta_m = atan2f(t.len, z + eps);
-    mx = x * cam.fx * theta_m / t.len + cam.cx;
-    my = y * cam.fy * theta_m / t.len + cam.cy;
-    J.j00 = cam.fx * (t.x2 * t.a + t.y2 * t.b);
-    J.j01 = cam.fx * t.xy * (t.a - t.b);
-    J.j02 = -cam.fx * x * t.inv_rho;
-    J.j10 = cam.fy * t.xy * (t.a - t.b);
-    J.j11 = cam.fy * (t.y2 * t.a + t.x2 * t.b);
-    J.j12 = -cam.fy * y * t.inv_rho;
 }
 
 // cov2d = J Sigma J^T
@@ -304,57 +219,7 @@ GS_DEV void project_one_vjp(
     float vj12 = 2.f * (gj10 * Sc.xz + gj11 * Sc.yz + gj12 * Sc.zz);
 
     float vx, vy, vz; // d/d pc
-    if (camera_model == GS_CAMERA_PINHOLE) {
-        // proj.cuh:122-199
-        float rz = 1.f / z, rz2 = rz * rz, rz3 = rz2 * rz;
-        float tan_fovx = 0.5f * W / cam.fx, tan_fovy = 0.5f * H / cam.fy;
-        float lim_x_pos = (W - cam.cx) / cam.fx + 0.3f * tan_fovx;
-        float lim_x_neg = cam.cx / cam.fx + 0.3f * tan_fovx;
-        float lim_y_pos = (H - cam.cy) / cam.fy + 0.3f * tan_fovy;
-        float lim_y_neg = cam.cy / cam.fy + 0.3f * tan_fovy;
-        vx = cam.fx * rz * v_mx;
-        vy = cam.fy * rz * v_my;
-        vz = -(cam.fx * x * v_mx + cam.fy * y * v_my) * rz2;
-        float xr = x * rz, yr = y * rz;
-        if (xr <= lim_x_pos && xr >= -lim_x_neg) vx += -cam.fx * rz2 * vj02;
-        else vz += -cam.fx * rz3 * vj02 * txc;
-        if (yr <= lim_y_pos && yr >= -lim_y_neg) vy += -cam.fy * rz2 * vj12;
-        else vz += -cam.fy * rz3 * vj12 * tyc;
-        vz += -cam.fx * rz2 * vj00 - cam.fy * rz2 * vj11 + 2.f * cam.fx * txc * rz3 * vj02 +
-              2.f * cam.fy * tyc * rz3 * vj12;
-    } else if (camera_model == GS_CAMERA_ORTHO) {
-        vx = cam.fx * v_mx;
-        vy = cam.fy * v_my;
-        vz = 0.f;
-    } else {
-        // fisheye: mean2d gradient through J itself (J is the Jacobian of the map),
-        // and d J / d pc from the radial derivatives of a(r,z), b(r,z).
-        // Equivalent in exact arithmetic to proj.cuh:245-343.
-        vx = J.j00 * v_mx + J.j10 * v_my;
-        vy = J.j01 * v_mx + J.j11 * v_my;
-        vz = J.j02 * v_mx + J.j12 * v_my;
-        float r2 = ft.r2, rho = ft.rho, len = ft.len;
-        float inv_rho2 = ft.inv_rho * ft.inv_rho;
-        float inv_r = 1.f / len;
-        float a_z = (r2 - z * z) * inv_rho2 / r2;
-        float a_r = -2.f * z * (2.f * r2 + z * z) * inv_rho2 / (r2 * len);
-        float b_z = -ft.inv_rho / r2;
-        float b_r = (z * ft.inv_rho) / (r2 * len) - 3.f * ft.theta / (r2 * r2);
-        float rx = x * inv_r, ry = y * inv_r;
-        float amb = ft.a - ft.b, amb_r = a_r - b_r, amb_z = a_z - b_z;
-        float q0_r = ft.x2 * a_r + ft.y2 * b_r; // radial part of (x2 a + y2 b)
-        float q1_r = ft.y2 * a_r + ft.x2 * b_r; // radial part of (y2 a + x2 b)
-        // rows scaled by fx / fy
-        float d00x = 2.f * x * ft.a + q0_r * rx, d00y = 2.f * y * ft.b + q0_r * ry, d00z = ft.x2 * a_z + ft.y2 * b_z;
-        float d01x = y * amb + ft.xy * amb_r * rx, d01y = x * amb + ft.xy * amb_r * ry, d01z = ft.xy * amb_z;
-        float d02x = -ft.inv_rho + 2.f * x * x * inv_rho2, d02y = 2.f * ft.xy * inv_rho2, d02z = 2.f * x * z * inv_rho2;
-        float d11x = 2.f * x * ft.b + q1_r * rx, d11y = 2.f * y * ft.a + q1_r * ry, d11z = ft.y2 * a_z + ft.x2 * b_z;
-        float d12x = 2.f * ft.xy * inv_rho2, d12y = -ft.inv_rho + 2.f * y * y * inv_rho2, d12z = 2.f * y * z * inv_rho2;
-        (void)rho;
-        vx += cam.fx * (d00x * vj00 + d01x * vj01 + d02x * vj02) + cam.fy * (d01x * vj10 + d11x * vj11 + d12x * vj12);
-        vy += cam.fx * (d00y * vj00 + d01y * vj01 + d02y * vj02) + cam.fy * (d01y * vj10 + d11y * vj11 + d12y * vj12);
-        vz += cam.fx * (d00z * vj00 + d01z * vj01 + d02z * vj02) + cam.fy * (d01z * vj10 + d11z * vj11 + d12z * vj12);
-    }
+    proj_mean_vjp(cam, camera_model, x, y, z, W, H, v_mx, v_my, vj00, vj01, vj02, vj10, vj11, vj12, vx, vy, vz);
     vz += v_depth;
 
     // world->camera VJP (gsplat/cuda/include/transform.cuh:19-69)

@@ -1,0 +1,404 @@
+// unfused.hip -- the reference's stand-alone public ops that the fused pipeline does not need but
+// its API (and its tests/test_basic.py) exposes: world_to_cam, proj, rasterize_to_indices_in_range.
+//
+// Replaces gsplat/cuda/csrc/world_to_cam_{fwd,bwd}.cu, proj_{fwd,bwd}.cu and
+// rasterize_to_indices_in_range.cu.  Unlike the fused projection these take GENERAL 3x3 matrices
+// ([.., 3, 3] row-major, not assumed symmetric), exactly like the reference's glm code
+// (include/transform.cuh:40-68, include/proj.cuh).  All three are streaming / helper kernels:
+// one lane per element, no shared state; the backward of world_to_cam loops over cameras inside the
+// lane (no atomics on the per-gaussian gradients) and reduces the per-camera pose gradient with DPP
+// wave sums + one atomic group per wave.
+#include "gs_common.h"
+#include "proj_models.h"
+
+namespace {
+
+struct M3 {
+    float m[3][3];
+};
+
+GS_DEV M3 load_m3(const float *p) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r.m[i][j] = p[3 * i + j];
+    return r;
+}
+GS_DEV void store_m3(float *p, const M3 &a) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) p[3 * i + j] = a.m[i][j];
+}
+GS_DEV M3 mul(const M3 &a, const M3 &b) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+    return r;
+}
+GS_DEV M3 transpose(const M3 &a) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[j][i];
+    return r;
+}
+GS_DEV M3 rot_of(const float *V) { // upper-left 3x3 of a row-major 4x4
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r.m[i][j] = V[4 * i + j];
+    return r;
+}
+
+// ---------------------------------------------------------------- world_to_cam
+__global__ void __launch_bounds__(GS_BLOCK) world_to_cam_fwd_kernel(uint32_t C, uint32_t N, const float *__restrict__ means,
+                                                                    const float *__restrict__ covars, const float *__restrict__ viewmats,
+                                                                    float *__restrict__ means_c, float *__restrict__ covars_c) {
+    const uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
+    const uint32_t c = blockIdx.y;
+    if (n >= N) return;
+    const float *V = viewmats + 16 * c; // wave-uniform
+    const M3 R = rot_of(V);
+    const size_t o = (size_t)c * N + n;
+    if (means_c != nullptr) {
+        const float *p = means + 3 * (size_t)n;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) means_c[3 * o + i] = R.m[i][0] * p[0] + R.m[i][1] * p[1] + R.m[i][2] * p[2] + V[4 * i + 3];
+    }
+    if (covars_c != nullptr) {
+        const M3 S = load_m3(covars + 9 * (size_t)n);
+        store_m3(covars_c + 9 * o, mul(mul(R, S), transpose(R)));
+    }
+}
+
+template <bool NEED_VIEW>
+__global__ void __launch_bounds__(GS_BLOCK) world_to_cam_bwd_kernel(uint32_t C, uint32_t N, const float *__restrict__ means,
+                                                                    const float *__restrict__ covars, const float *__restrict__ viewmats,
+                                                                    const float *__restrict__ v_means_c, const float *__restrict__ v_covars_c,
+                                                                    float *__restrict__ v_means, float *__restrict__ v_covars,
+                                                                    float *__restrict__ v_viewmats) {
+    const uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
+    const bool live = n < N;
+    float p[3] = {0.f, 0.f, 0.f};
+    M3 S = {};
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) p[i] = means[3 * (size_t)n + i];
+        if (covars != nullptr) S = load_m3(covars + 9 * (size_t)n);
+    }
+    float vp[3] = {0.f, 0.f, 0.f};
+    M3 vS = {};
+    for (uint32_t c = 0; c < C; ++c) {
+        const float *V = viewmats + 16 * c;
+        const M3 R = rot_of(V);
+        const size_t o = (size_t)c * N + n;
+        float g[3] = {0.f, 0.f, 0.f};
+        M3 G = {};
+        if (live && v_means_c != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) g[i] = v_means_c[3 * o + i];
+        }
+        if (live && v_covars_c != nullptr) G = load_m3(v_covars_c + 9 * o);
+        // v_p += R^T g ; v_S += R^T G R   (transform.cuh:19-37, 49-68)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vp[j] += R.m[0][j] * g[0] + R.m[1][j] * g[1] + R.m[2][j] * g[2];
+        const M3 t = mul(mul(transpose(R), G), R);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vS.m[i][j] += t.m[i][j];
+        if (NEED_VIEW) {
+            // v_R = g p^T + G R S^T + G^T R S ; v_t = g   -- summed over the gaussians of this wave
+            const M3 a = mul(mul(G, R), transpose(S));
+            const M3 b = mul(mul(transpose(G), R), S);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float tot = wave_sum(g[i] * p[j] + a.m[i][j] + b.m[i][j]);
+                    if (lane_id() == 0 && tot != 0.f) unsafeAtomicAdd(v_viewmats + 16 * c + 4 * i + j, tot);
+                }
+                const float tt = wave_sum(g[i]);
+                if (lane_id() == 0 && tt != 0.f) unsafeAtomicAdd(v_viewmats + 16 * c + 4 * i + 3, tt);
+            }
+        }
+    }
+    if (!live) return;
+    if (v_means != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v_means[3 * (size_t)n + i] = vp[i];
+    }
+    if (v_covars != nullptr) store_m3(v_covars + 9 * (size_t)n, vS);
+}
+
+// ---------------------------------------------------------------- proj
+GS_DEV Camera intrinsics_only(const float *__restrict__ Ks, uint32_t c) {
+    const float *K = Ks + 9 * c;
+    Camera cam = {};
+    cam.fx = K[0]; cam.cx = K[2]; cam.fy = K[4]; cam.cy = K[5];
+    return cam;
+}
+
+GS_DEV void model_jac(const Camera &cam, int camera_model, float x, float y, float z, int W, int H, Jac &J, float &mx, float &my) {
+    float txc, tyc;
+    if (camera_model == GS_CAMERA_PINHOLE) pinhole_jac(cam, x, y, z, W, H, J, mx, my, txc, tyc);
+    else if (camera_model == GS_CAMERA_ORTHO) ortho_jac(cam, x, y, J, mx, my);
+    else fisheye_jac(cam, x, y, z, J, mx, my);
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) proj_fwd_kernel(uint32_t C, uint32_t N, const float *__restrict__ means,
+                                                            const float *__restrict__ covars, const float *__restrict__ Ks, int W, int H,
+                                                            int camera_model, float *__restrict__ means2d, float *__restrict__ covars2d) {
+    const uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
+    const uint32_t c = blockIdx.y;
+    if (n >= N) return;
+    const Camera cam = intrinsics_only(Ks, c);
+    const size_t o = (size_t)c * N + n;
+    const float *p = means + 3 * o;
+    const M3 S = load_m3(covars + 9 * o);
+    Jac J;
+    float mx, my;
+    model_jac(cam, camera_model, p[0], p[1], p[2], W, H, J, mx, my);
+    const float Jm[2][3] = {{J.j00, J.j01, J.j02}, {J.j10, J.j11, J.j12}};
+    float JS[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int l = 0; l < 3; ++l) JS[i][l] = Jm[i][0] * S.m[0][l] + Jm[i][1] * S.m[1][l] + Jm[i][2] * S.m[2][l];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) covars2d[4 * o + 2 * i + j] = JS[i][0] * Jm[j][0] + JS[i][1] * Jm[j][1] + JS[i][2] * Jm[j][2];
+    means2d[2 * o] = mx;
+    means2d[2 * o + 1] = my;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) proj_bwd_kernel(uint32_t C, uint32_t N, const float *__restrict__ means,
+                                                            const float *__restrict__ covars, const float *__restrict__ Ks, int W, int H,
+                                                            int camera_model, const float *__restrict__ v_means2d,
+                                                            const float *__restrict__ v_covars2d, float *__restrict__ v_means,
+                                                            float *__restrict__ v_covars) {
+    const uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
+    const uint32_t c = blockIdx.y;
+    if (n >= N) return;
+    const Camera cam = intrinsics_only(Ks, c);
+    const size_t o = (size_t)c * N + n;
+    const float *p = means + 3 * o;
+    const M3 S = load_m3(covars + 9 * o);
+    Jac J;
+    float mx, my;
+    model_jac(cam, camera_model, p[0], p[1], p[2], W, H, J, mx, my);
+    const float Jm[2][3] = {{J.j00, J.j01, J.j02}, {J.j10, J.j11, J.j12}};
+    const float G[2][2] = {{v_covars2d[4 * o], v_covars2d[4 * o + 1]}, {v_covars2d[4 * o + 2], v_covars2d[4 * o + 3]}};
+    // v_S = J^T G J
+    float GJ[2][3], GtJ[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            GJ[i][l] = G[i][0] * Jm[0][l] + G[i][1] * Jm[1][l];
+            GtJ[i][l] = G[0][i] * Jm[0][l] + G[1][i] * Jm[1][l];
+        }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int l = 0; l < 3; ++l) v_covars[9 * o + 3 * k + l] = Jm[0][k] * GJ[0][l] + Jm[1][k] * GJ[1][l];
+    // v_J = G J S^T + G^T J S   (proj.cuh:160-165)
+    float vJ[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            vJ[i][k] = GJ[i][0] * S.m[k][0] + GJ[i][1] * S.m[k][1] + GJ[i][2] * S.m[k][2] +
+                       GtJ[i][0] * S.m[0][k] + GtJ[i][1] * S.m[1][k] + GtJ[i][2] * S.m[2][k];
+    float vx, vy, vz;
+    proj_mean_vjp(cam, camera_model, p[0], p[1], p[2], W, H, v_means2d[2 * o], v_means2d[2 * o + 1], vJ[0][0], vJ[0][1], vJ[0][2],
+                  vJ[1][0], vJ[1][1], vJ[1][2], vx, vy, vz);
+    v_means[3 * o] = vx;
+    v_means[3 * o + 1] = vy;
+    v_means[3 * o + 2] = vz;
+}
+
+// ---------------------------------------------------------------- rasterize_to_indices_in_range
+// One thread per pixel, one workgroup per tile, entries staged through LDS in batches of
+// tile_size^2 (the batch size is part of the op's contract: range_start/range_end count batches).
+// FILL = false: count the contributing splats per pixel; FILL = true: write (gaussian, pixel) pairs.
+struct IdxRec {
+    float x, y, opac, ca, cb, cc;
+    int32_t g;
+};
+
+template <bool FILL>
+__global__ void indices_in_range_kernel(uint32_t range_start, uint32_t range_end, uint32_t C, uint32_t N, uint32_t n_isects,
+                                        const float *__restrict__ means2d, const float *__restrict__ conics,
+                                        const float *__restrict__ opacities, uint32_t W, uint32_t H, uint32_t tile_size,
+                                        uint32_t tile_width, uint32_t tile_height, const int32_t *__restrict__ tile_offsets,
+                                        const int32_t *__restrict__ flatten_ids, const float *__restrict__ transmittances,
+                                        const int32_t *__restrict__ chunk_starts, int32_t *__restrict__ chunk_cnts,
+                                        int64_t *__restrict__ gaussian_ids, int64_t *__restrict__ pixel_ids) {
+    extern __shared__ IdxRec s_batch[];
+    const uint32_t cam = blockIdx.x;
+    const uint32_t tile_id = blockIdx.y * tile_width + blockIdx.z;
+    const uint32_t i = blockIdx.y * tile_size + threadIdx.y, jx = blockIdx.z * tile_size + threadIdx.x;
+    const uint32_t block_size = blockDim.x * blockDim.y;
+    const uint32_t tr = threadIdx.y * blockDim.x + threadIdx.x;
+    const uint32_t lin = cam * tile_width * tile_height + tile_id;
+    const float px = (float)jx + 0.5f, py = (float)i + 0.5f;
+    const bool inside = i < H && jx < W;
+    const size_t pix = (size_t)cam * H * W + (size_t)i * W + jx;
+    bool done = !inside;
+    const int32_t rs = tile_offsets[lin];
+    const int32_t re = (lin + 1 == C * tile_width * tile_height) ? (int32_t)n_isects : tile_offsets[lin + 1];
+    const uint32_t num_batches = ((uint32_t)(re - rs) + block_size - 1) / block_size;
+    if (range_start >= num_batches) return; // this tile was finished by earlier calls (count stays at its zero fill)
+    float trans = inside ? transmittances[pix] : 0.f;
+    int32_t base = (FILL && inside) ? chunk_starts[pix] : 0;
+    int32_t cnt = 0;
+    const uint32_t b_end = range_end < num_batches ? range_end : num_batches;
+    for (uint32_t b = range_start; b < b_end; ++b) {
+        if (__syncthreads_count(done) >= (int)block_size) break;
+        const uint32_t batch_start = (uint32_t)rs + block_size * b;
+        const uint32_t idx = batch_start + tr;
+        if (idx < (uint32_t)re) {
+            const int32_t g = flatten_ids[idx];
+            IdxRec r;
+            r.g = g;
+            r.x = means2d[2 * (size_t)g];
+            r.y = means2d[2 * (size_t)g + 1];
+            r.opac = opacities[g];
+            r.ca = conics[3 * (size_t)g];
+            r.cb = conics[3 * (size_t)g + 1];
+            r.cc = conics[3 * (size_t)g + 2];
+            s_batch[tr] = r;
+        }
+        __syncthreads();
+        const uint32_t batch_size = min(block_size, (uint32_t)re - batch_start);
+        for (uint32_t t = 0; t < batch_size && !done; ++t) {
+            const IdxRec r = s_batch[t];
+            const float dx = r.x - px, dy = r.y - py;
+            const float sigma = 0.5f * (r.ca * dx * dx + r.cc * dy * dy) + r.cb * dx * dy;
+            const float alpha = fminf(0.999f, r.opac * __expf(-sigma));
+            if (sigma < 0.f || alpha < 1.f / 255.f) continue;
+            const float next_trans = trans * (1.f - alpha);
+            if (next_trans <= 1e-4f) { // exclusive stop
+                done = true;
+                break;
+            }
+            if (FILL) {
+                gaussian_ids[base + cnt] = (int64_t)(r.g % (int32_t)N);
+                pixel_ids[base + cnt] = (int64_t)pix;
+            }
+            cnt += 1;
+            trans = next_trans;
+        }
+    }
+    if (!FILL && inside) chunk_cnts[pix] = cnt;
+}
+
+} // namespace
+
+extern "C" int32_t gs_world_to_cam_fwd(uint32_t C, uint32_t N, const float *means, const float *covars, const float *viewmats,
+                                       float *means_c, float *covars_c, gs_stream_t stream) {
+    if (C == 0 || N == 0) return 0;
+    GS_CHECK_ARG(viewmats != nullptr, "null viewmats");
+    GS_CHECK_ARG((means_c == nullptr || means != nullptr) && (covars_c == nullptr || covars != nullptr), "output without its input");
+    hipLaunchKernelGGL(world_to_cam_fwd_kernel, dim3(gs_div_up(N, GS_BLOCK), C), dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means,
+                       covars, viewmats, means_c, covars_c);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_world_to_cam_bwd(uint32_t C, uint32_t N, const float *means, const float *covars, const float *viewmats,
+                                       const float *v_means_c, const float *v_covars_c, float *v_means, float *v_covars,
+                                       float *v_viewmats, gs_stream_t stream) {
+    if (C == 0 || N == 0) return 0;
+    GS_CHECK_ARG(means != nullptr && viewmats != nullptr, "null pointer");
+    GS_CHECK_ARG(v_covars_c == nullptr || covars != nullptr, "v_covars_c without covars");
+    dim3 grid(gs_div_up(N, GS_BLOCK));
+    if (v_viewmats != nullptr)
+        hipLaunchKernelGGL((world_to_cam_bwd_kernel<true>), grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means, covars, viewmats,
+                           v_means_c, v_covars_c, v_means, v_covars, v_viewmats);
+    else
+        hipLaunchKernelGGL((world_to_cam_bwd_kernel<false>), grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means, covars, viewmats,
+                           v_means_c, v_covars_c, v_means, v_covars, v_viewmats);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_proj_fwd(uint32_t C, uint32_t N, const float *means, const float *covars, const float *Ks, int32_t width,
+                               int32_t height, int32_t camera_model, float *means2d, float *covars2d, gs_stream_t stream) {
+    if (C == 0 || N == 0) return 0;
+    GS_CHECK_ARG(means && covars && Ks && means2d && covars2d, "null pointer");
+    GS_CHECK_ARG(camera_model >= 0 && camera_model <= 2, "unknown camera model");
+    hipLaunchKernelGGL(proj_fwd_kernel, dim3(gs_div_up(N, GS_BLOCK), C), dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means, covars, Ks,
+                       width, height, camera_model, means2d, covars2d);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_proj_bwd(uint32_t C, uint32_t N, const float *means, const float *covars, const float *Ks, int32_t width,
+                               int32_t height, int32_t camera_model, const float *v_means2d, const float *v_covars2d, float *v_means,
+                               float *v_covars, gs_stream_t stream) {
+    if (C == 0 || N == 0) return 0;
+    GS_CHECK_ARG(means && covars && Ks && v_means2d && v_covars2d && v_means && v_covars, "null pointer");
+    GS_CHECK_ARG(camera_model >= 0 && camera_model <= 2, "unknown camera model");
+    hipLaunchKernelGGL(proj_bwd_kernel, dim3(gs_div_up(N, GS_BLOCK), C), dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means, covars, Ks,
+                       width, height, camera_model, v_means2d, v_covars2d, v_means, v_covars);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+static int32_t indices_launch(bool fill, uint32_t range_start, uint32_t range_end, uint32_t C, uint32_t N, uint32_t n_isects,
+                              const float *means2d, const float *conics, const float *opacities, uint32_t W, uint32_t H,
+                              uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, const int32_t *tile_offsets,
+                              const int32_t *flatten_ids, const float *transmittances, const int32_t *chunk_starts, int32_t *chunk_cnts,
+                              int64_t *gaussian_ids, int64_t *pixel_ids, hipStream_t st) {
+    dim3 threads(tile_size, tile_size, 1), blocks(C, tile_height, tile_width);
+    const size_t shmem = (size_t)tile_size * tile_size * sizeof(IdxRec);
+    if (fill)
+        hipLaunchKernelGGL((indices_in_range_kernel<true>), blocks, threads, shmem, st, range_start, range_end, C, N, n_isects, means2d,
+                           conics, opacities, W, H, tile_size, tile_width, tile_height, tile_offsets, flatten_ids, transmittances,
+                           chunk_starts, chunk_cnts, gaussian_ids, pixel_ids);
+    else
+        hipLaunchKernelGGL((indices_in_range_kernel<false>), blocks, threads, shmem, st, range_start, range_end, C, N, n_isects, means2d,
+                           conics, opacities, W, H, tile_size, tile_width, tile_height, tile_offsets, flatten_ids, transmittances,
+                           chunk_starts, chunk_cnts, gaussian_ids, pixel_ids);
+    return 0;
+}
+
+extern "C" int32_t gs_rasterize_indices_count(uint32_t range_start, uint32_t range_end, uint32_t C, uint32_t N, uint32_t n_isects,
+                                              const float *means2d, const float *conics, const float *opacities, uint32_t image_width,
+                                              uint32_t image_height, uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+                                              const int32_t *tile_offsets, const int32_t *flatten_ids, const float *transmittances,
+                                              int32_t *chunk_cnts, gs_stream_t stream) {
+    if (C == 0 || n_isects == 0) return 0;
+    GS_CHECK_ARG(means2d && conics && opacities && tile_offsets && flatten_ids && transmittances && chunk_cnts, "null pointer");
+    GS_CHECK_ARG(tile_size >= 1 && tile_size <= 32, "tile_size must be in 1..32");
+    indices_launch(false, range_start, range_end, C, N, n_isects, means2d, conics, opacities, image_width, image_height, tile_size,
+                   tile_width, tile_height, tile_offsets, flatten_ids, transmittances, nullptr, chunk_cnts, nullptr, nullptr,
+                   (hipStream_t)stream);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_rasterize_indices_fill(uint32_t range_start, uint32_t range_end, uint32_t C, uint32_t N, uint32_t n_isects,
+                                             const float *means2d, const float *conics, const float *opacities, uint32_t image_width,
+                                             uint32_t image_height, uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+                                             const int32_t *tile_offsets, const int32_t *flatten_ids, const float *transmittances,
+                                             const int32_t *chunk_starts, int64_t *gaussian_ids, int64_t *pixel_ids, gs_stream_t stream) {
+    if (C == 0 || n_isects == 0) return 0;
+    GS_CHECK_ARG(means2d && conics && opacities && tile_offsets && flatten_ids && transmittances && chunk_starts && gaussian_ids &&
+                     pixel_ids, "null pointer");
+    GS_CHECK_ARG(tile_size >= 1 && tile_size <= 32, "tile_size must be in 1..32");
+    indices_launch(true, range_start, range_end, C, N, n_isects, means2d, conics, opacities, image_width, image_height, tile_size,
+                   tile_width, tile_height, tile_offsets, flatten_ids, transmittances, chunk_starts, nullptr, gaussian_ids, pixel_ids,
+                   (hipStream_t)stream);
+    GS_CHECK_LAUNCH();
+    return 0;
+}

@@ -378,6 +378,55 @@ int32_t gs_quat_scale_to_covar_preci_bwd(
     float *v_quats, float *v_scales,              /* overwritten */
     gs_stream_t stream);
 
+/* world_to_cam: means_c[c,n] = R_c p_n + t_c, covars_c[c,n] = R_c S_n R_c^T on GENERAL 3x3 matrices
+ * (reference world_to_cam_fwd_tensor, csrc/world_to_cam_fwd.cu:85-127; device code
+ * include/transform.cuh:8-46).  Either output (with its input) may be NULL.
+ * bwd (world_to_cam_bwd_tensor, csrc/world_to_cam_bwd.cu:125-195; transform.cuh:19-68): v_means [N,3] and
+ * v_covars [N,3,3] are OVERWRITTEN (summed over cameras inside the lane), v_viewmats [C,4,4] is
+ * ACCUMULATED with atomics (zero-fill first); any of the three may be NULL (= not needed). */
+int32_t gs_world_to_cam_fwd(
+    uint32_t C, uint32_t N, const float *means /* [N,3] */, const float *covars /* [N,3,3] */,
+    const float *viewmats /* [C,4,4] */, float *means_c /* [C,N,3] */, float *covars_c /* [C,N,3,3] */,
+    gs_stream_t stream);
+int32_t gs_world_to_cam_bwd(
+    uint32_t C, uint32_t N, const float *means, const float *covars, const float *viewmats,
+    const float *v_means_c /* [C,N,3] or NULL */, const float *v_covars_c /* [C,N,3,3] or NULL */,
+    float *v_means, float *v_covars, float *v_viewmats, gs_stream_t stream);
+
+/* proj: camera-space gaussians -> image plane, means2d [C,N,2], covars2d [C,N,2,2] = J S J^T with the
+ * pinhole / orthographic / fisheye Jacobian (reference proj_fwd_tensor, csrc/proj_fwd.cu:81-129,
+ * proj_bwd_tensor, csrc/proj_bwd.cu:128-182; device code include/proj.cuh).  No culling, general 3x3 S.
+ * bwd overwrites v_means [C,N,3] and v_covars [C,N,3,3]. */
+int32_t gs_proj_fwd(
+    uint32_t C, uint32_t N, const float *means /* [C,N,3] */, const float *covars /* [C,N,3,3] */,
+    const float *Ks /* [C,3,3] */, int32_t width, int32_t height, int32_t camera_model,
+    float *means2d, float *covars2d, gs_stream_t stream);
+int32_t gs_proj_bwd(
+    uint32_t C, uint32_t N, const float *means, const float *covars, const float *Ks,
+    int32_t width, int32_t height, int32_t camera_model,
+    const float *v_means2d, const float *v_covars2d, float *v_means, float *v_covars, gs_stream_t stream);
+
+/* rasterize_to_indices_in_range (reference rasterize_to_indices_in_range_tensor,
+ * csrc/rasterize_to_indices_in_range.cu:177-300, kernel 16-175): for the list batches
+ * [range_start, range_end) of every tile (one batch = tile_size^2 sorted entries) and the per-pixel
+ * transmittances reached so far, list the (gaussian, pixel) pairs that get composited.
+ * Two-call protocol: _count writes chunk_cnts i32 [C*H*W] (zero-fill first: untouched tiles stay 0), the
+ * caller forms the exclusive prefix sum chunk_starts (i32, like the reference's int32 cumsum) and
+ * the total, allocates, then _fill writes gaussian_ids (= flatten id % N) and pixel_ids
+ * (= camera * H * W + row * W + column), both i64, pixel-major, list order inside a pixel. */
+int32_t gs_rasterize_indices_count(
+    uint32_t range_start, uint32_t range_end, uint32_t C, uint32_t N, uint32_t n_isects,
+    const float *means2d, const float *conics, const float *opacities,
+    uint32_t image_width, uint32_t image_height, uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+    const int32_t *tile_offsets, const int32_t *flatten_ids, const float *transmittances,
+    int32_t *chunk_cnts, gs_stream_t stream);
+int32_t gs_rasterize_indices_fill(
+    uint32_t range_start, uint32_t range_end, uint32_t C, uint32_t N, uint32_t n_isects,
+    const float *means2d, const float *conics, const float *opacities,
+    uint32_t image_width, uint32_t image_height, uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+    const int32_t *tile_offsets, const int32_t *flatten_ids, const float *transmittances,
+    const int32_t *chunk_starts, int64_t *gaussian_ids, int64_t *pixel_ids, gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,65 @@
+"""CPU: the unfused-op oracle against the golden vectors recorded from the reference's _torch_impl
+(tests/golden/make_golden_unfused.py), and the indices oracle against a dense formulation."""
+import numpy as np
+import pytest
+import torch
+
+from util import golden
+
+from oracle import unfused_oracle as UO
+
+
+def test_world_to_cam_oracle_vs_reference():
+    gd = golden("unfused.npz")
+    (mc, cc), g = UO.with_grads(UO.world_to_cam, (gd["means"], gd["covars"], gd["viewmats"]), (gd["w2c.v_means_c"], gd["w2c.v_covars_c"]))
+    for got, key in ((mc, "means_c"), (cc, "covars_c"), (g[0], "v_means"), (g[1], "v_covars"), (g[2], "v_viewmats")):
+        ref = gd[f"w2c.{key}"]
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), key
+
+
+@pytest.mark.parametrize("model", ["pinhole", "ortho", "fisheye"])
+def test_proj_oracle_vs_reference(model):
+    gd = golden("unfused.npz")
+    Ks = torch.tensor(gd["Ks"], dtype=torch.float64)
+    W, H = int(gd["width"]), int(gd["height"])
+    (m2, c2), g = UO.with_grads(lambda a, b: UO.proj(a, b, Ks, W, H, model), (gd["proj.means"], gd["proj.covars"]),
+                                (gd["proj.v_means2d"], gd["proj.v_covars2d"]))
+    for got, key in ((m2, "means2d"), (c2, "covars2d"), (g[0], "v_means"), (g[1], "v_covars")):
+        ref = gd[f"proj.{model}.{key}"]
+        bad = np.abs(got - ref) > 1e-4 * np.abs(ref) + 1e-4 * np.abs(ref).mean()
+        assert bad.mean() < 2e-3, key
+
+
+def test_indices_oracle_matches_dense_formulation():
+    """Full-range call == every (pixel, splat) pair a front-to-back walk composites; split ranges concatenate."""
+    rng = np.random.default_rng(3)
+    C, N, W, H, ts = 1, 40, 24, 16, 8
+    means2d = rng.uniform([0, 0], [W, H], size=(C, N, 2)).astype(np.float32)
+    conics = np.tile(np.array([0.08, 0.01, 0.06], np.float32), (C, N, 1))
+    opac = rng.uniform(0.3, 1.0, size=(C, N)).astype(np.float32)
+    th, tw = H // ts, W // ts
+    # every splat in every tile, front-to-back = index order
+    flatten = np.tile(np.arange(N, dtype=np.int32), th * tw)
+    offsets = (np.arange(th * tw, dtype=np.int32) * N).reshape(C, th, tw)
+    T0 = np.ones((C, H, W), np.float32)
+    g, p, c = UO.rasterize_to_indices_in_range(0, 10**10, T0, means2d, conics, opac, W, H, ts, offsets, flatten)
+    assert len(g) > 0 and np.all(c == 0)
+    # dense check of one pixel
+    for pix in (0, 5 * W + 7, H * W - 1):
+        i, j = divmod(pix, W)
+        T = 1.0
+        exp_ids = []
+        for n in range(N):
+            dx, dy = means2d[0, n, 0] - (j + 0.5), means2d[0, n, 1] - (i + 0.5)
+            s = 0.5 * (0.08 * dx * dx + 0.06 * dy * dy) + 0.01 * dx * dy
+            a = min(0.999, opac[0, n] * np.exp(-s))
+            if s < 0 or a < 1 / 255:
+                continue
+            if T * (1 - a) <= 1e-4:
+                break
+            exp_ids.append(n)
+            T *= 1 - a
+        assert list(g[p == pix]) == exp_ids
+    # one batch = ts*ts = 64 entries >= N: a single batch per tile; range [1, 2) is empty
+    g2, _, _ = UO.rasterize_to_indices_in_range(1, 2, T0, means2d, conics, opac, W, H, ts, offsets, flatten)
+    assert len(g2) == 0
