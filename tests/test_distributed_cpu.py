@@ -130,6 +130,14 @@ def _grad_reduce(rank, world):
     params["means"].grad = g["means"].clone()
     D.all_reduce_splat_grads([params["means"]], average=True, algorithm="all_reduce")
     assert torch.allclose(params["means"].grad, torch.full((7, 3), 1.5))
+    # the copy-free per-tensor path (default on RCCL; on gloo it falls back to in-place all_reduce per tensor)
+    params["means"].grad = g["means"].clone()
+    params["sh"].grad = g["sh"].clone().transpose(1, 2).contiguous().transpose(1, 2)  # non-contiguous gradient
+    params["nograd"].grad = None
+    D.all_reduce_splat_grads(params, average=True, algorithm="direct")
+    assert torch.allclose(params["means"].grad, torch.full((7, 3), 1.5))
+    assert torch.allclose(params["sh"].grad, torch.full((7, 4, 3), 1.5)) and params["sh"].grad.is_contiguous()
+    assert torch.equal(params["nograd"].grad, torch.zeros(5))
     # camera-sharded equivalence on a toy differentiable "renderer": sum over ALL cameras of f(c, theta)
     theta = torch.nn.Parameter(torch.arange(6, dtype=torch.float32).reshape(3, 2))
     cams = torch.arange(1, 5, dtype=torch.float32)  # 4 cameras
