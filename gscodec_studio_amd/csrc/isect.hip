@@ -62,6 +62,18 @@ __global__ void __launch_bounds__(GS_BLOCK) gather_i32_kernel(
     if (i < n) out[i] = src[idx[i]];
 }
 
+// Wave-cooperative emission.  A wave owns 64 consecutive positions of the emission order, whose pairs
+// form ONE contiguous output range [cum[first-1], cum[last]).  The lanes first park their splat's
+// record (output start, tile box, key base, id) in LDS, then walk the output range 64 slots at a time:
+// slot o finds its owner by a 6-step binary search over the 64 starts and derives its tile from its
+// offset inside the owner's box.  Stores are fully coalesced (the one-thread-per-splat loop wrote 12 B
+// at ~160 B strides: 51 us for 4 M pairs at config 2, 2.7x the compulsory traffic).
+struct EmitRec {
+    int64_t key_base; // camera bits | depth bits
+    int32_t id;       // flatten id
+    int32_t x0, y0, w;
+};
+
 __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
     uint32_t n_elems, uint32_t N, const int32_t *__restrict__ perm, const int64_t *__restrict__ camera_ids,
     const float *__restrict__ means2d, const int32_t *__restrict__ radii,
@@ -70,26 +82,54 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
     int64_t *__restrict__ isect_ids, int32_t *__restrict__ flatten_ids) {
     // `pos` = position in the emission order (identity, or depth-sorted when perm is given);
     // `i` = the element it refers to.  cum_tiles is indexed by position.
-    uint32_t pos = blockIdx.x * GS_BLOCK + threadIdx.x;
-    if (pos >= n_elems) return;
-    uint32_t i = perm != nullptr ? (uint32_t)perm[pos] : pos;
-    int32_t r = radii[i];
-    if (r <= 0) return;
-    float2 m = reinterpret_cast<const float2 *>(means2d)[i];
-    TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
-    int64_t cid = camera_ids != nullptr ? camera_ids[i] : (int64_t)(i / N);
-    int64_t cid_enc = cid << (32 + tile_n_bits);
-    // raw IEEE bits of the (positive) depth, sign-extended like the reference's
-    // (int64_t)*(int32_t*)&depth  (isect_tiles.cu:91)
-    int64_t depth_enc = (int64_t)__float_as_int(depths[i]);
-    int64_t cur = (pos == 0) ? 0 : cum_tiles[pos - 1];
-    for (int32_t y = b.y0; y < b.y1; ++y) {
-        for (int32_t x = b.x0; x < b.x1; ++x) {
-            int64_t tile_id = (int64_t)y * tw + x;
-            isect_ids[cur] = cid_enc | (tile_id << 32) | depth_enc;
-            flatten_ids[cur] = (int32_t)i;
-            ++cur;
+    __shared__ EmitRec s_rec[GS_BLOCK];
+    __shared__ int32_t s_start[GS_BLOCK + GS_BLOCK / GS_WAVE]; // 65 starts per wave (last = total)
+    const uint32_t lane = threadIdx.x % GS_WAVE, wave = threadIdx.x / GS_WAVE;
+    const uint32_t pos = blockIdx.x * GS_BLOCK + threadIdx.x;
+    const uint32_t wave_first = blockIdx.x * GS_BLOCK + wave * GS_WAVE;
+    if (wave_first >= n_elems) return; // wave-uniform
+    const uint32_t wave_last = min(wave_first + GS_WAVE, n_elems) - 1;
+    const int64_t out0 = (wave_first == 0) ? 0 : cum_tiles[wave_first - 1];
+    const int64_t out1 = cum_tiles[wave_last];
+    if (out1 == out0) return; // nothing visible in this wave (wave-uniform)
+    EmitRec rec = {0, 0, 0, 0, 1};
+    int32_t start = (int32_t)(out1 - out0);
+    if (pos < n_elems) {
+        const uint32_t i = perm != nullptr ? (uint32_t)perm[pos] : pos;
+        start = (int32_t)(((pos == 0) ? 0 : cum_tiles[pos - 1]) - out0);
+        const int32_t r = radii[i];
+        if (r > 0) {
+            const float2 m = reinterpret_cast<const float2 *>(means2d)[i];
+            const TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
+            const int64_t cid = camera_ids != nullptr ? camera_ids[i] : (int64_t)(i / N);
+            // raw IEEE bits of the (positive) depth, sign-extended like the reference's
+            // (int64_t)*(int32_t*)&depth  (isect_tiles.cu:91)
+            rec.key_base = (cid << (32 + tile_n_bits)) | (int64_t)__float_as_int(depths[i]);
+            rec.id = (int32_t)i;
+            rec.x0 = b.x0;
+            rec.y0 = b.y0;
+            rec.w = max(b.x1 - b.x0, 1);
         }
+    }
+    EmitRec *wrec = s_rec + wave * GS_WAVE;
+    int32_t *wstart = s_start + wave * (GS_WAVE + 1);
+    wrec[lane] = rec;
+    wstart[lane] = start;
+    if (lane == 0) wstart[GS_WAVE] = (int32_t)(out1 - out0);
+    __builtin_amdgcn_wave_barrier();
+    const int32_t total = (int32_t)(out1 - out0);
+    for (int32_t t = (int32_t)lane; t < total; t += GS_WAVE) {
+        // largest s with start[s] <= t (zero-count lanes share their successor's start and are skipped)
+        int32_t sidx = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+            if (wstart[sidx + step] <= t) sidx += step;
+        const EmitRec o = wrec[sidx];
+        const int32_t k = t - wstart[sidx];
+        const int32_t dy = k / o.w, dx = k - dy * o.w;
+        const int64_t tile_id = (int64_t)(o.y0 + dy) * tw + (o.x0 + dx);
+        isect_ids[out0 + t] = o.key_base | (tile_id << 32);
+        flatten_ids[out0 + t] = o.id;
     }
 }
 
