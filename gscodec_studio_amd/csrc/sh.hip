@@ -321,7 +321,29 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
             vmx += gx; vmy += gy; vmz += gz;
         }
     }
-    if (SHARED) store_row<NB * 3, VEC>(v_coeffs + (size_t)n * row_len, acc, row_len);
+    if (SHARED) {
+        // Every lane holds one 4*NV-float gradient row; rows of neighbouring lanes are row_len floats apart, so
+        // storing them straight from registers puts the 64 lanes of each store on 64 different cache lines.
+        // When the rows are dense (row_len == NB*3, multiple of 4) a full wave transposes them through LDS
+        // and writes its 64 rows as one contiguous block, 1 KiB per store instruction.
+        constexpr int RL = NB * 3;
+        constexpr bool CAN_T = VEC && (RL % 4 == 0);
+        __shared__ float4 s_tr[CAN_T ? (GS_BLOCK / GS_WAVE) * GS_WAVE * (RL / 4) : 1];
+        const uint32_t lane = threadIdx.x % GS_WAVE, wave = threadIdx.x / GS_WAVE;
+        const uint32_t wave_n0 = blockIdx.x * GS_BLOCK + wave * GS_WAVE;
+        if (CAN_T && row_len == (uint32_t)RL && wave_n0 + GS_WAVE <= N) { // wave-uniform
+            constexpr int NV = RL / 4;
+            float4 *w = s_tr + wave * GS_WAVE * NV;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) w[lane * NV + i] = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+            __builtin_amdgcn_wave_barrier();
+            float4 *dst = reinterpret_cast<float4 *>(v_coeffs + (size_t)wave_n0 * RL);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) dst[i * GS_WAVE + lane] = w[i * GS_WAVE + lane];
+        } else {
+            store_row<NB * 3, VEC>(v_coeffs + (size_t)n * row_len, acc, row_len);
+        }
+    }
     if (v_means != nullptr) {
         v_means[3 * (size_t)n] = vmx; v_means[3 * (size_t)n + 1] = vmy; v_means[3 * (size_t)n + 2] = vmz;
     }
