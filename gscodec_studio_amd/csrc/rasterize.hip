@@ -430,10 +430,36 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
 // Sub-batches are aligned to multiples of 64 of the GLOBAL list index, so a checkpoint boundary
 // (multiple of seg) always coincides with a sub-batch start.
 // ---------------------------------------------------------------------------
-template <int CDIM, bool CKPT>
-__global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, const int32_t *__restrict__ order, float *__restrict__ ckpt, int32_t seg) {
+// Depth-split of HEAVY tiles (list length >= PartArgs::heavy_min): the list is cut at global multiples of
+// `plen` into parts that run as independent workgroups.
+//   MODE 2 (prepass)  : per part and pixel, the transmittance product t_k of the part alone (no colour).
+//   MODE 1 (part)     : the normal compositing of one part, started from T = prod_{j<k} t_j, writing partial
+//                       colour / end transmittance (negative = stopped inside) / last id to the part arrays.
+//   MODE 0 (tile)     : whole tiles; heavy ones return at once (their parts do the work).
+// raster_combine_kernel then adds up the parts of a tile in order, writes the image and turns the
+// part-local checkpoints into global ones.  A part started beyond a pixel's stopping point sees
+// T <= 1e-4 and composites nothing, so the result is the sequential algorithm's (up to the association
+// of the transmittance product).  Why: the kernel's duration was the serial walk of the heaviest tiles
+// (4.5-6 k entries: 280 of 300 us), everything else finished in half that time.
+struct PartArgs {
+    const uint2 *items;      // (tile, k): list entries [k*plen, (k+1)*plen) of that tile; parts of a tile are consecutive
+    const uint32_t *n_items; // device counter
+    float *tpart;            // [slot][256]        MODE 2 out, MODE 1 in
+    float *cpart;            // [slot][CDIM][256]  MODE 1 out
+    float *tend;             // [slot][256]        MODE 1 out: T at the part's end, negated when the pixel stopped inside
+    int32_t *curp;           // [slot][256]        MODE 1 out: last composited list index or -1
+    int32_t plen, heavy_min; // heavy_min == 0: no depth split
+    uint32_t max_parts;      // grid slots reserved for parts in the mixed launch
+};
+
+template <int CDIM, bool CKPT, int MODESET>
+__global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, const int32_t *__restrict__ order, float *__restrict__ ckpt, int32_t seg, PartArgs pa) {
     constexpr int REC = 3;
     constexpr int BATCH = 256;
+    // MODESET 0: whole tiles.  2: prepass of the parts.  3: ONE launch that runs the parts (blocks
+    // [0, pa.max_parts), dispatched first) AND the light tiles (the rest) so that both overlap.
+    const int mode = (MODESET == 3) ? (blockIdx.x < pa.max_parts ? 1 : 0) : MODESET;
+    const uint32_t bid = (MODESET == 3 && mode == 0) ? blockIdx.x - pa.max_parts : blockIdx.x;
     __shared__ float4 s_rec[2][BATCH * REC];
     __shared__ unsigned long long s_mask[2][4][4]; // [buffer][sub-batch (= staging wave)][quadrant]
     __shared__ uint32_t s_done[2][4];              // [buffer][quadrant]
@@ -446,7 +472,18 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     unsigned long long abl_bar = 0;
 #endif
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-    const TileGeom tg = tile_geom(a, order, xcd_remap(blockIdx.x, gridDim.x, a.xcd_group));
+    uint32_t tile_slot, part_k = 0, part_slot = 0;
+    if (mode == 0) {
+        tile_slot = xcd_remap(bid, (MODESET == 3) ? gridDim.x - pa.max_parts : gridDim.x, a.xcd_group);
+    } else {
+        const uint32_t n_items = *pa.n_items; // the grid is an upper bound
+        if (bid >= n_items) return;
+        part_slot = xcd_remap(bid, n_items, 4u);
+        const uint2 it = pa.items[part_slot];
+        tile_slot = it.x;
+        part_k = it.y;
+    }
+    TileGeom tg = tile_geom(a, order, tile_slot);
     const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels : nullptr;
 
     const uint32_t ox = lx + 8u * (w & 1u), oy = ly + 8u * (w >> 1);
@@ -455,12 +492,19 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     const float px = (float)x + 0.5f, py = (float)y + 0.5f;
     const size_t pix = ((size_t)tg.cam * a.image_height + y) * a.image_width + x;
 
-    if (a.masks != nullptr && !a.masks[tg.lin]) {
+    if (mode == 0 && a.masks != nullptr && !a.masks[tg.lin]) {
         if (inside) {
 #pragma unroll
             for (int k = 0; k < CDIM; ++k) a.render_colors[pix * CDIM + k] = bg ? bg[k] : 0.f;
         }
         return;
+    }
+    if (mode == 0 && pa.heavy_min > 0 && tg.range_end - tg.range_start >= pa.heavy_min) return; // done by its parts
+    const int32_t tile_start = tg.range_start;
+    const int32_t part_k0 = tile_start / (pa.plen > 0 ? pa.plen : 1); // first part index of this tile
+    if (mode != 0) { // restrict the walk to this part
+        tg.range_start = max(tg.range_start, (int32_t)part_k * pa.plen);
+        tg.range_end = min(tg.range_end, ((int32_t)part_k + 1) * pa.plen);
     }
 
     float qx0[4], qx1[4], qy0[4], qy1[4];
@@ -473,10 +517,16 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     }
 
     float T = 1.f, Tkeep = 1.f, out[CDIM];
-    int32_t cur = 0;
+    int32_t cur = (mode == 1) ? -1 : 0;
     bool done = !inside;
 #pragma unroll
     for (int k = 0; k < CDIM; ++k) out[k] = 0.f;
+    if (mode == 1) { // transmittance in front of this part = product of the earlier parts' products
+        const uint32_t p = w * 64u + lane;
+        for (uint32_t j = (uint32_t)part_k0; j < part_k; ++j) T *= pa.tpart[(size_t)(part_slot - (part_k - j)) * 256 + p];
+        Tkeep = T;
+        done = done || (T <= 1e-4f); // cannot composite any more: the first valid splat would stop it
+    }
 
     const int32_t n = tg.range_end - tg.range_start;
     const int32_t base0 = tg.range_start & ~(GS_WAVE - 1);
@@ -512,8 +562,11 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     Staged nxt;
     gather(id_cur, nxt);
 
-    int32_t next_b = CKPT ? (tg.range_start / seg + 1) * seg : 0x7fffffff;
-    int32_t next_k = CKPT ? next_b / seg : 0;
+    // first boundary this workgroup stores: strictly inside the list -- a later part also owns the boundary
+    // AT its start (the state "before entry k*plen" is its initial state)
+    int32_t next_b = 0x7fffffff;
+    if (CKPT && MODESET != 2) next_b = (mode == 1 && tg.range_start > tile_start) ? tg.range_start : (tg.range_start / seg + 1) * seg;
+    int32_t next_k = (CKPT && MODESET != 2) ? next_b / seg : 0;
     auto store_ckpt = [&]() {
         float *base = ckpt + (size_t)next_k * (CDIM + 1) * 256;
         const uint32_t p = w * 64u + lane;
@@ -595,38 +648,34 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
             // ~5 cycles and a record is a ~25-deep dependent chain, so one record at a time costs
             // ~390 cycles (measured) against ~40 instructions x 5 cycles of issue.  The four alpha
             // evaluations are independent; only T <- T - T a (one fma) is carried from record to record.
-            // The next group's records are read from LDS while this group is evaluated.
+            // (No explicit prefetch of the next group: it cost 40 VGPRs, i.e. two waves per SIMD, and the
+            // kernel's duration is rounds of workgroups x their lifetime, not the walk of one list.)
             constexpr int G = 4;
-            int tt[G];
-            bool vv[G];
-            float4 q0[G], q1[G], q2[G];
-            auto take = [&]() { // pop up to G set bits (wave-uniform); exhausted slots alias slot tt[0], masked by vv
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    vv[g] = m != 0ull;
-                    tt[g] = vv[g] ? __builtin_ctzll(m) : (g ? tt[0] : 0);
-                    m &= m - 1;
-                }
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    q0[g] = rec[tt[g] * REC + 0];
-                    q1[g] = rec[tt[g] * REC + 1];
-                    if (CDIM > 2) q2[g] = rec[tt[g] * REC + 2];
-                }
-            };
-            take();
-            while (vv[0]) {
-                float4 c0[G], c1[G], c2[G];
+            while (m != 0ull) {
+                float4 c0[G], c1[G];
+                float c2x[G], c2y[G]; // colours 2, 3 (only what CDIM needs is read)
                 int32_t idx[G];
                 bool rv[G];
+                {
+                    int t0 = 0;
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    c0[g] = q0[g]; c1[g] = q1[g];
-                    if (CDIM > 2) c2[g] = q2[g];
-                    idx[g] = sb_start + tt[g];
-                    rv[g] = vv[g];
+                    for (int g = 0; g < G; ++g) { // pop up to G set bits (wave-uniform); exhausted slots alias the first one, masked by rv
+                        rv[g] = m != 0ull;
+                        const int t = rv[g] ? __builtin_ctzll(m) : t0;
+                        if (g == 0) t0 = t;
+                        m &= m - 1;
+                        idx[g] = sb_start + t;
+                        c0[g] = rec[t * REC + 0];
+                        c1[g] = rec[t * REC + 1];
+                        c2x[g] = c2y[g] = 0.f;
+                        if (CDIM == 3) c2x[g] = reinterpret_cast<const float *>(rec + t * REC + 2)[0];
+                        if (CDIM > 3) {
+                            const float2 v = reinterpret_cast<const float2 *>(rec + t * REC + 2)[0];
+                            c2x[g] = v.x;
+                            c2y[g] = v.y;
+                        }
+                    }
                 }
-                take(); // prefetch the next group
                 float a_eff[G];
                 bool ok[G];
 #pragma unroll
@@ -636,6 +685,12 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
                     const float alpha = fminf(0.999f, __builtin_amdgcn_exp2f(power + c1[g].y));
                     ok[g] = rv[g] && !(power > 0.f) && (alpha >= ALPHA_MIN);
                     a_eff[g] = ok[g] ? alpha : 0.f;
+                }
+                if (MODESET == 2) { // transmittance product only; frozen once it cannot matter any more
+#pragma unroll
+                    for (int g = 0; g < G; ++g) T = done ? T : T - T * a_eff[g];
+                    done = done || (T <= 1e-4f);
+                    continue;
                 }
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -647,8 +702,8 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
                     const float vis = live ? a_eff[g] * Tj : 0.f;
                     out[0] += c1[g].z * vis;
                     if (CDIM > 1) out[CDIM > 1 ? 1 : 0] += c1[g].w * vis;
-                    if (CDIM > 2) out[CDIM > 2 ? 2 : 0] += c2[g].x * vis;
-                    if (CDIM > 3) out[CDIM > 3 ? 3 : 0] += c2[g].y * vis;
+                    if (CDIM > 2) out[CDIM > 2 ? 2 : 0] += c2x[g] * vis;
+                    if (CDIM > 3) out[CDIM > 3 ? 3 : 0] += c2y[g] * vis;
                     cur = (live && ok[g]) ? idx[g] : cur;
                     done = done || stop;
                     T = next_T;
@@ -658,13 +713,25 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
         }
     }
 
-    if (CKPT && n > 0) {
+    if (CKPT && MODESET != 2 && n > 0) {
         // boundaries after the last composited record (or after an early exit) carry the final state
         while (next_b < tg.range_end) {
             store_ckpt();
             next_b += seg;
             next_k += 1;
         }
+    }
+    if (MODESET == 2) {
+        pa.tpart[(size_t)part_slot * 256 + w * 64u + lane] = inside ? T : 1.f;
+        return;
+    }
+    if (mode == 1) {
+        const size_t p = (size_t)part_slot * 256 + w * 64u + lane;
+        pa.tend[p] = done ? -Tkeep : T;
+        pa.curp[p] = cur;
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) pa.cpart[((size_t)part_slot * CDIM + k) * 256 + w * 64u + lane] = out[k];
+        return;
     }
     if (inside) {
         const float Tf = done ? Tkeep : T;
@@ -674,8 +741,8 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
         a.last_ids[pix] = cur;
     }
 #if defined(GS_ABL) && GS_ABL == 9
-    if (lane == 0 && blockIdx.x * 4 + w < 65536u) {
-        const uint32_t slot = blockIdx.x * 4 + w;
+    if (mode == 0 && lane == 0 && bid * 4 + w < 65536u) {
+        const uint32_t slot = bid * 4 + w;
         g_abl_wave[slot * 4 + 0] = abl_t0;
         g_abl_wave[slot * 4 + 1] = wall_clock64();
         g_abl_wave[slot * 4 + 2] = ((unsigned long long)n << 32) | abl_evals;
@@ -684,13 +751,112 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
 #endif
 }
 
+// (tile, k) items of the heavy tiles: every global part [k*plen, (k+1)*plen) that intersects the tile's range
+struct HeavyTile {
+    uint32_t tile, first_slot, n_parts, k0;
+};
+
+__global__ void __launch_bounds__(GS_BLOCK) fwd_parts_kernel(uint32_t n_tiles_all, uint32_t n_isects, const int32_t *__restrict__ offsets,
+                                                             const uint8_t *__restrict__ masks, int32_t plen, int32_t heavy_min,
+                                                             uint32_t *__restrict__ counters /* [1] parts, [2] heavy tiles */,
+                                                             uint2 *__restrict__ items, HeavyTile *__restrict__ heavy) {
+    const uint32_t t = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (t >= n_tiles_all) return;
+    const int32_t rs = offsets[t];
+    const int32_t re = (t + 1 == n_tiles_all) ? (int32_t)n_isects : offsets[t + 1];
+    if (re - rs < heavy_min) return;
+    if (masks != nullptr && !masks[t]) return;
+    const int32_t k0 = rs / plen, k1 = (re - 1) / plen;
+    const uint32_t np = (uint32_t)(k1 - k0 + 1);
+    const uint32_t slot = atomicAdd(&counters[1], np);
+    const uint32_t h = atomicAdd(&counters[2], 1u);
+    heavy[h] = {t, slot, np, (uint32_t)k0};
+    for (uint32_t j = 0; j < np; ++j) items[slot + j] = make_uint2(t, (uint32_t)k0 + j);
+}
+
+// One workgroup per heavy tile, one thread per pixel (same pixel <-> thread map as the tile kernel):
+// sums the parts in order, writes the image, and rewrites the tile's checkpoints in place -- colour
+// becomes global (part-local + colour of the earlier parts), and every boundary behind the pixel's
+// stopping point carries the final state, exactly what the undivided walk stores.
 template <int CDIM>
-void launch_tile_fwd(const RasterArgs &a, const int32_t *order, float *ckpt, int32_t seg, hipStream_t st) {
-    dim3 grid(a.C * a.tile_width * a.tile_height);
-    if (ckpt != nullptr)
-        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true>), grid, dim3(256), 0, st, a, order, ckpt, seg);
-    else
-        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, false>), grid, dim3(256), 0, st, a, order, ckpt, seg);
+__global__ void __launch_bounds__(256) raster_combine_kernel(RasterArgs a, float *__restrict__ ckpt, int32_t seg, PartArgs pa,
+                                                              const HeavyTile *__restrict__ heavy, const uint32_t *__restrict__ counters) {
+    if (blockIdx.x >= counters[2]) return;
+    const HeavyTile ht = heavy[blockIdx.x];
+    const TileGeom tg = tile_geom(a, nullptr, ht.tile);
+    const uint32_t p = threadIdx.x, w = p >> 6, lane = p & 63u;
+    const uint32_t ox = (lane & 7u) + 8u * (w & 1u), oy = (lane >> 3) + 8u * (w >> 1);
+    const uint32_t x = tg.px0 + ox, y = tg.py0 + oy;
+    const bool inside = ox < a.tile_size && oy < a.tile_size && x < a.image_width && y < a.image_height;
+    float C_acc[CDIM];
+#pragma unroll
+    for (int k = 0; k < CDIM; ++k) C_acc[k] = 0.f;
+    bool stopped = false;
+    float T_stop = 1.f, T_last = 1.f;
+    int32_t last = -1;
+    for (uint32_t j = 0; j < ht.n_parts; ++j) {
+        const size_t slot = (size_t)ht.first_slot + j;
+        const int32_t part_start = max(tg.range_start, (int32_t)(ht.k0 + j) * pa.plen);
+        const int32_t part_end = min(tg.range_end, (int32_t)(ht.k0 + j + 1) * pa.plen);
+        if (ckpt != nullptr) {
+            const int32_t kk0 = (j == 0) ? tg.range_start / seg + 1 : part_start / seg;
+            for (int32_t kk = kk0; kk * seg < part_end; ++kk) {
+                float *base = ckpt + (size_t)kk * (CDIM + 1) * 256;
+                if (stopped) base[p] = T_stop;
+#pragma unroll
+                for (int k = 0; k < CDIM; ++k) base[(k + 1) * 256 + p] = stopped ? C_acc[k] : base[(k + 1) * 256 + p] + C_acc[k];
+            }
+        }
+        const float te = pa.tend[slot * 256 + p];
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) C_acc[k] += pa.cpart[(slot * CDIM + k) * 256 + p];
+        const int32_t c = pa.curp[slot * 256 + p];
+        if (c >= 0) last = c;
+        if (!stopped) {
+            if (te < 0.f) {
+                stopped = true;
+                T_stop = -te;
+            } else {
+                T_last = te;
+            }
+        }
+    }
+    if (!inside) return;
+    const float Tf = stopped ? T_stop : T_last;
+    const size_t pix = ((size_t)tg.cam * a.image_height + y) * a.image_width + x;
+    const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels : nullptr;
+    a.render_alphas[pix] = 1.f - Tf;
+#pragma unroll
+    for (int k = 0; k < CDIM; ++k) a.render_colors[pix * CDIM + k] = bg ? C_acc[k] + Tf * bg[k] : C_acc[k];
+    a.last_ids[pix] = last >= 0 ? last : 0;
+}
+
+struct PartPlan { // host view of the depth-split scratch
+    PartArgs pa;
+    HeavyTile *heavy;
+    uint32_t *counters;
+    uint32_t max_parts, max_heavy;
+};
+
+template <int CDIM>
+void launch_tile_fwd(const RasterArgs &a, const int32_t *order, float *ckpt, int32_t seg, const PartPlan *plan, hipStream_t st) {
+    const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;
+    dim3 grid(n_tiles_all);
+    PartArgs none = {};
+    if (plan == nullptr || ckpt == nullptr) {
+        if (ckpt != nullptr)
+            hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true, 0>), grid, dim3(256), 0, st, a, order, ckpt, seg, none);
+        else
+            hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, false, 0>), grid, dim3(256), 0, st, a, order, ckpt, seg, none);
+        return;
+    }
+    const PartArgs &pa = plan->pa;
+    hipLaunchKernelGGL(fwd_parts_kernel, dim3(gs_div_up(n_tiles_all, GS_BLOCK)), dim3(GS_BLOCK), 0, st, n_tiles_all, a.n_isects,
+                       a.tile_offsets, a.masks, pa.plen, pa.heavy_min, plan->counters, const_cast<uint2 *>(pa.items), plan->heavy);
+    hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, false, 2>), dim3(plan->max_parts), dim3(256), 0, st, a, nullptr, ckpt, seg, pa);
+    // parts (first in dispatch order) and light tiles in ONE launch: consecutive launches of a stream do not overlap
+    hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true, 3>), dim3(plan->max_parts + n_tiles_all), dim3(256), 0, st, a, order, ckpt, seg, pa);
+    hipLaunchKernelGGL((raster_combine_kernel<CDIM>), dim3(plan->max_heavy), dim3(256), 0, st, a, ckpt, seg, pa, plan->heavy, plan->counters);
 }
 
 // ---------------------------------------------------------------------------
@@ -1382,9 +1548,33 @@ int32_t seg_len(uint32_t n_isects) {
     return v;
 }
 
+// Depth split of the forward: part length and the list length from which a tile is split.
+// GS_RASTER_PART=<plen|0> (multiple of the segment length; 0 disables), GS_RASTER_HEAVY=<min list length>.
+void part_config(uint32_t n_isects, int32_t &plen, int32_t &heavy_min) {
+    const int32_t seg = seg_len(n_isects);
+    plen = 0; // opt-in: measured on MI355X at config 2 the forward is bound by rounds of workgroups, not by its
+              // heaviest tiles (207 tiles >= 2048 entries hold 18% of the pairs); the split pays for 10k+ entry lists
+    heavy_min = 2048;
+    if (const char *e = getenv("GS_RASTER_PART")) plen = atoi(e);
+    if (const char *e = getenv("GS_RASTER_HEAVY")) heavy_min = atoi(e);
+    if (seg <= 0 || plen <= 0) {
+        plen = 0;
+        heavy_min = 0;
+        return;
+    }
+    plen = ((plen + seg - 1) / seg) * seg;
+    if (heavy_min < plen + 1) heavy_min = plen + 1;
+    if ((int64_t)n_isects < heavy_min) { // no tile can be heavy
+        plen = 0;
+        heavy_min = 0;
+    }
+}
+
 struct ScratchLayout {
     size_t off_items, off_order, off_ckpt, total;
-    uint32_t max_items;
+    size_t off_pitems, off_heavy, off_tpart, off_cpart, off_tend, off_curp;
+    uint32_t max_items, max_parts, max_heavy;
+    int32_t plen, heavy_min;
 };
 
 ScratchLayout scratch_layout(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels) {
@@ -1399,6 +1589,19 @@ ScratchLayout scratch_layout(uint32_t n_tiles_all, uint32_t n_isects, uint32_t c
     o += up((size_t)n_tiles_all * sizeof(int32_t));
     L.off_ckpt = o;
     if (seg > 0 && channels <= 4) o += up(((size_t)n_isects / seg + 2) * (channels + 1) * 256 * sizeof(float));
+    part_config(n_isects, L.plen, L.heavy_min);
+    L.max_parts = L.max_heavy = 0;
+    L.off_pitems = L.off_heavy = L.off_tpart = L.off_cpart = L.off_tend = L.off_curp = o;
+    if (L.plen > 0 && channels <= 4) {
+        L.max_heavy = n_isects / (uint32_t)L.heavy_min + 1;
+        L.max_parts = n_isects / (uint32_t)L.plen + 2 * L.max_heavy + 1;
+        L.off_pitems = o; o += up((size_t)L.max_parts * sizeof(uint2));
+        L.off_heavy = o;  o += up((size_t)L.max_heavy * sizeof(HeavyTile));
+        L.off_tpart = o;  o += up((size_t)L.max_parts * 256 * sizeof(float));
+        L.off_cpart = o;  o += up((size_t)L.max_parts * channels * 256 * sizeof(float));
+        L.off_tend = o;   o += up((size_t)L.max_parts * 256 * sizeof(float));
+        L.off_curp = o;   o += up((size_t)L.max_parts * 256 * sizeof(int32_t));
+    }
     L.total = o;
     return L;
 }
@@ -1458,11 +1661,34 @@ int32_t raster_wave_fwd(const RasterArgs &a_in, void *scratch, size_t scratch_by
     const char *efw = getenv("GS_RASTER_FWD"); // "wave": independent quadrant waves (previous default, A/B)
     if (a.channels <= 4 && !nq4 && !(efw != nullptr && efw[0] == 'w')) {
         a.xcd_group = xcd_group_env("GS_RASTER_XCD_FWD", 64u) / 4u; // groups of 16 tiles per XCD
+        PartPlan plan;
+        const PartPlan *pp = nullptr;
+        if (ckpt != nullptr && L.max_parts > 0 && order == nullptr) {
+            char *sp = (char *)scratch;
+            plan.counters = (uint32_t *)scratch;
+            plan.heavy = (HeavyTile *)(sp + L.off_heavy);
+            plan.max_parts = L.max_parts;
+            plan.max_heavy = L.max_heavy;
+            plan.pa.items = (const uint2 *)(sp + L.off_pitems);
+            plan.pa.n_items = plan.counters + 1;
+            plan.pa.tpart = (float *)(sp + L.off_tpart);
+            plan.pa.cpart = (float *)(sp + L.off_cpart);
+            plan.pa.tend = (float *)(sp + L.off_tend);
+            plan.pa.curp = (int32_t *)(sp + L.off_curp);
+            plan.pa.plen = L.plen;
+            plan.pa.heavy_min = L.heavy_min;
+            plan.pa.max_parts = L.max_parts;
+            if (hipMemsetAsync(plan.counters + 1, 0, 2 * sizeof(uint32_t), st) != hipSuccess) {
+                gs_set_error("gs_rasterize_fwd: memset failed");
+                return 2;
+            }
+            pp = &plan;
+        }
         switch (a.channels) {
-            case 1: launch_tile_fwd<1>(a, order, ckpt, seg, st); break;
-            case 2: launch_tile_fwd<2>(a, order, ckpt, seg, st); break;
-            case 3: launch_tile_fwd<3>(a, order, ckpt, seg, st); break;
-            default: launch_tile_fwd<4>(a, order, ckpt, seg, st); break;
+            case 1: launch_tile_fwd<1>(a, order, ckpt, seg, pp, st); break;
+            case 2: launch_tile_fwd<2>(a, order, ckpt, seg, pp, st); break;
+            case 3: launch_tile_fwd<3>(a, order, ckpt, seg, pp, st); break;
+            default: launch_tile_fwd<4>(a, order, ckpt, seg, pp, st); break;
         }
         return 0;
     }

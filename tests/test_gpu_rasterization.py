@@ -220,3 +220,33 @@ def test_camera_centers_and_pose_gradients():
     assert_close(N(rc), N(rc2), 1e-5, 1e-6, "fused vs unfused SH route", max_bad_frac=1e-4)
     rc.sum().backward()
     assert Vg.grad is not None and bool(torch.isfinite(Vg.grad).all()) and float(Vg.grad.abs().sum()) > 0
+
+
+def test_depth_split_forward_matches_undivided(monkeypatch):
+    """Opt-in depth split of heavy tiles (GS_RASTER_PART / GS_RASTER_HEAVY): parts composited by independent
+    workgroups from the prepass transmittances, combined afterwards, checkpoints made global -- images,
+    last ids and all gradients must equal the undivided walk's."""
+    from gscodec_studio_amd import rasterization
+
+    d = _inputs(n=4000, cams=2, sh_degree=None, scale_mult=12.0)  # big splats: lists of several hundred entries per tile
+
+    def run():
+        ps = [T(d[k]).requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")]
+        bg = torch.tensor([[0.2, 0.4, 0.6], [0.1, 0.1, 0.9]], device="cuda")
+        rc, ra, meta = rasterization(*ps, T(d["viewmats"]), T(d["Ks"]), d["W"], d["H"], packed=False, backgrounds=bg)
+        w = torch.linspace(0.5, 1.5, rc.numel(), device="cuda").reshape(rc.shape)
+        ((rc * w).sum() + 0.3 * ra.sum()).backward()
+        return N(rc), N(ra), [N(p.grad) for p in ps], meta
+
+    monkeypatch.delenv("GS_RASTER_PART", raising=False)
+    rc0, ra0, g0, meta = run()
+    offs = N(meta["isect_offsets"]).reshape(-1)
+    lens = np.diff(np.concatenate([offs, [meta["flatten_ids"].numel()]]))
+    assert lens.max() >= 600, int(lens.max())  # the split below really triggers (several parts per tile)
+    monkeypatch.setenv("GS_RASTER_PART", "256")
+    monkeypatch.setenv("GS_RASTER_HEAVY", "300")
+    rc1, ra1, g1, _ = run()
+    assert_close(rc1, rc0, 1e-4, 2e-6, "colors", max_bad_frac=1e-4)
+    assert_close(ra1, ra0, 1e-4, 2e-6, "alphas", max_bad_frac=1e-4)
+    for a, b, name in zip(g1, g0, ("means", "quats", "scales", "opacities", "colors")):
+        assert rel_l2(a, b) < 2e-4, (name, rel_l2(a, b))
