@@ -1,0 +1,41 @@
+"""Build profiles/r01_pmc_traffic.json from two rocprofv3 counter-collection CSVs (separate --pmc passes).
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+
+bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB, and FETCH_SIZE reports half of the
+fetched bytes on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def load(path, counter):
+    acc = defaultdict(lambda: defaultdict(float))  # kernel -> dispatch -> value (summed over the rows of one dispatch)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        acc[r["Kernel_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    return {k: sum(v.values()) / len(v) for k, v in acc.items()}
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
+    kernels = {}
+    for k in f:
+        fk, wk = f[k], w.get(k, 0.0)
+        kernels[k] = {"FETCH_SIZE_KB_avg": fk, "WRITE_SIZE_KB_avg": wk, "traffic_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
+    kernels = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"]))
+    json.dump({
+        "workload_key": "grid3_1920x1080_sh3",
+        "command": "cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline ; same with --pmc WRITE_SIZE (separate passes)",
+        "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: KB units; FETCH_SIZE reports 1/2 of the fetched bytes on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated",
+        "kernels": kernels,
+    }, open(out, "w"), indent=1)
+    for k, v in list(kernels.items())[:8]:
+        print(f"{v['traffic_bytes_per_launch'] / 1e6:9.1f} MB  {k[:90]}")
+
+
+if __name__ == "__main__":
+    main()
