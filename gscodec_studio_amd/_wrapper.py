@@ -843,6 +843,7 @@ class _RasterizeToPixels(torch.autograd.Function):
                               render_alphas, last_ids, scratch)
         ctx.render_colors = render_colors.detach()
         ctx.width, ctx.height, ctx.tile_size, ctx.absgrad = width, height, tile_size, absgrad
+        ctx.set_materialize_grads(False)
         return render_colors, render_alphas
 
     @staticmethod
@@ -854,8 +855,12 @@ class _RasterizeToPixels(torch.autograd.Function):
         channels = colors.shape[-1]
         n_elems = opacities.numel()
         n_isects = flatten_ids.shape[0]
+        # undefined upstream gradients arrive as None (set_materialize_grads(False) in forward): the kernel takes a
+        # NULL v_render_alphas, which saves a [C,H,W] zero-fill and one of the 12 per-pixel loads of every work item
+        if v_render_colors is None:
+            v_render_colors = torch.zeros_like(render_colors)
         v_render_colors = _f32c(v_render_colors)
-        v_render_alphas = _f32c(v_render_alphas)
+        v_render_alphas = _f32c(v_render_alphas) if v_render_alphas is not None else None
         # accumulated with atomics -> zero-filled.  Up to 4 channels: ONE packed [n_elems,16] buffer
         # (64-byte row per splat: vx vy | ca cb cc | o | c0..c3 | ax ay) so that a splat's whole
         # gradient is one L2 request; the tensors handed to autograd are views of it.
