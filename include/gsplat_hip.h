@@ -303,7 +303,7 @@ int32_t gs_rasterize_bwd(
     const int32_t *tile_offsets, const int32_t *flatten_ids,
     const float *render_colors, /* forward output, or NULL (disables the segmented path) */
     const float *render_alphas, const int32_t *last_ids,
-    const float *v_render_colors, const float *v_render_alphas,
+    const float *v_render_colors, const float *v_render_alphas /* or NULL (= zero) */,
     float *v_means2d_abs, /* [n_elems,2] or NULL */
     float *v_means2d,     /* [n_elems,2] */
     float *v_conics,      /* [n_elems,3] */
