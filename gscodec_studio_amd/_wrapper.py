@@ -684,11 +684,24 @@ def isect_tiles(
         assert depths.shape == (C, N), depths.size()
         camera_ids = None
         n_elems = C * N
+    return isect_tiles_finish(isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height, sort, C, N,
+                                                n_elems, camera_ids))
+
+
+@torch.no_grad()
+def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height, sort, C, N, n_elems, camera_ids):
+    """First half of ``isect_tiles``: everything up to the data-dependent size -- count, splat-level depth sort,
+    prefix sum -- plus an ASYNCHRONOUS read-back of n_isects into pinned memory.  Work launched between
+    ``begin`` and ``finish`` (the SH colours in ``rasterization``) runs while the host waits for the count, so the
+    GPU does not idle across the one host sync of the pipeline (reference: the blocking ``.item()`` of
+    isect_tiles.cu:200)."""
     _require_gpu(means2d, "isect_tiles")
     means2d, depths = _f32c(means2d), _f32c(depths)
     radii = radii.contiguous()
     assert radii.dtype == torch.int32, radii.dtype
     dev = means2d.device
+    st_ = dict(means2d=means2d, radii=radii, depths=depths, tile_size=tile_size, tile_width=tile_width,
+               tile_height=tile_height, sort=sort, C=C, N=N, n_elems=n_elems, camera_ids=camera_ids, dev=dev)
     st = _stream(means2d)
 
     n_tiles = tile_width * tile_height
@@ -696,21 +709,12 @@ def isect_tiles(
     tile_n_bits = int(math.floor(math.log2(n_tiles))) + 1 if n_tiles > 0 else 1
     cam_n_bits = int(math.floor(math.log2(C))) + 1 if C > 0 else 1
     assert tile_n_bits + cam_n_bits <= 32, "tile_n_bits + cam_n_bits must be <= 32"
+    st_["tile_n_bits"], st_["cam_n_bits"] = tile_n_bits, cam_n_bits
 
     tiles_per_gauss = torch.empty(radii.shape, dtype=torch.int32, device=dev)
-
-    def _sort(n, keys, vals, begin_bit, end_bit):
-        ko, vo = torch.empty_like(keys), torch.empty_like(vals)
-        tb = B.query("gs_sort_temp_bytes", n)
-        temp = torch.empty(tb, dtype=torch.uint8, device=dev)
-        B.call("gs_sort_pairs_u64_i32", n, B.ptr(keys), B.ptr(vals), B.ptr(ko), B.ptr(vo), begin_bit, end_bit,
-               B.ptr(temp), tb, st)
-        return ko, vo
-
+    st_["tiles_per_gauss"] = tiles_per_gauss
+    st_["cum"] = st_["perm"] = st_["pinned"] = st_["event"] = None
     with _device_of(means2d):
-        n_isects = 0
-        cum = None
-        perm = None
         if n_elems > 0:
             B.call("gs_isect_count", n_elems, B.ptr(means2d), B.ptr(radii), tile_size, tile_width, tile_height,
                    B.ptr(tiles_per_gauss), st)
@@ -720,23 +724,51 @@ def isect_tiles(
                 dkeys = torch.empty(n_elems, dtype=torch.int64, device=dev)
                 dvals = torch.empty(n_elems, dtype=torch.int32, device=dev)
                 B.call("gs_isect_depth_keys", n_elems, B.ptr(radii), B.ptr(depths), B.ptr(dkeys), B.ptr(dvals), st)
-                _, perm = _sort(n_elems, dkeys, dvals, 32, 64)
+                _, perm = _sort_pairs(n_elems, dkeys, dvals, 32, 64, dev, st)
                 counts = torch.empty(n_elems, dtype=torch.int32, device=dev)
                 B.call("gs_gather_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(perm), B.ptr(counts), st)
+                st_["perm"] = perm
             cum = torch.empty(n_elems, dtype=torch.int64, device=dev)
             sb = B.query("gs_cumsum_scratch_bytes", n_elems)
             scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
             B.call("gs_cumsum_i32", n_elems, B.ptr(counts), B.ptr(cum), B.ptr(scratch), sb, st)
-            n_isects = int(cum[-1].item())  # the one host sync (isect_tiles.cu:200)
+            pinned = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            pinned.copy_(cum[-1:], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            st_["cum"], st_["pinned"], st_["event"] = cum, pinned, ev
+    return st_
+
+
+@torch.no_grad()
+def isect_tiles_finish(st_) -> Tuple[Tensor, Tensor, Tensor]:
+    """Second half of ``isect_tiles``: wait for n_isects, emit the (tile, depth) pairs, sort them."""
+    means2d, radii, depths, dev = st_["means2d"], st_["radii"], st_["depths"], st_["dev"]
+    st = _stream(means2d)
+    n_isects = 0
+    if st_["event"] is not None:
+        st_["event"].synchronize()  # the one host sync (isect_tiles.cu:200)
+        n_isects = int(st_["pinned"][0])
+    with _device_of(means2d):
         isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
         flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
         if n_isects > 0:
-            B.call("gs_isect_emit", n_elems, max(N, 1), B.ptr(perm), B.ptr(camera_ids), B.ptr(means2d), B.ptr(radii),
-                   B.ptr(depths), B.ptr(cum), tile_size, tile_width, tile_height, tile_n_bits, B.ptr(isect_ids),
-                   B.ptr(flatten_ids), st)
-            if sort:
-                isect_ids, flatten_ids = _sort(n_isects, isect_ids, flatten_ids, 32, 32 + tile_n_bits + cam_n_bits)
-    return tiles_per_gauss, isect_ids, flatten_ids
+            B.call("gs_isect_emit", st_["n_elems"], max(st_["N"], 1), B.ptr(st_["perm"]), B.ptr(st_["camera_ids"]),
+                   B.ptr(means2d), B.ptr(radii), B.ptr(depths), B.ptr(st_["cum"]), st_["tile_size"], st_["tile_width"],
+                   st_["tile_height"], st_["tile_n_bits"], B.ptr(isect_ids), B.ptr(flatten_ids), st)
+            if st_["sort"]:
+                isect_ids, flatten_ids = _sort_pairs(n_isects, isect_ids, flatten_ids, 32,
+                                                     32 + st_["tile_n_bits"] + st_["cam_n_bits"], dev, st)
+    return st_["tiles_per_gauss"], isect_ids, flatten_ids
+
+
+def _sort_pairs(n, keys, vals, begin_bit, end_bit, dev, st):
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    tb = B.query("gs_sort_temp_bytes", n)
+    temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+    B.call("gs_sort_pairs_u64_i32", n, B.ptr(keys), B.ptr(vals), B.ptr(ko), B.ptr(vo), begin_bit, end_bit,
+           B.ptr(temp), tb, st)
+    return ko, vo
 
 
 @torch.no_grad()

@@ -27,6 +27,8 @@ from ._wrapper import (
     fully_fused_projection,
     isect_offset_encode,
     isect_tiles,
+    isect_tiles_begin,
+    isect_tiles_finish,
     rasterize_to_pixels,
     spherical_harmonics,
     spherical_harmonics_shared,
@@ -187,6 +189,16 @@ def rasterization(
         }
     )
 
+    tile_width = math.ceil(width / float(tile_size))
+    tile_height = math.ceil(height / float(tile_size))
+    # Tile binning is split around its one host sync (the intersection count): the first half is queued here, the
+    # colour evaluation below then runs on the GPU while the host waits for the count.
+    isect_state = None
+    if not distributed:
+        n_elems = int(radii.numel())
+        isect_state = isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height, True, C,
+                                        0 if packed else N, n_elems, camera_ids.contiguous() if packed else None)
+
     # colours -> [C, N, D] or [nnz, D]
     if sh_degree is None:
         if packed:
@@ -235,12 +247,13 @@ def rasterization(
         if backgrounds is not None:
             backgrounds = torch.zeros(C, 1, device=backgrounds.device)
 
-    tile_width = math.ceil(width / float(tile_size))
-    tile_height = math.ceil(height / float(tile_size))
-    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
-        means2d, radii, depths, tile_size, tile_width, tile_height,
-        packed=packed, n_cameras=C, camera_ids=camera_ids, gaussian_ids=gaussian_ids,
-    )
+    if isect_state is not None:
+        tiles_per_gauss, isect_ids, flatten_ids = isect_tiles_finish(isect_state)
+    else:
+        tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
+            means2d, radii, depths, tile_size, tile_width, tile_height,
+            packed=packed, n_cameras=C, camera_ids=camera_ids, gaussian_ids=gaussian_ids,
+        )
     isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
 
     meta.update(
