@@ -117,6 +117,8 @@ def algorithmic_bytes(stats):
         "gs_isect_depth_keys": 8 * N + 12 * N,
         "gs_gather_i32": 12 * N,
         "gs_isect_count": 12 * N + 4 * N,
+        "gs_isect_count_keys": 16 * N + 4 * N + 12 * N,
+        "gs_cumsum_gather_i32": 8 * N + 8 * N,
         "gs_cumsum_i32": 4 * N + 8 * N,
         "gs_isect_emit": 24 * V + 12 * I,
         "gs_sort_pairs_u64_i32": 24 * I,

@@ -716,22 +716,22 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
     st_["cum"] = st_["perm"] = st_["pinned"] = st_["event"] = None
     with _device_of(means2d):
         if n_elems > 0:
-            B.call("gs_isect_count", n_elems, B.ptr(means2d), B.ptr(radii), tile_size, tile_width, tile_height,
-                   B.ptr(tiles_per_gauss), st)
-            counts = tiles_per_gauss
+            cum = torch.empty(n_elems, dtype=torch.int64, device=dev)
+            sb = B.query("gs_cumsum_scratch_bytes", n_elems)
+            scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
             if sort:
                 # splat-level depth pre-sort: afterwards only the (camera, tile) bits need sorting
                 dkeys = torch.empty(n_elems, dtype=torch.int64, device=dev)
                 dvals = torch.empty(n_elems, dtype=torch.int32, device=dev)
-                B.call("gs_isect_depth_keys", n_elems, B.ptr(radii), B.ptr(depths), B.ptr(dkeys), B.ptr(dvals), st)
+                B.call("gs_isect_count_keys", n_elems, B.ptr(means2d), B.ptr(radii), B.ptr(depths), tile_size, tile_width,
+                       tile_height, B.ptr(tiles_per_gauss), B.ptr(dkeys), B.ptr(dvals), st)
                 _, perm = _sort_pairs(n_elems, dkeys, dvals, 32, 64, dev, st)
-                counts = torch.empty(n_elems, dtype=torch.int32, device=dev)
-                B.call("gs_gather_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(perm), B.ptr(counts), st)
                 st_["perm"] = perm
-            cum = torch.empty(n_elems, dtype=torch.int64, device=dev)
-            sb = B.query("gs_cumsum_scratch_bytes", n_elems)
-            scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
-            B.call("gs_cumsum_i32", n_elems, B.ptr(counts), B.ptr(cum), B.ptr(scratch), sb, st)
+                B.call("gs_cumsum_gather_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(perm), B.ptr(cum), B.ptr(scratch), sb, st)
+            else:
+                B.call("gs_isect_count", n_elems, B.ptr(means2d), B.ptr(radii), tile_size, tile_width, tile_height,
+                       B.ptr(tiles_per_gauss), st)
+                B.call("gs_cumsum_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(cum), B.ptr(scratch), sb, st)
             pinned = torch.empty(1, dtype=torch.int64, pin_memory=True)
             pinned.copy_(cum[-1:], non_blocking=True)
             ev = torch.cuda.Event()

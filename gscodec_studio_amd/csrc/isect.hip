@@ -56,6 +56,27 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_depth_keys_kernel(
     vals[i] = (int32_t)i;
 }
 
+// isect_count_kernel + isect_depth_keys_kernel in one launch (the sorted path needs both)
+__global__ void __launch_bounds__(GS_BLOCK) isect_count_keys_kernel(
+    uint32_t n_elems, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+    const float *__restrict__ depths, float tile_size, int32_t tw, int32_t th,
+    int32_t *__restrict__ tiles_per_gauss, int64_t *__restrict__ keys, int32_t *__restrict__ vals) {
+    uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (i >= n_elems) return;
+    const int32_t r = radii[i];
+    int32_t cnt = 0;
+    uint32_t d = 0x7fffffffu;
+    if (r > 0) {
+        float2 m = reinterpret_cast<const float2 *>(means2d)[i];
+        TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
+        cnt = (b.y1 - b.y0) * (b.x1 - b.x0);
+        d = (uint32_t)__float_as_int(depths[i]) & 0x7fffffffu;
+    }
+    tiles_per_gauss[i] = cnt;
+    keys[i] = (int64_t)(((uint64_t)d << 32) | (uint64_t)i);
+    vals[i] = (int32_t)i;
+}
+
 __global__ void __launch_bounds__(GS_BLOCK) gather_i32_kernel(
     uint32_t n, const int32_t *__restrict__ src, const int32_t *__restrict__ idx, int32_t *__restrict__ out) {
     uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x;
@@ -191,14 +212,14 @@ GS_DEV int64_t block_exclusive_scan_i64(int64_t v, int64_t &total, int64_t *s_wa
 }
 
 __global__ void __launch_bounds__(GS_BLOCK) scan_block_sums_kernel(
-    uint64_t n, const int32_t *__restrict__ in, int64_t *__restrict__ block_sums) {
+    uint64_t n, const int32_t *__restrict__ in, const int32_t *__restrict__ idx, int64_t *__restrict__ block_sums) {
     __shared__ int64_t s_wave[GS_BLOCK / GS_WAVE];
     uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
     int64_t s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         uint64_t i = base + (uint64_t)k * GS_BLOCK + threadIdx.x;
-        if (i < n) s += in[i];
+        if (i < n) s += idx != nullptr ? in[idx[i]] : in[i];
     }
     int64_t total;
     block_exclusive_scan_i64(s, total, s_wave);
@@ -221,7 +242,7 @@ __global__ void __launch_bounds__(GS_BLOCK) scan_spine_kernel(uint32_t n_blocks,
 
 template <typename OutT>
 __global__ void __launch_bounds__(GS_BLOCK) scan_apply_kernel(
-    uint64_t n, const int32_t *__restrict__ in, const int64_t *__restrict__ block_sums,
+    uint64_t n, const int32_t *__restrict__ in, const int32_t *__restrict__ idx, const int64_t *__restrict__ block_sums,
     OutT *__restrict__ out) {
     __shared__ int64_t s_wave[GS_BLOCK / GS_WAVE];
     // blocked arrangement: thread t owns items [t*ITEMS, (t+1)*ITEMS)
@@ -231,7 +252,7 @@ __global__ void __launch_bounds__(GS_BLOCK) scan_apply_kernel(
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         uint64_t i = base + k;
-        v[k] = i < n ? in[i] : 0;
+        v[k] = i < n ? (idx != nullptr ? in[idx[i]] : in[i]) : 0;
         s += v[k];
     }
     int64_t total;
@@ -245,7 +266,7 @@ __global__ void __launch_bounds__(GS_BLOCK) scan_apply_kernel(
 }
 
 template <typename OutT>
-int32_t cumsum_impl(uint64_t n, const int32_t *in, OutT *out, void *scratch, size_t scratch_bytes,
+int32_t cumsum_impl(uint64_t n, const int32_t *in, const int32_t *idx, OutT *out, void *scratch, size_t scratch_bytes,
                     hipStream_t st) {
     if (n == 0) return 0;
     uint32_t n_blocks = gs_div_up(n, SCAN_TILE);
@@ -254,9 +275,9 @@ int32_t cumsum_impl(uint64_t n, const int32_t *in, OutT *out, void *scratch, siz
         return 1;
     }
     int64_t *sums = (int64_t *)scratch;
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(n_blocks), dim3(GS_BLOCK), 0, st, n, in, sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(n_blocks), dim3(GS_BLOCK), 0, st, n, in, idx, sums);
     hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(GS_BLOCK), 0, st, n_blocks, sums);
-    hipLaunchKernelGGL((scan_apply_kernel<OutT>), dim3(n_blocks), dim3(GS_BLOCK), 0, st, n, in, sums, out);
+    hipLaunchKernelGGL((scan_apply_kernel<OutT>), dim3(n_blocks), dim3(GS_BLOCK), 0, st, n, in, idx, sums, out);
     return 0;
 }
 
@@ -283,7 +304,7 @@ extern "C" int32_t gs_cumsum_i32(
     uint64_t n, const int32_t *in, int64_t *out, void *scratch, size_t scratch_bytes, gs_stream_t stream) {
     if (n == 0) return 0;
     GS_CHECK_ARG(in && out, "null pointer");
-    int32_t rc = cumsum_impl<int64_t>(n, in, out, scratch, scratch_bytes, (hipStream_t)stream);
+    int32_t rc = cumsum_impl<int64_t>(n, in, nullptr, out, scratch, scratch_bytes, (hipStream_t)stream);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;
@@ -293,8 +314,31 @@ extern "C" int32_t gs_cumsum_i32_i32(
     uint64_t n, const int32_t *in, int32_t *out, void *scratch, size_t scratch_bytes, gs_stream_t stream) {
     if (n == 0) return 0;
     GS_CHECK_ARG(in && out, "null pointer");
-    int32_t rc = cumsum_impl<int32_t>(n, in, out, scratch, scratch_bytes, (hipStream_t)stream);
+    int32_t rc = cumsum_impl<int32_t>(n, in, nullptr, out, scratch, scratch_bytes, (hipStream_t)stream);
     if (rc) return rc;
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_cumsum_gather_i32(
+    uint64_t n, const int32_t *in, const int32_t *idx, int64_t *out, void *scratch, size_t scratch_bytes, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(in && idx && out, "null pointer");
+    int32_t rc = cumsum_impl<int64_t>(n, in, idx, out, scratch, scratch_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_isect_count_keys(
+    uint32_t n_elems, const float *means2d, const int32_t *radii, const float *depths, uint32_t tile_size,
+    uint32_t tile_width, uint32_t tile_height, int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals, gs_stream_t stream) {
+    if (n_elems == 0) return 0;
+    GS_CHECK_ARG(means2d && radii && depths && tiles_per_gauss && keys && vals, "null pointer");
+    GS_CHECK_ARG(tile_size > 0, "tile_size must be > 0");
+    hipLaunchKernelGGL(isect_count_keys_kernel, dim3(gs_div_up(n_elems, GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
+                       n_elems, means2d, radii, depths, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
+                       tiles_per_gauss, keys, vals);
     GS_CHECK_LAUNCH();
     return 0;
 }

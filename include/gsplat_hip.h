@@ -232,6 +232,15 @@ int32_t gs_isect_depth_keys(
     uint32_t n_elems, const int32_t *radii, const float *depths,
     int64_t *keys, int32_t *vals, gs_stream_t stream);
 int32_t gs_gather_i32(uint32_t n, const int32_t *src, const int32_t *idx, int32_t *out, gs_stream_t stream);
+/* the same in fewer launches: gs_isect_count + gs_isect_depth_keys in one kernel, and the inclusive prefix sum
+ * of in[idx[i]] (= gs_gather_i32 followed by gs_cumsum_i32) without the intermediate array */
+int32_t gs_isect_count_keys(
+    uint32_t n_elems, const float *means2d, const int32_t *radii, const float *depths,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+    int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals, gs_stream_t stream);
+int32_t gs_cumsum_gather_i32(
+    uint64_t n, const int32_t *in, const int32_t *idx, int64_t *out,
+    void *scratch, size_t scratch_bytes, gs_stream_t stream);
 
 int32_t gs_isect_emit(
     uint32_t n_elems, uint32_t N,   /* camera of element i = i / N when camera_ids NULL */
