@@ -109,5 +109,5 @@ def test_compression_simulation_hooks():
         assert float(dyn[k].min()) >= lo and float(dyn[k].max()) <= hi
         lv = (new2[k] - lo) / ((hi - lo) / 255)
         assert float((lv - lv.round()).abs().max()) < 1e-3
-    with pytest.raises(NotImplementedError):
-        CompressionSimulation(entropy_model_enable=True, entropy_steps={})
+    with pytest.raises(NotImplementedError):  # the hash-grid Gaussian model is not built (the factorized prior is: test_gpu_entropy.py)
+        CompressionSimulation(entropy_model_enable=True, entropy_model_type="gaussian_model", entropy_steps={"scales": 1})
