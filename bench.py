@@ -190,7 +190,7 @@ def main():
 
     B.lib()  # fail loudly if the HIP library is missing
     w = sh_workload(scene_grid=args.scene_grid, width=args.width, height=args.height, n_cameras=world,
-                    sh_degree=args.sh_degree, device=dev)
+                    sh_degree=args.sh_degree, device=dev, camera_mode="jitter0")  # equal work per rank (weak scaling)
     N = w["N"]
     params = {k: w[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "sh")}
     viewmats, Ks = w["viewmats"][rank: rank + 1].contiguous(), w["Ks"][rank: rank + 1].contiguous()

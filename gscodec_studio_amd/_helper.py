@@ -67,11 +67,13 @@ def rescale_intrinsics(Ks: torch.Tensor, width: int, height: int, new_width: int
 
 
 def sh_workload(scene_grid: int = 3, width: int = 1920, height: int = 1080, n_cameras: int = 1, sh_degree: int = 3,
-                device="cuda", seed: int = 42) -> Dict:
+                device="cuda", seed: int = 42, camera_mode: str = "fixture") -> Dict:
     """BASELINE.json config 2: scene_grid=3 -> N = 1,006,065 gaussians, SH degree 3, 1080p.
 
-    Cameras: the fixture's 3 cameras, cycled when n_cameras > 3 with a small seeded yaw so that
-    every camera of a multi-GPU batch is distinct.
+    Cameras, ``camera_mode="fixture"``: the fixture's 3 cameras, cycled when n_cameras > 3 with a small yaw so
+    that every camera of a batch is distinct.  ``"jitter0"``: camera 0 (the one config 2 is quoted on) for
+    every slot, yawed by +-0.01 rad * slot -- equal work per camera, which is what a weak-scaling run over
+    camera-sharded ranks needs (the three fixture cameras differ ~2x in visible splats).
     """
     means, quats, scales, opacities, rgb, viewmats, Ks, w0, h0 = load_test_data(device="cpu", scene_grid=scene_grid, seed=seed)
     Ks = rescale_intrinsics(Ks, w0, h0, width, height)
@@ -84,14 +86,15 @@ def sh_workload(scene_grid: int = 3, width: int = 1920, height: int = 1080, n_ca
         sh[:, 1:] = torch.randn((N, K - 1, 3), generator=g) * 0.05
     vm, kk = [], []
     for i in range(n_cameras):
-        V = viewmats[i % 3].clone()
-        if i >= 3:
-            a = 0.05 * (i // 3) * (1 if i % 2 else -1)
+        jitter = camera_mode == "jitter0"
+        V = viewmats[0 if jitter else i % 3].clone()
+        if jitter or i >= 3:
+            a = (0.01 * i if jitter else 0.05 * (i // 3)) * (1 if i % 2 else -1)
             c, s = float(np.cos(a)), float(np.sin(a))
             Rz = torch.tensor([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=torch.float32)
             V = V @ Rz
         vm.append(V)
-        kk.append(Ks[i % 3])
+        kk.append(Ks[0 if jitter else i % 3])
     d = dict(means=means, quats=quats, scales=scales, opacities=opacities, sh=sh, rgb=rgb,
              viewmats=torch.stack(vm), Ks=torch.stack(kk))
     d = {k: v.contiguous().to(device) for k, v in d.items()}
