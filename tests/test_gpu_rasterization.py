@@ -250,3 +250,32 @@ def test_depth_split_forward_matches_undivided(monkeypatch):
     assert_close(ra1, ra0, 1e-4, 2e-6, "alphas", max_bad_frac=1e-4)
     for a, b, name in zip(g1, g0, ("means", "quats", "scales", "opacities", "colors")):
         assert rel_l2(a, b) < 2e-4, (name, rel_l2(a, b))
+
+
+def test_full_size_linearity_determinism_and_adjoint():
+    """BASELINE config 2 size, post-activation colours [N,3]: the forward is bit-reproducible (no atomics), exactly
+    linear in the colours (same weights), and the backward is its adjoint: <W, render(c)> == <v_colors(W), c>."""
+    from gscodec_studio_amd import rasterization
+    from gscodec_studio_amd._helper import sh_workload
+
+    w = sh_workload(scene_grid=3, device="cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    c1 = torch.rand(w["N"], 3, device="cuda", generator=g)
+    c2 = torch.rand(w["N"], 3, device="cuda", generator=g)
+    args = (w["means"], w["quats"], w["scales"], w["opacities"])
+    kw = dict(viewmats=w["viewmats"], Ks=w["Ks"], width=w["width"], height=w["height"], packed=False)
+    r1, a1, _ = rasterization(*args, c1, **kw)
+    r1b, a1b, _ = rasterization(*args, c1, **kw)
+    assert torch.equal(r1, r1b) and torch.equal(a1, a1b)  # deterministic forward
+    r2, _, _ = rasterization(*args, c2, **kw)
+    r12, _, _ = rasterization(*args, c1 + 2.0 * c2, **kw)
+    lin = r1 + 2.0 * r2
+    assert float((r12 - lin).abs().max()) <= 1e-4 * float(lin.abs().max())
+    # adjoint identity (double accumulation of the two inner products)
+    W = torch.rand(r1.shape, device="cuda", generator=g)
+    cg = c1.clone().requires_grad_(True)
+    rg, _, _ = rasterization(*args, cg, **kw)
+    (rg * W).sum().backward()
+    lhs = float((rg.detach().double() * W.double()).sum())
+    rhs = float((cg.grad.double() * c1.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * abs(lhs), (lhs, rhs)
