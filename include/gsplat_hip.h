@@ -436,6 +436,25 @@ int32_t gs_rasterize_indices_fill(
     const int32_t *tile_offsets, const int32_t *flatten_ids, const float *transmittances,
     const int32_t *chunk_starts, int64_t *gaussian_ids, int64_t *pixel_ids, gs_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Temporal slicing of dynamic (spacetime) gaussians at one timestamp: the elementwise
+ * chain in front of rasterization() in examples/simple_trainer_dyngs.py:506-521 -- trbf opacity decay
+ * exp(-((t - center) / (sqrt2 scale))^2), cubic motion of the means (motion [N,9] = linear | quadratic |
+ * cubic coefficients), quats + (t - center) omega re-normalised (F.normalize, eps 1e-12).  t - center is
+ * detached where it drives motion and rotation (as `tforpoly` is), so trbf_center / trbf_scale receive
+ * gradient through the opacity only.  trbf (optional output) is what the caller thresholds (> 0.05) for
+ * the temporal visibility mask.  bwd: every output pointer may be NULL (not needed); all are overwritten. */
+int32_t gs_temporal_slice_fwd(
+    uint32_t n, const float *means, const float *motion, const float *quats, const float *omega,
+    const float *opacities, const float *trbf_center, const float *trbf_scale, float timestamp,
+    float *means_t, float *quats_t, float *opacity_t, float *trbf /* or NULL */, gs_stream_t stream);
+int32_t gs_temporal_slice_bwd(
+    uint32_t n, const float *means, const float *motion, const float *quats, const float *omega,
+    const float *opacities, const float *trbf_center, const float *trbf_scale, float timestamp,
+    const float *v_means_t, const float *v_quats_t, const float *v_opacity_t, const float *v_trbf /* each or NULL */,
+    float *v_means, float *v_motion, float *v_quats, float *v_omega, float *v_opacities,
+    float *v_trbf_center, float *v_trbf_scale, gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,3 +114,17 @@ def rasterize_to_indices_in_range(range_start, range_end, transmittances, means2
                     c_out.append(c)
                     T = nT
     return np.array(g_out, np.int64), np.array(p_out, np.int64), np.array(c_out, np.int64)
+
+
+def temporal_slice(means, motion, quats, omega, opacities, trbf_center, trbf_scale, timestamp):
+    """examples/simple_trainer_dyngs.py:506-521 restated (float64 torch; ``tau`` detached where the trainer detaches
+    ``tforpoly``).  PARITY UNPINNED by executable reference code: the trainer script cannot be imported here
+    (tyro / nerfview / datasets missing); the formula is short and is also checked by finite differences."""
+    tau = timestamp - trbf_center.reshape(-1)
+    trbf = torch.exp(-((tau / (2.0 ** 0.5 * trbf_scale.reshape(-1))) ** 2))
+    opacity = opacities * trbf
+    tp = tau.detach()[:, None]
+    means_t = means + motion[:, 0:3] * tp + motion[:, 3:6] * tp * tp + motion[:, 6:9] * tp * tp * tp
+    x = quats + tp * omega
+    quats_t = x / torch.clamp(x.norm(dim=-1, keepdim=True), min=1e-12)
+    return means_t, quats_t, opacity, trbf

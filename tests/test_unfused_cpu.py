@@ -63,3 +63,36 @@ def test_indices_oracle_matches_dense_formulation():
     # one batch = ts*ts = 64 entries >= N: a single batch per tile; range [1, 2) is empty
     g2, _, _ = UO.rasterize_to_indices_in_range(1, 2, T0, means2d, conics, opac, W, H, ts, offsets, flatten)
     assert len(g2) == 0
+
+
+def test_temporal_slice_oracle_finite_differences():
+    """The slicing oracle (parity unpinned by reference code) against central differences of itself, incl. the
+    detached tau: trbf_center must get gradient through the opacity only."""
+    rs = np.random.RandomState(0)
+    n = 6
+    vals = [rs.randn(n, 3), 0.3 * rs.randn(n, 9), rs.randn(n, 4), 0.5 * rs.randn(n, 4), rs.uniform(0.1, 1, n),
+            rs.uniform(0, 1, (n, 1)), np.exp(rs.uniform(-1, 0.5, (n, 1)))]
+    vm, vq, vo = rs.randn(n, 3), rs.randn(n, 4), rs.randn(n)
+    t = 0.4
+    _, grads = UO.with_grads(lambda *a: UO.temporal_slice(*a, t)[:3], vals, (vm, vq, vo))
+
+    def loss(vs, detach_check=False):
+        ins = [torch.tensor(v, dtype=torch.float64) for v in vs]
+        m, q, o, _ = UO.temporal_slice(*ins, t)
+        return float((m * torch.tensor(vm)).sum() + (q * torch.tensor(vq)).sum() + (o * torch.tensor(vo)).sum())
+
+    eps = 1e-6
+    for which, idx in [(1, (2, 4)), (3, (1, 2)), (4, (3,)), (6, (0, 0))]:  # motion, omega, opacities, trbf_scale
+        vp = [v.copy() for v in vals]
+        vm_ = [v.copy() for v in vals]
+        vp[which][idx] += eps
+        vm_[which][idx] -= eps
+        fd = (loss(vp) - loss(vm_)) / (2 * eps)
+        assert abs(fd - grads[which][idx]) <= 1e-5 * (abs(fd) + 1e-3), (which, fd, grads[which][idx])
+    # centre: the true derivative of the loss includes the motion/rotation paths; the (detached) oracle gradient is the
+    # opacity path alone, which is what the trainer trains with
+    ins = [torch.tensor(v, dtype=torch.float64) for v in vals]
+    tau = t - ins[5].reshape(-1)
+    d = tau / (2 ** 0.5 * ins[6].reshape(-1))
+    want = torch.tensor(vo) * ins[4] * torch.exp(-d * d) * (-2 * d) * (-1 / (2 ** 0.5 * ins[6].reshape(-1)))
+    assert np.allclose(grads[5].reshape(-1), want.numpy(), rtol=1e-9, atol=1e-12)
