@@ -1,4 +1,5 @@
-// quantize.hip -- Q1/Q2: per-splat quantize/dequantize straight-through estimators (gfx950).
+// quantize.hip -- Q1/Q2: per-splat quantize/dequantize straight-through estimators, and the min-max
+// grid quantizer of the on-disk attribute format (gfx950).
 //
 // Replaces the elementwise torch chains of
 //   gsplat/compression_simulation/ops.py:39-54 (fake_quantize_ste, "noise" mode)
@@ -106,6 +107,51 @@ bool aligned16(const void *a, const void *b, const void *c) {
     return ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && ((uintptr_t)c % 16 == 0);
 }
 
+
+// ---------------------------------------------------------------------------
+// On-disk attribute format: per-channel min-max quantization of a [rows, channels] grid
+// to 8 / k (<= 8) / 16 bits, and its exact inverse.  Reference arithmetic
+// (gsplat/compression/png_compression.py:186-193, 260-268, 332-345 encode; 224-232, 298-306, 375-389 decode):
+//   encode: norm = (x - min) / (max - min) in fp32 (torch), img = round(norm * (2^q - 1)) in fp32 with
+//           round-half-to-even (numpy), k-bit images are shifted left by 8 - q, 16-bit ones split in two planes;
+//   decode: norm = img / (2^q - 1) in float64 (numpy), grid = norm * (max - min) + min with (max - min) formed in
+//           fp32 and the product / sum in float64 (torch type promotion), then cast to fp32.
+// NaN (max == min) encodes as 0, like numpy's float -> uint8 cast on x86.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(GS_BLOCK) grid_quantize_kernel(uint64_t n, uint32_t channels, const float *__restrict__ x,
+                                                                 const float *__restrict__ mins, const float *__restrict__ maxs,
+                                                                 float levels, uint32_t shift, uint8_t *__restrict__ lo,
+                                                                 uint8_t *__restrict__ hi) {
+    const uint64_t stride = (uint64_t)gridDim.x * GS_BLOCK;
+    for (uint64_t i = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint32_t c = (uint32_t)(i % channels);
+        const float mn = mins[c];
+        const float norm = __fdiv_rn(__fsub_rn(x[i], mn), __fsub_rn(maxs[c], mn));
+        const float r = rintf(__fmul_rn(norm, levels));
+        uint32_t q = (r == r) ? (uint32_t)fminf(fmaxf(r, 0.f), 65535.f) : 0u;
+        if (hi != nullptr) {
+            lo[i] = (uint8_t)(q & 0xFFu);
+            hi[i] = (uint8_t)((q >> 8) & 0xFFu);
+        } else {
+            lo[i] = (uint8_t)((q & 0xFFu) << shift);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) grid_dequantize_kernel(uint64_t n, uint32_t channels, const uint8_t *__restrict__ lo,
+                                                                   const uint8_t *__restrict__ hi, const float *__restrict__ mins,
+                                                                   const float *__restrict__ maxs, double levels, uint32_t shift,
+                                                                   float *__restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * GS_BLOCK;
+    for (uint64_t i = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint32_t c = (uint32_t)(i % channels);
+        const uint32_t q = hi != nullptr ? (((uint32_t)hi[i] << 8) + (uint32_t)lo[i]) : ((uint32_t)lo[i] >> shift);
+        const double norm = (double)q / levels;
+        const float range = __fsub_rn(maxs[c], mins[c]);
+        out[i] = (float)(norm * (double)range + (double)mins[c]);
+    }
+}
+
 } // namespace
 
 extern "C" int32_t gs_quantize_noise_fwd(
@@ -136,6 +182,38 @@ extern "C" int32_t gs_quantize_round_fwd(
     GS_CHECK_ARG(x_inplace && out, "null pointer");
     hipLaunchKernelGGL(quant_round_fwd_kernel, dim3(stream_grid(n)), dim3(GS_BLOCK), 0, (hipStream_t)stream, n,
                        x_inplace, lo, hi, range, q_step_norm, out, (int)aligned16(x_inplace, out, out));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_grid_quantize(uint64_t n, uint32_t channels, const float *x, const float *mins, const float *maxs,
+                                    uint32_t bits, uint8_t *plane_lo, uint8_t *plane_hi, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(x && mins && maxs && plane_lo, "null pointer");
+    GS_CHECK_ARG(channels >= 1 && n % channels == 0, "n must be a multiple of channels");
+    GS_CHECK_ARG((bits >= 1 && bits <= 8 && plane_hi == nullptr) || (bits == 16 && plane_hi != nullptr),
+                 "bits must be 1..8 (one plane) or 16 (two planes)");
+    const float levels = (float)((1u << bits) - 1u);
+    const uint32_t shift = bits <= 8 ? 8u - bits : 0u;
+    const uint32_t blocks = (uint32_t)(gs_div_up(n, GS_BLOCK) < 8192u ? gs_div_up(n, GS_BLOCK) : 8192u);
+    hipLaunchKernelGGL(grid_quantize_kernel, dim3(blocks), dim3(GS_BLOCK), 0, (hipStream_t)stream, n, channels, x, mins, maxs, levels,
+                       shift, plane_lo, plane_hi);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_grid_dequantize(uint64_t n, uint32_t channels, const uint8_t *plane_lo, const uint8_t *plane_hi,
+                                      const float *mins, const float *maxs, uint32_t bits, float *out, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(plane_lo && mins && maxs && out, "null pointer");
+    GS_CHECK_ARG(channels >= 1 && n % channels == 0, "n must be a multiple of channels");
+    GS_CHECK_ARG((bits >= 1 && bits <= 8 && plane_hi == nullptr) || (bits == 16 && plane_hi != nullptr),
+                 "bits must be 1..8 (one plane) or 16 (two planes)");
+    const double levels = (double)((1u << bits) - 1u);
+    const uint32_t shift = bits <= 8 ? 8u - bits : 0u;
+    const uint32_t blocks = (uint32_t)(gs_div_up(n, GS_BLOCK) < 8192u ? gs_div_up(n, GS_BLOCK) : 8192u);
+    hipLaunchKernelGGL(grid_dequantize_kernel, dim3(blocks), dim3(GS_BLOCK), 0, (hipStream_t)stream, n, channels, plane_lo, plane_hi,
+                       mins, maxs, levels, shift, out);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -437,6 +437,21 @@ int32_t gs_rasterize_indices_fill(
     const int32_t *chunk_starts, int64_t *gaussian_ids, int64_t *pixel_ids, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * On-disk attribute format: per-channel min-max quantization of a row-major
+ * [rows, channels] grid and its exact inverse -- the arithmetic of _compress_png / _compress_png_kbit /
+ * _compress_png_16bit and the matching _decompress_* (gsplat/compression/png_compression.py:166-389)
+ * without the PNG container.  bits 1..8: ONE uint8 plane holding round(norm * (2^bits - 1)) << (8 - bits);
+ * bits 16: low and high byte planes.  mins / maxs: [channels] device floats (torch.amin / amax of the grid).
+ * Encode is fp32 with round-half-to-even, decode is float64 then cast, exactly like the numpy / torch mix
+ * of the reference, so both are bit-exact against it. */
+int32_t gs_grid_quantize(
+    uint64_t n /* rows * channels */, uint32_t channels, const float *x, const float *mins, const float *maxs,
+    uint32_t bits, uint8_t *plane_lo, uint8_t *plane_hi /* 16-bit only, else NULL */, gs_stream_t stream);
+int32_t gs_grid_dequantize(
+    uint64_t n, uint32_t channels, const uint8_t *plane_lo, const uint8_t *plane_hi /* or NULL */,
+    const float *mins, const float *maxs, uint32_t bits, float *out, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Temporal slicing of dynamic (spacetime) gaussians at one timestamp: the elementwise
  * chain in front of rasterization() in examples/simple_trainer_dyngs.py:506-521 -- trbf opacity decay
  * exp(-((t - center) / (sqrt2 scale))^2), cubic motion of the means (motion [N,9] = linear | quadratic |

@@ -1,0 +1,38 @@
+"""CPU: the attribute-quantizer oracle against the golden vectors recorded from the reference's
+png_compression.py functions (tests/golden/make_golden_codec.py): bit-exact planes and decoded values."""
+import numpy as np
+import pytest
+
+from util import golden
+
+from oracle import codec_oracle as CO
+
+CASES = ["means16", "scales8k", "quats6k", "opac8", "sh0_8k"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_codec_oracle_bit_exact(name):
+    gd = golden("codec.npz")
+    side, bits = int(gd["n_sidelen"]), int(gd[f"{name}.bits"])
+    x = gd[f"{name}.x"]
+    planes, mins, maxs = CO.quantize(x, side, bits)
+    assert np.array_equal(mins, gd[f"{name}.mins"]) and np.array_equal(maxs, gd[f"{name}.maxs"])
+    for i, p in enumerate(planes):
+        assert np.array_equal(p.squeeze(), gd[f"{name}.plane{i}"])
+    dec = CO.dequantize([gd[f"{name}.plane{i}"].reshape(side, side, -1) for i in range(len(planes))], mins, maxs, bits, x.shape)
+    assert np.array_equal(dec.view(np.uint32), gd[f"{name}.decoded"].view(np.uint32))
+    step = (maxs - mins) / (2**bits - 1)
+    assert np.all(np.abs(dec - x).reshape(side * side, -1) <= 0.5 * step * (1 + 1e-4) + 1e-6)
+
+
+def test_codec_module_fails_loudly_on_cpu():
+    import torch
+
+    from gscodec_studio_amd.compression import dequantize_grid, inverse_log_transform, log_transform, quantize_grid
+
+    with pytest.raises(RuntimeError):
+        quantize_grid(torch.zeros(16, 3), 4)
+    with pytest.raises(RuntimeError):
+        dequantize_grid([torch.zeros(4, 4, 3, dtype=torch.uint8)], {"shape": [16, 3], "dtype": "float32", "mins": [0, 0, 0], "maxs": [1, 1, 1]}, device="cpu")
+    x = torch.tensor([-3.0, -0.1, 0.0, 0.5, 20.0])
+    assert torch.allclose(inverse_log_transform(log_transform(x)), x, rtol=1e-6, atol=1e-7)
