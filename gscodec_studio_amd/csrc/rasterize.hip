@@ -606,6 +606,10 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
             if (lane == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) s_mask[buf][w][q] = m[q];
+#if defined(GS_ABL) && GS_ABL == 5
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s_mask[buf][w][q] = 0ull; // ablation: staging only, no record evaluation
+#endif
                 s_done[buf][w] = wave_done ? 1u : 0u;
             }
         }
