@@ -863,13 +863,16 @@ class _RasterizeToPixels(torch.autograd.Function):
         last_ids = torch.empty((C, height, width), dtype=torch.int32, device=dev)
         m8 = masks.view(torch.uint8) if masks is not None else None
         assert isect_offsets.dtype == torch.int32 and flatten_ids.dtype == torch.int32
+        # the scratch carries the forward checkpoints of the depth-segmented backward (128 MB written at 1 M splats /
+        # 1080p): only ask for them when a backward can follow
+        needs_bwd = any(ctx.needs_input_grad[:5])
         with _device_of(means2d):
-            sb = B.query("gs_rasterize_scratch_bytes", C * tile_height * tile_width, n_isects, channels)
+            sb = B.query("gs_rasterize_scratch_bytes", C * tile_height * tile_width, n_isects, channels) if needs_bwd else 0
             scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
             B.call("gs_rasterize_fwd", C, n_elems, n_isects, channels, B.ptr(means2d), B.ptr(conics), B.ptr(colors),
                    B.ptr(opacities), B.ptr(backgrounds), B.ptr(m8), width, height, tile_size, tile_width,
                    tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_colors),
-                   B.ptr(render_alphas), B.ptr(last_ids), B.ptr(scratch), sb, _stream(means2d))
+                   B.ptr(render_alphas), B.ptr(last_ids), B.ptr(scratch) if sb else None, sb, _stream(means2d))
         # scratch carries the forward checkpoints of the depth-segmented backward
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids,
                               render_alphas, last_ids, scratch)
