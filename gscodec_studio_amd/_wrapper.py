@@ -713,7 +713,7 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
 
     tiles_per_gauss = torch.empty(radii.shape, dtype=torch.int32, device=dev)
     st_["tiles_per_gauss"] = tiles_per_gauss
-    st_["cum"] = st_["perm"] = st_["pinned"] = st_["event"] = None
+    st_["cum"] = st_["perm"] = st_["pinned"] = st_["event"] = st_["n_kept"] = None
     with _device_of(means2d):
         if n_elems > 0:
             cum = torch.empty(n_elems, dtype=torch.int64, device=dev)
@@ -725,9 +725,16 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                 dvals = torch.empty(n_elems, dtype=torch.int32, device=dev)
                 B.call("gs_isect_count_keys", n_elems, B.ptr(means2d), B.ptr(radii), B.ptr(depths), tile_size, tile_width,
                        tile_height, B.ptr(tiles_per_gauss), B.ptr(dkeys), B.ptr(dvals), st)
-                _, perm = _sort_pairs(n_elems, dkeys, dvals, 32, 64, dev, st)
-                st_["perm"] = perm
-                B.call("gs_cumsum_gather_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(perm), B.ptr(cum), B.ptr(scratch), sb, st)
+                # culled elements carry the maximal key: the sort drops them in its first pass
+                ko, perm = torch.empty_like(dkeys), torch.empty_like(dvals)
+                n_kept = torch.empty(1, dtype=torch.int32, device=dev)
+                tb = B.query("gs_sort_temp_bytes", n_elems)
+                temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+                B.call("gs_sort_pairs_u64_i32_drop", n_elems, B.ptr(dkeys), B.ptr(dvals), B.ptr(ko), B.ptr(perm), 32, 64,
+                       0x7FFFFFFF, B.ptr(n_kept), B.ptr(temp), tb, st)
+                st_["perm"], st_["n_kept"] = perm, n_kept
+                B.call("gs_cumsum_gather_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(perm), B.ptr(n_kept), B.ptr(cum),
+                       B.ptr(scratch), sb, st)
             else:
                 B.call("gs_isect_count", n_elems, B.ptr(means2d), B.ptr(radii), tile_size, tile_width, tile_height,
                        B.ptr(tiles_per_gauss), st)
@@ -753,7 +760,7 @@ def isect_tiles_finish(st_) -> Tuple[Tensor, Tensor, Tensor]:
         isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
         flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
         if n_isects > 0:
-            B.call("gs_isect_emit", st_["n_elems"], max(st_["N"], 1), B.ptr(st_["perm"]), B.ptr(st_["camera_ids"]),
+            B.call("gs_isect_emit", st_["n_elems"], max(st_["N"], 1), B.ptr(st_["perm"]), B.ptr(st_["n_kept"]), B.ptr(st_["camera_ids"]),
                    B.ptr(means2d), B.ptr(radii), B.ptr(depths), B.ptr(st_["cum"]), st_["tile_size"], st_["tile_width"],
                    st_["tile_height"], st_["tile_n_bits"], B.ptr(isect_ids), B.ptr(flatten_ids), st)
             if st_["sort"]:

@@ -96,7 +96,8 @@ struct EmitRec {
 };
 
 __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
-    uint32_t n_elems, uint32_t N, const int32_t *__restrict__ perm, const int64_t *__restrict__ camera_ids,
+    uint32_t n_elems, uint32_t N, const int32_t *__restrict__ perm, const uint32_t *__restrict__ n_valid,
+    const int64_t *__restrict__ camera_ids,
     const float *__restrict__ means2d, const int32_t *__restrict__ radii,
     const float *__restrict__ depths, const int64_t *__restrict__ cum_tiles,
     float tile_size, int32_t tw, int32_t th, uint32_t tile_n_bits,
@@ -116,9 +117,11 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
     EmitRec rec = {0, 0, 0, 0, 1};
     int32_t start = (int32_t)(out1 - out0);
     if (pos < n_elems) {
-        const uint32_t i = perm != nullptr ? (uint32_t)perm[pos] : pos;
         start = (int32_t)(((pos == 0) ? 0 : cum_tiles[pos - 1]) - out0);
-        const int32_t r = radii[i];
+        // positions behind *n_valid hold no element (perm is only defined for the kept ones)
+        const bool has = n_valid == nullptr || pos < *n_valid;
+        const uint32_t i = has ? (perm != nullptr ? (uint32_t)perm[pos] : pos) : 0u;
+        const int32_t r = has ? radii[i] : 0;
         if (r > 0) {
             const float2 m = reinterpret_cast<const float2 *>(means2d)[i];
             const TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
@@ -211,15 +214,18 @@ GS_DEV int64_t block_exclusive_scan_i64(int64_t v, int64_t &total, int64_t *s_wa
     return base + inc - v;
 }
 
+// idx != nullptr: the scanned value is in[idx[i]]; n_valid != nullptr: positions >= *n_valid count as 0
 __global__ void __launch_bounds__(GS_BLOCK) scan_block_sums_kernel(
-    uint64_t n, const int32_t *__restrict__ in, const int32_t *__restrict__ idx, int64_t *__restrict__ block_sums) {
+    uint64_t n, const int32_t *__restrict__ in, const int32_t *__restrict__ idx, const uint32_t *__restrict__ n_valid,
+    int64_t *__restrict__ block_sums) {
     __shared__ int64_t s_wave[GS_BLOCK / GS_WAVE];
     uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    const uint64_t nv = n_valid != nullptr ? min(n, (uint64_t)*n_valid) : n;
     int64_t s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         uint64_t i = base + (uint64_t)k * GS_BLOCK + threadIdx.x;
-        if (i < n) s += idx != nullptr ? in[idx[i]] : in[i];
+        if (i < nv) s += idx != nullptr ? in[idx[i]] : in[i];
     }
     int64_t total;
     block_exclusive_scan_i64(s, total, s_wave);
@@ -242,9 +248,10 @@ __global__ void __launch_bounds__(GS_BLOCK) scan_spine_kernel(uint32_t n_blocks,
 
 template <typename OutT>
 __global__ void __launch_bounds__(GS_BLOCK) scan_apply_kernel(
-    uint64_t n, const int32_t *__restrict__ in, const int32_t *__restrict__ idx, const int64_t *__restrict__ block_sums,
-    OutT *__restrict__ out) {
+    uint64_t n, const int32_t *__restrict__ in, const int32_t *__restrict__ idx, const uint32_t *__restrict__ n_valid,
+    const int64_t *__restrict__ block_sums, OutT *__restrict__ out) {
     __shared__ int64_t s_wave[GS_BLOCK / GS_WAVE];
+    const uint64_t nv = n_valid != nullptr ? min(n, (uint64_t)*n_valid) : n;
     // blocked arrangement: thread t owns items [t*ITEMS, (t+1)*ITEMS)
     uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
     int32_t v[SCAN_ITEMS];
@@ -252,7 +259,7 @@ __global__ void __launch_bounds__(GS_BLOCK) scan_apply_kernel(
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         uint64_t i = base + k;
-        v[k] = i < n ? (idx != nullptr ? in[idx[i]] : in[i]) : 0;
+        v[k] = i < nv ? (idx != nullptr ? in[idx[i]] : in[i]) : 0;
         s += v[k];
     }
     int64_t total;
@@ -266,8 +273,8 @@ __global__ void __launch_bounds__(GS_BLOCK) scan_apply_kernel(
 }
 
 template <typename OutT>
-int32_t cumsum_impl(uint64_t n, const int32_t *in, const int32_t *idx, OutT *out, void *scratch, size_t scratch_bytes,
-                    hipStream_t st) {
+int32_t cumsum_impl(uint64_t n, const int32_t *in, const int32_t *idx, const uint32_t *n_valid, OutT *out, void *scratch,
+                    size_t scratch_bytes, hipStream_t st) {
     if (n == 0) return 0;
     uint32_t n_blocks = gs_div_up(n, SCAN_TILE);
     if (scratch == nullptr || scratch_bytes < (size_t)n_blocks * sizeof(int64_t)) {
@@ -275,9 +282,9 @@ int32_t cumsum_impl(uint64_t n, const int32_t *in, const int32_t *idx, OutT *out
         return 1;
     }
     int64_t *sums = (int64_t *)scratch;
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(n_blocks), dim3(GS_BLOCK), 0, st, n, in, idx, sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(n_blocks), dim3(GS_BLOCK), 0, st, n, in, idx, n_valid, sums);
     hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(GS_BLOCK), 0, st, n_blocks, sums);
-    hipLaunchKernelGGL((scan_apply_kernel<OutT>), dim3(n_blocks), dim3(GS_BLOCK), 0, st, n, in, idx, sums, out);
+    hipLaunchKernelGGL((scan_apply_kernel<OutT>), dim3(n_blocks), dim3(GS_BLOCK), 0, st, n, in, idx, n_valid, sums, out);
     return 0;
 }
 
@@ -304,7 +311,7 @@ extern "C" int32_t gs_cumsum_i32(
     uint64_t n, const int32_t *in, int64_t *out, void *scratch, size_t scratch_bytes, gs_stream_t stream) {
     if (n == 0) return 0;
     GS_CHECK_ARG(in && out, "null pointer");
-    int32_t rc = cumsum_impl<int64_t>(n, in, nullptr, out, scratch, scratch_bytes, (hipStream_t)stream);
+    int32_t rc = cumsum_impl<int64_t>(n, in, nullptr, nullptr, out, scratch, scratch_bytes, (hipStream_t)stream);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;
@@ -314,17 +321,18 @@ extern "C" int32_t gs_cumsum_i32_i32(
     uint64_t n, const int32_t *in, int32_t *out, void *scratch, size_t scratch_bytes, gs_stream_t stream) {
     if (n == 0) return 0;
     GS_CHECK_ARG(in && out, "null pointer");
-    int32_t rc = cumsum_impl<int32_t>(n, in, nullptr, out, scratch, scratch_bytes, (hipStream_t)stream);
+    int32_t rc = cumsum_impl<int32_t>(n, in, nullptr, nullptr, out, scratch, scratch_bytes, (hipStream_t)stream);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int32_t gs_cumsum_gather_i32(
-    uint64_t n, const int32_t *in, const int32_t *idx, int64_t *out, void *scratch, size_t scratch_bytes, gs_stream_t stream) {
+    uint64_t n, const int32_t *in, const int32_t *idx, const uint32_t *n_valid, int64_t *out, void *scratch,
+    size_t scratch_bytes, gs_stream_t stream) {
     if (n == 0) return 0;
     GS_CHECK_ARG(in && idx && out, "null pointer");
-    int32_t rc = cumsum_impl<int64_t>(n, in, idx, out, scratch, scratch_bytes, (hipStream_t)stream);
+    int32_t rc = cumsum_impl<int64_t>(n, in, idx, n_valid, out, scratch, scratch_bytes, (hipStream_t)stream);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;
@@ -362,7 +370,7 @@ extern "C" int32_t gs_gather_i32(uint32_t n, const int32_t *src, const int32_t *
 }
 
 extern "C" int32_t gs_isect_emit(
-    uint32_t n_elems, uint32_t N, const int32_t *perm, const int64_t *camera_ids, const float *means2d,
+    uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids, const float *means2d,
     const int32_t *radii, const float *depths, const int64_t *cum_tiles_per_gauss,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits,
     int64_t *isect_ids, int32_t *flatten_ids, gs_stream_t stream) {
@@ -371,7 +379,7 @@ extern "C" int32_t gs_isect_emit(
     GS_CHECK_ARG(camera_ids != nullptr || N > 0, "N must be > 0 when camera_ids is NULL");
     GS_CHECK_ARG(tile_n_bits < 32, "tile_n_bits must be < 32");
     hipLaunchKernelGGL(isect_emit_kernel, dim3(gs_div_up(n_elems, GS_BLOCK)), dim3(GS_BLOCK), 0,
-                       (hipStream_t)stream, n_elems, N, perm, camera_ids, means2d, radii, depths,
+                       (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids, means2d, radii, depths,
                        cum_tiles_per_gauss, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
                        tile_n_bits, isect_ids, flatten_ids);
     GS_CHECK_LAUNCH();

@@ -30,21 +30,33 @@ struct DigitSpec {
     uint32_t shift;
     uint32_t mask;
     uint32_t flip; // xor applied to the digit (sign bit handling when end_bit == 64)
+    uint32_t drop; // != 0: keys whose upper 32 bits equal drop_hi are DROPPED by this pass (not counted, not written)
+    uint32_t drop_hi;
 };
+
+GS_DEV bool key_kept(uint64_t key, DigitSpec d) { return !(d.drop != 0u && (uint32_t)(key >> 32) == d.drop_hi); }
 
 GS_DEV uint32_t digit_of(uint64_t key, DigitSpec d) { return ((uint32_t)(key >> d.shift) & d.mask) ^ d.flip; }
 
 __global__ void __launch_bounds__(GS_BLOCK) sort_hist_kernel(
-    uint64_t n, const uint64_t *__restrict__ keys, DigitSpec d, uint32_t n_blocks,
+    uint64_t n, const uint32_t *__restrict__ n_dev, const uint64_t *__restrict__ keys, DigitSpec d, uint32_t n_blocks,
     uint32_t *__restrict__ hist /* [RADIX][n_blocks] */) {
     __shared__ uint32_t s_hist[RADIX];
     s_hist[threadIdx.x] = 0;
+    if (n_dev != nullptr) n = min(n, (uint64_t)*n_dev); // element count known only on the device
+    if ((uint64_t)blockIdx.x * SORT_TILE >= n) { // nothing here (the grid is sized for the host-side upper bound)
+        hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = 0;
+        return;
+    }
     __syncthreads();
     uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
 #pragma unroll 4
     for (int k = 0; k < SORT_TILE / GS_BLOCK; ++k) {
         uint64_t i = base + (uint64_t)k * GS_BLOCK + threadIdx.x;
-        if (i < n) atomicAdd(&s_hist[digit_of(keys[i], d)], 1u);
+        if (i < n) {
+            const uint64_t key = keys[i];
+            if (key_kept(key, d)) atomicAdd(&s_hist[digit_of(key, d)], 1u);
+        }
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = s_hist[threadIdx.x];
@@ -81,8 +93,19 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scan_kernel(
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+// totals of the 256 digits of a pass = number of keys it kept
+__global__ void __launch_bounds__(GS_BLOCK) sort_total_kernel(const uint32_t *__restrict__ totals, uint32_t *__restrict__ n_out) {
+    __shared__ uint32_t s[GS_BLOCK / GS_WAVE];
+    uint32_t v = totals[threadIdx.x];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (threadIdx.x % GS_WAVE == 0) s[threadIdx.x / GS_WAVE] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) *n_out = s[0] + s[1] + s[2] + s[3];
+}
+
 __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
-    uint64_t n, const uint64_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
+    uint64_t n, const uint32_t *__restrict__ n_dev, const uint64_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
     uint64_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, DigitSpec d,
     uint32_t n_blocks, const uint32_t *__restrict__ hist_scan, const uint32_t *__restrict__ totals) {
     __shared__ uint32_t s_cnt[SORT_WAVES][RADIX]; // per-wave digit counters -> per-wave prefix
@@ -90,7 +113,10 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
     __shared__ uint32_t s_gofs[RADIX];            // global base of (digit, this block) - s_lbase
     __shared__ uint32_t s_scan[SORT_WAVES];
     __shared__ uint64_t s_keys[SORT_TILE];        // 32 KB staging (keys, then values)
+    __shared__ uint32_t s_count;
     const uint32_t tid = threadIdx.x, lane = tid % GS_WAVE, wave = tid / GS_WAVE;
+    if (n_dev != nullptr) n = min(n, (uint64_t)*n_dev);
+    if ((uint64_t)blockIdx.x * SORT_TILE >= n) return; // block-uniform
 #pragma unroll
     for (int w = 0; w < SORT_WAVES; ++w) s_cnt[w][tid] = 0;
     __syncthreads();
@@ -99,6 +125,7 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint64_t key[SORT_ROUNDS];
     uint32_t rank[SORT_ROUNDS];
+    uint32_t kept = 0; // bit r: the key of round r takes part in this pass
 
     // phase 1: stable rank of every key within (wave, digit)
 #pragma unroll
@@ -106,6 +133,8 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
         uint64_t i = wave_base + (uint64_t)r * GS_WAVE + lane;
         bool valid = i < n;
         key[r] = valid ? keys_in[i] : 0;
+        valid = valid && key_kept(key[r], d);
+        kept |= valid ? (1u << r) : 0u;
         uint32_t dg = digit_of(key[r], d);
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -153,6 +182,7 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
         const uint32_t gbase = block_excl_scan(totals[tid]) + hist_scan[(size_t)tid * n_blocks + blockIdx.x];
         const uint32_t lbase = block_excl_scan(run);
         s_lbase[tid] = lbase;
+        if (tid == RADIX - 1) s_count = lbase + run; // keys of this block that take part
         s_gofs[tid] = gbase - lbase; // (unsigned wrap-around is fine: only s_gofs[dg] + j is used)
     }
     __syncthreads();
@@ -161,15 +191,13 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
     // written out with consecutive lanes on consecutive addresses (runs of one digit).  Writing straight
     // from the ranking registers made every lane of a store hit a different 8-byte location: the first
     // pass of the pair sort (random low tile bits) took 92 us for 4 M pairs against 26 us for the second.
-    const uint64_t block_base = (uint64_t)blockIdx.x * SORT_TILE;
-    const uint32_t block_count = (uint32_t)((n - block_base) < (uint64_t)SORT_TILE ? (n - block_base) : (uint64_t)SORT_TILE);
+    const uint32_t block_count = s_count;
     uint32_t lp[SORT_ROUNDS];
 #pragma unroll
     for (int r = 0; r < SORT_ROUNDS; ++r) {
-        uint64_t i = wave_base + (uint64_t)r * GS_WAVE + lane;
         uint32_t dg = digit_of(key[r], d);
         lp[r] = s_lbase[dg] + s_cnt[wave][dg] + rank[r];
-        if (i < n) s_keys[lp[r]] = key[r];
+        if ((kept >> r) & 1u) s_keys[lp[r]] = key[r];
     }
     __syncthreads();
     uint32_t pos[SORT_ROUNDS];
@@ -188,7 +216,7 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
 #pragma unroll
     for (int r = 0; r < SORT_ROUNDS; ++r) {
         uint64_t i = wave_base + (uint64_t)r * GS_WAVE + lane;
-        if (i < n) s_vals[lp[r]] = vals_in[i];
+        if ((kept >> r) & 1u) s_vals[lp[r]] = vals_in[i];
     }
     __syncthreads();
 #pragma unroll
@@ -224,25 +252,23 @@ SortLayout sort_layout(uint64_t n) {
 
 extern "C" size_t gs_sort_temp_bytes(uint64_t n) { return sort_layout(n).total; }
 
-extern "C" int32_t gs_sort_pairs_u64_i32(
-    uint64_t n, const int64_t *keys_in, const int32_t *vals_in, int64_t *keys_out,
-    int32_t *vals_out, int32_t begin_bit, int32_t end_bit, void *temp, size_t temp_bytes,
-    gs_stream_t stream) {
+static int32_t sort_impl(uint64_t n, const int64_t *keys_in, const int32_t *vals_in, int64_t *keys_out, int32_t *vals_out,
+                         int32_t begin_bit, int32_t end_bit, bool drop, uint32_t drop_hi, uint32_t *n_valid_out, void *temp,
+                         size_t temp_bytes, hipStream_t st, const char *who) {
     if (n == 0) return 0;
-    GS_CHECK_ARG(keys_in && vals_in && keys_out && vals_out, "null pointer");
-    GS_CHECK_ARG(begin_bit >= 0 && end_bit <= 64 && begin_bit <= end_bit, "bad bit range");
-    GS_CHECK_ARG(n < (1ull << 32), "n must be < 2^32");
-    hipStream_t st = (hipStream_t)stream;
     int passes = (end_bit - begin_bit + RADIX_BITS - 1) / RADIX_BITS;
     if (passes == 0) {
+        if (drop) {
+            gs_set_error("%s: dropping keys needs at least one sorted bit", who);
+            return 1;
+        }
         (void)hipMemcpyAsync(keys_out, keys_in, n * sizeof(int64_t), hipMemcpyDeviceToDevice, st);
         (void)hipMemcpyAsync(vals_out, vals_in, n * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
-        GS_CHECK_LAUNCH();
         return 0;
     }
     SortLayout L = sort_layout(n);
     if (temp == nullptr || temp_bytes < L.total) {
-        gs_set_error("gs_sort_pairs_u64_i32: temp too small (%zu < %zu)", temp_bytes, L.total);
+        gs_set_error("%s: temp too small (%zu < %zu)", who, temp_bytes, L.total);
         return 1;
     }
     char *tp = (char *)temp;
@@ -260,6 +286,7 @@ extern "C" int32_t gs_sort_pairs_u64_i32(
     // ordered state, and fewer bins there mean longer runs per bin and block
     const int first_bits = (end_bit - begin_bit) - (passes - 1) * RADIX_BITS;
     int shift = begin_bit;
+    const uint32_t *n_dev = nullptr; // after a dropping first pass the element count lives on the device
     for (int p = 0; p < passes; ++p) {
         DigitSpec d;
         d.shift = (uint32_t)shift;
@@ -268,16 +295,49 @@ extern "C" int32_t gs_sort_pairs_u64_i32(
         d.mask = (1u << bits) - 1u;
         // int64 keys: when the range includes bit 63 CUB orders them as signed values
         d.flip = (end_bit == 64 && p == passes - 1) ? (1u << (bits - 1)) : 0u;
+        d.drop = (drop && p == 0) ? 1u : 0u;
+        d.drop_hi = drop_hi;
         uint64_t *dst_k = to_out ? (uint64_t *)keys_out : tkeys;
         int32_t *dst_v = to_out ? vals_out : tvals;
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, src_k, d, L.n_blocks, hist);
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, hist);
         hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, hist, totals);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, src_k, src_v, dst_k,
+        if (drop && p == 0) hipLaunchKernelGGL(sort_total_kernel, dim3(1), dim3(GS_BLOCK), 0, st, totals, n_valid_out);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, src_v, dst_k,
                            dst_v, d, L.n_blocks, hist, totals);
+        if (drop && p == 0) n_dev = n_valid_out;
         src_k = dst_k;
         src_v = dst_v;
         to_out = !to_out;
     }
+    return 0;
+}
+
+extern "C" int32_t gs_sort_pairs_u64_i32(
+    uint64_t n, const int64_t *keys_in, const int32_t *vals_in, int64_t *keys_out,
+    int32_t *vals_out, int32_t begin_bit, int32_t end_bit, void *temp, size_t temp_bytes,
+    gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(keys_in && vals_in && keys_out && vals_out, "null pointer");
+    GS_CHECK_ARG(begin_bit >= 0 && end_bit <= 64 && begin_bit <= end_bit, "bad bit range");
+    GS_CHECK_ARG(n < (1ull << 32), "n must be < 2^32");
+    int32_t rc = sort_impl(n, keys_in, vals_in, keys_out, vals_out, begin_bit, end_bit, false, 0u, nullptr, temp, temp_bytes,
+                           (hipStream_t)stream, "gs_sort_pairs_u64_i32");
+    if (rc) return rc;
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_sort_pairs_u64_i32_drop(
+    uint64_t n, const int64_t *keys_in, const int32_t *vals_in, int64_t *keys_out,
+    int32_t *vals_out, int32_t begin_bit, int32_t end_bit, uint32_t drop_hi32, uint32_t *n_kept, void *temp,
+    size_t temp_bytes, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(keys_in && vals_in && keys_out && vals_out && n_kept, "null pointer");
+    GS_CHECK_ARG(begin_bit >= 0 && end_bit <= 64 && begin_bit < end_bit, "bad bit range");
+    GS_CHECK_ARG(n < (1ull << 32), "n must be < 2^32");
+    int32_t rc = sort_impl(n, keys_in, vals_in, keys_out, vals_out, begin_bit, end_bit, true, drop_hi32, n_kept, temp, temp_bytes,
+                           (hipStream_t)stream, "gs_sort_pairs_u64_i32_drop");
+    if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;
 }

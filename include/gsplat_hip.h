@@ -239,12 +239,13 @@ int32_t gs_isect_count_keys(
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
     int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals, gs_stream_t stream);
 int32_t gs_cumsum_gather_i32(
-    uint64_t n, const int32_t *in, const int32_t *idx, int64_t *out,
-    void *scratch, size_t scratch_bytes, gs_stream_t stream);
+    uint64_t n, const int32_t *in, const int32_t *idx, const uint32_t *n_valid /* device scalar or NULL: positions >= *n_valid count 0 */,
+    int64_t *out, void *scratch, size_t scratch_bytes, gs_stream_t stream);
 
 int32_t gs_isect_emit(
     uint32_t n_elems, uint32_t N,   /* camera of element i = i / N when camera_ids NULL */
     const int32_t *perm,            /* [n_elems] emission order or NULL (identity) */
+    const uint32_t *n_valid,        /* device scalar or NULL: only perm[0 .. *n_valid) is defined (gs_sort_pairs_u64_i32_drop) */
     const int64_t *camera_ids,      /* [nnz] or NULL */
     const float *means2d, const int32_t *radii, const float *depths,
     const int64_t *cum_tiles_per_gauss, /* inclusive, indexed by emission position */
@@ -264,6 +265,14 @@ int32_t gs_sort_pairs_u64_i32(
     const int64_t *keys_in, const int32_t *vals_in,
     int64_t *keys_out, int32_t *vals_out,
     int32_t begin_bit, int32_t end_bit,
+    void *temp, size_t temp_bytes, gs_stream_t stream);
+/* Same sort, but keys whose upper 32 bits equal drop_hi32 are DROPPED by the first pass (not counted, not written):
+ * the outputs hold the *n_kept surviving pairs in sorted order (n_kept: device scalar, written by the call), the rest
+ * of the output arrays is untouched.  Used for the splat-level depth pre-sort, where culled splats carry the maximal
+ * key and would otherwise be moved through every pass (71% of the elements at BASELINE config 2). */
+int32_t gs_sort_pairs_u64_i32_drop(
+    uint64_t n, const int64_t *keys_in, const int32_t *vals_in, int64_t *keys_out, int32_t *vals_out,
+    int32_t begin_bit, int32_t end_bit, uint32_t drop_hi32, uint32_t *n_kept,
     void *temp, size_t temp_bytes, gs_stream_t stream);
 
 int32_t gs_isect_offset_encode(
