@@ -147,7 +147,8 @@ def spherical_harmonics_view(
     (reference rendering.py:372-392) in ONE kernel each way -- no ``dirs`` / mask / clamp
     tensors, and the backward writes ``v_means`` (summed over cameras) directly."""
     C, N = campos.shape[0], means.shape[0]
-    assert means.shape == (N, 3) and campos.shape == (C, 3), (means.shape, campos.shape)
+    # campos: [C, 3] camera centres, or the [C, 4, 4] world->camera matrices themselves (centre derived in-kernel)
+    assert means.shape == (N, 3) and (campos.shape == (C, 3) or campos.shape == (C, 4, 4)), (means.shape, campos.shape)
     assert coeffs.dim() == 3 and coeffs.shape[0] == N and coeffs.shape[2] == 3, coeffs.shape
     assert (degrees_to_use + 1) ** 2 <= coeffs.shape[-2], coeffs.shape
     if radii is not None:
@@ -164,7 +165,7 @@ class _SphericalHarmonicsView(torch.autograd.Function):
         C, N, K = campos.shape[0], means.shape[0], coeffs.shape[1]
         colors = torch.empty((C, N, 3), dtype=torch.float32, device=means.device)
         with _device_of(means):
-            B.call("gs_sh_view_fwd", C, N, K, sh_degree, B.ptr(means), B.ptr(campos), B.ptr(coeffs), B.ptr(radii),
+            B.call("gs_sh_view_fwd", C, N, K, sh_degree, B.ptr(means), B.ptr(campos), int(campos.dim() == 3), B.ptr(coeffs), B.ptr(radii),
                    B.ptr(colors), _stream(means))
         ctx.save_for_backward(means, campos, coeffs, radii, colors)
         ctx.sh_degree = sh_degree
@@ -178,7 +179,7 @@ class _SphericalHarmonicsView(torch.autograd.Function):
         v_coeffs = torch.empty_like(coeffs)
         v_means = torch.empty_like(means) if ctx.needs_input_grad[1] else None
         with _device_of(means):
-            B.call("gs_sh_view_bwd", C, N, K, ctx.sh_degree, B.ptr(means), B.ptr(campos), B.ptr(coeffs), B.ptr(radii),
+            B.call("gs_sh_view_bwd", C, N, K, ctx.sh_degree, B.ptr(means), B.ptr(campos), int(campos.dim() == 3), B.ptr(coeffs), B.ptr(radii),
                    B.ptr(colors), B.ptr(v_colors), vstride, B.ptr(v_coeffs), B.ptr(v_means), _stream(means))
         if not ctx.needs_input_grad[3]:
             v_coeffs = None

@@ -654,7 +654,10 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
             // evaluations are independent; only T <- T - T a (one fma) is carried from record to record.
             // (No explicit prefetch of the next group: it cost 40 VGPRs, i.e. two waves per SIMD, and the
             // kernel's duration is rounds of workgroups x their lifetime, not the walk of one list.)
-            constexpr int G = 4;
+#ifndef GS_FWD_G
+#define GS_FWD_G 4
+#endif
+            constexpr int G = GS_FWD_G;
             while (m != 0ull) {
                 float4 c0[G], c1[G];
                 float c2x[G], c2y[G]; // colours 2, 3 (only what CDIM needs is read)

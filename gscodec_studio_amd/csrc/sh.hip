@@ -171,11 +171,27 @@ GS_DEV void zero_row(float *__restrict__ p, uint32_t row_len) {
 // "View" mode (used by rasterization()): directions are means[n] - campos[c] computed in-kernel,
 // the mask is radii[c,n] > 0 and the output is clamp_min(colour + 0.5, 0) -- i.e. the torch ops
 // around the reference's spherical_harmonics call (rendering.py:372-392) are fused in.
+// -A^-1 t of the affine world->camera matrix V = [[A, t], [0, 1]] (adjugate form): the camera centre in world space
+GS_DEV void camera_center(const float *__restrict__ V, float &x, float &y, float &z) {
+    float a00 = V[0], a01 = V[1], a02 = V[2], t0 = V[3];
+    float a10 = V[4], a11 = V[5], a12 = V[6], t1 = V[7];
+    float a20 = V[8], a21 = V[9], a22 = V[10], t2 = V[11];
+    // rows of adj(A) = cross products of the columns of A
+    float r00 = a11 * a22 - a21 * a12, r01 = a21 * a02 - a01 * a22, r02 = a01 * a12 - a11 * a02;
+    float r10 = a12 * a20 - a22 * a10, r11 = a22 * a00 - a02 * a20, r12 = a02 * a10 - a12 * a00;
+    float r20 = a10 * a21 - a20 * a11, r21 = a20 * a01 - a00 * a21, r22 = a00 * a11 - a10 * a01;
+    float inv = 1.f / (a00 * r00 + a10 * r01 + a20 * r02);
+    x = -(r00 * t0 + r01 * t1 + r02 * t2) * inv;
+    y = -(r10 * t0 + r11 * t1 + r12 * t2) * inv;
+    z = -(r20 * t0 + r21 * t1 + r22 * t2) * inv;
+}
+
 struct ShView {
     const float *means;   // [N,3] or nullptr (then `dirs` is used)
-    const float *campos;  // [C,3]
+    const float *campos;  // [C,3] camera centres, or [C,4,4] world->camera matrices when from_viewmats
     const int32_t *radii; // [C,N] or nullptr
     int clamp_half;       // colour = max(colour + 0.5, 0)
+    int from_viewmats;    // the centre is derived in-kernel (wave-uniform math; saves the gs_camera_centers launch)
 };
 
 GS_DEV bool sh_active(const uint8_t *masks, const ShView &v, size_t e) {
@@ -186,9 +202,15 @@ GS_DEV bool sh_active(const uint8_t *masks, const ShView &v, size_t e) {
 
 GS_DEV void sh_dir(const float *dirs, const ShView &v, uint32_t c, uint32_t n, size_t e, float &dx, float &dy, float &dz) {
     if (v.means != nullptr) {
-        dx = v.means[3 * (size_t)n] - v.campos[3 * c];
-        dy = v.means[3 * (size_t)n + 1] - v.campos[3 * c + 1];
-        dz = v.means[3 * (size_t)n + 2] - v.campos[3 * c + 2];
+        float cx, cy, cz;
+        if (v.from_viewmats) {
+            camera_center(v.campos + 16 * c, cx, cy, cz);
+        } else {
+            cx = v.campos[3 * c]; cy = v.campos[3 * c + 1]; cz = v.campos[3 * c + 2];
+        }
+        dx = v.means[3 * (size_t)n] - cx;
+        dy = v.means[3 * (size_t)n + 1] - cy;
+        dz = v.means[3 * (size_t)n + 2] - cz;
     } else {
         dx = dirs[3 * e]; dy = dirs[3 * e + 1]; dz = dirs[3 * e + 2];
     }
@@ -387,7 +409,7 @@ extern "C" int32_t gs_sh_fwd(
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K);
-    ShView view = {nullptr, nullptr, nullptr, 0};
+    ShView view = {nullptr, nullptr, nullptr, 0, 0};
     switch (degree) {
         case 0: launch_fwd<0>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
         case 1: launch_fwd<1>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
@@ -403,19 +425,7 @@ extern "C" int32_t gs_sh_fwd(
 __global__ void camera_centers_kernel(uint32_t C, const float *__restrict__ viewmats, float *__restrict__ out) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float *V = viewmats + 16 * c;
-    float a00 = V[0], a01 = V[1], a02 = V[2], t0 = V[3];
-    float a10 = V[4], a11 = V[5], a12 = V[6], t1 = V[7];
-    float a20 = V[8], a21 = V[9], a22 = V[10], t2 = V[11];
-    // rows of adj(A) = cross products of the columns of A
-    float r00 = a11 * a22 - a21 * a12, r01 = a21 * a02 - a01 * a22, r02 = a01 * a12 - a11 * a02;
-    float r10 = a12 * a20 - a22 * a10, r11 = a22 * a00 - a02 * a20, r12 = a02 * a10 - a12 * a00;
-    float r20 = a10 * a21 - a20 * a11, r21 = a20 * a01 - a00 * a21, r22 = a00 * a11 - a10 * a01;
-    float det = a00 * r00 + a10 * r01 + a20 * r02;
-    float inv = 1.f / det;
-    out[3 * c] = -(r00 * t0 + r01 * t1 + r02 * t2) * inv;
-    out[3 * c + 1] = -(r10 * t0 + r11 * t1 + r12 * t2) * inv;
-    out[3 * c + 2] = -(r20 * t0 + r21 * t1 + r22 * t2) * inv;
+    camera_center(viewmats + 16 * c, out[3 * c], out[3 * c + 1], out[3 * c + 2]);
 }
 
 extern "C" int32_t gs_camera_centers(uint32_t C, const float *viewmats, float *campos, gs_stream_t stream) {
@@ -427,7 +437,7 @@ extern "C" int32_t gs_camera_centers(uint32_t C, const float *viewmats, float *c
 }
 
 extern "C" int32_t gs_sh_view_fwd(
-    uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos,
+    uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos, int32_t campos_from_viewmats,
     const float *coeffs, const int32_t *radii, float *colors, gs_stream_t stream) {
     GS_CHECK_ARG(means && campos && coeffs && colors, "null pointer");
     GS_CHECK_ARG(degree <= 4, "degree must be <= 4");
@@ -436,7 +446,7 @@ extern "C" int32_t gs_sh_view_fwd(
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K);
-    ShView view = {means, campos, radii, 1};
+    ShView view = {means, campos, radii, 1, campos_from_viewmats};
     switch (degree) {
         case 0: launch_fwd<0>(vec, grid, st, C, N, K, nullptr, coeffs, 1, nullptr, colors, view); break;
         case 1: launch_fwd<1>(vec, grid, st, C, N, K, nullptr, coeffs, 1, nullptr, colors, view); break;
@@ -461,7 +471,7 @@ extern "C" int32_t gs_sh_bwd(
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K) && rows_vectorizable(v_coeffs, K);
     bool shared = coeffs_shared != 0;
-    ShView view = {nullptr, nullptr, nullptr, 0};
+    ShView view = {nullptr, nullptr, nullptr, 0, 0};
     switch (degree) {
         case 0: launch_bwd<0>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
         case 1: launch_bwd<1>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
@@ -474,7 +484,7 @@ extern "C" int32_t gs_sh_bwd(
 }
 
 extern "C" int32_t gs_sh_view_bwd(
-    uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos,
+    uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos, int32_t campos_from_viewmats,
     const float *coeffs, const int32_t *radii, const float *colors_out, const float *v_colors,
     uint32_t v_colors_stride, float *v_coeffs, float *v_means, gs_stream_t stream) {
     GS_CHECK_ARG(means && campos && coeffs && colors_out && v_colors && v_coeffs, "null pointer");
@@ -485,7 +495,7 @@ extern "C" int32_t gs_sh_view_bwd(
     dim3 grid(gs_div_up(N, GS_BLOCK));
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K) && rows_vectorizable(v_coeffs, K);
-    ShView view = {means, campos, radii, 1};
+    ShView view = {means, campos, radii, 1, campos_from_viewmats};
     switch (degree) {
         case 0: launch_bwd<0>(vec, true, grid, st, C, N, K, nullptr, coeffs, nullptr, v_colors, v_coeffs, nullptr, view, colors_out, v_colors_stride, v_means); break;
         case 1: launch_bwd<1>(vec, true, grid, st, C, N, K, nullptr, coeffs, nullptr, v_colors, v_coeffs, nullptr, view, colors_out, v_colors_stride, v_means); break;

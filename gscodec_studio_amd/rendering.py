@@ -207,17 +207,18 @@ def rasterization(
             if colors.dim() == 2:
                 colors = colors.expand(C, -1, -1)
     else:
-        campos = _camera_centers(viewmats)  # [C, 3] == inverse(viewmats)[:, :3, 3]
         fused_sh = False
+        fuse = (not packed) and colors.dim() == 3 and not viewmats.requires_grad and viewmats.is_cuda
+        campos = None if fuse else _camera_centers(viewmats)  # [C, 3] == inverse(viewmats)[:, :3, 3]
         if packed:
             dirs = means[gaussian_ids, :] - campos[camera_ids]  # [nnz, 3]
             masks = radii > 0
             shs = colors[gaussian_ids, :, :] if colors.dim() == 3 else colors[camera_ids, gaussian_ids, :, :]
             colors = spherical_harmonics(sh_degree, dirs, shs, masks=masks)  # [nnz, 3]
         else:
-            if colors.dim() == 3 and not campos.requires_grad:
-                # fused: dirs, mask, SH and clamp_min(. + 0.5, 0) in one kernel each way
-                colors = spherical_harmonics_view(sh_degree, means, campos, colors, radii)  # [C, N, 3]
+            if fuse:
+                # fused: camera centres, dirs, mask, SH and clamp_min(. + 0.5, 0) in one kernel each way
+                colors = spherical_harmonics_view(sh_degree, means, viewmats, colors, radii)  # [C, N, 3]
                 fused_sh = True
             else:
                 dirs = means[None, :, :] - campos[:, None, :]  # [C, N, 3]

@@ -176,7 +176,8 @@ int32_t gs_sh_bwd(
 
 /* Fused "view" form used by rasterization() for coefficients shared by all cameras: the torch
  * ops around the reference's spherical_harmonics call (gsplat/rendering.py:372-392) are folded in:
- *   dirs = means[n] - campos[c]   (campos = inverse(viewmats)[:, :3, 3], [C,3])
+ *   dirs = means[n] - campos[c]   (campos = inverse(viewmats)[:, :3, 3], [C,3]; with campos_from_viewmats != 0 the
+ *                                  pointer holds the [C,4,4] world->camera matrices and the centre is derived in-kernel)
  *   mask = radii[c,n] > 0         (radii may be NULL: no mask)
  *   colors = max(SH + 0.5, 0)
  * bwd: colors_out is the forward output (gradient of the clamp); v_colors may be a strided view
@@ -187,11 +188,11 @@ int32_t gs_sh_bwd(
 int32_t gs_camera_centers(uint32_t C, const float *viewmats, float *campos, gs_stream_t stream);
 int32_t gs_sh_view_fwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree,
-    const float *means, const float *campos, const float *coeffs, const int32_t *radii,
+    const float *means, const float *campos, int32_t campos_from_viewmats, const float *coeffs, const int32_t *radii,
     float *colors, gs_stream_t stream);
 int32_t gs_sh_view_bwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree,
-    const float *means, const float *campos, const float *coeffs, const int32_t *radii,
+    const float *means, const float *campos, int32_t campos_from_viewmats, const float *coeffs, const int32_t *radii,
     const float *colors_out, const float *v_colors, uint32_t v_colors_stride,
     float *v_coeffs, float *v_means, gs_stream_t stream);
 

@@ -1,0 +1,16 @@
+import torch, time, sys
+sys.path.insert(0, "/root/repo")
+from gscodec_studio_amd import rasterization
+from gscodec_studio_amd._helper import sh_workload
+for C in (1, 2, 4, 8):
+    w = sh_workload(scene_grid=3, device="cuda:0", n_cameras=C, camera_mode="jitter0")
+    P = [w[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "sh")]
+    def step():
+        for p in P: p.grad = None
+        rc, ra, meta = rasterization(*P, w["viewmats"], w["Ks"], w["width"], w["height"], sh_degree=3, packed=False)
+        rc.sum().backward()
+    for _ in range(5): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20 * 1e3
+    print(f"C={C}: {dt:.3f} ms/step, {dt / C:.3f} ms per camera, {w['N'] * C / dt / 1e3:.0f} Msplats/s")
