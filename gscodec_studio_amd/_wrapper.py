@@ -135,13 +135,26 @@ def _row_strided(t: Tensor, width: int):
     return t.contiguous(), width
 
 
+def _elem_strided(t: Tensor):
+    """(tensor, element_stride) for a [C, N] gradient that is contiguous or one column of a wider row-major buffer
+    (the opacity slot of the packed [C*N, 16] compositing gradients); anything else is copied."""
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32 tensor, got {t.dtype}")
+    if t.is_contiguous():
+        return t, 1
+    if t.dim() == 2 and t.stride(1) >= 1 and (t.shape[0] == 1 or t.stride(0) == t.shape[1] * t.stride(1)):
+        return t, t.stride(1)
+    return t.contiguous(), 1
+
+
 def spherical_harmonics_view(
     degrees_to_use: int,
     means: Tensor,  # [N, 3]
     campos: Tensor,  # [C, 3] camera centres in world space
     coeffs: Tensor,  # [N, K, 3] shared by all cameras
     radii: Optional[Tensor] = None,  # [C, N] int32: evaluate only where radii > 0
-) -> Tensor:
+    opacities: Optional[Tensor] = None,  # [N]: also return opacities.repeat(C, 1) (and sum its gradient over cameras)
+):
     """Fused colour evaluation used by ``rasterization``:
     ``clamp_min(spherical_harmonics(deg, means[None] - campos[:, None], coeffs, radii > 0) + 0.5, 0)``
     (reference rendering.py:372-392) in ONE kernel each way -- no ``dirs`` / mask / clamp
@@ -153,39 +166,58 @@ def spherical_harmonics_view(
     assert (degrees_to_use + 1) ** 2 <= coeffs.shape[-2], coeffs.shape
     if radii is not None:
         assert radii.shape == (C, N) and radii.dtype == torch.int32, (radii.shape, radii.dtype)
-    return _SphericalHarmonicsView.apply(degrees_to_use, means.contiguous(), campos.contiguous(), coeffs.contiguous(),
-                                         radii.contiguous() if radii is not None else None)
+    if opacities is not None:
+        assert opacities.shape == (N,), opacities.shape
+    colors, opac_cn = _SphericalHarmonicsView.apply(degrees_to_use, means.contiguous(), campos.contiguous(), coeffs.contiguous(),
+                                                    radii.contiguous() if radii is not None else None,
+                                                    opacities.contiguous() if opacities is not None else None)
+    return colors if opacities is None else (colors, opac_cn)
 
 
 class _SphericalHarmonicsView(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, sh_degree, means, campos, coeffs, radii):
+    def forward(ctx, sh_degree, means, campos, coeffs, radii, opacities):
         _require_gpu(coeffs, "spherical_harmonics_view")
         means, campos, coeffs = _f32c(means), _f32c(campos), _f32c(coeffs)
         C, N, K = campos.shape[0], means.shape[0], coeffs.shape[1]
         colors = torch.empty((C, N, 3), dtype=torch.float32, device=means.device)
+        opacities = _f32c(opacities) if opacities is not None else None
+        opac_cn = torch.empty((C, N), dtype=torch.float32, device=means.device) if opacities is not None else None
         with _device_of(means):
             B.call("gs_sh_view_fwd", C, N, K, sh_degree, B.ptr(means), B.ptr(campos), int(campos.dim() == 3), B.ptr(coeffs), B.ptr(radii),
-                   B.ptr(colors), _stream(means))
+                   B.ptr(colors), B.ptr(opacities), B.ptr(opac_cn), _stream(means))
         ctx.save_for_backward(means, campos, coeffs, radii, colors)
         ctx.sh_degree = sh_degree
-        return colors
+        ctx.has_opac = opacities is not None
+        ctx.set_materialize_grads(False)
+        return colors, opac_cn
 
     @staticmethod
-    def backward(ctx, v_colors):
+    def backward(ctx, v_colors, v_opac_cn):
         means, campos, coeffs, radii, colors = ctx.saved_tensors
         C, N, K = campos.shape[0], means.shape[0], coeffs.shape[1]
+        if v_colors is None:
+            v_colors = torch.zeros_like(colors)
         v_colors, vstride = _row_strided(v_colors, 3)
         v_coeffs = torch.empty_like(coeffs)
         v_means = torch.empty_like(means) if ctx.needs_input_grad[1] else None
+        v_opac = ostride = None
+        if ctx.has_opac and ctx.needs_input_grad[5]:
+            v_opac = torch.empty((N,), dtype=torch.float32, device=means.device)
+            if v_opac_cn is None:
+                v_opac.zero_()
+            else:
+                v_opac_cn, ostride = _elem_strided(v_opac_cn)
         with _device_of(means):
             B.call("gs_sh_view_bwd", C, N, K, ctx.sh_degree, B.ptr(means), B.ptr(campos), int(campos.dim() == 3), B.ptr(coeffs), B.ptr(radii),
-                   B.ptr(colors), B.ptr(v_colors), vstride, B.ptr(v_coeffs), B.ptr(v_means), _stream(means))
+                   B.ptr(colors), B.ptr(v_colors), vstride, B.ptr(v_coeffs), B.ptr(v_means),
+                   B.ptr(v_opac_cn) if ostride is not None else None, ostride or 0, B.ptr(v_opac) if ostride is not None else None,
+                   _stream(means))
         if not ctx.needs_input_grad[3]:
             v_coeffs = None
         # campos (camera poses) gets no gradient on this path; rasterization() takes the unfused
         # route when viewmats require grad.
-        return None, v_means, None, v_coeffs, None
+        return None, v_means, None, v_coeffs, None, v_opac
 
 
 class _SphericalHarmonics(torch.autograd.Function):

@@ -192,6 +192,12 @@ struct ShView {
     const int32_t *radii; // [C,N] or nullptr
     int clamp_half;       // colour = max(colour + 0.5, 0)
     int from_viewmats;    // the centre is derived in-kernel (wave-uniform math; saves the gs_camera_centers launch)
+    // per-view opacities riding along (rendering.py:331 `opacities.repeat(C, 1)` and the sum over cameras in its backward):
+    const float *opac_in;    // fwd: [N]
+    float *opac_out;         // fwd: [C,N] <- opac_in[n]
+    const float *v_opac_cn;  // bwd: [C,N] rows with stride v_opac_stride floats
+    uint32_t v_opac_stride;
+    float *v_opac_out;       // bwd: [N] <- sum over cameras
 };
 
 GS_DEV bool sh_active(const uint8_t *masks, const ShView &v, size_t e) {
@@ -226,6 +232,7 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_fwd_kernel(
     uint32_t c = blockIdx.y;
     if (n >= N) return;
     size_t e = (size_t)c * N + n;
+    if (view.opac_out != nullptr) view.opac_out[e] = view.opac_in[n]; // every element, visible or not (like .repeat)
     if (!sh_active(masks, view, e)) return;
     float Y[NB];
     if (DEG >= 1) {
@@ -269,6 +276,11 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
     uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
     if (n >= N) return;
     float vmx = 0.f, vmy = 0.f, vmz = 0.f; // view mode: d/d means = sum over cameras of d/d dirs
+    if (view.v_opac_out != nullptr) { // culled (c, n) pairs hold exact zeros in the gradient rows
+        float vo = 0.f;
+        for (uint32_t c = 0; c < C; ++c) vo += view.v_opac_cn[((size_t)c * N + n) * view.v_opac_stride];
+        view.v_opac_out[n] = vo;
+    }
     const uint32_t row_len = K * 3;
     float acc[NB * 3];
     if (SHARED) {
@@ -409,7 +421,7 @@ extern "C" int32_t gs_sh_fwd(
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K);
-    ShView view = {nullptr, nullptr, nullptr, 0, 0};
+    ShView view = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0u, nullptr};
     switch (degree) {
         case 0: launch_fwd<0>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
         case 1: launch_fwd<1>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
@@ -438,7 +450,7 @@ extern "C" int32_t gs_camera_centers(uint32_t C, const float *viewmats, float *c
 
 extern "C" int32_t gs_sh_view_fwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos, int32_t campos_from_viewmats,
-    const float *coeffs, const int32_t *radii, float *colors, gs_stream_t stream) {
+    const float *coeffs, const int32_t *radii, float *colors, const float *opacities, float *opacities_cn, gs_stream_t stream) {
     GS_CHECK_ARG(means && campos && coeffs && colors, "null pointer");
     GS_CHECK_ARG(degree <= 4, "degree must be <= 4");
     GS_CHECK_ARG((degree + 1) * (degree + 1) <= K, "K too small for degree");
@@ -446,7 +458,8 @@ extern "C" int32_t gs_sh_view_fwd(
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K);
-    ShView view = {means, campos, radii, 1, campos_from_viewmats};
+    ShView view = {means, campos, radii, 1, campos_from_viewmats, opacities, opacities_cn, nullptr, 0u, nullptr};
+    GS_CHECK_ARG((opacities == nullptr) == (opacities_cn == nullptr), "opacities and opacities_cn go together");
     switch (degree) {
         case 0: launch_fwd<0>(vec, grid, st, C, N, K, nullptr, coeffs, 1, nullptr, colors, view); break;
         case 1: launch_fwd<1>(vec, grid, st, C, N, K, nullptr, coeffs, 1, nullptr, colors, view); break;
@@ -471,7 +484,7 @@ extern "C" int32_t gs_sh_bwd(
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K) && rows_vectorizable(v_coeffs, K);
     bool shared = coeffs_shared != 0;
-    ShView view = {nullptr, nullptr, nullptr, 0, 0};
+    ShView view = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0u, nullptr};
     switch (degree) {
         case 0: launch_bwd<0>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
         case 1: launch_bwd<1>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
@@ -486,7 +499,8 @@ extern "C" int32_t gs_sh_bwd(
 extern "C" int32_t gs_sh_view_bwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos, int32_t campos_from_viewmats,
     const float *coeffs, const int32_t *radii, const float *colors_out, const float *v_colors,
-    uint32_t v_colors_stride, float *v_coeffs, float *v_means, gs_stream_t stream) {
+    uint32_t v_colors_stride, float *v_coeffs, float *v_means, const float *v_opacities_cn, uint32_t v_opacities_stride,
+    float *v_opacities, gs_stream_t stream) {
     GS_CHECK_ARG(means && campos && coeffs && colors_out && v_colors && v_coeffs, "null pointer");
     GS_CHECK_ARG(degree <= 4, "degree must be <= 4");
     GS_CHECK_ARG((degree + 1) * (degree + 1) <= K, "K too small for degree");
@@ -495,7 +509,8 @@ extern "C" int32_t gs_sh_view_bwd(
     dim3 grid(gs_div_up(N, GS_BLOCK));
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K) && rows_vectorizable(v_coeffs, K);
-    ShView view = {means, campos, radii, 1, campos_from_viewmats};
+    ShView view = {means, campos, radii, 1, campos_from_viewmats, nullptr, nullptr, v_opacities_cn, v_opacities_stride, v_opacities};
+    GS_CHECK_ARG((v_opacities_cn == nullptr) == (v_opacities == nullptr), "v_opacities_cn and v_opacities go together");
     switch (degree) {
         case 0: launch_bwd<0>(vec, true, grid, st, C, N, K, nullptr, coeffs, nullptr, v_colors, v_coeffs, nullptr, view, colors_out, v_colors_stride, v_means); break;
         case 1: launch_bwd<1>(vec, true, grid, st, C, N, K, nullptr, coeffs, nullptr, v_colors, v_coeffs, nullptr, view, colors_out, v_colors_stride, v_means); break;

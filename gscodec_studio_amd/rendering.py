@@ -171,8 +171,14 @@ def rasterization(
         opacities = opacities[gaussian_ids]  # [nnz]
     else:
         radii, means2d, depths, conics, compensations = proj_results
-        opacities = opacities.repeat(C, 1)  # [C, N]
         camera_ids, gaussian_ids = None, None
+        # classic mode + shared SH on the fused route: the per-view opacities ride along with the colour kernels
+        # (written by the SH forward, summed over cameras by its backward) instead of `.repeat` + autograd's sum
+        opacity_rider = (compensations is None and sh_degree is not None and colors.dim() == 3 and not distributed
+                         and not viewmats.requires_grad and viewmats.is_cuda)
+        opacities_n = opacities
+        if not opacity_rider:
+            opacities = opacities.repeat(C, 1)  # [C, N]
 
     if compensations is not None:
         opacities = opacities * compensations
@@ -218,7 +224,11 @@ def rasterization(
         else:
             if fuse:
                 # fused: camera centres, dirs, mask, SH and clamp_min(. + 0.5, 0) in one kernel each way
-                colors = spherical_harmonics_view(sh_degree, means, viewmats, colors, radii)  # [C, N, 3]
+                if opacity_rider:
+                    colors, opacities = spherical_harmonics_view(sh_degree, means, viewmats, colors, radii, opacities=opacities_n)
+                    meta["opacities"] = opacities
+                else:
+                    colors = spherical_harmonics_view(sh_degree, means, viewmats, colors, radii)  # [C, N, 3]
                 fused_sh = True
             else:
                 dirs = means[None, :, :] - campos[:, None, :]  # [C, N, 3]

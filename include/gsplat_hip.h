@@ -182,19 +182,24 @@ int32_t gs_sh_bwd(
  *   colors = max(SH + 0.5, 0)
  * bwd: colors_out is the forward output (gradient of the clamp); v_colors may be a strided view
  * (row stride v_colors_stride floats, e.g. 16 for the packed compositing gradient rows);
- * v_coeffs [N,K,3] and v_means [N,3] (= sum over cameras of d/d dirs; may be NULL) are OVERWRITTEN. */
+ * v_coeffs [N,K,3] and v_means [N,3] (= sum over cameras of d/d dirs; may be NULL) are OVERWRITTEN.
+ * Optional riders (both NULL to disable): fwd writes opacities_cn[c,n] = opacities[n] for EVERY element (the
+ * `opacities.repeat(C, 1)` of rendering.py:331); bwd writes v_opacities[n] = sum_c v_opacities_cn[c,n] (row stride
+ * v_opacities_stride floats) -- the two extra torch kernels of the pipeline disappear into passes that run anyway. */
 /* campos[c] = inverse(viewmats[c])[:3, 3] for affine world->camera matrices, closed form
  * (replaces torch.inverse(viewmats) of gsplat/rendering.py:370, which host-synchronises on ROCm). */
 int32_t gs_camera_centers(uint32_t C, const float *viewmats, float *campos, gs_stream_t stream);
 int32_t gs_sh_view_fwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree,
     const float *means, const float *campos, int32_t campos_from_viewmats, const float *coeffs, const int32_t *radii,
-    float *colors, gs_stream_t stream);
+    float *colors, const float *opacities /* [N] or NULL */, float *opacities_cn /* [C,N] or NULL */, gs_stream_t stream);
 int32_t gs_sh_view_bwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree,
     const float *means, const float *campos, int32_t campos_from_viewmats, const float *coeffs, const int32_t *radii,
     const float *colors_out, const float *v_colors, uint32_t v_colors_stride,
-    float *v_coeffs, float *v_means, gs_stream_t stream);
+    float *v_coeffs, float *v_means,
+    const float *v_opacities_cn /* or NULL */, uint32_t v_opacities_stride, float *v_opacities /* [N] or NULL */,
+    gs_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * R3 / R4  tile intersection, 64-bit radix sort, offset encode
