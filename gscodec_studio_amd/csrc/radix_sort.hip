@@ -10,7 +10,7 @@
 //   1. sort_hist_kernel   : per-block digit histogram -> hist[digit][block]
 //   2. sort_scan_kernel   : one block per digit, exclusive scan over blocks (+ digit total)
 //   3. sort_scatter_kernel: stable local ranking with wave64 ballot matching, scatter.
-// A block owns 4096 consecutive keys; wave w owns 1024 of them and walks them in 16
+// A block owns 4096 (large inputs) or 1024 consecutive keys; wave w owns a quarter of them and walks them in 16 (4)
 // rounds of 64, so (wave, round, lane) order == index order, which is what makes the
 // ballot-based rank stable.  Keys stay in VGPRs between the ranking and scatter phases; the scatter
 // itself goes through LDS (block-sorted order first, then coalesced runs per digit).
@@ -22,9 +22,13 @@ namespace {
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 constexpr int SORT_WAVES = GS_BLOCK / GS_WAVE; // 4
-constexpr int SORT_ROUNDS = 16;
-constexpr int SORT_WAVE_KEYS = GS_WAVE * SORT_ROUNDS;  // 1024
-constexpr int SORT_TILE = SORT_WAVES * SORT_WAVE_KEYS; // 4096
+// Keys per block = 256 * ROUNDS.  16 rounds (4096 keys) for large inputs; 4 rounds (1024 keys) up to SORT_SMALL_N
+// keys: there a pass is bound by the LATENCY of one block (all blocks are resident at once: 17 us per scatter
+// launch at 1 M keys with 4096-key blocks, whatever the number of live keys), so shorter blocks win.
+constexpr int SORT_ROUNDS_BIG = 16, SORT_ROUNDS_SMALL = 4;
+constexpr uint64_t SORT_SMALL_N = 2u << 20;
+constexpr int sort_tile(int rounds) { return GS_BLOCK * rounds; }
+inline int sort_rounds_for(uint64_t n) { return n <= SORT_SMALL_N ? SORT_ROUNDS_SMALL : SORT_ROUNDS_BIG; }
 
 struct DigitSpec {
     uint32_t shift;
@@ -38,9 +42,11 @@ GS_DEV bool key_kept(uint64_t key, DigitSpec d) { return !(d.drop != 0u && (uint
 
 GS_DEV uint32_t digit_of(uint64_t key, DigitSpec d) { return ((uint32_t)(key >> d.shift) & d.mask) ^ d.flip; }
 
+template <int SORT_ROUNDS>
 __global__ void __launch_bounds__(GS_BLOCK) sort_hist_kernel(
     uint64_t n, const uint32_t *__restrict__ n_dev, const uint64_t *__restrict__ keys, DigitSpec d, uint32_t n_blocks,
     uint32_t *__restrict__ hist /* [RADIX][n_blocks] */) {
+    constexpr int SORT_TILE = sort_tile(SORT_ROUNDS);
     __shared__ uint32_t s_hist[RADIX];
     s_hist[threadIdx.x] = 0;
     if (n_dev != nullptr) n = min(n, (uint64_t)*n_dev); // element count known only on the device
@@ -104,10 +110,13 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_total_kernel(const uint32_t *__
     if (threadIdx.x == 0) *n_out = s[0] + s[1] + s[2] + s[3];
 }
 
+template <int SORT_ROUNDS>
 __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
     uint64_t n, const uint32_t *__restrict__ n_dev, const uint64_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
     uint64_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, DigitSpec d,
     uint32_t n_blocks, const uint32_t *__restrict__ hist_scan, const uint32_t *__restrict__ totals) {
+    constexpr int SORT_TILE = sort_tile(SORT_ROUNDS);
+    constexpr int SORT_WAVE_KEYS = GS_WAVE * SORT_ROUNDS;
     __shared__ uint32_t s_cnt[SORT_WAVES][RADIX]; // per-wave digit counters -> per-wave prefix
     __shared__ uint32_t s_lbase[RADIX];           // base of the digit inside this block's sorted order
     __shared__ uint32_t s_gofs[RADIX];            // global base of (digit, this block) - s_lbase
@@ -233,7 +242,7 @@ struct SortLayout {
 
 SortLayout sort_layout(uint64_t n) {
     SortLayout L;
-    L.n_blocks = gs_div_up(n, SORT_TILE);
+    L.n_blocks = gs_div_up(n, sort_tile(sort_rounds_for(n)));
     size_t o = 0;
     auto take = [&](size_t bytes) {
         size_t r = o;
@@ -287,6 +296,7 @@ static int32_t sort_impl(uint64_t n, const int64_t *keys_in, const int32_t *vals
     const int first_bits = (end_bit - begin_bit) - (passes - 1) * RADIX_BITS;
     int shift = begin_bit;
     const uint32_t *n_dev = nullptr; // after a dropping first pass the element count lives on the device
+    const bool small = sort_rounds_for(n) == SORT_ROUNDS_SMALL;
     for (int p = 0; p < passes; ++p) {
         DigitSpec d;
         d.shift = (uint32_t)shift;
@@ -299,11 +309,18 @@ static int32_t sort_impl(uint64_t n, const int64_t *keys_in, const int32_t *vals
         d.drop_hi = drop_hi;
         uint64_t *dst_k = to_out ? (uint64_t *)keys_out : tkeys;
         int32_t *dst_v = to_out ? vals_out : tvals;
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, hist);
+        if (small)
+            hipLaunchKernelGGL((sort_hist_kernel<SORT_ROUNDS_SMALL>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, hist);
+        else
+            hipLaunchKernelGGL((sort_hist_kernel<SORT_ROUNDS_BIG>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, hist);
         hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, hist, totals);
         if (drop && p == 0) hipLaunchKernelGGL(sort_total_kernel, dim3(1), dim3(GS_BLOCK), 0, st, totals, n_valid_out);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, src_v, dst_k,
-                           dst_v, d, L.n_blocks, hist, totals);
+        if (small)
+            hipLaunchKernelGGL((sort_scatter_kernel<SORT_ROUNDS_SMALL>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, src_v,
+                               dst_k, dst_v, d, L.n_blocks, hist, totals);
+        else
+            hipLaunchKernelGGL((sort_scatter_kernel<SORT_ROUNDS_BIG>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, src_v,
+                               dst_k, dst_v, d, L.n_blocks, hist, totals);
         if (drop && p == 0) n_dev = n_valid_out;
         src_k = dst_k;
         src_v = dst_v;
