@@ -561,6 +561,7 @@ class _FullyFusedProjection(torch.autograd.Function):
         ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, radii, conics, compensations)
         ctx.width, ctx.height, ctx.eps2d, ctx.cm = width, height, eps2d, cm
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)  # unused outputs (radii, depths in RGB mode) arrive as None, not as zero tensors
         return radii, means2d, depths, conics, compensations
 
     @staticmethod
@@ -568,8 +569,12 @@ class _FullyFusedProjection(torch.autograd.Function):
         means, covars, quats, scales, viewmats, Ks, radii, conics, compensations = ctx.saved_tensors
         C, N = viewmats.shape[0], means.shape[0]
         dev = means.device
+        if v_means2d is None:
+            v_means2d = torch.zeros((C, N, 2), dtype=torch.float32, device=dev)
+        if v_conics is None:
+            v_conics = torch.zeros((C, N, 3), dtype=torch.float32, device=dev)
         (v_means2d, s_m2), (v_conics, s_cn) = _row_strided(v_means2d, 2), _row_strided(v_conics, 3)
-        v_depths = _f32c(v_depths)
+        v_depths = _f32c(v_depths) if v_depths is not None else None
         v_compensations = _f32c(v_compensations) if v_compensations is not None else None
         need = ctx.needs_input_grad
         # rows are fully written by the kernel -> empty, not zeros

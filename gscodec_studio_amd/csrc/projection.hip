@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
                 cam, px, py, pz, S, W, H, eps2d, camera_model,
                 conics[3 * idx], conics[3 * idx + 1], conics[3 * idx + 2],
                 has_comp ? compensations[idx] : 0.f, has_comp ? v_compensations[idx] : 0.f, has_comp,
-                v_means2d[s_m2 * idx], v_means2d[s_m2 * idx + 1], v_depths[idx],
+                v_means2d[s_m2 * idx], v_means2d[s_m2 * idx + 1], v_depths != nullptr ? v_depths[idx] : 0.f,
                 v_conics[s_cn * idx], v_conics[s_cn * idx + 1], v_conics[s_cn * idx + 2], g);
             any = true;
         }
@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_packed_bwd_kernel(
         cam, px, py, pz, S, W, H, eps2d, camera_model, conics[3 * (size_t)idx],
         conics[3 * (size_t)idx + 1], conics[3 * (size_t)idx + 2],
         has_comp ? compensations[idx] : 0.f, has_comp ? v_compensations[idx] : 0.f, has_comp,
-        v_means2d[2 * (size_t)idx], v_means2d[2 * (size_t)idx + 1], v_depths[idx],
+        v_means2d[2 * (size_t)idx], v_means2d[2 * (size_t)idx + 1], v_depths != nullptr ? v_depths[idx] : 0.f,
         v_conics[3 * (size_t)idx], v_conics[3 * (size_t)idx + 1], v_conics[3 * (size_t)idx + 2], g);
 
     float vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
@@ -570,7 +570,7 @@ extern "C" int32_t gs_projection_bwd(
     const float *v_depths, const float *v_conics, const float *v_compensations, float *v_means,
     float *v_covars, float *v_quats, float *v_scales, float *v_viewmats, uint32_t v_means2d_stride,
     uint32_t v_conics_stride, gs_stream_t stream) {
-    GS_CHECK_ARG(means && viewmats && Ks && radii && conics && v_means2d && v_depths && v_conics,
+    GS_CHECK_ARG(means && viewmats && Ks && radii && conics && v_means2d && v_conics,
                  "null pointer");
     GS_CHECK_ARG(v_means2d_stride >= 2 && v_conics_stride >= 3, "bad gradient row strides");
     GS_CHECK_ARG((covars != nullptr) != (quats != nullptr && scales != nullptr),
@@ -647,7 +647,7 @@ extern "C" int32_t gs_projection_packed_bwd(
     GS_CHECK_ARG((covars != nullptr) != (quats != nullptr && scales != nullptr),
                  "exactly one of covars / (quats, scales) must be given");
     if (nnz == 0) return 0;
-    GS_CHECK_ARG(camera_ids && gaussian_ids && conics && v_means2d && v_depths && v_conics, "null pointer");
+    GS_CHECK_ARG(camera_ids && gaussian_ids && conics && v_means2d && v_conics, "null pointer");
     dim3 grid(gs_div_up(nnz, GS_BLOCK));
     if (v_viewmats != nullptr) {
         hipLaunchKernelGGL(projection_packed_bwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream,

@@ -89,7 +89,7 @@ int32_t gs_projection_bwd(
     const float *conics,         /* [C,N,3] */
     const float *compensations,  /* [C,N] or NULL */
     const float *v_means2d,      /* [C,N,2] */
-    const float *v_depths,       /* [C,N] */
+    const float *v_depths,       /* [C,N] or NULL (= zero) */
     const float *v_conics,       /* [C,N,3] */
     const float *v_compensations,/* [C,N] or NULL */
     float *v_means,   /* [N,3] or NULL */
