@@ -251,6 +251,43 @@ def test_radix_sort_stable_bit_exact(ops, n, end_bit):
     assert np.array_equal(N(vo), vals[order])
 
 
+@pytest.mark.parametrize("n", [1, 1000, 4097, 300_000, 2_200_000, 3_000_001])
+def test_radix_sort_drop_variant_and_gather_cumsum(ops, n):
+    """gs_sort_pairs_u64_i32_drop: keys with a given upper word vanish in the first pass, the survivors come out in stable
+    sorted order, their count lands on the device; gs_cumsum_gather_i32 honours that device-side count.  Sizes on both
+    sides of the 1024- / 4096-key block switch (2 M keys)."""
+    from gscodec_studio_amd import _backend as B
+
+    rs = np.random.RandomState(n % 1009)
+    hi = rs.randint(0, 1 << 10, size=n).astype(np.int64) << 21  # few distinct values: ties
+    drop = rs.rand(n) < 0.7
+    hi[drop] = 0x7FFFFFFF
+    keys = (hi << 32) | np.arange(n, dtype=np.int64)
+    vals = np.arange(n, dtype=np.int32)
+    k_t, v_t = T(keys), T(vals)
+    ko, vo = torch.full_like(k_t, -1), torch.full_like(v_t, -1)
+    n_kept = torch.zeros(1, dtype=torch.int32, device=k_t.device)
+    tb = B.query("gs_sort_temp_bytes", n)
+    temp = torch.empty(tb, dtype=torch.uint8, device=k_t.device)
+    st = torch.cuda.current_stream().cuda_stream
+    B.call("gs_sort_pairs_u64_i32_drop", n, B.ptr(k_t), B.ptr(v_t), B.ptr(ko), B.ptr(vo), 32, 64, 0x7FFFFFFF, B.ptr(n_kept),
+           B.ptr(temp), tb, st)
+    kept = np.nonzero(~drop)[0]
+    assert int(n_kept.item()) == len(kept)
+    order = kept[np.argsort(keys[kept] >> 32, kind="stable")]
+    assert np.array_equal(N(vo)[: len(kept)], vals[order]) and np.array_equal(N(ko)[: len(kept)], keys[order])
+    assert np.all(N(vo)[len(kept):] == -1)  # the rest of the outputs is untouched
+    # prefix sum of src[perm[i]] over the kept positions only
+    src = rs.randint(0, 9, size=n).astype(np.int32)
+    out = torch.empty(n, dtype=torch.int64, device=k_t.device)
+    sb = B.query("gs_cumsum_scratch_bytes", n)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=k_t.device)
+    B.call("gs_cumsum_gather_i32", n, B.ptr(T(src)), B.ptr(vo), B.ptr(n_kept), B.ptr(out), B.ptr(scratch), sb, st)
+    ref = np.zeros(n, np.int64)
+    ref[: len(kept)] = src[order]
+    assert np.array_equal(N(out), np.cumsum(ref))
+
+
 def test_cumsum_matches_numpy(ops):
     from gscodec_studio_amd import _backend as B
 
