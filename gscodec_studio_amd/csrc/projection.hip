@@ -549,11 +549,11 @@ extern "C" int32_t gs_projection_fwd(
     int32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
     int32_t camera_model, int32_t *radii, float *means2d, float *depths, float *conics,
     float *compensations, gs_stream_t stream) {
+    if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && viewmats && Ks && radii && means2d && depths && conics, "null pointer");
     GS_CHECK_ARG((covars != nullptr) != (quats != nullptr && scales != nullptr),
                  "exactly one of covars / (quats, scales) must be given");
     GS_CHECK_ARG(camera_model >= 0 && camera_model <= 2, "bad camera_model");
-    if (C == 0 || N == 0) return 0;
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipLaunchKernelGGL(projection_fwd_kernel, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means,
                        covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d, near_plane,
@@ -570,6 +570,7 @@ extern "C" int32_t gs_projection_bwd(
     const float *v_depths, const float *v_conics, const float *v_compensations, float *v_means,
     float *v_covars, float *v_quats, float *v_scales, float *v_viewmats, uint32_t v_means2d_stride,
     uint32_t v_conics_stride, gs_stream_t stream) {
+    if (N == 0) return 0;
     GS_CHECK_ARG(means && viewmats && Ks && radii && conics && v_means2d && v_conics,
                  "null pointer");
     GS_CHECK_ARG(v_means2d_stride >= 2 && v_conics_stride >= 3, "bad gradient row strides");
@@ -577,7 +578,6 @@ extern "C" int32_t gs_projection_bwd(
                  "exactly one of covars / (quats, scales) must be given");
     GS_CHECK_ARG((v_compensations == nullptr) || (compensations != nullptr),
                  "v_compensations given without compensations");
-    if (N == 0) return 0;
     dim3 grid(gs_div_up(N, GS_BLOCK));
     if (v_viewmats != nullptr) {
         hipLaunchKernelGGL(projection_bwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
@@ -601,10 +601,10 @@ extern "C" int32_t gs_projection_packed_count(
     const float *scales, const float *viewmats, const float *Ks, int32_t image_width,
     int32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
     int32_t camera_model, int32_t *block_cnts, gs_stream_t stream) {
+    if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && viewmats && Ks && block_cnts, "null pointer");
     GS_CHECK_ARG((covars != nullptr) != (quats != nullptr && scales != nullptr),
                  "exactly one of covars / (quats, scales) must be given");
-    if (C == 0 || N == 0) return 0;
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipLaunchKernelGGL(projection_packed_kernel<false>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
                        means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
@@ -622,10 +622,10 @@ extern "C" int32_t gs_projection_packed_fill(
     int32_t camera_model, const int32_t *block_accum, int32_t *indptr, int64_t *camera_ids,
     int64_t *gaussian_ids, int32_t *radii, float *means2d, float *depths, float *conics,
     float *compensations, gs_stream_t stream) {
+    if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && viewmats && Ks && block_accum && indptr, "null pointer");
     GS_CHECK_ARG((covars != nullptr) != (quats != nullptr && scales != nullptr),
                  "exactly one of covars / (quats, scales) must be given");
-    if (C == 0 || N == 0) return 0;
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipLaunchKernelGGL(projection_packed_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
                        means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
@@ -643,10 +643,10 @@ extern "C" int32_t gs_projection_packed_bwd(
     const float *compensations, const float *v_means2d, const float *v_depths,
     const float *v_conics, const float *v_compensations, int32_t sparse_grad, float *v_means,
     float *v_covars, float *v_quats, float *v_scales, float *v_viewmats, gs_stream_t stream) {
+    if (nnz == 0) return 0;
     GS_CHECK_ARG(means && viewmats && Ks, "null pointer");
     GS_CHECK_ARG((covars != nullptr) != (quats != nullptr && scales != nullptr),
                  "exactly one of covars / (quats, scales) must be given");
-    if (nnz == 0) return 0;
     GS_CHECK_ARG(camera_ids && gaussian_ids && conics && v_means2d && v_conics, "null pointer");
     dim3 grid(gs_div_up(nnz, GS_BLOCK));
     if (v_viewmats != nullptr) {

@@ -413,11 +413,11 @@ void launch_bwd(bool vec, bool shared, dim3 grid, hipStream_t st, uint32_t C, ui
 extern "C" int32_t gs_sh_fwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *dirs, const float *coeffs,
     int32_t coeffs_shared, const uint8_t *masks, float *colors, gs_stream_t stream) {
+    if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(coeffs && colors, "null pointer");
     GS_CHECK_ARG(degree <= 4, "degree must be <= 4");
     GS_CHECK_ARG((degree + 1) * (degree + 1) <= K, "K too small for degree");
     GS_CHECK_ARG(degree == 0 || dirs != nullptr, "dirs required for degree >= 1");
-    if (C == 0 || N == 0) return 0;
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K);
@@ -451,10 +451,10 @@ extern "C" int32_t gs_camera_centers(uint32_t C, const float *viewmats, float *c
 extern "C" int32_t gs_sh_view_fwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos, int32_t campos_from_viewmats,
     const float *coeffs, const int32_t *radii, float *colors, const float *opacities, float *opacities_cn, gs_stream_t stream) {
+    if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && campos && coeffs && colors, "null pointer");
     GS_CHECK_ARG(degree <= 4, "degree must be <= 4");
     GS_CHECK_ARG((degree + 1) * (degree + 1) <= K, "K too small for degree");
-    if (C == 0 || N == 0) return 0;
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K);
@@ -475,11 +475,11 @@ extern "C" int32_t gs_sh_bwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *dirs, const float *coeffs,
     int32_t coeffs_shared, const uint8_t *masks, const float *v_colors, float *v_coeffs,
     float *v_dirs, gs_stream_t stream) {
+    if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(coeffs && v_colors && v_coeffs, "null pointer");
     GS_CHECK_ARG(degree <= 4, "degree must be <= 4");
     GS_CHECK_ARG((degree + 1) * (degree + 1) <= K, "K too small for degree");
     GS_CHECK_ARG(degree == 0 || dirs != nullptr, "dirs required for degree >= 1");
-    if (C == 0 || N == 0) return 0;
     dim3 grid(gs_div_up(N, GS_BLOCK));
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K) && rows_vectorizable(v_coeffs, K);
@@ -501,11 +501,11 @@ extern "C" int32_t gs_sh_view_bwd(
     const float *coeffs, const int32_t *radii, const float *colors_out, const float *v_colors,
     uint32_t v_colors_stride, float *v_coeffs, float *v_means, const float *v_opacities_cn, uint32_t v_opacities_stride,
     float *v_opacities, gs_stream_t stream) {
+    if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && campos && coeffs && colors_out && v_colors && v_coeffs, "null pointer");
     GS_CHECK_ARG(degree <= 4, "degree must be <= 4");
     GS_CHECK_ARG((degree + 1) * (degree + 1) <= K, "K too small for degree");
     GS_CHECK_ARG(v_colors_stride >= 3, "v_colors_stride must be >= 3");
-    if (C == 0 || N == 0) return 0;
     dim3 grid(gs_div_up(N, GS_BLOCK));
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K) && rows_vectorizable(v_coeffs, K);

@@ -279,3 +279,36 @@ def test_full_size_linearity_determinism_and_adjoint():
     lhs = float((rg.detach().double() * W.double()).sum())
     rhs = float((cg.grad.double() * c1.double()).sum())
     assert abs(lhs - rhs) <= 1e-4 * abs(lhs), (lhs, rhs)
+
+
+def test_degenerate_inputs_do_not_crash():
+    """Zero splats, nothing visible (packed and unpacked), image sizes that are not multiples of the tile size, odd tile
+    sizes, a single splat: shapes are right, everything is finite, empty scenes render (background) zeros."""
+    from gscodec_studio_amd import rasterization
+
+    fx = garden(500, scale_mult=5.0)
+    W, H = 100, 70
+    V, K = T(fx["viewmats"][:2]), T(fx["Ks"][:2]).clone()
+    K[:, :2] *= W / fx["width"]
+    m, q, s, o, c = (T(fx[k]) for k in ("means", "quats", "scales", "opacities", "rgb"))
+
+    def run(means, quats, scales, opac, colors, **kw):
+        ps = [t.clone().requires_grad_(True) for t in (means, quats, scales, opac, colors)]
+        rc, ra, meta = rasterization(*ps, V, K, W, H, **kw)
+        (rc.sum() + ra.sum()).backward()
+        return rc, ra, meta, ps
+
+    for packed in (False, True):
+        rc, ra, meta, ps = run(m + 1000.0, q, s, o, c, packed=packed)  # everything behind the cameras
+        assert meta["flatten_ids"].numel() == 0 and float(ra.abs().max()) == 0.0 and float(rc.abs().max()) == 0.0
+        assert all(float(p.grad.abs().max()) == 0.0 for p in ps)
+    z = lambda *sh: torch.zeros(*sh, device="cuda")  # noqa: E731
+    rc, ra, meta, ps = run(z(0, 3), z(0, 4), z(0, 3), z(0), z(0, 3), packed=False)
+    assert rc.shape == (2, H, W, 3) and float(ra.abs().max()) == 0.0
+    bg = torch.rand(2, 3, device="cuda")
+    for ts in (8, 12, 16):
+        rc, ra, meta, ps = run(m, q, s, o, c, packed=False, tile_size=ts, backgrounds=bg, absgrad=True, render_mode="RGB+ED")
+        assert rc.shape == (2, H, W, 4) and bool(torch.isfinite(rc).all()) and meta["means2d"].absgrad.shape == (2, 500, 2)
+        assert all(bool(torch.isfinite(p.grad).all()) for p in ps)
+    rc, ra, meta, ps = run(m[:1], q[:1], s[:1] * 5, o[:1], torch.rand(1, 1, 3, device="cuda"), packed=False, sh_degree=0)
+    assert bool(torch.isfinite(rc).all())
