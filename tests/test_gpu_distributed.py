@@ -1,0 +1,66 @@
+"""RCCL path (needs >= 2 GPUs; skipped on the 1-GPU test boxes): camera-sharded rendering on 2 ranks + the copy-free
+gradient exchange reproduce the single-process batch, and the collectives of the gaussian-sharded mode run over RCCL.
+The same logic is covered on CPU with gloo in tests/test_distributed_cpu.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from util import garden, garden_sh
+
+        from gscodec_studio_amd import distributed as D
+        from gscodec_studio_amd import rasterization
+
+        fx = garden(3000, scale_mult=5.0)
+        dev = torch.device("cuda", rank)
+        t = lambda a: torch.tensor(a, device=dev)  # noqa: E731
+        names = ("means", "quats", "scales", "opacities")
+        params = {k: t(fx[k]).requires_grad_(True) for k in names}
+        params["sh"] = t(garden_sh(fx["rgb"], K=16)).requires_grad_(True)
+        V, K = t(fx["viewmats"][:2]), t(fx["Ks"][:2])
+        rc, ra, meta, idx = D.rasterization_camera_sharded(params["means"], params["quats"], params["scales"], params["opacities"],
+                                                           params["sh"], V, K, fx["width"], fx["height"], sh_degree=3, packed=False)
+        assert idx == [rank]
+        rc.sum().backward()
+        D.all_reduce_splat_grads(params, average=False)  # "direct" on RCCL: reduce_scatter + all_gather on the SH tensor
+        ref = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+        rr, _, _ = rasterization(ref["means"], ref["quats"], ref["scales"], ref["opacities"], ref["sh"], V, K, fx["width"], fx["height"],
+                                 sh_degree=3, packed=False)
+        assert torch.allclose(rr[rank], rc[0], rtol=1e-5, atol=1e-6)
+        rr.sum().backward()
+        for k in params:
+            d = (params[k].grad - ref[k].grad).norm() / (ref[k].grad.norm() + 1e-12)
+            assert float(d) < 1e-4, (k, float(d))
+        assert D.all_gather_int32(world, rank + 10, device=dev) == [10, 11]
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL)")
+def test_camera_sharded_rccl_world2():
+    mp.spawn(_worker, args=(2, _free_port()), nprocs=2, join=True)
