@@ -40,10 +40,45 @@ def _backend_name() -> str:
     return str(dist.get_backend()).lower()
 
 
+def _single(world_size: int) -> bool:
+    """World-1 short cut of every collective; GS_DIST_FORCE_COLLECTIVES=1 disables it so that a one-rank run
+    still drives RCCL (used by the tests on single-GPU boxes)."""
+    return world_size == 1 and os.environ.get("GS_DIST_FORCE_COLLECTIVES", "0") != "1"
+
+
+def _staged(t: Tensor) -> bool:
+    """Device tensors under a host-only backend (gloo) are exchanged through host memory.  This is what lets the
+    world_size-2 tests run both ranks on the single GPU of a test box; RCCL never takes this route."""
+    return t.is_cuda and "nccl" not in _backend_name()
+
+
+def _all_gather_into(out: Tensor, inp: Tensor) -> None:
+    if _staged(inp):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu())
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp)
+
+
+def _all_reduce_sum(t: Tensor) -> None:
+    if _staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 def _all_to_all_single(out: Tensor, inp: Tensor, out_splits: List[int], in_splits: List[int]) -> None:
     """all_to_all_single with a P2P fallback for backends without it (gloo)."""
     if "nccl" in _backend_name():
         dist.all_to_all_single(out, inp, out_splits, in_splits)
+        return
+    if _staged(inp):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        _all_to_all_single(o, inp.cpu(), out_splits, in_splits)
+        out.copy_(o)
         return
     rank, world = dist.get_rank(), dist.get_world_size()
     in_chunks = list(inp.split(in_splits, dim=0))
@@ -87,7 +122,7 @@ class _AllGatherRows(torch.autograd.Function):
         world = dist.get_world_size()
         # concatenated form [world * N, ...] (accepted by both RCCL and gloo)
         out = data.new_empty((world * data.shape[0],) + tuple(data.shape[1:]))
-        dist.all_gather_into_tensor(out, data.contiguous())
+        _all_gather_into(out, data.contiguous())
         ctx.rows = data.shape[0]
         return out
 
@@ -95,7 +130,7 @@ class _AllGatherRows(torch.autograd.Function):
     def backward(ctx, v_out: Tensor):
         # d/d(local) = sum over ranks of their gradient for my slab
         v = v_out.contiguous().clone()
-        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        _all_reduce_sum(v)
         r = dist.get_rank()
         return v[r * ctx.rows : (r + 1) * ctx.rows]
 
@@ -107,7 +142,7 @@ def all_gather_int32(
     world_size: int, value: Union[int, Tensor], device: Optional[torch.device] = None
 ) -> List[Union[int, Tensor]]:
     """Gather a 32-bit integer from all ranks (reference distributed.py:10-52)."""
-    if world_size == 1:
+    if _single(world_size):
         return [value]
     if isinstance(value, int):
         assert device is not None, "device is required for scalar input"
@@ -115,7 +150,7 @@ def all_gather_int32(
     else:
         t = value.reshape(1)
     out = torch.empty(world_size, dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t)
+    _all_gather_into(out, t)
     return out.tolist() if isinstance(value, int) else list(out.unbind())
 
 
@@ -123,7 +158,7 @@ def all_to_all_int32(
     world_size: int, values: List[Union[int, Tensor]], device: Optional[torch.device] = None
 ) -> List[Union[int, Tensor]]:
     """Exchange one 32-bit integer with every rank (reference distributed.py:55-99)."""
-    if world_size == 1:
+    if _single(world_size):
         return values
     assert len(values) == world_size, "The length of values should be equal to world_size"
     scalar = any(isinstance(v, int) for v in values)
@@ -144,7 +179,7 @@ def all_gather_tensor_list(world_size: int, tensor_list: List[Tensor]) -> List[T
     Returns, for every input tensor of shape [N, *], the concatenation over ranks
     [world_size * N, *].  Differentiable.
     """
-    if world_size == 1:
+    if _single(world_size):
         return tensor_list
     N = len(tensor_list[0])
     for t in tensor_list:
@@ -155,7 +190,7 @@ def all_gather_tensor_list(world_size: int, tensor_list: List[Tensor]) -> List[T
         gathered = _AllGatherRows.apply(data)
     else:
         gathered = data.new_empty((world_size * N,) + tuple(data.shape[1:]))
-        dist.all_gather_into_tensor(gathered, data.contiguous())
+        _all_gather_into(gathered, data.contiguous())
     gathered = gathered.reshape(world_size * N, -1)
     outs = torch.split(gathered, sizes, dim=-1)
     return [o.reshape(-1, *t.shape[1:]) for o, t in zip(outs, tensor_list)]
@@ -168,7 +203,7 @@ def all_to_all_tensor_list(
     output_splits: Optional[List[Union[int, Tensor]]] = None,
 ) -> List[Tensor]:
     """Split every tensor along dim 0 by ``splits`` and exchange (reference distributed.py:170-257)."""
-    if world_size == 1:
+    if _single(world_size):
         return tensor_list
     N = len(tensor_list[0])
     for t in tensor_list:
@@ -325,7 +360,7 @@ def all_reduce_splat_grads(
         world_size = dist.get_world_size() if dist.is_initialized() else 1
     plist = list(params.values()) if isinstance(params, dict) else list(params)
     plist = [p for p in plist if p.requires_grad]
-    if world_size == 1 or not plist:
+    if _single(world_size) or not plist:
         return
     if algorithm == "auto":
         algorithm = os.environ.get("GS_DP_ALGO", "direct" if "nccl" in _backend_name() else "all_reduce")
@@ -346,7 +381,7 @@ def all_reduce_splat_grads(
                     shard.mul_(scale)
                 dist.all_gather_into_tensor(flat, shard)
             else:
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                _all_reduce_sum(flat)
                 if average:
                     flat.mul_(scale)
             if g is not p.grad:
@@ -365,7 +400,7 @@ def all_reduce_splat_grads(
         dist.all_gather_into_tensor(bucket, shard)
         bucket = bucket[:n]
     elif algorithm == "all_reduce":
-        dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+        _all_reduce_sum(bucket)
         if average:
             bucket.mul_(1.0 / world_size)
     else:
@@ -378,7 +413,8 @@ def all_reduce_splat_grads(
             p.grad.copy_(g)
 
 
-_DIRECT_RS_AG_MIN_BYTES = 8 << 20  # below this an in-place all_reduce (latency-bound anyway)
+# below this an in-place all_reduce (latency-bound anyway); GS_DP_RS_AG_MIN_BYTES overrides (tests)
+_DIRECT_RS_AG_MIN_BYTES = int(os.environ.get("GS_DP_RS_AG_MIN_BYTES", 8 << 20))
 
 
 # ---------------------------------------------------------------------------

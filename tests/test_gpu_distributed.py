@@ -1,8 +1,18 @@
-"""RCCL path (needs >= 2 GPUs; skipped on the 1-GPU test boxes): camera-sharded rendering on 2 ranks + the copy-free
-gradient exchange reproduce the single-process batch, and the collectives of the gaussian-sharded mode run over RCCL.
-The same logic is covered on CPU with gloo in tests/test_distributed_cpu.py."""
+"""Multi-rank rendering on the GPU, end to end through the HIP library.
+
+* camera-sharded data parallelism (north star): rank r renders camera r of a shared scene, the splat gradients are summed
+  over ranks, and the result equals the single-process 2-camera batch;
+* gaussian-sharded mode of the reference (``rasterization(distributed=True)``, reference rendering.py:279-478): every
+  rank owns a slice of the splats and one camera, the projected splats are exchanged both ways, and every rank ends up
+  with the image of ITS camera over ALL splats and the gradient of ITS slice summed over ALL cameras.
+
+With >= 2 GPUs the ranks use one GPU each over RCCL.  The test boxes have ONE GPU: there both ranks share cuda:0 and
+the exchanges go through host memory on gloo (RCCL refuses two ranks on one device), which still runs every kernel,
+the autograd plumbing and the regrouping logic of the two-rank path.  The world-1 variants run the RCCL set-up itself.
+"""
 import os
 import socket
+import sys
 
 import pytest
 import torch
@@ -20,53 +30,109 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port):
+def _setup(rank, world, port, backend):
+    if world == 1:  # drive RCCL even though there is nobody to talk to (see distributed._single)
+        os.environ["GS_DIST_FORCE_COLLECTIVES"] = "1"
+        os.environ["GS_DP_RS_AG_MIN_BYTES"] = "1024"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    dev_idx = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev_idx)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_idx))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    return torch.device("cuda", dev_idx)
+
+
+def _scene(dev, n_cameras):
+    from util import garden, garden_sh
+
+    fx = garden(3000, scale_mult=5.0)
+    t = lambda a: torch.tensor(a, device=dev)  # noqa: E731
+    params = {k: t(fx[k]) for k in ("means", "quats", "scales", "opacities")}
+    params["sh"] = t(garden_sh(fx["rgb"], K=16))
+    return params, t(fx["viewmats"][:n_cameras]), t(fx["Ks"][:n_cameras]), fx["width"], fx["height"]
+
+
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def _camera_sharded(rank, world, port, backend):
+    dev = _setup(rank, world, port, backend)
     try:
-        import sys
-
-        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-        from util import garden, garden_sh
-
         from gscodec_studio_amd import distributed as D
         from gscodec_studio_amd import rasterization
 
-        fx = garden(3000, scale_mult=5.0)
-        dev = torch.device("cuda", rank)
-        t = lambda a: torch.tensor(a, device=dev)  # noqa: E731
-        names = ("means", "quats", "scales", "opacities")
-        params = {k: t(fx[k]).requires_grad_(True) for k in names}
-        params["sh"] = t(garden_sh(fx["rgb"], K=16)).requires_grad_(True)
-        V, K = t(fx["viewmats"][:world]), t(fx["Ks"][:world])
+        base, V, K, W, H = _scene(dev, world)
+        params = {k: v.clone().requires_grad_(True) for k, v in base.items()}
         rc, ra, meta, idx = D.rasterization_camera_sharded(params["means"], params["quats"], params["scales"], params["opacities"],
-                                                           params["sh"], V, K, fx["width"], fx["height"], sh_degree=3, packed=False)
+                                                           params["sh"], V, K, W, H, sh_degree=3, packed=False)
         assert idx == [rank]
         rc.sum().backward()
         D.all_reduce_splat_grads(params, average=False)  # "direct" on RCCL: reduce_scatter + all_gather on the SH tensor
-        ref = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-        rr, _, _ = rasterization(ref["means"], ref["quats"], ref["scales"], ref["opacities"], ref["sh"], V, K, fx["width"], fx["height"],
+        ref = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        rr, _, _ = rasterization(ref["means"], ref["quats"], ref["scales"], ref["opacities"], ref["sh"], V, K, W, H,
                                  sh_degree=3, packed=False)
         assert torch.allclose(rr[rank], rc[0], rtol=1e-5, atol=1e-6)
         rr.sum().backward()
         for k in params:
-            d = (params[k].grad - ref[k].grad).norm() / (ref[k].grad.norm() + 1e-12)
-            assert float(d) < 1e-4, (k, float(d))
+            assert _rel(params[k].grad, ref[k].grad) < 1e-4, (k, _rel(params[k].grad, ref[k].grad))
         assert D.all_gather_int32(world, rank + 10, device=dev) == [10, 11][:world]
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL)")
-def test_camera_sharded_rccl_world2():
-    mp.spawn(_worker, args=(2, _free_port()), nprocs=2, join=True)
+def _gaussian_sharded(rank, world, port, backend, packed):
+    dev = _setup(rank, world, port, backend)
+    try:
+        from gscodec_studio_amd import rasterization
+
+        base, V, K, W, H = _scene(dev, world)
+        N = base["means"].shape[0]
+        cuts = [0, N // 3, N][: world + 1] if world == 2 else [0, N]  # unequal slices on purpose
+        sl = slice(cuts[rank], cuts[rank + 1])
+        mine = {k: v[sl].clone().requires_grad_(True) for k, v in base.items()}
+        rc, ra, meta = rasterization(mine["means"], mine["quats"], mine["scales"], mine["opacities"], mine["sh"],
+                                     V[rank: rank + 1], K[rank: rank + 1], W, H, sh_degree=3, packed=packed, distributed=True)
+        assert rc.shape == (1, H, W, 3)
+        # a per-camera weight so that a gradient routed to the wrong camera would show
+        (rc.sum() * (rank + 1.0)).backward()
+
+        ref = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        rr, ar, _ = rasterization(ref["means"], ref["quats"], ref["scales"], ref["opacities"], ref["sh"], V, K, W, H,
+                                  sh_degree=3, packed=packed)
+        assert torch.allclose(rr[rank], rc[0], rtol=1e-5, atol=1e-6), float((rr[rank] - rc[0]).abs().max())
+        assert torch.allclose(ar[rank], ra[0], rtol=1e-5, atol=1e-6)
+        sum(rr[c].sum() * (c + 1.0) for c in range(world)).backward()
+        for k in mine:
+            assert _rel(mine[k].grad, ref[k].grad[sl]) < 1e-4, (k, _rel(mine[k].grad, ref[k].grad[sl]))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _backend_for(world):
+    return "nccl" if torch.cuda.device_count() >= world else "gloo"
+
+
+def test_camera_sharded_world2():
+    mp.spawn(_camera_sharded, args=(2, _free_port(), _backend_for(2)), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_gaussian_sharded_world2(packed):
+    mp.spawn(_gaussian_sharded, args=(2, _free_port(), _backend_for(2), packed), nprocs=2, join=True)
 
 
 def test_camera_sharded_rccl_world1():
-    """Same worker on one rank: process-group set-up over RCCL, the sharded entry point and the collectives' plumbing
-    (the exchange itself degenerates to a no-op)."""
-    mp.spawn(_worker, args=(1, _free_port()), nprocs=1, join=True)
+    """Process-group set-up over RCCL, the sharded entry point and the collectives' plumbing on one rank."""
+    mp.spawn(_camera_sharded, args=(1, _free_port(), "nccl"), nprocs=1, join=True)
+
+
+def test_gaussian_sharded_rccl_world1():
+    mp.spawn(_gaussian_sharded, args=(1, _free_port(), "nccl", False), nprocs=1, join=True)
