@@ -7,10 +7,18 @@ one 1920x1080 camera per GPU, packed=False, near=0.01, far=1e10, radius_clip=0, 
 tile 16; a "step" is rasterization() forward + backward of sum(render_colors) (the protocol
 of the reference's profiling/main.py:104-133), inputs resident in HBM.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): camera-sharded weak scaling -- the
-splats are replicated, rank r renders camera r, and the step ends with the RCCL sum of the
-splat gradients (gscodec_studio_amd.distributed.all_reduce_splat_grads).  value counts
-splat-camera pairs: N_splats * n_gpus / step time.
+Multi-GPU (--gpus N, launched by torch.distributed.run): weak scaling over cameras, rank r
+renders camera r of an N-camera batch over the whole scene; value counts splat-camera pairs:
+N_splats * n_gpus / step time.  Two exchange patterns compute that batch (--dp-mode):
+  camera    splats replicated, no communication in the forward, the step ends with the RCCL sum
+            of the splat gradients (distributed.all_reduce_splat_grads; 236 B/splat);
+  gaussian  the reference's own multi-GPU layout (rasterization(distributed=True), reference
+            rendering.py:279-478): every rank owns 1/N of the splats, projects + colours them
+            for all N cameras, one all-to-all hands the projected splats to the camera's rank
+            (44 B per splat-camera pair) and its dual returns their gradients (40 B); every
+            rank ends with the gradient of its own splats, summed over all cameras.
+  auto      (default) times a few untimed steps of both and runs the faster one; the choice and
+            both calibration timings are reported in the JSON line.
 
 The JSON line carries two extra objects:
   roofline      the dominant kernel (largest average time per step among the C-ABI entry
@@ -69,6 +77,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scene-grid", type=int, default=1)
     ap.add_argument("--breakdown", action="store_true", help="print per-entry-point timings to stderr")
+    ap.add_argument("--dp-mode", choices=["auto", "camera", "gaussian"], default="auto",
+                    help="multi-GPU exchange pattern (see the module docstring); ignored with one GPU")
+    ap.add_argument("--calib-steps", type=int, default=5)
     return ap.parse_args()
 
 
@@ -173,8 +184,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # GS_BENCH_PG=1 / a forced mode: one GPU still goes through the process group and RCCL (debugging aid)
+    use_pg = world > 1 or args.dp_mode == "gaussian" or os.environ.get("GS_BENCH_PG") == "1"
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", world_size=world, rank=rank,
@@ -192,7 +206,7 @@ def main():
     w = sh_workload(scene_grid=args.scene_grid, width=args.width, height=args.height, n_cameras=world,
                     sh_degree=args.sh_degree, device=dev, camera_mode="jitter0")  # equal work per rank (weak scaling)
     N = w["N"]
-    params = {k: w[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "sh")}
+    names = ("means", "quats", "scales", "opacities", "sh")
     viewmats, Ks = w["viewmats"][rank: rank + 1].contiguous(), w["Ks"][rank: rank + 1].contiguous()
     sim = None
     if args.quantize:
@@ -202,25 +216,57 @@ def main():
 
     last_meta = {}
 
-    def step():
-        for p in params.values():
-            p.grad = None
-        if sim is not None:
-            q, _ = sim.simulate_compression({"scales": params["scales"], "quats": params["quats"]}, step=0)
-            quats, scales = q["quats"], q["scales"]
+    def make_step(mode):
+        """One fwd+bwd pass (+ the mode's exchange).  `camera`: all splats on every rank; `gaussian`: a contiguous
+        1/world slice of the same scene on every rank."""
+        if mode == "gaussian":
+            lo, hi = rank * N // world, (rank + 1) * N // world
+            params = {k: w[k][lo:hi].clone().requires_grad_(True) for k in names}
         else:
-            quats, scales = params["quats"], params["scales"]
-        rc, ra, meta = rasterization(params["means"], quats, scales, params["opacities"], params["sh"], viewmats, Ks,
-                                     w["width"], w["height"], sh_degree=args.sh_degree, packed=False)
-        rc.sum().backward()
-        if world > 1:
-            all_reduce_splat_grads(params, world_size=world, average=False)
-        last_meta.update(meta)
+            params = {k: w[k].clone().requires_grad_(True) for k in names}
+
+        def step():
+            for p in params.values():
+                p.grad = None
+            if sim is not None:
+                q, _ = sim.simulate_compression({"scales": params["scales"], "quats": params["quats"]}, step=0)
+                quats, scales = q["quats"], q["scales"]
+            else:
+                quats, scales = params["quats"], params["scales"]
+            rc, ra, meta = rasterization(params["means"], quats, scales, params["opacities"], params["sh"], viewmats, Ks,
+                                         w["width"], w["height"], sh_degree=args.sh_degree, packed=False,
+                                         distributed=(mode == "gaussian"))
+            rc.sum().backward()
+            if mode == "camera" and use_pg:
+                all_reduce_splat_grads(params, world_size=world, average=False)
+            last_meta.update(meta)
+
+        return step
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # multi-GPU: pick the exchange pattern (untimed calibration; every rank sees the same max-over-ranks numbers)
+    mode, calib = ("camera" if args.dp_mode == "auto" else args.dp_mode), {}
+    if use_pg and args.dp_mode == "auto":
+        for m in ("camera", "gaussian"):
+            st = make_step(m)
+            for _ in range(2):
+                st()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.calib_steps):
+                st()
+            barrier()
+            dt = torch.tensor([(time.perf_counter() - t0) / args.calib_steps * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            calib[m] = float(dt.item())
+            del st
+            torch.cuda.empty_cache()
+        mode = min(calib, key=calib.get)
+    step = make_step(mode)
 
     for _ in range(args.warmup):
         step()
@@ -248,7 +294,7 @@ def main():
         t1 = time.perf_counter()
     dom_ms = float(np.mean(ct.totals_ms()[dominant]))
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_pg:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -270,7 +316,9 @@ def main():
                 "workload": f"BASELINE config 2: load_test_data(scene_grid={args.scene_grid}) -> {N} gaussians, "
                             f"SH degree {args.sh_degree}, {world}x1 camera {w['width']}x{w['height']}, packed=False, "
                             f"tile 16, fwd + bwd of sum(render)" + (", quantize hooks on" if args.quantize else ""),
-                "visible": stats["V"], "n_isects": stats["I"], "parallelism": f"camera-sharded dp{world}",
+                "visible": stats["V"], "n_isects": stats["I"], "parallelism": (f"camera-sharded dp{world}" + (", RCCL sum of splat gradients" if world > 1 else "")) if mode == "camera"
+                else f"gaussian-sharded x{world}, 1 camera per rank, all-to-all of projected splats + dual for gradients",
+                **({"dp_mode": mode, "dp_calibration_ms_per_step": calib} if use_pg else {}),
             },
             "roofline": {
                 "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -286,7 +334,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.sh_degree)
         print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

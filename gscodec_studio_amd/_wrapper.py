@@ -147,6 +147,57 @@ def _elem_strided(t: Tensor):
     return t.contiguous(), 1
 
 
+def _rows_table(parts, n_rows: int):
+    import ctypes
+
+    n = len(parts)
+    ptrs, widths, strides, keep = (ctypes.c_void_p * n)(), (ctypes.c_int32 * n)(), (ctypes.c_int64 * n)(), []
+    for k, (t, w) in enumerate(parts):
+        widths[k], strides[k], ptrs[k] = w, w, None
+        if t is None:
+            continue
+        if t.dtype == torch.int32:
+            t = t.view(torch.float32)
+        assert t.numel() == n_rows * w, (tuple(t.shape), n_rows, w)
+        if w == 1:
+            t, rs = _elem_strided(t if t.dim() == 2 else t.reshape(1, -1))
+        else:
+            t, rs = _row_strided(t, w)
+        keep.append(t)
+        ptrs[k], strides[k] = t.data_ptr(), rs
+    return n, ptrs, widths, strides, keep
+
+
+def rows_pack(parts, n_rows: int, like: Tensor) -> Tensor:
+    """Gather column blocks into wire rows: ``parts`` = [(tensor [..., w] fp32 / int32 (bit pattern) or None = zeros, w)];
+    returns [n_rows, sum(w)] fp32.  Column views of wider row-major buffers are read in place (gs_rows_pack)."""
+    _require_gpu(like, "rows_pack")
+    n, ptrs, widths, strides, keep = _rows_table(parts, n_rows)
+    wire = torch.empty((n_rows, sum(w for _, w in parts)), dtype=torch.float32, device=like.device)
+    import ctypes
+
+    with _device_of(like):
+        B.call("gs_rows_pack", n_rows, n, ctypes.addressof(ptrs), ctypes.addressof(widths), ctypes.addressof(strides), B.ptr(wire),
+               _stream(like))
+    return wire
+
+
+def rows_unpack(wire: Tensor, parts) -> None:
+    """Scatter wire rows [n_rows, sum(w)] into ``parts`` = [(contiguous destination tensor or None = skipped, w)]."""
+    _require_gpu(wire, "rows_unpack")
+    assert wire.is_contiguous() and wire.dtype == torch.float32
+    for t, _ in parts:
+        assert t is None or t.is_contiguous()
+    n_rows = wire.shape[0]
+    n, ptrs, widths, strides, keep = _rows_table(parts, n_rows)
+    assert sum(w for _, w in parts) == wire.shape[1]
+    import ctypes
+
+    with _device_of(wire):
+        B.call("gs_rows_unpack", n_rows, n, ctypes.addressof(ptrs), ctypes.addressof(widths), ctypes.addressof(strides), B.ptr(wire),
+               _stream(wire))
+
+
 def spherical_harmonics_view(
     degrees_to_use: int,
     means: Tensor,  # [N, 3]

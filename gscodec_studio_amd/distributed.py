@@ -154,6 +154,49 @@ def all_gather_int32(
     return out.tolist() if isinstance(value, int) else list(out.unbind())
 
 
+_HOST_GROUP = {}
+
+
+def _host_group():
+    """A gloo group next to the RCCL one, for exchanging HOST integers (shard sizes) without touching the GPU queue:
+    a device-side gather + read-back would make the host wait for the whole previous step before it can queue the
+    next one.  None when it cannot be created (then the device path is used)."""
+    key = id(dist.group.WORLD)
+    if key not in _HOST_GROUP:
+        g = None
+        if "nccl" in _backend_name() and os.environ.get("GS_DIST_HOST_GROUP", "1") == "1":
+            try:
+                g = dist.new_group(backend="gloo")
+            except Exception:  # noqa: BLE001 -- same outcome on every rank (same environment)
+                g = None
+        _HOST_GROUP[key] = g
+    return _HOST_GROUP[key]
+
+
+def gather_shard_meta(world_size: int, N: int, viewmats: Tensor, Ks: Tensor) -> Tuple[List[int], Tensor, Tensor]:
+    """What the gaussian-sharded mode needs from the other ranks before it can project (reference rendering.py:283-291:
+    three collectives and a read-back): the shard sizes and ALL cameras.  The sizes are host integers and travel over
+    the host group (no GPU synchronisation); the cameras take ONE device all-gather of [viewmats | Ks] per rank.
+    Returns (N_world, viewmats [C_total,4,4], Ks [C_total,3,3]); cameras carry no gradient here."""
+    C = viewmats.shape[0]
+    hg = _host_group()
+    cams = torch.cat([viewmats.detach().reshape(-1).float(), Ks.detach().reshape(-1).float()])
+    if hg is not None:
+        sizes = torch.empty(world_size, dtype=torch.int64)
+        dist.all_gather_into_tensor(sizes, torch.tensor([N], dtype=torch.int64), group=hg)
+        N_world = sizes.tolist()
+        buf = cams
+    else:
+        n = torch.tensor([N], dtype=torch.int32, device=viewmats.device).view(torch.float32)
+        buf = torch.cat([cams, n])
+    out = buf.new_empty((world_size, buf.numel()))
+    _all_gather_into(out.view(-1), buf)
+    if hg is None:
+        N_world = out[:, 25 * C].contiguous().view(torch.int32).tolist()
+    return (N_world, out[:, :16 * C].reshape(world_size * C, 4, 4).contiguous(),
+            out[:, 16 * C:25 * C].reshape(world_size * C, 3, 3).contiguous())
+
+
 def all_to_all_int32(
     world_size: int, values: List[Union[int, Tensor]], device: Optional[torch.device] = None
 ) -> List[Union[int, Tensor]]:
@@ -260,24 +303,91 @@ def exchange_projected(
         )
         return C_local, radii, means2d, depths, conics, opacities, colors, camera_ids, gaussian_ids
 
-    splits = [C_i * N for C_i in C_world]
-    out_splits = [C_local * N_i for N_i in N_world]
+    out = _ExchangeDense.apply(radii, means2d, depths, conics, opacities, colors, N, tuple(N_world), tuple(C_world), world_rank)
+    return (C_local,) + tuple(out) + (None, None)
 
-    def regroup(x: Tensor) -> Tensor:
-        # received rows are rank-major [(C_local * N_i) for each i]; make them [C_local, sum N_i, ...]
-        parts = x.split(out_splits, dim=0)
-        parts = [p.reshape(C_local, N_i, *p.shape[1:]) for p, N_i in zip(parts, N_world)]
-        return torch.cat(parts, dim=1)
 
-    (radii,) = all_to_all_tensor_list(world_size, [radii.flatten(0, 1)], splits, output_splits=out_splits)
-    means2d, depths, conics, opacities, colors = all_to_all_tensor_list(
-        world_size,
-        [means2d.flatten(0, 1), depths.flatten(0, 1), conics.flatten(0, 1), opacities.flatten(0, 1),
-         colors.flatten(0, 1)],
-        splits, output_splits=out_splits,
-    )
-    return (C_local, regroup(radii), regroup(means2d), regroup(depths), regroup(conics), regroup(opacities),
-            regroup(colors), None, None)
+def _pack_rows(parts, rows: int, like: Tensor) -> Tensor:
+    """[rows, sum(widths)] fp32 wire rows from column blocks (None = zeros; int32 travels as its bit pattern)."""
+    if like.is_cuda:
+        from ._wrapper import rows_pack
+
+        return rows_pack(parts, rows, like)
+    cols = []
+    for t, w in parts:
+        if t is None:
+            cols.append(like.new_zeros((rows, w), dtype=torch.float32))
+        else:
+            t = t.reshape(rows, w)
+            cols.append(t.view(torch.float32) if t.dtype == torch.int32 else t)
+    return torch.cat(cols, dim=1)
+
+
+def _unpack_rows(wire: Tensor, parts) -> None:
+    if wire.is_cuda:
+        from ._wrapper import rows_unpack
+
+        return rows_unpack(wire, parts)
+    off = 0
+    for t, w in parts:
+        src = wire[:, off:off + w]
+        t.copy_((src.contiguous().view(torch.int32) if t.dtype == torch.int32 else src).reshape(t.shape))
+        off += w
+
+
+_DENSE_WIDTHS = (1, 2, 1, 3, 1)  # radii (int32 bits) | means2d | depths | conics | opacities | then D colour channels
+
+
+class _ExchangeDense(torch.autograd.Function):
+    """The unpacked gaussian-sharded -> camera-sharded redistribution as ONE exchange each way.
+
+    Forward: the six per-(camera, gaussian) arrays [C_total, N_local, *] are packed into one [C_total * N_local, 8 + D]
+    fp32 row buffer (radii travel as their bit pattern), one all-to-all moves the rows of camera c to the rank that
+    renders it, and the rows come out as [C_local, N_total, *] (source ranks are gaussian-contiguous, so for one camera
+    per rank the received order already is the final one).  Backward: the five gradients are packed the same way, the
+    dual all-to-all returns them, and they are handed on as column views of the received buffer (the projection / SH
+    backward kernels read strided rows; nothing is unpacked)."""
+
+    @staticmethod
+    def forward(ctx, radii, means2d, depths, conics, opacities, colors, N, N_world, C_world, rank):
+        ctx.set_materialize_grads(False)
+        C_total, C_local, D = sum(C_world), C_world[rank], colors.shape[-1]
+        rows = C_total * N
+        parts = [(radii, 1), (means2d, 2), (depths, 1), (conics, 3), (opacities, 1), (colors, D)]
+        send = _pack_rows(parts, rows, means2d)
+        in_splits = [c * N for c in C_world]
+        out_splits = [C_local * n for n in N_world]
+        recv = send.new_empty((sum(out_splits), send.shape[1]))
+        _all_to_all_single(recv, send, out_splits, in_splits)
+        N_total = sum(N_world)
+        if C_local != 1:  # rank-major [(C_local, N_i) per source rank] -> [C_local, N_total]
+            recv = torch.cat([p.view(C_local, n, -1) for p, n in zip(recv.split(out_splits, dim=0), N_world)], dim=1)
+        recv = recv.view(C_local * N_total, -1)
+        ctx.meta = (N, N_world, C_world, rank, D)
+        outs = [recv.new_empty((C_local, N_total) + ((w,) if k in (1, 3, 5) else ()), dtype=torch.int32 if k == 0 else torch.float32)
+                for k, w in enumerate(list(_DENSE_WIDTHS) + [D])]
+        _unpack_rows(recv, list(zip(outs, list(_DENSE_WIDTHS) + [D])))
+        radii_o = outs[0]
+        ctx.mark_non_differentiable(radii_o)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_opacities, v_colors):
+        N, N_world, C_world, rank, D = ctx.meta
+        C_total, C_local, N_total = sum(C_world), C_world[rank], sum(N_world)
+        ref = next(g for g in (v_means2d, v_conics, v_colors, v_opacities, v_depths) if g is not None)
+        v_recv = _pack_rows([(v_means2d, 2), (v_depths, 1), (v_conics, 3), (v_opacities, 1), (v_colors, D)], C_local * N_total, ref)
+        v_recv = v_recv.view(C_local, N_total, -1)  # [C_local, N_total, 7 + D]; absent gradients are zero columns
+        W = v_recv.shape[-1]
+        if C_local != 1:
+            v_recv = torch.cat([p.reshape(-1, W) for p in v_recv.split(list(N_world), dim=1)], dim=0)
+        v_recv = v_recv.view(C_local * N_total, W)
+        v_send = v_recv.new_empty((C_total * N, W))
+        _all_to_all_single(v_send, v_recv, [c * N for c in C_world], [C_local * n for n in N_world])
+        v = v_send.view(C_total, N, W)
+        g_m2, g_d, g_cn, g_op, g_col = v.split([2, 1, 3, 1, D], dim=-1)
+        # every rank renders with the same mode, so an absent depth gradient here is absent everywhere (its column is zeros)
+        return (None, g_m2, None if v_depths is None else g_d.squeeze(-1), g_cn, g_op.squeeze(-1), g_col, None, None, None, None)
 
 
 # ---------------------------------------------------------------------------

@@ -154,9 +154,12 @@ def rasterization(
         world_rank = torch.distributed.get_rank()
         world_size = torch.distributed.get_world_size()
         # gaussians are sharded over ranks; gather #gaussians and all cameras
-        N_world = D.all_gather_int32(world_size, N, device=device)
         C_world = [C] * world_size
-        viewmats, Ks = D.all_gather_tensor_list(world_size, [viewmats, Ks])
+        if viewmats.requires_grad or Ks.requires_grad:
+            N_world = D.all_gather_int32(world_size, N, device=device)
+            viewmats, Ks = D.all_gather_tensor_list(world_size, [viewmats, Ks])
+        else:
+            N_world, viewmats, Ks = D.gather_shard_meta(world_size, N, viewmats, Ks)
         C = len(viewmats)
 
     proj_results = fully_fused_projection(
@@ -174,7 +177,7 @@ def rasterization(
         camera_ids, gaussian_ids = None, None
         # classic mode + shared SH on the fused route: the per-view opacities ride along with the colour kernels
         # (written by the SH forward, summed over cameras by its backward) instead of `.repeat` + autograd's sum
-        opacity_rider = (compensations is None and sh_degree is not None and colors.dim() == 3 and not distributed
+        opacity_rider = (compensations is None and sh_degree is not None and colors.dim() == 3
                          and not viewmats.requires_grad and viewmats.is_cuda)
         opacities_n = opacities
         if not opacity_rider:

@@ -485,6 +485,21 @@ int32_t gs_temporal_slice_bwd(
     float *v_means, float *v_motion, float *v_quats, float *v_omega, float *v_opacities,
     float *v_trbf_center, float *v_trbf_scale, gs_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Row packing around the multi-GPU exchange of projected splats.  The gaussian-sharded mode of the reference
+ * (gsplat/rendering.py:397-478, gsplat/distributed.py:170-257) concatenates radii | means2d | depths | conics |
+ * opacities | colours with torch.cat before every all-to-all and splits them afterwards; these two replace the
+ * cat / split: gs_rows_pack gathers the column blocks of up to 8 row-major arrays of 4-byte elements (part k:
+ * device pointer parts[k] or NULL = zeros, widths[k] columns, row stride row_strides[k] elements, so column views
+ * of wider buffers are read in place) into wire rows of sum(widths) elements; gs_rows_unpack scatters wire rows
+ * back (NULL part = skipped).  parts / widths / row_strides are HOST arrays of n_parts entries. */
+int32_t gs_rows_pack(
+    uint64_t n_rows, int32_t n_parts, const void *const *parts, const int32_t *widths, const int64_t *row_strides,
+    void *wire, gs_stream_t stream);
+int32_t gs_rows_unpack(
+    uint64_t n_rows, int32_t n_parts, void *const *parts, const int32_t *widths, const int64_t *row_strides,
+    const void *wire, gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

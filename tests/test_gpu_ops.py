@@ -387,3 +387,28 @@ def test_rasterize_masks_tilesize_and_last_ids(ops):
         o_rc, o_ra, o_li, bl = O.rasterize_fwd(means2d, conics, cols, op, W, H, ts, offs, flat, return_borderline=True)
         rc, ra = ops.rasterize_to_pixels(T(means2d), T(conics), T(cols), T(op), W, H, ts, T(offs), T(flat))
         assert_close(N(rc)[bl == 0], o_rc[bl == 0], 1e-4, 2e-5, f"tile {ts}", max_bad_frac=1e-4)
+
+
+# --------------------------------------------------------------------------- exchange row packing
+@pytest.mark.parametrize("n_rows", [0, 1, 255, 256, 257, 70001])
+def test_rows_pack_unpack(n_rows):
+    """gs_rows_pack / gs_rows_unpack against torch.cat / column slices: dense parts, an int32 part travelling as its bit
+    pattern, a missing part (zeros), and parts that are column views of a wider buffer (read in place)."""
+    from gscodec_studio_amd._wrapper import rows_pack, rows_unpack
+
+    g = torch.Generator(device="cuda").manual_seed(n_rows)
+    radii = torch.randint(-5, 1000, (n_rows,), device="cuda", dtype=torch.int32, generator=g)
+    m2 = torch.randn(n_rows, 2, device="cuda", generator=g)
+    wide = torch.randn(n_rows, 16, device="cuda", generator=g)  # packed gradient rows: conic at 4..6, opacity at 10
+    conic, opac = wide[:, 4:7], wide[:, 10]
+    col = torch.randn(n_rows, 5, device="cuda", generator=g)
+    parts = [(radii, 1), (m2, 2), (None, 1), (conic, 3), (opac.reshape(1, -1), 1), (col, 5)]
+    wire = rows_pack(parts, n_rows, m2)
+    want = torch.cat([radii.view(torch.float32)[:, None], m2, torch.zeros(n_rows, 1, device="cuda"), conic, opac[:, None], col], dim=1)
+    assert wire.shape == (n_rows, 13)
+    assert torch.equal(wire.view(torch.int32), want.view(torch.int32))
+    outs = [torch.empty(n_rows, dtype=torch.int32, device="cuda"), torch.empty(n_rows, 2, device="cuda"), None,
+            torch.empty(n_rows, 3, device="cuda"), torch.empty(1, n_rows, device="cuda"), torch.empty(n_rows, 5, device="cuda")]
+    rows_unpack(wire, list(zip(outs, [1, 2, 1, 3, 1, 5])))
+    assert torch.equal(outs[0], radii) and torch.equal(outs[1], m2) and torch.equal(outs[3], conic)
+    assert torch.equal(outs[4][0], opac) and torch.equal(outs[5], col)
