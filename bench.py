@@ -190,6 +190,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node by contract; the host name may not resolve
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", world_size=world, rank=rank,
                                 device_id=torch.device("cuda", local_rank))
@@ -333,10 +334,12 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.sh_degree)
-        print(json.dumps(out))
     if use_pg:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)  # the last line of stdout, after any library banners
 
 
 if __name__ == "__main__":
