@@ -203,6 +203,28 @@ def test_isect_bit_exact_vs_reference_golden(ops, case):
         assert np.array_equal(N(flat_u), gd["a_flatten_ids_unsorted"])
 
 
+@pytest.mark.parametrize("C,tw,th,ts,n", [(5, 256, 256, 16, 20000), (1, 1024, 64, 4, 30000), (9, 3, 2, 16, 5000), (64, 8, 8, 16, 300),
+                                          (2, 2048, 1024, 16, 4000)])
+def test_isect_key_bit_budget(ops, C, tw, th, ts, n):
+    """The key layout at the ends of its range (reference isect_tiles.cu:155-159: tile_n_bits + cam_n_bits <= 32): up to
+    21 tile bits and 7 camera bits, i.e. one to three pair-sort passes and every split of the leading digit, bit-exact
+    against the oracle, with depth ties (stability) and splats hanging over the image border."""
+    rng = np.random.default_rng(C * 1000 + tw)
+    W, H = tw * ts, th * ts
+    means2d = (rng.random((C, n, 2), dtype=np.float32) * np.array([W + 40, H + 40], np.float32) - 20).astype(np.float32)
+    radii = rng.integers(0, 3 * ts, (C, n)).astype(np.int32)
+    radii[rng.random((C, n)) < 0.3] = 0
+    depths = np.round(rng.random((C, n), dtype=np.float32) * 8 + 0.5, 1).astype(np.float32)  # many exact ties
+    tpg, ids, flat = ops.isect_tiles(T(means2d), T(radii), T(depths), ts, tw, th)
+    offs = ops.isect_offset_encode(ids, C, tw, th)
+    o_tpg, o_ids, o_flat = O.isect_tiles(means2d, radii, depths, ts, tw, th)
+    o_offs = O.isect_offset_encode(o_ids, C, tw, th)
+    assert np.array_equal(N(tpg), o_tpg)
+    assert np.array_equal(N(ids), o_ids)
+    assert np.array_equal(N(flat), o_flat)
+    assert np.array_equal(N(offs), o_offs)
+
+
 def test_isect_packed_and_empty(ops):
     gd = golden("isect.npz")
     m, r, d = gd["b_means2d"], gd["b_radii"], gd["b_depths"]
