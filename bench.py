@@ -49,8 +49,8 @@ KERNEL_OF_ENTRY = {"gs_rasterize_bwd": "raster_seg_bwd_kernel", "gs_rasterize_fw
                    "gs_sh_view_bwd": "sh_bwd_kernel", "gs_sort_pairs_u64_i32": "sort_scatter_kernel"}
 
 
-def measured_traffic(entry, workload_key):
-    """HBM bytes per launch of the kernel behind `entry` from the committed PMC summary, or None."""
+def measured_pmc(entry, workload_key, field="traffic_bytes_per_launch"):
+    """A per-launch PMC figure of the kernel behind `entry` from the committed summary (HBM bytes by default), or None."""
     try:
         d = json.load(open(TRAFFIC_JSON))
         if d.get("workload_key") != workload_key:
@@ -58,10 +58,18 @@ def measured_traffic(entry, workload_key):
         frag = KERNEL_OF_ENTRY.get(entry)
         for name, v in d["kernels"].items():
             if frag and frag in name:
-                return v["traffic_bytes_per_launch"]
+                return v.get(field)
     except Exception:
         pass
     return None
+
+
+def measured_traffic(entry, workload_key):
+    return measured_pmc(entry, workload_key)
+
+
+# fp32 vector peak 157.3 TFLOP/s = 256 CU x 4 SIMD x 2.4 GHz x one wave64 instruction per 2 cycles (MI355X_MICROARCH.md)
+VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2
 
 
 def parse():
@@ -326,6 +334,13 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(dominant, f"grid{args.scene_grid}_{w['width']}x{w['height']}_sh{args.sh_degree}"),
                 "kernel_ms": dom_ms,
+                # the compositing kernels are VALU-issue bound, not HBM bound: SQ_INSTS_VALU per launch
+                # (committed PMC pass) over the live kernel time, against one wave64 VALU instruction per 2 cycles per SIMD
+                "valu": (lambda vi: None if vi is None else {
+                    "wave_instr_per_launch": vi, "achieved": vi / (dom_ms * 1e-3), "peak": VALU_PEAK_WAVE_INSTR_PER_S,
+                    "unit": "wave64 VALU instr/s", "frac": vi / (dom_ms * 1e-3) / VALU_PEAK_WAVE_INSTR_PER_S})(
+                    measured_pmc(dominant, f"grid{args.scene_grid}_{w['width']}x{w['height']}_sh{args.sh_degree}",
+                                 "valu_wave_instr_per_launch")),
                 "algorithmic_bytes": alg.get(dominant, 0),
                 "whole_step": {"algorithmic_bytes": total_alg, "achieved": total_alg / (ms_per_step * 1e-3) / 1e9,
                                "frac": total_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -1,6 +1,6 @@
 """Build profiles/r01_pmc_traffic.json from two rocprofv3 counter-collection CSVs (separate --pmc passes).
 
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [<sq_insts_valu.csv>]
 
 bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB, and FETCH_SIZE reports half of the
 fetched bytes on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
@@ -22,10 +22,13 @@ def load(path, counter):
 def main():
     fetch, write, out = sys.argv[1:4]
     f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
+    valu = load(sys.argv[4], "SQ_INSTS_VALU") if len(sys.argv) > 4 else {}
     kernels = {}
     for k in f:
         fk, wk = f[k], w.get(k, 0.0)
         kernels[k] = {"FETCH_SIZE_KB_avg": fk, "WRITE_SIZE_KB_avg": wk, "traffic_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
+        if k in valu:  # wave-level VALU instructions per launch (third pass: --pmc SQ_INSTS_VALU)
+            kernels[k]["valu_wave_instr_per_launch"] = valu[k]
     kernels = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"]))
     json.dump({
         "workload_key": "grid3_1920x1080_sh3",
