@@ -460,7 +460,11 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     // [0, pa.max_parts), dispatched first) AND the light tiles (the rest) so that both overlap.
     const int mode = (MODESET == 3) ? (blockIdx.x < pa.max_parts ? 1 : 0) : MODESET;
     const uint32_t bid = (MODESET == 3 && mode == 0) ? blockIdx.x - pa.max_parts : blockIdx.x;
-    __shared__ float4 s_rec[2][BATCH * REC];
+    // records of both buffers in ONE array + a null record (alpha = 0) that pads every list to a multiple of four
+    __shared__ float4 s_rec[2 * BATCH * REC + REC];
+    constexpr uint32_t NULL_REC_OFF = 2u * BATCH * REC * 16u; // byte offset of the null record
+    // per (buffer, sub-batch, quadrant): byte offsets (into s_rec) of the records that touch the quadrant, in list order
+    __shared__ __attribute__((aligned(8))) uint16_t s_list[2][4][4][72];
     __shared__ unsigned long long s_mask[2][4][4]; // [buffer][sub-batch (= staging wave)][quadrant]
     __shared__ uint32_t s_done[2][4];              // [buffer][quadrant]
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -472,6 +476,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     unsigned long long abl_bar = 0;
 #endif
     const uint32_t lx = lane & 7u, ly = lane >> 3;
+    if (tid < REC) s_rec[2 * BATCH * REC + tid] = make_float4(0.f, tid == 1 ? -__builtin_inff() : 0.f, 0.f, 0.f); // log2(opacity) = -inf
     uint32_t tile_slot, part_k = 0, part_slot = 0;
     if (mode == 0) {
         tile_slot = xcd_remap(bid, (MODESET == 3) ? gridDim.x - pa.max_parts : gridDim.x, a.xcd_group);
@@ -597,10 +602,22 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
                 if (CDIM > 1) c1 = st.col[CDIM > 1 ? 1 : 0];
                 if (CDIM > 2) c2 = st.col[CDIM > 2 ? 2 : 0];
                 if (CDIM > 3) c3 = st.col[CDIM > 3 ? 3 : 0];
-                float4 *r = &s_rec[buf][tid * REC];
+                float4 *r = &s_rec[(buf * BATCH + tid) * REC];
                 r[0] = make_float4(st.s.mx, st.s.my, -0.5f * LOG2E * st.s.ca, -LOG2E * st.s.cb);
                 r[1] = make_float4(-0.5f * LOG2E * st.s.cc, __log2f(st.s.opac), c0, c1);
                 if (CDIM > 2) r[2] = make_float4(c2, c3, 0.f, 0.f);
+            }
+            {
+                // compacted lists: a lone wave issues one instruction per ~5 cycles WHATEVER its kind, so the consumer
+                // must not spend a dozen scalar instructions per record on bit scans -- it reads ready-made offsets
+                const uint16_t my_off = (uint16_t)((buf * BATCH + tid) * REC * 16u);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[q], 0u));
+                    if ((m[q] >> lane) & 1ull) s_list[buf][w][q][below] = my_off;
+                    const uint32_t cnt = (uint32_t)__popcll(m[q]);
+                    if (lane < 3u && cnt + lane < ((cnt + 3u) & ~3u)) s_list[buf][w][q][cnt + lane] = (uint16_t)NULL_REC_OFF;
+                }
             }
             const bool wave_done = __all(done); // evaluated by all 64 lanes, before the branch
             if (lane == 0) {
@@ -631,6 +648,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
             qdone[0] = qdone[0] || d0; qdone[1] = qdone[1] || d1; qdone[2] = qdone[2] || d2; qdone[3] = qdone[3] || d3;
         }
         // ---- composite my quadrant over the four sub-batches
+        uint32_t cur_off = 0xffffffffu; // record offset of the last contributor inside this batch (none yet)
 #pragma unroll 1
         for (int sub = 0; sub < 4; ++sub) {
             const int32_t sb_start = batch_start + sub * GS_WAVE;
@@ -647,37 +665,35 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
 #if defined(GS_ABL) && GS_ABL == 9
             abl_evals += __popcll(m);
 #endif
-            const float4 *rec = &s_rec[buf][sub * GS_WAVE * REC];
             // FOUR records per iteration, in one basic block: a lone wave issues one instruction per
             // ~5 cycles and a record is a ~25-deep dependent chain, so one record at a time costs
             // ~390 cycles (measured) against ~40 instructions x 5 cycles of issue.  The four alpha
             // evaluations are independent; only T <- T - T a (one fma) is carried from record to record.
+            // The records come from the compacted list of this (sub-batch, quadrant), padded with null records
+            // (alpha = 0) to a multiple of four: no bit scan, no validity flags.
             // (No explicit prefetch of the next group: it cost 40 VGPRs, i.e. two waves per SIMD, and the
             // kernel's duration is rounds of workgroups x their lifetime, not the walk of one list.)
-#ifndef GS_FWD_G
-#define GS_FWD_G 4
-#endif
-            constexpr int G = GS_FWD_G;
-            while (m != 0ull) {
+            constexpr int G = 4;
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            const uint16_t *lst = &s_list[buf][sub][w][0];
+            uint2 pk_next = *reinterpret_cast<const uint2 *>(lst); // four 16-bit offsets, one broadcast read
+            for (uint32_t j = 0; j < cnt; j += G) {
                 float4 c0[G], c1[G];
                 float c2x[G], c2y[G]; // colours 2, 3 (only what CDIM needs is read)
-                int32_t idx[G];
-                bool rv[G];
+                uint32_t off[G];
                 {
-                    int t0 = 0;
+                    const uint2 pk = pk_next;
+                    pk_next = *reinterpret_cast<const uint2 *>(lst + j + G); // next group's offsets (row is 72 long: in bounds)
+                    off[0] = pk.x & 0xffffu; off[1] = pk.x >> 16; off[2] = pk.y & 0xffffu; off[3] = pk.y >> 16;
 #pragma unroll
-                    for (int g = 0; g < G; ++g) { // pop up to G set bits (wave-uniform); exhausted slots alias the first one, masked by rv
-                        rv[g] = m != 0ull;
-                        const int t = rv[g] ? __builtin_ctzll(m) : t0;
-                        if (g == 0) t0 = t;
-                        m &= m - 1;
-                        idx[g] = sb_start + t;
-                        c0[g] = rec[t * REC + 0];
-                        c1[g] = rec[t * REC + 1];
+                    for (int g = 0; g < G; ++g) {
+                        const float4 *r = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rec) + off[g]);
+                        c0[g] = r[0];
+                        c1[g] = r[1];
                         c2x[g] = c2y[g] = 0.f;
-                        if (CDIM == 3) c2x[g] = reinterpret_cast<const float *>(rec + t * REC + 2)[0];
+                        if (CDIM == 3) c2x[g] = reinterpret_cast<const float *>(r + 2)[0];
                         if (CDIM > 3) {
-                            const float2 v = reinterpret_cast<const float2 *>(rec + t * REC + 2)[0];
+                            const float2 v = reinterpret_cast<const float2 *>(r + 2)[0];
                             c2x[g] = v.x;
                             c2y[g] = v.y;
                         }
@@ -690,7 +706,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
                     const float dx = c0[g].x - px, dy = c0[g].y - py;
                     const float power = dx * (c0[g].z * dx + c0[g].w * dy) + c1[g].x * dy * dy; // = -sigma log2(e)
                     const float alpha = fminf(0.999f, __builtin_amdgcn_exp2f(power + c1[g].y));
-                    ok[g] = rv[g] && !(power > 0.f) && (alpha >= ALPHA_MIN);
+                    ok[g] = !(power > 0.f) && (alpha >= ALPHA_MIN);
                     a_eff[g] = ok[g] ? alpha : 0.f;
                 }
                 if (MODESET == 2) { // transmittance product only; frozen once it cannot matter any more
@@ -711,13 +727,15 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
                     if (CDIM > 1) out[CDIM > 1 ? 1 : 0] += c1[g].w * vis;
                     if (CDIM > 2) out[CDIM > 2 ? 2 : 0] += c2x[g] * vis;
                     if (CDIM > 3) out[CDIM > 3 ? 3 : 0] += c2y[g] * vis;
-                    cur = (live && ok[g]) ? idx[g] : cur;
+                    cur_off = (live && ok[g]) ? off[g] : cur_off;
                     done = done || stop;
                     T = next_T;
                 }
             }
             if (__all(done)) break;
         }
+        if (cur_off != 0xffffffffu) // offset -> list index: (offset / 16 - buffer base) / 3, exact for these small multiples of 3
+            cur = batch_start + (int32_t)((((cur_off >> 4) - buf * (uint32_t)(BATCH * REC)) * 43691u) >> 17);
     }
 
     if (CKPT && MODESET != 2 && n > 0) {
@@ -845,6 +863,12 @@ struct PartPlan { // host view of the depth-split scratch
     uint32_t max_parts, max_heavy;
 };
 
+// debug: extra dynamic LDS per workgroup (bytes) to cap the workgroups resident per CU (GS_FWD_LDS_PAD)
+static uint32_t fwd_lds_pad() {
+    const char *e = getenv("GS_FWD_LDS_PAD");
+    return e ? (uint32_t)atoi(e) : 0u;
+}
+
 template <int CDIM>
 void launch_tile_fwd(const RasterArgs &a, const int32_t *order, float *ckpt, int32_t seg, const PartPlan *plan, hipStream_t st) {
     const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;
@@ -852,7 +876,7 @@ void launch_tile_fwd(const RasterArgs &a, const int32_t *order, float *ckpt, int
     PartArgs none = {};
     if (plan == nullptr || ckpt == nullptr) {
         if (ckpt != nullptr)
-            hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true, 0>), grid, dim3(256), 0, st, a, order, ckpt, seg, none);
+            hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true, 0>), grid, dim3(256), fwd_lds_pad(), st, a, order, ckpt, seg, none);
         else
             hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, false, 0>), grid, dim3(256), 0, st, a, order, ckpt, seg, none);
         return;
