@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     __shared__ float4 s_rec[2 * BATCH * REC + REC];
     constexpr uint32_t NULL_REC_OFF = 2u * BATCH * REC * 16u; // byte offset of the null record
     // per (buffer, sub-batch, quadrant): byte offsets (into s_rec) of the records that touch the quadrant, in list order
-    __shared__ __attribute__((aligned(8))) uint16_t s_list[2][4][4][72];
+    __shared__ __attribute__((aligned(16))) uint32_t s_list[2][4][4][72];
     __shared__ unsigned long long s_mask[2][4][4]; // [buffer][sub-batch (= staging wave)][quadrant]
     __shared__ uint32_t s_done[2][4];              // [buffer][quadrant]
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
         qdone[q] = r.empty;
     }
 
-    float T = 1.f, Tkeep = 1.f, out[CDIM];
+    float T = 1.f, out[CDIM]; // T freezes at the stopping splat: it is the transmittance in front of it
     int32_t cur = (mode == 1) ? -1 : 0;
     bool done = !inside;
 #pragma unroll
@@ -529,7 +529,6 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     if (mode == 1) { // transmittance in front of this part = product of the earlier parts' products
         const uint32_t p = w * 64u + lane;
         for (uint32_t j = (uint32_t)part_k0; j < part_k; ++j) T *= pa.tpart[(size_t)(part_slot - (part_k - j)) * 256 + p];
-        Tkeep = T;
         done = done || (T <= 1e-4f); // cannot composite any more: the first valid splat would stop it
     }
 
@@ -575,7 +574,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     auto store_ckpt = [&]() {
         float *base = ckpt + (size_t)next_k * (CDIM + 1) * 256;
         const uint32_t p = w * 64u + lane;
-        base[p] = done ? Tkeep : T;
+        base[p] = T;
 #pragma unroll
         for (int k = 0; k < CDIM; ++k) base[(k + 1) * 256 + p] = out[k];
     };
@@ -610,13 +609,13 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
             {
                 // compacted lists: a lone wave issues one instruction per ~5 cycles WHATEVER its kind, so the consumer
                 // must not spend a dozen scalar instructions per record on bit scans -- it reads ready-made offsets
-                const uint16_t my_off = (uint16_t)((buf * BATCH + tid) * REC * 16u);
+                const uint32_t my_off = (buf * BATCH + tid) * REC * 16u;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[q], 0u));
                     if ((m[q] >> lane) & 1ull) s_list[buf][w][q][below] = my_off;
                     const uint32_t cnt = (uint32_t)__popcll(m[q]);
-                    if (lane < 3u && cnt + lane < ((cnt + 3u) & ~3u)) s_list[buf][w][q][cnt + lane] = (uint16_t)NULL_REC_OFF;
+                    if (lane < 3u && cnt + lane < ((cnt + 3u) & ~3u)) s_list[buf][w][q][cnt + lane] = NULL_REC_OFF;
                 }
             }
             const bool wave_done = __all(done); // evaluated by all 64 lanes, before the branch
@@ -675,16 +674,16 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
             // kernel's duration is rounds of workgroups x their lifetime, not the walk of one list.)
             constexpr int G = 4;
             const uint32_t cnt = (uint32_t)__popcll(m);
-            const uint16_t *lst = &s_list[buf][sub][w][0];
-            uint2 pk_next = *reinterpret_cast<const uint2 *>(lst); // four 16-bit offsets, one broadcast read
+            const uint32_t *lst = &s_list[buf][sub][w][0];
+            uint4 pk_next = *reinterpret_cast<const uint4 *>(lst); // four record offsets, one broadcast read
             for (uint32_t j = 0; j < cnt; j += G) {
                 float4 c0[G], c1[G];
                 float c2x[G], c2y[G]; // colours 2, 3 (only what CDIM needs is read)
                 uint32_t off[G];
                 {
-                    const uint2 pk = pk_next;
-                    pk_next = *reinterpret_cast<const uint2 *>(lst + j + G); // next group's offsets (row is 72 long: in bounds)
-                    off[0] = pk.x & 0xffffu; off[1] = pk.x >> 16; off[2] = pk.y & 0xffffu; off[3] = pk.y >> 16;
+                    const uint4 pk = pk_next;
+                    pk_next = *reinterpret_cast<const uint4 *>(lst + j + G); // next group's offsets (row is 72 long: in bounds)
+                    off[0] = pk.x; off[1] = pk.y; off[2] = pk.z; off[3] = pk.w;
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const float4 *r = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rec) + off[g]);
@@ -715,13 +714,14 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
                     done = done || (T <= 1e-4f);
                     continue;
                 }
+                // T is FROZEN at the stopping splat (= the transmittance in front of it, what the epilogue and the
+                // checkpoints need), so a live pixel always has T > 1e-4 and a rejected record (a_eff = 0) cannot stop it
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const float Tj = T;
-                    const float next_T = Tj - Tj * a_eff[g];      // the loop-carried chain: one fma
-                    const bool stop = ok[g] && (next_T <= 1e-4f); // exclusive stop
-                    const bool live = !done && !stop;             // this record is composited
-                    Tkeep = done ? Tkeep : Tj;                    // transmittance before the stopping splat
+                    const float next_T = Tj - Tj * a_eff[g];
+                    const bool stop = next_T <= 1e-4f;  // exclusive stop
+                    const bool live = !done && !stop;   // this record is composited (or rejected: a_eff = 0)
                     const float vis = live ? a_eff[g] * Tj : 0.f;
                     out[0] += c1[g].z * vis;
                     if (CDIM > 1) out[CDIM > 1 ? 1 : 0] += c1[g].w * vis;
@@ -729,7 +729,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
                     if (CDIM > 3) out[CDIM > 3 ? 3 : 0] += c2y[g] * vis;
                     cur_off = (live && ok[g]) ? off[g] : cur_off;
                     done = done || stop;
-                    T = next_T;
+                    T = live ? next_T : Tj;
                 }
             }
             if (__all(done)) break;
@@ -752,14 +752,14 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     }
     if (mode == 1) {
         const size_t p = (size_t)part_slot * 256 + w * 64u + lane;
-        pa.tend[p] = done ? -Tkeep : T;
+        pa.tend[p] = done ? -T : T;
         pa.curp[p] = cur;
 #pragma unroll
         for (int k = 0; k < CDIM; ++k) pa.cpart[((size_t)part_slot * CDIM + k) * 256 + w * 64u + lane] = out[k];
         return;
     }
     if (inside) {
-        const float Tf = done ? Tkeep : T;
+        const float Tf = T;
         a.render_alphas[pix] = 1.f - Tf;
 #pragma unroll
         for (int k = 0; k < CDIM; ++k) a.render_colors[pix * CDIM + k] = bg ? out[k] + Tf * bg[k] : out[k];
