@@ -464,7 +464,12 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     __shared__ float4 s_rec[2 * BATCH * REC + REC];
     constexpr uint32_t NULL_REC_OFF = 2u * BATCH * REC * 16u; // byte offset of the null record
     // per (buffer, sub-batch, quadrant): byte offsets (into s_rec) of the records that touch the quadrant, in list order
-    __shared__ __attribute__((aligned(16))) uint32_t s_list[2][4][4][72];
+#ifdef GS_FWD_L32
+    typedef uint32_t list_t; // (measured: 34 KB of LDS = 4 workgroups per CU, 0.252 ms against 0.244 ms)
+#else
+    typedef uint16_t list_t; // 16-bit entries keep the workgroup under 32 KB of LDS (5 per CU) for one extraction per record
+#endif
+    __shared__ __attribute__((aligned(16))) list_t s_list[2][4][4][72];
     __shared__ unsigned long long s_mask[2][4][4]; // [buffer][sub-batch (= staging wave)][quadrant]
     __shared__ uint32_t s_done[2][4];              // [buffer][quadrant]
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -613,9 +618,9 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[q], 0u));
-                    if ((m[q] >> lane) & 1ull) s_list[buf][w][q][below] = my_off;
+                    if ((m[q] >> lane) & 1ull) s_list[buf][w][q][below] = (list_t)my_off;
                     const uint32_t cnt = (uint32_t)__popcll(m[q]);
-                    if (lane < 3u && cnt + lane < ((cnt + 3u) & ~3u)) s_list[buf][w][q][cnt + lane] = NULL_REC_OFF;
+                    if (lane < 3u && cnt + lane < ((cnt + 3u) & ~3u)) s_list[buf][w][q][cnt + lane] = (list_t)NULL_REC_OFF;
                 }
             }
             const bool wave_done = __all(done); // evaluated by all 64 lanes, before the branch
@@ -672,18 +677,23 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
             // (alpha = 0) to a multiple of four: no bit scan, no validity flags.
             // (No explicit prefetch of the next group: it cost 40 VGPRs, i.e. two waves per SIMD, and the
             // kernel's duration is rounds of workgroups x their lifetime, not the walk of one list.)
-            constexpr int G = 4;
+#ifndef GS_FWD_G
+#define GS_FWD_G 4
+#endif
+            constexpr int G = GS_FWD_G; // 4 or 2 (lists are padded to a multiple of four either way)
+            struct alignas(sizeof(list_t) * G) Pack { list_t v[G]; };
             const uint32_t cnt = (uint32_t)__popcll(m);
-            const uint32_t *lst = &s_list[buf][sub][w][0];
-            uint4 pk_next = *reinterpret_cast<const uint4 *>(lst); // four record offsets, one broadcast read
+            const list_t *lst = &s_list[buf][sub][w][0];
+            Pack pk_next = *reinterpret_cast<const Pack *>(lst); // G record offsets, one broadcast read
             for (uint32_t j = 0; j < cnt; j += G) {
                 float4 c0[G], c1[G];
                 float c2x[G], c2y[G]; // colours 2, 3 (only what CDIM needs is read)
                 uint32_t off[G];
                 {
-                    const uint4 pk = pk_next;
-                    pk_next = *reinterpret_cast<const uint4 *>(lst + j + G); // next group's offsets (row is 72 long: in bounds)
-                    off[0] = pk.x; off[1] = pk.y; off[2] = pk.z; off[3] = pk.w;
+                    const Pack pk = pk_next;
+                    pk_next = *reinterpret_cast<const Pack *>(lst + j + G); // next group's offsets (row is 72 long: in bounds)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) off[g] = pk.v[g];
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const float4 *r = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rec) + off[g]);
