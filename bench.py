@@ -199,9 +199,16 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node by contract; the host name may not resolve
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", world_size=world, rank=rank,
-                                device_id=torch.device("cuda", local_rank))
+        if os.environ.get("GS_BENCH_SHARE_GPU") == "1":
+            # debugging aid for 1-GPU boxes: all ranks on cuda:0, exchanges through host memory on gloo (RCCL refuses two
+            # ranks on one device) -- exercises the N > 1 control flow, says nothing about its speed
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo", world_size=world, rank=rank)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", world_size=world, rank=rank,
+                                    device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -252,6 +259,13 @@ def main():
 
         return step
 
+    def max_over_ranks(x):
+        if not use_pg:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     def barrier():
         if use_pg:
             dist.barrier()
@@ -269,9 +283,7 @@ def main():
             for _ in range(args.calib_steps):
                 st()
             barrier()
-            dt = torch.tensor([(time.perf_counter() - t0) / args.calib_steps * 1e3], dtype=torch.float64, device=dev)
-            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-            calib[m] = float(dt.item())
+            calib[m] = max_over_ranks((time.perf_counter() - t0) / args.calib_steps * 1e3)
             del st
             torch.cuda.empty_cache()
         mode = min(calib, key=calib.get)
@@ -302,15 +314,15 @@ def main():
         barrier()
         t1 = time.perf_counter()
     dom_ms = float(np.mean(ct.totals_ms()[dominant]))
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if use_pg:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+    elapsed = max_over_ranks(t1 - t0)
     ms_per_step = elapsed / args.steps * 1e3
 
     if rank == 0:
         meta = last_meta
-        stats = dict(N=N, V=int((meta["radii"] > 0).sum()), I=int(meta["flatten_ids"].numel()),
+        # gaussian mode: meta["radii"] is the pre-exchange tensor (this rank's splats x all cameras, as in the reference);
+        # the splats visible in THIS rank's camera are the ones with tiles
+        vis = (meta["tiles_per_gauss"] > 0) if mode == "gaussian" else (meta["radii"] > 0)
+        stats = dict(N=N, V=int(vis.sum()), I=int(meta["flatten_ids"].numel()),
                      P=w["width"] * w["height"], T=meta["tile_width"] * meta["tile_height"], K=(args.sh_degree + 1) ** 2)
         alg = algorithmic_bytes(stats)
         achieved = alg.get(dominant, 0) / (dom_ms * 1e-3) / 1e9
