@@ -16,7 +16,8 @@ N_splats * n_gpus / step time.  Two exchange patterns compute that batch (--dp-m
             rendering.py:279-478): every rank owns 1/N of the splats, projects + colours them
             for all N cameras, one all-to-all hands the projected splats to the camera's rank
             (44 B per splat-camera pair) and its dual returns their gradients (40 B); every
-            rank ends with the gradient of its own splats, summed over all cameras.
+            rank ends with the gradient of its own splats, summed over all cameras.  Only the
+            rows of visible splats travel (gaussian_dense: all rows, no count read-back).
   auto      (default) times a few untimed steps of both and runs the faster one; the choice and
             both calibration timings are reported in the JSON line.
 
@@ -85,7 +86,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scene-grid", type=int, default=1)
     ap.add_argument("--breakdown", action="store_true", help="print per-entry-point timings to stderr")
-    ap.add_argument("--dp-mode", choices=["auto", "camera", "gaussian"], default="auto",
+    ap.add_argument("--dp-mode", choices=["auto", "camera", "gaussian", "gaussian_dense"], default="auto",
                     help="multi-GPU exchange pattern (see the module docstring); ignored with one GPU")
     ap.add_argument("--calib-steps", type=int, default=5)
     return ap.parse_args()
@@ -193,7 +194,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # GS_BENCH_PG=1 / a forced mode: one GPU still goes through the process group and RCCL (debugging aid)
-    use_pg = world > 1 or args.dp_mode == "gaussian" or os.environ.get("GS_BENCH_PG") == "1"
+    use_pg = world > 1 or args.dp_mode.startswith("gaussian") or os.environ.get("GS_BENCH_PG") == "1"
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -235,7 +236,10 @@ def main():
     def make_step(mode):
         """One fwd+bwd pass (+ the mode's exchange).  `camera`: all splats on every rank; `gaussian`: a contiguous
         1/world slice of the same scene on every rank."""
-        if mode == "gaussian":
+        gaussian = mode.startswith("gaussian")
+        if gaussian:
+            # "gaussian": only the rows of visible splats travel; "gaussian_dense": every (camera, gaussian) row
+            os.environ["GS_DIST_SPARSE"] = "0" if mode == "gaussian_dense" else "1"
             lo, hi = rank * N // world, (rank + 1) * N // world
             params = {k: w[k][lo:hi].clone().requires_grad_(True) for k in names}
         else:
@@ -251,7 +255,7 @@ def main():
                 quats, scales = params["quats"], params["scales"]
             rc, ra, meta = rasterization(params["means"], quats, scales, params["opacities"], params["sh"], viewmats, Ks,
                                          w["width"], w["height"], sh_degree=args.sh_degree, packed=False,
-                                         distributed=(mode == "gaussian"))
+                                         distributed=gaussian)
             rc.sum().backward()
             if mode == "camera" and use_pg:
                 all_reduce_splat_grads(params, world_size=world, average=False)
@@ -274,7 +278,7 @@ def main():
     # multi-GPU: pick the exchange pattern (untimed calibration; every rank sees the same max-over-ranks numbers)
     mode, calib = ("camera" if args.dp_mode == "auto" else args.dp_mode), {}
     if use_pg and args.dp_mode == "auto":
-        for m in ("camera", "gaussian"):
+        for m in ("camera", "gaussian", "gaussian_dense"):
             st = make_step(m)
             for _ in range(2):
                 st()
@@ -321,7 +325,7 @@ def main():
         meta = last_meta
         # gaussian mode: meta["radii"] is the pre-exchange tensor (this rank's splats x all cameras, as in the reference);
         # the splats visible in THIS rank's camera are the ones with tiles
-        vis = (meta["tiles_per_gauss"] > 0) if mode == "gaussian" else (meta["radii"] > 0)
+        vis = (meta["tiles_per_gauss"] > 0) if mode.startswith("gaussian") else (meta["radii"] > 0)
         stats = dict(N=N, V=int(vis.sum()), I=int(meta["flatten_ids"].numel()),
                      P=w["width"] * w["height"], T=meta["tile_width"] * meta["tile_height"], K=(args.sh_degree + 1) ** 2)
         alg = algorithmic_bytes(stats)
@@ -338,7 +342,8 @@ def main():
                             f"SH degree {args.sh_degree}, {world}x1 camera {w['width']}x{w['height']}, packed=False, "
                             f"tile 16, fwd + bwd of sum(render)" + (", quantize hooks on" if args.quantize else ""),
                 "visible": stats["V"], "n_isects": stats["I"], "parallelism": (f"camera-sharded dp{world}" + (", RCCL sum of splat gradients" if world > 1 else "")) if mode == "camera"
-                else f"gaussian-sharded x{world}, 1 camera per rank, all-to-all of projected splats + dual for gradients",
+                else f"gaussian-sharded x{world}, 1 camera per rank, all-to-all of projected splats + dual for gradients"
+                     + (" (visible rows only)" if mode == "gaussian" else " (all rows)"),
                 **({"dp_mode": mode, "dp_calibration_ms_per_step": calib} if use_pg else {}),
             },
             "roofline": {

@@ -147,55 +147,101 @@ def _elem_strided(t: Tensor):
     return t.contiguous(), 1
 
 
-def _rows_table(parts, n_rows: int):
+def _rows_table(parts, n_rows: int, row_index=None):
+    """ctypes tables for gs_rows_*: parts = [(tensor | None, width[, indexed])].  An indexed part pairs wire row r with
+    ITS row row_index[r] (any number of rows); the others have exactly n_rows rows."""
     import ctypes
 
     n = len(parts)
-    ptrs, widths, strides, keep = (ctypes.c_void_p * n)(), (ctypes.c_int32 * n)(), (ctypes.c_int64 * n)(), []
-    for k, (t, w) in enumerate(parts):
-        widths[k], strides[k], ptrs[k] = w, w, None
+    ptrs, widths, strides = (ctypes.c_void_p * n)(), (ctypes.c_int32 * n)(), (ctypes.c_int64 * n)()
+    flags, keep = (ctypes.c_int32 * n)(), []
+    for k, part in enumerate(parts):
+        t, w = part[0], part[1]
+        indexed = bool(part[2]) if len(part) > 2 else False
+        widths[k], strides[k], ptrs[k], flags[k] = w, w, None, int(indexed)
         if t is None:
             continue
         if t.dtype == torch.int32:
             t = t.view(torch.float32)
-        assert t.numel() == n_rows * w, (tuple(t.shape), n_rows, w)
+        if not indexed:
+            assert t.numel() == n_rows * w, (tuple(t.shape), n_rows, w)
+        else:
+            assert row_index is not None and t.numel() % w == 0
         if w == 1:
             t, rs = _elem_strided(t if t.dim() == 2 else t.reshape(1, -1))
         else:
             t, rs = _row_strided(t, w)
         keep.append(t)
         ptrs[k], strides[k] = t.data_ptr(), rs
-    return n, ptrs, widths, strides, keep
+    return n, ptrs, widths, strides, flags, keep
 
 
-def rows_pack(parts, n_rows: int, like: Tensor) -> Tensor:
-    """Gather column blocks into wire rows: ``parts`` = [(tensor [..., w] fp32 / int32 (bit pattern) or None = zeros, w)];
-    returns [n_rows, sum(w)] fp32.  Column views of wider row-major buffers are read in place (gs_rows_pack)."""
+def _index_arg(row_index):
+    """(pointer, element stride) of an int32 index list: a contiguous [n] tensor or one column of a row-major buffer."""
+    if row_index is None:
+        return None, 1
+    assert row_index.dtype == torch.int32 and row_index.dim() == 1
+    return row_index.data_ptr(), int(row_index.stride(0)) if row_index.numel() > 1 else 1
+
+
+def rows_pack(parts, n_rows: int, like: Tensor, row_index: Optional[Tensor] = None) -> Tensor:
+    """Gather column blocks into wire rows: ``parts`` = [(tensor [..., w] fp32 / int32 (bit pattern) or None = zeros, w
+    [, indexed])]; returns [n_rows, sum(w)] fp32.  Column views of wider row-major buffers are read in place; with
+    ``row_index`` (int32 [n_rows]) the indexed parts are read at row ``row_index[r]`` (gs_rows_pack[_indexed])."""
     _require_gpu(like, "rows_pack")
-    n, ptrs, widths, strides, keep = _rows_table(parts, n_rows)
-    wire = torch.empty((n_rows, sum(w for _, w in parts)), dtype=torch.float32, device=like.device)
     import ctypes
 
+    n, ptrs, widths, strides, flags, keep = _rows_table(parts, n_rows, row_index)
+    wire = torch.empty((n_rows, sum(p[1] for p in parts)), dtype=torch.float32, device=like.device)
+    ip, istride = _index_arg(row_index)
     with _device_of(like):
-        B.call("gs_rows_pack", n_rows, n, ctypes.addressof(ptrs), ctypes.addressof(widths), ctypes.addressof(strides), B.ptr(wire),
-               _stream(like))
+        if row_index is None:
+            B.call("gs_rows_pack", n_rows, n, ctypes.addressof(ptrs), ctypes.addressof(widths), ctypes.addressof(strides),
+                   B.ptr(wire), _stream(like))
+        else:
+            B.call("gs_rows_pack_indexed", n_rows, n, ctypes.addressof(ptrs), ctypes.addressof(widths), ctypes.addressof(strides),
+                   ctypes.addressof(flags), ip, istride, B.ptr(wire), _stream(like))
     return wire
 
 
-def rows_unpack(wire: Tensor, parts) -> None:
-    """Scatter wire rows [n_rows, sum(w)] into ``parts`` = [(contiguous destination tensor or None = skipped, w)]."""
+def rows_unpack(wire: Tensor, parts, row_index: Optional[Tensor] = None) -> None:
+    """Scatter wire rows [n_rows, sum(w)] into ``parts`` = [(contiguous destination tensor or None = skipped, w[, indexed])];
+    indexed parts are written at row ``row_index[r]`` (``row_index`` may be an int32 column view of the wire itself)."""
     _require_gpu(wire, "rows_unpack")
     assert wire.is_contiguous() and wire.dtype == torch.float32
-    for t, _ in parts:
-        assert t is None or t.is_contiguous()
-    n_rows = wire.shape[0]
-    n, ptrs, widths, strides, keep = _rows_table(parts, n_rows)
-    assert sum(w for _, w in parts) == wire.shape[1]
+    for part in parts:
+        assert part[0] is None or part[0].is_contiguous()
     import ctypes
 
+    n_rows = wire.shape[0]
+    n, ptrs, widths, strides, flags, keep = _rows_table(parts, n_rows, row_index)
+    assert sum(p[1] for p in parts) == wire.shape[1]
+    ip, istride = _index_arg(row_index)
     with _device_of(wire):
-        B.call("gs_rows_unpack", n_rows, n, ctypes.addressof(ptrs), ctypes.addressof(widths), ctypes.addressof(strides), B.ptr(wire),
-               _stream(wire))
+        if row_index is None:
+            B.call("gs_rows_unpack", n_rows, n, ctypes.addressof(ptrs), ctypes.addressof(widths), ctypes.addressof(strides),
+                   B.ptr(wire), _stream(wire))
+        else:
+            B.call("gs_rows_unpack_indexed", n_rows, n, ctypes.addressof(ptrs), ctypes.addressof(widths), ctypes.addressof(strides),
+                   ctypes.addressof(flags), ip, istride, B.ptr(wire), _stream(wire))
+
+
+def exchange_compact(radii: Tensor, C_local: int, world: int, cap: int, N_total: int, N_off: int):
+    """Lists of the visible rows of ``radii`` [C_total, N] per destination rank (gs_exchange_compact): returns
+    (src_index i32 [world * (cap + 1)], hdr i32 [world * (cap + 1), 2], counters i32 [world], stats i32 [2])."""
+    _require_gpu(radii, "exchange_compact")
+    assert radii.dtype == torch.int32 and radii.is_contiguous() and radii.dim() == 2
+    C_total, N = radii.shape
+    rows = world * (cap + 1)
+    dev = radii.device
+    src_index = torch.empty(rows, dtype=torch.int32, device=dev)
+    hdr = torch.empty((rows, 2), dtype=torch.int32, device=dev)
+    counters = torch.empty(world, dtype=torch.int32, device=dev)
+    stats = torch.empty(2, dtype=torch.int32, device=dev)
+    with _device_of(radii):
+        B.call("gs_exchange_compact", C_total, N, C_local, world, cap, N_total, N_off, B.ptr(radii), B.ptr(src_index), B.ptr(hdr),
+               B.ptr(counters), B.ptr(stats), _stream(radii))
+    return src_index, hdr, counters, stats
 
 
 def spherical_harmonics_view(

@@ -22,16 +22,23 @@ struct RowParts {
     int32_t begin[MAX_PARTS + 1];  // first wire column of part k; begin[n] = wire width
     uint64_t inv[MAX_PARTS];  // floor(2^32 / width) + 1: j / width == (j * inv) >> 32 for the j < 2^14 used here
     int32_t n;
+    uint32_t indexed;  // bit k: part k's row is row_index[wire row], not the wire row itself
 };
 
 // One workgroup moves 256 rows through LDS: the wire side is one contiguous chunk (coalesced), and each part is
 // walked in its own element order, so a part whose rows are dense in memory is one contiguous chunk too.
 template <bool PACK>
-__global__ void __launch_bounds__(GS_BLOCK) rows_kernel(uint64_t n_rows, uint32_t width, RowParts t, uint32_t *__restrict__ wire) {
+__global__ void __launch_bounds__(GS_BLOCK) rows_kernel(uint64_t n_rows, uint32_t width, RowParts t, uint32_t *__restrict__ wire,
+                                                        const int32_t *__restrict__ row_index, int64_t index_stride) {
     extern __shared__ uint32_t tile[];  // [rows][width]
+    __shared__ int32_t s_index[ROWS_PER_BLOCK];
     const uint64_t row0 = (uint64_t)blockIdx.x * ROWS_PER_BLOCK;
     const uint32_t nr = (uint32_t)min((uint64_t)ROWS_PER_BLOCK, n_rows - row0);
     uint32_t *w0 = wire + row0 * width;
+    if (t.indexed != 0u) {
+        if (threadIdx.x < nr) s_index[threadIdx.x] = row_index[(int64_t)(row0 + threadIdx.x) * index_stride];
+        __syncthreads();
+    }
     if (!PACK) {
         for (uint32_t j = threadIdx.x; j < nr * width; j += GS_BLOCK) tile[j] = w0[j];
         __syncthreads();
@@ -42,13 +49,15 @@ __global__ void __launch_bounds__(GS_BLOCK) rows_kernel(uint64_t n_rows, uint32_
         const uint32_t b = (uint32_t)t.begin[k], w = (uint32_t)t.begin[k + 1] - b;
         const uint64_t inv = t.inv[k];
         const int64_t s = t.stride[k];
-        p += row0 * s;
+        const bool idx = (t.indexed >> k) & 1u;  // uniform
+        if (!idx && p != nullptr) p += row0 * s;
         for (uint32_t j = threadIdx.x; j < nr * w; j += GS_BLOCK) {
             const uint32_t r = (uint32_t)(((uint64_t)j * inv) >> 32), c = j - r * w;
+            const int64_t row = idx ? (int64_t)s_index[r] : (int64_t)r;  // a negative index = no row: zeros in, skipped out
             if (PACK)
-                tile[r * width + b + c] = p != nullptr ? p[(int64_t)r * s + c] : 0u;
-            else
-                p[(int64_t)r * s + c] = tile[r * width + b + c];
+                tile[r * width + b + c] = (p != nullptr && row >= 0) ? p[row * s + c] : 0u;
+            else if (row >= 0)
+                p[row * s + c] = tile[r * width + b + c];
         }
     }
     if (PACK) {
@@ -59,7 +68,7 @@ __global__ void __launch_bounds__(GS_BLOCK) rows_kernel(uint64_t n_rows, uint32_
 
 template <bool PACK>
 int32_t rows_launch(uint64_t n_rows, int32_t n_parts, void *const *parts, const int32_t *widths, const int64_t *strides, void *wire,
-                    gs_stream_t stream) {
+                    gs_stream_t stream, const int32_t *indexed = nullptr, const int32_t *row_index = nullptr, int64_t index_stride = 1) {
     GS_CHECK_ARG(n_parts >= 1 && n_parts <= MAX_PARTS, "between 1 and 8 parts");
     GS_CHECK_ARG(parts && widths && strides, "null table");
     RowParts t = {};
@@ -71,8 +80,10 @@ int32_t rows_launch(uint64_t n_rows, int32_t n_parts, void *const *parts, const 
         t.stride[k] = strides[k];
         t.begin[k] = w;
         t.inv[k] = (1ull << 32) / (uint64_t)widths[k] + 1ull;
+        if (indexed != nullptr && indexed[k] != 0) t.indexed |= 1u << k;
         w += widths[k];
     }
+    GS_CHECK_ARG(t.indexed == 0u || (row_index != nullptr && index_stride >= 1), "indexed parts need row_index");
     for (int k = n_parts; k <= MAX_PARTS; ++k) t.begin[k] = w;
     if (n_rows == 0) return 0;
     GS_CHECK_ARG(wire != nullptr, "null pointer");
@@ -80,12 +91,74 @@ int32_t rows_launch(uint64_t n_rows, int32_t n_parts, void *const *parts, const 
     const uint64_t blocks = (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     GS_CHECK_ARG(blocks < (1ull << 31), "too many rows");
     hipLaunchKernelGGL(rows_kernel<PACK>, dim3((uint32_t)blocks), dim3(GS_BLOCK), ROWS_PER_BLOCK * w * sizeof(uint32_t),
-                       (hipStream_t)stream, n_rows, (uint32_t)w, t, (uint32_t *)wire);
+                       (hipStream_t)stream, n_rows, (uint32_t)w, t, (uint32_t *)wire, row_index, index_stride);
     GS_CHECK_LAUNCH();
     return 0;
 }
 
+// Compaction of the visible (camera, gaussian) rows for the sparse exchange.  Destination rank d gets a chunk of `cap` row
+// slots plus one header row; slot order inside a chunk is arbitrary (the receiver scatters by the destination index).
+//   src_index[d * (cap + 1) + p]     = c * N + n                       (pre-filled with -1)
+//   hdr      [d * (cap + 1) + p]     = (destination row (c % C_local) * N_total + N_off + n, 0)   (pre-filled with -1)
+//   counters [d]                     = rows wanted by d (may exceed cap: then rows were dropped -> overflow)
+__global__ void __launch_bounds__(GS_BLOCK) exchange_compact_kernel(uint32_t N, uint32_t C_local, uint32_t cap, uint32_t N_total,
+                                                                    uint32_t N_off, const int32_t *__restrict__ radii,
+                                                                    int32_t *__restrict__ src_index, int2 *__restrict__ hdr,
+                                                                    uint32_t *__restrict__ counters) {
+    const uint32_t c = blockIdx.y, n = blockIdx.x * GS_BLOCK + threadIdx.x, d = c / C_local;  // d is block-uniform
+    const bool vis = n < N && radii[(size_t)c * N + n] > 0;
+    const unsigned long long m = __ballot(vis);
+    if (m == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[d], (uint32_t)__popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    const uint32_t p = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (vis && p < cap) {
+        const size_t o = (size_t)d * (cap + 1) + p;
+        src_index[o] = (int32_t)(c * N + n);
+        hdr[o] = make_int2((int32_t)((c % C_local) * N_total + N_off + n), 0);
+    }
+}
+
+// header row of every chunk: (-1, count | overflow << 30); stats[0] = max count, stats[1] = 1 if any chunk overflowed
+__global__ void exchange_header_kernel(uint32_t world, uint32_t cap, const uint32_t *__restrict__ counters, int2 *__restrict__ hdr,
+                                       uint32_t *__restrict__ stats) {
+    const uint32_t d = threadIdx.x;
+    if (d >= world) return;
+    const uint32_t cnt = counters[d], over = cnt > cap ? 1u : 0u;
+    hdr[(size_t)d * (cap + 1) + cap] = make_int2(-1, (int32_t)(min(cnt, cap) | (over << 30)));
+    atomicMax(&stats[0], cnt);
+    if (over) atomicMax(&stats[1], 1u);
+}
+
 }  // namespace
+
+extern "C" int32_t gs_exchange_compact(uint32_t C_total, uint32_t N, uint32_t C_local, uint32_t world, uint32_t cap, uint32_t N_total,
+                                       uint32_t N_off, const int32_t *radii, int32_t *src_index, int32_t *hdr, uint32_t *counters,
+                                       uint32_t *stats, gs_stream_t stream) {
+    GS_CHECK_ARG(C_local >= 1 && world >= 1 && C_total == C_local * world && world <= 1024, "C_total = C_local * world, world <= 1024");
+    GS_CHECK_ARG(src_index && hdr && counters && stats, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t rows = (size_t)world * (cap + 1);
+    hipError_t e = hipMemsetAsync(src_index, 0xff, rows * sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(hdr, 0xff, rows * 2 * sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, world * sizeof(uint32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(stats, 0, 2 * sizeof(uint32_t), st);
+    if (e != hipSuccess) {
+        gs_set_error("gs_exchange_compact: memset failed: %s", hipGetErrorString(e));
+        return 2;
+    }
+    if (N > 0) {
+        GS_CHECK_ARG(radii != nullptr, "null pointer");
+        hipLaunchKernelGGL(exchange_compact_kernel, dim3(gs_div_up(N, GS_BLOCK), C_total), dim3(GS_BLOCK), 0, st, N, C_local, cap, N_total,
+                           N_off, radii, src_index, (int2 *)hdr, counters);
+        GS_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(exchange_header_kernel, dim3(1), dim3(1024), 0, st, world, cap, counters, (int2 *)hdr, stats);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int32_t gs_rows_pack(uint64_t n_rows, int32_t n_parts, const void *const *parts, const int32_t *widths,
                                 const int64_t *row_strides, void *wire, gs_stream_t stream) {
@@ -95,4 +168,16 @@ extern "C" int32_t gs_rows_pack(uint64_t n_rows, int32_t n_parts, const void *co
 extern "C" int32_t gs_rows_unpack(uint64_t n_rows, int32_t n_parts, void *const *parts, const int32_t *widths,
                                   const int64_t *row_strides, const void *wire, gs_stream_t stream) {
     return rows_launch<false>(n_rows, n_parts, parts, widths, row_strides, (void *)wire, stream);
+}
+
+extern "C" int32_t gs_rows_pack_indexed(uint64_t n_rows, int32_t n_parts, const void *const *parts, const int32_t *widths,
+                                        const int64_t *row_strides, const int32_t *indexed, const int32_t *row_index,
+                                        int64_t index_stride, void *wire, gs_stream_t stream) {
+    return rows_launch<true>(n_rows, n_parts, (void *const *)parts, widths, row_strides, wire, stream, indexed, row_index, index_stride);
+}
+
+extern "C" int32_t gs_rows_unpack_indexed(uint64_t n_rows, int32_t n_parts, void *const *parts, const int32_t *widths,
+                                          const int64_t *row_strides, const int32_t *indexed, const int32_t *row_index,
+                                          int64_t index_stride, const void *wire, gs_stream_t stream) {
+    return rows_launch<false>(n_rows, n_parts, parts, widths, row_strides, (void *)wire, stream, indexed, row_index, index_stride);
 }

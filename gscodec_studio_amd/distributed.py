@@ -173,27 +173,30 @@ def _host_group():
     return _HOST_GROUP[key]
 
 
-def gather_shard_meta(world_size: int, N: int, viewmats: Tensor, Ks: Tensor) -> Tuple[List[int], Tensor, Tensor]:
+def gather_shard_meta(world_size: int, N: int, viewmats: Tensor, Ks: Tensor, cap: int = 0
+                      ) -> Tuple[List[int], List[int], Tensor, Tensor]:
     """What the gaussian-sharded mode needs from the other ranks before it can project (reference rendering.py:283-291:
-    three collectives and a read-back): the shard sizes and ALL cameras.  The sizes are host integers and travel over
+    three collectives and a read-back): the shard sizes and ALL cameras -- plus, for the sparse exchange, the chunk
+    capacity every rank is going to use (``cap``, see ``sparse_capacity``).  The integers are host values and travel over
     the host group (no GPU synchronisation); the cameras take ONE device all-gather of [viewmats | Ks] per rank.
-    Returns (N_world, viewmats [C_total,4,4], Ks [C_total,3,3]); cameras carry no gradient here."""
+    Returns (N_world, cap_world, viewmats [C_total,4,4], Ks [C_total,3,3]); cameras carry no gradient here."""
     C = viewmats.shape[0]
     hg = _host_group()
     cams = torch.cat([viewmats.detach().reshape(-1).float(), Ks.detach().reshape(-1).float()])
     if hg is not None:
-        sizes = torch.empty(world_size, dtype=torch.int64)
-        dist.all_gather_into_tensor(sizes, torch.tensor([N], dtype=torch.int64), group=hg)
-        N_world = sizes.tolist()
+        ints = torch.empty(2 * world_size, dtype=torch.int64)
+        dist.all_gather_into_tensor(ints, torch.tensor([N, cap], dtype=torch.int64), group=hg)
+        ints = ints.view(world_size, 2)
         buf = cams
     else:
-        n = torch.tensor([N], dtype=torch.int32, device=viewmats.device).view(torch.float32)
+        n = torch.tensor([N, cap], dtype=torch.int32, device=viewmats.device).view(torch.float32)
         buf = torch.cat([cams, n])
     out = buf.new_empty((world_size, buf.numel()))
     _all_gather_into(out.view(-1), buf)
     if hg is None:
-        N_world = out[:, 25 * C].contiguous().view(torch.int32).tolist()
-    return (N_world, out[:, :16 * C].reshape(world_size * C, 4, 4).contiguous(),
+        ints = out[:, 25 * C:25 * C + 2].contiguous().view(torch.int32)
+    N_world, cap_world = ints[:, 0].tolist(), ints[:, 1].tolist()
+    return (N_world, cap_world, out[:, :16 * C].reshape(world_size * C, 4, 4).contiguous(),
             out[:, 16 * C:25 * C].reshape(world_size * C, 3, 3).contiguous())
 
 
@@ -270,7 +273,7 @@ def all_to_all_tensor_list(
 def exchange_projected(
     world_rank: int, world_size: int, N: int, N_world: List[int], C_world: List[int], packed: bool,
     radii: Tensor, means2d: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor, colors: Tensor,
-    camera_ids: Optional[Tensor], gaussian_ids: Optional[Tensor],
+    camera_ids: Optional[Tensor], gaussian_ids: Optional[Tensor], cap_world: Optional[Sequence[int]] = None,
 ):
     """Gaussian-sharded -> camera-sharded redistribution (reference rendering.py:397-478).
 
@@ -303,35 +306,49 @@ def exchange_projected(
         )
         return C_local, radii, means2d, depths, conics, opacities, colors, camera_ids, gaussian_ids
 
-    out = _ExchangeDense.apply(radii, means2d, depths, conics, opacities, colors, N, tuple(N_world), tuple(C_world), world_rank)
+    if cap_world is not None and sparse_enabled(means2d, C_world):
+        out = _ExchangeSparse.apply(radii, means2d, depths, conics, opacities, colors, N, tuple(N_world), tuple(C_world), world_rank,
+                                    tuple(cap_world))
+    else:
+        out = _ExchangeDense.apply(radii, means2d, depths, conics, opacities, colors, N, tuple(N_world), tuple(C_world), world_rank)
     return (C_local,) + tuple(out) + (None, None)
 
 
-def _pack_rows(parts, rows: int, like: Tensor) -> Tensor:
-    """[rows, sum(widths)] fp32 wire rows from column blocks (None = zeros; int32 travels as its bit pattern)."""
+def _pack_rows(parts, rows: int, like: Tensor, row_index: Optional[Tensor] = None) -> Tensor:
+    """[rows, sum(widths)] fp32 wire rows from column blocks (None = zeros; int32 travels as its bit pattern; parts flagged
+    ``indexed`` are read at row ``row_index[r]``)."""
     if like.is_cuda:
         from ._wrapper import rows_pack
 
-        return rows_pack(parts, rows, like)
+        return rows_pack(parts, rows, like, row_index)
     cols = []
-    for t, w in parts:
+    for part in parts:
+        t, w = part[0], part[1]
         if t is None:
             cols.append(like.new_zeros((rows, w), dtype=torch.float32))
-        else:
-            t = t.reshape(rows, w)
-            cols.append(t.view(torch.float32) if t.dtype == torch.int32 else t)
+            continue
+        t = t.reshape(-1, w)
+        if len(part) > 2 and part[2]:
+            t = t[row_index.long()]
+        cols.append(t.view(torch.float32) if t.dtype == torch.int32 else t)
     return torch.cat(cols, dim=1)
 
 
-def _unpack_rows(wire: Tensor, parts) -> None:
+def _unpack_rows(wire: Tensor, parts, row_index: Optional[Tensor] = None) -> None:
     if wire.is_cuda:
         from ._wrapper import rows_unpack
 
-        return rows_unpack(wire, parts)
+        return rows_unpack(wire, parts, row_index)
     off = 0
-    for t, w in parts:
-        src = wire[:, off:off + w]
-        t.copy_((src.contiguous().view(torch.int32) if t.dtype == torch.int32 else src).reshape(t.shape))
+    for part in parts:
+        t, w = part[0], part[1]
+        if t is not None:
+            src = wire[:, off:off + w].contiguous()
+            src = src.view(torch.int32) if t.dtype == torch.int32 else src
+            if len(part) > 2 and part[2]:
+                t.view(-1, w)[row_index.long()] = src
+            else:
+                t.copy_(src.reshape(t.shape))
         off += w
 
 
@@ -388,6 +405,119 @@ class _ExchangeDense(torch.autograd.Function):
         g_m2, g_d, g_cn, g_op, g_col = v.split([2, 1, 3, 1, D], dim=-1)
         # every rank renders with the same mode, so an absent depth gradient here is absent everywhere (its column is zeros)
         return (None, g_m2, None if v_depths is None else g_d.squeeze(-1), g_cn, g_op.squeeze(-1), g_col, None, None, None, None)
+
+
+# state of the sparse exchange: the visible fraction seen so far (drives the chunk capacity) and the read-backs in flight
+_SPARSE: Dict[str, Any] = {"frac": 1.0, "stats": None, "overflow": None}
+_SPARSE_HEADROOM, _SPARSE_QUANTUM = 1.25, 1024
+
+
+def sparse_enabled(like: Tensor, C_world: Sequence[int]) -> bool:
+    return like.is_cuda and os.environ.get("GS_DIST_SPARSE", "1") == "1" and len(set(C_world)) == 1
+
+
+def sparse_capacity(C_local: int, N: int, full: bool = False) -> int:
+    """Row slots per destination chunk for the next sparse exchange of [C_local * world, N] rows: the largest visible
+    count of the previous exchange x 1.25 (everything on the first call).  No synchronisation: the previous step's
+    statistics were copied to pinned memory before its tile-count read-back, so they are complete by now."""
+    st = _SPARSE
+    if st["stats"] is not None:
+        pinned, ev, rows = st["stats"]
+        ev.synchronize()
+        if rows > 0:
+            st["frac"] = min(1.0, float(pinned[0]) / rows * _SPARSE_HEADROOM + 0.01)
+        st["stats"] = None
+    rows = C_local * N
+    if full or st["frac"] >= 1.0:
+        return rows
+    cap = -(-int(st["frac"] * rows) // _SPARSE_QUANTUM) * _SPARSE_QUANTUM
+    return max(min(cap, rows), min(rows, _SPARSE_QUANTUM))
+
+
+def exchange_overflowed() -> bool:
+    """True when some rank had more visible rows than its chunk capacity in the last sparse exchange (every rank sees the
+    same answer: the flags travel in the chunk headers).  Call after a host synchronisation that follows the exchange
+    (the tile-count read-back); the caller then repeats the exchange at full capacity."""
+    st = _SPARSE
+    if st["overflow"] is None:
+        return False
+    pinned, ev = st["overflow"]
+    ev.synchronize()
+    st["overflow"] = None
+    over = int(pinned[0]) != 0
+    if over:
+        st["frac"], st["stats"] = 1.0, None
+    return over
+
+
+_HDR_ROWS: Dict[Any, Tensor] = {}
+
+
+class _ExchangeSparse(torch.autograd.Function):
+    """`_ExchangeDense` with only the VISIBLE (camera, gaussian) rows on the wire (29 % of them at bench config 2), and
+    still no read-back: every rank sends one fixed-size chunk per destination, sized from the visible fraction of ITS
+    previous exchanges (the sizes travel with the shard sizes over the host group), and `gs_exchange_compact` fills the
+    chunk with the rows whose radii > 0.  A chunk ends with a header row carrying the real count and an overflow flag;
+    every receiver reads the headers of all chunks, so all ranks agree when some chunk was too small and repeat the
+    exchange at full capacity (`exchange_overflowed`).  The receiver still gets the reference's dense [C_local, N_total, *]
+    arrays: radii are zero wherever nothing arrived, the others are only defined where radii > 0 (as the reference leaves
+    them, SURVEY 8a' quirk 2).  Wire row: destination row | aux | radii | means2d | depths | conics | opacity | colours."""
+
+    @staticmethod
+    def forward(ctx, radii, means2d, depths, conics, opacities, colors, N, N_world, C_world, rank, cap_world):
+        from ._wrapper import exchange_compact
+
+        ctx.set_materialize_grads(False)
+        world = len(C_world)
+        C_total, C_local, D = sum(C_world), C_world[rank], colors.shape[-1]
+        N_total, N_off, cap = sum(N_world), sum(N_world[:rank]), int(cap_world[rank])
+        dev = means2d.device
+        src_index, hdr, counters, stats = exchange_compact(radii.contiguous(), C_local, world, cap, N_total, N_off)
+        rows = world * (cap + 1)
+        send = _pack_rows([(hdr, 2), (radii, 1, True), (means2d, 2, True), (depths, 1, True), (conics, 3, True),
+                           (opacities, 1, True), (colors, D, True)], rows, means2d, src_index)
+        send_splits = [cap + 1] * world
+        recv_splits = [int(c) + 1 for c in cap_world]
+        recv = send.new_empty((sum(recv_splits), send.shape[1]))
+        _all_to_all_single(recv, send, recv_splits, send_splits)
+        recv_i = recv.view(torch.int32)
+        dst_recv = recv_i[:, 0]  # a column of the wire: read in place, kept for the backward
+        outs = [torch.zeros((C_local, N_total), dtype=torch.int32, device=dev)]
+        outs += [torch.empty((C_local, N_total) + ((w,) if k in (0, 2, 4) else ()), dtype=torch.float32, device=dev)
+                 for k, w in enumerate([2, 1, 3, 1, D])]
+        _unpack_rows(recv, [(None, 2)] + [(o, w, True) for o, w in zip(outs, [1, 2, 1, 3, 1, D])], dst_recv)
+        # overflow flags of ALL senders (header rows of the received chunks) and my own statistics -> pinned memory
+        key = (tuple(recv_splits), dev)
+        if key not in _HDR_ROWS:
+            _HDR_ROWS[key] = (torch.tensor(recv_splits, dtype=torch.int64).cumsum(0) - 1).to(dev)
+        over = (recv_i[_HDR_ROWS[key], 1] >> 30).max().reshape(1)
+        if _SPARSE.get("pinned") is None:
+            _SPARSE["pinned"] = (torch.empty(1, dtype=torch.int32).pin_memory(), torch.empty(2, dtype=torch.int32).pin_memory())
+        p_over, p_stats = _SPARSE["pinned"]
+        p_over.copy_(over, non_blocking=True)
+        p_stats.copy_(stats, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        _SPARSE["overflow"], _SPARSE["stats"] = (p_over, ev), (p_stats, ev, C_local * N)
+        ctx.meta = (N, C_total, D, send_splits, recv_splits)
+        ctx.save_for_backward(src_index, dst_recv)
+        ctx.mark_non_differentiable(outs[0])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_opacities, v_colors):
+        N, C_total, D, send_splits, recv_splits = ctx.meta
+        src_index, dst_recv = ctx.saved_tensors
+        ref = next(g for g in (v_means2d, v_conics, v_colors, v_opacities, v_depths) if g is not None)
+        v_wire = _pack_rows([(v_means2d, 2, True), (v_depths, 1, True), (v_conics, 3, True), (v_opacities, 1, True),
+                             (v_colors, D, True)], int(dst_recv.numel()), ref, dst_recv)
+        W = v_wire.shape[1]
+        v_back = v_wire.new_empty((int(src_index.numel()), W))
+        _all_to_all_single(v_back, v_wire, send_splits, recv_splits)
+        v = v_back.new_zeros((C_total * N, W))  # rows that never left stay zero
+        _unpack_rows(v_back, [(v, W, True)], src_index)
+        g_m2, g_d, g_cn, g_op, g_col = v.view(C_total, N, W).split([2, 1, 3, 1, D], dim=-1)
+        return (None, g_m2, None if v_depths is None else g_d.squeeze(-1), g_cn, g_op.squeeze(-1), g_col) + (None,) * 5
 
 
 # ---------------------------------------------------------------------------

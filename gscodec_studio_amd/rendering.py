@@ -155,11 +155,16 @@ def rasterization(
         world_size = torch.distributed.get_world_size()
         # gaussians are sharded over ranks; gather #gaussians and all cameras
         C_world = [C] * world_size
+        cap_world = None  # chunk capacities of the sparse exchange (None: every row travels)
         if viewmats.requires_grad or Ks.requires_grad:
             N_world = D.all_gather_int32(world_size, N, device=device)
             viewmats, Ks = D.all_gather_tensor_list(world_size, [viewmats, Ks])
         else:
-            N_world, viewmats, Ks = D.gather_shard_meta(world_size, N, viewmats, Ks)
+            sparse = (not packed) and D.sparse_enabled(means, C_world)
+            N_world, cap_world, viewmats, Ks = D.gather_shard_meta(world_size, N, viewmats, Ks,
+                                                                   D.sparse_capacity(C, N) if sparse else 0)
+            if not sparse:
+                cap_world = None
         C = len(viewmats)
 
     proj_results = fully_fused_projection(
@@ -247,10 +252,20 @@ def rasterization(
     if distributed:
         from . import distributed as D
 
-        (C, radii, means2d, depths, conics, opacities, colors, camera_ids, gaussian_ids) = D.exchange_projected(
-            world_rank, world_size, N, N_world, C_world, packed, radii, means2d, depths, conics, opacities,
-            colors, camera_ids, gaussian_ids,
-        )
+        # redistribute, then bin.  The sparse exchange sizes its chunks from earlier steps without a read-back; should a
+        # chunk have been too small (every rank learns it at the tile-count read-back), repeat once at full capacity.
+        pre = (radii, means2d, depths, conics, opacities, colors, camera_ids, gaussian_ids)
+        for attempt in range(2):
+            (C, radii, means2d, depths, conics, opacities, colors, camera_ids, gaussian_ids) = D.exchange_projected(
+                world_rank, world_size, N, N_world, C_world, packed, *pre, cap_world=cap_world,
+            )
+            tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
+                means2d, radii, depths, tile_size, tile_width, tile_height,
+                packed=packed, n_cameras=C, camera_ids=camera_ids, gaussian_ids=gaussian_ids,
+            )
+            if cap_world is None or not D.exchange_overflowed():
+                break
+            cap_world = [C_world[r] * N_world[r] for r in range(world_size)]
 
     if render_mode in ["RGB+D", "RGB+ED"]:
         colors = torch.cat((colors, depths[..., None]), dim=-1)
@@ -263,7 +278,7 @@ def rasterization(
 
     if isect_state is not None:
         tiles_per_gauss, isect_ids, flatten_ids = isect_tiles_finish(isect_state)
-    else:
+    elif not distributed:
         tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
             means2d, radii, depths, tile_size, tile_width, tile_height,
             packed=packed, n_cameras=C, camera_ids=camera_ids, gaussian_ids=gaussian_ids,

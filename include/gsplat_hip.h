@@ -499,6 +499,25 @@ int32_t gs_rows_pack(
 int32_t gs_rows_unpack(
     uint64_t n_rows, int32_t n_parts, void *const *parts, const int32_t *widths, const int64_t *row_strides,
     const void *wire, gs_stream_t stream);
+/* Sparse form (only the rows of visible splats travel): wire row r pairs with row row_index[r * index_stride] of every
+ * part whose indexed[k] flag (HOST array) is non-zero, and with row r of the others -- a gather on the way in, a scatter
+ * on the way out.  row_index may alias a column of the wire itself (index_stride = wire width). */
+int32_t gs_rows_pack_indexed(
+    uint64_t n_rows, int32_t n_parts, const void *const *parts, const int32_t *widths, const int64_t *row_strides,
+    const int32_t *indexed, const int32_t *row_index, int64_t index_stride, void *wire, gs_stream_t stream);
+int32_t gs_rows_unpack_indexed(
+    uint64_t n_rows, int32_t n_parts, void *const *parts, const int32_t *widths, const int64_t *row_strides,
+    const int32_t *indexed, const int32_t *row_index, int64_t index_stride, const void *wire, gs_stream_t stream);
+/* Compaction for the sparse form of that exchange: the rows with radii > 0 of radii [C_total, N] are listed per
+ * destination rank d = c / C_local in a chunk of `cap` slots + 1 header row (slot order arbitrary):
+ * src_index [world * (cap + 1)] = c * N + n or -1; hdr [world * (cap + 1), 2] = (row in the receiver's [C_local * N_total]
+ * arrays, 0) or -1, header row = (-1, min(count, cap) | overflow << 30); counters [world] = rows wanted per destination;
+ * stats [2] = (largest count, any overflow).  Both index arrays feed gs_rows_pack_indexed (a negative index packs
+ * zeros / is skipped by gs_rows_unpack_indexed).  No read-back: `cap` comes from the caller's previous steps, and an
+ * overflow is visible to every receiver in the header rows. */
+int32_t gs_exchange_compact(
+    uint32_t C_total, uint32_t N, uint32_t C_local, uint32_t world, uint32_t cap, uint32_t N_total, uint32_t N_off,
+    const int32_t *radii, int32_t *src_index, int32_t *hdr, uint32_t *counters, uint32_t *stats, gs_stream_t stream);
 
 #ifdef __cplusplus
 }

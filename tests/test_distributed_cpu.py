@@ -24,8 +24,8 @@ def _worker(rank, world, port, fn_name):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         globals()[fn_name](rank, world)
-    finally:
         dist.barrier()
+    finally:  # (no barrier here: after an exception on one rank it would never return)
         dist.destroy_process_group()
 
 

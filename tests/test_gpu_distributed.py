@@ -82,12 +82,13 @@ def _camera_sharded(rank, world, port, backend):
         for k in params:
             assert _rel(params[k].grad, ref[k].grad) < 1e-4, (k, _rel(params[k].grad, ref[k].grad))
         assert D.all_gather_int32(world, rank + 10, device=dev) == [10, 11][:world]
-    finally:
         dist.barrier()
+    finally:  # (no barrier here: after an exception on one rank it would never return)
         dist.destroy_process_group()
 
 
-def _gaussian_sharded(rank, world, port, backend, packed):
+def _gaussian_sharded(rank, world, port, backend, packed, sparse=True):
+    os.environ["GS_DIST_SPARSE"] = "1" if sparse else "0"  # only the visible rows on the wire / every row
     dev = _setup(rank, world, port, backend)
     try:
         from gscodec_studio_amd import rasterization
@@ -111,9 +112,41 @@ def _gaussian_sharded(rank, world, port, backend, packed):
         sum(rr[c].sum() * (c + 1.0) for c in range(world)).backward()
         for k in mine:
             assert _rel(mine[k].grad, ref[k].grad[sl]) < 1e-4, (k, _rel(mine[k].grad, ref[k].grad[sl]))
-    finally:
+        if sparse and not packed:
+            from gscodec_studio_amd import distributed as D
+
+            # 2nd call: chunk capacity from the first call's statistics (1.25 x the visible fraction) -- same result
+            assert D._SPARSE["stats"] is not None
+            rc2, _, _ = rasterization(mine["means"], mine["quats"], mine["scales"], mine["opacities"], mine["sh"],
+                                      V[rank: rank + 1], K[rank: rank + 1], W, H, sh_degree=3, packed=False, distributed=True)
+            assert D._SPARSE["frac"] <= 1.0 and torch.equal(rc2, rc), (D._SPARSE["frac"], float((rc2 - rc).abs().max()))
+            # 3rd call: capacity forced far too small -> every rank sees the overflow flag and repeats at full capacity
+            D._SPARSE["frac"], D._SPARSE["stats"] = 0.01, None
+            for p in mine.values():
+                p.grad = None
+            rc3, _, _ = rasterization(mine["means"], mine["quats"], mine["scales"], mine["opacities"], mine["sh"],
+                                      V[rank: rank + 1], K[rank: rank + 1], W, H, sh_degree=3, packed=False, distributed=True)
+            assert torch.equal(rc3, rc) and D._SPARSE["frac"] == 1.0
+            (rc3.sum() * (rank + 1.0)).backward()
+            for k in mine:
+                assert _rel(mine[k].grad, ref[k].grad[sl]) < 1e-4, (k, "after overflow", _rel(mine[k].grad, ref[k].grad[sl]))
         dist.barrier()
+    finally:  # (no barrier here: after an exception on one rank it would never return)
         dist.destroy_process_group()
+
+
+def _spawn(fn, args, nprocs, deadline_s=150):
+    """mp.spawn with a deadline: a rank stuck in a collective (its peer died) must not hang the suite."""
+    import time
+
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    t0 = time.time()
+    while not ctx.join(timeout=2):
+        if time.time() - t0 > deadline_s:
+            for p in ctx.processes:
+                if p.is_alive():
+                    p.kill()
+            raise TimeoutError(f"{fn.__name__}: ranks still running after {deadline_s} s")
 
 
 def _backend_for(world):
@@ -121,18 +154,19 @@ def _backend_for(world):
 
 
 def test_camera_sharded_world2():
-    mp.spawn(_camera_sharded, args=(2, _free_port(), _backend_for(2)), nprocs=2, join=True)
+    _spawn(_camera_sharded, (2, _free_port(), _backend_for(2)), 2)
 
 
-@pytest.mark.parametrize("packed", [False, True])
-def test_gaussian_sharded_world2(packed):
-    mp.spawn(_gaussian_sharded, args=(2, _free_port(), _backend_for(2), packed), nprocs=2, join=True)
+@pytest.mark.parametrize("packed,sparse", [(False, True), (False, False), (True, True)])
+def test_gaussian_sharded_world2(packed, sparse):
+    _spawn(_gaussian_sharded, (2, _free_port(), _backend_for(2), packed, sparse), 2)
 
 
 def test_camera_sharded_rccl_world1():
     """Process-group set-up over RCCL, the sharded entry point and the collectives' plumbing on one rank."""
-    mp.spawn(_camera_sharded, args=(1, _free_port(), "nccl"), nprocs=1, join=True)
+    _spawn(_camera_sharded, (1, _free_port(), "nccl"), 1)
 
 
-def test_gaussian_sharded_rccl_world1():
-    mp.spawn(_gaussian_sharded, args=(1, _free_port(), "nccl", False), nprocs=1, join=True)
+@pytest.mark.parametrize("sparse", [True, False])
+def test_gaussian_sharded_rccl_world1(sparse):
+    _spawn(_gaussian_sharded, (1, _free_port(), "nccl", False, sparse), 1)

@@ -434,3 +434,30 @@ def test_rows_pack_unpack(n_rows):
     rows_unpack(wire, list(zip(outs, [1, 2, 1, 3, 1, 5])))
     assert torch.equal(outs[0], radii) and torch.equal(outs[1], m2) and torch.equal(outs[3], conic)
     assert torch.equal(outs[4][0], opac) and torch.equal(outs[5], col)
+
+
+def test_rows_pack_unpack_indexed():
+    """The sparse form: wire row r <-> row index[r] of the indexed parts (gather in, scatter out), dense parts unaffected,
+    and the index list may be a column of the wire itself."""
+    from gscodec_studio_amd._wrapper import rows_pack, rows_unpack
+
+    g = torch.Generator(device="cuda").manual_seed(7)
+    n_src, n_rows = 5000, 1777
+    idx = torch.randperm(n_src, device="cuda", generator=g)[:n_rows].to(torch.int32)
+    a = torch.randn(n_src, 3, device="cuda", generator=g)
+    wide = torch.randn(n_src, 16, device="cuda", generator=g)
+    b = wide[:, 10]  # one column of a wider buffer
+    r = torch.randint(0, 99, (n_src,), device="cuda", dtype=torch.int32, generator=g)
+    wire = rows_pack([(idx, 1), (a, 3, True), (b.reshape(1, -1), 1, True), (r, 1, True), (None, 2, True)], n_rows, a, idx)
+    li = idx.long()
+    want = torch.cat([idx.view(torch.float32)[:, None], a[li], b[li][:, None], r[li].view(torch.float32)[:, None],
+                      torch.zeros(n_rows, 2, device="cuda")], dim=1)
+    assert torch.equal(wire.view(torch.int32), want.view(torch.int32))
+    out_a = torch.full((n_src, 3), -1.0, device="cuda")
+    out_r = torch.zeros(n_src, dtype=torch.int32, device="cuda")
+    rows_unpack(wire, [(None, 1), (out_a, 3, True), (None, 1), (out_r, 1, True), (None, 2)], wire[:, 0].view(torch.int32))
+    ref_a = torch.full((n_src, 3), -1.0, device="cuda")
+    ref_a[li] = a[li]
+    ref_r = torch.zeros(n_src, dtype=torch.int32, device="cuda")
+    ref_r[li] = r[li]
+    assert torch.equal(out_a, ref_a) and torch.equal(out_r, ref_r)
