@@ -450,6 +450,7 @@ struct PartArgs {
     int32_t *curp;           // [slot][256]        MODE 1 out: last composited list index or -1
     int32_t plen, heavy_min; // heavy_min == 0: no depth split
     uint32_t max_parts;      // grid slots reserved for parts in the mixed launch
+    int32_t solo_min;        // whole tiles with at least this many entries run their four waves independently (0: never)
 };
 
 template <int CDIM, bool CKPT, int MODESET>
@@ -584,6 +585,140 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
         for (int k = 0; k < CDIM; ++k) base[(k + 1) * 256 + p] = out[k];
     };
 
+    // ---- the record walk of one (sub-batch, quadrant) list, shared by the cooperative and the solo path
+#ifndef GS_FWD_G
+#define GS_FWD_G 4
+#endif
+    constexpr int G = GS_FWD_G; // 4 or 2 (lists are padded to a multiple of four either way)
+    struct alignas(sizeof(list_t) * G) Pack { list_t v[G]; };
+    auto walk = [&](const list_t *lst, const uint32_t cnt, uint32_t &cur_off) {
+            // FOUR records per iteration, in one basic block: a lone wave issues one instruction per
+            // ~5 cycles and a record is a ~25-deep dependent chain, so one record at a time costs
+            // ~390 cycles (measured) against ~40 instructions x 5 cycles of issue.  The four alpha
+            // evaluations are independent; only T <- T - T a (one fma) is carried from record to record.
+            // The records come from the compacted list of this (sub-batch, quadrant), padded with null records
+            // (alpha = 0) to a multiple of four: no bit scan, no validity flags.
+            // (No explicit prefetch of the next group: it cost 40 VGPRs, i.e. two waves per SIMD, and the
+            // kernel's duration is rounds of workgroups x their lifetime, not the walk of one list.)
+            Pack pk_next = *reinterpret_cast<const Pack *>(lst); // G record offsets, one broadcast read
+            for (uint32_t j = 0; j < cnt; j += G) {
+                float4 c0[G], c1[G];
+                float c2x[G], c2y[G]; // colours 2, 3 (only what CDIM needs is read)
+                uint32_t off[G];
+                {
+                    const Pack pk = pk_next;
+                    pk_next = *reinterpret_cast<const Pack *>(lst + j + G); // next group's offsets (row is 72 long: in bounds)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) off[g] = pk.v[g];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const float4 *r = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rec) + off[g]);
+                        c0[g] = r[0];
+                        c1[g] = r[1];
+                        c2x[g] = c2y[g] = 0.f;
+                        if (CDIM == 3) c2x[g] = reinterpret_cast<const float *>(r + 2)[0];
+                        if (CDIM > 3) {
+                            const float2 v = reinterpret_cast<const float2 *>(r + 2)[0];
+                            c2x[g] = v.x;
+                            c2y[g] = v.y;
+                        }
+                    }
+                }
+                float a_eff[G];
+                bool ok[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float dx = c0[g].x - px, dy = c0[g].y - py;
+                    const float power = dx * (c0[g].z * dx + c0[g].w * dy) + c1[g].x * dy * dy; // = -sigma log2(e)
+                    const float alpha = fminf(0.999f, __builtin_amdgcn_exp2f(power + c1[g].y));
+                    ok[g] = !(power > 0.f) && (alpha >= ALPHA_MIN);
+                    a_eff[g] = ok[g] ? alpha : 0.f;
+                }
+                if (MODESET == 2) { // transmittance product only; frozen once it cannot matter any more
+#pragma unroll
+                    for (int g = 0; g < G; ++g) T = done ? T : T - T * a_eff[g];
+                    done = done || (T <= 1e-4f);
+                    continue;
+                }
+                // T is FROZEN at the stopping splat (= the transmittance in front of it, what the epilogue and the
+                // checkpoints need), so a live pixel always has T > 1e-4 and a rejected record (a_eff = 0) cannot stop it
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float Tj = T;
+                    const float next_T = Tj - Tj * a_eff[g];
+                    const bool stop = next_T <= 1e-4f;  // exclusive stop
+                    const bool live = !done && !stop;   // this record is composited (or rejected: a_eff = 0)
+                    const float vis = live ? a_eff[g] * Tj : 0.f;
+                    out[0] += c1[g].z * vis;
+                    if (CDIM > 1) out[CDIM > 1 ? 1 : 0] += c1[g].w * vis;
+                    if (CDIM > 2) out[CDIM > 2 ? 2 : 0] += c2x[g] * vis;
+                    if (CDIM > 3) out[CDIM > 3 ? 3 : 0] += c2y[g] * vis;
+                    cur_off = (live && ok[g]) ? off[g] : cur_off;
+                    done = done || stop;
+                    T = live ? next_T : Tj;
+                }
+            }
+    };
+
+    // ---- SOLO path for the longest lists.  A tile's lifetime under the cooperative scheme is the sum over its batches
+    // of the BUSIEST quadrant's work (the four waves meet at a barrier every 256 entries); the tiles with thousands of
+    // entries run alone at the end of the kernel and set its duration.  There every wave walks the whole list by itself,
+    // 64 entries at a time, culling against its own quadrant only: no barrier, its time is its own work, and a quadrant
+    // that is done leaves.  (4x the gathers for these tiles -- 18 % of the pairs at config 2.)
+    const bool solo = MODESET == 0 && pa.solo_min > 0 && n >= pa.solo_min;
+    if (solo) {
+        float rx0 = qx0[0], rx1 = qx1[0], ry0 = qy0[0], ry1 = qy1[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (w == (uint32_t)q) { rx0 = qx0[q]; rx1 = qx1[q]; ry0 = qy0[q]; ry1 = qy1[q]; }
+        const int32_t n_sb = (tg.range_end - base0 + GS_WAVE - 1) / GS_WAVE;
+        int32_t sid_cur = load_id(base0 + (int32_t)lane);
+        int32_t sid_nxt = load_id(base0 + GS_WAVE + (int32_t)lane);
+        Staged snx;
+        gather(sid_cur, snx);
+        __syncthreads(); // the null record (written by the first lanes of wave 0) is visible to every wave
+        for (int32_t sbi = 0; sbi < n_sb; ++sbi) {
+            const uint32_t buf = (uint32_t)sbi & 1u;
+            const int32_t sb_start = base0 + sbi * GS_WAVE;
+            const uint32_t slot = buf * BATCH + w * GS_WAVE + lane; // my record slot: the wave's own quarter of the buffer
+            unsigned long long m;
+            {
+                const Staged st = snx;
+                CullSplat cs;
+                const bool live = sid_cur >= 0 && cull_prepare(st.s, cs);
+                const bool touch = live && rect_touch(st.s, cs, rx0, rx1, ry0, ry1);
+                m = __ballot(touch);
+                if (touch) {
+                    float c0 = st.col[0], c1 = 0.f, c2 = 0.f, c3 = 0.f;
+                    if (CDIM > 1) c1 = st.col[CDIM > 1 ? 1 : 0];
+                    if (CDIM > 2) c2 = st.col[CDIM > 2 ? 2 : 0];
+                    if (CDIM > 3) c3 = st.col[CDIM > 3 ? 3 : 0];
+                    float4 *r = &s_rec[slot * REC];
+                    r[0] = make_float4(st.s.mx, st.s.my, -0.5f * LOG2E * st.s.ca, -LOG2E * st.s.cb);
+                    r[1] = make_float4(-0.5f * LOG2E * st.s.cc, __log2f(st.s.opac), c0, c1);
+                    if (CDIM > 2) r[2] = make_float4(c2, c3, 0.f, 0.f);
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    s_list[buf][w][w][below] = (list_t)(slot * REC * 16u);
+                }
+                const uint32_t cnt = (uint32_t)__popcll(m);
+                if (lane < 3u && cnt + lane < ((cnt + 3u) & ~3u)) s_list[buf][w][w][cnt + lane] = (list_t)NULL_REC_OFF;
+            }
+            sid_cur = sid_nxt;
+            if (sbi + 1 < n_sb) gather(sid_cur, snx);
+            sid_nxt = (sbi + 2 < n_sb) ? load_id(sb_start + 2 * GS_WAVE + (int32_t)lane) : -1;
+            __builtin_amdgcn_wave_barrier(); // (LDS operations of one wave complete in order)
+            if (CKPT && sb_start == next_b && next_b < tg.range_end) { // state before list entry next_b
+                store_ckpt();
+                next_b += seg;
+                next_k += 1;
+            }
+            if (m == 0ull) continue;
+            uint32_t cur_off = 0xffffffffu;
+            walk(&s_list[buf][w][w][0], (uint32_t)__popcll(m), cur_off);
+            if (cur_off != 0xffffffffu) cur = sb_start + (int32_t)(((((cur_off >> 4) * 43691u) >> 17)) & 63u);
+            if (__all(done)) break;
+        }
+    } else
     for (int32_t b = 0; b < num_batches; ++b) {
         const uint32_t buf = (uint32_t)b & 1u;
         const int32_t batch_start = base0 + b * BATCH;
@@ -669,79 +804,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
 #if defined(GS_ABL) && GS_ABL == 9
             abl_evals += __popcll(m);
 #endif
-            // FOUR records per iteration, in one basic block: a lone wave issues one instruction per
-            // ~5 cycles and a record is a ~25-deep dependent chain, so one record at a time costs
-            // ~390 cycles (measured) against ~40 instructions x 5 cycles of issue.  The four alpha
-            // evaluations are independent; only T <- T - T a (one fma) is carried from record to record.
-            // The records come from the compacted list of this (sub-batch, quadrant), padded with null records
-            // (alpha = 0) to a multiple of four: no bit scan, no validity flags.
-            // (No explicit prefetch of the next group: it cost 40 VGPRs, i.e. two waves per SIMD, and the
-            // kernel's duration is rounds of workgroups x their lifetime, not the walk of one list.)
-#ifndef GS_FWD_G
-#define GS_FWD_G 4
-#endif
-            constexpr int G = GS_FWD_G; // 4 or 2 (lists are padded to a multiple of four either way)
-            struct alignas(sizeof(list_t) * G) Pack { list_t v[G]; };
-            const uint32_t cnt = (uint32_t)__popcll(m);
-            const list_t *lst = &s_list[buf][sub][w][0];
-            Pack pk_next = *reinterpret_cast<const Pack *>(lst); // G record offsets, one broadcast read
-            for (uint32_t j = 0; j < cnt; j += G) {
-                float4 c0[G], c1[G];
-                float c2x[G], c2y[G]; // colours 2, 3 (only what CDIM needs is read)
-                uint32_t off[G];
-                {
-                    const Pack pk = pk_next;
-                    pk_next = *reinterpret_cast<const Pack *>(lst + j + G); // next group's offsets (row is 72 long: in bounds)
-#pragma unroll
-                    for (int g = 0; g < G; ++g) off[g] = pk.v[g];
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        const float4 *r = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rec) + off[g]);
-                        c0[g] = r[0];
-                        c1[g] = r[1];
-                        c2x[g] = c2y[g] = 0.f;
-                        if (CDIM == 3) c2x[g] = reinterpret_cast<const float *>(r + 2)[0];
-                        if (CDIM > 3) {
-                            const float2 v = reinterpret_cast<const float2 *>(r + 2)[0];
-                            c2x[g] = v.x;
-                            c2y[g] = v.y;
-                        }
-                    }
-                }
-                float a_eff[G];
-                bool ok[G];
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const float dx = c0[g].x - px, dy = c0[g].y - py;
-                    const float power = dx * (c0[g].z * dx + c0[g].w * dy) + c1[g].x * dy * dy; // = -sigma log2(e)
-                    const float alpha = fminf(0.999f, __builtin_amdgcn_exp2f(power + c1[g].y));
-                    ok[g] = !(power > 0.f) && (alpha >= ALPHA_MIN);
-                    a_eff[g] = ok[g] ? alpha : 0.f;
-                }
-                if (MODESET == 2) { // transmittance product only; frozen once it cannot matter any more
-#pragma unroll
-                    for (int g = 0; g < G; ++g) T = done ? T : T - T * a_eff[g];
-                    done = done || (T <= 1e-4f);
-                    continue;
-                }
-                // T is FROZEN at the stopping splat (= the transmittance in front of it, what the epilogue and the
-                // checkpoints need), so a live pixel always has T > 1e-4 and a rejected record (a_eff = 0) cannot stop it
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const float Tj = T;
-                    const float next_T = Tj - Tj * a_eff[g];
-                    const bool stop = next_T <= 1e-4f;  // exclusive stop
-                    const bool live = !done && !stop;   // this record is composited (or rejected: a_eff = 0)
-                    const float vis = live ? a_eff[g] * Tj : 0.f;
-                    out[0] += c1[g].z * vis;
-                    if (CDIM > 1) out[CDIM > 1 ? 1 : 0] += c1[g].w * vis;
-                    if (CDIM > 2) out[CDIM > 2 ? 2 : 0] += c2x[g] * vis;
-                    if (CDIM > 3) out[CDIM > 3 ? 3 : 0] += c2y[g] * vis;
-                    cur_off = (live && ok[g]) ? off[g] : cur_off;
-                    done = done || stop;
-                    T = live ? next_T : Tj;
-                }
-            }
+            walk(&s_list[buf][sub][w][0], (uint32_t)__popcll(m), cur_off);
             if (__all(done)) break;
         }
         if (cur_off != 0xffffffffu) // offset -> list index: (offset / 16 - buffer base) / 3, exact for these small multiples of 3
@@ -884,6 +947,10 @@ void launch_tile_fwd(const RasterArgs &a, const int32_t *order, float *ckpt, int
     const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;
     dim3 grid(n_tiles_all);
     PartArgs none = {};
+    {
+        const char *e = getenv("GS_RASTER_SOLO"); // debug / A-B: list length from which a tile's waves stop cooperating
+        none.solo_min = e ? atoi(e) : 2048;
+    }
     if (plan == nullptr || ckpt == nullptr) {
         if (ckpt != nullptr)
             hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true, 0>), grid, dim3(256), fwd_lds_pad(), st, a, order, ckpt, seg, none);

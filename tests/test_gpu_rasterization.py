@@ -252,6 +252,36 @@ def test_depth_split_forward_matches_undivided(monkeypatch):
         assert rel_l2(a, b) < 2e-4, (name, rel_l2(a, b))
 
 
+def test_solo_waves_match_cooperative_tiles(monkeypatch):
+    """Long lists are composited by four independent waves (each walks the whole list and culls against its own quadrant)
+    instead of the cooperative workgroup (GS_RASTER_SOLO = list length from which that happens, 2048 by default).  Same
+    records in the same order with the same arithmetic: images, alphas, last ids (through the gradients) and the
+    checkpoints the backward restarts from must be IDENTICAL, with and without backgrounds, for a mix of both kinds."""
+    from gscodec_studio_amd import rasterization
+
+    d = _inputs(n=4000, cams=2, sh_degree=None, scale_mult=12.0)
+
+    def run(bg):
+        ps = [T(d[k]).requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")]
+        rc, ra, meta = rasterization(*ps, T(d["viewmats"]), T(d["Ks"]), d["W"], d["H"], packed=False, backgrounds=bg)
+        w = torch.linspace(0.5, 1.5, rc.numel(), device="cuda").reshape(rc.shape)
+        ((rc * w).sum() + 0.3 * ra.sum()).backward()
+        return N(rc), N(ra), [N(p.grad) for p in ps], meta
+
+    for bg in (None, torch.tensor([[0.2, 0.4, 0.6], [0.1, 0.1, 0.9]], device="cuda")):
+        monkeypatch.setenv("GS_RASTER_SOLO", "0")  # every tile cooperative
+        rc0, ra0, g0, meta = run(bg)
+        offs = N(meta["isect_offsets"]).reshape(-1)
+        lens = np.diff(np.concatenate([offs, [meta["flatten_ids"].numel()]]))
+        for thr in (1, int(np.median(lens[lens > 0]))):  # every tile solo / about half of them
+            monkeypatch.setenv("GS_RASTER_SOLO", str(thr))
+            rc1, ra1, g1, _ = run(bg)
+            assert np.array_equal(rc1, rc0) and np.array_equal(ra1, ra0), thr
+            for a, b, name in zip(g1, g0, ("means", "quats", "scales", "opacities", "colors")):
+                assert rel_l2(a, b) < 2e-5, (thr, name, rel_l2(a, b))  # (float atomics: the summation order varies run to run)
+    monkeypatch.delenv("GS_RASTER_SOLO")
+
+
 def test_full_size_linearity_determinism_and_adjoint():
     """BASELINE config 2 size, post-activation colours [N,3]: the forward is bit-reproducible (no atomics), exactly
     linear in the colours (same weights), and the backward is its adjoint: <W, render(c)> == <v_colors(W), c>."""
