@@ -196,6 +196,7 @@ GS_DEV Rect wave_rect(const RasterArgs &a, const TileGeom &tg, uint32_t q_first)
 #ifdef GS_ABL
 __device__ unsigned long long g_abl_stats[16];
 __device__ unsigned long long g_abl_wave[65536 * 4];
+__device__ unsigned long long g_abl_bwave[65536 * 2]; // backward work items: (start, end) wall clock
 #endif
 template <int NQ, int CDIM, bool COLOR_LDS, bool CKPT>
 __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, const int32_t *__restrict__ order, uint32_t cnt, uint32_t ch_off, float *__restrict__ ckpt, int32_t seg) {
@@ -1313,6 +1314,9 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
     __shared__ float4 s_acc[GS_WAVE * ACC];
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
+#if defined(GS_ABL) && (GS_ABL == 9 || GS_ABL == 8)
+    const unsigned long long abl_bt0 = wall_clock64();
+#endif
     const uint32_t n_work = *sg.n_items; // the grid is an upper bound
     if (blockIdx.x >= n_work) return;
     const uint2 it = sg.items[xcd_remap(blockIdx.x, n_work, a.xcd_group)];
@@ -1595,6 +1599,12 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
         }
         __builtin_amdgcn_wave_barrier();
     }
+#if defined(GS_ABL) && (GS_ABL == 9 || GS_ABL == 8)
+    if (lane == 0 && blockIdx.x < 65536u) {
+        g_abl_bwave[blockIdx.x * 2 + 0] = abl_bt0;
+        g_abl_bwave[blockIdx.x * 2 + 1] = wall_clock64();
+    }
+#endif
 }
 
 // segmented launch: one wave per (tile, segment) item, 4 pixels per lane
@@ -1719,6 +1729,9 @@ ScratchLayout scratch_layout(uint32_t n_tiles_all, uint32_t n_isects, uint32_t c
 #ifdef GS_ABL
 extern "C" void gs_debug_abl_waves(unsigned long long *out) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_abl_wave), sizeof(unsigned long long) * 65536 * 4);
+}
+extern "C" void gs_debug_abl_bwaves(unsigned long long *out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_abl_bwave), sizeof(unsigned long long) * 65536 * 2);
 }
 extern "C" void gs_debug_abl_stats(unsigned long long *out) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_abl_stats), sizeof(unsigned long long) * 16);
