@@ -83,10 +83,10 @@ __global__ void __launch_bounds__(GS_BLOCK) gather_i32_kernel(
     if (i < n) out[i] = src[idx[i]];
 }
 
-// Wave-cooperative emission.  A wave owns 64 consecutive positions of the emission order, whose pairs
+// Wave-cooperative emission.  A wave owns a few consecutive positions of the emission order, whose pairs
 // form ONE contiguous output range [cum[first-1], cum[last]).  The lanes first park their splat's
 // record (output start, tile box, key base, id) in LDS, then walk the output range 64 slots at a time:
-// slot o finds its owner by a 6-step binary search over the 64 starts and derives its tile from its
+// slot o finds its owner by a binary search over the starts and derives its tile from its
 // offset inside the owner's box.  Stores are fully coalesced (the one-thread-per-splat loop wrote 12 B
 // at ~160 B strides: 51 us for 4 M pairs at config 2, 2.7x the compulsory traffic).
 struct EmitRec {
@@ -94,6 +94,15 @@ struct EmitRec {
     int32_t id;       // flatten id
     int32_t x0, y0, w;
 };
+
+// A wave owns EMIT_SPW consecutive positions of the emission order (16, not 64: the emission order is the depth order, so the big near splats
+// sit next to each other and a 64-splat wave could own thousands of pairs while most own a few hundred -- the kernel
+// lasted as long as that wave: 37 us at config 2 against 24 us with 16).
+#ifndef GS_EMIT_SPW
+#define GS_EMIT_SPW 16
+#endif
+constexpr uint32_t EMIT_SPW = GS_EMIT_SPW;
+constexpr uint32_t EMIT_WAVES = GS_BLOCK / GS_WAVE;
 
 __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
     uint32_t n_elems, uint32_t N, const int32_t *__restrict__ perm, const uint32_t *__restrict__ n_valid,
@@ -104,49 +113,51 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
     int64_t *__restrict__ isect_ids, int32_t *__restrict__ flatten_ids) {
     // `pos` = position in the emission order (identity, or depth-sorted when perm is given);
     // `i` = the element it refers to.  cum_tiles is indexed by position.
-    __shared__ EmitRec s_rec[GS_BLOCK];
-    __shared__ int32_t s_start[GS_BLOCK + GS_BLOCK / GS_WAVE]; // 65 starts per wave (last = total)
+    __shared__ EmitRec s_rec[EMIT_WAVES * EMIT_SPW];
+    __shared__ int32_t s_start[EMIT_WAVES * (EMIT_SPW + 1)]; // SPW + 1 starts per wave (last = total)
     const uint32_t lane = threadIdx.x % GS_WAVE, wave = threadIdx.x / GS_WAVE;
-    const uint32_t pos = blockIdx.x * GS_BLOCK + threadIdx.x;
-    const uint32_t wave_first = blockIdx.x * GS_BLOCK + wave * GS_WAVE;
+    const uint32_t wave_first = (blockIdx.x * EMIT_WAVES + wave) * EMIT_SPW;
     if (wave_first >= n_elems) return; // wave-uniform
-    const uint32_t wave_last = min(wave_first + GS_WAVE, n_elems) - 1;
+    const uint32_t pos = wave_first + lane; // lanes >= EMIT_SPW carry no splat
+    const uint32_t wave_last = min(wave_first + EMIT_SPW, n_elems) - 1;
     const int64_t out0 = (wave_first == 0) ? 0 : cum_tiles[wave_first - 1];
     const int64_t out1 = cum_tiles[wave_last];
     if (out1 == out0) return; // nothing visible in this wave (wave-uniform)
-    EmitRec rec = {0, 0, 0, 0, 1};
-    int32_t start = (int32_t)(out1 - out0);
-    if (pos < n_elems) {
-        start = (int32_t)(((pos == 0) ? 0 : cum_tiles[pos - 1]) - out0);
-        // positions behind *n_valid hold no element (perm is only defined for the kept ones)
-        const bool has = n_valid == nullptr || pos < *n_valid;
-        const uint32_t i = has ? (perm != nullptr ? (uint32_t)perm[pos] : pos) : 0u;
-        const int32_t r = has ? radii[i] : 0;
-        if (r > 0) {
-            const float2 m = reinterpret_cast<const float2 *>(means2d)[i];
-            const TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
-            const int64_t cid = camera_ids != nullptr ? camera_ids[i] : (int64_t)(i / N);
-            // raw IEEE bits of the (positive) depth, sign-extended like the reference's
-            // (int64_t)*(int32_t*)&depth  (isect_tiles.cu:91)
-            rec.key_base = (cid << (32 + tile_n_bits)) | (int64_t)__float_as_int(depths[i]);
-            rec.id = (int32_t)i;
-            rec.x0 = b.x0;
-            rec.y0 = b.y0;
-            rec.w = max(b.x1 - b.x0, 1);
+    EmitRec *wrec = s_rec + wave * EMIT_SPW;
+    int32_t *wstart = s_start + wave * (EMIT_SPW + 1);
+    if (lane < EMIT_SPW) {
+        EmitRec rec = {0, 0, 0, 0, 1};
+        int32_t start = (int32_t)(out1 - out0);
+        if (pos < n_elems) {
+            start = (int32_t)(((pos == 0) ? 0 : cum_tiles[pos - 1]) - out0);
+            // positions behind *n_valid hold no element (perm is only defined for the kept ones)
+            const bool has = n_valid == nullptr || pos < *n_valid;
+            const uint32_t i = has ? (perm != nullptr ? (uint32_t)perm[pos] : pos) : 0u;
+            const int32_t r = has ? radii[i] : 0;
+            if (r > 0) {
+                const float2 m = reinterpret_cast<const float2 *>(means2d)[i];
+                const TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
+                const int64_t cid = camera_ids != nullptr ? camera_ids[i] : (int64_t)(i / N);
+                // raw IEEE bits of the (positive) depth, sign-extended like the reference's
+                // (int64_t)*(int32_t*)&depth  (isect_tiles.cu:91)
+                rec.key_base = (cid << (32 + tile_n_bits)) | (int64_t)__float_as_int(depths[i]);
+                rec.id = (int32_t)i;
+                rec.x0 = b.x0;
+                rec.y0 = b.y0;
+                rec.w = max(b.x1 - b.x0, 1);
+            }
         }
+        wrec[lane] = rec;
+        wstart[lane] = start;
     }
-    EmitRec *wrec = s_rec + wave * GS_WAVE;
-    int32_t *wstart = s_start + wave * (GS_WAVE + 1);
-    wrec[lane] = rec;
-    wstart[lane] = start;
-    if (lane == 0) wstart[GS_WAVE] = (int32_t)(out1 - out0);
+    if (lane == 0) wstart[EMIT_SPW] = (int32_t)(out1 - out0);
     __builtin_amdgcn_wave_barrier();
     const int32_t total = (int32_t)(out1 - out0);
     for (int32_t t = (int32_t)lane; t < total; t += GS_WAVE) {
         // largest s with start[s] <= t (zero-count lanes share their successor's start and are skipped)
         int32_t sidx = 0;
 #pragma unroll
-        for (int step = 32; step > 0; step >>= 1)
+        for (int step = EMIT_SPW / 2; step > 0; step >>= 1)
             if (wstart[sidx + step] <= t) sidx += step;
         const EmitRec o = wrec[sidx];
         const int32_t k = t - wstart[sidx];
@@ -378,7 +389,7 @@ extern "C" int32_t gs_isect_emit(
     GS_CHECK_ARG(means2d && radii && depths && cum_tiles_per_gauss, "null pointer");
     GS_CHECK_ARG(camera_ids != nullptr || N > 0, "N must be > 0 when camera_ids is NULL");
     GS_CHECK_ARG(tile_n_bits < 32, "tile_n_bits must be < 32");
-    hipLaunchKernelGGL(isect_emit_kernel, dim3(gs_div_up(n_elems, GS_BLOCK)), dim3(GS_BLOCK), 0,
+    hipLaunchKernelGGL(isect_emit_kernel, dim3(gs_div_up(n_elems, EMIT_WAVES * EMIT_SPW)), dim3(GS_BLOCK), 0,
                        (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids, means2d, radii, depths,
                        cum_tiles_per_gauss, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
                        tile_n_bits, isect_ids, flatten_ids);
