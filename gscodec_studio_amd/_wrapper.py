@@ -147,6 +147,21 @@ def _elem_strided(t: Tensor):
     return t.contiguous(), 1
 
 
+def _pixel_strided(t: Tensor):
+    """(tensor, pixel stride, channel stride) of an image gradient [C,H,W,D] whose pixels are laid out uniformly: a dense
+    tensor -> (D, 1); the expanded scalar autograd produces for ``sum(render)`` -> (0, 0), read in place by the kernels
+    instead of being materialised (25 MB at 1080p); anything else is copied."""
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32 tensor, got {t.dtype}")
+    if t.is_contiguous():
+        return t, t.shape[-1], 1
+    C, H, W, D = t.shape
+    sp, sc = t.stride(2), t.stride(3)
+    if sp >= 0 and sc >= 0 and t.stride(1) == W * sp and t.stride(0) == H * W * sp and (sp == 0 or sp >= D * max(sc, 1)):
+        return t, sp, sc
+    return t.contiguous(), D, 1
+
+
 def _rows_table(parts, n_rows: int, row_index=None):
     """ctypes tables for gs_rows_*: parts = [(tensor | None, width[, indexed])].  An indexed part pairs wire row r with
     ITS row row_index[r] (any number of rows); the others have exactly n_rows rows."""
@@ -1036,7 +1051,7 @@ class _RasterizeToPixels(torch.autograd.Function):
         # NULL v_render_alphas, which saves a [C,H,W] zero-fill and one of the 12 per-pixel loads of every work item
         if v_render_colors is None:
             v_render_colors = torch.zeros_like(render_colors)
-        v_render_colors = _f32c(v_render_colors)
+        v_render_colors, vrc_pix, vrc_ch = _pixel_strided(v_render_colors)
         v_render_alphas = _f32c(v_render_alphas) if v_render_alphas is not None else None
         # accumulated with atomics -> zero-filled.  Up to 4 channels: ONE packed [n_elems,16] buffer
         # (64-byte row per splat: vx vy | ca cb cc | o | c0..c3 | ax ay) so that a splat's whole
@@ -1061,7 +1076,7 @@ class _RasterizeToPixels(torch.autograd.Function):
             B.call("gs_rasterize_bwd", C, n_elems, n_isects, channels, B.ptr(means2d), B.ptr(conics), B.ptr(colors),
                    B.ptr(opacities), B.ptr(backgrounds), B.ptr(m8), ctx.width, ctx.height, ctx.tile_size,
                    tile_width, tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_colors),
-                   B.ptr(render_alphas), B.ptr(last_ids), B.ptr(v_render_colors), B.ptr(v_render_alphas), *out_ptrs,
+                   B.ptr(render_alphas), B.ptr(last_ids), B.ptr(v_render_colors), B.ptr(v_render_alphas), vrc_pix, vrc_ch, *out_ptrs,
                    int(packed), B.ptr(scratch), sb, _stream(means2d))
         if ctx.absgrad:
             means2d.absgrad = v_means2d_abs

@@ -1022,6 +1022,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
     float px[NQ], py[NQ], T[NQ], Tw[NQ], Bq[NQ], vc[NQ][CR];
     int32_t bin_final[NQ];
     size_t pixv[NQ];
+    int64_t vpix[NQ]; // the same pixel in v_render_colors (its own strides)
     const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels + ch_off : nullptr;
     int32_t bin_max = -1;
 #pragma unroll
@@ -1034,6 +1035,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
         py[i] = (float)y + 0.5f;
         const size_t pix = inside[i] ? ((size_t)tg.cam * a.image_height + y) * a.image_width + x : 0;
         pixv[i] = pix * a.channels + ch_off;
+        vpix[i] = (int64_t)pix * ga.s_vrc_pix + (int64_t)ch_off * ga.s_vrc_ch;
         const float T_final = inside[i] ? 1.f - ga.render_alphas[pix] : 1.f;
         T[i] = T_final;
         Bq[i] = 0.f;
@@ -1041,13 +1043,13 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
         if (CMODE != 2) {
 #pragma unroll
             for (int k = 0; k < CR; ++k) {
-                vc[i][k] = (inside[i] && (uint32_t)k < cnt) ? ga.v_render_colors[pixv[i] + k] : 0.f;
+                vc[i][k] = (inside[i] && (uint32_t)k < cnt) ? ga.v_render_colors[vpix[i] + k * ga.s_vrc_ch] : 0.f;
                 if (bg != nullptr && (uint32_t)k < cnt) bg_dot += bg[k] * vc[i][k];
             }
         } else {
             vc[i][0] = 0.f;
             if (bg != nullptr && inside[i])
-                for (uint32_t k = 0; k < cnt; ++k) bg_dot += bg[k] * ga.v_render_colors[pixv[i] + k];
+                for (uint32_t k = 0; k < cnt; ++k) bg_dot += bg[k] * ga.v_render_colors[vpix[i] + k * ga.s_vrc_ch];
         }
         const float v_a = (inside[i] && use_v_alpha) ? ga.v_render_alphas[pix] : 0.f;
         Tw[i] = T_final * (v_a - bg_dot);
@@ -1161,7 +1163,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
                 float D = 0.f;
                 if (CMODE == 2) {
                     if (valid)
-                        for (uint32_t k = 0; k < cnt; ++k) D += cp[k] * ga.v_render_colors[pixv[i] + k];
+                        for (uint32_t k = 0; k < cnt; ++k) D += cp[k] * ga.v_render_colors[vpix[i] + k * ga.s_vrc_ch];
                 } else {
 #pragma unroll
                     for (int k = 0; k < CR; ++k) {
@@ -1194,7 +1196,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
                 for (uint32_t k = 0; k < cnt; ++k) {
                     float c = 0.f;
 #pragma unroll
-                    for (int i = 0; i < NQ; ++i) c += facs[i] * (inside[i] ? ga.v_render_colors[pixv[i] + k] : 0.f);
+                    for (int i = 0; i < NQ; ++i) c += facs[i] * (inside[i] ? ga.v_render_colors[vpix[i] + k * ga.s_vrc_ch] : 0.f);
                     c = wave_reduce_sum_dpp(c);
                     if (lane == GS_WAVE - 1) unsafeAtomicAdd(vcol + k, c);
                 }
@@ -1360,7 +1362,7 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
         float bg_dot = 0.f;
 #pragma unroll
         for (int k = 0; k < CDIM; ++k) {
-            vc[i][k] = inside[i] ? ga.v_render_colors[pix * CDIM + k] : 0.f;
+            vc[i][k] = inside[i] ? ga.v_render_colors[pix * ga.s_vrc_pix + k * ga.s_vrc_ch] : 0.f;
             if (bg != nullptr) bg_dot += bg[k] * vc[i][k];
         }
         const float v_a = (inside[i] && use_v_alpha) ? ga.v_render_alphas[pix] : 0.f;

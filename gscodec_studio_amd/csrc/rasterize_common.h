@@ -34,6 +34,9 @@ struct RasterGradArgs {
     // Packed mode (one 64-byte row per splat: [vx vy | ca cb cc | o | c0..c3 | ax ay | pad]): all 16.
     uint32_t s_abs, s_xy, s_conic, s_color, s_opac;
     uint32_t packed; // 1: the pointers above alias one [n_elems,16] buffer
+    // element strides of v_render_colors per pixel / per channel: (channels, 1) for a dense [C,H,W,channels] tensor,
+    // (0, 0) for the broadcast gradient of sum(render) (autograd hands over an expanded scalar: nothing to materialise)
+    int64_t s_vrc_pix, s_vrc_ch;
 };
 
 // 64-lane sum with DPP row shifts + row broadcasts (GFX9 family).  The total is valid in

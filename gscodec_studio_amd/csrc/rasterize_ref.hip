@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(GS_BLOCK) raster_ref_bwd_kernel(RasterArgs a, 
 #pragma unroll
     for (int k = 0; k < CDIM; ++k) {
         buffer[k] = 0.f;
-        v_c[k] = (inside && (uint32_t)k < cnt) ? ga.v_render_colors[pix * a.channels + ch_off + k] : 0.f;
+        v_c[k] = (inside && (uint32_t)k < cnt) ? ga.v_render_colors[(int64_t)pix * ga.s_vrc_pix + (int64_t)(ch_off + k) * ga.s_vrc_ch] : 0.f;
     }
     const float v_a = (inside && use_v_alpha) ? ga.v_render_alphas[pix] : 0.f;
     const int32_t bin_final = inside ? ga.last_ids[pix] : 0;

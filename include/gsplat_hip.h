@@ -328,6 +328,9 @@ int32_t gs_rasterize_bwd(
     const float *render_colors, /* forward output, or NULL (disables the segmented path) */
     const float *render_alphas, const int32_t *last_ids,
     const float *v_render_colors, const float *v_render_alphas /* or NULL (= zero) */,
+    int64_t v_render_colors_pixel_stride,   /* element strides of v_render_colors: (channels, 1) for a dense */
+    int64_t v_render_colors_channel_stride, /* [C,H,W,channels] tensor; (0, 0) for a broadcast scalar (the gradient
+                                               of sum(render)): nothing has to be materialised */
     float *v_means2d_abs, /* [n_elems,2] or NULL */
     float *v_means2d,     /* [n_elems,2] */
     float *v_conics,      /* [n_elems,3] */

@@ -342,3 +342,28 @@ def test_degenerate_inputs_do_not_crash():
         assert all(bool(torch.isfinite(p.grad).all()) for p in ps)
     rc, ra, meta, ps = run(m[:1], q[:1], s[:1] * 5, o[:1], torch.rand(1, 1, 3, device="cuda"), packed=False, sh_degree=0)
     assert bool(torch.isfinite(rc).all())
+
+
+def test_broadcast_image_gradient_is_read_in_place():
+    """``render.sum().backward()`` hands the compositing backward an EXPANDED scalar (all strides 0); the kernels read it
+    through (pixel, channel) strides instead of a materialised [C,H,W,3] copy.  Same gradients as the dense tensor of
+    ones, also for a per-channel weight (pixel stride 0, channel stride 1) and with a background."""
+    from gscodec_studio_amd import rasterization
+
+    d = _inputs(n=3000, cams=2, sh_degree=None, scale_mult=6.0)
+    bg = torch.tensor([[0.2, 0.4, 0.6], [0.1, 0.1, 0.9]], device="cuda")
+
+    def grads(loss_of):
+        ps = [T(d[k]).requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")]
+        rc, ra, _ = rasterization(*ps, T(d["viewmats"]), T(d["Ks"]), d["W"], d["H"], packed=False, backgrounds=bg)
+        loss_of(rc).backward()
+        return [N(p.grad) for p in ps]
+
+    wc = torch.tensor([0.5, 1.0, 2.0], device="cuda")
+    for sparse_loss, dense_loss in (
+        (lambda rc: rc.sum(), lambda rc: (rc * torch.ones_like(rc)).sum()),
+        (lambda rc: (rc * wc).sum(), lambda rc: (rc * wc.expand_as(rc).contiguous()).sum()),
+    ):
+        g0, g1 = grads(sparse_loss), grads(dense_loss)
+        for a, b, name in zip(g0, g1, ("means", "quats", "scales", "opacities", "colors")):
+            assert rel_l2(a, b) < 2e-5, (name, rel_l2(a, b))
