@@ -152,6 +152,7 @@ extern "C" int32_t gs_exchange_compact(uint32_t C_total, uint32_t N, uint32_t C_
                                        uint32_t *stats, gs_stream_t stream) {
     GS_CHECK_ARG(C_local >= 1 && world >= 1 && C_total == C_local * world && world <= 1024, "C_total = C_local * world, world <= 1024");
     GS_CHECK_ARG(src_index && hdr && counters && stats, "null pointer");
+    GS_CHECK_ARG((uint64_t)C_total * N < (1ull << 31) && (uint64_t)C_local * N_total < (1ull << 31), "row indices must fit 31 bits");
     hipStream_t st = (hipStream_t)stream;
     const size_t rows = (size_t)world * (cap + 1);
     hipError_t e = hipMemsetAsync(src_index, 0xff, rows * sizeof(int32_t), st);
