@@ -245,15 +245,26 @@ def main():
         else:
             params = {k: w[k].clone().requires_grad_(True) for k in names}
 
+        if sim is not None:
+            # the hooks work on the trainer's RAW parameters (reference simple_trainer.py:779-800): log-scales, opacity
+            # logits, sh0 / shN; the activations follow the hooks
+            with torch.no_grad():
+                params["scales"] = params["scales"].log().requires_grad_(True)
+                params["opacities"] = torch.logit(params["opacities"].clamp(1e-6, 1 - 1e-6)).requires_grad_(True)
+                params["sh0"] = params["sh"][:, :1, :].clone().requires_grad_(True)
+                params["shN"] = params["sh"][:, 1:, :].clone().requires_grad_(True)
+                del params["sh"]
+
         def step():
             for p in params.values():
                 p.grad = None
             if sim is not None:
-                q, _ = sim.simulate_compression({"scales": params["scales"], "quats": params["quats"]}, step=0)
-                quats, scales = q["quats"], q["scales"]
+                q, _ = sim.simulate_compression({k: params[k] for k in ("scales", "quats", "opacities", "sh0", "shN")}, step=0)
+                quats, scales, opac = q["quats"], torch.exp(q["scales"]), torch.sigmoid(q["opacities"])
+                sh = torch.cat([q["sh0"], q["shN"]], dim=1)
             else:
-                quats, scales = params["quats"], params["scales"]
-            rc, ra, meta = rasterization(params["means"], quats, scales, params["opacities"], params["sh"], viewmats, Ks,
+                quats, scales, opac, sh = params["quats"], params["scales"], params["opacities"], params["sh"]
+            rc, ra, meta = rasterization(params["means"], quats, scales, opac, sh, viewmats, Ks,
                                          w["width"], w["height"], sh_degree=args.sh_degree, packed=False,
                                          distributed=gaussian)
             rc.sum().backward()
