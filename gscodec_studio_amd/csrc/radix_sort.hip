@@ -99,24 +99,20 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scan_kernel(
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-// totals of the 256 digits of a pass = number of keys it kept
-__global__ void __launch_bounds__(GS_BLOCK) sort_total_kernel(const uint32_t *__restrict__ totals, uint32_t *__restrict__ n_out) {
-    __shared__ uint32_t s[GS_BLOCK / GS_WAVE];
-    uint32_t v = totals[threadIdx.x];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (threadIdx.x % GS_WAVE == 0) s[threadIdx.x / GS_WAVE] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) *n_out = s[0] + s[1] + s[2] + s[3];
-}
-
 template <int SORT_ROUNDS>
 __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
     uint64_t n, const uint32_t *__restrict__ n_dev, const uint64_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
     uint64_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, DigitSpec d,
-    uint32_t n_blocks, const uint32_t *__restrict__ hist_scan, const uint32_t *__restrict__ totals) {
+    uint32_t n_blocks, const uint32_t *__restrict__ hist_scan, const uint32_t *__restrict__ totals,
+    uint32_t *__restrict__ n_kept_out /* or NULL: block 0 also publishes the number of keys this pass kept */) {
     constexpr int SORT_TILE = sort_tile(SORT_ROUNDS);
     constexpr int SORT_WAVE_KEYS = GS_WAVE * SORT_ROUNDS;
+    if (n_kept_out != nullptr && blockIdx.x == 0 && threadIdx.x < GS_WAVE) { // sum of the 256 digit totals (one wave)
+        uint32_t v = totals[threadIdx.x] + totals[threadIdx.x + 64] + totals[threadIdx.x + 128] + totals[threadIdx.x + 192];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (threadIdx.x == 0) *n_kept_out = v;
+    }
     __shared__ uint32_t s_cnt[SORT_WAVES][RADIX]; // per-wave digit counters -> per-wave prefix
     __shared__ uint32_t s_lbase[RADIX];           // base of the digit inside this block's sorted order
     __shared__ uint32_t s_gofs[RADIX];            // global base of (digit, this block) - s_lbase
@@ -314,13 +310,12 @@ static int32_t sort_impl(uint64_t n, const int64_t *keys_in, const int32_t *vals
         else
             hipLaunchKernelGGL((sort_hist_kernel<SORT_ROUNDS_BIG>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, hist);
         hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, hist, totals);
-        if (drop && p == 0) hipLaunchKernelGGL(sort_total_kernel, dim3(1), dim3(GS_BLOCK), 0, st, totals, n_valid_out);
         if (small)
             hipLaunchKernelGGL((sort_scatter_kernel<SORT_ROUNDS_SMALL>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, src_v,
-                               dst_k, dst_v, d, L.n_blocks, hist, totals);
+                               dst_k, dst_v, d, L.n_blocks, hist, totals, (drop && p == 0) ? n_valid_out : nullptr);
         else
             hipLaunchKernelGGL((sort_scatter_kernel<SORT_ROUNDS_BIG>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, src_v,
-                               dst_k, dst_v, d, L.n_blocks, hist, totals);
+                               dst_k, dst_v, d, L.n_blocks, hist, totals, (drop && p == 0) ? n_valid_out : nullptr);
         if (drop && p == 0) n_dev = n_valid_out;
         src_k = dst_k;
         src_v = dst_v;
