@@ -260,9 +260,21 @@ __global__ void __launch_bounds__(GS_BLOCK) scan_spine_kernel(uint32_t n_blocks,
 template <typename OutT>
 __global__ void __launch_bounds__(GS_BLOCK) scan_apply_kernel(
     uint64_t n, const int32_t *__restrict__ in, const int32_t *__restrict__ idx, const uint32_t *__restrict__ n_valid,
-    const int64_t *__restrict__ block_sums, OutT *__restrict__ out) {
+    const int64_t *__restrict__ block_sums, OutT *__restrict__ out, int32_t raw_sums) {
     __shared__ int64_t s_wave[GS_BLOCK / GS_WAVE];
     const uint64_t nv = n_valid != nullptr ? min(n, (uint64_t)*n_valid) : n;
+    // raw_sums: block_sums holds the per-block totals themselves (no spine launch for up to a few thousand blocks):
+    // the offset of this block is the sum of its predecessors' totals
+    int64_t offset;
+    if (raw_sums) {
+        int64_t pre = 0;
+        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += GS_BLOCK) pre += block_sums[i];
+        int64_t tot;
+        block_exclusive_scan_i64(pre, tot, s_wave);
+        offset = tot;
+    } else {
+        offset = block_sums[blockIdx.x];
+    }
     // blocked arrangement: thread t owns items [t*ITEMS, (t+1)*ITEMS)
     uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
     int32_t v[SCAN_ITEMS];
@@ -274,7 +286,7 @@ __global__ void __launch_bounds__(GS_BLOCK) scan_apply_kernel(
         s += v[k];
     }
     int64_t total;
-    int64_t run = block_exclusive_scan_i64(s, total, s_wave) + block_sums[blockIdx.x];
+    int64_t run = block_exclusive_scan_i64(s, total, s_wave) + offset;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         uint64_t i = base + k;
@@ -294,8 +306,9 @@ int32_t cumsum_impl(uint64_t n, const int32_t *in, const int32_t *idx, const uin
     }
     int64_t *sums = (int64_t *)scratch;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(n_blocks), dim3(GS_BLOCK), 0, st, n, in, idx, n_valid, sums);
-    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(GS_BLOCK), 0, st, n_blocks, sums);
-    hipLaunchKernelGGL((scan_apply_kernel<OutT>), dim3(n_blocks), dim3(GS_BLOCK), 0, st, n, in, idx, n_valid, sums, out);
+    const int32_t raw = n_blocks <= 4096u ? 1 : 0; // every block sums its predecessors' totals itself (<= 16 loads per thread)
+    if (!raw) hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(GS_BLOCK), 0, st, n_blocks, sums);
+    hipLaunchKernelGGL((scan_apply_kernel<OutT>), dim3(n_blocks), dim3(GS_BLOCK), 0, st, n, in, idx, n_valid, sums, out, raw);
     return 0;
 }
 

@@ -313,7 +313,7 @@ def test_radix_sort_drop_variant_and_gather_cumsum(ops, n):
 def test_cumsum_matches_numpy(ops):
     from gscodec_studio_amd import _backend as B
 
-    for n in (1, 255, 2048, 2049, 1_000_003):
+    for n in (1, 255, 2048, 2049, 1_000_003, 4096 * 2048 + 5):  # the last one: more than 4096 blocks (separate spine launch)
         x = np.random.RandomState(n % 97).randint(0, 50, size=n).astype(np.int32)
         x_t = T(x)
         out = torch.empty(n, dtype=torch.int64, device=x_t.device)
