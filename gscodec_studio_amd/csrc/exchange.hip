@@ -137,9 +137,17 @@ __global__ void __launch_bounds__(COMPACT_BLOCK) exchange_compact_kernel(uint32_
 // header row of every chunk: (-1, count | overflow << 30); stats[0] = max count, stats[1] = 1 if any chunk overflowed
 __global__ void exchange_header_kernel(uint32_t world, uint32_t cap, const uint32_t *__restrict__ counters, int2 *__restrict__ hdr,
                                        uint32_t *__restrict__ stats) {
+    // the flag in EVERY header says "some chunk of this rank overflowed": a receiver only sees the chunks addressed to it,
+    // and all ranks must take the same decision about repeating the exchange
+    __shared__ uint32_t s_over;
     const uint32_t d = threadIdx.x;
+    if (d == 0) s_over = 0u;
+    __syncthreads();
+    const uint32_t cnt = d < world ? counters[d] : 0u;
+    if (cnt > cap) atomicOr(&s_over, 1u);
+    __syncthreads();
     if (d >= world) return;
-    const uint32_t cnt = counters[d], over = cnt > cap ? 1u : 0u;
+    const uint32_t over = s_over;
     hdr[(size_t)d * (cap + 1) + cap] = make_int2(-1, (int32_t)(min(cnt, cap) | (over << 30)));
     atomicMax(&stats[0], cnt);
     if (over) atomicMax(&stats[1], 1u);

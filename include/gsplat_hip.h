@@ -514,7 +514,7 @@ int32_t gs_rows_unpack_indexed(
 /* Compaction for the sparse form of that exchange: the rows with radii > 0 of radii [C_total, N] are listed per
  * destination rank d = c / C_local in a chunk of `cap` slots + 1 header row (slot order arbitrary):
  * src_index [world * (cap + 1)] = c * N + n or -1; hdr [world * (cap + 1), 2] = (row in the receiver's [C_local * N_total]
- * arrays, 0) or -1, header row = (-1, min(count, cap) | overflow << 30); counters [world] = rows wanted per destination;
+ * arrays, 0) or -1, header row = (-1, min(count, cap) | overflow << 30) where overflow = SOME chunk of this call was too small; counters [world] = rows wanted per destination;
  * stats [2] = (largest count, any overflow).  Both index arrays feed gs_rows_pack_indexed (a negative index packs
  * zeros / is skipped by gs_rows_unpack_indexed).  No read-back: `cap` comes from the caller's previous steps, and an
  * overflow is visible to every receiver in the header rows. */

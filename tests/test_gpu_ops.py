@@ -461,3 +461,32 @@ def test_rows_pack_unpack_indexed():
     ref_r = torch.zeros(n_src, dtype=torch.int32, device="cuda")
     ref_r[li] = r[li]
     assert torch.equal(out_a, ref_a) and torch.equal(out_r, ref_r)
+
+
+def test_exchange_compact_lists_and_overflow_flag():
+    """gs_exchange_compact: every visible (camera, gaussian) row is listed once in the chunk of its destination rank with
+    the right destination row; when ONE chunk is too small, EVERY header carries the overflow flag (a receiver only sees
+    the chunks addressed to it, and all ranks have to agree on repeating the exchange)."""
+    from gscodec_studio_amd._wrapper import exchange_compact
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    world, C_local, N, N_total, N_off = 3, 2, 5000, 17000, 4000
+    radii = (torch.rand(world * C_local, N, device="cuda", generator=g) < 0.2).to(torch.int32) * 7
+    radii[0:2] = ((torch.rand(2, N, device="cuda", generator=g) < 0.6).to(torch.int32) * 3)  # destination 0 wants far more rows
+    want = [int((radii[d * C_local:(d + 1) * C_local] > 0).sum()) for d in range(world)]
+    for cap in (max(want) + 10, (want[0] + max(want[1:])) // 2):
+        src, hdr, counters, stats = exchange_compact(radii, C_local, world, cap, N_total, N_off)
+        assert counters.tolist() == want and int(stats[0]) == max(want)
+        over = int(any(w > cap for w in want))
+        assert int(stats[1]) == over
+        src, hdr = src.view(world, cap + 1), hdr.view(world, cap + 1, 2)
+        for d in range(world):
+            assert int(hdr[d, cap, 0]) == -1 and int(hdr[d, cap, 1]) == (min(want[d], cap) | (over << 30)), (d, cap)
+            rows = src[d, :cap]
+            rows = rows[rows >= 0]
+            assert rows.numel() == min(want[d], cap) and rows.unique().numel() == rows.numel()
+            cam, gau = rows // N, rows % N
+            assert bool(((cam // C_local) == d).all()) and bool((radii.view(-1)[rows.long()] > 0).all())
+            dst = hdr[d, :cap, 0]
+            dst = dst[dst >= 0]
+            assert torch.equal(dst.sort().values, ((cam % C_local) * N_total + N_off + gau).to(torch.int32).sort().values)
