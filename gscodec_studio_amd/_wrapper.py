@@ -241,6 +241,39 @@ def rows_unpack(wire: Tensor, parts, row_index: Optional[Tensor] = None) -> None
                    ctypes.addressof(flags), ip, istride, B.ptr(wire), _stream(wire))
 
 
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src: Tensor, ids: Tensor) -> Tensor:
+        _require_gpu(src, "gather_rows")
+        src = _f32c(src)
+        ids = ids.contiguous()
+        assert ids.dtype == torch.int64 and ids.dim() == 1
+        width = int(src.numel() // max(src.shape[0], 1))
+        out = torch.empty((ids.shape[0],) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+        with _device_of(src):
+            B.call("gs_gather_rows_f32", ids.shape[0], width, B.ptr(src), B.ptr(ids), B.ptr(out), _stream(src))
+        ctx.save_for_backward(ids)
+        ctx.src_shape, ctx.width = tuple(src.shape), width
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out: Tensor):
+        (ids,) = ctx.saved_tensors
+        v_out = _f32c(v_out)
+        v_src = torch.zeros(ctx.src_shape, dtype=torch.float32, device=v_out.device)
+        with _device_of(v_out):
+            B.call("gs_scatter_add_rows_f32", ids.shape[0], ctx.width, B.ptr(v_out), B.ptr(ids), B.ptr(v_src), _stream(v_out))
+        return v_src, None
+
+
+def gather_rows(src: Tensor, ids: Tensor) -> Tensor:
+    """``src[ids]`` for fp32 ``src`` [N, ...] and int64 ``ids`` [nnz] with a one-pass atomic backward (the packed pipeline's
+    per-splat gathers; torch's indexing backward sorts the ids and costs ~0.45 ms per step at 2.8 M splats)."""
+    if not src.is_cuda or src.dtype != torch.float32 or ids.dtype != torch.int64 or ids.dim() != 1:
+        return src[ids]
+    return _GatherRows.apply(src, ids)
+
+
 def exchange_compact(radii: Tensor, C_local: int, world: int, cap: int, N_total: int, N_off: int):
     """Lists of the visible rows of ``radii`` [C_total, N] per destination rank (gs_exchange_compact): returns
     (src_index i32 [world * (cap + 1)], hdr i32 [world * (cap + 1), 2], counters i32 [world], stats i32 [2])."""

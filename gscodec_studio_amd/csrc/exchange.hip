@@ -203,3 +203,54 @@ extern "C" int32_t gs_rows_unpack_indexed(uint64_t n_rows, int32_t n_parts, void
                                           int64_t index_stride, const void *wire, gs_stream_t stream) {
     return rows_launch<false>(n_rows, n_parts, parts, widths, row_strides, (void *)wire, stream, indexed, row_index, index_stride);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row gather and its adjoint for the packed (COO) pipeline: `opacities[gaussian_ids]`, `colors[gaussian_ids]`,
+// `means[gaussian_ids]` of reference gsplat/rendering.py:325, 365-380.  torch's backward of such an index sorts the ids
+// and runs ~45 small kernels (0.45 ms per step at 2.8 M splats); here it is one pass of float atomics (ids repeat only
+// across cameras).  One lane per element, the packed side is coalesced.
+namespace {
+
+__global__ void __launch_bounds__(GS_BLOCK) gather_rows_kernel(uint64_t total, uint32_t width, const float *__restrict__ src,
+                                                               const int64_t *__restrict__ ids, float *__restrict__ out) {
+    const uint64_t e = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (e >= total) return;
+    const uint64_t r = e / width;
+    const uint32_t c = (uint32_t)(e - r * width);
+    out[e] = src[(uint64_t)ids[r] * width + c];
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) scatter_add_rows_kernel(uint64_t total, uint32_t width, const float *__restrict__ v_out,
+                                                                    const int64_t *__restrict__ ids, float *__restrict__ v_src) {
+    const uint64_t e = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (e >= total) return;
+    const uint64_t r = e / width;
+    const uint32_t c = (uint32_t)(e - r * width);
+    unsafeAtomicAdd(v_src + (uint64_t)ids[r] * width + c, v_out[e]);
+}
+
+}  // namespace
+
+extern "C" int32_t gs_gather_rows_f32(uint64_t n_rows, uint32_t width, const float *src, const int64_t *ids, float *out,
+                                      gs_stream_t stream) {
+    if (n_rows == 0 || width == 0) return 0;
+    GS_CHECK_ARG(src && ids && out, "null pointer");
+    const uint64_t total = n_rows * width;
+    GS_CHECK_ARG(total / GS_BLOCK < (1ull << 31), "too many elements");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)((total + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
+                       total, width, src, ids, out);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_scatter_add_rows_f32(uint64_t n_rows, uint32_t width, const float *v_out, const int64_t *ids, float *v_src,
+                                           gs_stream_t stream) {
+    if (n_rows == 0 || width == 0) return 0;
+    GS_CHECK_ARG(v_out && ids && v_src, "null pointer");
+    const uint64_t total = n_rows * width;
+    GS_CHECK_ARG(total / GS_BLOCK < (1ull << 31), "too many elements");
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((uint32_t)((total + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0,
+                       (hipStream_t)stream, total, width, v_out, ids, v_src);
+    GS_CHECK_LAUNCH();
+    return 0;
+}

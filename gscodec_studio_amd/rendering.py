@@ -25,6 +25,7 @@ from typing_extensions import Literal
 
 from ._wrapper import (
     fully_fused_projection,
+    gather_rows,
     isect_offset_encode,
     isect_tiles,
     isect_tiles_begin,
@@ -176,7 +177,7 @@ def rasterization(
 
     if packed:
         camera_ids, gaussian_ids, radii, means2d, depths, conics, compensations = proj_results
-        opacities = opacities[gaussian_ids]  # [nnz]
+        opacities = gather_rows(opacities, gaussian_ids)  # [nnz] = opacities[gaussian_ids], one-pass atomic backward
     else:
         radii, means2d, depths, conics, compensations = proj_results
         camera_ids, gaussian_ids = None, None
@@ -216,7 +217,7 @@ def rasterization(
     # colours -> [C, N, D] or [nnz, D]
     if sh_degree is None:
         if packed:
-            colors = colors[gaussian_ids] if colors.dim() == 2 else colors[camera_ids, gaussian_ids]
+            colors = gather_rows(colors, gaussian_ids) if colors.dim() == 2 else colors[camera_ids, gaussian_ids]
         else:
             if colors.dim() == 2:
                 colors = colors.expand(C, -1, -1)
@@ -225,9 +226,9 @@ def rasterization(
         fuse = (not packed) and colors.dim() == 3 and not viewmats.requires_grad and viewmats.is_cuda
         campos = None if fuse else _camera_centers(viewmats)  # [C, 3] == inverse(viewmats)[:, :3, 3]
         if packed:
-            dirs = means[gaussian_ids, :] - campos[camera_ids]  # [nnz, 3]
+            dirs = gather_rows(means, gaussian_ids) - campos[camera_ids]  # [nnz, 3]
             masks = radii > 0
-            shs = colors[gaussian_ids, :, :] if colors.dim() == 3 else colors[camera_ids, gaussian_ids, :, :]
+            shs = gather_rows(colors, gaussian_ids) if colors.dim() == 3 else colors[camera_ids, gaussian_ids, :, :]
             colors = spherical_harmonics(sh_degree, dirs, shs, masks=masks)  # [nnz, 3]
         else:
             if fuse:

@@ -521,6 +521,15 @@ int32_t gs_rows_unpack_indexed(
 int32_t gs_exchange_compact(
     uint32_t C_total, uint32_t N, uint32_t C_local, uint32_t world, uint32_t cap, uint32_t N_total, uint32_t N_off,
     const int32_t *radii, int32_t *src_index, int32_t *hdr, uint32_t *counters, uint32_t *stats, gs_stream_t stream);
+/* ------------------------------------------------------------------------
+ * Row gather and its adjoint for the packed (COO) pipeline: the torch indexing `opacities[gaussian_ids]`,
+ * `colors[gaussian_ids]`, `means[gaussian_ids]` of gsplat/rendering.py:325, 365-380 and its backward (torch sorts the
+ * ids and runs ~45 small kernels there).  src [*, width] fp32, ids int64 [n_rows]; gs_scatter_add_rows_f32 ADDS
+ * v_out [n_rows, width] into v_src [*, width] (zero-fill first) with float atomics. */
+int32_t gs_gather_rows_f32(
+    uint64_t n_rows, uint32_t width, const float *src, const int64_t *ids, float *out, gs_stream_t stream);
+int32_t gs_scatter_add_rows_f32(
+    uint64_t n_rows, uint32_t width, const float *v_out, const int64_t *ids, float *v_src, gs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -490,3 +490,22 @@ def test_exchange_compact_lists_and_overflow_flag():
             dst = hdr[d, :cap, 0]
             dst = dst[dst >= 0]
             assert torch.equal(dst.sort().values, ((cam % C_local) * N_total + N_off + gau).to(torch.int32).sort().values)
+
+
+@pytest.mark.parametrize("shape", [(5000,), (5000, 3), (5000, 16, 3)])
+def test_gather_rows_and_atomic_backward(shape):
+    """gather_rows == src[ids] with the same gradient (ids repeat: a splat seen by several cameras)."""
+    from gscodec_studio_amd._wrapper import gather_rows
+
+    g = torch.Generator(device="cuda").manual_seed(len(shape))
+    src = torch.randn(*shape, device="cuda", generator=g)
+    ids = torch.randint(0, shape[0], (12345,), device="cuda", generator=g)
+    w = torch.randn(12345, *shape[1:], device="cuda", generator=g)
+    a = src.clone().requires_grad_(True)
+    b = src.clone().requires_grad_(True)
+    out = gather_rows(a, ids)
+    ref = b[ids]
+    assert torch.equal(out, ref)
+    (out * w).sum().backward()
+    (ref * w).sum().backward()
+    assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-5)
