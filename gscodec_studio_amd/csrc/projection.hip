@@ -490,27 +490,33 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_packed_bwd_kernel(
             }
         }
     } else {
-        // dense: several cameras may hit the same gaussian row
+        // dense: several cameras may hit the same gaussian row -> float atomics; with ONE camera every gaussian appears at
+        // most once and the (zero-filled) row is simply written
         size_t o = n;
+        const bool one = C == 1u;
+        auto put = [&](float *dst, float v) {
+            if (one) *dst = v;
+            else atomicAdd(dst, v);
+        };
         if (v_means != nullptr) {
-            atomicAdd(v_means + 3 * o, g.v_px);
-            atomicAdd(v_means + 3 * o + 1, g.v_py);
-            atomicAdd(v_means + 3 * o + 2, g.v_pz);
+            put(v_means + 3 * o, g.v_px);
+            put(v_means + 3 * o + 1, g.v_py);
+            put(v_means + 3 * o + 2, g.v_pz);
         }
         if (covars != nullptr) {
             if (v_covars != nullptr) {
                 float *d = v_covars + 6 * o;
-                atomicAdd(d, g.v_S.xx); atomicAdd(d + 1, 2.f * g.v_S.xy); atomicAdd(d + 2, 2.f * g.v_S.xz);
-                atomicAdd(d + 3, g.v_S.yy); atomicAdd(d + 4, 2.f * g.v_S.yz); atomicAdd(d + 5, g.v_S.zz);
+                put(d, g.v_S.xx); put(d + 1, 2.f * g.v_S.xy); put(d + 2, 2.f * g.v_S.xz);
+                put(d + 3, g.v_S.yy); put(d + 4, 2.f * g.v_S.yz); put(d + 5, g.v_S.zz);
             }
         } else {
             if (v_quats != nullptr) {
                 float *d = v_quats + 4 * o;
-                atomicAdd(d, vq[0]); atomicAdd(d + 1, vq[1]); atomicAdd(d + 2, vq[2]); atomicAdd(d + 3, vq[3]);
+                put(d, vq[0]); put(d + 1, vq[1]); put(d + 2, vq[2]); put(d + 3, vq[3]);
             }
             if (v_scales != nullptr) {
                 float *d = v_scales + 3 * o;
-                atomicAdd(d, vs[0]); atomicAdd(d + 1, vs[1]); atomicAdd(d + 2, vs[2]);
+                put(d, vs[0]); put(d + 1, vs[1]); put(d + 2, vs[2]);
             }
         }
     }
