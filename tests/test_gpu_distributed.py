@@ -10,6 +10,7 @@ With >= 2 GPUs the ranks use one GPU each over RCCL.  The test boxes have ONE GP
 the exchanges go through host memory on gloo (RCCL refuses two ranks on one device), which still runs every kernel,
 the autograd plumbing and the regrouping logic of the two-rank path.  The world-1 variants run the RCCL set-up itself.
 """
+import math
 import os
 import socket
 import sys
@@ -87,29 +88,38 @@ def _camera_sharded(rank, world, port, backend):
         dist.destroy_process_group()
 
 
-def _gaussian_sharded(rank, world, port, backend, packed, sparse=True):
+def _gaussian_sharded(rank, world, port, backend, packed, sparse=True, cpr=1):
     os.environ["GS_DIST_SPARSE"] = "1" if sparse else "0"  # only the visible rows on the wire / every row
     dev = _setup(rank, world, port, backend)
     try:
         from gscodec_studio_amd import rasterization
 
-        base, V, K, W, H = _scene(dev, world)
+        base, V, K, W, H = _scene(dev, min(world * cpr, 3))
+        if world * cpr > V.shape[0]:  # more cameras than the fixture has: reuse them with a small roll
+            extra = world * cpr - V.shape[0]
+            a = 0.03
+            Rz = torch.tensor([[math.cos(a), -math.sin(a), 0, 0], [math.sin(a), math.cos(a), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]],
+                              device=dev)
+            V = torch.cat([V, V[:extra] @ Rz], 0)
+            K = torch.cat([K, K[:extra]], 0)
         N = base["means"].shape[0]
         cuts = [0, N // 3, N][: world + 1] if world == 2 else [0, N]  # unequal slices on purpose
         sl = slice(cuts[rank], cuts[rank + 1])
         mine = {k: v[sl].clone().requires_grad_(True) for k, v in base.items()}
+        cs = slice(rank * cpr, (rank + 1) * cpr)  # my cameras
         rc, ra, meta = rasterization(mine["means"], mine["quats"], mine["scales"], mine["opacities"], mine["sh"],
-                                     V[rank: rank + 1], K[rank: rank + 1], W, H, sh_degree=3, packed=packed, distributed=True)
-        assert rc.shape == (1, H, W, 3)
+                                     V[cs], K[cs], W, H, sh_degree=3, packed=packed, distributed=True)
+        assert rc.shape == (cpr, H, W, 3)
         # a per-camera weight so that a gradient routed to the wrong camera would show
-        (rc.sum() * (rank + 1.0)).backward()
+        wcam = torch.arange(1, world * cpr + 1, device=dev, dtype=torch.float32)
+        (rc.sum(dim=(1, 2, 3)) * wcam[cs]).sum().backward()
 
         ref = {k: v.clone().requires_grad_(True) for k, v in base.items()}
         rr, ar, _ = rasterization(ref["means"], ref["quats"], ref["scales"], ref["opacities"], ref["sh"], V, K, W, H,
                                   sh_degree=3, packed=packed)
-        assert torch.allclose(rr[rank], rc[0], rtol=1e-5, atol=1e-6), float((rr[rank] - rc[0]).abs().max())
-        assert torch.allclose(ar[rank], ra[0], rtol=1e-5, atol=1e-6)
-        sum(rr[c].sum() * (c + 1.0) for c in range(world)).backward()
+        assert torch.allclose(rr[cs], rc, rtol=1e-5, atol=1e-6), float((rr[cs] - rc).abs().max())
+        assert torch.allclose(ar[cs], ra, rtol=1e-5, atol=1e-6)
+        (rr.sum(dim=(1, 2, 3)) * wcam).sum().backward()
         for k in mine:
             assert _rel(mine[k].grad, ref[k].grad[sl]) < 1e-4, (k, _rel(mine[k].grad, ref[k].grad[sl]))
         if sparse and not packed:
@@ -118,16 +128,16 @@ def _gaussian_sharded(rank, world, port, backend, packed, sparse=True):
             # 2nd call: chunk capacity from the first call's statistics (1.25 x the visible fraction) -- same result
             assert D._SPARSE["stats"] is not None
             rc2, _, _ = rasterization(mine["means"], mine["quats"], mine["scales"], mine["opacities"], mine["sh"],
-                                      V[rank: rank + 1], K[rank: rank + 1], W, H, sh_degree=3, packed=False, distributed=True)
+                                      V[cs], K[cs], W, H, sh_degree=3, packed=False, distributed=True)
             assert D._SPARSE["frac"] <= 1.0 and torch.equal(rc2, rc), (D._SPARSE["frac"], float((rc2 - rc).abs().max()))
             # 3rd call: capacity forced far too small -> every rank sees the overflow flag and repeats at full capacity
             D._SPARSE["frac"], D._SPARSE["stats"] = 0.01, None
             for p in mine.values():
                 p.grad = None
             rc3, _, _ = rasterization(mine["means"], mine["quats"], mine["scales"], mine["opacities"], mine["sh"],
-                                      V[rank: rank + 1], K[rank: rank + 1], W, H, sh_degree=3, packed=False, distributed=True)
+                                      V[cs], K[cs], W, H, sh_degree=3, packed=False, distributed=True)
             assert torch.equal(rc3, rc) and D._SPARSE["frac"] == 1.0
-            (rc3.sum() * (rank + 1.0)).backward()
+            (rc3.sum(dim=(1, 2, 3)) * wcam[cs]).sum().backward()
             for k in mine:
                 assert _rel(mine[k].grad, ref[k].grad[sl]) < 1e-4, (k, "after overflow", _rel(mine[k].grad, ref[k].grad[sl]))
         dist.barrier()
@@ -157,9 +167,11 @@ def test_camera_sharded_world2():
     _spawn(_camera_sharded, (2, _free_port(), _backend_for(2)), 2)
 
 
-@pytest.mark.parametrize("packed,sparse", [(False, True), (False, False), (True, True)])
-def test_gaussian_sharded_world2(packed, sparse):
-    _spawn(_gaussian_sharded, (2, _free_port(), _backend_for(2), packed, sparse), 2)
+@pytest.mark.parametrize("packed,sparse,cpr", [(False, True, 1), (False, False, 1), (True, True, 1), (False, True, 2), (False, False, 2),
+                                               (True, True, 2)])
+def test_gaussian_sharded_world2(packed, sparse, cpr):
+    """cpr = cameras per rank (2: four cameras in all, the receiver regroups rows of two cameras per source rank)."""
+    _spawn(_gaussian_sharded, (2, _free_port(), _backend_for(2), packed, sparse, cpr), 2)
 
 
 def test_camera_sharded_rccl_world1():
