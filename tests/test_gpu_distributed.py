@@ -82,7 +82,7 @@ def _camera_sharded(rank, world, port, backend):
         rr.sum().backward()
         for k in params:
             assert _rel(params[k].grad, ref[k].grad) < 1e-4, (k, _rel(params[k].grad, ref[k].grad))
-        assert D.all_gather_int32(world, rank + 10, device=dev) == [10, 11][:world]
+        assert D.all_gather_int32(world, rank + 10, device=dev) == [10, 11, 12][:world]
         dist.barrier()
     finally:  # (no barrier here: after an exception on one rank it would never return)
         dist.destroy_process_group()
@@ -103,7 +103,7 @@ def _gaussian_sharded(rank, world, port, backend, packed, sparse=True, cpr=1):
             V = torch.cat([V, V[:extra] @ Rz], 0)
             K = torch.cat([K, K[:extra]], 0)
         N = base["means"].shape[0]
-        cuts = [0, N // 3, N][: world + 1] if world == 2 else [0, N]  # unequal slices on purpose
+        cuts = {1: [0, N], 2: [0, N // 3, N], 3: [0, N // 5, N // 2, N]}[world]  # unequal slices on purpose
         sl = slice(cuts[rank], cuts[rank + 1])
         mine = {k: v[sl].clone().requires_grad_(True) for k, v in base.items()}
         cs = slice(rank * cpr, (rank + 1) * cpr)  # my cameras
@@ -172,6 +172,12 @@ def test_camera_sharded_world2():
 def test_gaussian_sharded_world2(packed, sparse, cpr):
     """cpr = cameras per rank (2: four cameras in all, the receiver regroups rows of two cameras per source rank)."""
     _spawn(_gaussian_sharded, (2, _free_port(), _backend_for(2), packed, sparse, cpr), 2)
+
+
+@pytest.mark.parametrize("sparse", [True, False])
+def test_gaussian_sharded_world3(sparse):
+    """Three ranks (three chunks per sender, three source blocks per receiver)."""
+    _spawn(_gaussian_sharded, (3, _free_port(), _backend_for(3), False, sparse, 1), 3, deadline_s=240)
 
 
 def test_camera_sharded_rccl_world1():
