@@ -1477,9 +1477,12 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
                 st_empty += (__ballot(valid) == 0ull) ? 1u : 0u;
                 st_empty_a += (__ballot(!(power > 0.f) && (alpha >= ALPHA_MIN)) == 0ull) ? 1u : 0u;
 #endif
-                const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+                // a rejected record gets alpha = 0: then ra = rcp(1) = 1 exactly, Tn = T and facv = 0, i.e. the
+                // transmittance and the colour sums need no select of their own (selects cost 1.5 issue units here)
+                const float av = valid ? alpha : 0.f;
+                const float ra = __builtin_amdgcn_rcpf(1.f - av);
                 const float Tn = T[i] * ra;
-                const float facv = valid ? alpha * Tn : 0.f;
+                const float facv = av * Tn;
                 float D = 0.f;
 #pragma unroll
                 for (int k = 0; k < CDIM; ++k) {
@@ -1489,7 +1492,7 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
                 const float v_alpha = D * Tn + Wq[i] * ra;
                 const float v_sigma = (valid && araw <= 0.999f) ? -araw * v_alpha : 0.f;
                 Wq[i] -= facv * D;
-                T[i] = valid ? Tn : T[i];
+                T[i] = Tn;
                 const float sdx = v_sigma * dx, sdy = v_sigma * dy;
                 S0 += v_sigma;
                 Sx += sdx;
