@@ -81,7 +81,7 @@ def _camera_sharded(rank, world, port, backend):
         assert torch.allclose(rr[rank], rc[0], rtol=1e-5, atol=1e-6)
         rr.sum().backward()
         for k in params:
-            assert _rel(params[k].grad, ref[k].grad) < 1e-4, (k, _rel(params[k].grad, ref[k].grad))
+            assert _rel(params[k].grad, ref[k].grad) < 5e-4, (k, _rel(params[k].grad, ref[k].grad))
         assert D.all_gather_int32(world, rank + 10, device=dev) == [10, 11, 12][:world]
         dist.barrier()
     finally:  # (no barrier here: after an exception on one rank it would never return)
@@ -121,7 +121,7 @@ def _gaussian_sharded(rank, world, port, backend, packed, sparse=True, cpr=1):
         assert torch.allclose(ar[cs], ra, rtol=1e-5, atol=1e-6)
         (rr.sum(dim=(1, 2, 3)) * wcam).sum().backward()
         for k in mine:
-            assert _rel(mine[k].grad, ref[k].grad[sl]) < 1e-4, (k, _rel(mine[k].grad, ref[k].grad[sl]))
+            assert _rel(mine[k].grad, ref[k].grad[sl]) < 5e-4, (k, _rel(mine[k].grad, ref[k].grad[sl]))
         if sparse and not packed:
             from gscodec_studio_amd import distributed as D
 
@@ -139,7 +139,7 @@ def _gaussian_sharded(rank, world, port, backend, packed, sparse=True, cpr=1):
             assert torch.equal(rc3, rc) and D._SPARSE["frac"] == 1.0
             (rc3.sum(dim=(1, 2, 3)) * wcam[cs]).sum().backward()
             for k in mine:
-                assert _rel(mine[k].grad, ref[k].grad[sl]) < 1e-4, (k, "after overflow", _rel(mine[k].grad, ref[k].grad[sl]))
+                assert _rel(mine[k].grad, ref[k].grad[sl]) < 5e-4, (k, "after overflow", _rel(mine[k].grad, ref[k].grad[sl]))
         dist.barrier()
     finally:  # (no barrier here: after an exception on one rank it would never return)
         dist.destroy_process_group()
