@@ -88,7 +88,7 @@ def _camera_sharded(rank, world, port, backend):
         dist.destroy_process_group()
 
 
-def _gaussian_sharded(rank, world, port, backend, packed, sparse=True, cpr=1):
+def _gaussian_sharded(rank, world, port, backend, packed, sparse=True, cpr=1, empty_last=False):
     os.environ["GS_DIST_SPARSE"] = "1" if sparse else "0"  # only the visible rows on the wire / every row
     dev = _setup(rank, world, port, backend)
     try:
@@ -104,6 +104,8 @@ def _gaussian_sharded(rank, world, port, backend, packed, sparse=True, cpr=1):
             K = torch.cat([K, K[:extra]], 0)
         N = base["means"].shape[0]
         cuts = {1: [0, N], 2: [0, N // 3, N], 3: [0, N // 5, N // 2, N]}[world]  # unequal slices on purpose
+        if empty_last:  # the last rank owns no gaussian at all (it still renders its cameras over everybody else's)
+            cuts = cuts[:-2] + [N, N] if world > 1 else cuts
         sl = slice(cuts[rank], cuts[rank + 1])
         mine = {k: v[sl].clone().requires_grad_(True) for k, v in base.items()}
         cs = slice(rank * cpr, (rank + 1) * cpr)  # my cameras
@@ -172,6 +174,11 @@ def test_camera_sharded_world2():
 def test_gaussian_sharded_world2(packed, sparse, cpr):
     """cpr = cameras per rank (2: four cameras in all, the receiver regroups rows of two cameras per source rank)."""
     _spawn(_gaussian_sharded, (2, _free_port(), _backend_for(2), packed, sparse, cpr), 2)
+
+
+@pytest.mark.parametrize("sparse", [True, False])
+def test_gaussian_sharded_world2_one_rank_without_gaussians(sparse):
+    _spawn(_gaussian_sharded, (2, _free_port(), _backend_for(2), False, sparse, 1, True), 2)
 
 
 @pytest.mark.parametrize("sparse", [True, False])
