@@ -26,8 +26,10 @@ The JSON line carries two extra objects:
                 points, timed live with HIP events on the launch stream inside the timed
                 region): algorithmic bytes / average
                 duration vs the 8 TB/s HBM peak.
-  cpu_baseline  the CPU oracle (oracle/gs_oracle.c, a port -- kind "port") timed on this host on a
-                bounded sample (scene_grid=1: 111,785 gaussians, same camera / resolution / SH).
+  cpu_baseline  the CPU oracle (oracle/gs_oracle.c, a port -- kind "port") timed on this host on the bench workload itself
+                (1 warm-up + 3 fwd+bwd passes, ~3 s each on 128 threads; --cpu-scene-grid 1 selects 1/9 of it).
+Also reported: peak_mem_gb / step_mem_gb (the reference protocol's Mem column), ms_per_step_dense_image_grad (the same step
+with a dense [C,H,W,3] image gradient instead of the protocol's broadcast one), psnr_vs_oracle (config 1).
 """
 import argparse
 import json
@@ -84,7 +86,11 @@ def parse():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--quantize", action="store_true", help="run the compression-simulation hooks before each render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scene-grid", type=int, default=1)
+    ap.add_argument("--cpu-scene-grid", type=int, default=0,
+                    help="scene_grid of the cpu_baseline sample (0 = the bench scene itself: ~3 s per pass on 128 threads)")
+    ap.add_argument("--min-timed-s", type=float, default=0.5,
+                    help="the exactly-K-step timed region is repeated until this much time has been measured")
+    ap.add_argument("--no-extras", action="store_true", help="skip the dense-image-gradient variant and the config-1 PSNR")
     ap.add_argument("--breakdown", action="store_true", help="print per-entry-point timings to stderr")
     ap.add_argument("--dp-mode", choices=["auto", "camera", "gaussian", "gaussian_dense"], default="auto",
                     help="multi-GPU exchange pattern (see the module docstring); ignored with one GPU")
@@ -155,7 +161,8 @@ def cpu_baseline(args, sh_degree):
     from gscodec_studio_amd._helper import sh_workload
     from oracle import gs_oracle as O
 
-    w = sh_workload(scene_grid=args.cpu_scene_grid, width=args.width, height=args.height, n_cameras=1,
+    grid = args.cpu_scene_grid or args.scene_grid
+    w = sh_workload(scene_grid=grid, width=args.width, height=args.height, n_cameras=1,
                     sh_degree=sh_degree, device="cpu")
     a = {k: w[k].numpy() for k in ("means", "quats", "scales", "opacities", "sh", "viewmats", "Ks")}
     W, H = w["width"], w["height"]
@@ -175,17 +182,36 @@ def cpu_baseline(args, sh_degree):
                          m["radii"], m["conics"], None, v_m2, np.zeros_like(m["depths"]), v_cn, None, need_viewmats=False)
         return time.perf_counter() - t0
 
+    n = a["means"].shape[0]
     one_pass()  # warm-up (page faults, OpenMP thread start)
     runs = sorted(one_pass() for _ in range(3))
     dt = runs[1]  # median of 3
-    n = a["means"].shape[0]
+    how = ("the bench workload itself (same scene, camera, resolution)" if grid == args.scene_grid else
+           f"scene_grid={grid}: 1/{args.scene_grid ** 2 // grid ** 2} of the bench scene, same camera and resolution")
+    how += "; 1 warm-up + 3 runs, median"
     return {
         "value": n / dt / 1e6, "unit": "Msplats/s", "cores": int(O.lib().orc_num_threads()), "kind": "port",
-        "sample": f"oracle/gs_oracle.c fwd+bwd, scene_grid={args.cpu_scene_grid} ({n} gaussians, 1/"
-                  f"{args.scene_grid ** 2 // args.cpu_scene_grid ** 2} of the bench scene), same camera, "
-                  f"{W}x{H}, SH deg {sh_degree}; 1 warm-up + 3 runs, median {dt:.1f} s wall",
+        "sample": f"oracle/gs_oracle.c fwd+bwd (C restatement of the reference's path, OpenMP), {n} gaussians, {W}x{H}, "
+                  f"SH deg {sh_degree}; {how}: {dt:.1f} s wall",
         "host_cpus": os.cpu_count(),
     }
+
+
+def psnr_vs_oracle(dev):
+    """BASELINE config 1 (the reference's own CPU-runnable case): garden crop, 111,785 gaussians, camera 0, 648x420, RGB --
+    PSNR of the GPU render against the CPU oracle's render of the same splats (peak 1.0)."""
+    from gscodec_studio_amd import rasterization
+    from gscodec_studio_amd._helper import load_test_data
+    from oracle import gs_oracle as O
+
+    means, quats, scales, opac, rgb, viewmats, Ks, W, H = load_test_data(device=dev, scene_grid=1)
+    with torch.no_grad():
+        rc, _, _ = rasterization(means, quats, scales, opac, rgb, viewmats[:1], Ks[:1], W, H, packed=False)
+    c = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    o_rc, _, _ = O.rasterization(c(means), c(quats), c(scales), c(opac), c(rgb), c(viewmats[:1]), c(Ks[:1]), W, H)
+    mse = float(np.mean((c(rc).astype(np.float64) - o_rc.astype(np.float64)) ** 2))
+    return {"db": (10 * np.log10(1.0 / mse)) if mse > 0 else float("inf"), "mse": mse,
+            "config": f"config 1: garden crop {means.shape[0]} gaussians, camera 0, {W}x{H}, RGB, GPU render vs CPU oracle render"}
 
 
 def main():
@@ -232,6 +258,7 @@ def main():
         sim = CompressionSimulation(entropy_model_enable=False, entropy_steps={})
 
     last_meta = {}
+    dense_grad = [None]  # set to a dense tensor of ones for the dense-image-gradient variant
 
     def make_step(mode):
         """One fwd+bwd pass (+ the mode's exchange).  `camera`: all splats on every rank; `gaussian`: a contiguous
@@ -267,7 +294,10 @@ def main():
             rc, ra, meta = rasterization(params["means"], quats, scales, opac, sh, viewmats, Ks,
                                          w["width"], w["height"], sh_degree=args.sh_degree, packed=False,
                                          distributed=gaussian)
-            rc.sum().backward()
+            if dense_grad[0] is None:
+                rc.sum().backward()  # the reference's timing protocol (profiling/main.py:125-133): a broadcast gradient of ones
+            else:
+                rc.backward(gradient=dense_grad[0])  # a training loss hands the compositing backward a DENSE [C,H,W,3] gradient
             if mode == "camera" and use_pg:
                 all_reduce_splat_grads(params, world_size=world, average=False)
             last_meta.update(meta)
@@ -320,17 +350,44 @@ def main():
         for k, v in sorted(per_step.items(), key=lambda kv: -kv[1]):
             print(f"  {k:32s} {v:8.3f} ms/step", file=sys.stderr)
 
-    # timed region: exactly K steps, only the dominant entry point carries events
-    barrier()
-    with CallTimer(B, only={dominant}) as ct:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+    # timed region: exactly K steps between barrier + synchronize on both sides, only the dominant entry point carries
+    # events.  K = 20 steps last ~20 ms, so the region is REPEATED (every repetition bracketed the same way, the number of
+    # repetitions agreed by all ranks) until --min-timed-s has been measured; ms_per_step is total time / total steps.
+    def timed_region(n_steps, timer_only):
         barrier()
-        t1 = time.perf_counter()
-    dom_ms = float(np.mean(ct.totals_ms()[dominant]))
-    elapsed = max_over_ranks(t1 - t0)
-    ms_per_step = elapsed / args.steps * 1e3
+        with CallTimer(B, only=timer_only) as ct_:
+            t0_ = time.perf_counter()
+            for _ in range(n_steps):
+                step()
+            barrier()
+            t1_ = time.perf_counter()
+        return max_over_ranks(t1_ - t0_), ct_
+
+    torch.cuda.reset_peak_memory_stats(dev)
+    mem_before = torch.cuda.memory_allocated(dev)
+    elapsed, ct = timed_region(args.steps, {dominant})
+    dom_all = list(ct.totals_ms()[dominant])
+    peak_mem = torch.cuda.max_memory_allocated(dev)
+    regions = [elapsed]
+    n_rep = int(min(200, max(0, np.ceil(args.min_timed_s / max(elapsed, 1e-6)) - 1)))
+    for _ in range(n_rep):
+        e_, ct_ = timed_region(args.steps, {dominant})
+        regions.append(e_)
+        dom_all += list(ct_.totals_ms()[dominant])
+    dom_ms = float(np.mean(dom_all))
+    ms_per_step = sum(regions) / (len(regions) * args.steps) * 1e3
+    if args.breakdown and rank == 0:
+        print("  regions (ms/step): " + " ".join(f"{r / args.steps * 1e3:.3f}" for r in regions), file=sys.stderr)
+
+    # variant: a DENSE image gradient (what a real training loss produces) next to the broadcast one of the protocol
+    dense_ms = None
+    if not args.no_extras:
+        dense_grad[0] = torch.ones((1, w["height"], w["width"], 3), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            step()
+        e_, _ = timed_region(args.steps, set())
+        dense_ms = e_ / args.steps * 1e3
+        dense_grad[0] = None
 
     if rank == 0:
         meta = last_meta
@@ -347,6 +404,12 @@ def main():
             "value": N * world / (ms_per_step * 1e-3) / 1e6,
             "unit": "Msplats/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "timed": {"regions": len(regions), "steps_per_region": args.steps, "total_s": sum(regions),
+                      "ms_per_step_min_region": min(regions) / args.steps * 1e3, "ms_per_step_max_region": max(regions) / args.steps * 1e3},
+            # reference protocol reports memory too (profiling/main.py:141-151): peak allocation during the timed steps,
+            # and what the steps add on top of the resident scene + parameters
+            "peak_mem_gb": peak_mem / 2**30, "step_mem_gb": (peak_mem - mem_before) / 2**30,
+            "ms_per_step_dense_image_grad": dense_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"BASELINE config 2: load_test_data(scene_grid={args.scene_grid}) -> {N} gaussians, "
@@ -375,6 +438,8 @@ def main():
                 "per_entry_point_ms": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
             },
         }
+        if not args.no_extras and world == 1:
+            out["psnr_vs_oracle"] = psnr_vs_oracle(dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.sh_degree)
     if use_pg:

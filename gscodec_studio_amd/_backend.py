@@ -24,7 +24,21 @@ from typing import Dict, List, Optional, Tuple
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _REPO_DIR = os.path.dirname(_PKG_DIR)
-HEADER_PATH = os.path.join(_REPO_DIR, "include", "gsplat_hip.h")
+
+
+
+def _find_header() -> str:
+    """The ABI header: $GSPLAT_HIP_HEADER, the copy the build puts inside the package (``<pkg>/include``, what an
+    installed / vendored package carries), or the repository's ``include/`` (source checkout)."""
+    cands = [os.environ.get("GSPLAT_HIP_HEADER"), os.path.join(_PKG_DIR, "include", "gsplat_hip.h"),
+             os.path.join(_REPO_DIR, "include", "gsplat_hip.h")]
+    for c in cands:
+        if c and os.path.exists(c):
+            return c
+    return cands[-1]
+
+
+HEADER_PATH = _find_header()
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB", os.path.join(_PKG_DIR, "csrc", "libgsplat_hip.so"))
 
 _SCALARS = {
@@ -86,6 +100,11 @@ def lib() -> ctypes.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C gscodec_studio_amd/csrc`. There is no CPU fallback."
         )
+    if not os.path.exists(HEADER_PATH):
+        raise ImportError(
+            f"gscodec_studio_amd: ABI header gsplat_hip.h not found (looked at $GSPLAT_HIP_HEADER, "
+            f"{os.path.join(_PKG_DIR, 'include')}, {os.path.join(_REPO_DIR, 'include')}); the ctypes prototypes are "
+            "derived from it. `make -C gscodec_studio_amd/csrc` copies it into the package.")
     _PROTOS = parse_header()
     L = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes, _) in _PROTOS.items():

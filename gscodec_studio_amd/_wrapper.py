@@ -1029,6 +1029,7 @@ def rasterize_to_pixels(
     tile_height, tile_width = isect_offsets.shape[1:3]
     assert tile_height * tile_size >= image_height, f"Assert Failed: {tile_height} * {tile_size} >= {image_height}"
     assert tile_width * tile_size >= image_width, f"Assert Failed: {tile_width} * {tile_size} >= {image_width}"
+    assert 1 <= tile_size <= 16, f"tile_size must be in [1, 16] on the HIP backend, got {tile_size}"
 
     return _RasterizeToPixels.apply(
         means2d.contiguous(), conics.contiguous(), colors.contiguous(), opacities.contiguous(), backgrounds,
@@ -1063,10 +1064,13 @@ class _RasterizeToPixels(torch.autograd.Function):
                    B.ptr(opacities), B.ptr(backgrounds), B.ptr(m8), width, height, tile_size, tile_width,
                    tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_colors),
                    B.ptr(render_alphas), B.ptr(last_ids), B.ptr(scratch) if sb else None, sb, _stream(means2d))
-        # scratch carries the forward checkpoints of the depth-segmented backward
+        # scratch carries the forward checkpoints of the depth-segmented backward.  The segmented backward rebuilds
+        # "colour behind the segment" from the FINAL render (B = v_out . (colour_final - colour_ckpt)), so the output is
+        # saved through save_for_backward: autograd then version-checks it and an in-place edit of the returned image
+        # before backward() raises instead of silently corrupting the gradients (the reference does not need its
+        # output in the backward, so this is the one place where in-place post-processing must become out-of-place).
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids,
-                              render_alphas, last_ids, scratch)
-        ctx.render_colors = render_colors.detach()
+                              render_alphas, last_ids, scratch, render_colors)
         ctx.width, ctx.height, ctx.tile_size, ctx.absgrad = width, height, tile_size, absgrad
         ctx.set_materialize_grads(False)
         return render_colors, render_alphas
@@ -1074,8 +1078,7 @@ class _RasterizeToPixels(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_render_colors: Tensor, v_render_alphas: Tensor):
         (means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas,
-         last_ids, scratch) = ctx.saved_tensors
-        render_colors = ctx.render_colors
+         last_ids, scratch, render_colors) = ctx.saved_tensors
         C, tile_height, tile_width = isect_offsets.shape
         channels = colors.shape[-1]
         n_elems = opacities.numel()

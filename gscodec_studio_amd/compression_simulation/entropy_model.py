@@ -106,11 +106,18 @@ class Entropy_factorized_optimized_refactor(nn.Module):
         self._factor = nn.ParameterList([])
         for i in range(len(self.filters) + 1):  # initialisation as reference entropy_model.py:107-124
             init = np.log(np.expm1(1.0 / scale / widths[i + 1]))
-            self._matrices.append(nn.Parameter(torch.full((self.channel, widths[i + 1], widths[i]), float(init))))
+            # the reference also binds every new Parameter to the attributes `matrix` / `bias` / `factor`
+            # (entropy_model.py:112-126), so its state dicts carry those three keys (aliases of the LAST layer's tensors)
+            # and named_parameters() lists the last layer under them: same registration order here, so reference
+            # checkpoints load with strict=True and per-parameter optimizer groups get the same names
+            self.matrix = nn.Parameter(torch.full((self.channel, widths[i + 1], widths[i]), float(init)))
+            self._matrices.append(self.matrix)
             noise = np.random.uniform(-0.5, 0.5, (self.channel, widths[i + 1], 1))
-            self._bias.append(nn.Parameter(torch.from_numpy(noise).float()))
+            self.bias = nn.Parameter(torch.from_numpy(noise).float())
+            self._bias.append(self.bias)
             if i < len(self.filters):
-                self._factor.append(nn.Parameter(torch.zeros(self.channel, widths[i + 1], 1)))
+                self.factor = nn.Parameter(torch.zeros(self.channel, widths[i + 1], 1))
+                self._factor.append(self.factor)
         self.register_buffer("filters_len", torch.tensor(len(self.filters)))
         self.register_buffer("factor_len", torch.tensor(len(self._factor)))
         self.likelihood_bound = float(likelihood_bound)

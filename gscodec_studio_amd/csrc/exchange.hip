@@ -9,12 +9,15 @@
 // HBM-bound: 8 B per element.
 #include "gs_common.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int MAX_PARTS = 8;
 
-constexpr int ROWS_PER_BLOCK = 256;
-constexpr int MAX_WIDTH = 64;
+constexpr int ROWS_PER_BLOCK = 256;   // rows per workgroup for wire rows of up to 64 elements ...
+constexpr int TILE_ELEMS = 15360;     // ... wider rows get fewer rows per workgroup: the LDS tile stays at 60 KB (+ 1 KB of indices)
+constexpr int MAX_WIDTH = TILE_ELEMS; // (the reference's distributed path takes any channel count; 513 + 10 columns is the widest real row)
 
 struct RowParts {
     uint32_t *ptr[MAX_PARTS];
@@ -28,12 +31,12 @@ struct RowParts {
 // One workgroup moves 256 rows through LDS: the wire side is one contiguous chunk (coalesced), and each part is
 // walked in its own element order, so a part whose rows are dense in memory is one contiguous chunk too.
 template <bool PACK>
-__global__ void __launch_bounds__(GS_BLOCK) rows_kernel(uint64_t n_rows, uint32_t width, RowParts t, uint32_t *__restrict__ wire,
+__global__ void __launch_bounds__(GS_BLOCK) rows_kernel(uint64_t n_rows, uint32_t width, uint32_t rpb, RowParts t, uint32_t *__restrict__ wire,
                                                         const int32_t *__restrict__ row_index, int64_t index_stride) {
     extern __shared__ uint32_t tile[];  // [rows][width]
     __shared__ int32_t s_index[ROWS_PER_BLOCK];
-    const uint64_t row0 = (uint64_t)blockIdx.x * ROWS_PER_BLOCK;
-    const uint32_t nr = (uint32_t)min((uint64_t)ROWS_PER_BLOCK, n_rows - row0);
+    const uint64_t row0 = (uint64_t)blockIdx.x * rpb;
+    const uint32_t nr = (uint32_t)min((uint64_t)rpb, n_rows - row0);
     uint32_t *w0 = wire + row0 * width;
     if (t.indexed != 0u) {
         if (threadIdx.x < nr) s_index[threadIdx.x] = row_index[(int64_t)(row0 + threadIdx.x) * index_stride];
@@ -87,11 +90,14 @@ int32_t rows_launch(uint64_t n_rows, int32_t n_parts, void *const *parts, const 
     for (int k = n_parts; k <= MAX_PARTS; ++k) t.begin[k] = w;
     if (n_rows == 0) return 0;
     GS_CHECK_ARG(wire != nullptr, "null pointer");
-    GS_CHECK_ARG(w <= MAX_WIDTH, "wire rows of at most 64 elements");
-    const uint64_t blocks = (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    GS_CHECK_ARG(w <= MAX_WIDTH, "wire rows of at most 15360 elements");
+    // rows per workgroup: 256 up to 64 columns, fewer for wider rows (rpb * w < 2^14 keeps the LDS tile under 64 KB and the
+    // multiply-shift division of the kernel exact)
+    const uint32_t rpb = (uint32_t)std::max(1, std::min(ROWS_PER_BLOCK, TILE_ELEMS / w));
+    const uint64_t blocks = (n_rows + rpb - 1) / rpb;
     GS_CHECK_ARG(blocks < (1ull << 31), "too many rows");
-    hipLaunchKernelGGL(rows_kernel<PACK>, dim3((uint32_t)blocks), dim3(GS_BLOCK), ROWS_PER_BLOCK * w * sizeof(uint32_t),
-                       (hipStream_t)stream, n_rows, (uint32_t)w, t, (uint32_t *)wire, row_index, index_stride);
+    hipLaunchKernelGGL(rows_kernel<PACK>, dim3((uint32_t)blocks), dim3(GS_BLOCK), (size_t)rpb * w * sizeof(uint32_t),
+                       (hipStream_t)stream, n_rows, (uint32_t)w, rpb, t, (uint32_t *)wire, row_index, index_stride);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -129,6 +129,10 @@ def rasterization(
     assert viewmats.shape == (C, 4, 4), viewmats.shape
     assert Ks.shape == (C, 3, 3), Ks.shape
     assert render_mode in ["RGB", "D", "ED", "RGB+D", "RGB+ED"], render_mode
+    # the compositing kernels map a tile onto wave64 quadrants of 8x8 pixels: tiles up to 16x16 (the reference launches
+    # tile_size^2 threads per block, i.e. accepts up to 32; every caller in the reference uses 16).  Checked here, before
+    # projection and binning run, instead of surfacing as a native error afterwards.
+    assert 1 <= tile_size <= 16, f"tile_size must be in [1, 16] on the HIP backend, got {tile_size}"
 
     if sh_degree is None:
         # post-activation values [N, D] or [C, N, D]

@@ -667,6 +667,42 @@ void orc_rasterize_fwd(uint32_t C, uint32_t n_isects, uint32_t channels, const f
     }
 }
 
+/* Test helper (no reference counterpart): per pixel, the largest blending weight alpha_i * T_i that ANY entry of the
+ * pixel's tile list could contribute, thresholds ignored (an entry just under alpha = 1/255 or with sigma just below 0
+ * counts, and the walk continues past the stop).  When a threshold decision of a "borderline" pixel flips between two
+ * exp implementations, ONE entry enters or leaves the sum: the colour moves by at most its own weight plus the rescaling
+ * of everything behind it, i.e. by <= 2 * max_weight * max|colour|.  The parity tests bound the excluded pixels by it. */
+void orc_rasterize_max_weight(uint32_t C, uint32_t n_isects, const float *means2d, const float *conics,
+                              const float *opacities, uint32_t W, uint32_t H, uint32_t tile_size, uint32_t tw, uint32_t th,
+                              const int32_t *tile_offsets, const int32_t *flatten_ids, float *max_weight) {
+    int64_t n_tiles_all = (int64_t)C * tw * th;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t tl = 0; tl < n_tiles_all; ++tl) {
+        uint32_t cam = (uint32_t)(tl / (tw * th)), tile_id = (uint32_t)(tl % (tw * th));
+        uint32_t ty = tile_id / tw, tx = tile_id % tw;
+        int32_t rs = tile_offsets[tl];
+        int32_t re = (tl == n_tiles_all - 1) ? (int32_t)n_isects : tile_offsets[tl + 1];
+        for (uint32_t ly = 0; ly < tile_size; ++ly)
+            for (uint32_t lx = 0; lx < tile_size; ++lx) {
+                uint32_t i = ty * tile_size + ly, j = tx * tile_size + lx;
+                if (i >= H || j >= W) continue;
+                size_t pix = ((size_t)cam * H + i) * W + j;
+                float px = (float)j + 0.5f, py = (float)i + 0.5f, T = 1.f, mw = 0.f;
+                for (int32_t idx = rs; idx < re; ++idx) {
+                    int32_t g = flatten_ids[idx];
+                    const float *xy = means2d + 2 * (size_t)g, *con = conics + 3 * (size_t)g;
+                    float dx = xy[0] - px, dy = xy[1] - py;
+                    float sigma = 0.5f * (con[0] * dx * dx + con[2] * dy * dy) + con[1] * dx * dy;
+                    float alpha = fminf(0.999f, opacities[g] * expf(-fmaxf(sigma, 0.f)));
+                    mw = fmaxf(mw, alpha * T);
+                    if (sigma < 0.f || alpha < 1.f / 255.f) continue;
+                    T = fmaxf(T * (1.0f - alpha), 1e-4f); /* the stop may flip too: keep walking with the floor */
+                }
+                max_weight[pix] = mw;
+            }
+    }
+}
+
 /* rasterize_to_pixels_bwd.cu:105-275, per pixel back-to-front from last_ids.  The per-splat
  * sums (the reference's warp reductions + atomics) are accumulated in double and written
  * as fp32: gradient buffers are overwritten ([n_elems,*]). */

@@ -15,20 +15,54 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_DIR, "_build", "libgs_oracle.so")
+_LIB64_PATH = os.path.join(_DIR, "_build", "libgs_oracle_f64.so")
 _lib = None
+_lib64 = None
+_BITS = [32]
+
+
+class precision:
+    """``with precision(64):`` -- run the oracle functions of this module in float64: the SAME C source compiled with
+    every ``float`` replaced by ``double`` (oracle/Makefile, libgs_oracle_f64.so), numpy arrays in and out as float64.
+    The threshold constants (1/255, 0.999, 1e-4) keep their fp32 values, so it is the reference's algorithm evaluated
+    without rounding noise: the ground truth the gradient tests measure both the HIP kernels and the fp32 oracle against.
+    Only the floating-point stages (projection, SH, compositing) are meaningful in this mode."""
+
+    def __init__(self, bits: int):
+        assert bits in (32, 64)
+        self.bits = bits
+
+    def __enter__(self):
+        _BITS.append(self.bits)
+        return self
+
+    def __exit__(self, *a):
+        _BITS.pop()
+
+
+def _real():
+    return np.float64 if _BITS[-1] == 64 else np.float32
 
 CAMERA_MODELS = {"pinhole": 0, "ortho": 1, "fisheye": 2}
 
 
 def build(force: bool = False) -> str:
     src = os.path.join(_DIR, "gs_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _DIR, "-B" if force else "-s", "_build/libgs_oracle.so"])
+    stale = any(not os.path.exists(q) or os.path.getmtime(q) < os.path.getmtime(src) for q in (_LIB_PATH, _LIB64_PATH))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _DIR] + (["-B"] if force else ["-s"]))
     return _LIB_PATH
 
 
 def lib():
-    global _lib
+    global _lib, _lib64
+    if _BITS[-1] == 64:
+        if _lib64 is None:
+            if not os.path.exists(_LIB64_PATH):
+                build()
+            _lib64 = ctypes.CDLL(_LIB64_PATH)
+            _lib64.orc_isect_count.restype = ctypes.c_int64
+        return _lib64
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
@@ -45,10 +79,14 @@ def _p(a: Optional[np.ndarray]):
 
 
 def _f(a) -> Optional[np.ndarray]:
-    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+    return None if a is None else np.ascontiguousarray(a, dtype=_real())
 
 
-_u32, _u64, _i32, _cf = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int32, ctypes.c_float
+_u32, _u64, _i32 = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int32
+
+
+def _cf(v):
+    return ctypes.c_double(v) if _BITS[-1] == 64 else ctypes.c_float(v)
 
 
 def projection_fwd(means, covars, quats, scales, viewmats, Ks, width, height, eps2d=0.3, near_plane=0.01,
@@ -59,10 +97,10 @@ def projection_fwd(means, covars, quats, scales, viewmats, Ks, width, height, ep
     means, covars, quats, scales, viewmats, Ks = map(_f, (means, covars, quats, scales, viewmats, Ks))
     C, N = viewmats.shape[0], means.shape[0]
     radii = np.zeros((C, N), np.int32)
-    means2d = np.zeros((C, N, 2), np.float32)
-    depths = np.zeros((C, N), np.float32)
-    conics = np.zeros((C, N, 3), np.float32)
-    comp = np.zeros((C, N), np.float32) if calc_compensations else None
+    means2d = np.zeros((C, N, 2), _real())
+    depths = np.zeros((C, N), _real())
+    conics = np.zeros((C, N, 3), _real())
+    comp = np.zeros((C, N), _real()) if calc_compensations else None
     lib().orc_projection_fwd(_u32(C), _u32(N), _p(means), _p(covars), _p(quats), _p(scales), _p(viewmats), _p(Ks),
                              _i32(width), _i32(height), _cf(eps2d), _cf(near_plane), _cf(far_plane),
                              _cf(radius_clip), _i32(CAMERA_MODELS[camera_model]), _i32(int(packed_formula)),
@@ -78,11 +116,11 @@ def projection_bwd(means, covars, quats, scales, viewmats, Ks, width, height, ep
     v_means2d, v_depths, v_conics, v_compensations = map(_f, (v_means2d, v_depths, v_conics, v_compensations))
     radii = np.ascontiguousarray(radii, np.int32)
     C, N = viewmats.shape[0], means.shape[0]
-    v_means = np.zeros((N, 3), np.float32)
-    v_covars = np.zeros((N, 6), np.float32) if covars is not None else None
-    v_quats = np.zeros((N, 4), np.float32) if covars is None else None
-    v_scales = np.zeros((N, 3), np.float32) if covars is None else None
-    v_view = np.zeros((C, 4, 4), np.float32) if need_viewmats else None
+    v_means = np.zeros((N, 3), _real())
+    v_covars = np.zeros((N, 6), _real()) if covars is not None else None
+    v_quats = np.zeros((N, 4), _real()) if covars is None else None
+    v_scales = np.zeros((N, 3), _real()) if covars is None else None
+    v_view = np.zeros((C, 4, 4), _real()) if need_viewmats else None
     lib().orc_projection_bwd(_u32(C), _u32(N), _p(means), _p(covars), _p(quats), _p(scales), _p(viewmats), _p(Ks),
                              _i32(width), _i32(height), _cf(eps2d), _i32(CAMERA_MODELS[camera_model]), _p(radii),
                              _p(conics), _p(compensations), _p(v_means2d), _p(v_depths), _p(v_conics),
@@ -167,8 +205,8 @@ def rasterize_fwd(means2d, conics, colors, opacities, width, height, tile_size, 
     flatten_ids = np.ascontiguousarray(flatten_ids, np.int32)
     C, th, tw = isect_offsets.shape
     D = colors.shape[-1]
-    rc = np.zeros((C, height, width, D), np.float32)
-    ra = np.zeros((C, height, width, 1), np.float32)
+    rc = np.zeros((C, height, width, D), _real())
+    ra = np.zeros((C, height, width, 1), _real())
     li = np.zeros((C, height, width), np.int32)
     bl = np.zeros((C, height, width), np.uint8)
     m = None if masks is None else np.ascontiguousarray(masks, np.uint8)
@@ -178,6 +216,19 @@ def rasterize_fwd(means2d, conics, colors, opacities, width, height, tile_size, 
     if return_borderline:
         return rc, ra, li, bl
     return rc, ra, li
+
+
+def rasterize_max_weight(means2d, conics, opacities, width, height, tile_size, isect_offsets, flatten_ids):
+    """-> [C,H,W]: the largest blending weight alpha * T any single list entry could contribute to the pixel (thresholds
+    ignored): a flipped threshold decision moves the pixel's colour by at most 2 x this x max|colour| (gs_oracle.c)."""
+    means2d, conics, opacities = map(_f, (means2d, conics, opacities))
+    isect_offsets = np.ascontiguousarray(isect_offsets, np.int32)
+    flatten_ids = np.ascontiguousarray(flatten_ids, np.int32)
+    C, th, tw = isect_offsets.shape
+    mw = np.zeros((C, height, width), _real())
+    lib().orc_rasterize_max_weight(_u32(C), _u32(flatten_ids.size), _p(means2d), _p(conics), _p(opacities), _u32(width),
+                                   _u32(height), _u32(tile_size), _u32(tw), _u32(th), _p(isect_offsets), _p(flatten_ids), _p(mw))
+    return mw
 
 
 def rasterize_bwd(means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
@@ -249,11 +300,11 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     if sh_degree is None:
         cols = np.ascontiguousarray(np.broadcast_to(colors[None], (C,) + colors.shape)) if colors.ndim == 2 else colors
     else:
-        c2w = np.linalg.inv(viewmats.astype(np.float64)).astype(np.float32)
+        c2w = np.linalg.inv(viewmats.astype(np.float64)).astype(_real())
         dirs = means[None] - c2w[:, None, :3, 3]
         shs = np.ascontiguousarray(np.broadcast_to(colors[None], (C,) + colors.shape)) if colors.ndim == 3 else colors
         cols = sh_fwd(sh_degree, dirs, shs, masks=radii > 0)
-        cols = np.maximum(cols + 0.5, 0.0).astype(np.float32)
+        cols = np.maximum(cols + 0.5, 0.0).astype(_real())
     tw, th = math.ceil(width / tile_size), math.ceil(height / tile_size)
     tpg, ids, flat = isect_tiles(means2d, radii, depths, tile_size, tw, th)
     offs = isect_offset_encode(ids, C, tw, th)

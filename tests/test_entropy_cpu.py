@@ -88,7 +88,16 @@ def test_module_matches_reference_parameter_layout():
 
     m = M(channel=4)  # default filters (3, 3, 3)
     names = [n for n, _ in m.named_parameters()]
-    assert names == [f"_matrices.{i}" for i in range(4)] + [f"_bias.{i}" for i in range(4)] + [f"_factor.{i}" for i in range(3)]
+    # captured by importing the reference module in the build container (channel=4, default filters): the last layer's
+    # tensors are ALSO bound to the attributes matrix / bias / factor (reference entropy_model.py:112-126), so
+    # named_parameters() lists them under those names and the state dict carries the three alias keys
+    assert names == ["matrix", "bias", "factor", "_matrices.0", "_matrices.1", "_matrices.2", "_bias.0", "_bias.1", "_bias.2",
+                     "_factor.0", "_factor.1"]
+    assert list(m.state_dict().keys()) == ["matrix", "bias", "factor", "filters_len", "factor_len", "_matrices.0", "_matrices.1",
+                                           "_matrices.2", "_matrices.3", "_bias.0", "_bias.1", "_bias.2", "_bias.3", "_factor.0",
+                                           "_factor.1", "_factor.2", "likelihood_lower_bound.bound"]
+    assert m.matrix is m._matrices[3] and m.bias is m._bias[3] and m.factor is m._factor[2]
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()}, strict=True)
     assert [tuple(p.shape) for p in m._matrices] == [(4, 3, 1), (4, 3, 3), (4, 3, 3), (4, 1, 3)]
     assert [tuple(p.shape) for p in m._bias] == [(4, 3, 1), (4, 3, 1), (4, 3, 1), (4, 1, 1)]
     assert [tuple(p.shape) for p in m._factor] == [(4, 3, 1)] * 3

@@ -88,7 +88,7 @@ def _camera_sharded(rank, world, port, backend):
         dist.destroy_process_group()
 
 
-def _gaussian_sharded(rank, world, port, backend, packed, sparse=True, cpr=1, empty_last=False):
+def _gaussian_sharded(rank, world, port, backend, packed, sparse=True, cpr=1, empty_last=False, D=0):
     os.environ["GS_DIST_SPARSE"] = "1" if sparse else "0"  # only the visible rows on the wire / every row
     dev = _setup(rank, world, port, backend)
     try:
@@ -107,24 +107,28 @@ def _gaussian_sharded(rank, world, port, backend, packed, sparse=True, cpr=1, em
         if empty_last:  # the last rank owns no gaussian at all (it still renders its cameras over everybody else's)
             cuts = cuts[:-2] + [N, N] if world > 1 else cuts
         sl = slice(cuts[rank], cuts[rank + 1])
+        shd = 3
+        if D:  # D post-activation feature channels instead of SH (wire rows of 10 + D floats: wider than 64 for D >= 55)
+            base["sh"] = torch.rand(N, D, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+            shd = None
         mine = {k: v[sl].clone().requires_grad_(True) for k, v in base.items()}
         cs = slice(rank * cpr, (rank + 1) * cpr)  # my cameras
         rc, ra, meta = rasterization(mine["means"], mine["quats"], mine["scales"], mine["opacities"], mine["sh"],
-                                     V[cs], K[cs], W, H, sh_degree=3, packed=packed, distributed=True)
-        assert rc.shape == (cpr, H, W, 3)
+                                     V[cs], K[cs], W, H, sh_degree=shd, packed=packed, distributed=True, channel_chunk=128)
+        assert rc.shape == (cpr, H, W, D or 3)
         # a per-camera weight so that a gradient routed to the wrong camera would show
         wcam = torch.arange(1, world * cpr + 1, device=dev, dtype=torch.float32)
         (rc.sum(dim=(1, 2, 3)) * wcam[cs]).sum().backward()
 
         ref = {k: v.clone().requires_grad_(True) for k, v in base.items()}
         rr, ar, _ = rasterization(ref["means"], ref["quats"], ref["scales"], ref["opacities"], ref["sh"], V, K, W, H,
-                                  sh_degree=3, packed=packed)
+                                  sh_degree=shd, packed=packed, channel_chunk=128)
         assert torch.allclose(rr[cs], rc, rtol=1e-5, atol=1e-6), float((rr[cs] - rc).abs().max())
         assert torch.allclose(ar[cs], ra, rtol=1e-5, atol=1e-6)
         (rr.sum(dim=(1, 2, 3)) * wcam).sum().backward()
         for k in mine:
             assert _rel(mine[k].grad, ref[k].grad[sl]) < 5e-4, (k, _rel(mine[k].grad, ref[k].grad[sl]))
-        if sparse and not packed:
+        if sparse and not packed and not D:
             from gscodec_studio_amd import distributed as D
 
             # 2nd call: chunk capacity from the first call's statistics (1.25 x the visible fraction) -- same result
@@ -179,6 +183,13 @@ def test_gaussian_sharded_world2(packed, sparse, cpr):
 @pytest.mark.parametrize("sparse", [True, False])
 def test_gaussian_sharded_world2_one_rank_without_gaussians(sparse):
     _spawn(_gaussian_sharded, (2, _free_port(), _backend_for(2), False, sparse, 1, True), 2)
+
+
+@pytest.mark.parametrize("sparse", [True, False])
+def test_gaussian_sharded_world2_64_channels(sparse):
+    """D = 64 colour channels: wire rows of 72 (dense) / 74 (sparse) floats, beyond the 64 columns one LDS tile of
+    gs_rows_pack used to be limited to (the reference's distributed path takes any D)."""
+    _spawn(_gaussian_sharded, (2, _free_port(), _backend_for(2), False, sparse, 1, False, 64), 2)
 
 
 @pytest.mark.parametrize("sparse", [True, False])

@@ -388,3 +388,30 @@ def test_packed_single_camera_gradients_match_unpacked():
     assert_close(rc1, rc0, 1e-4, 2e-6, "colors", max_bad_frac=1e-3)  # (the packed radius formula differs by design, quirk 1)
     for a, b, name in zip(g1, g0, ("means", "quats", "scales", "opacities", "colors")):
         assert rel_l2(a, b) < 2e-3, (name, rel_l2(a, b))
+
+
+def test_inplace_edit_of_the_render_before_backward_raises():
+    """The segmented backward needs the FINAL render (colour behind a segment = final - checkpoint); the output is therefore
+    saved through save_for_backward, and modifying the returned image in place before backward() must raise autograd's
+    version-counter error instead of silently producing wrong gradients.  Out-of-place post-processing is unaffected."""
+    from gscodec_studio_amd import rasterization
+
+    d = _inputs(n=1500, cams=1, sh_degree=None)
+    P = {k: T(d[k], True) for k in ("means", "quats", "scales", "opacities", "colors")}
+    args = (T(d["viewmats"]), T(d["Ks"]), d["W"], d["H"])
+    rc, ra, _ = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], *args, packed=False)
+    rc.clamp_(0.0, 0.5)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        rc.sum().backward()
+    rc, ra, _ = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], *args, packed=False)
+    torch.clamp(rc, 0.0, 0.5).sum().backward()  # the out-of-place form works
+    assert all(bool(torch.isfinite(p.grad).all()) for p in P.values())
+
+
+def test_tile_size_above_16_is_rejected_up_front():
+    from gscodec_studio_amd import rasterization
+
+    d = _inputs(n=100, cams=1, sh_degree=None)
+    with pytest.raises(AssertionError, match="tile_size"):
+        rasterization(T(d["means"]), T(d["quats"]), T(d["scales"]), T(d["opacities"]), T(d["colors"]), T(d["viewmats"]), T(d["Ks"]),
+                      d["W"], d["H"], packed=False, tile_size=32)

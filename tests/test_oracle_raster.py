@@ -128,3 +128,57 @@ def test_masks_multi_tile_and_empty():
     z = np.zeros((0,), np.int32)
     rc, ra, li = O.rasterize_fwd(means2d, conics, colors, opac, W, H, ts, np.zeros((1, th, tw), np.int32), z)
     assert (rc == 0).all() and (ra == 0).all() and (li == 0).all()
+
+
+def test_float64_build_matches_dense_autograd_to_rounding():
+    """The float64 build of the oracle (same C source, `float` -> `double`) is the ground truth of the GPU gradient tests:
+    here it is pinned against the independent dense float64 torch formulation to 1e-7 (forward and all four gradients;
+    not tighter because the alpha clamp is the fp32 VALUE of 0.999 in the oracle and the double 0.999 in the dense formulation)."""
+    W = H = 16
+    means2d, conics, colors, opac, depths, radii = make_scene(opaque=True, n=150, seed=7)
+    tpg, ids, flat = O.isect_tiles(means2d, radii + 40, depths, 16, 1, 1)
+    offs = O.isect_offset_encode(ids, 1, 1, 1)
+    bg = np.array([[0.3, 0.6, 0.1]], np.float32)
+    with O.precision(64):
+        rc, ra, li, bl = O.rasterize_fwd(means2d, conics, colors, opac, W, H, 16, offs, flat, backgrounds=bg, return_borderline=True)
+    assert rc.dtype == np.float64
+    t = lambda a: torch.tensor(a[0], dtype=torch.float64, requires_grad=True)
+    m_t, c_t, col_t, o_t = t(means2d), t(conics), t(colors), t(opac)
+    d_rgb, d_a, d_last = dense_composite(m_t, c_t, col_t, o_t, torch.tensor(flat.astype(np.int64)), W, H, torch.tensor(bg[0], dtype=torch.float64))
+    ok = bl[0] == 0
+    assert ok.mean() > 0.98
+    # (the dense formulation uses double thresholds 1/255 and 1e-4, the oracle their fp32 values: borderline pixels excluded)
+    assert_close(rc[0][ok], d_rgb.detach().numpy()[ok], 1e-7, 1e-9, "colors f64")
+    assert_close(ra[0][ok], d_a.detach().numpy()[ok], 1e-7, 1e-9, "alphas f64")
+    assert np.array_equal(li[0][ok], d_last.numpy()[ok])
+    rs = np.random.RandomState(1)
+    v_rc = rs.randn(1, H, W, 3) * ok[None, ..., None]
+    v_ra = rs.randn(1, H, W, 1) * ok[None, ..., None]
+    loss = (d_rgb * torch.tensor(v_rc[0])).sum() + (d_a * torch.tensor(v_ra[0])).sum()
+    g_m, g_c, g_col, g_o = torch.autograd.grad(loss, (m_t, c_t, col_t, o_t))
+    with O.precision(64):
+        v_m, v_c, v_col, v_o, _ = O.rasterize_bwd(means2d, conics, colors, opac, W, H, 16, offs, flat, ra, li, v_rc, v_ra, backgrounds=bg)
+    for name, got, ref in (("v_means2d", v_m[0], g_m), ("v_conics", v_c[0], g_c), ("v_colors", v_col[0], g_col), ("v_opacities", v_o[0], g_o)):
+        assert rel_l2(got, ref.numpy()) < 1e-7, (name, rel_l2(got, ref.numpy()))
+
+
+def test_float64_projection_and_sh_match_the_fp32_oracle():
+    """Projection and SH in the float64 build agree with the (reference-pinned) fp32 oracle to fp32 rounding."""
+    from util import garden, garden_sh
+
+    fx = garden(1500, scale_mult=3.0)
+    W, H = fx["width"], fx["height"]
+    args = (fx["means"], None, fx["quats"], fx["scales"], fx["viewmats"][:2], fx["Ks"][:2], W, H)
+    r32 = O.projection_fwd(*args)
+    with O.precision(64):
+        r64 = O.projection_fwd(*args)
+    vis = (r32[0] > 0) & (r64[0] > 0)
+    assert (r32[0] == r64[0]).mean() > 0.999
+    for a, b, name in ((r32[1], r64[1], "means2d"), (r32[2], r64[2], "depths"), (r32[3], r64[3], "conics")):
+        assert_close(a[vis], b[vis], 2e-4, 1e-5, name, max_bad_frac=1e-3)
+    sh = garden_sh(fx["rgb"])
+    dirs = fx["means"][None] - np.linalg.inv(fx["viewmats"][:1])[:, None, :3, 3]
+    c32 = O.sh_fwd(3, dirs, sh[None])
+    with O.precision(64):
+        c64 = O.sh_fwd(3, dirs, sh[None])
+    assert_close(c32, c64, 1e-5, 1e-6, "sh")
