@@ -32,6 +32,7 @@ Also reported: peak_mem_gb / step_mem_gb (the reference protocol's Mem column), 
 with a dense [C,H,W,3] image gradient instead of the protocol's broadcast one), psnr_vs_oracle (config 1).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -354,13 +355,20 @@ def main():
     # events.  K = 20 steps last ~20 ms, so the region is REPEATED (every repetition bracketed the same way, the number of
     # repetitions agreed by all ranks) until --min-timed-s has been measured; ms_per_step is total time / total steps.
     def timed_region(n_steps, timer_only):
-        barrier()
-        with CallTimer(B, only=timer_only) as ct_:
-            t0_ = time.perf_counter()
-            for _ in range(n_steps):
-                step()
+        # the cyclic garbage collector is paused inside the region (a generation-2 sweep over the few thousand event
+        # objects of the timers showed up as one 40 ms stall in every ~10th region); collected between regions instead
+        gc.collect()
+        gc.disable()
+        try:
             barrier()
-            t1_ = time.perf_counter()
+            with CallTimer(B, only=timer_only) as ct_:
+                t0_ = time.perf_counter()
+                for _ in range(n_steps):
+                    step()
+                barrier()
+                t1_ = time.perf_counter()
+        finally:
+            gc.enable()
         return max_over_ranks(t1_ - t0_), ct_
 
     torch.cuda.reset_peak_memory_stats(dev)

@@ -19,11 +19,15 @@ void gs_set_error(const char *fmt, ...) {
 extern "C" int32_t gs_version(void) { return GS_ABI_VERSION; }
 extern "C" const char *gs_last_error(void) { return g_err; }
 
-// GS_RASTER_IMPL=ref selects the one-thread-per-pixel baseline kernels; anything else
-// (default) the wave-per-tile kernels.
-static bool use_ref_raster() {
-    const char *e = getenv("GS_RASTER_IMPL");
-    return e != nullptr && strcmp(e, "ref") == 0;
+// Run-time tuning knobs (segment length, solo threshold, XCD grouping: see rasterize.hip).  Their defaults come from the
+// environment, read once; tests use this entry point to exercise the non-default values.
+extern "C" int32_t gs_set_tuning(const char *key, int32_t value) {
+    GS_CHECK_ARG(key != nullptr, "null key");
+    if (raster_set_tuning(key, value) != 0) {
+        gs_set_error("gs_set_tuning: unknown key '%s'", key);
+        return 1;
+    }
+    return 0;
 }
 
 static int32_t check_raster_args(const RasterArgs &a) {
@@ -61,7 +65,7 @@ extern "C" int32_t gs_rasterize_fwd(
                     render_colors, render_alphas, last_ids, 0u};
     if (int32_t rc = check_raster_args(a)) return rc;
     if (C == 0 || image_width == 0 || image_height == 0) return 0;
-    int32_t rc = use_ref_raster() ? raster_ref_fwd(a, (hipStream_t)stream) : raster_wave_fwd(a, scratch, scratch_bytes, (hipStream_t)stream);
+    int32_t rc = raster_wave_fwd(a, scratch, scratch_bytes, (hipStream_t)stream);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;
@@ -101,7 +105,7 @@ extern "C" int32_t gs_rasterize_bwd(
     }
     if (int32_t rc = check_raster_args(a)) return rc;
     if (C == 0 || image_width == 0 || image_height == 0 || n_isects == 0) return 0;
-    int32_t rc = use_ref_raster() ? raster_ref_bwd(a, ga, (hipStream_t)stream) : raster_wave_bwd(a, ga, render_colors, scratch, scratch_bytes, (hipStream_t)stream);
+    int32_t rc = raster_wave_bwd(a, ga, render_colors, scratch, scratch_bytes, (hipStream_t)stream);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;

@@ -1,5 +1,5 @@
 // rasterize.hip -- R5: per-tile front-to-back alpha compositing, fwd + bwd, wave-per-tile
-// kernels for gfx950 (the default implementation; rasterize_ref.hip is the baseline).
+// kernels for gfx950.
 //
 // Replaces gsplat/cuda/csrc/rasterize_to_pixels_fwd.cu:16-185 and
 // rasterize_to_pixels_bwd.cu:17-277.  Same per-pixel arithmetic and decisions
@@ -26,9 +26,8 @@
 //     pixel of the tile, which the reference skips too.  The next batch's gathers are issued
 //     before the current batch is processed (software prefetch), and inside a batch the next
 //     record is read while the current one is evaluated.
-//   * Tiles are walked heaviest-first (tile_order, built by tile_order_kernel): the longest
-//     list bounds the kernel's critical path (one wave walks it serially), so those waves must
-//     start first, spread over all SIMDs, and run at raised priority (s_setprio).
+//   * The longest lists bound the critical path (their waves run alone at the end of the kernel), so those
+//     waves run at raised priority (s_setprio) and, in the tile forward, without per-batch barriers (SOLO).
 //   * Backward, per (pixel, splat) with the running transmittance T and
 //         D = sum_k colour_k v_out_k,   B = sum_{splats behind} fac D   (a scalar),
 //     v_alpha = D T + (T_final (v_alpha_out - bg . v_out) - B) / (1 - alpha) -- the reference's
@@ -51,6 +50,7 @@
 #include "dpp_reduce.h"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -148,10 +148,10 @@ struct TileGeom {
     uint32_t px0, py0;
 };
 
-GS_DEV TileGeom tile_geom(const RasterArgs &a, const int32_t *__restrict__ order, uint32_t slot) {
+GS_DEV TileGeom tile_geom(const RasterArgs &a, uint32_t slot) {
     TileGeom g;
     const uint32_t tiles = a.tile_width * a.tile_height;
-    g.lin = order != nullptr ? (uint32_t)order[slot] : slot;
+    g.lin = slot;
     g.cam = g.lin / tiles;
     g.tile_id = g.lin % tiles;
     g.range_start = a.tile_offsets[g.lin];
@@ -193,24 +193,14 @@ GS_DEV Rect wave_rect(const RasterArgs &a, const TileGeom &tg, uint32_t q_first)
 // ---------------------------------------------------------------------------
 // CKPT: write per-pixel checkpoints (T, accumulated colour) "before list entry b" for every
 // b = k * seg strictly inside the tile's range, planar: ckpt[k][c][256] with c = 0 (T), 1..CDIM.
-#ifdef GS_ABL
-__device__ unsigned long long g_abl_stats[16];
-__device__ unsigned long long g_abl_wave[65536 * 4];
-__device__ unsigned long long g_abl_bwave[65536 * 2]; // backward work items: (start, end) wall clock
-#endif
 template <int NQ, int CDIM, bool COLOR_LDS, bool CKPT>
-__global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, const int32_t *__restrict__ order, uint32_t cnt, uint32_t ch_off, float *__restrict__ ckpt, int32_t seg) {
+__global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, uint32_t cnt, uint32_t ch_off, float *__restrict__ ckpt, int32_t seg) {
     constexpr int REC = 3;
     __shared__ float4 s_rec[(GS_WAVE + 1) * REC];
     const uint32_t lane = threadIdx.x;
-#if defined(GS_ABL) && GS_ABL == 9
-    const unsigned long long abl_t0 = wall_clock64();
-    const unsigned long long abl_c0 = clock64();
-    unsigned abl_evals = 0;
-#endif
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const uint32_t vitem = xcd_remap(blockIdx.x, gridDim.x, a.xcd_group);
-    const TileGeom tg = tile_geom(a, order, (NQ == 4) ? vitem : (vitem >> 2));
+    const TileGeom tg = tile_geom(a, (NQ == 4) ? vitem : (vitem >> 2));
     const uint32_t q_first = (NQ == 4) ? 0u : (vitem & 3u);
     const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels + ch_off : nullptr;
 
@@ -297,9 +287,6 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
         const bool live = have && cull_prepare(s, cs) && rect_touch(s, cs, rect.x0, rect.x1, rect.y0, rect.y1);
         const unsigned long long lm = __ballot(live);
         const int count = __popcll(lm);
-#if defined(GS_ABL) && GS_ABL == 9
-        abl_evals += count;
-#endif
         if (live) {
             const int slot = __popcll(lm & lt_mask);
             float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
@@ -402,15 +389,6 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
                 a.render_colors[pix[i] * a.channels + ch_off + k] = bg ? out[i][k] + Tf * bg[k] : out[i][k];
         a.last_ids[pix[i]] = cur[i];
     }
-#if defined(GS_ABL) && GS_ABL == 9
-    if (lane == 0 && blockIdx.x < 65536u) {
-        const unsigned long long t1 = wall_clock64();
-        g_abl_wave[blockIdx.x * 4 + 0] = abl_t0;
-        g_abl_wave[blockIdx.x * 4 + 1] = t1;
-        g_abl_wave[blockIdx.x * 4 + 2] = ((unsigned long long)(tg.range_end - tg.range_start) << 32) | abl_evals;
-        g_abl_wave[blockIdx.x * 4 + 3] = (clock64() - abl_c0) << 24;
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -420,7 +398,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
 // (rect_touch) and writes its record once; four ballots per wave give one 64-bit mask per
 // (64-entry sub-batch, quadrant).  After one barrier, wave q walks the set bits of "its" four
 // masks (s_ff1 on SGPRs) and reads the records as LDS broadcasts.
-// Why (measured with per-wave timestamps, tools/abl_run.py): with one independent wave per
+// Why (measured with per-wave timestamps): with one independent wave per
 // quadrant the kernel's duration was the life of the heaviest waves (list 5-6k entries, 311 us of
 // a 320 us kernel), and ~60% of that was the exposed latency of the two dependent gathers
 // (flatten_ids -> splat) once per 64 entries, because culling leaves only ~15 records to
@@ -431,71 +409,23 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
 // Sub-batches are aligned to multiples of 64 of the GLOBAL list index, so a checkpoint boundary
 // (multiple of seg) always coincides with a sub-batch start.
 // ---------------------------------------------------------------------------
-// Depth-split of HEAVY tiles (list length >= PartArgs::heavy_min): the list is cut at global multiples of
-// `plen` into parts that run as independent workgroups.
-//   MODE 2 (prepass)  : per part and pixel, the transmittance product t_k of the part alone (no colour).
-//   MODE 1 (part)     : the normal compositing of one part, started from T = prod_{j<k} t_j, writing partial
-//                       colour / end transmittance (negative = stopped inside) / last id to the part arrays.
-//   MODE 0 (tile)     : whole tiles; heavy ones return at once (their parts do the work).
-// raster_combine_kernel then adds up the parts of a tile in order, writes the image and turns the
-// part-local checkpoints into global ones.  A part started beyond a pixel's stopping point sees
-// T <= 1e-4 and composites nothing, so the result is the sequential algorithm's (up to the association
-// of the transmittance product).  Why: the kernel's duration was the serial walk of the heaviest tiles
-// (4.5-6 k entries: 280 of 300 us), everything else finished in half that time.
-struct PartArgs {
-    const uint2 *items;      // (tile, k): list entries [k*plen, (k+1)*plen) of that tile; parts of a tile are consecutive
-    const uint32_t *n_items; // device counter
-    float *tpart;            // [slot][256]        MODE 2 out, MODE 1 in
-    float *cpart;            // [slot][CDIM][256]  MODE 1 out
-    float *tend;             // [slot][256]        MODE 1 out: T at the part's end, negated when the pixel stopped inside
-    int32_t *curp;           // [slot][256]        MODE 1 out: last composited list index or -1
-    int32_t plen, heavy_min; // heavy_min == 0: no depth split
-    uint32_t max_parts;      // grid slots reserved for parts in the mixed launch
-    int32_t solo_min;        // whole tiles with at least this many entries run their four waves independently (0: never)
-};
-
-template <int CDIM, bool CKPT, int MODESET>
-__global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, const int32_t *__restrict__ order, float *__restrict__ ckpt, int32_t seg, PartArgs pa) {
+template <int CDIM, bool CKPT>
+__global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, float *__restrict__ ckpt, int32_t seg, int32_t solo_min) {
     constexpr int REC = 3;
     constexpr int BATCH = 256;
-    // MODESET 0: whole tiles.  2: prepass of the parts.  3: ONE launch that runs the parts (blocks
-    // [0, pa.max_parts), dispatched first) AND the light tiles (the rest) so that both overlap.
-    const int mode = (MODESET == 3) ? (blockIdx.x < pa.max_parts ? 1 : 0) : MODESET;
-    const uint32_t bid = (MODESET == 3 && mode == 0) ? blockIdx.x - pa.max_parts : blockIdx.x;
     // records of both buffers in ONE array + a null record (alpha = 0) that pads every list to a multiple of four
     __shared__ float4 s_rec[2 * BATCH * REC + REC];
     constexpr uint32_t NULL_REC_OFF = 2u * BATCH * REC * 16u; // byte offset of the null record
     // per (buffer, sub-batch, quadrant): byte offsets (into s_rec) of the records that touch the quadrant, in list order
-#ifdef GS_FWD_L32
-    typedef uint32_t list_t; // (measured: 34 KB of LDS = 4 workgroups per CU, 0.252 ms against 0.244 ms)
-#else
-    typedef uint16_t list_t; // 16-bit entries keep the workgroup under 32 KB of LDS (5 per CU) for one extraction per record
-#endif
+    typedef uint16_t list_t; // 16-bit entries keep the workgroup under 32 KB of LDS (5 per CU); 32-bit ones measured 0.252 vs 0.244 ms
     __shared__ __attribute__((aligned(16))) list_t s_list[2][4][4][72];
     __shared__ unsigned long long s_mask[2][4][4]; // [buffer][sub-batch (= staging wave)][quadrant]
     __shared__ uint32_t s_done[2][4];              // [buffer][quadrant]
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6); // staging sub-batch AND composited quadrant
-#if defined(GS_ABL) && GS_ABL == 9
-    const unsigned long long abl_t0 = wall_clock64();
-    const unsigned long long abl_c0 = clock64();
-    unsigned abl_evals = 0;
-    unsigned long long abl_bar = 0;
-#endif
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     if (tid < REC) s_rec[2 * BATCH * REC + tid] = make_float4(0.f, tid == 1 ? -__builtin_inff() : 0.f, 0.f, 0.f); // log2(opacity) = -inf
-    uint32_t tile_slot, part_k = 0, part_slot = 0;
-    if (mode == 0) {
-        tile_slot = xcd_remap(bid, (MODESET == 3) ? gridDim.x - pa.max_parts : gridDim.x, a.xcd_group);
-    } else {
-        const uint32_t n_items = *pa.n_items; // the grid is an upper bound
-        if (bid >= n_items) return;
-        part_slot = xcd_remap(bid, n_items, 4u);
-        const uint2 it = pa.items[part_slot];
-        tile_slot = it.x;
-        part_k = it.y;
-    }
-    TileGeom tg = tile_geom(a, order, tile_slot);
+    const TileGeom tg = tile_geom(a, xcd_remap(blockIdx.x, gridDim.x, a.xcd_group));
     const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels : nullptr;
 
     const uint32_t ox = lx + 8u * (w & 1u), oy = ly + 8u * (w >> 1);
@@ -504,19 +434,12 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     const float px = (float)x + 0.5f, py = (float)y + 0.5f;
     const size_t pix = ((size_t)tg.cam * a.image_height + y) * a.image_width + x;
 
-    if (mode == 0 && a.masks != nullptr && !a.masks[tg.lin]) {
+    if (a.masks != nullptr && !a.masks[tg.lin]) {
         if (inside) {
 #pragma unroll
             for (int k = 0; k < CDIM; ++k) a.render_colors[pix * CDIM + k] = bg ? bg[k] : 0.f;
         }
         return;
-    }
-    if (mode == 0 && pa.heavy_min > 0 && tg.range_end - tg.range_start >= pa.heavy_min) return; // done by its parts
-    const int32_t tile_start = tg.range_start;
-    const int32_t part_k0 = tile_start / (pa.plen > 0 ? pa.plen : 1); // first part index of this tile
-    if (mode != 0) { // restrict the walk to this part
-        tg.range_start = max(tg.range_start, (int32_t)part_k * pa.plen);
-        tg.range_end = min(tg.range_end, ((int32_t)part_k + 1) * pa.plen);
     }
 
     float qx0[4], qx1[4], qy0[4], qy1[4];
@@ -529,15 +452,10 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     }
 
     float T = 1.f, out[CDIM]; // T freezes at the stopping splat: it is the transmittance in front of it
-    int32_t cur = (mode == 1) ? -1 : 0;
+    int32_t cur = 0;
     bool done = !inside;
 #pragma unroll
     for (int k = 0; k < CDIM; ++k) out[k] = 0.f;
-    if (mode == 1) { // transmittance in front of this part = product of the earlier parts' products
-        const uint32_t p = w * 64u + lane;
-        for (uint32_t j = (uint32_t)part_k0; j < part_k; ++j) T *= pa.tpart[(size_t)(part_slot - (part_k - j)) * 256 + p];
-        done = done || (T <= 1e-4f); // cannot composite any more: the first valid splat would stop it
-    }
 
     const int32_t n = tg.range_end - tg.range_start;
     const int32_t base0 = tg.range_start & ~(GS_WAVE - 1);
@@ -573,11 +491,9 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     Staged nxt;
     gather(id_cur, nxt);
 
-    // first boundary this workgroup stores: strictly inside the list -- a later part also owns the boundary
-    // AT its start (the state "before entry k*plen" is its initial state)
-    int32_t next_b = 0x7fffffff;
-    if (CKPT && MODESET != 2) next_b = (mode == 1 && tg.range_start > tile_start) ? tg.range_start : (tg.range_start / seg + 1) * seg;
-    int32_t next_k = (CKPT && MODESET != 2) ? next_b / seg : 0;
+    // first boundary this workgroup stores: strictly inside the list
+    int32_t next_b = CKPT ? (tg.range_start / seg + 1) * seg : 0x7fffffff;
+    int32_t next_k = CKPT ? next_b / seg : 0;
     auto store_ckpt = [&]() {
         float *base = ckpt + (size_t)next_k * (CDIM + 1) * 256;
         const uint32_t p = w * 64u + lane;
@@ -587,10 +503,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     };
 
     // ---- the record walk of one (sub-batch, quadrant) list, shared by the cooperative and the solo path
-#ifndef GS_FWD_G
-#define GS_FWD_G 4
-#endif
-    constexpr int G = GS_FWD_G; // 4 or 2 (lists are padded to a multiple of four either way)
+    constexpr int G = 4; // records per iteration (lists are padded to a multiple of four)
     struct alignas(sizeof(list_t) * G) Pack { list_t v[G]; };
     auto walk = [&](const list_t *lst, const uint32_t cnt, uint32_t &cur_off) {
             // FOUR records per iteration, in one basic block: a lone wave issues one instruction per
@@ -635,12 +548,6 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
                     ok[g] = !(power > 0.f) && (alpha >= ALPHA_MIN);
                     a_eff[g] = ok[g] ? alpha : 0.f;
                 }
-                if (MODESET == 2) { // transmittance product only; frozen once it cannot matter any more
-#pragma unroll
-                    for (int g = 0; g < G; ++g) T = done ? T : T - T * a_eff[g];
-                    done = done || (T <= 1e-4f);
-                    continue;
-                }
                 // T is FROZEN at the stopping splat (= the transmittance in front of it, what the epilogue and the
                 // checkpoints need), so a live pixel always has T > 1e-4 and a rejected record (a_eff = 0) cannot stop it
 #pragma unroll
@@ -666,7 +573,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
     // entries run alone at the end of the kernel and set its duration.  There every wave walks the whole list by itself,
     // 64 entries at a time, culling against its own quadrant only: no barrier, its time is its own work, and a quadrant
     // that is done leaves.  (4x the gathers for these tiles -- 18 % of the pairs at config 2.)
-    const bool solo = MODESET == 0 && pa.solo_min > 0 && n >= pa.solo_min;
+    const bool solo = solo_min > 0 && n >= solo_min;
     if (solo) {
         float rx0 = qx0[0], rx1 = qx1[0], ry0 = qy0[0], ry1 = qy1[0];
 #pragma unroll
@@ -763,10 +670,6 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
             if (lane == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) s_mask[buf][w][q] = m[q];
-#if defined(GS_ABL) && GS_ABL == 5
-#pragma unroll
-                for (int q = 0; q < 4; ++q) s_mask[buf][w][q] = 0ull; // ablation: staging only, no record evaluation
-#endif
                 s_done[buf][w] = wave_done ? 1u : 0u;
             }
         }
@@ -775,13 +678,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
         if (b + 1 < num_batches) gather(id_cur, nxt);
         id_nxt = (b + 2 < num_batches) ? load_id(batch_start + 2 * BATCH + (int32_t)tid) : -1;
         // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the gathers just issued
-#if defined(GS_ABL) && GS_ABL == 9
-        const unsigned long long abl_b0 = clock64();
-#endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#if defined(GS_ABL) && GS_ABL == 9
-        abl_bar += clock64() - abl_b0;
-#endif
         {
             const uint32_t d0 = s_done[buf][0], d1 = s_done[buf][1], d2 = s_done[buf][2], d3 = s_done[buf][3];
             if (d0 & d1 & d2 & d3) break; // every pixel of the tile is finished (block-uniform)
@@ -802,9 +699,6 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
             m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) |
                 (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)m); // (the builtin returns int: no sign extension)
             if (m == 0ull) continue;
-#if defined(GS_ABL) && GS_ABL == 9
-            abl_evals += __popcll(m);
-#endif
             walk(&s_list[buf][sub][w][0], (uint32_t)__popcll(m), cur_off);
             if (__all(done)) break;
         }
@@ -812,25 +706,13 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
             cur = batch_start + (int32_t)((((cur_off >> 4) - buf * (uint32_t)(BATCH * REC)) * 43691u) >> 17);
     }
 
-    if (CKPT && MODESET != 2 && n > 0) {
+    if (CKPT && n > 0) {
         // boundaries after the last composited record (or after an early exit) carry the final state
         while (next_b < tg.range_end) {
             store_ckpt();
             next_b += seg;
             next_k += 1;
         }
-    }
-    if (MODESET == 2) {
-        pa.tpart[(size_t)part_slot * 256 + w * 64u + lane] = inside ? T : 1.f;
-        return;
-    }
-    if (mode == 1) {
-        const size_t p = (size_t)part_slot * 256 + w * 64u + lane;
-        pa.tend[p] = done ? -T : T;
-        pa.curp[p] = cur;
-#pragma unroll
-        for (int k = 0; k < CDIM; ++k) pa.cpart[((size_t)part_slot * CDIM + k) * 256 + w * 64u + lane] = out[k];
-        return;
     }
     if (inside) {
         const float Tf = T;
@@ -839,133 +721,15 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, cons
         for (int k = 0; k < CDIM; ++k) a.render_colors[pix * CDIM + k] = bg ? out[k] + Tf * bg[k] : out[k];
         a.last_ids[pix] = cur;
     }
-#if defined(GS_ABL) && GS_ABL == 9
-    if (mode == 0 && lane == 0 && bid * 4 + w < 65536u) {
-        const uint32_t slot = bid * 4 + w;
-        g_abl_wave[slot * 4 + 0] = abl_t0;
-        g_abl_wave[slot * 4 + 1] = wall_clock64();
-        g_abl_wave[slot * 4 + 2] = ((unsigned long long)n << 32) | abl_evals;
-        g_abl_wave[slot * 4 + 3] = ((clock64() - abl_c0) << 24) | (abl_bar >> 8 & 0xffffffull);
-    }
-#endif
-}
-
-// (tile, k) items of the heavy tiles: every global part [k*plen, (k+1)*plen) that intersects the tile's range
-struct HeavyTile {
-    uint32_t tile, first_slot, n_parts, k0;
-};
-
-__global__ void __launch_bounds__(GS_BLOCK) fwd_parts_kernel(uint32_t n_tiles_all, uint32_t n_isects, const int32_t *__restrict__ offsets,
-                                                             const uint8_t *__restrict__ masks, int32_t plen, int32_t heavy_min,
-                                                             uint32_t *__restrict__ counters /* [1] parts, [2] heavy tiles */,
-                                                             uint2 *__restrict__ items, HeavyTile *__restrict__ heavy) {
-    const uint32_t t = blockIdx.x * GS_BLOCK + threadIdx.x;
-    if (t >= n_tiles_all) return;
-    const int32_t rs = offsets[t];
-    const int32_t re = (t + 1 == n_tiles_all) ? (int32_t)n_isects : offsets[t + 1];
-    if (re - rs < heavy_min) return;
-    if (masks != nullptr && !masks[t]) return;
-    const int32_t k0 = rs / plen, k1 = (re - 1) / plen;
-    const uint32_t np = (uint32_t)(k1 - k0 + 1);
-    const uint32_t slot = atomicAdd(&counters[1], np);
-    const uint32_t h = atomicAdd(&counters[2], 1u);
-    heavy[h] = {t, slot, np, (uint32_t)k0};
-    for (uint32_t j = 0; j < np; ++j) items[slot + j] = make_uint2(t, (uint32_t)k0 + j);
-}
-
-// One workgroup per heavy tile, one thread per pixel (same pixel <-> thread map as the tile kernel):
-// sums the parts in order, writes the image, and rewrites the tile's checkpoints in place -- colour
-// becomes global (part-local + colour of the earlier parts), and every boundary behind the pixel's
-// stopping point carries the final state, exactly what the undivided walk stores.
-template <int CDIM>
-__global__ void __launch_bounds__(256) raster_combine_kernel(RasterArgs a, float *__restrict__ ckpt, int32_t seg, PartArgs pa,
-                                                              const HeavyTile *__restrict__ heavy, const uint32_t *__restrict__ counters) {
-    if (blockIdx.x >= counters[2]) return;
-    const HeavyTile ht = heavy[blockIdx.x];
-    const TileGeom tg = tile_geom(a, nullptr, ht.tile);
-    const uint32_t p = threadIdx.x, w = p >> 6, lane = p & 63u;
-    const uint32_t ox = (lane & 7u) + 8u * (w & 1u), oy = (lane >> 3) + 8u * (w >> 1);
-    const uint32_t x = tg.px0 + ox, y = tg.py0 + oy;
-    const bool inside = ox < a.tile_size && oy < a.tile_size && x < a.image_width && y < a.image_height;
-    float C_acc[CDIM];
-#pragma unroll
-    for (int k = 0; k < CDIM; ++k) C_acc[k] = 0.f;
-    bool stopped = false;
-    float T_stop = 1.f, T_last = 1.f;
-    int32_t last = -1;
-    for (uint32_t j = 0; j < ht.n_parts; ++j) {
-        const size_t slot = (size_t)ht.first_slot + j;
-        const int32_t part_start = max(tg.range_start, (int32_t)(ht.k0 + j) * pa.plen);
-        const int32_t part_end = min(tg.range_end, (int32_t)(ht.k0 + j + 1) * pa.plen);
-        if (ckpt != nullptr) {
-            const int32_t kk0 = (j == 0) ? tg.range_start / seg + 1 : part_start / seg;
-            for (int32_t kk = kk0; kk * seg < part_end; ++kk) {
-                float *base = ckpt + (size_t)kk * (CDIM + 1) * 256;
-                if (stopped) base[p] = T_stop;
-#pragma unroll
-                for (int k = 0; k < CDIM; ++k) base[(k + 1) * 256 + p] = stopped ? C_acc[k] : base[(k + 1) * 256 + p] + C_acc[k];
-            }
-        }
-        const float te = pa.tend[slot * 256 + p];
-#pragma unroll
-        for (int k = 0; k < CDIM; ++k) C_acc[k] += pa.cpart[(slot * CDIM + k) * 256 + p];
-        const int32_t c = pa.curp[slot * 256 + p];
-        if (c >= 0) last = c;
-        if (!stopped) {
-            if (te < 0.f) {
-                stopped = true;
-                T_stop = -te;
-            } else {
-                T_last = te;
-            }
-        }
-    }
-    if (!inside) return;
-    const float Tf = stopped ? T_stop : T_last;
-    const size_t pix = ((size_t)tg.cam * a.image_height + y) * a.image_width + x;
-    const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels : nullptr;
-    a.render_alphas[pix] = 1.f - Tf;
-#pragma unroll
-    for (int k = 0; k < CDIM; ++k) a.render_colors[pix * CDIM + k] = bg ? C_acc[k] + Tf * bg[k] : C_acc[k];
-    a.last_ids[pix] = last >= 0 ? last : 0;
-}
-
-struct PartPlan { // host view of the depth-split scratch
-    PartArgs pa;
-    HeavyTile *heavy;
-    uint32_t *counters;
-    uint32_t max_parts, max_heavy;
-};
-
-// debug: extra dynamic LDS per workgroup (bytes) to cap the workgroups resident per CU (GS_FWD_LDS_PAD)
-static uint32_t fwd_lds_pad() {
-    const char *e = getenv("GS_FWD_LDS_PAD");
-    return e ? (uint32_t)atoi(e) : 0u;
 }
 
 template <int CDIM>
-void launch_tile_fwd(const RasterArgs &a, const int32_t *order, float *ckpt, int32_t seg, const PartPlan *plan, hipStream_t st) {
-    const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;
-    dim3 grid(n_tiles_all);
-    PartArgs none = {};
-    {
-        const char *e = getenv("GS_RASTER_SOLO"); // debug / A-B: list length from which a tile's waves stop cooperating
-        none.solo_min = e ? atoi(e) : 2048;
-    }
-    if (plan == nullptr || ckpt == nullptr) {
-        if (ckpt != nullptr)
-            hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true, 0>), grid, dim3(256), fwd_lds_pad(), st, a, order, ckpt, seg, none);
-        else
-            hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, false, 0>), grid, dim3(256), 0, st, a, order, ckpt, seg, none);
-        return;
-    }
-    const PartArgs &pa = plan->pa;
-    hipLaunchKernelGGL(fwd_parts_kernel, dim3(gs_div_up(n_tiles_all, GS_BLOCK)), dim3(GS_BLOCK), 0, st, n_tiles_all, a.n_isects,
-                       a.tile_offsets, a.masks, pa.plen, pa.heavy_min, plan->counters, const_cast<uint2 *>(pa.items), plan->heavy);
-    hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, false, 2>), dim3(plan->max_parts), dim3(256), 0, st, a, nullptr, ckpt, seg, pa);
-    // parts (first in dispatch order) and light tiles in ONE launch: consecutive launches of a stream do not overlap
-    hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true, 3>), dim3(plan->max_parts + n_tiles_all), dim3(256), 0, st, a, order, ckpt, seg, pa);
-    hipLaunchKernelGGL((raster_combine_kernel<CDIM>), dim3(plan->max_heavy), dim3(256), 0, st, a, ckpt, seg, pa, plan->heavy, plan->counters);
+void launch_tile_fwd(const RasterArgs &a, float *ckpt, int32_t seg, int32_t solo_min, hipStream_t st) {
+    dim3 grid(a.C * a.tile_width * a.tile_height);
+    if (ckpt != nullptr)
+        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true>), grid, dim3(256), 0, st, a, ckpt, seg, solo_min);
+    else
+        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, false>), grid, dim3(256), 0, st, a, ckpt, seg, solo_min);
 }
 
 // ---------------------------------------------------------------------------
@@ -986,37 +750,19 @@ struct SegArgs {
     int32_t seg;
 };
 
-template <int NQ, int CDIM, int CMODE, bool ABS, bool SEG>
-__global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, RasterGradArgs ga, const int32_t *__restrict__ order, uint32_t cnt, uint32_t ch_off, int use_v_alpha, SegArgs sg) {
+template <int NQ, int CDIM, int CMODE, bool ABS>
+__global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, RasterGradArgs ga, uint32_t cnt, uint32_t ch_off, int use_v_alpha) {
     constexpr int REC = 4;
     constexpr int CR = (CMODE == 2) ? 1 : CDIM; // registers for v_out / colour sums
     __shared__ float4 s_rec[(GS_WAVE + 1) * REC];
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-    uint32_t n_work = gridDim.x;
-    if (SEG) {
-        n_work = *sg.n_items; // the grid is an upper bound
-        if (blockIdx.x >= n_work) return;
-    }
-    const uint32_t vitem = xcd_remap(blockIdx.x, n_work, a.xcd_group);
-    uint32_t slot = (NQ == 4) ? vitem : (vitem >> 2);
-    int32_t seg_k = 0;
-    if (SEG) {
-        const uint2 it = sg.items[vitem];
-        slot = it.x;
-        seg_k = (int32_t)it.y;
-    }
-    TileGeom tg = tile_geom(a, SEG ? nullptr : order, slot);
+    const uint32_t vitem = xcd_remap(blockIdx.x, gridDim.x, a.xcd_group);
+    const TileGeom tg = tile_geom(a, (NQ == 4) ? vitem : (vitem >> 2));
     if (a.masks != nullptr && !a.masks[tg.lin]) return;
     const uint32_t q_first = (NQ == 4) ? 0u : (vitem & 3u);
     const Rect rect = wave_rect<NQ>(a, tg, q_first);
     if (rect.empty || tg.range_end <= tg.range_start) return;
-    const int32_t tile_end = tg.range_end;
-    if (SEG) {
-        tg.range_start = max(tg.range_start, seg_k * sg.seg);
-        tg.range_end = min(tg.range_end, (seg_k + 1) * sg.seg);
-    }
-    const bool from_ckpt = SEG && tg.range_end < tile_end;
 
     bool inside[NQ];
     float px[NQ], py[NQ], T[NQ], Tw[NQ], Bq[NQ], vc[NQ][CR];
@@ -1055,22 +801,6 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
         Tw[i] = T_final * (v_a - bg_dot);
         bin_final[i] = inside[i] ? ga.last_ids[pix] : -1; // never matches
         bin_max = max(bin_max, bin_final[i]);
-        if (SEG && CMODE == 0) {
-            if (from_ckpt && inside[i]) {
-                const float *cb = sg.ckpt + (size_t)(seg_k + 1) * (CDIM + 1) * 256 + q * 64u + lane;
-                T[i] = cb[0];
-                float bsum = 0.f;
-#pragma unroll
-                for (int k = 0; k < CR; ++k) {
-                    if ((uint32_t)k < cnt) {
-                        float fin = sg.render_colors[pixv[i] + k];
-                        if (bg != nullptr) fin -= T_final * bg[k];
-                        bsum += vc[i][k] * (fin - cb[(k + 1) * 256]);
-                    }
-                }
-                Bq[i] = bsum;
-            }
-        }
     }
     bin_max = wave_max_i32(bin_max);
     if (bin_max < tg.range_start) return; // nothing was composited in this wave's pixels
@@ -1236,61 +966,20 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
     }
 }
 
-// ---------------------------------------------------------------------------
-// heaviest-first tile order (approximate: 64 length classes, 4 per octave), one workgroup.
-// Only scheduling depends on it, never results.
-// ---------------------------------------------------------------------------
-GS_DEV uint32_t length_class(uint32_t len) {
-    if (len < 4) return len; // 0..3
-    uint32_t msb = 31u - (uint32_t)__clz((int)len);
-    uint32_t c = 4u * (msb - 1u) + ((len >> (msb - 2u)) & 3u); // len 4 -> 4
-    return min(c, 63u);
+// more than 4 channels (feature rendering): one quadrant per wave, colours read from global memory
+template <int CDIM>
+void launch_fwd(const RasterArgs &a, uint32_t cnt, uint32_t off, hipStream_t st) {
+    dim3 grid(a.C * a.tile_width * a.tile_height * 4);
+    hipLaunchKernelGGL((raster_wave_fwd_kernel<1, CDIM, false, false>), grid, dim3(GS_WAVE), 0, st, a, cnt, off, (float *)nullptr, 0);
 }
 
-__global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t n_tiles_all, uint32_t n_isects,
-                                                          const int32_t *__restrict__ offsets,
-                                                          int32_t *__restrict__ order) {
-    __shared__ uint32_t s_cnt[64];
-    __shared__ uint32_t s_base[64];
-    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_tiles_all; i += blockDim.x) {
-        int32_t e = (i + 1 == n_tiles_all) ? (int32_t)n_isects : offsets[i + 1];
-        atomicAdd(&s_cnt[length_class((uint32_t)max(0, e - offsets[i]))], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int c = 63; c >= 0; --c) { // heaviest class first
-            s_base[c] = run;
-            run += s_cnt[c];
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_tiles_all; i += blockDim.x) {
-        int32_t e = (i + 1 == n_tiles_all) ? (int32_t)n_isects : offsets[i + 1];
-        uint32_t pos = atomicAdd(&s_base[length_class((uint32_t)max(0, e - offsets[i]))], 1u);
-        order[pos] = (int32_t)i;
-    }
-}
-
-template <int NQ, int CDIM, bool COLOR_LDS>
-void launch_fwd(const RasterArgs &a, const int32_t *order, uint32_t cnt, uint32_t off, float *ckpt, int32_t seg, hipStream_t st) {
-    dim3 grid(a.C * a.tile_width * a.tile_height * (NQ == 4 ? 1 : 4));
-    if (ckpt != nullptr)
-        hipLaunchKernelGGL((raster_wave_fwd_kernel<NQ, CDIM, COLOR_LDS, true>), grid, dim3(GS_WAVE), 0, st, a, order, cnt, off, ckpt, seg);
-    else
-        hipLaunchKernelGGL((raster_wave_fwd_kernel<NQ, CDIM, COLOR_LDS, false>), grid, dim3(GS_WAVE), 0, st, a, order, cnt, off, ckpt, seg);
-}
-
-template <int NQ, int CDIM, int CMODE>
-void launch_bwd(const RasterArgs &a, const RasterGradArgs &ga, const int32_t *order, uint32_t cnt, uint32_t off, int use_va, hipStream_t st) {
-    dim3 grid(a.C * a.tile_width * a.tile_height * (NQ == 4 ? 1 : 4));
-    SegArgs sg = {nullptr, nullptr, nullptr, nullptr, 0};
+template <int CDIM, int CMODE>
+void launch_bwd(const RasterArgs &a, const RasterGradArgs &ga, uint32_t cnt, uint32_t off, int use_va, hipStream_t st) {
+    dim3 grid(a.C * a.tile_width * a.tile_height * 4);
     if (ga.v_means2d_abs != nullptr)
-        hipLaunchKernelGGL((raster_wave_bwd_kernel<NQ, CDIM, CMODE, true, false>), grid, dim3(GS_WAVE), 0, st, a, ga, order, cnt, off, use_va, sg);
+        hipLaunchKernelGGL((raster_wave_bwd_kernel<1, CDIM, CMODE, true>), grid, dim3(GS_WAVE), 0, st, a, ga, cnt, off, use_va);
     else
-        hipLaunchKernelGGL((raster_wave_bwd_kernel<NQ, CDIM, CMODE, false, false>), grid, dim3(GS_WAVE), 0, st, a, ga, order, cnt, off, use_va, sg);
+        hipLaunchKernelGGL((raster_wave_bwd_kernel<1, CDIM, CMODE, false>), grid, dim3(GS_WAVE), 0, st, a, ga, cnt, off, use_va);
 }
 
 // ---------------------------------------------------------------------------
@@ -1316,14 +1005,11 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
     __shared__ float4 s_acc[GS_WAVE * ACC];
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-#if defined(GS_ABL) && (GS_ABL == 9 || GS_ABL == 8)
-    const unsigned long long abl_bt0 = wall_clock64();
-#endif
     const uint32_t n_work = *sg.n_items; // the grid is an upper bound
     if (blockIdx.x >= n_work) return;
     const uint2 it = sg.items[xcd_remap(blockIdx.x, n_work, a.xcd_group)];
     const int32_t seg_k = (int32_t)it.y;
-    TileGeom tg = tile_geom(a, nullptr, it.x);
+    TileGeom tg = tile_geom(a, it.x);
     if (a.masks != nullptr && !a.masks[tg.lin]) return;
     const int32_t tile_end = tg.range_end;
     tg.range_start = max(tg.range_start, seg_k * sg.seg);
@@ -1427,19 +1113,10 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
         int tn = any ? __builtin_ctzll(any) : 0;
         float4 n0 = s_rec[tn * REC + 0], n1 = s_rec[tn * REC + 1], n2 = s_rec[tn * REC + 2];
         float4 n3 = ABS ? s_rec[tn * REC + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
-#if defined(GS_ABL) && GS_ABL == 9
-        unsigned st_visit = 0, st_pass = 0, st_red = 0, st_lanes = 0, st_empty = 0, st_empty_a = 0;
-#endif
-#ifdef GS_ABL
-        float abl_dummy = 0.f;
-#endif
         while (any) {
             const int t = tn;
             any &= any - 1;
             const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
-#if defined(GS_ABL) && GS_ABL == 9
-            st_visit++;
-#endif
             tn = any ? __builtin_ctzll(any) : 0;
             n0 = s_rec[tn * REC + 0];
             n1 = s_rec[tn * REC + 1];
@@ -1459,24 +1136,12 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (!((qm[i] >> t) & 1ull)) continue; // wave-uniform (scalar) branch
-#if defined(GS_ABL) && GS_ABL == 2
-                abl_dummy += r0.x + r1.x + r2.x;
-                continue;
-#endif
-#if defined(GS_ABL) && GS_ABL == 9
-                st_pass++;
-#endif
                 const float dx = r0.x - (px0 + 8.f * (float)(i & 1)), dy = r0.y - (py0 + 8.f * (float)(i >> 1));
                 const float power = dx * (r0.z * dx + r0.w * dy) + r1.x * dy * dy;
                 const float araw = __builtin_amdgcn_exp2f(power + r1.y); // = o exp(-sigma)
                 const float alpha = fminf(0.999f, araw);
                 const bool valid = (idx <= bin_final[i]) && !(power > 0.f) && (alpha >= ALPHA_MIN);
                 any_valid |= valid;
-#if defined(GS_ABL) && GS_ABL == 9
-                st_lanes += __popcll(__ballot(valid));
-                st_empty += (__ballot(valid) == 0ull) ? 1u : 0u;
-                st_empty_a += (__ballot(!(power > 0.f) && (alpha >= ALPHA_MIN)) == 0ull) ? 1u : 0u;
-#endif
                 // a rejected record gets alpha = 0: then ra = rcp(1) = 1 exactly, Tn = T and facv = 0, i.e. the
                 // transmittance and the colour sums need no select of their own (selects cost 1.5 issue units here)
                 const float av = valid ? alpha : 0.f;
@@ -1506,13 +1171,6 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
                 }
             }
             if (!__any(any_valid)) continue;
-#if defined(GS_ABL) && GS_ABL == 9
-            st_red++;
-#endif
-#if defined(GS_ABL) && GS_ABL == 1
-            abl_dummy += S0 + Sx + Sy + Sxx + Sxy + Syy + Cs[0] + Cs[CDIM - 1] + Ax + Ay + Cs[CDIM > 1 ? 1 : 0];
-            continue;
-#endif
             // 8 values through the permlane butterfly (20 VALU), the rest through plain DPP chains.
             // slot floats: [Sx, Sy | Sxx, Sxy | Syy, S0 | C0, C1 | C2, C3, Ax, Ay]
             float lo, hi;
@@ -1538,23 +1196,6 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
             if (lane == GS_WAVE - 1) s_acc[t * ACC + 2] = make_float4(C2v, C3v, Ax, Ay);
         }
         __builtin_amdgcn_wave_barrier();
-#ifdef GS_ABL
-        if (abl_dummy == 123.456f) ga.v_opacities[lane] = abl_dummy;
-#if GS_ABL == 3
-        touched = 0ull;
-#endif
-#if GS_ABL == 9
-        if (lane == 0) {
-            atomicAdd(&g_abl_stats[0], (unsigned long long)st_visit);
-            atomicAdd(&g_abl_stats[1], (unsigned long long)st_pass);
-            atomicAdd(&g_abl_stats[2], (unsigned long long)st_red);
-            atomicAdd(&g_abl_stats[3], (unsigned long long)st_lanes);
-            atomicAdd(&g_abl_stats[4], 1ull);
-            atomicAdd(&g_abl_stats[5], (unsigned long long)st_empty);
-            atomicAdd(&g_abl_stats[6], (unsigned long long)st_empty_a);
-        }
-#endif
-#endif
         if (ga.packed) {
             // Packed gradient rows [n_elems,16]: finalise per slot in LDS, then issue the atomics with
             // lane = (slot, component): the <= 12 components of a splat go out as ONE request to ONE
@@ -1604,26 +1245,12 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
         }
         __builtin_amdgcn_wave_barrier();
     }
-#if defined(GS_ABL) && (GS_ABL == 9 || GS_ABL == 8)
-    if (lane == 0 && blockIdx.x < 65536u) {
-        g_abl_bwave[blockIdx.x * 2 + 0] = abl_bt0;
-        g_abl_bwave[blockIdx.x * 2 + 1] = wall_clock64();
-    }
-#endif
 }
 
 // segmented launch: one wave per (tile, segment) item, 4 pixels per lane
 template <int CDIM>
 void launch_bwd_seg(const RasterArgs &a, const RasterGradArgs &ga, uint32_t max_items, int use_va, const SegArgs &sg, hipStream_t st) {
     dim3 grid(max_items, 1);
-    const char *e = getenv("GS_RASTER_SEG_KERNEL"); // "generic" selects the compacting generic kernel (A/B)
-    if (e != nullptr && e[0] == 'g') {
-        if (ga.v_means2d_abs != nullptr)
-            hipLaunchKernelGGL((raster_wave_bwd_kernel<4, CDIM, 0, true, true>), grid, dim3(GS_WAVE), 0, st, a, ga, (const int32_t *)nullptr, (uint32_t)CDIM, 0u, use_va, sg);
-        else
-            hipLaunchKernelGGL((raster_wave_bwd_kernel<4, CDIM, 0, false, true>), grid, dim3(GS_WAVE), 0, st, a, ga, (const int32_t *)nullptr, (uint32_t)CDIM, 0u, use_va, sg);
-        return;
-    }
     if (ga.v_means2d_abs != nullptr)
         hipLaunchKernelGGL((raster_seg_bwd_kernel<CDIM, true>), grid, dim3(GS_WAVE), 0, st, a, ga, use_va, sg);
     else
@@ -1651,53 +1278,45 @@ __global__ void __launch_bounds__(GS_BLOCK) seg_items_kernel(uint32_t n_tiles_al
 // gs_rasterize_bwd; its contents must be preserved in between):
 //   [0, 256)                      item counter (uint32) + padding
 //   [256, 256 + items)            (tile, k) work items of the segmented backward (uint2)
-//   [.., .. + order)              optional heaviest-first tile order (int32)
 //   [.., .. + ckpt)               forward checkpoints, (n_isects / seg + 2) x (channels + 1) x 256 floats
 // ---------------------------------------------------------------------------
 namespace {
 
-// Segment length of the depth-segmented backward: 128 list entries (measured best on MI355X:
-// 512 -> 1.14 ms, 256 -> 0.97 ms, 128 -> 0.89 ms at config 2), doubled until the checkpoint
-// array stays below 65536 boundaries (256 MB for RGB).  GS_RASTER_SEG overrides; 0 disables.
-int32_t seg_len(uint32_t n_isects) {
-    const char *e = getenv("GS_RASTER_SEG");
-    if (e != nullptr) {
-        int v = atoi(e);
-        if (v <= 0) return 0;
-        return ((v + 63) / 64) * 64;
+// Tuning knobs.  Defaults are the measured optima on MI355X (profiles/round1_notes.md); the environment is read ONCE,
+// when the library first needs them, and gs_set_tuning() changes them at run time (tests exercise the non-default
+// values through it -- nothing is looked up per launch):
+//   GS_RASTER_SEG      segment length of the depth-segmented backward in list entries (multiple of 64; 0: no segments,
+//                      the generic one-quadrant-per-wave backward runs instead).  128: 512 -> 1.14 ms, 256 -> 0.97 ms,
+//                      128 -> 0.89 ms at config 2 when it was introduced.
+//   GS_RASTER_SOLO     list length from which a tile's four forward waves stop cooperating (0: never). 2048.
+//   GS_RASTER_XCD_FWD / GS_RASTER_XCD_BWD   work items per XCD group (xcd_remap).  16 tiles / 16 segment items.
+struct RasterTuning {
+    int32_t seg = 128, solo_min = 2048;
+    uint32_t xcd_fwd = 16, xcd_bwd = 16;
+    RasterTuning() {
+        if (const char *e = getenv("GS_RASTER_SEG")) seg = atoi(e) <= 0 ? 0 : ((atoi(e) + 63) / 64) * 64;
+        if (const char *e = getenv("GS_RASTER_SOLO")) solo_min = atoi(e);
+        if (const char *e = getenv("GS_RASTER_XCD_FWD")) xcd_fwd = (uint32_t)atoi(e);
+        if (const char *e = getenv("GS_RASTER_XCD_BWD")) xcd_bwd = (uint32_t)atoi(e);
     }
-    int32_t v = 128;
+};
+RasterTuning &tuning() {
+    static RasterTuning t;
+    return t;
+}
+
+// Segment length for this launch: the tuned value, doubled until the checkpoint array stays below 65536 boundaries
+// (256 MB for RGB).
+int32_t seg_len(uint32_t n_isects) {
+    int32_t v = tuning().seg;
+    if (v <= 0) return 0;
     while ((uint64_t)n_isects / (uint32_t)v > 65536u) v *= 2;
     return v;
 }
 
-// Depth split of the forward: part length and the list length from which a tile is split.
-// GS_RASTER_PART=<plen|0> (multiple of the segment length; 0 disables), GS_RASTER_HEAVY=<min list length>.
-void part_config(uint32_t n_isects, int32_t &plen, int32_t &heavy_min) {
-    const int32_t seg = seg_len(n_isects);
-    plen = 0; // opt-in: measured on MI355X at config 2 the forward is bound by rounds of workgroups, not by its
-              // heaviest tiles (207 tiles >= 2048 entries hold 18% of the pairs); the split pays for 10k+ entry lists
-    heavy_min = 2048;
-    if (const char *e = getenv("GS_RASTER_PART")) plen = atoi(e);
-    if (const char *e = getenv("GS_RASTER_HEAVY")) heavy_min = atoi(e);
-    if (seg <= 0 || plen <= 0) {
-        plen = 0;
-        heavy_min = 0;
-        return;
-    }
-    plen = ((plen + seg - 1) / seg) * seg;
-    if (heavy_min < plen + 1) heavy_min = plen + 1;
-    if ((int64_t)n_isects < heavy_min) { // no tile can be heavy
-        plen = 0;
-        heavy_min = 0;
-    }
-}
-
 struct ScratchLayout {
-    size_t off_items, off_order, off_ckpt, total;
-    size_t off_pitems, off_heavy, off_tpart, off_cpart, off_tend, off_curp;
-    uint32_t max_items, max_parts, max_heavy;
-    int32_t plen, heavy_min;
+    size_t off_items, off_ckpt, total;
+    uint32_t max_items;
 };
 
 ScratchLayout scratch_layout(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels) {
@@ -1708,130 +1327,54 @@ ScratchLayout scratch_layout(uint32_t n_tiles_all, uint32_t n_isects, uint32_t c
     L.max_items = n_tiles_all + (seg > 0 ? n_isects / (uint32_t)seg : 0) + 1;
     L.off_items = o;
     o += up((size_t)L.max_items * sizeof(uint2));
-    L.off_order = o;
-    o += up((size_t)n_tiles_all * sizeof(int32_t));
     L.off_ckpt = o;
     if (seg > 0 && channels <= 4) o += up(((size_t)n_isects / seg + 2) * (channels + 1) * 256 * sizeof(float));
-    part_config(n_isects, L.plen, L.heavy_min);
-    L.max_parts = L.max_heavy = 0;
-    L.off_pitems = L.off_heavy = L.off_tpart = L.off_cpart = L.off_tend = L.off_curp = o;
-    if (L.plen > 0 && channels <= 4) {
-        L.max_heavy = n_isects / (uint32_t)L.heavy_min + 1;
-        L.max_parts = n_isects / (uint32_t)L.plen + 2 * L.max_heavy + 1;
-        L.off_pitems = o; o += up((size_t)L.max_parts * sizeof(uint2));
-        L.off_heavy = o;  o += up((size_t)L.max_heavy * sizeof(HeavyTile));
-        L.off_tpart = o;  o += up((size_t)L.max_parts * 256 * sizeof(float));
-        L.off_cpart = o;  o += up((size_t)L.max_parts * channels * 256 * sizeof(float));
-        L.off_tend = o;   o += up((size_t)L.max_parts * 256 * sizeof(float));
-        L.off_curp = o;   o += up((size_t)L.max_parts * 256 * sizeof(int32_t));
-    }
     L.total = o;
     return L;
 }
 
 } // namespace
 
-#ifdef GS_ABL
-extern "C" void gs_debug_abl_waves(unsigned long long *out) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_abl_wave), sizeof(unsigned long long) * 65536 * 4);
+int32_t raster_set_tuning(const char *key, int32_t value) {
+    RasterTuning &t = tuning();
+    if (strcmp(key, "raster_seg") == 0) t.seg = value <= 0 ? 0 : ((value + 63) / 64) * 64;
+    else if (strcmp(key, "raster_solo_min") == 0) t.solo_min = value;
+    else if (strcmp(key, "raster_xcd_fwd") == 0) t.xcd_fwd = (uint32_t)max(value, 0);
+    else if (strcmp(key, "raster_xcd_bwd") == 0) t.xcd_bwd = (uint32_t)max(value, 0);
+    else return 1;
+    return 0;
 }
-extern "C" void gs_debug_abl_bwaves(unsigned long long *out) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_abl_bwave), sizeof(unsigned long long) * 65536 * 2);
-}
-extern "C" void gs_debug_abl_stats(unsigned long long *out) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_abl_stats), sizeof(unsigned long long) * 16);
-}
-#endif
 
 size_t raster_wave_scratch_bytes(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels) {
     return scratch_layout(n_tiles_all, n_isects, channels).total;
 }
 
-// Build the heaviest-first order (opt-in); returns the order pointer or nullptr (natural order).
-static const int32_t *build_order(const RasterArgs &a, void *scratch, size_t scratch_bytes, hipStream_t st) {
-    const uint32_t n = a.C * a.tile_width * a.tile_height;
-    const char *e = getenv("GS_RASTER_ORDER"); // measured: no effect on MI355X (all waves resident); opt-in
-    if (e == nullptr || e[0] != '1') return nullptr;
-    ScratchLayout L = scratch_layout(n, a.n_isects, a.channels);
-    if (scratch == nullptr || scratch_bytes < L.total || n < 1024) return nullptr;
-    int32_t *order = (int32_t *)((char *)scratch + L.off_order);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, n, a.n_isects, a.tile_offsets, order);
-    return order;
-}
-
-static uint32_t xcd_group_env(const char *name, uint32_t dflt) {
-    const char *e = getenv(name);
-    return e ? (uint32_t)atoi(e) : dflt;
-}
-
 int32_t raster_wave_fwd(const RasterArgs &a_in, void *scratch, size_t scratch_bytes, hipStream_t st) {
     RasterArgs a = a_in;
-#if defined(GS_ABL) && GS_ABL == 9
-    {
-        static unsigned long long init[8] = {0ull, ~0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_abl_stats), init, sizeof(init), 8 * sizeof(unsigned long long), hipMemcpyHostToDevice, st);
-    }
-#endif
-    a.xcd_group = xcd_group_env("GS_RASTER_XCD_FWD", 64u); // 16 tiles x 4 quadrants (sweep: profiles/round1_notes.md)
-    const int32_t *order = build_order(a, scratch, scratch_bytes, st);
     const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;
-    const ScratchLayout L = scratch_layout(n_tiles_all, a.n_isects, a.channels);
-    const int32_t seg = seg_len(a.n_isects);
-    float *ckpt = nullptr;
-    if (seg > 0 && a.channels <= 4 && scratch != nullptr && scratch_bytes >= L.total) ckpt = (float *)((char *)scratch + L.off_ckpt);
-    // One quadrant per wave (NQ = 1) by default: the kernel is bound by the serial walk of the
-    // longest tile list, and four quadrant waves walk it 2.6x faster than one tile wave
-    // (measured, profiles/round1_notes.md).  GS_RASTER_NQ_FWD=4 selects 4 pixels per lane.
-    const char *enq = getenv("GS_RASTER_NQ_FWD");
-    const bool nq4 = enq != nullptr && enq[0] == '4';
-    const char *efw = getenv("GS_RASTER_FWD"); // "wave": independent quadrant waves (previous default, A/B)
-    if (a.channels <= 4 && !nq4 && !(efw != nullptr && efw[0] == 'w')) {
-        a.xcd_group = xcd_group_env("GS_RASTER_XCD_FWD", 64u) / 4u; // groups of 16 tiles per XCD
-        PartPlan plan;
-        const PartPlan *pp = nullptr;
-        if (ckpt != nullptr && L.max_parts > 0 && order == nullptr) {
-            char *sp = (char *)scratch;
-            plan.counters = (uint32_t *)scratch;
-            plan.heavy = (HeavyTile *)(sp + L.off_heavy);
-            plan.max_parts = L.max_parts;
-            plan.max_heavy = L.max_heavy;
-            plan.pa.items = (const uint2 *)(sp + L.off_pitems);
-            plan.pa.n_items = plan.counters + 1;
-            plan.pa.tpart = (float *)(sp + L.off_tpart);
-            plan.pa.cpart = (float *)(sp + L.off_cpart);
-            plan.pa.tend = (float *)(sp + L.off_tend);
-            plan.pa.curp = (int32_t *)(sp + L.off_curp);
-            plan.pa.plen = L.plen;
-            plan.pa.heavy_min = L.heavy_min;
-            plan.pa.max_parts = L.max_parts;
-            if (hipMemsetAsync(plan.counters + 1, 0, 2 * sizeof(uint32_t), st) != hipSuccess) {
-                gs_set_error("gs_rasterize_fwd: memset failed");
-                return 2;
-            }
-            pp = &plan;
-        }
-        switch (a.channels) {
-            case 1: launch_tile_fwd<1>(a, order, ckpt, seg, pp, st); break;
-            case 2: launch_tile_fwd<2>(a, order, ckpt, seg, pp, st); break;
-            case 3: launch_tile_fwd<3>(a, order, ckpt, seg, pp, st); break;
-            default: launch_tile_fwd<4>(a, order, ckpt, seg, pp, st); break;
-        }
-        return 0;
-    }
     if (a.channels <= 4) {
+        // one 256-thread workgroup per tile; checkpoints for the segmented backward when the caller handed over scratch
+        const ScratchLayout L = scratch_layout(n_tiles_all, a.n_isects, a.channels);
+        const int32_t seg = seg_len(a.n_isects);
+        float *ckpt = nullptr;
+        if (seg > 0 && scratch != nullptr && scratch_bytes >= L.total) ckpt = (float *)((char *)scratch + L.off_ckpt);
+        a.xcd_group = tuning().xcd_fwd;
+        const int32_t solo = tuning().solo_min;
         switch (a.channels) {
-            case 1: if (nq4) launch_fwd<4, 1, true>(a, order, 1, 0, ckpt, seg, st); else launch_fwd<1, 1, true>(a, order, 1, 0, ckpt, seg, st); break;
-            case 2: if (nq4) launch_fwd<4, 2, true>(a, order, 2, 0, ckpt, seg, st); else launch_fwd<1, 2, true>(a, order, 2, 0, ckpt, seg, st); break;
-            case 3: if (nq4) launch_fwd<4, 3, true>(a, order, 3, 0, ckpt, seg, st); else launch_fwd<1, 3, true>(a, order, 3, 0, ckpt, seg, st); break;
-            default: if (nq4) launch_fwd<4, 4, true>(a, order, 4, 0, ckpt, seg, st); else launch_fwd<1, 4, true>(a, order, 4, 0, ckpt, seg, st); break;
+            case 1: launch_tile_fwd<1>(a, ckpt, seg, solo, st); break;
+            case 2: launch_tile_fwd<2>(a, ckpt, seg, solo, st); break;
+            case 3: launch_tile_fwd<3>(a, ckpt, seg, solo, st); break;
+            default: launch_tile_fwd<4>(a, ckpt, seg, solo, st); break;
         }
         return 0;
     }
+    // more than 4 channels: one quadrant per wave, exact chunks of 32 channels
+    a.xcd_group = tuning().xcd_fwd * 4u;
     for (uint32_t off = 0; off < a.channels; off += 32) {
         uint32_t cnt = min(32u, a.channels - off);
-        if (cnt <= 8) launch_fwd<1, 8, false>(a, order, cnt, off, nullptr, 0, st);
-        else if (cnt <= 16) launch_fwd<1, 16, false>(a, order, cnt, off, nullptr, 0, st);
-        else launch_fwd<1, 32, false>(a, order, cnt, off, nullptr, 0, st);
+        if (cnt <= 8) launch_fwd<8>(a, cnt, off, st);
+        else if (cnt <= 16) launch_fwd<16>(a, cnt, off, st);
+        else launch_fwd<32>(a, cnt, off, st);
     }
     return 0;
 }
@@ -1839,7 +1382,7 @@ int32_t raster_wave_fwd(const RasterArgs &a_in, void *scratch, size_t scratch_by
 int32_t raster_wave_bwd(const RasterArgs &a_in, const RasterGradArgs &ga, const float *render_colors, void *scratch,
                         size_t scratch_bytes, hipStream_t st) {
     RasterArgs a = a_in;
-    a.xcd_group = xcd_group_env("GS_RASTER_XCD_BWD", 16u);
+    a.xcd_group = tuning().xcd_bwd;
     const int use_va = ga.v_render_alphas != nullptr;
     const uint32_t c = a.channels;
     const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;
@@ -1865,24 +1408,24 @@ int32_t raster_wave_bwd(const RasterArgs &a_in, const RasterGradArgs &ga, const 
         }
         return 0;
     }
-    const int32_t *order = build_order(a, scratch, scratch_bytes, st);
-    const char *enq = getenv("GS_RASTER_NQ_BWD");
-    const bool nq4 = enq != nullptr && enq[0] == '4';
+    // no checkpoints (forward ran without scratch, or segments are switched off) or more than 4 channels:
+    // one quadrant per wave walking the whole list back to front
+    a.xcd_group = tuning().xcd_bwd * 4u;
     if (c <= 4) {
         switch (c) {
-            case 1: if (nq4) launch_bwd<4, 1, 0>(a, ga, order, 1, 0, use_va, st); else launch_bwd<1, 1, 0>(a, ga, order, 1, 0, use_va, st); break;
-            case 2: if (nq4) launch_bwd<4, 2, 0>(a, ga, order, 2, 0, use_va, st); else launch_bwd<1, 2, 0>(a, ga, order, 2, 0, use_va, st); break;
-            case 3: if (nq4) launch_bwd<4, 3, 0>(a, ga, order, 3, 0, use_va, st); else launch_bwd<1, 3, 0>(a, ga, order, 3, 0, use_va, st); break;
-            default: if (nq4) launch_bwd<4, 4, 0>(a, ga, order, 4, 0, use_va, st); else launch_bwd<1, 4, 0>(a, ga, order, 4, 0, use_va, st); break;
+            case 1: launch_bwd<1, 0>(a, ga, 1, 0, use_va, st); break;
+            case 2: launch_bwd<2, 0>(a, ga, 2, 0, use_va, st); break;
+            case 3: launch_bwd<3, 0>(a, ga, 3, 0, use_va, st); break;
+            default: launch_bwd<4, 0>(a, ga, 4, 0, use_va, st); break;
         }
     } else if (c <= 8) {
-        launch_bwd<1, 8, 1>(a, ga, order, c, 0, use_va, st);
+        launch_bwd<8, 1>(a, ga, c, 0, use_va, st);
     } else if (c <= 16) {
-        launch_bwd<1, 16, 1>(a, ga, order, c, 0, use_va, st);
+        launch_bwd<16, 1>(a, ga, c, 0, use_va, st);
     } else if (c <= 32) {
-        launch_bwd<1, 32, 1>(a, ga, order, c, 0, use_va, st);
+        launch_bwd<32, 1>(a, ga, c, 0, use_va, st);
     } else {
-        launch_bwd<1, 1, 2>(a, ga, order, c, 0, use_va, st);
+        launch_bwd<1, 2>(a, ga, c, 0, use_va, st);
     }
     return 0;
 }

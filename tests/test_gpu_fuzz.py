@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import N, T, assert_close, rel_l2
+from util import ROUTES, N, T, assert_close, rel_l2, tuned
 
 pytestmark = pytest.mark.gpu
 
@@ -41,8 +41,17 @@ def _scene(rs):
                 colors=colors, bg=bg, masks=masks, tw=tw, th=thh)
 
 
-@pytest.mark.parametrize("seed", range(24))
-def test_compositing_fuzz_vs_oracle(seed):
+# every kernel route the tuning knobs can select runs in the suite: the default over 24 scenes, the others over 8 each
+_FUZZ = [("default", s) for s in range(24)] + [(r, s) for r in ROUTES if r != "default" for s in range(8)]
+
+
+@pytest.mark.parametrize("route,seed", _FUZZ)
+def test_compositing_fuzz_vs_oracle(route, seed):
+    with tuned(route):
+        _compositing_fuzz(seed)
+
+
+def _compositing_fuzz(seed):
     from oracle import gs_oracle as O
 
     from gscodec_studio_amd import _wrapper as ops

@@ -344,14 +344,7 @@ def _raster_case(n=3000, scale_mult=6.0, cams=2, channels=3, seed=0, opac_boost=
 
 
 @pytest.mark.parametrize("channels", [3, 1, 4, 7, 32, 40])
-@pytest.mark.parametrize("impl", ["default", "ref"])
-def test_rasterize_fwd_bwd_vs_oracle(ops, channels, impl, monkeypatch):
-    if impl == "ref":
-        if channels > 32:
-            pytest.skip("the baseline kernels chunk > 32 channels (absgrad then differs by construction)")
-        monkeypatch.setenv("GS_RASTER_IMPL", "ref")
-    else:
-        monkeypatch.delenv("GS_RASTER_IMPL", raising=False)
+def test_rasterize_fwd_bwd_vs_oracle(ops, channels):
     c = _raster_case(n=2500 if channels > 8 else 4000, channels=channels, opac_boost=(channels == 3))
     rs = np.random.RandomState(5)
     bg = rs.rand(c["C"], channels).astype(np.float32)

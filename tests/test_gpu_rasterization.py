@@ -222,39 +222,9 @@ def test_camera_centers_and_pose_gradients():
     assert Vg.grad is not None and bool(torch.isfinite(Vg.grad).all()) and float(Vg.grad.abs().sum()) > 0
 
 
-def test_depth_split_forward_matches_undivided(monkeypatch):
-    """Opt-in depth split of heavy tiles (GS_RASTER_PART / GS_RASTER_HEAVY): parts composited by independent
-    workgroups from the prepass transmittances, combined afterwards, checkpoints made global -- images,
-    last ids and all gradients must equal the undivided walk's."""
-    from gscodec_studio_amd import rasterization
-
-    d = _inputs(n=4000, cams=2, sh_degree=None, scale_mult=12.0)  # big splats: lists of several hundred entries per tile
-
-    def run():
-        ps = [T(d[k]).requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")]
-        bg = torch.tensor([[0.2, 0.4, 0.6], [0.1, 0.1, 0.9]], device="cuda")
-        rc, ra, meta = rasterization(*ps, T(d["viewmats"]), T(d["Ks"]), d["W"], d["H"], packed=False, backgrounds=bg)
-        w = torch.linspace(0.5, 1.5, rc.numel(), device="cuda").reshape(rc.shape)
-        ((rc * w).sum() + 0.3 * ra.sum()).backward()
-        return N(rc), N(ra), [N(p.grad) for p in ps], meta
-
-    monkeypatch.delenv("GS_RASTER_PART", raising=False)
-    rc0, ra0, g0, meta = run()
-    offs = N(meta["isect_offsets"]).reshape(-1)
-    lens = np.diff(np.concatenate([offs, [meta["flatten_ids"].numel()]]))
-    assert lens.max() >= 600, int(lens.max())  # the split below really triggers (several parts per tile)
-    monkeypatch.setenv("GS_RASTER_PART", "256")
-    monkeypatch.setenv("GS_RASTER_HEAVY", "300")
-    rc1, ra1, g1, _ = run()
-    assert_close(rc1, rc0, 1e-4, 2e-6, "colors", max_bad_frac=1e-4)
-    assert_close(ra1, ra0, 1e-4, 2e-6, "alphas", max_bad_frac=1e-4)
-    for a, b, name in zip(g1, g0, ("means", "quats", "scales", "opacities", "colors")):
-        assert rel_l2(a, b) < 5e-4, (name, rel_l2(a, b))
-
-
-def test_solo_waves_match_cooperative_tiles(monkeypatch):
+def test_solo_waves_match_cooperative_tiles():
     """Long lists are composited by four independent waves (each walks the whole list and culls against its own quadrant)
-    instead of the cooperative workgroup (GS_RASTER_SOLO = list length from which that happens, 2048 by default).  Same
+    instead of the cooperative workgroup (tuning "raster_solo_min" = list length from which that happens, 2048 by default).  Same
     records in the same order with the same arithmetic: images, alphas, last ids (through the gradients) and the
     checkpoints the backward restarts from must be IDENTICAL, with and without backgrounds, for a mix of both kinds."""
     from gscodec_studio_amd import rasterization
@@ -268,18 +238,19 @@ def test_solo_waves_match_cooperative_tiles(monkeypatch):
         ((rc * w).sum() + 0.3 * ra.sum()).backward()
         return N(rc), N(ra), [N(p.grad) for p in ps], meta
 
+    from util import tuned
+
     for bg in (None, torch.tensor([[0.2, 0.4, 0.6], [0.1, 0.1, 0.9]], device="cuda")):
-        monkeypatch.setenv("GS_RASTER_SOLO", "0")  # every tile cooperative
-        rc0, ra0, g0, meta = run(bg)
+        with tuned("no_solo"):  # every tile cooperative
+            rc0, ra0, g0, meta = run(bg)
         offs = N(meta["isect_offsets"]).reshape(-1)
         lens = np.diff(np.concatenate([offs, [meta["flatten_ids"].numel()]]))
         for thr in (1, int(np.median(lens[lens > 0]))):  # every tile solo / about half of them
-            monkeypatch.setenv("GS_RASTER_SOLO", str(thr))
-            rc1, ra1, g1, _ = run(bg)
+            with tuned({"raster_solo_min": thr}):
+                rc1, ra1, g1, _ = run(bg)
             assert np.array_equal(rc1, rc0) and np.array_equal(ra1, ra0), thr
             for a, b, name in zip(g1, g0, ("means", "quats", "scales", "opacities", "colors")):
                 assert rel_l2(a, b) < 3e-4, (thr, name, rel_l2(a, b))  # (float atomics: the summation order varies run to run)
-    monkeypatch.delenv("GS_RASTER_SOLO")
 
 
 def test_full_size_linearity_determinism_and_adjoint():

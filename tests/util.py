@@ -70,3 +70,36 @@ def rel_l2(a, e):
     a = np.asarray(a, np.float64)
     e = np.asarray(e, np.float64)
     return float(np.linalg.norm(a - e) / max(np.linalg.norm(e), 1e-30))
+
+
+TUNING_DEFAULTS = {"raster_seg": 128, "raster_solo_min": 2048, "raster_xcd_fwd": 16, "raster_xcd_bwd": 16}
+# kernel routes a tuning value selects (all must give the reference's results; the fuzz tests run every one of them)
+ROUTES = {
+    "default": {},
+    "all_solo": {"raster_solo_min": 1},        # every tile: four independent forward waves
+    "no_solo": {"raster_solo_min": 0},         # every tile: cooperative staging, one barrier per batch
+    "seg256": {"raster_seg": 256},             # longer backward segments (fewer checkpoints)
+    "unsegmented": {"raster_seg": 0},          # no checkpoints: one quadrant per wave walks the whole list backwards
+    "xcd_identity": {"raster_xcd_fwd": 0, "raster_xcd_bwd": 0},
+}
+
+
+def set_tuning(**kv):
+    """gs_set_tuning for every key (None restores the defaults)."""
+    from gscodec_studio_amd import _backend as B
+
+    for k, v in kv.items():
+        B.call("gs_set_tuning", k.encode(), int(v))
+
+
+class tuned:
+    """``with tuned("all_solo"):`` -- run a block under one of ROUTES, restoring the defaults afterwards."""
+
+    def __init__(self, route):
+        self.kv = ROUTES[route] if isinstance(route, str) else dict(route)
+
+    def __enter__(self):
+        set_tuning(**self.kv)
+
+    def __exit__(self, *a):
+        set_tuning(**TUNING_DEFAULTS)
