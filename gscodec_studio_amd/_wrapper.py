@@ -942,23 +942,23 @@ def isect_tiles_finish(st_) -> Tuple[Tensor, Tensor, Tensor]:
     with _device_of(means2d):
         isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
         flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
-        if n_isects > 0:
+        if n_isects > 0 and st_["sort"]:
+            # compact form: (32-bit camera|tile key, flatten id) pairs = 8 B instead of 12 through the sort; its last pass
+            # writes the reference's 64-bit ids (key << 32 | depth bits) and the flatten ids
+            keys32 = torch.empty(n_isects, dtype=torch.int32, device=dev)
+            vals = torch.empty(n_isects, dtype=torch.int32, device=dev)
+            B.call("gs_isect_emit_compact", st_["n_elems"], max(st_["N"], 1), B.ptr(st_["perm"]), B.ptr(st_["n_kept"]),
+                   B.ptr(st_["camera_ids"]), B.ptr(means2d), B.ptr(radii), B.ptr(depths), B.ptr(st_["cum"]), st_["tile_size"],
+                   st_["tile_width"], st_["tile_height"], st_["tile_n_bits"], B.ptr(keys32), B.ptr(vals), st)
+            tb = B.query("gs_sort_isect_temp_bytes", n_isects)
+            temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+            B.call("gs_sort_isect_pairs", n_isects, B.ptr(keys32), B.ptr(vals), B.ptr(depths), st_["tile_n_bits"] + st_["cam_n_bits"],
+                   B.ptr(isect_ids), B.ptr(flatten_ids), B.ptr(temp), tb, st)
+        elif n_isects > 0:
             B.call("gs_isect_emit", st_["n_elems"], max(st_["N"], 1), B.ptr(st_["perm"]), B.ptr(st_["n_kept"]), B.ptr(st_["camera_ids"]),
                    B.ptr(means2d), B.ptr(radii), B.ptr(depths), B.ptr(st_["cum"]), st_["tile_size"], st_["tile_width"],
                    st_["tile_height"], st_["tile_n_bits"], B.ptr(isect_ids), B.ptr(flatten_ids), st)
-            if st_["sort"]:
-                isect_ids, flatten_ids = _sort_pairs(n_isects, isect_ids, flatten_ids, 32,
-                                                     32 + st_["tile_n_bits"] + st_["cam_n_bits"], dev, st)
     return st_["tiles_per_gauss"], isect_ids, flatten_ids
-
-
-def _sort_pairs(n, keys, vals, begin_bit, end_bit, dev, st):
-    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
-    tb = B.query("gs_sort_temp_bytes", n)
-    temp = torch.empty(tb, dtype=torch.uint8, device=dev)
-    B.call("gs_sort_pairs_u64_i32", n, B.ptr(keys), B.ptr(vals), B.ptr(ko), B.ptr(vo), begin_bit, end_bit,
-           B.ptr(temp), tb, st)
-    return ko, vo
 
 
 @torch.no_grad()

@@ -104,13 +104,16 @@ struct EmitRec {
 constexpr uint32_t EMIT_SPW = GS_EMIT_SPW;
 constexpr uint32_t EMIT_WAVES = GS_BLOCK / GS_WAVE;
 
+// COMPACT: the pair is written as (32-bit key camera << tile_n_bits | tile, flatten id) = 8 bytes for the 32-bit pair sort
+// (gs_sort_isect_pairs rebuilds the 64-bit id with the depth bits in its last pass); else the reference's 64-bit id.
+template <bool COMPACT>
 __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
     uint32_t n_elems, uint32_t N, const int32_t *__restrict__ perm, const uint32_t *__restrict__ n_valid,
     const int64_t *__restrict__ camera_ids,
     const float *__restrict__ means2d, const int32_t *__restrict__ radii,
     const float *__restrict__ depths, const int64_t *__restrict__ cum_tiles,
     float tile_size, int32_t tw, int32_t th, uint32_t tile_n_bits,
-    int64_t *__restrict__ isect_ids, int32_t *__restrict__ flatten_ids) {
+    int64_t *__restrict__ isect_ids, uint32_t *__restrict__ keys32, int32_t *__restrict__ flatten_ids) {
     // `pos` = position in the emission order (identity, or depth-sorted when perm is given);
     // `i` = the element it refers to.  cum_tiles is indexed by position.
     __shared__ EmitRec s_rec[EMIT_WAVES * EMIT_SPW];
@@ -140,7 +143,7 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
                 const int64_t cid = camera_ids != nullptr ? camera_ids[i] : (int64_t)(i / N);
                 // raw IEEE bits of the (positive) depth, sign-extended like the reference's
                 // (int64_t)*(int32_t*)&depth  (isect_tiles.cu:91)
-                rec.key_base = (cid << (32 + tile_n_bits)) | (int64_t)__float_as_int(depths[i]);
+                rec.key_base = COMPACT ? (cid << tile_n_bits) : ((cid << (32 + tile_n_bits)) | (int64_t)__float_as_int(depths[i]));
                 rec.id = (int32_t)i;
                 rec.x0 = b.x0;
                 rec.y0 = b.y0;
@@ -163,7 +166,8 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
         const int32_t k = t - wstart[sidx];
         const int32_t dy = k / o.w, dx = k - dy * o.w;
         const int64_t tile_id = (int64_t)(o.y0 + dy) * tw + (o.x0 + dx);
-        isect_ids[out0 + t] = o.key_base | (tile_id << 32);
+        if (COMPACT) keys32[out0 + t] = (uint32_t)(o.key_base | tile_id);
+        else isect_ids[out0 + t] = o.key_base | (tile_id << 32);
         flatten_ids[out0 + t] = o.id;
     }
 }
@@ -402,10 +406,27 @@ extern "C" int32_t gs_isect_emit(
     GS_CHECK_ARG(means2d && radii && depths && cum_tiles_per_gauss, "null pointer");
     GS_CHECK_ARG(camera_ids != nullptr || N > 0, "N must be > 0 when camera_ids is NULL");
     GS_CHECK_ARG(tile_n_bits < 32, "tile_n_bits must be < 32");
-    hipLaunchKernelGGL(isect_emit_kernel, dim3(gs_div_up(n_elems, EMIT_WAVES * EMIT_SPW)), dim3(GS_BLOCK), 0,
+    hipLaunchKernelGGL(isect_emit_kernel<false>, dim3(gs_div_up(n_elems, EMIT_WAVES * EMIT_SPW)), dim3(GS_BLOCK), 0,
                        (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids, means2d, radii, depths,
                        cum_tiles_per_gauss, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
-                       tile_n_bits, isect_ids, flatten_ids);
+                       tile_n_bits, isect_ids, (uint32_t *)nullptr, flatten_ids);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_isect_emit_compact(
+    uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids, const float *means2d,
+    const int32_t *radii, const float *depths, const int64_t *cum_tiles_per_gauss,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits,
+    uint32_t *keys32, int32_t *flatten_ids, gs_stream_t stream) {
+    if (n_elems == 0) return 0;
+    GS_CHECK_ARG(means2d && radii && depths && cum_tiles_per_gauss && keys32 && flatten_ids, "null pointer");
+    GS_CHECK_ARG(camera_ids != nullptr || N > 0, "N must be > 0 when camera_ids is NULL");
+    GS_CHECK_ARG(tile_n_bits < 32, "tile_n_bits must be < 32");
+    hipLaunchKernelGGL(isect_emit_kernel<true>, dim3(gs_div_up(n_elems, EMIT_WAVES * EMIT_SPW)), dim3(GS_BLOCK), 0,
+                       (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids, means2d, radii, depths,
+                       cum_tiles_per_gauss, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
+                       tile_n_bits, (int64_t *)nullptr, keys32, flatten_ids);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -59,6 +59,9 @@ constexpr float LN2 = 0.6931471805599453f;
 constexpr float ALPHA_MIN = 1.f / 255.f;
 constexpr float LOG2_255 = 7.994353436858858f;
 constexpr int HEAVY_TILE = 1024; // list length from which a wave raises its priority
+// cost classes of the backward's work items (cost >> 4: a 128-entry segment costs at most 4 x 128 record evaluations)
+constexpr int COST_CLASSES = 32;
+GS_DEV uint32_t cost_class(uint32_t c) { return min(c >> 4, (uint32_t)COST_CLASSES - 1u); }
 
 struct SplatRaw {
     int32_t g;
@@ -410,7 +413,9 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
 // (multiple of seg) always coincides with a sub-batch start.
 // ---------------------------------------------------------------------------
 template <int CDIM, bool CKPT>
-__global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, float *__restrict__ ckpt, int32_t seg, int32_t solo_min) {
+__global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, float *__restrict__ ckpt, int32_t seg, int32_t solo_min,
+                                                              uint32_t *__restrict__ cost_head, uint32_t *__restrict__ cost_body,
+                                                              uint32_t *__restrict__ body_tile, uint32_t *__restrict__ class_count) {
     constexpr int REC = 3;
     constexpr int BATCH = 256;
     // records of both buffers in ONE array + a null record (alpha = 0) that pads every list to a multiple of four
@@ -425,6 +430,8 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6); // staging sub-batch AND composited quadrant
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     if (tid < REC) s_rec[2 * BATCH * REC + tid] = make_float4(0.f, tid == 1 ? -__builtin_inff() : 0.f, 0.f, 0.f); // log2(opacity) = -inf
+    // the class counters of the backward's work list (seg_items_build_kernel runs after this kernel, in the same call)
+    if (CKPT && blockIdx.x == 0 && tid < (uint32_t)COST_CLASSES) class_count[tid] = 0u;
     const TileGeom tg = tile_geom(a, xcd_remap(blockIdx.x, gridDim.x, a.xcd_group));
     const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels : nullptr;
 
@@ -494,12 +501,30 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
     // first boundary this workgroup stores: strictly inside the list
     int32_t next_b = CKPT ? (tg.range_start / seg + 1) * seg : 0x7fffffff;
     int32_t next_k = CKPT ? next_b / seg : 0;
+    // COST of every backward work item (tile, segment) = records this wave evaluated inside the segment: the backward's
+    // work list is ordered by it, longest first (seg_items_sorted_kernel).  The tile's first segment reports into
+    // cost_head[tile][wave]; a later segment k owns boundary k * seg and reports into cost_body[k][wave] -- written once
+    // per (item, wave), no zero-fill and no atomics.
+    uint32_t evals = 0;
+    bool first_seg = true;
+    auto store_cost = [&]() { // the segment in front of boundary next_k has ended
+        if (lane == 0) {
+            if (first_seg) cost_head[tg.lin * 4u + w] = evals;
+            else {
+                cost_body[(size_t)(next_k - 1) * 4u + w] = evals;
+                if (w == 0u) body_tile[next_k - 1] = tg.lin; // the tile that owns boundary (next_k - 1) * seg
+            }
+        }
+        evals = 0;
+        first_seg = false;
+    };
     auto store_ckpt = [&]() {
         float *base = ckpt + (size_t)next_k * (CDIM + 1) * 256;
         const uint32_t p = w * 64u + lane;
         base[p] = T;
 #pragma unroll
         for (int k = 0; k < CDIM; ++k) base[(k + 1) * 256 + p] = out[k];
+        store_cost();
     };
 
     // ---- the record walk of one (sub-batch, quadrant) list, shared by the cooperative and the solo path
@@ -622,6 +647,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
             }
             if (m == 0ull) continue;
             uint32_t cur_off = 0xffffffffu;
+            if (CKPT) evals += (uint32_t)__popcll(m);
             walk(&s_list[buf][w][w][0], (uint32_t)__popcll(m), cur_off);
             if (cur_off != 0xffffffffu) cur = sb_start + (int32_t)(((((cur_off >> 4) * 43691u) >> 17)) & 63u);
             if (__all(done)) break;
@@ -699,6 +725,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
             m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) |
                 (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)m); // (the builtin returns int: no sign extension)
             if (m == 0ull) continue;
+            if (CKPT) evals += (uint32_t)__popcll(m);
             walk(&s_list[buf][sub][w][0], (uint32_t)__popcll(m), cur_off);
             if (__all(done)) break;
         }
@@ -713,6 +740,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
             next_b += seg;
             next_k += 1;
         }
+        store_cost(); // the tile's last segment
     }
     if (inside) {
         const float Tf = T;
@@ -724,12 +752,13 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
 }
 
 template <int CDIM>
-void launch_tile_fwd(const RasterArgs &a, float *ckpt, int32_t seg, int32_t solo_min, hipStream_t st) {
+void launch_tile_fwd(const RasterArgs &a, float *ckpt, int32_t seg, int32_t solo_min, uint32_t *cost_head, uint32_t *cost_body,
+                     uint32_t *body_tile, uint32_t *class_count, hipStream_t st) {
     dim3 grid(a.C * a.tile_width * a.tile_height);
     if (ckpt != nullptr)
-        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true>), grid, dim3(256), 0, st, a, ckpt, seg, solo_min);
+        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true>), grid, dim3(256), 0, st, a, ckpt, seg, solo_min, cost_head, cost_body, body_tile, class_count);
     else
-        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, false>), grid, dim3(256), 0, st, a, ckpt, seg, solo_min);
+        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, false>), grid, dim3(256), 0, st, a, ckpt, seg, solo_min, cost_head, cost_body, body_tile, class_count);
 }
 
 // ---------------------------------------------------------------------------
@@ -743,9 +772,10 @@ void launch_tile_fwd(const RasterArgs &a, float *ckpt, int32_t seg, int32_t solo
 // tile.  The state at the item's far end comes from the forward's checkpoint k+1
 // (T, accumulated colour) and the final render: B = v_out . (colour_final - colour_ckpt).
 struct SegArgs {
-    const uint2 *items;      // (tile, k)
-    const uint32_t *n_items; // device counter
-    const float *ckpt;       // [k][CDIM+1][256]
+    const uint2 *items;          // [COST_CLASSES][max_items] (tile, k), one region per cost class
+    const uint32_t *class_count; // [COST_CLASSES] items per class
+    uint32_t max_items;          // region length
+    const float *ckpt;           // [k][CDIM+1][256]
     const float *render_colors;
     int32_t seg;
 };
@@ -1005,9 +1035,19 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
     __shared__ float4 s_acc[GS_WAVE * ACC];
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-    const uint32_t n_work = *sg.n_items; // the grid is an upper bound
+    // block index -> item: the classes in order of decreasing cost (the grid is an upper bound on the total)
+    uint32_t n_work = 0;
+#pragma unroll 8
+    for (int c = 0; c < COST_CLASSES; ++c) n_work += sg.class_count[c];
     if (blockIdx.x >= n_work) return;
-    const uint2 it = sg.items[xcd_remap(blockIdx.x, n_work, a.xcd_group)];
+    uint32_t r = xcd_remap(blockIdx.x, n_work, a.xcd_group);
+    int cls = COST_CLASSES - 1;
+    for (; cls > 0; --cls) {
+        const uint32_t nc = sg.class_count[cls];
+        if (r < nc) break;
+        r -= nc;
+    }
+    const uint2 it = sg.items[(size_t)cls * sg.max_items + r];
     const int32_t seg_k = (int32_t)it.y;
     TileGeom tg = tile_geom(a, it.x);
     if (a.masks != nullptr && !a.masks[tg.lin]) return;
@@ -1257,17 +1297,63 @@ void launch_bwd_seg(const RasterArgs &a, const RasterGradArgs &ga, uint32_t max_
         hipLaunchKernelGGL((raster_seg_bwd_kernel<CDIM, false>), grid, dim3(GS_WAVE), 0, st, a, ga, use_va, sg);
 }
 
-// (tile, k) items: every global segment [k*seg, (k+1)*seg) that intersects a tile's range
-__global__ void __launch_bounds__(GS_BLOCK) seg_items_kernel(uint32_t n_tiles_all, uint32_t n_isects, const int32_t *__restrict__ offsets,
-                                                             int32_t seg, uint32_t *__restrict__ counter, uint2 *__restrict__ items) {
-    uint32_t t = blockIdx.x * GS_BLOCK + threadIdx.x;
-    if (t >= n_tiles_all) return;
-    int32_t rs = offsets[t];
-    int32_t re = (t + 1 == n_tiles_all) ? (int32_t)n_isects : offsets[t + 1];
-    if (re <= rs) return;
-    int32_t k0 = rs / seg, k1 = (re - 1) / seg;
-    uint32_t base = atomicAdd(counter, (uint32_t)(k1 - k0 + 1));
-    for (int32_t k = k0; k <= k1; ++k) items[base + (uint32_t)(k - k0)] = make_uint2(t, (uint32_t)k);
+// Work list of the segmented backward, ORDERED BY COST, longest first.  Why: a (tile, segment) item lasts 20 ... 120 us
+// (p10 ... max) and the hardware starts workgroups in index order, so with a list in arrival order the kernel ended with a
+// ~95 us drain of long items at low occupancy; longest-first (LPT) leaves the short items for the end (measured: 365 -> 329 us).
+// cost = what the forward counted for the item (records evaluated by the four quadrant waves).  Items are bucketed into
+// COST_CLASSES classes, each with its own region of the item array and a counter (zeroed by the forward kernel); the
+// backward maps its block index through the class counts, most expensive class first.  Built right after the forward
+// kernel, inside gs_rasterize_fwd: the backward itself is ONE launch, and a repeated backward (retain_graph) reuses it.
+//   unit u < n_tiles_all           : the first segment of tile u
+//   unit u = n_tiles_all + k       : segment k of the tile that owns list boundary k * seg (body_tile[k], verified)
+__global__ void __launch_bounds__(GS_BLOCK) seg_items_build_kernel(uint32_t n_tiles_all, uint32_t n_isects, const int32_t *__restrict__ offsets,
+                                                                   const uint8_t *__restrict__ masks, int32_t seg, uint32_t n_bounds,
+                                                                   const uint32_t *__restrict__ cost_head, const uint32_t *__restrict__ cost_body,
+                                                                   const uint32_t *__restrict__ body_tile, uint32_t *__restrict__ class_count,
+                                                                   uint2 *__restrict__ items, uint32_t max_items) {
+    __shared__ uint32_t s_cnt[COST_CLASSES], s_base[COST_CLASSES];
+    if (threadIdx.x < COST_CLASSES) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t u = blockIdx.x * GS_BLOCK + threadIdx.x;
+    uint32_t tile = 0, cls = 0, local = 0;
+    int32_t k = 0;
+    bool valid = false;
+    auto range = [&](uint32_t t, int32_t &rs, int32_t &re) {
+        rs = offsets[t];
+        re = (t + 1 == n_tiles_all) ? (int32_t)n_isects : offsets[t + 1];
+    };
+    if (u < n_tiles_all) {
+        int32_t rs, re;
+        range(u, rs, re);
+        valid = re > rs && (masks == nullptr || masks[u]);
+        tile = u;
+        k = rs / seg;
+        if (valid) {
+            const uint4 c = reinterpret_cast<const uint4 *>(cost_head)[u];
+            cls = cost_class(c.x + c.y + c.z + c.w);
+        }
+    } else if (u - n_tiles_all < n_bounds) {
+        k = (int32_t)(u - n_tiles_all);
+        const uint32_t t = body_tile[k]; // stale or never written unless boundary k * seg lies strictly inside a live tile
+        if (k > 0 && t < n_tiles_all) {
+            int32_t rs, re;
+            range(t, rs, re);
+            valid = (int64_t)rs < (int64_t)k * seg && (int64_t)k * seg < (int64_t)re && (masks == nullptr || masks[t]);
+            tile = t;
+            if (valid) {
+                const uint4 c = reinterpret_cast<const uint4 *>(cost_body)[k];
+                cls = cost_class(c.x + c.y + c.z + c.w);
+            }
+        }
+    }
+    if (valid) local = atomicAdd(&s_cnt[cls], 1u);
+    __syncthreads();
+    if (threadIdx.x < COST_CLASSES) {
+        const uint32_t c = s_cnt[threadIdx.x];
+        s_base[threadIdx.x] = c ? atomicAdd(&class_count[threadIdx.x], c) : 0u;
+    }
+    __syncthreads();
+    if (valid) items[(size_t)cls * max_items + s_base[cls] + local] = make_uint2(tile, (uint32_t)k);
 }
 
 } // namespace
@@ -1276,8 +1362,10 @@ __global__ void __launch_bounds__(GS_BLOCK) seg_items_kernel(uint32_t n_tiles_al
 // host side
 // scratch layout (the SAME buffer must be handed to gs_rasterize_fwd and to the matching
 // gs_rasterize_bwd; its contents must be preserved in between):
-//   [0, 256)                      item counter (uint32) + padding
-//   [256, 256 + items)            (tile, k) work items of the segmented backward (uint2)
+//   [0, 256)                      item counters of the 32 cost classes (uint32) + padding
+//   [256, 256 + items)            (tile, k) work items of the segmented backward (uint2), one region per cost class
+//   [.., .. + cost)               cost of every work item as counted by the forward ([tile][4] + [boundary][4] uint32)
+//                                 and the owner tile of every list boundary
 //   [.., .. + ckpt)               forward checkpoints, (n_isects / seg + 2) x (channels + 1) x 256 floats
 // ---------------------------------------------------------------------------
 namespace {
@@ -1315,8 +1403,8 @@ int32_t seg_len(uint32_t n_isects) {
 }
 
 struct ScratchLayout {
-    size_t off_items, off_ckpt, total;
-    uint32_t max_items;
+    size_t off_items, off_cost_head, off_cost_body, off_body_tile, off_ckpt, total;
+    uint32_t max_items, n_bounds;
 };
 
 ScratchLayout scratch_layout(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels) {
@@ -1324,9 +1412,16 @@ ScratchLayout scratch_layout(uint32_t n_tiles_all, uint32_t n_isects, uint32_t c
     const int32_t seg = seg_len(n_isects);
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t o = 256;
-    L.max_items = n_tiles_all + (seg > 0 ? n_isects / (uint32_t)seg : 0) + 1;
+    L.n_bounds = (seg > 0 ? n_isects / (uint32_t)seg : 0) + 2; // list boundaries k * seg, k < n_bounds
+    L.max_items = n_tiles_all + L.n_bounds;
     L.off_items = o;
-    o += up((size_t)L.max_items * sizeof(uint2));
+    if (seg > 0 && channels <= 4) o += up((size_t)COST_CLASSES * L.max_items * sizeof(uint2));
+    L.off_cost_head = o; // per (tile, quadrant wave): cost of the tile's first backward segment
+    o += up((size_t)n_tiles_all * 4 * sizeof(uint32_t));
+    L.off_cost_body = o; // per (segment boundary, quadrant wave): cost of the later segments
+    if (seg > 0 && channels <= 4) o += up((size_t)L.n_bounds * 4 * sizeof(uint32_t));
+    L.off_body_tile = o; // per segment boundary: the tile that owns it
+    if (seg > 0 && channels <= 4) o += up((size_t)L.n_bounds * sizeof(uint32_t));
     L.off_ckpt = o;
     if (seg > 0 && channels <= 4) o += up(((size_t)n_isects / seg + 2) * (channels + 1) * 256 * sizeof(float));
     L.total = o;
@@ -1360,12 +1455,19 @@ int32_t raster_wave_fwd(const RasterArgs &a_in, void *scratch, size_t scratch_by
         if (seg > 0 && scratch != nullptr && scratch_bytes >= L.total) ckpt = (float *)((char *)scratch + L.off_ckpt);
         a.xcd_group = tuning().xcd_fwd;
         const int32_t solo = tuning().solo_min;
+        uint32_t *ch = ckpt ? (uint32_t *)((char *)scratch + L.off_cost_head) : nullptr;
+        uint32_t *cb = ckpt ? (uint32_t *)((char *)scratch + L.off_cost_body) : nullptr;
+        uint32_t *bt = ckpt ? (uint32_t *)((char *)scratch + L.off_body_tile) : nullptr;
+        uint32_t *cc = ckpt ? (uint32_t *)scratch : nullptr;
         switch (a.channels) {
-            case 1: launch_tile_fwd<1>(a, ckpt, seg, solo, st); break;
-            case 2: launch_tile_fwd<2>(a, ckpt, seg, solo, st); break;
-            case 3: launch_tile_fwd<3>(a, ckpt, seg, solo, st); break;
-            default: launch_tile_fwd<4>(a, ckpt, seg, solo, st); break;
+            case 1: launch_tile_fwd<1>(a, ckpt, seg, solo, ch, cb, bt, cc, st); break;
+            case 2: launch_tile_fwd<2>(a, ckpt, seg, solo, ch, cb, bt, cc, st); break;
+            case 3: launch_tile_fwd<3>(a, ckpt, seg, solo, ch, cb, bt, cc, st); break;
+            default: launch_tile_fwd<4>(a, ckpt, seg, solo, ch, cb, bt, cc, st); break;
         }
+        if (ckpt != nullptr) // the backward's work list, ordered by the costs just counted
+            hipLaunchKernelGGL(seg_items_build_kernel, dim3(gs_div_up(L.max_items, GS_BLOCK)), dim3(GS_BLOCK), 0, st, n_tiles_all, a.n_isects,
+                               a.tile_offsets, a.masks, seg, L.n_bounds, ch, cb, bt, cc, (uint2 *)((char *)scratch + L.off_items), L.max_items);
         return 0;
     }
     // more than 4 channels: one quadrant per wave, exact chunks of 32 channels
@@ -1390,16 +1492,9 @@ int32_t raster_wave_bwd(const RasterArgs &a_in, const RasterGradArgs &ga, const 
     const int32_t seg = seg_len(a.n_isects);
     // Depth-segmented backward: needs the forward's checkpoints (same scratch) and the render.
     if (seg > 0 && c <= 4 && scratch != nullptr && scratch_bytes >= L.total && render_colors != nullptr) {
-        uint32_t *counter = (uint32_t *)scratch;
-        uint2 *items = (uint2 *)((char *)scratch + L.off_items);
-        hipError_t e = hipMemsetAsync(counter, 0, sizeof(uint32_t), st);
-        if (e != hipSuccess) {
-            gs_set_error("gs_rasterize_bwd: memset failed: %s", hipGetErrorString(e));
-            return 2;
-        }
-        hipLaunchKernelGGL(seg_items_kernel, dim3(gs_div_up(n_tiles_all, GS_BLOCK)), dim3(GS_BLOCK), 0, st, n_tiles_all,
-                           a.n_isects, a.tile_offsets, seg, counter, items);
-        SegArgs sg = {items, counter, (const float *)((char *)scratch + L.off_ckpt), render_colors, seg};
+        // the work list was built by gs_rasterize_fwd (seg_items_build_kernel): ONE launch here
+        SegArgs sg = {(const uint2 *)((char *)scratch + L.off_items), (const uint32_t *)scratch, L.max_items,
+                      (const float *)((char *)scratch + L.off_ckpt), render_colors, seg};
         switch (c) {
             case 1: launch_bwd_seg<1>(a, ga, L.max_items, use_va, sg, st); break;
             case 2: launch_bwd_seg<2>(a, ga, L.max_items, use_va, sg, st); break;

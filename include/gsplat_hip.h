@@ -270,6 +270,24 @@ int32_t gs_isect_emit(
     int32_t *flatten_ids, /* [n_isects] */
     gs_stream_t stream);
 
+/* The sorted path in compact form (what rasterization() uses): gs_isect_emit_compact writes every (tile, splat) pair as a
+ * 32-bit key  camera << tile_n_bits | tile  plus the flatten id (8 bytes instead of 12), in the depth order of `perm`;
+ * gs_sort_isect_pairs sorts the pairs stably by the low `key_bits` (= tile_n_bits + cam_n_bits) bits of the key and its
+ * LAST pass writes the reference's outputs: isect_ids = key << 32 | float_bits(depths[flatten id]) and flatten_ids --
+ * bit-identical to gs_isect_emit + gs_sort_pairs_u64_i32 (isect_tiles.cu:89-103, 245-299).  keys32 / vals are scratch:
+ * destroyed.  temp: gs_sort_isect_temp_bytes(n). */
+int32_t gs_isect_emit_compact(
+    uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids,
+    const float *means2d, const int32_t *radii, const float *depths, const int64_t *cum_tiles_per_gauss,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits,
+    uint32_t *keys32,     /* [n_isects] */
+    int32_t *flatten_ids, /* [n_isects] */
+    gs_stream_t stream);
+size_t gs_sort_isect_temp_bytes(uint64_t n);
+int32_t gs_sort_isect_pairs(
+    uint64_t n, uint32_t *keys32, int32_t *vals, const float *depths /* indexed by the flatten id */, int32_t key_bits,
+    int64_t *isect_ids, int32_t *flatten_ids, void *temp, size_t temp_bytes, gs_stream_t stream);
+
 /* Stable LSD radix sort of (uint64 key, int32 value) pairs on key bits
  * [begin_bit, end_bit) -- the replacement for cub::DeviceRadixSort::SortPairs
  * (gsplat/cuda/csrc/isect_tiles.cu:245-299).  Inputs are not modified; the sorted
