@@ -118,6 +118,10 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scan_kernel(
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+// Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the global
+// STORES of the keys to be acknowledged before the values may be staged.
+GS_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <typename KeyT, int SORT_ROUNDS, bool FINAL_ISECT>
 __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
     uint64_t n, const uint32_t *__restrict__ n_dev, const KeyT *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
@@ -238,7 +242,7 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
         lp[r] = s_lbase[dg] + s_cnt[wave][dg] + rank[r];
         if ((kept >> r) & 1u) s_keys[lp[r]] = key[r];
     }
-    __syncthreads();
+    lds_barrier();
     uint32_t pos[SORT_ROUNDS];
     KeyT kept_key[FINAL_ISECT ? SORT_ROUNDS : 1]; // the final pass of the binning needs the key again next to the value
 #pragma unroll
@@ -252,14 +256,14 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
             else keys_out[pos[k]] = kk;
         }
     }
-    __syncthreads();
+    lds_barrier();
     int32_t *s_vals = reinterpret_cast<int32_t *>(s_keys); // the same LDS, second trip for the values
 #pragma unroll
     for (int r = 0; r < SORT_ROUNDS; ++r) {
         const uint64_t i = wave_base + (uint64_t)r * GS_WAVE + lane;
         if ((kept >> r) & 1u) s_vals[lp[r]] = vals_in[i];
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < SORT_ROUNDS; ++k) {
         const uint32_t j = (uint32_t)k * GS_BLOCK + tid;
