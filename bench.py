@@ -378,10 +378,9 @@ def main():
     peak_mem = torch.cuda.max_memory_allocated(dev)
     regions = [elapsed]
     n_rep = int(min(200, max(0, np.ceil(args.min_timed_s / max(elapsed, 1e-6)) - 1)))
-    for _ in range(n_rep):
-        e_, ct_ = timed_region(args.steps, {dominant})
+    for _ in range(n_rep):  # (the repetitions run without event timers: nothing but the steps inside the region)
+        e_, _ = timed_region(args.steps, set())
         regions.append(e_)
-        dom_all += list(ct_.totals_ms()[dominant])
     dom_ms = float(np.mean(dom_all))
     ms_per_step = sum(regions) / (len(regions) * args.steps) * 1e3
     if args.breakdown and rank == 0:
