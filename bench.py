@@ -12,6 +12,8 @@ renders camera r of an N-camera batch over the whole scene; value counts splat-c
 N_splats * n_gpus / step time.  Two exchange patterns compute that batch (--dp-mode):
   camera    splats replicated, no communication in the forward, the step ends with the RCCL sum
             of the splat gradients (distributed.all_reduce_splat_grads; 236 B/splat);
+  camera_sparse  the same with only the rows some camera saw on the wire (visibility masks gathered
+            in the forward, distributed.plan_sparse_grad_exchange);
   gaussian  the reference's own multi-GPU layout (rasterization(distributed=True), reference
             rendering.py:279-478): every rank owns 1/N of the splats, projects + colours them
             for all N cameras, one all-to-all hands the projected splats to the camera's rank
@@ -93,7 +95,7 @@ def parse():
                     help="the exactly-K-step timed region is repeated until this much time has been measured")
     ap.add_argument("--no-extras", action="store_true", help="skip the dense-image-gradient variant and the config-1 PSNR")
     ap.add_argument("--breakdown", action="store_true", help="print per-entry-point timings to stderr")
-    ap.add_argument("--dp-mode", choices=["auto", "camera", "gaussian", "gaussian_dense"], default="auto",
+    ap.add_argument("--dp-mode", choices=["auto", "camera", "camera_sparse", "gaussian", "gaussian_dense"], default="auto",
                     help="multi-GPU exchange pattern (see the module docstring); ignored with one GPU")
     ap.add_argument("--calib-steps", type=int, default=5)
     return ap.parse_args()
@@ -244,7 +246,8 @@ def main():
     from gscodec_studio_amd import _backend as B
     from gscodec_studio_amd import rasterization
     from gscodec_studio_amd._helper import sh_workload
-    from gscodec_studio_amd.distributed import all_reduce_splat_grads
+    from gscodec_studio_amd import distributed as D
+    from gscodec_studio_amd.distributed import all_reduce_splat_grads, plan_sparse_grad_exchange
 
     B.lib()  # fail loudly if the HIP library is missing
     w = sh_workload(scene_grid=args.scene_grid, width=args.width, height=args.height, n_cameras=world,
@@ -295,12 +298,13 @@ def main():
             rc, ra, meta = rasterization(params["means"], quats, scales, opac, sh, viewmats, Ks,
                                          w["width"], w["height"], sh_degree=args.sh_degree, packed=False,
                                          distributed=gaussian)
+            plan = plan_sparse_grad_exchange(meta["radii"], world) if (mode == "camera_sparse" and use_pg) else None
             if dense_grad[0] is None:
                 rc.sum().backward()  # the reference's timing protocol (profiling/main.py:125-133): a broadcast gradient of ones
             else:
                 rc.backward(gradient=dense_grad[0])  # a training loss hands the compositing backward a DENSE [C,H,W,3] gradient
-            if mode == "camera" and use_pg:
-                all_reduce_splat_grads(params, world_size=world, average=False)
+            if mode in ("camera", "camera_sparse") and use_pg:
+                all_reduce_splat_grads(params, world_size=world, average=False, plan=plan)
             last_meta.update(meta)
 
         return step
@@ -320,7 +324,7 @@ def main():
     # multi-GPU: pick the exchange pattern (untimed calibration; every rank sees the same max-over-ranks numbers)
     mode, calib = ("camera" if args.dp_mode == "auto" else args.dp_mode), {}
     if use_pg and args.dp_mode == "auto":
-        for m in ("camera", "gaussian", "gaussian_dense"):
+        for m in ("camera", "camera_sparse", "gaussian", "gaussian_dense"):
             st = make_step(m)
             for _ in range(2):
                 st()
@@ -373,7 +377,9 @@ def main():
 
     torch.cuda.reset_peak_memory_stats(dev)
     mem_before = torch.cuda.memory_allocated(dev)
+    D.WIRE["bytes"] = 0
     elapsed, ct = timed_region(args.steps, {dominant})
+    wire_bytes_per_step = D.WIRE["bytes"] / args.steps
     dom_all = list(ct.totals_ms()[dominant])
     peak_mem = torch.cuda.max_memory_allocated(dev)
     regions = [elapsed]
@@ -416,13 +422,18 @@ def main():
             # reference protocol reports memory too (profiling/main.py:141-151): peak allocation during the timed steps,
             # and what the steps add on top of the resident scene + parameters
             "peak_mem_gb": peak_mem / 2**30, "step_mem_gb": (peak_mem - mem_before) / 2**30,
+            # multi-GPU: payload bytes leaving THIS rank per step (counted from the collectives' shapes) and the time the
+            # 7 xGMI links of one MI355X (7 x 153 GB/s, MI355X_MICROARCH.md) need for them at peak -- a lower bound that
+            # the measured step time can be read against
+            "wire": {"bytes_out_per_rank_per_step": wire_bytes_per_step, "xgmi_floor_ms": wire_bytes_per_step / (7 * 153e9) * 1e3,
+                     "xgmi_peak_gbs_per_gpu": 7 * 153} if use_pg else None,
             "ms_per_step_dense_image_grad": dense_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"BASELINE config 2: load_test_data(scene_grid={args.scene_grid}) -> {N} gaussians, "
                             f"SH degree {args.sh_degree}, {world}x1 camera {w['width']}x{w['height']}, packed=False, "
                             f"tile 16, fwd + bwd of sum(render)" + (", quantize hooks on" if args.quantize else ""),
-                "visible": stats["V"], "n_isects": stats["I"], "parallelism": (f"camera-sharded dp{world}" + (", RCCL sum of splat gradients" if world > 1 else "")) if mode == "camera"
+                "visible": stats["V"], "n_isects": stats["I"], "parallelism": (f"camera-sharded dp{world}" + ((", RCCL sum of splat gradients" + (" (visible rows only)" if mode == "camera_sparse" else "")) if world > 1 else "")) if mode.startswith("camera")
                 else f"gaussian-sharded x{world}, 1 camera per rank, all-to-all of projected splats + dual for gradients"
                      + (" (visible rows only)" if mode == "gaussian" else " (all rows)"),
                 **({"dp_mode": mode, "dp_calibration_ms_per_step": calib} if use_pg else {}),

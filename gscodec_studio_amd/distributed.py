@@ -14,10 +14,13 @@ Two things live here:
 
 2. The camera-sharded data-parallel path asked for by the north star: splats are
    replicated, the camera batch is sharded (rank r renders cameras r::world), forward
-   needs no communication, and the only exchange is the sum of splat gradients:
-   ``all_reduce_splat_grads`` packs every gradient into one fp32 bucket and reduces it
-   with reduce_scatter + all_gather (each of the 7 xGMI peers carries 1/8 of the bucket
-   concurrently) instead of a ring all-reduce that is bound by a single link.
+   needs no communication, and the only exchange is the sum of splat gradients
+   (``all_reduce_splat_grads``).  Default on RCCL: every gradient tensor is reduced where it
+   lies -- reduce_scatter_tensor + all_gather_into_tensor for the large ones (each of the 7
+   xGMI peers carries 1/8 concurrently, no packing copies), an in-place all_reduce for the
+   small ones.  With a ``SparseGradPlan`` (built in the forward from the visibility masks)
+   only the rows of splats that SOME camera saw travel: ~30 % of the 236 B/splat at the bench
+   workload (``plan_sparse_grad_exchange`` / ``all_reduce_splat_grads(..., plan=...)``).
 
 On CPU (gloo; used by the world_size-2 tests) the same code paths run with point-to-point
 fallbacks for the collectives gloo lacks.
@@ -40,6 +43,16 @@ def _backend_name() -> str:
     return str(dist.get_backend()).lower()
 
 
+# bytes this rank puts on the wire (payload leaving the GPU, computed from the collective's shape: all-to-all = everything
+# but the self chunk; all-gather = (world - 1) x input; reduce-scatter = (world - 1) / world x input; all-reduce counted as
+# reduce-scatter + all-gather).  bench.py reads and resets it to report bytes per rank and step next to the xGMI floor.
+WIRE = {"bytes": 0}
+
+
+def _wire(nbytes: float) -> None:
+    WIRE["bytes"] += int(nbytes)
+
+
 def _single(world_size: int) -> bool:
     """World-1 short cut of every collective; GS_DIST_FORCE_COLLECTIVES=1 disables it so that a one-rank run
     still drives RCCL (used by the tests on single-GPU boxes)."""
@@ -53,6 +66,7 @@ def _staged(t: Tensor) -> bool:
 
 
 def _all_gather_into(out: Tensor, inp: Tensor) -> None:
+    _wire(inp.numel() * inp.element_size() * (dist.get_world_size() - 1))
     if _staged(inp):
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(o, inp.cpu())
@@ -62,6 +76,8 @@ def _all_gather_into(out: Tensor, inp: Tensor) -> None:
 
 
 def _all_reduce_sum(t: Tensor) -> None:
+    w = dist.get_world_size()
+    _wire(2.0 * t.numel() * t.element_size() * (w - 1) / w)
     if _staged(t):
         h = t.cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM)
@@ -72,6 +88,9 @@ def _all_reduce_sum(t: Tensor) -> None:
 
 def _all_to_all_single(out: Tensor, inp: Tensor, out_splits: List[int], in_splits: List[int]) -> None:
     """all_to_all_single with a P2P fallback for backends without it (gloo)."""
+    if not _staged(inp):
+        row = inp.element_size() * (inp.numel() // max(inp.shape[0], 1))
+        _wire(row * (sum(in_splits) - in_splits[dist.get_rank()]))
     if "nccl" in _backend_name():
         dist.all_to_all_single(out, inp, out_splits, in_splits)
         return
@@ -538,6 +557,9 @@ def rasterization_camera_sharded(
     ``viewmats`` / ``Ks`` hold the GLOBAL batch [C,...]; rank r renders cameras r::world.
     Returns (render_colors [C_local,H,W,X], render_alphas, meta, camera_indices).  No
     communication happens here; call ``all_reduce_splat_grads`` after ``backward()``.
+    ``sparse_grads=True`` (unpacked mode) additionally gathers the ranks' visibility masks (1 byte per splat) and leaves
+    a ``SparseGradPlan`` in ``meta["grad_plan"]``: pass it to ``all_reduce_splat_grads(..., plan=...)`` and only the
+    rows some camera saw travel.
     """
     from .rendering import rasterization
 
@@ -551,8 +573,12 @@ def rasterization_camera_sharded(
     if colors.dim() == (4 if kwargs.get("sh_degree") is not None else 3):
         colors = colors[sel]  # per-view colours follow their cameras
     kwargs.pop("distributed", None)
+    sparse_grads = kwargs.pop("sparse_grads", False)
     rc, ra, meta = rasterization(means, quats, scales, opacities, colors, viewmats[sel], Ks[sel], width, height,
                                  distributed=False, **kwargs)
+    if sparse_grads and not kwargs.get("packed", True):
+        # visibility masks of all ranks + row counts, for all_reduce_splat_grads(..., plan=meta["grad_plan"])
+        meta["grad_plan"] = plan_sparse_grad_exchange(meta["radii"], world_size)
     return rc, ra, meta, idx
 
 
@@ -577,11 +603,131 @@ def flatten_grads(params: Sequence[Tensor]) -> Tuple[Tensor, List[Tuple[int, tor
     return bucket, layout
 
 
+class SparseGradPlan:
+    """What the sparse gradient reduction needs to know, gathered in the FORWARD pass (``plan_sparse_grad_exchange``):
+    every rank's visibility mask (which splats can have a non-zero gradient there), the union mask, and -- on the host,
+    read back together with the renderer's own intersection count, so without a synchronisation of its own -- how many
+    rows every rank holds for every owner block and how many rows every block's union has."""
+
+    def __init__(self, N, world, rank, block, masks, union, pinned, event):
+        self.N, self.world, self.rank, self.block = N, world, rank, block
+        self.masks, self.union = masks, union  # uint8 [world, world * block], bool [world * block]
+        self._pinned, self._event = pinned, event
+        self._counts = None
+
+    def counts(self):
+        """(rows[r][o] held by rank r for owner o, union rows per owner) as host integers."""
+        if self._counts is None:
+            if self._event is not None:
+                self._event.synchronize()
+            c = self._pinned.view(self.world + 1, self.world).tolist()
+            self._counts = (c[: self.world], c[self.world])
+        return self._counts
+
+
+def plan_sparse_grad_exchange(radii: Tensor, world_size: Optional[int] = None) -> Optional[SparseGradPlan]:
+    """Call in the forward pass, right after projection (``meta["radii"]`` [C_local, N]): all-gathers the per-splat
+    visibility masks of all ranks (1 byte per splat and rank: 1 MB at 1 M splats against the 236 MB of gradients) and
+    starts the asynchronous read-back of the row counts.  Splat n belongs to owner block n // ceil(N / world)."""
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    if _single(world_size):
+        return None
+    rank = dist.get_rank()
+    N = radii.shape[-1]
+    block = -(-N // world_size)
+    vis = torch.zeros(world_size * block, dtype=torch.uint8, device=radii.device)
+    vis[:N] = (radii.reshape(-1, N) > 0).any(0)
+    masks = torch.empty((world_size, world_size * block), dtype=torch.uint8, device=radii.device)
+    _all_gather_into(masks.view(-1), vis)
+    union = masks.any(0)
+    rows = masks.view(world_size, world_size, block).sum(-1, dtype=torch.int32)      # [rank, owner]
+    urows = union.view(world_size, block).sum(-1, dtype=torch.int32)                 # [owner]
+    both = torch.cat([rows.reshape(-1), urows]).to(torch.int64)
+    if both.is_cuda:
+        pinned = torch.empty(both.numel(), dtype=torch.int64).pin_memory()
+        pinned.copy_(both, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(radii.device))
+    else:
+        pinned, ev = both.clone(), None
+    return SparseGradPlan(N, world_size, rank, block, masks, union, pinned, ev)
+
+
+def _sparse_all_reduce(plist: List[Tensor], plan: SparseGradPlan, average: bool) -> None:
+    """Sum of the splat gradients over ranks moving only the rows some camera saw.
+
+    Phase 1 (reduce-scatter): rank r sends owner o its visible rows of block o, in index order, as one variable-split
+    all-to-all of bare values (the receiver knows every sender's mask, so no indices travel); the owner adds them into a
+    dense accumulator of its block.  Phase 2 (all-gather): every owner sends the rows of its block's UNION, padded to the
+    largest union, and every rank writes them back at the union's indices.  Rows outside the union are zero on every
+    rank and stay untouched.  No host synchronisation beyond the plan's counts (read back in the forward)."""
+    W, rank, N, block = plan.world, plan.rank, plan.N, plan.block
+    rows, urows = plan.counts()
+    dev = plist[0].device
+    widths = [p.numel() // N for p in plist]
+    D = sum(widths)
+    for p in plist:
+        assert p.shape[0] == N, "sparse gradient exchange: every parameter must have one row per splat"
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        elif p.grad.is_sparse:
+            p.grad = p.grad.to_dense()
+        elif not p.grad.is_contiguous():
+            p.grad = p.grad.contiguous()
+    G = [p.grad.view(N, -1) for p in plist]
+    # ---- phase 1
+    n_mine = sum(rows[rank])
+    idx = torch.nonzero_static(plan.masks[rank], size=n_mine).view(-1)              # ascending: owner blocks are contiguous
+    parts = [(g, wdt, True) for g, wdt in zip(G, widths)]
+    send = _pack_rows(parts, n_mine, G[0], idx.to(torch.int32)) if n_mine else torch.empty((0, D), dtype=torch.float32, device=dev)
+    in_splits = [int(c) for c in rows[rank]]
+    out_splits = [int(rows[r][rank]) for r in range(W)]
+    recv = send.new_empty((sum(out_splits), D))
+    _all_to_all_single(recv, send.contiguous(), out_splits, in_splits)
+    acc = torch.zeros((block, D), dtype=torch.float32, device=dev)
+    lo = rank * block
+    # rows arrive sender by sender, each sender's in index order: one compaction of the senders' masks of MY block gives
+    # all their positions at once
+    src = torch.nonzero_static(plan.masks[:, lo:lo + block].reshape(-1), size=sum(out_splits)).view(-1) % block
+    if src.numel():
+        _scatter_add_rows(acc, src, recv)
+    if average:
+        acc.mul_(1.0 / W)
+    # ---- phase 2
+    n_union = sum(int(u) for u in urows)
+    gidx = torch.nonzero_static(plan.union, size=n_union).view(-1)                   # ascending = owner order
+    u_off = sum(int(u) for u in urows[:rank])
+    uidx = gidx[u_off:u_off + int(urows[rank])] - lo
+    umax = max(int(u) for u in urows)
+    mine = acc.new_zeros((umax, D))
+    if uidx.numel():
+        mine[: uidx.numel()] = acc.index_select(0, uidx)
+    allrows = acc.new_empty((W, umax, D))
+    _all_gather_into(allrows.view(-1), mine.view(-1))
+    if n_union:
+        vals = torch.cat([allrows[o, : int(urows[o])] for o in range(W)], dim=0) if W > 1 else allrows[0, :n_union]
+        _unpack_rows(vals.contiguous(), [(g, wdt, True) for g, wdt in zip(G, widths)], gidx.to(torch.int32))
+
+
+def _scatter_add_rows(acc: Tensor, idx: Tensor, rows: Tensor) -> None:
+    """acc[idx[r]] += rows[r] (one pass of float atomics on the GPU; index_add_ elsewhere)."""
+    if acc.is_cuda:
+        from . import _backend as B
+
+        with torch.cuda.device(acc.device):
+            B.call("gs_scatter_add_rows_f32", rows.shape[0], rows.shape[1], B.ptr(rows.contiguous()), B.ptr(idx.contiguous()),
+                   B.ptr(acc), torch.cuda.current_stream(acc.device).cuda_stream)
+    else:
+        acc.index_add_(0, idx, rows)
+
+
 def all_reduce_splat_grads(
     params: Union[Dict[str, Tensor], Sequence[Tensor]],
     world_size: Optional[int] = None,
     average: bool = True,
     algorithm: str = "auto",
+    plan: Optional[SparseGradPlan] = None,
 ) -> None:
     """Sum (or average) the splat gradients of all ranks in place.
 
@@ -595,12 +741,17 @@ def all_reduce_splat_grads(
       * "rs_ag": one packed bucket, reduce_scatter_tensor + all_gather_into_tensor.
       * "all_reduce": one packed bucket, single all_reduce (what "auto" uses on gloo, which has no reduce_scatter).
     ``average=True`` matches a single-process batch whose loss is a mean over all C images.
+    ``plan`` (from ``plan_sparse_grad_exchange``, built in the forward): only the rows of splats that some camera saw
+    travel (``_sparse_all_reduce``); every parameter must then have one row per splat.
     """
     if world_size is None:
         world_size = dist.get_world_size() if dist.is_initialized() else 1
     plist = list(params.values()) if isinstance(params, dict) else list(params)
     plist = [p for p in plist if p.requires_grad]
     if _single(world_size) or not plist:
+        return
+    if plan is not None:
+        _sparse_all_reduce(plist, plan, average)
         return
     if algorithm == "auto":
         algorithm = os.environ.get("GS_DP_ALGO", "direct" if "nccl" in _backend_name() else "all_reduce")
@@ -616,6 +767,7 @@ def all_reduce_splat_grads(
             n = flat.numel()
             if n % world_size == 0 and n * flat.element_size() >= _DIRECT_RS_AG_MIN_BYTES and "nccl" in _backend_name():
                 shard = flat.new_empty(n // world_size)
+                _wire(2.0 * n * flat.element_size() * (world_size - 1) / world_size)
                 dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
                 if average:
                     shard.mul_(scale)

@@ -62,7 +62,7 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
-def _camera_sharded(rank, world, port, backend):
+def _camera_sharded(rank, world, port, backend, sparse=False):
     dev = _setup(rank, world, port, backend)
     try:
         from gscodec_studio_amd import distributed as D
@@ -71,10 +71,23 @@ def _camera_sharded(rank, world, port, backend):
         base, V, K, W, H = _scene(dev, world)
         params = {k: v.clone().requires_grad_(True) for k, v in base.items()}
         rc, ra, meta, idx = D.rasterization_camera_sharded(params["means"], params["quats"], params["scales"], params["opacities"],
-                                                           params["sh"], V, K, W, H, sh_degree=3, packed=False)
+                                                           params["sh"], V, K, W, H, sh_degree=3, packed=False,
+                                                           sparse_grads=sparse)
         assert idx == [rank]
         rc.sum().backward()
-        D.all_reduce_splat_grads(params, average=False)  # "direct" on RCCL: reduce_scatter + all_gather on the SH tensor
+        if sparse:  # only the rows some camera saw travel; world 1 with forced collectives drives the RCCL all-to-all
+            plan = meta["grad_plan"]
+            if world > 1 or os.environ.get("GS_DIST_FORCE_COLLECTIVES") == "1":
+                assert plan is not None
+                rows, urows = plan.counts()
+                assert sum(rows[rank]) == int((meta["radii"] > 0).any(0).sum()) and sum(urows) <= base["means"].shape[0]
+            D.WIRE["bytes"] = 0
+            D.all_reduce_splat_grads(params, average=False, plan=plan)
+            if world > 1:
+                dense = sum(p.numel() * 4 for p in params.values()) * 2 * (world - 1) / world
+                assert 0 < D.WIRE["bytes"] < dense, (D.WIRE["bytes"], dense)
+        else:
+            D.all_reduce_splat_grads(params, average=False)  # "direct" on RCCL: reduce_scatter + all_gather on the SH tensor
         ref = {k: v.clone().requires_grad_(True) for k, v in base.items()}
         rr, _, _ = rasterization(ref["means"], ref["quats"], ref["scales"], ref["opacities"], ref["sh"], V, K, W, H,
                                  sh_degree=3, packed=False)
@@ -173,6 +186,15 @@ def test_camera_sharded_world2():
     _spawn(_camera_sharded, (2, _free_port(), _backend_for(2)), 2)
 
 
+def test_camera_sharded_sparse_gradients_world2():
+    """The sum of the splat gradients with only the visible rows on the wire equals the single-process batch."""
+    _spawn(_camera_sharded, (2, _free_port(), _backend_for(2), True), 2)
+
+
+def test_camera_sharded_sparse_gradients_world3():
+    _spawn(_camera_sharded, (3, _free_port(), _backend_for(3), True), 3, deadline_s=240)
+
+
 @pytest.mark.parametrize("packed,sparse,cpr", [(False, True, 1), (False, False, 1), (True, True, 1), (False, True, 2), (False, False, 2),
                                                (True, True, 2)])
 def test_gaussian_sharded_world2(packed, sparse, cpr):
@@ -201,6 +223,35 @@ def test_gaussian_sharded_world3(sparse):
 def test_camera_sharded_rccl_world1():
     """Process-group set-up over RCCL, the sharded entry point and the collectives' plumbing on one rank."""
     _spawn(_camera_sharded, (1, _free_port(), "nccl"), 1)
+
+
+def test_camera_sharded_sparse_rccl_world1():
+    """The sparse reduction's variable-split all-to-all and padded all-gather driven through RCCL itself."""
+    _spawn(_camera_sharded, (1, _free_port(), "nccl", True), 1)
+
+
+def _uneven_all_to_all_rccl(rank, world, port, backend):
+    dev = _setup(rank, world, port, backend)
+    try:
+        from gscodec_studio_amd import distributed as D
+
+        # the reference's all_to_all_tensor_list with a non-trivial split list through RCCL's all_to_all_single
+        # (uneven splits, several tensors of different widths fused into one exchange), forward and dual backward
+        n = 1237
+        a = torch.randn(n, 3, device=dev, requires_grad=True)
+        b = torch.arange(n, device=dev, dtype=torch.float32)
+        oa, ob = D.all_to_all_tensor_list(world, [a, b], [n], output_splits=[n])
+        assert torch.equal(oa, a) and torch.equal(ob, b)
+        (oa * 2).sum().backward()
+        assert torch.equal(a.grad, torch.full_like(a, 2.0))
+        assert D.all_to_all_int32(world, [41], device=dev) == [41]
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_uneven_all_to_all_rccl_world1():
+    _spawn(_uneven_all_to_all_rccl, (1, _free_port(), "nccl"), 1)
 
 
 @pytest.mark.parametrize("sparse", [True, False])
