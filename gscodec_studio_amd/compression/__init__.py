@@ -1,11 +1,18 @@
-"""On-disk quantized attribute format, array level.
+"""On-disk quantized attribute format.
 
-The min-max grid quantizer behind the reference's ``PngCompression`` (gsplat/compression/png_compression.py)
--- 8-bit, k-bit and 16-bit planes and their exact inverse -- as HIP kernels, plus the attribute-level
-pre/post-processing (log transform of the means, quaternion normalisation, square crop).  The lossless
-containers (PNG via ``imageio``), the PLAS sort and the K-means codebook for shN are NOT built: none of those
-packages is in the image, and they are CPU / library code outside the GPU hot path.
+* ``grid_codec``: the min-max grid quantizer behind the reference's ``PngCompression``
+  (gsplat/compression/png_compression.py) -- 8-bit, k-bit and 16-bit planes and their exact inverse -- as HIP kernels, plus
+  the attribute-level pre/post-processing (log transform of the means, quaternion normalisation, square crop);
+* ``decode``: the compressed planes decoded STRAIGHT INTO ``rasterization()``'s inputs by one kernel
+  (``decode_to_rasterizer_inputs``), the K-means codebook of the higher SH bands (``kmeans_decode`` bit-exact against the
+  reference's ``_decompress_kmeans``; ``kmeans_encode`` = seeded Lloyd iteration writing the same format), and the splat
+  ordering in front of the grid codec (``sort_splats`` = PLAS, an external package as in the reference; ``morton_order`` =
+  deterministic substitute).
+
+Not built: the lossless containers themselves (PNG via ``imageio``, npz files) -- CPU library code on either side of the
+arrays this package produces and consumes.
 """
+from .decode import decode_to_rasterizer_inputs, kmeans_decode, kmeans_encode, morton_order, sort_splats
 from .grid_codec import (
     compress_to_arrays,
     decompress_from_arrays,
@@ -16,4 +23,5 @@ from .grid_codec import (
 )
 
 __all__ = ["quantize_grid", "dequantize_grid", "compress_to_arrays", "decompress_from_arrays", "log_transform",
-           "inverse_log_transform"]
+           "inverse_log_transform", "decode_to_rasterizer_inputs", "kmeans_decode", "kmeans_encode", "morton_order",
+           "sort_splats"]

@@ -496,6 +496,25 @@ int32_t gs_grid_dequantize(
     uint64_t n, uint32_t channels, const uint8_t *plane_lo, const uint8_t *plane_hi /* or NULL */,
     const float *mins, const float *maxs, uint32_t bits, float *out, gs_stream_t stream);
 
+/* Decode of the compressed attribute planes STRAIGHT INTO rasterization()'s inputs: replaces the
+ * host-side chain of the reference's eval path -- PngCompression.decompress (gsplat/compression/png_compression.py:166-236:
+ * _decompress_png_16bit for the means, _decompress_png_kbit / _decompress_png for scales, quats, opacities, sh0), the
+ * inverse log transform of the means (228-230) and the trainer's activations (examples/simple_trainer.py:779-786) -- by one
+ * kernel over the uint8 planes.  Planes are the [n, C] row-major views of the reference's [side, side, C] images; k-bit
+ * planes keep their value in the top bits of the byte (as stored).  mins14 / maxs14 are HOST arrays: the per-channel
+ * bounds of meta.json in the order means(3) scales(3) quats(4) opacities(1) sh0(3); bits5 (host): bit depth per attribute,
+ * means = 16.  activate = 1: scales = exp(.), opacities = sigmoid(.) (what rasterization() takes); 0: the trainer's raw
+ * parameters, bit-identical to gs_grid_dequantize.  normalize_quats = 1: quats / max(||quats||, 1e-12). */
+int32_t gs_decode_splats(
+    uint64_t n, const uint8_t *means_lo, const uint8_t *means_hi, const uint8_t *scales, const uint8_t *quats,
+    const uint8_t *opacities, const uint8_t *sh0, const float *mins14, const float *maxs14, const uint32_t *bits5,
+    int32_t normalize_quats, int32_t activate, float *means_out, float *scales_out, float *quats_out, float *opacities_out,
+    float *sh0_out, gs_stream_t stream);
+/* K-means codebook decode of the higher SH bands (png_compression.py:487-520): out[r, :] =
+ * centroids_quant[labels[r], :] / (2^bits - 1) * (maxs - mins) + mins (float64 arithmetic like the reference). */
+int32_t gs_kmeans_decode(uint64_t n_rows, uint32_t width, const int32_t *labels, const uint8_t *centroids_quant,
+                         uint32_t bits, float mins, float maxs, float *out, gs_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Temporal slicing of dynamic (spacetime) gaussians at one timestamp: the elementwise
  * chain in front of rasterization() in examples/simple_trainer_dyngs.py:506-521 -- trbf opacity decay

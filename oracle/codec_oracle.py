@@ -33,3 +33,26 @@ def dequantize(planes, mins, maxs, bits: int, shape):
     rng = (np.asarray(maxs, np.float32) - np.asarray(mins, np.float32)).astype(np.float64)
     grid = norm.reshape(-1, len(np.atleast_1d(mins))) * rng + np.asarray(mins, np.float32).astype(np.float64)
     return grid.reshape(shape).astype(np.float32)
+
+
+def kmeans_decode(centroids_quant, labels, mins, maxs, bits, shape, mask=None):
+    """_decompress_kmeans / _decompress_masked_kmeans (png_compression.py:487-520, 603-640): float64 normalisation of the
+    codebook, fp32 scalar range, float64 affine map, gather by label, cast to fp32; masked-out splats are zero."""
+    norm = centroids_quant / (2**bits - 1)  # float64
+    rng = np.float64(np.float32(maxs) - np.float32(mins))
+    cent = norm * rng + np.float64(np.float32(mins))
+    rows = cent[np.asarray(labels).astype(np.int32)]
+    if mask is not None:
+        full = np.zeros((len(mask), rows.shape[1]), np.float64)
+        full[np.asarray(mask, bool)] = rows
+        rows = full
+    return rows.reshape(shape).astype(np.float32)
+
+
+def decode_pipeline(planes, mins, maxs, bits, shape, log_means=False):
+    """One attribute of PngCompression.decompress: dequantize (+ the inverse log transform of the means, utils.py:40-41,
+    in fp32 like torch: sign(y) * expm1(|y|))."""
+    x = dequantize(planes, mins, maxs, bits, shape)
+    if log_means:
+        x = (np.sign(x) * np.expm1(np.abs(x))).astype(np.float32)
+    return x

@@ -36,3 +36,23 @@ def test_codec_module_fails_loudly_on_cpu():
         dequantize_grid([torch.zeros(4, 4, 3, dtype=torch.uint8)], {"shape": [16, 3], "dtype": "float32", "mins": [0, 0, 0], "maxs": [1, 1, 1]}, device="cpu")
     x = torch.tensor([-3.0, -0.1, 0.0, 0.5, 20.0])
     assert torch.allclose(inverse_log_transform(log_transform(x)), x, rtol=1e-6, atol=1e-7)
+
+
+def test_decode_pipeline_oracle_vs_reference_decompress():
+    """The oracle's decode of a whole compressed directory against what the reference's PngCompression.decompress returned
+    (tests/golden/make_golden_codec_pipeline.py): bit-exact for every attribute, the masked K-means shN included; the
+    means to 1 ulp of fp32 (torch.expm1 vs numpy.expm1)."""
+    gd = golden("codec_pipeline.npz")
+    side = int(gd["n_sidelen"])
+    for name in ("means", "scales", "quats", "opacities", "sh0"):
+        bits = int(gd[f"{name}.bits"])
+        planes = [gd[f"{name}.plane0"].reshape(side, side, -1)] + ([gd[f"{name}.plane1"].reshape(side, side, -1)] if bits == 16 else [])
+        dec = CO.decode_pipeline(planes, gd[f"{name}.mins"], gd[f"{name}.maxs"], bits, tuple(gd[f"{name}.shape"]), log_means=(name == "means"))
+        ref = gd[f"{name}.decoded"]
+        if name == "means":
+            assert np.all(np.abs(dec - ref) <= 2.4e-7 * np.abs(ref))
+        else:
+            assert np.array_equal(dec.view(np.uint32), ref.view(np.uint32)), name
+    shn = CO.kmeans_decode(gd["shN.centroids"], gd["shN.labels"], gd["shN.mins"], gd["shN.maxs"], 8, gd["shN.decoded"].shape, gd["shN.mask"])
+    assert np.array_equal(shn.view(np.uint32), gd["shN.decoded"].view(np.uint32))
+    assert (gd["shN.decoded"][~gd["shN.mask"]] == 0).all()

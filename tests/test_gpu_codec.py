@@ -65,3 +65,82 @@ def test_splat_dictionary_round_trip_full_size():
     # idempotence: re-encoding the decoded attributes reproduces the same planes (scales: min/max are grid points)
     arrays2, _ = compress_to_arrays({k: v for k, v in out.items()})
     assert torch.equal(arrays2["scales"][0], arrays["scales"][0]) and torch.equal(arrays2["opacities"][0], arrays["opacities"][0])
+
+
+def _pipeline_arrays():
+    gd = golden("codec_pipeline.npz")
+    arrays, meta = {}, {}
+    for name in ("means", "scales", "quats", "opacities", "sh0"):
+        bits = int(gd[f"{name}.bits"])
+        arrays[name] = [T(gd[f"{name}.plane0"])] + ([T(gd[f"{name}.plane1"])] if bits == 16 else [])
+        meta[name] = {"shape": [int(v) for v in gd[f"{name}.shape"]], "dtype": "float32", "mins": gd[f"{name}.mins"].tolist(),
+                      "maxs": gd[f"{name}.maxs"].tolist()}
+        if bits not in (8, 16) or name in ("scales", "quats", "sh0"):
+            meta[name]["quantization"] = bits
+    arrays["shN"] = [T(gd["shN.centroids"]), T(gd["shN.labels"].astype(np.int32)), T(gd["shN.mask"])]
+    meta["shN"] = {"shape": list(gd["shN.decoded"].shape), "dtype": "float32", "mins": float(gd["shN.mins"]), "maxs": float(gd["shN.maxs"]),
+                   "quantization": 8}
+    return gd, arrays, meta
+
+
+def test_fused_decode_matches_reference_decompress():
+    """decode_to_rasterizer_inputs on the planes of a directory the REFERENCE compressed and decompressed
+    (tests/golden/make_golden_codec_pipeline.py): raw parameters bit for bit (means: within 2 ulp, expm1f vs torch.expm1),
+    the masked K-means shN bit for bit; with activations on, what exp / sigmoid of the reference's output give."""
+    from gscodec_studio_amd.compression import decode_to_rasterizer_inputs
+
+    gd, arrays, meta = _pipeline_arrays()
+    raw = decode_to_rasterizer_inputs(arrays, meta, activate=False, normalize_quats=False)
+    for name in ("scales", "quats", "opacities", "sh0", "shN"):
+        assert raw[name].dtype == torch.float32 and tuple(raw[name].shape) == gd[f"{name}.decoded"].shape, name
+        assert np.array_equal(N(raw[name]).view(np.uint32), gd[f"{name}.decoded"].view(np.uint32)), name
+    ref_m = gd["means.decoded"]
+    assert np.all(np.abs(N(raw["means"]) - ref_m) <= 2.4e-7 * np.abs(ref_m) + 1e-30)
+    act = decode_to_rasterizer_inputs(arrays, meta)  # what rasterization() takes
+    assert np.allclose(N(act["scales"]), np.exp(gd["scales.decoded"]), rtol=2e-6, atol=0)
+    assert np.allclose(N(act["opacities"]), 1 / (1 + np.exp(-gd["opacities.decoded"].astype(np.float64))), rtol=2e-6, atol=1e-9)
+    q = gd["quats.decoded"]
+    assert np.allclose(N(act["quats"]), q / np.linalg.norm(q, axis=-1, keepdims=True), rtol=2e-6, atol=1e-7)
+    assert torch.equal(act["sh0"], raw["sh0"]) and torch.equal(act["means"], raw["means"])
+
+
+def test_decode_then_render_full_size_and_kmeans_round_trip():
+    """1,006,009 splats (1003^2): compress_to_arrays -> decode_to_rasterizer_inputs == decompress_from_arrays + activations,
+    the decoded splats render, and a K-means codebook written by kmeans_encode is read back by kmeans_decode."""
+    from gscodec_studio_amd import rasterization
+    from gscodec_studio_amd._helper import sh_workload
+    from gscodec_studio_amd.compression import (compress_to_arrays, decode_to_rasterizer_inputs, decompress_from_arrays, kmeans_decode,
+                                                kmeans_encode, morton_order)
+
+    w = sh_workload(scene_grid=3, device="cuda:0")
+    side = 1003
+    order = morton_order(w["means"])
+    assert torch.equal(torch.sort(order).values, torch.arange(w["N"], device="cuda:0"))  # a permutation
+    splats = {"means": w["means"], "scales": w["scales"].clamp_min(1e-6).log(), "quats": w["quats"],
+              "opacities": torch.logit(w["opacities"].clamp(1e-4, 1 - 1e-4)), "sh0": w["sh"][:, :1].contiguous()}
+    splats = {k: v[order] for k, v in splats.items()}
+    arrays, meta = compress_to_arrays(splats)
+    dec = decode_to_rasterizer_inputs(arrays, meta)
+    ref = decompress_from_arrays(arrays, meta)
+    assert dec["means"].shape == (side * side, 3)
+    assert torch.allclose(dec["means"], ref["means"], rtol=3e-7, atol=0)
+    assert torch.allclose(dec["scales"], torch.exp(ref["scales"]), rtol=2e-6) and torch.allclose(dec["opacities"], torch.sigmoid(ref["opacities"]), rtol=2e-6, atol=1e-9)
+    assert torch.equal(dec["sh0"], ref["sh0"])
+    vm, Ks = w["viewmats"][:1], w["Ks"][:1]
+    rc, ra, _ = rasterization(dec["means"], dec["quats"], dec["scales"], dec["opacities"], dec["sh0"], vm, Ks, w["width"], w["height"],
+                              sh_degree=0, packed=False)
+    assert bool(torch.isfinite(rc).all()) and float(ra.max()) > 0.5
+    # K-means: encode 50 k rows of higher bands into 256 centroids, decode, error bounded by cluster radius + quantization
+    shn = w["sh"][:50_000, 1:].contiguous()
+    cq, labels, m = kmeans_encode(shn, n_clusters=256, iters=4)
+    assert cq.dtype == torch.uint8 and cq.shape == (256, 45) and labels.dtype == torch.int32 and int(labels.max()) < 256
+    back = kmeans_decode(cq, labels, m)
+    assert back.shape == shn.shape
+    step = (m["maxs"] - m["mins"]) / 255
+    cent = back.reshape(50_000, -1)
+    # every row decodes to ITS centroid: rows with equal labels decode identically, and the centroid is the cluster mean up to q/2
+    l0 = int(labels[0])
+    same = (labels == l0)
+    assert bool((cent[same] == cent[same][0]).all())
+    mean0 = shn.reshape(50_000, -1)[same].mean(0)
+    assert float((cent[same][0] - mean0).abs().max()) <= 0.5 * step * 1.01 + 1e-6
