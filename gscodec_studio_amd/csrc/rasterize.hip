@@ -59,9 +59,9 @@ constexpr float LN2 = 0.6931471805599453f;
 constexpr float ALPHA_MIN = 1.f / 255.f;
 constexpr float LOG2_255 = 7.994353436858858f;
 constexpr int HEAVY_TILE = 1024; // list length from which a wave raises its priority
-// cost classes of the backward's work items (cost >> 4: a 128-entry segment costs at most 4 x 128 record evaluations)
+// cost classes of the backward's work items: a segment of `seg` entries costs at most 4 * seg record evaluations
 constexpr int COST_CLASSES = 32;
-GS_DEV uint32_t cost_class(uint32_t c) { return min(c >> 4, (uint32_t)COST_CLASSES - 1u); }
+GS_DEV uint32_t cost_class(uint32_t c, int32_t seg) { return min(c * 8u / (uint32_t)seg, (uint32_t)COST_CLASSES - 1u); }
 
 struct SplatRaw {
     int32_t g;
@@ -1370,7 +1370,7 @@ __global__ void __launch_bounds__(GS_BLOCK) seg_items_build_kernel(uint32_t n_ti
         k = rs / seg;
         if (valid) {
             const uint4 c = reinterpret_cast<const uint4 *>(cost_head)[u];
-            cls = cost_class(c.x + c.y + c.z + c.w);
+            cls = cost_class(c.x + c.y + c.z + c.w, seg);
         }
     } else if (u - n_tiles_all < n_bounds) {
         k = (int32_t)(u - n_tiles_all);
@@ -1382,7 +1382,7 @@ __global__ void __launch_bounds__(GS_BLOCK) seg_items_build_kernel(uint32_t n_ti
             tile = t;
             if (valid) {
                 const uint4 c = reinterpret_cast<const uint4 *>(cost_body)[k];
-                cls = cost_class(c.x + c.y + c.z + c.w);
+                cls = cost_class(c.x + c.y + c.z + c.w, seg);
             }
         }
     }
@@ -1414,12 +1414,14 @@ namespace {
 // when the library first needs them, and gs_set_tuning() changes them at run time (tests exercise the non-default
 // values through it -- nothing is looked up per launch):
 //   GS_RASTER_SEG      segment length of the depth-segmented backward in list entries (multiple of 64; 0: no segments,
-//                      the generic one-quadrant-per-wave backward runs instead).  128: 512 -> 1.14 ms, 256 -> 0.97 ms,
-//                      128 -> 0.89 ms at config 2 when it was introduced.
+//                      the generic one-quadrant-per-wave backward runs instead).  256 since the work list is ordered
+//                      longest-first (round 2: 128 / 192 / 256 / 320 / 384 / 512 -> 0.338 / 0.317 / 0.305 / 0.312 / 0.324 /
+//                      0.331 ms backward, and half the checkpoint planes in the forward); with the list in arrival order
+//                      128 was best (round 1: 512 -> 1.14 ms, 256 -> 0.97 ms, 128 -> 0.89 ms).
 //   GS_RASTER_SOLO     list length from which a tile's four forward waves stop cooperating (0: never). 2048.
 //   GS_RASTER_XCD_FWD / GS_RASTER_XCD_BWD   work items per XCD group (xcd_remap).  16 tiles / 16 segment items.
 struct RasterTuning {
-    int32_t seg = 128, solo_min = 2048;
+    int32_t seg = 256, solo_min = 2048;
     uint32_t xcd_fwd = 16, xcd_bwd = 16;
     RasterTuning() {
         if (const char *e = getenv("GS_RASTER_SEG")) seg = atoi(e) <= 0 ? 0 : ((atoi(e) + 63) / 64) * 64;

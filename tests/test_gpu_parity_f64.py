@@ -6,9 +6,9 @@ float per-splat sums, different summation orders).  Comparing them with each oth
 error; comparing BOTH with float64 can.  For every gradient this file asserts
 
   * rel_l2(HIP, f64) <= 1e-4                      -- the north star's "grads within 1e-4 rel fp32"
-    (measured on MI355X: 2e-6 ... 3e-5 for the compositing gradients, where the fp32 ORACLE is at 4e-5 ... 2e-4: the
+    (measured on MI355X: 7e-6 ... 3e-5 for the compositing gradients, where the fp32 ORACLE is at 4e-5 ... 2e-4: the
     reference's back-to-front T <- T / (1 - alpha) recurrence over the whole list loses digits that the segmented
-    backward, restarting from forward checkpoints every 128 entries, keeps);
+    backward, restarting from forward checkpoints every 256 entries, keeps);
   * rel_l2(HIP, f64) <= FACTOR * rel_l2(oracle_f32, f64) + 2e-6   -- the HIP path is as accurate as fp32 gets
     (FACTOR 4: the oracle accumulates its per-splat sums in double, the kernels in fp32 registers and float atomics);
   * max |HIP - f64| <= 1e-4 max |f64|;

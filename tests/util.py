@@ -72,13 +72,13 @@ def rel_l2(a, e):
     return float(np.linalg.norm(a - e) / max(np.linalg.norm(e), 1e-30))
 
 
-TUNING_DEFAULTS = {"raster_seg": 128, "raster_solo_min": 2048, "raster_xcd_fwd": 16, "raster_xcd_bwd": 16}
+TUNING_DEFAULTS = {"raster_seg": 256, "raster_solo_min": 2048, "raster_xcd_fwd": 16, "raster_xcd_bwd": 16}
 # kernel routes a tuning value selects (all must give the reference's results; the fuzz tests run every one of them)
 ROUTES = {
     "default": {},
     "all_solo": {"raster_solo_min": 1},        # every tile: four independent forward waves
     "no_solo": {"raster_solo_min": 0},         # every tile: cooperative staging, one barrier per batch
-    "seg256": {"raster_seg": 256},             # longer backward segments (fewer checkpoints)
+    "seg128": {"raster_seg": 128},             # shorter backward segments (more checkpoints)
     "unsegmented": {"raster_seg": 0},          # no checkpoints: one quadrant per wave walks the whole list backwards
     "xcd_identity": {"raster_xcd_fwd": 0, "raster_xcd_bwd": 0},
 }
