@@ -1,4 +1,4 @@
-"""Build profiles/r01_pmc_traffic.json from two rocprofv3 counter-collection CSVs (separate --pmc passes).
+"""Build profiles/rNN_pmc_traffic.json (driven by tools/pmc.sh) from two rocprofv3 counter-collection CSVs (separate --pmc passes).
 
     python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [<sq_insts_valu.csv>]
 
@@ -32,7 +32,7 @@ def main():
     kernels = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"]))
     json.dump({
         "workload_key": "grid3_1920x1080_sh3",
-        "command": "cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline ; same with --pmc WRITE_SIZE (separate passes)",
+        "command": "tools/pmc.sh: cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras ; same with --pmc WRITE_SIZE and --pmc SQ_INSTS_VALU (separate passes)",
         "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: KB units; FETCH_SIZE reports 1/2 of the fetched bytes on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated",
         "kernels": kernels,
     }, open(out, "w"), indent=1)
