@@ -35,7 +35,7 @@ def test_version_and_error_string():
     assert isinstance(L.gs_last_error(), bytes)
     assert B.query("gs_sort_temp_bytes", 1000) >= 1000 * 12
     assert B.query("gs_cumsum_scratch_bytes", 10_000) >= 8
-    assert B.query("gs_rasterize_scratch_bytes", 8160, 4_000_000, 3) > 4_000_000 // 128 * 4 * 256 * 4
+    assert B.query("gs_rasterize_scratch_bytes", 8160, 4_000_000, 3) > 4_000_000 // 256 * 4 * 256 * 4  # checkpoint planes every 256 entries
 
 
 def test_argument_validation_happens_before_any_launch():
