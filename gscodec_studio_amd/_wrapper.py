@@ -871,6 +871,17 @@ def isect_tiles(
                                                 n_elems, camera_ids))
 
 
+# pinned host buffers the count kernel writes its per-block sums into: taken in isect_tiles_begin, handed back in
+# isect_tiles_finish once read (a buffer is never shared by two calls in flight; one whose finish never runs is simply
+# garbage-collected).  Re-used so that the steady state makes no pinned allocation.
+_PINNED_FREE: dict = {}
+
+
+def _pinned_take(n: int) -> Tensor:
+    free = _PINNED_FREE.get(n)
+    return free.pop() if free else torch.empty(n, dtype=torch.int32, pin_memory=True)
+
+
 @torch.no_grad()
 def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height, sort, C, N, n_elems, camera_ids):
     """First half of ``isect_tiles``: everything up to the data-dependent size -- count, splat-level depth sort,
@@ -906,8 +917,15 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                 # splat-level depth pre-sort: afterwards only the (camera, tile) bits need sorting
                 dkeys = torch.empty(n_elems, dtype=torch.int64, device=dev)
                 dvals = torch.empty(n_elems, dtype=torch.int32, device=dev)
+                # n_isects = the sum of the per-block counts, known to the host ~100 us of GPU work (pre-sort, prefix sum,
+                # SH colours) before the pipeline needs it
+                # sum there.  The kernel stores them STRAIGHT into pinned host memory (device-visible under HIP's unified
+                # addressing; a few thousand posted 4-byte writes): no device-to-host copy command in the stream.
+                pinned = _pinned_take(B.query("gs_isect_count_blocks", n_elems))
                 B.call("gs_isect_count_keys", n_elems, B.ptr(means2d), B.ptr(radii), B.ptr(depths), tile_size, tile_width,
-                       tile_height, B.ptr(tiles_per_gauss), B.ptr(dkeys), B.ptr(dvals), st)
+                       tile_height, B.ptr(tiles_per_gauss), B.ptr(dkeys), B.ptr(dvals), B.ptr(pinned), st)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
                 # culled elements carry the maximal key: the sort drops them in its first pass
                 ko, perm = torch.empty_like(dkeys), torch.empty_like(dvals)
                 n_kept = torch.empty(1, dtype=torch.int32, device=dev)
@@ -922,10 +940,10 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                 B.call("gs_isect_count", n_elems, B.ptr(means2d), B.ptr(radii), tile_size, tile_width, tile_height,
                        B.ptr(tiles_per_gauss), st)
                 B.call("gs_cumsum_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(cum), B.ptr(scratch), sb, st)
-            pinned = torch.empty(1, dtype=torch.int64, pin_memory=True)
-            pinned.copy_(cum[-1:], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
+                pinned = torch.empty(1, dtype=torch.int64, pin_memory=True)
+                pinned.copy_(cum[-1:], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
             st_["cum"], st_["pinned"], st_["event"] = cum, pinned, ev
     return st_
 
@@ -938,7 +956,10 @@ def isect_tiles_finish(st_) -> Tuple[Tensor, Tensor, Tensor]:
     n_isects = 0
     if st_["event"] is not None:
         st_["event"].synchronize()  # the one host sync (isect_tiles.cu:200)
-        n_isects = int(st_["pinned"][0])
+        n_isects = int(st_["pinned"].sum(dtype=torch.int64))
+        if st_["pinned"].dtype == torch.int32:
+            _PINNED_FREE.setdefault(st_["pinned"].numel(), []).append(st_["pinned"])
+            st_["pinned"] = None
     with _device_of(means2d):
         isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
         flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)

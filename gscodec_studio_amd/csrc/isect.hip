@@ -57,24 +57,38 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_depth_keys_kernel(
 }
 
 // isect_count_kernel + isect_depth_keys_kernel in one launch (the sorted path needs both)
+// block_sums (optional): the block's number of intersections.  Their sum is n_isects -- available right after THIS kernel,
+// ~100 us of GPU work (depth pre-sort, prefix sum, SH colours) before the pipeline needs it on the host: the caller copies
+// the partial sums to pinned memory here and adds them up on the host, so the one host read-back of the pipeline
+// (isect_tiles.cu:200 in the reference) no longer leaves the GPU idle while the host wakes up and queues the rest.
 __global__ void __launch_bounds__(GS_BLOCK) isect_count_keys_kernel(
     uint32_t n_elems, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
     const float *__restrict__ depths, float tile_size, int32_t tw, int32_t th,
-    int32_t *__restrict__ tiles_per_gauss, int64_t *__restrict__ keys, int32_t *__restrict__ vals) {
+    int32_t *__restrict__ tiles_per_gauss, int64_t *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ block_sums) {
+    __shared__ int32_t s_sum[GS_BLOCK / GS_WAVE];
     uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x;
-    if (i >= n_elems) return;
-    const int32_t r = radii[i];
     int32_t cnt = 0;
-    uint32_t d = 0x7fffffffu;
-    if (r > 0) {
-        float2 m = reinterpret_cast<const float2 *>(means2d)[i];
-        TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
-        cnt = (b.y1 - b.y0) * (b.x1 - b.x0);
-        d = (uint32_t)__float_as_int(depths[i]) & 0x7fffffffu;
+    if (i < n_elems) {
+        const int32_t r = radii[i];
+        uint32_t d = 0x7fffffffu;
+        if (r > 0) {
+            float2 m = reinterpret_cast<const float2 *>(means2d)[i];
+            TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
+            cnt = (b.y1 - b.y0) * (b.x1 - b.x0);
+            d = (uint32_t)__float_as_int(depths[i]) & 0x7fffffffu;
+        }
+        tiles_per_gauss[i] = cnt;
+        keys[i] = (int64_t)(((uint64_t)d << 32) | (uint64_t)i);
+        vals[i] = (int32_t)i;
     }
-    tiles_per_gauss[i] = cnt;
-    keys[i] = (int64_t)(((uint64_t)d << 32) | (uint64_t)i);
-    vals[i] = (int32_t)i;
+    if (block_sums != nullptr) { // (block-uniform)
+        int32_t v = cnt;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63u) == 0u) s_sum[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) block_sums[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    }
 }
 
 __global__ void __launch_bounds__(GS_BLOCK) gather_i32_kernel(
@@ -366,15 +380,18 @@ extern "C" int32_t gs_cumsum_gather_i32(
     return 0;
 }
 
+extern "C" uint32_t gs_isect_count_blocks(uint32_t n_elems) { return gs_div_up(n_elems, GS_BLOCK); }
+
 extern "C" int32_t gs_isect_count_keys(
     uint32_t n_elems, const float *means2d, const int32_t *radii, const float *depths, uint32_t tile_size,
-    uint32_t tile_width, uint32_t tile_height, int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals, gs_stream_t stream) {
+    uint32_t tile_width, uint32_t tile_height, int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals, int32_t *block_sums,
+    gs_stream_t stream) {
     if (n_elems == 0) return 0;
     GS_CHECK_ARG(means2d && radii && depths && tiles_per_gauss && keys && vals, "null pointer");
     GS_CHECK_ARG(tile_size > 0, "tile_size must be > 0");
     hipLaunchKernelGGL(isect_count_keys_kernel, dim3(gs_div_up(n_elems, GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
                        n_elems, means2d, radii, depths, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
-                       tiles_per_gauss, keys, vals);
+                       tiles_per_gauss, keys, vals, block_sums);
     GS_CHECK_LAUNCH();
     return 0;
 }

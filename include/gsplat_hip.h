@@ -252,7 +252,12 @@ int32_t gs_gather_i32(uint32_t n, const int32_t *src, const int32_t *idx, int32_
 int32_t gs_isect_count_keys(
     uint32_t n_elems, const float *means2d, const int32_t *radii, const float *depths,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
-    int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals, gs_stream_t stream);
+    int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals,
+    int32_t *block_sums /* [gs_isect_count_blocks(n_elems)] or NULL: intersections per block; their sum is n_isects,
+                           known here -- before the depth pre-sort and the prefix sum -- so the host read-back of
+                           isect_tiles.cu:200 can overlap them */,
+    gs_stream_t stream);
+uint32_t gs_isect_count_blocks(uint32_t n_elems);
 int32_t gs_cumsum_gather_i32(
     uint64_t n, const int32_t *in, const int32_t *idx, const uint32_t *n_valid /* device scalar or NULL: positions >= *n_valid count 0 */,
     int64_t *out, void *scratch, size_t scratch_bytes, gs_stream_t stream);
