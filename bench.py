@@ -359,22 +359,23 @@ def main():
     # events.  K = 20 steps last ~20 ms, so the region is REPEATED (every repetition bracketed the same way, the number of
     # repetitions agreed by all ranks) until --min-timed-s has been measured; ms_per_step is total time / total steps.
     def timed_region(n_steps, timer_only):
-        # the cyclic garbage collector is paused inside the region (a generation-2 sweep over the few thousand event
-        # objects of the timers showed up as one 40 ms stall in every ~10th region); collected between regions instead
-        gc.collect()
-        gc.disable()
-        try:
+        barrier()
+        with CallTimer(B, only=timer_only) as ct_:
+            t0_ = time.perf_counter()
+            for _ in range(n_steps):
+                step()
             barrier()
-            with CallTimer(B, only=timer_only) as ct_:
-                t0_ = time.perf_counter()
-                for _ in range(n_steps):
-                    step()
-                barrier()
-                t1_ = time.perf_counter()
-        finally:
-            gc.enable()
+            t1_ = time.perf_counter()
         return max_over_ranks(t1_ - t0_), ct_
 
+    # the cyclic garbage collector is paused while measuring (a generation-2 sweep over the few thousand event objects of
+    # the timers showed up as a 40 ms stall in some regions).  Collected ONCE here, followed by untimed steps: a 40 ms
+    # collection leaves the GPU idle long enough for its clocks to drop, and a region started right after it read ~4%
+    # slow at K = 20 (3% at K = 50) until they had ramped up again -- the regions run back to back instead.
+    gc.collect()
+    gc.disable()
+    for _ in range(max(2, min(args.warmup, 5))):
+        step()
     torch.cuda.reset_peak_memory_stats(dev)
     mem_before = torch.cuda.memory_allocated(dev)
     D.WIRE["bytes"] = 0
@@ -401,6 +402,7 @@ def main():
         e_, _ = timed_region(args.steps, set())
         dense_ms = e_ / args.steps * 1e3
         dense_grad[0] = None
+    gc.enable()
 
     if rank == 0:
         meta = last_meta
