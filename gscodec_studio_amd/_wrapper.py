@@ -641,6 +641,7 @@ def fully_fused_projection(
     sparse_grad: bool = False,
     calc_compensations: bool = False,
     camera_model: Literal["pinhole", "ortho", "fisheye"] = "pinhole",
+    _means_alias: bool = False,  # (internal, unpacked only) also return the means, routed through the projection's backward
 ):
     """Projects Gaussians to 2D.
 
@@ -678,15 +679,16 @@ def fully_fused_projection(
         )
     return _FullyFusedProjection.apply(
         means, covars, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
-        radius_clip, calc_compensations, camera_model,
+        radius_clip, calc_compensations, camera_model, _means_alias,
     )
 
 
 class _FullyFusedProjection(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, covars, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
-                far_plane, radius_clip, calc_compensations, camera_model="pinhole"):
+                far_plane, radius_clip, calc_compensations, camera_model="pinhole", means_alias=False):
         _require_gpu(means, "fully_fused_projection")
+        means_in = means
         means, covars, quats, scales = _f32c(means), _f32c(covars), _f32c(quats), _f32c(scales)
         viewmats, Ks = _f32c(viewmats), _f32c(Ks)
         C, N = viewmats.shape[0], means.shape[0]
@@ -707,10 +709,15 @@ class _FullyFusedProjection(torch.autograd.Function):
         ctx.width, ctx.height, ctx.eps2d, ctx.cm = width, height, eps2d, cm
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)  # unused outputs (radii, depths in RGB mode) arrive as None, not as zero tensors
+        if means_alias:
+            # the means handed through: what a second consumer (the SH view directions) sends back for them arrives in
+            # THIS node's backward, where the projection kernel adds it while writing v_means -- instead of autograd
+            # summing two [N,3] gradients in a pass of its own
+            return radii, means2d, depths, conics, compensations, means_in
         return radii, means2d, depths, conics, compensations
 
     @staticmethod
-    def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_compensations):
+    def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_compensations, v_means_add=None):
         means, covars, quats, scales, viewmats, Ks, radii, conics, compensations = ctx.saved_tensors
         C, N = viewmats.shape[0], means.shape[0]
         dev = means.device
@@ -733,8 +740,9 @@ class _FullyFusedProjection(torch.autograd.Function):
                    B.ptr(viewmats), B.ptr(Ks), int(ctx.width), int(ctx.height), float(ctx.eps2d), ctx.cm,
                    B.ptr(radii), B.ptr(conics), B.ptr(compensations), B.ptr(v_means2d), B.ptr(v_depths),
                    B.ptr(v_conics), B.ptr(v_compensations), B.ptr(v_means), B.ptr(v_covars), B.ptr(v_quats),
-                   B.ptr(v_scales), B.ptr(v_viewmats), s_m2, s_cn, _stream(means))
-        return (v_means, v_covars, v_quats, v_scales, v_viewmats) + (None,) * 9
+                   B.ptr(v_scales), B.ptr(v_viewmats), s_m2, s_cn,
+                   B.ptr(_f32c(v_means_add)) if (v_means_add is not None and v_means is not None) else None, _stream(means))
+        return (v_means, v_covars, v_quats, v_scales, v_viewmats) + (None,) * 10
 
 
 class _FullyFusedProjectionPacked(torch.autograd.Function):
@@ -1081,10 +1089,17 @@ class _RasterizeToPixels(torch.autograd.Function):
         with _device_of(means2d):
             sb = B.query("gs_rasterize_scratch_bytes", C * tile_height * tile_width, n_isects, channels) if needs_bwd else 0
             scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+            # the packed gradient rows of the backward ([n_elems,16], accumulated with atomics) are zero-filled by THIS
+            # launch, as a side job of the tile workgroups: no fill pass in the backward
+            grad_rows = None
+            if needs_bwd and channels <= 4 and n_elems > 0:
+                grad_rows = torch.empty(opacities.shape + (16,), dtype=torch.float32, device=dev)
             B.call("gs_rasterize_fwd", C, n_elems, n_isects, channels, B.ptr(means2d), B.ptr(conics), B.ptr(colors),
                    B.ptr(opacities), B.ptr(backgrounds), B.ptr(m8), width, height, tile_size, tile_width,
                    tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_colors),
-                   B.ptr(render_alphas), B.ptr(last_ids), B.ptr(scratch) if sb else None, sb, _stream(means2d))
+                   B.ptr(render_alphas), B.ptr(last_ids), B.ptr(scratch) if sb else None, sb,
+                   B.ptr(grad_rows), grad_rows.numel() * 4 if grad_rows is not None else 0, _stream(means2d))
+        ctx.grad_rows = grad_rows  # consumed by the first backward; a repeated one (retain_graph) fills its own
         # scratch carries the forward checkpoints of the depth-segmented backward.  The segmented backward rebuilds
         # "colour behind the segment" from the FINAL render (B = v_out . (colour_final - colour_ckpt)), so the output is
         # saved through save_for_backward: autograd then version-checks it and an in-place edit of the returned image
@@ -1115,7 +1130,9 @@ class _RasterizeToPixels(torch.autograd.Function):
         # gradient is one L2 request; the tensors handed to autograd are views of it.
         packed = channels <= 4
         if packed:
-            P = torch.zeros(opacities.shape + (16,), dtype=torch.float32, device=means2d.device)
+            P, ctx.grad_rows = ctx.grad_rows, None
+            if P is None:
+                P = torch.zeros(opacities.shape + (16,), dtype=torch.float32, device=means2d.device)
             v_means2d, v_conics, v_opacities = P[..., 0:2], P[..., 2:5], P[..., 5]
             v_colors = P[..., 6:6 + channels]
             v_means2d_abs = P[..., 10:12] if ctx.absgrad else None

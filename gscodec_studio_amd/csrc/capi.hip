@@ -57,15 +57,21 @@ extern "C" int32_t gs_rasterize_fwd(
     const uint8_t *masks, uint32_t image_width, uint32_t image_height, uint32_t tile_size,
     uint32_t tile_width, uint32_t tile_height, const int32_t *tile_offsets,
     const int32_t *flatten_ids, float *render_colors, float *render_alphas, int32_t *last_ids,
-    void *scratch, size_t scratch_bytes, gs_stream_t stream) {
+    void *scratch, size_t scratch_bytes, void *zero_fill, size_t zero_fill_bytes, gs_stream_t stream) {
     GS_CHECK_ARG(render_colors && render_alphas && last_ids && tile_offsets, "null pointer");
+    GS_CHECK_ARG(zero_fill_bytes == 0 || (zero_fill && (uintptr_t)zero_fill % 16 == 0 && zero_fill_bytes % 16 == 0),
+                 "zero_fill must be 16-byte aligned and a multiple of 16 bytes long");
     GS_CHECK_ARG(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids), "null pointer");
     RasterArgs a = {C, n_elems, n_isects, channels, means2d, conics, colors, opacities, backgrounds, masks,
                     image_width, image_height, tile_size, tile_width, tile_height, tile_offsets, flatten_ids,
                     render_colors, render_alphas, last_ids, 0u};
     if (int32_t rc = check_raster_args(a)) return rc;
-    if (C == 0 || image_width == 0 || image_height == 0) return 0;
-    int32_t rc = raster_wave_fwd(a, scratch, scratch_bytes, (hipStream_t)stream);
+    if (C == 0 || image_width == 0 || image_height == 0) {
+        if (zero_fill_bytes > 0 && hipMemsetAsync(zero_fill, 0, zero_fill_bytes, (hipStream_t)stream) != hipSuccess)
+            { gs_set_error("rasterize: zero fill failed"); return 1; }
+        return 0;
+    }
+    int32_t rc = raster_wave_fwd(a, scratch, scratch_bytes, zero_fill, zero_fill_bytes, (hipStream_t)stream);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;

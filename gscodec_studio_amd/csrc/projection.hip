@@ -258,11 +258,17 @@ GS_DEV void store_gaussian_grads(
     const float *__restrict__ covars, const float *__restrict__ quats,
     const float *__restrict__ scales,
     float *__restrict__ v_means, float *__restrict__ v_covars,
-    float *__restrict__ v_quats, float *__restrict__ v_scales) {
+    float *__restrict__ v_quats, float *__restrict__ v_scales, const float *__restrict__ v_means_add) {
     if (v_means != nullptr) {
-        v_means[3 * (size_t)n] = g.v_px;
-        v_means[3 * (size_t)n + 1] = g.v_py;
-        v_means[3 * (size_t)n + 2] = g.v_pz;
+        // v_means_add: a contribution to d/d means that reached the caller by another path (the view directions of the SH
+        // colours); summed here instead of by a separate elementwise pass over [N,3]
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        if (v_means_add != nullptr) {
+            ax = v_means_add[3 * (size_t)n]; ay = v_means_add[3 * (size_t)n + 1]; az = v_means_add[3 * (size_t)n + 2];
+        }
+        v_means[3 * (size_t)n] = g.v_px + ax;
+        v_means[3 * (size_t)n + 1] = g.v_py + ay;
+        v_means[3 * (size_t)n + 2] = g.v_pz + az;
     }
     if (covars != nullptr) {
         if (v_covars != nullptr) {
@@ -302,7 +308,8 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
     const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
     const float *__restrict__ v_conics, const float *__restrict__ v_compensations,
     float *__restrict__ v_means, float *__restrict__ v_covars, float *__restrict__ v_quats,
-    float *__restrict__ v_scales, float *__restrict__ v_viewmats, uint32_t s_m2, uint32_t s_cn) {
+    float *__restrict__ v_scales, float *__restrict__ v_viewmats, uint32_t s_m2, uint32_t s_cn,
+    const float *__restrict__ v_means_add) {
     __shared__ float s_view[GS_BLOCK / GS_WAVE][12];
     uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
     bool in_range = n < N;
@@ -361,7 +368,7 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
             __syncthreads();
         }
     }
-    if (in_range) store_gaussian_grads(g, n, any, covars, quats, scales, v_means, v_covars, v_quats, v_scales);
+    if (in_range) store_gaussian_grads(g, n, any, covars, quats, scales, v_means, v_covars, v_quats, v_scales, v_means_add);
 }
 
 // ---------------------------------------------------------------------------
@@ -575,7 +582,7 @@ extern "C" int32_t gs_projection_bwd(
     const float *conics, const float *compensations, const float *v_means2d,
     const float *v_depths, const float *v_conics, const float *v_compensations, float *v_means,
     float *v_covars, float *v_quats, float *v_scales, float *v_viewmats, uint32_t v_means2d_stride,
-    uint32_t v_conics_stride, gs_stream_t stream) {
+    uint32_t v_conics_stride, const float *v_means_add, gs_stream_t stream) {
     if (N == 0) return 0;
     GS_CHECK_ARG(means && viewmats && Ks && radii && conics && v_means2d && v_conics,
                  "null pointer");
@@ -590,13 +597,13 @@ extern "C" int32_t gs_projection_bwd(
                            means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
                            camera_model, radii, conics, compensations, v_means2d, v_depths, v_conics,
                            v_compensations, v_means, v_covars, v_quats, v_scales, v_viewmats, v_means2d_stride,
-                           v_conics_stride);
+                           v_conics_stride, v_means_add);
     } else {
         hipLaunchKernelGGL(projection_bwd_kernel<false>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
                            means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
                            camera_model, radii, conics, compensations, v_means2d, v_depths, v_conics,
                            v_compensations, v_means, v_covars, v_quats, v_scales, v_viewmats, v_means2d_stride,
-                           v_conics_stride);
+                           v_conics_stride, v_means_add);
     }
     GS_CHECK_LAUNCH();
     return 0;

@@ -435,7 +435,8 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
 template <int CDIM, bool CKPT>
 __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, float *__restrict__ ckpt, int32_t seg, int32_t solo_min,
                                                               uint32_t *__restrict__ cost_head, uint32_t *__restrict__ cost_body,
-                                                              uint32_t *__restrict__ body_tile, uint32_t *__restrict__ class_count) {
+                                                              uint32_t *__restrict__ body_tile, uint32_t *__restrict__ class_count,
+                                                              ZeroFill zf) {
     constexpr int REC = 3;
     constexpr int BATCH = 256;
     // records of both buffers in ONE array + a null record (alpha = 0) that pads every list to a multiple of four
@@ -461,11 +462,22 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
     const float px = (float)x + 0.5f, py = (float)y + 0.5f;
     const size_t pix = ((size_t)tg.cam * a.image_height + y) * a.image_width + x;
 
+    // Side job: this workgroup's slice of the buffer the matching backward will accumulate into (zf, see gs_rasterize_fwd).
+    // Issued as the workgroup's LAST instructions: nothing waits for the stores, and the memory pipes are mostly idle
+    // while the chip composites -- the separate 64 MB fill kernel (+ its launch gap) of the backward disappears.
+    auto zero_fill_slice = [&]() {
+        if (!CKPT || zf.ptr == nullptr) return;
+        const size_t base = (size_t)blockIdx.x * zf.per_block;
+        for (uint32_t i = tid; i < zf.per_block; i += 256u)
+            if (base + i < zf.n) zf.ptr[base + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+
     if (a.masks != nullptr && !a.masks[tg.lin]) {
         if (inside) {
 #pragma unroll
             for (int k = 0; k < CDIM; ++k) a.render_colors[pix * CDIM + k] = bg ? bg[k] : 0.f;
         }
+        zero_fill_slice();
         return;
     }
 
@@ -778,16 +790,17 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
         for (int k = 0; k < CDIM; ++k) a.render_colors[pix * CDIM + k] = bg ? out[k] + Tf * bg[k] : out[k];
         a.last_ids[pix] = cur;
     }
+    zero_fill_slice();
 }
 
 template <int CDIM>
 void launch_tile_fwd(const RasterArgs &a, float *ckpt, int32_t seg, int32_t solo_min, uint32_t *cost_head, uint32_t *cost_body,
-                     uint32_t *body_tile, uint32_t *class_count, hipStream_t st) {
+                     uint32_t *body_tile, uint32_t *class_count, ZeroFill zf, hipStream_t st) {
     dim3 grid(a.C * a.tile_width * a.tile_height);
     if (ckpt != nullptr)
-        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true>), grid, dim3(256), 0, st, a, ckpt, seg, solo_min, cost_head, cost_body, body_tile, class_count);
+        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true>), grid, dim3(256), 0, st, a, ckpt, seg, solo_min, cost_head, cost_body, body_tile, class_count, zf);
     else
-        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, false>), grid, dim3(256), 0, st, a, ckpt, seg, solo_min, cost_head, cost_body, body_tile, class_count);
+        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, false>), grid, dim3(256), 0, st, a, ckpt, seg, solo_min, cost_head, cost_body, body_tile, class_count, zf);
 }
 
 // ---------------------------------------------------------------------------
@@ -1486,9 +1499,20 @@ size_t raster_wave_scratch_bytes(uint32_t n_tiles_all, uint32_t n_isects, uint32
     return scratch_layout(n_tiles_all, n_isects, channels).total;
 }
 
-int32_t raster_wave_fwd(const RasterArgs &a_in, void *scratch, size_t scratch_bytes, hipStream_t st) {
+int32_t raster_wave_fwd(const RasterArgs &a_in, void *scratch, size_t scratch_bytes, void *zero_fill, size_t zero_fill_bytes,
+                        hipStream_t st) {
     RasterArgs a = a_in;
     const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;
+    // the side job: spread over the tile workgroups when each gets at most 64 KB of it, a plain fill otherwise
+    ZeroFill zf = {nullptr, 0, 0u};
+    if (zero_fill != nullptr && zero_fill_bytes > 0) {
+        const size_t n16 = zero_fill_bytes / 16;
+        const size_t per = (n16 + n_tiles_all - 1) / (n_tiles_all ? n_tiles_all : 1);
+        const bool in_kernel = a.channels <= 4 && seg_len(a.n_isects) > 0 && scratch != nullptr && n_tiles_all > 0 && per <= 4096 &&
+                               scratch_bytes >= scratch_layout(n_tiles_all, a.n_isects, a.channels).total;
+        if (in_kernel) zf = {(float4 *)zero_fill, n16, (uint32_t)per};
+        else if (hipMemsetAsync(zero_fill, 0, zero_fill_bytes, st) != hipSuccess) { gs_set_error("rasterize: zero fill failed"); return 1; }
+    }
     if (a.channels <= 4) {
         // one 256-thread workgroup per tile; checkpoints for the segmented backward when the caller handed over scratch
         const ScratchLayout L = scratch_layout(n_tiles_all, a.n_isects, a.channels);
@@ -1502,10 +1526,10 @@ int32_t raster_wave_fwd(const RasterArgs &a_in, void *scratch, size_t scratch_by
         uint32_t *bt = ckpt ? (uint32_t *)((char *)scratch + L.off_body_tile) : nullptr;
         uint32_t *cc = ckpt ? (uint32_t *)scratch : nullptr;
         switch (a.channels) {
-            case 1: launch_tile_fwd<1>(a, ckpt, seg, solo, ch, cb, bt, cc, st); break;
-            case 2: launch_tile_fwd<2>(a, ckpt, seg, solo, ch, cb, bt, cc, st); break;
-            case 3: launch_tile_fwd<3>(a, ckpt, seg, solo, ch, cb, bt, cc, st); break;
-            default: launch_tile_fwd<4>(a, ckpt, seg, solo, ch, cb, bt, cc, st); break;
+            case 1: launch_tile_fwd<1>(a, ckpt, seg, solo, ch, cb, bt, cc, zf, st); break;
+            case 2: launch_tile_fwd<2>(a, ckpt, seg, solo, ch, cb, bt, cc, zf, st); break;
+            case 3: launch_tile_fwd<3>(a, ckpt, seg, solo, ch, cb, bt, cc, zf, st); break;
+            default: launch_tile_fwd<4>(a, ckpt, seg, solo, ch, cb, bt, cc, zf, st); break;
         }
         if (ckpt != nullptr) // the backward's work list, ordered by the costs just counted
             hipLaunchKernelGGL(seg_items_build_kernel, dim3(gs_div_up(L.max_items, GS_BLOCK)), dim3(GS_BLOCK), 0, st, n_tiles_all, a.n_isects,

@@ -20,6 +20,13 @@ struct RasterArgs {
     uint32_t xcd_group; // XCD-aware work-item grouping (0 = off), set by the dispatcher
 };
 
+// a buffer the forward zero-fills on the side: n float4s, per_block of them per tile workgroup
+struct ZeroFill {
+    float4 *ptr;
+    size_t n;
+    uint32_t per_block;
+};
+
 struct RasterGradArgs {
     const float *render_alphas;
     const int32_t *last_ids;
@@ -55,6 +62,7 @@ GS_DEV float wave_reduce_sum_dpp(float v) {
 
 int32_t raster_set_tuning(const char *key, int32_t value);
 size_t raster_wave_scratch_bytes(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels);
-int32_t raster_wave_fwd(const RasterArgs &a, void *scratch, size_t scratch_bytes, hipStream_t st);
+int32_t raster_wave_fwd(const RasterArgs &a, void *scratch, size_t scratch_bytes, void *zero_fill, size_t zero_fill_bytes,
+                        hipStream_t st);
 int32_t raster_wave_bwd(const RasterArgs &a, const RasterGradArgs &ga, const float *render_colors, void *scratch,
                         size_t scratch_bytes, hipStream_t st);

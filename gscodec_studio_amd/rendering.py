@@ -172,12 +172,19 @@ def rasterization(
                 cap_world = None
         C = len(viewmats)
 
+    # the fused SH route reads the means a second time (view directions): it gets them back FROM the projection, so that
+    # its contribution to d/d means is added inside the projection's backward kernel
+    means_alias = (sh_degree is not None and not packed and colors.dim() == 3 and means.requires_grad
+                   and not viewmats.requires_grad and viewmats.is_cuda)
     proj_results = fully_fused_projection(
         means, covars, quats, scales, viewmats, Ks, width, height,
         eps2d=eps2d, packed=packed, near_plane=near_plane, far_plane=far_plane,
         radius_clip=radius_clip, sparse_grad=sparse_grad,
-        calc_compensations=(rasterize_mode == "antialiased"), camera_model=camera_model,
+        calc_compensations=(rasterize_mode == "antialiased"), camera_model=camera_model, _means_alias=means_alias,
     )
+    means_sh = means
+    if means_alias:
+        means_sh, proj_results = proj_results[5], proj_results[:5]
 
     if packed:
         camera_ids, gaussian_ids, radii, means2d, depths, conics, compensations = proj_results
@@ -238,10 +245,10 @@ def rasterization(
             if fuse:
                 # fused: camera centres, dirs, mask, SH and clamp_min(. + 0.5, 0) in one kernel each way
                 if opacity_rider:
-                    colors, opacities = spherical_harmonics_view(sh_degree, means, viewmats, colors, radii, opacities=opacities_n)
+                    colors, opacities = spherical_harmonics_view(sh_degree, means_sh, viewmats, colors, radii, opacities=opacities_n)
                     meta["opacities"] = opacities
                 else:
-                    colors = spherical_harmonics_view(sh_degree, means, viewmats, colors, radii)  # [C, N, 3]
+                    colors = spherical_harmonics_view(sh_degree, means_sh, viewmats, colors, radii)  # [C, N, 3]
                 fused_sh = True
             else:
                 dirs = means[None, :, :] - campos[:, None, :]  # [C, N, 3]

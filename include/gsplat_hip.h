@@ -108,6 +108,8 @@ int32_t gs_projection_bwd(
     float *v_viewmats,/* [C,4,4] or NULL */
     uint32_t v_means2d_stride, /* row stride of v_means2d in floats: 2, or 16 for the packed compositing rows */
     uint32_t v_conics_stride,  /* row stride of v_conics in floats: 3, or 16 */
+    const float *v_means_add,  /* [N,3] or NULL: added to v_means (the d/d means that arrives through the SH view
+                                  directions, rendering.py:381-391 in the reference; saves autograd's elementwise sum) */
     gs_stream_t stream);
 
 /* packed (COO) projection, replaces fully_fused_projection_packed_fwd_tensor
@@ -348,6 +350,10 @@ int32_t gs_rasterize_fwd(
     float *render_alphas, /* [C,H,W,1] */
     int32_t *last_ids,    /* [C,H,W] */
     void *scratch, size_t scratch_bytes,
+    void *zero_fill, size_t zero_fill_bytes, /* optional side job (NULL, 0: none): a 16-byte aligned buffer this call
+                                                zero-fills, its stores spread over the tile workgroups' last instructions --
+                                                meant for the gradient rows the matching gs_rasterize_bwd accumulates into,
+                                                which then need no fill pass of their own */
     gs_stream_t stream);
 
 int32_t gs_rasterize_bwd(

@@ -47,9 +47,9 @@ def test_argument_validation_happens_before_any_launch():
     with pytest.raises(RuntimeError, match="degree must be <= 4"):
         B.call("gs_sh_fwd", 1, 1, 36, 5, 1, 1, 0, None, 1, None)
     with pytest.raises(RuntimeError, match="unsupported number of colour channels"):
-        B.call("gs_rasterize_fwd", 1, 1, 0, 600, None, None, None, None, None, None, 16, 16, 16, 1, 1, 1, None, 1, 1, 1, None, 0, None)
+        B.call("gs_rasterize_fwd", 1, 1, 0, 600, None, None, None, None, None, None, 16, 16, 16, 1, 1, 1, None, 1, 1, 1, None, 0, None, 0, None)
     with pytest.raises(RuntimeError, match="tile_size must be in"):
-        B.call("gs_rasterize_fwd", 1, 1, 0, 3, None, None, None, None, None, None, 16, 16, 32, 1, 1, 1, None, 1, 1, 1, None, 0, None)
+        B.call("gs_rasterize_fwd", 1, 1, 0, 3, None, None, None, None, None, None, 16, 16, 32, 1, 1, 1, None, 1, 1, 1, None, 0, None, 0, None)
     with pytest.raises(RuntimeError, match="temp too small"):
         B.call("gs_sort_pairs_u64_i32", 10, 1, 1, 1, 1, 0, 40, None, 0, None)
 
