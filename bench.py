@@ -30,7 +30,10 @@ The JSON line carries two extra objects:
                 duration vs the 8 TB/s HBM peak.
   cpu_baseline  the CPU oracle (oracle/gs_oracle.c, a port -- kind "port") timed on this host on the bench workload itself
                 (1 warm-up + 3 fwd+bwd passes, ~3 s each on 128 threads; --cpu-scene-grid 1 selects 1/9 of it).
-Also reported: peak_mem_gb / step_mem_gb (the reference protocol's Mem column), ms_per_step_dense_image_grad (the same step
+Also reported: ms_per_step_without_loss_forward (the reference times rasterization() and loss.backward() but evaluates
+loss = render.sum() once, outside its timers (profiling/main.py:104-133); ``value`` keeps the sum's forward kernel inside
+every step, this figure shows the step without it),
+peak_mem_gb / step_mem_gb (the reference protocol's Mem column), ms_per_step_dense_image_grad (the same step
 with a dense [C,H,W,3] image gradient instead of the protocol's broadcast one), psnr_vs_oracle (config 1).
 """
 import argparse
@@ -301,6 +304,10 @@ def main():
             plan = plan_sparse_grad_exchange(meta["radii"], world) if (mode == "camera_sparse" and use_pg) else None
             if dense_grad[0] is None:
                 rc.sum().backward()  # the reference's timing protocol (profiling/main.py:125-133): a broadcast gradient of ones
+            elif isinstance(dense_grad[0], str):  # "expanded-one"
+                # what the reference's timed backward() actually contains: loss = render.sum() is evaluated ONCE, outside
+                # its timers; loss.backward() then creates a one-element gradient and expands it
+                rc.backward(gradient=torch.ones((), dtype=rc.dtype, device=rc.device).expand_as(rc))
             else:
                 rc.backward(gradient=dense_grad[0])  # a training loss hands the compositing backward a DENSE [C,H,W,3] gradient
             if mode in ("camera", "camera_sparse") and use_pg:
@@ -394,13 +401,18 @@ def main():
         print("  regions (ms/step): " + " ".join(f"{r / args.steps * 1e3:.3f}" for r in regions), file=sys.stderr)
 
     # variant: a DENSE image gradient (what a real training loss produces) next to the broadcast one of the protocol
-    dense_ms = None
+    dense_ms = nosum_ms = None
     if not args.no_extras:
         dense_grad[0] = torch.ones((1, w["height"], w["width"], 3), dtype=torch.float32, device=dev)
         for _ in range(3):
             step()
         e_, _ = timed_region(args.steps, set())
         dense_ms = e_ / args.steps * 1e3
+        dense_grad[0] = "expanded-one"
+        for _ in range(3):
+            step()
+        e_, _ = timed_region(args.steps, set())
+        nosum_ms = e_ / args.steps * 1e3
         dense_grad[0] = None
     gc.enable()
 
@@ -430,6 +442,7 @@ def main():
             "wire": {"bytes_out_per_rank_per_step": wire_bytes_per_step, "xgmi_floor_ms": wire_bytes_per_step / (7 * 153e9) * 1e3,
                      "xgmi_peak_gbs_per_gpu": 7 * 153} if use_pg else None,
             "ms_per_step_dense_image_grad": dense_ms,
+            "ms_per_step_without_loss_forward": nosum_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"BASELINE config 2: load_test_data(scene_grid={args.scene_grid}) -> {N} gaussians, "

@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
     const uint32_t lane = threadIdx.x % GS_WAVE, wave = threadIdx.x / GS_WAVE;
     const uint32_t wave_first = (blockIdx.x * EMIT_WAVES + wave) * EMIT_SPW;
     if (wave_first >= n_elems) return; // wave-uniform
+    if (n_valid != nullptr && wave_first >= *n_valid) return; // behind the valid prefix (cum_tiles is not defined there)
     const uint32_t pos = wave_first + lane; // lanes >= EMIT_SPW carry no splat
     const uint32_t wave_last = min(wave_first + EMIT_SPW, n_elems) - 1;
     const int64_t out0 = (wave_first == 0) ? 0 : cum_tiles[wave_first - 1];
@@ -250,6 +251,7 @@ __global__ void __launch_bounds__(GS_BLOCK) scan_block_sums_kernel(
     __shared__ int64_t s_wave[GS_BLOCK / GS_WAVE];
     uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
     const uint64_t nv = n_valid != nullptr ? min(n, (uint64_t)*n_valid) : n;
+    if (n_valid != nullptr && base >= nv) return; // behind the valid prefix: nobody reads this block's sum (see scan_apply_kernel)
     int64_t s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
@@ -281,6 +283,9 @@ __global__ void __launch_bounds__(GS_BLOCK) scan_apply_kernel(
     const int64_t *__restrict__ block_sums, OutT *__restrict__ out, int32_t raw_sums) {
     __shared__ int64_t s_wave[GS_BLOCK / GS_WAVE];
     const uint64_t nv = n_valid != nullptr ? min(n, (uint64_t)*n_valid) : n;
+    // positions behind the valid prefix carry no element: `out` stays unwritten from the first block that lies entirely
+    // behind it (gs_isect_emit* never reads there when it is handed the same n_valid)
+    if (n_valid != nullptr && (uint64_t)blockIdx.x * SCAN_TILE >= nv) return;
     // raw_sums: block_sums holds the per-block totals themselves (no spine launch for up to a few thousand blocks):
     // the offset of this block is the sum of its predecessors' totals
     int64_t offset;

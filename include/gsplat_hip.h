@@ -261,7 +261,7 @@ int32_t gs_isect_count_keys(
     gs_stream_t stream);
 uint32_t gs_isect_count_blocks(uint32_t n_elems);
 int32_t gs_cumsum_gather_i32(
-    uint64_t n, const int32_t *in, const int32_t *idx, const uint32_t *n_valid /* device scalar or NULL: positions >= *n_valid count 0 */,
+    uint64_t n, const int32_t *in, const int32_t *idx, const uint32_t *n_valid /* device scalar or NULL: only out[0, *n_valid) is defined (hand the same n_valid to gs_isect_emit*) */,
     int64_t *out, void *scratch, size_t scratch_bytes, gs_stream_t stream);
 
 int32_t gs_isect_emit(
