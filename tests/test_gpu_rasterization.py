@@ -403,6 +403,16 @@ def test_repeated_backward_and_means_gradient_routes():
     g2 = torch.autograd.grad((rc * w).sum() + ra.sum(), P)
     for a, b, name in zip(g1, g2, ("means", "quats", "scales", "opacities", "sh")):
         assert rel_l2(N(a), N(b)) < 1e-4, name  # (float atomics: the order differs run to run; quaternion gradients reach ~2e-5)
+    # the same on a 32x16 crop: two tiles for 5000 gradient rows, i.e. more than a tile workgroup takes on as its side job --
+    # the forward zero-fills them with a plain fill instead
+    rc_s, ra_s, meta_s = rasterization(*P, T(d["viewmats"]), T(d["Ks"]), 32, 16, sh_degree=3, packed=False)
+    assert int((meta_s["tiles_per_gauss"] > 0).sum()) > 0
+    h1 = torch.autograd.grad(rc_s.sum() + ra_s.sum(), P, retain_graph=True)
+    h2 = torch.autograd.grad(rc_s.sum() + ra_s.sum(), P)
+    for a, b, name in zip(h1, h2, ("means", "quats", "scales", "opacities", "sh")):
+        assert rel_l2(N(a), N(b)) < 1e-4, name
+    untouched = N((meta_s["tiles_per_gauss"] == 0).all(dim=0))
+    assert (N(h1[3])[untouched] == 0).all() and (N(h1[4])[untouched] == 0).all()
 
     # route split: colours computed from detached means (no SH route), then from detached geometry (SH route only)
     m = P[0]
