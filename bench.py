@@ -478,6 +478,10 @@ def main():
     if use_pg:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL writes its version banner through C stdio, which a pipe buffers until exit: push it out now, so that the JSON
+    # line really is the last line of stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(out), flush=True)  # the last line of stdout, after any library banners
