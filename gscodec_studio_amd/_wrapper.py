@@ -855,6 +855,13 @@ def isect_tiles(
     Returns (tiles_per_gauss i32, isect_ids i64 [n_isects], flatten_ids i32 [n_isects]);
     an id is ``camera_id << (32 + tile_bits) | tile_id << 32 | float_bits(depth)``.
     """
+    return isect_tiles_finish(isect_tiles_start(means2d, radii, depths, tile_size, tile_width, tile_height, sort, packed,
+                                                n_cameras, camera_ids, gaussian_ids))
+
+
+def isect_tiles_start(means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, packed=False, n_cameras=None,
+                      camera_ids=None, gaussian_ids=None):
+    """``isect_tiles`` up to its host read-back (same arguments); hand the result to ``isect_tiles_finish``."""
     if packed:
         nnz = means2d.size(0)
         assert means2d.shape == (nnz, 2), means2d.size()
@@ -875,8 +882,7 @@ def isect_tiles(
         assert depths.shape == (C, N), depths.size()
         camera_ids = None
         n_elems = C * N
-    return isect_tiles_finish(isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height, sort, C, N,
-                                                n_elems, camera_ids))
+    return isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height, sort, C, N, n_elems, camera_ids)
 
 
 # pinned host buffers the count kernel writes its per-block sums into: taken in isect_tiles_begin, handed back in

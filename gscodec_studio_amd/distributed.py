@@ -444,7 +444,7 @@ def sparse_capacity(C_local: int, N: int, full: bool = False) -> int:
         pinned, ev, rows = st["stats"]
         ev.synchronize()
         if rows > 0:
-            st["frac"] = min(1.0, float(pinned[0]) / rows * _SPARSE_HEADROOM + 0.01)
+            st["frac"] = min(1.0, float(pinned[1]) / rows * _SPARSE_HEADROOM + 0.01)  # (overflow, max count, own overflow)
         st["stats"] = None
     rows = C_local * N
     if full or st["frac"] >= 1.0:
@@ -509,15 +509,20 @@ class _ExchangeSparse(torch.autograd.Function):
         key = (tuple(recv_splits), dev)
         if key not in _HDR_ROWS:
             _HDR_ROWS[key] = (torch.tensor(recv_splits, dtype=torch.int64).cumsum(0) - 1).to(dev)
-        over = (recv_i[_HDR_ROWS[key], 1] >> 30).max().reshape(1)
+        # one small kernel stores (overflow, max count, own overflow) straight into pinned host memory: no torch indexing /
+        # reduction kernels, no copy commands, and the host reads them after the tile-count event it waits for anyway
+        from . import _backend as B
+
+        # (one persistent buffer: both readers run on the host before the next exchange is queued)
         if _SPARSE.get("pinned") is None:
-            _SPARSE["pinned"] = (torch.empty(1, dtype=torch.int32).pin_memory(), torch.empty(2, dtype=torch.int32).pin_memory())
-        p_over, p_stats = _SPARSE["pinned"]
-        p_over.copy_(over, non_blocking=True)
-        p_stats.copy_(stats, non_blocking=True)
+            _SPARSE["pinned"] = torch.empty(3, dtype=torch.int32).pin_memory()
+        p3 = _SPARSE["pinned"]
+        with torch.cuda.device(dev):
+            B.call("gs_exchange_flags", world, B.ptr(recv_i), int(recv.shape[1]), B.ptr(_HDR_ROWS[key]), B.ptr(stats), B.ptr(p3),
+                   torch.cuda.current_stream(dev).cuda_stream)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        _SPARSE["overflow"], _SPARSE["stats"] = (p_over, ev), (p_stats, ev, C_local * N)
+        _SPARSE["overflow"], _SPARSE["stats"] = (p3, ev), (p3, ev, C_local * N)
         ctx.meta = (N, C_total, D, send_splits, recv_splits)
         ctx.save_for_backward(src_index, dst_recv)
         ctx.mark_non_differentiable(outs[0])

@@ -30,6 +30,7 @@ from ._wrapper import (
     isect_tiles,
     isect_tiles_begin,
     isect_tiles_finish,
+    isect_tiles_start,
     rasterize_to_pixels,
     spherical_harmonics,
     spherical_harmonics_shared,
@@ -271,7 +272,9 @@ def rasterization(
             (C, radii, means2d, depths, conics, opacities, colors, camera_ids, gaussian_ids) = D.exchange_projected(
                 world_rank, world_size, N, N_world, C_world, packed, *pre, cap_world=cap_world,
             )
-            tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
+            # binning up to its read-back; the depth pre-sort queued behind the count keeps the GPU busy while the host
+            # looks at the overflow flags (stored to pinned memory before the count) and comes back for the rest
+            isect_state = isect_tiles_start(
                 means2d, radii, depths, tile_size, tile_width, tile_height,
                 packed=packed, n_cameras=C, camera_ids=camera_ids, gaussian_ids=gaussian_ids,
             )

@@ -578,6 +578,12 @@ int32_t gs_rows_unpack_indexed(
 int32_t gs_exchange_compact(
     uint32_t C_total, uint32_t N, uint32_t C_local, uint32_t world, uint32_t cap, uint32_t N_total, uint32_t N_off,
     const int32_t *radii, int32_t *src_index, int32_t *hdr, uint32_t *counters, uint32_t *stats, gs_stream_t stream);
+/* After the all-to-all of those chunks: out3 = (some sender overflowed (bit 30 of the count in the header row hdr_rows[d] of
+ * every received chunk; recv rows are row_width ints wide), stats[0], stats[1]).  out3 may be pinned HOST memory: the flags
+ * then reach the host with the renderer's own tile-count read-back, without a copy command or a sync of their own. */
+int32_t gs_exchange_flags(
+    uint32_t world, const int32_t *recv, uint32_t row_width, const int64_t *hdr_rows, const uint32_t *stats, int32_t *out3,
+    gs_stream_t stream);
 /* ------------------------------------------------------------------------
  * Row gather and its adjoint for the packed (COO) pipeline: the torch indexing `opacities[gaussian_ids]`,
  * `colors[gaussian_ids]`, `means[gaussian_ids]` of gsplat/rendering.py:325, 365-380 and its backward (torch sorts the
