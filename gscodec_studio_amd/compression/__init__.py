@@ -9,10 +9,12 @@
   ordering in front of the grid codec (``sort_splats`` = PLAS, an external package as in the reference; ``morton_order`` =
   deterministic substitute).
 
-Not built: the lossless containers themselves (PNG via ``imageio``, npz files) -- CPU library code on either side of the
-arrays this package produces and consumes.
+* ``png_compression``: the file level -- ``PngCompression.compress(dir, splats)`` / ``decompress(dir)`` with the reference's
+  directory layout (PNG image grids, ``shN.npz`` + ``mask.bin``, ``meta.json``) and a self-contained 8-bit PNG reader /
+  writer (the image has no imageio), so directories written by either implementation are read by the other.
 """
 from .decode import decode_to_rasterizer_inputs, kmeans_decode, kmeans_encode, morton_order, sort_splats
+from .png_compression import PngCompression, png_read, png_write
 from .grid_codec import (
     compress_to_arrays,
     decompress_from_arrays,
@@ -24,4 +26,4 @@ from .grid_codec import (
 
 __all__ = ["quantize_grid", "dequantize_grid", "compress_to_arrays", "decompress_from_arrays", "log_transform",
            "inverse_log_transform", "decode_to_rasterizer_inputs", "kmeans_decode", "kmeans_encode", "morton_order",
-           "sort_splats"]
+           "sort_splats", "PngCompression", "png_read", "png_write"]

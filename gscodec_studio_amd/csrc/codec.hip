@@ -117,3 +117,31 @@ extern "C" int32_t gs_kmeans_decode(uint64_t n_rows, uint32_t width, const int32
     GS_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PNG scanline reconstruction (host code; the inverse of the five PNG filter types, PNG specification section 9): the
+// sequential-in-x part of reading the reference's image grids (imageio / Pillow write them with adaptive filters).
+// data: h rows of (1 + stride) bytes -- filter type, then the filtered scanline; out: h rows of stride bytes.
+extern "C" int32_t gs_png_unfilter(const uint8_t *data, uint32_t h, uint32_t stride, uint32_t bpp, uint8_t *out) {
+    GS_CHECK_ARG(data && out && bpp >= 1 && bpp <= 8 && stride >= bpp, "null pointer / bytes per pixel");
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t *src = data + (size_t)y * (stride + 1);
+        const uint8_t ft = src[0];
+        const uint8_t *in = src + 1, *up = y ? out + (size_t)(y - 1) * stride : nullptr;
+        uint8_t *o = out + (size_t)y * stride;
+        GS_CHECK_ARG(ft <= 4, "unknown PNG filter type");
+        for (uint32_t x = 0; x < stride; ++x) {
+            const int a = x >= bpp ? o[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
+            int pred = 0;
+            if (ft == 1) pred = a;
+            else if (ft == 2) pred = b;
+            else if (ft == 3) pred = (a + b) >> 1;
+            else if (ft == 4) {
+                const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            }
+            o[x] = (uint8_t)(in[x] + pred);
+        }
+    }
+    return 0;
+}

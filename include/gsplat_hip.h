@@ -525,6 +525,11 @@ int32_t gs_decode_splats(
  * centroids_quant[labels[r], :] / (2^bits - 1) * (maxs - mins) + mins (float64 arithmetic like the reference). */
 int32_t gs_kmeans_decode(uint64_t n_rows, uint32_t width, const int32_t *labels, const uint8_t *centroids_quant,
                          uint32_t bits, float mins, float maxs, float *out, gs_stream_t stream);
+/* PNG scanline reconstruction, HOST code (PNG specification section 9: filter types 0..4): data = h rows of 1 + stride bytes
+ * (filter type, filtered scanline), out = h rows of stride bytes, bpp = bytes per pixel.  The sequential part of reading the
+ * image grids the reference writes through imageio (gsplat/compression/png_compression.py:196, 271, 344-349). */
+int32_t gs_png_unfilter(const uint8_t *data, uint32_t h, uint32_t stride, uint32_t bpp, uint8_t *out);
+
 
 /* ------------------------------------------------------------------------
  * Temporal slicing of dynamic (spacetime) gaussians at one timestamp: the elementwise

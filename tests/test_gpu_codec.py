@@ -144,3 +144,91 @@ def test_decode_then_render_full_size_and_kmeans_round_trip():
     assert bool((cent[same] == cent[same][0]).all())
     mean0 = shn.reshape(50_000, -1)[same].mean(0)
     assert float((cent[same][0] - mean0).abs().max()) <= 0.5 * step * 1.01 + 1e-6
+
+
+def test_png_directory_written_like_the_reference_is_decoded_bit_exact(tmp_path):
+    """File level: the golden planes laid out on disk the way PngCompression.compress of the reference does (image grids as
+    PNG files -- written with Sub / Up / Average / Paeth rows like imageio's encoder chooses them --, shN.npz, mask.bin,
+    meta.json) and read back by ``PngCompression.decompress``: what the reference's own decompress returned for the same
+    planes (tests/golden/make_golden_codec_pipeline.py)."""
+    import json
+    import struct
+    import zlib
+
+    from test_png_cpu import CTYPE, MAGIC, _chunk, _filter_rows
+
+    from gscodec_studio_amd.compression import PngCompression
+
+    gd, arrays, meta = _pipeline_arrays()
+    side = int(gd["n_sidelen"])
+
+    def write_png(name, plane):
+        img = plane.reshape(side, side, -1)
+        types = [(y * 7 + 3) % 5 for y in range(side)]
+        ihdr = struct.pack(">IIBBBBB", side, side, 8, CTYPE[img.shape[2]], 0, 0, 0)
+        (tmp_path / name).write_bytes(MAGIC + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", zlib.compress(_filter_rows(img, types))) + _chunk(b"IEND", b""))
+
+    for name in ("means", "scales", "quats", "opacities", "sh0"):
+        if int(gd[f"{name}.bits"]) == 16:
+            write_png(f"{name}_l.png", gd[f"{name}.plane0"])
+            write_png(f"{name}_u.png", gd[f"{name}.plane1"])
+        else:
+            write_png(f"{name}.png", gd[f"{name}.plane0"])
+    mask = gd["shN.mask"].astype(bool)
+    np.packbits(mask)[: (len(mask) + 7) // 8].tofile(str(tmp_path / "mask.bin"))
+    np.savez_compressed(str(tmp_path / "shN.npz"), centroids=gd["shN.centroids"], labels=gd["shN.labels"].astype(np.uint16))
+    meta["shN"].update({"mask_bits": len(mask), "mask_byte": (len(mask) + 7) // 8})
+    (tmp_path / "meta.json").write_text(json.dumps(meta))
+
+    out = PngCompression().decompress(str(tmp_path))
+    for name in ("scales", "quats", "opacities", "sh0", "shN"):
+        assert np.array_equal(N(out[name]).view(np.uint32), gd[f"{name}.decoded"].view(np.uint32)), name
+    ref_m = gd["means.decoded"]
+    assert np.all(np.abs(N(out["means"]) - ref_m) <= 2.4e-7 * np.abs(ref_m) + 1e-30)
+
+
+def test_png_compression_directory_round_trip(tmp_path):
+    """compress -> files -> decompress equals the array-level pipeline on the same (filtered, cropped, ordered) splats;
+    PLAS ordering needs the external package exactly as in the reference."""
+    import os
+
+    from gscodec_studio_amd.compression import PngCompression, compress_to_arrays, decompress_from_arrays, morton_order
+
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n = 70 * 70 + 37
+    splats = {"means": torch.randn(n, 3, generator=g) * 4, "scales": torch.randn(n, 3, generator=g) - 3,
+              "quats": torch.randn(n, 4, generator=g), "opacities": torch.randn(n, generator=g) * 3,
+              "sh0": torch.randn(n, 1, 3, generator=g), "shN": torch.randn(n, 15, 3, generator=g) * 0.1,
+              "features": torch.randn(n, 5, generator=g)}
+    splats["shN"][::3] = -splats["shN"][::3].abs()  # a third of the splats has no positive higher-band coefficient: masked out
+    splats = {k: v.cuda() for k, v in splats.items()}
+    with pytest.raises(ImportError):
+        PngCompression(verbose=False).compress(str(tmp_path / "plas"), dict(splats))
+
+    for mode in (False, "morton"):
+        d = str(tmp_path / f"dir_{mode}")
+        PngCompression(use_sort=mode, verbose=False, n_clusters=256).compress(d, dict(splats))
+        assert sorted(os.listdir(d)) == sorted(["meta.json", "means_l.png", "means_u.png", "scales.png", "quats.png", "opacities.png",
+                                                "sh0.png", "shN.npz", "mask.bin", "features.npz"])
+        out = PngCompression().decompress(d)
+        # the same splats through the array-level pipeline
+        keep = torch.sigmoid(splats["opacities"]) >= 0.005
+        kept = {k: v[keep] for k, v in splats.items()}
+        side = int(len(kept["means"]) ** 0.5)
+        crop = torch.argsort(kept["opacities"], descending=True)[: side * side]
+        kept = {k: v[crop] for k, v in kept.items()}
+        if mode == "morton":
+            from gscodec_studio_amd.compression import log_transform
+            order = morton_order(log_transform(kept["means"]))
+            kept = {k: v[order] for k, v in kept.items()}
+        arrays, meta = compress_to_arrays({k: kept[k] for k in ("means", "scales", "quats", "opacities", "sh0")})
+        want = decompress_from_arrays(arrays, meta)
+        for k in ("means", "scales", "quats", "opacities", "sh0"):
+            assert torch.equal(out[k], want[k]), (mode, k)
+        assert torch.equal(out["features"], kept["features"])
+        has = (kept["shN"] > 0).any(dim=1).any(dim=1)
+        assert bool((out["shN"][~has] == 0).all()) and out["shN"].shape == kept["shN"].shape
+        # a 256-entry codebook of 15x3 coefficients: coarse, but every decoded row must be one codebook row
+        rows = out["shN"][has].reshape(int(has.sum()), -1)
+        assert torch.unique(rows, dim=0).shape[0] <= 256
+        assert float((rows - kept["shN"][has].reshape(rows.shape)).abs().mean()) < 0.2
