@@ -388,6 +388,20 @@ def test_rasterize_masks_tilesize_and_last_ids(ops):
     pm = np.repeat(np.repeat(masks, 16, 1), 16, 2)[:, :c["H"], :c["W"]]
     assert_close(N(rc)[pm], o_rc[pm], 1e-4, 2e-5, "masked render (kept tiles)", max_bad_frac=1e-4)
     assert (N(rc)[~pm] == 0).all()
+    # ... and their backward: masked tiles contribute nothing (their workgroups leave the forward early, but still clear their
+    # share of the gradient rows)
+    m2, cn, col, op = T(c["means2d"], True), T(c["conics"], True), T(c["colors"], True), T(c["opacities"], True)
+    rc2, ra2 = ops.rasterize_to_pixels(m2, cn, col, op, c["W"], c["H"], 16, T(c["offs"]), T(c["flat"]), masks=T(masks))
+    o_rc, o_ra, o_li, bl = O.rasterize_fwd(c["means2d"], c["conics"], c["colors"], c["opacities"], c["W"], c["H"], 16,
+                                           c["offs"], c["flat"], masks=masks, return_borderline=True)
+    ok = (bl == 0)
+    v_rc = rs.randn(*o_rc.shape).astype(np.float32) * ok[..., None]
+    v_ra = rs.randn(*o_ra.shape).astype(np.float32) * ok[..., None]
+    g = torch.autograd.grad((rc2 * T(v_rc)).sum() + (ra2 * T(v_ra)).sum(), (m2, cn, col, op))
+    o = O.rasterize_bwd(c["means2d"], c["conics"], c["colors"], c["opacities"], c["W"], c["H"], 16, c["offs"], c["flat"],
+                        o_ra, o_li, v_rc, v_ra, masks=masks)
+    for name, got, ref in zip(("v_means2d", "v_conics", "v_colors", "v_opacities"), g, o[:4]):
+        assert rel_l2(N(got), ref) < 2e-4, (name, rel_l2(N(got), ref))
     # small tiles
     fx = garden(1500, scale_mult=6.0)
     W, H = 160, 100
