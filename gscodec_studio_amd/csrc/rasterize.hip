@@ -609,18 +609,20 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
                 // checkpoints need), so a live pixel always has T > 1e-4 and a rejected record (a_eff = 0) cannot stop it
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
+                    // exclusive stop: the record that would take T to <= 1e-4 is not composited and ends the pixel.  ONE
+                    // select (the alpha actually applied: 0 for a finished or finishing pixel) instead of separate selects
+                    // for the weight and for T -- T is then recomputed with it (a second fma is cheaper than a select)
                     const float Tj = T;
-                    const float next_T = Tj - Tj * a_eff[g];
-                    const bool stop = next_T <= 1e-4f;  // exclusive stop
-                    const bool live = !done && !stop;   // this record is composited (or rejected: a_eff = 0)
-                    const float vis = live ? a_eff[g] * Tj : 0.f;
+                    const bool stop = __builtin_fmaf(-Tj, a_eff[g], Tj) <= 1e-4f;
+                    done = done || stop;
+                    const float a_use = done ? 0.f : a_eff[g];
+                    const float vis = a_use * Tj;
                     out[0] += c1[g].z * vis;
                     if (CDIM > 1) out[CDIM > 1 ? 1 : 0] += c1[g].w * vis;
                     if (CDIM > 2) out[CDIM > 2 ? 2 : 0] += c2x[g] * vis;
                     if (CDIM > 3) out[CDIM > 3 ? 3 : 0] += c2y[g] * vis;
-                    cur_off = (live && ok[g]) ? off[g] : cur_off;
-                    done = done || stop;
-                    T = live ? next_T : Tj;
+                    cur_off = (ok[g] && !done) ? off[g] : cur_off;
+                    T = __builtin_fmaf(-Tj, a_use, Tj);
                 }
             }
     };
