@@ -595,15 +595,21 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
                         }
                     }
                 }
-                float a_eff[G];
+                // The forward is ~80 % VALU-issue bound (every extra instruction per record costs ~6 us of the kernel, round 2):
+                // the selects are merged (one for the alpha actually applied, one for the last contributor, both on the same
+                // condition) and the conditions themselves combined on the scalar unit.
+                float alpha[G];
                 bool ok[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const float dx = c0[g].x - px, dy = c0[g].y - py;
-                    const float power = dx * (c0[g].z * dx + c0[g].w * dy) + c1[g].x * dy * dy; // = -sigma log2(e)
-                    const float alpha = fminf(0.999f, __builtin_amdgcn_exp2f(power + c1[g].y));
-                    ok[g] = !(power > 0.f) && (alpha >= ALPHA_MIN);
-                    a_eff[g] = ok[g] ? alpha : 0.f;
+                    // pl = power + log2(opacity), power = -sigma log2(e) = dx (a' dx + b' dy) + c' dy^2; the constant rides in
+                    // the last fma, and "sigma < 0" (reject) is read off as pl > log2(opacity): the two differ only for
+                    // |sigma| below the rounding of pl, where the sign of a computed sigma is rounding noise in any case
+                    const float lo = c1[g].y;
+                    const float pl = __builtin_fmaf(dx, __builtin_fmaf(c0[g].w, dy, c0[g].z * dx), __builtin_fmaf(c1[g].x * dy, dy, lo));
+                    alpha[g] = fminf(0.999f, __builtin_amdgcn_exp2f(pl));
+                    ok[g] = !(pl > lo) && (alpha[g] >= ALPHA_MIN);
                 }
                 // T is FROZEN at the stopping splat (= the transmittance in front of it, what the epilogue and the
                 // checkpoints need), so a live pixel always has T > 1e-4 and a rejected record (a_eff = 0) cannot stop it
@@ -613,15 +619,16 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
                     // select (the alpha actually applied: 0 for a finished or finishing pixel) instead of separate selects
                     // for the weight and for T -- T is then recomputed with it (a second fma is cheaper than a select)
                     const float Tj = T;
-                    const bool stop = __builtin_fmaf(-Tj, a_eff[g], Tj) <= 1e-4f;
+                    const bool stop = ok[g] && (__builtin_fmaf(-Tj, alpha[g], Tj) <= 1e-4f);
                     done = done || stop;
-                    const float a_use = done ? 0.f : a_eff[g];
+                    const bool use = ok[g] && !done; // composited: accepted, and the pixel neither finished nor finishing
+                    const float a_use = use ? alpha[g] : 0.f;
                     const float vis = a_use * Tj;
                     out[0] += c1[g].z * vis;
                     if (CDIM > 1) out[CDIM > 1 ? 1 : 0] += c1[g].w * vis;
                     if (CDIM > 2) out[CDIM > 2 ? 2 : 0] += c2x[g] * vis;
                     if (CDIM > 3) out[CDIM > 3 ? 3 : 0] += c2y[g] * vis;
-                    cur_off = (ok[g] && !done) ? off[g] : cur_off;
+                    cur_off = use ? off[g] : cur_off;
                     T = __builtin_fmaf(-Tj, a_use, Tj);
                 }
             }
