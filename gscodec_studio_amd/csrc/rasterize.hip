@@ -1212,18 +1212,22 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
         unsigned long long any = qm[0] | qm[1] | qm[2] | qm[3];
         unsigned long long touched = 0ull; // slots whose sums were stored this batch
         // software pipeline: the next record is read from LDS while the current one is processed
-        int tn = any ? __builtin_ctzll(any) : 0;
-        float4 n0 = s_rec[tn * REC + 0], n1 = s_rec[tn * REC + 1], n2 = s_rec[tn * REC + 2];
-        float4 n3 = ABS ? s_rec[tn * REC + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
-        while (any) {
-            const int t = tn;
-            any &= any - 1;
-            const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
-            tn = any ? __builtin_ctzll(any) : 0;
-            n0 = s_rec[tn * REC + 0];
-            n1 = s_rec[tn * REC + 1];
-            n2 = s_rec[tn * REC + 2];
-            if (ABS) n3 = s_rec[tn * REC + 3];
+        // (both compositing kernels are bound by the number of instructions a wave issues, scalar ones included -- round 2:
+        // one dummy s_add per record costs as much as one dummy v_fma -- so the bookkeeping is kept on as few as possible)
+        // The loop is unrolled by two with the roles of the two record register sets swapped (A current / B next, then B
+        // current / A next): written as one set copied into the other, the copy was nine v_mov per record.
+        struct Rec {
+            float4 r0, r1, r2, r3;
+        };
+        auto load_rec = [&](int slot, Rec &r) {
+            r.r0 = s_rec[slot * REC + 0];
+            r.r1 = s_rec[slot * REC + 1];
+            r.r2 = s_rec[slot * REC + 2];
+            r.r3 = ABS ? s_rec[slot * REC + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        auto next_slot = [&]() { return __builtin_ctzll(any | (1ull << 63)); }; // (an empty set prefetches slot 63: in bounds, never used)
+        auto body = [&](const int t, const Rec &rec) {
+            const float4 r0 = rec.r0, r1 = rec.r1, r2 = rec.r2, r3 = rec.r3;
             float col[CDIM];
             col[0] = r1.z;
             if (CDIM > 1) col[CDIM > 1 ? 1 : 0] = r1.w;
@@ -1234,7 +1238,7 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
             float Cs[CDIM];
 #pragma unroll
             for (int k = 0; k < CDIM; ++k) Cs[k] = 0.f;
-            bool any_valid = false;
+            float av_sum = 0.f; // > 0 in the lanes with a valid sample in some quadrant (one add per pass; a lane-mask "or" costs four scalar instructions per pass)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (!((qm[i] >> t) & 1ull)) continue; // wave-uniform (scalar) branch
@@ -1243,10 +1247,10 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
                 const float araw = __builtin_amdgcn_exp2f(power + r1.y); // = o exp(-sigma)
                 const float alpha = fminf(0.999f, araw);
                 const bool valid = (idx <= bin_final[i]) && !(power > 0.f) && (alpha >= ALPHA_MIN);
-                any_valid |= valid;
                 // a rejected record gets alpha = 0: then ra = rcp(1) = 1 exactly, Tn = T and facv = 0, i.e. the
                 // transmittance and the colour sums need no select of their own (selects cost 1.5 issue units here)
                 const float av = valid ? alpha : 0.f;
+                av_sum += av;
                 const float ra = __builtin_amdgcn_rcpf(1.f - av);
                 const float Tn = T[i] * ra;
                 const float facv = av * Tn;
@@ -1272,14 +1276,19 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
                     Ay += fabsf(r2.w * sdx + r3.x * sdy);
                 }
             }
-            if (!__any(any_valid)) continue;
+            if (!__any(av_sum > 0.f)) return;
             // 8 values through the permlane butterfly (20 VALU), the rest through plain DPP chains.
             // slot floats: [Sx, Sy | Sxx, Sxy | Syy, S0 | C0, C1 | C2, C3, Ax, Ay]
             float lo, hi;
             const float C1v = CDIM > 1 ? Cs[CDIM > 1 ? 1 : 0] : 0.f;
-            wave_reduce_sum_8_butterfly(Sx, Syy, Sxx, Cs[0], Sy, S0, Sxy, C1v, lo, hi);
             float C2v = CDIM > 2 ? Cs[CDIM > 2 ? 2 : 0] : 0.f, C3v = CDIM > 3 ? Cs[CDIM > 3 ? 3 : 0] : 0.f;
-            if (ABS) {
+            // RGB without absgrad (the hot case): the ninth sum rides in the row reduction of the butterfly and is stored as
+            // its four row partials (added up at the flush, once per batch) -- 4 DPP adds instead of a chain of 6 with padding
+            constexpr bool ROW3 = !ABS && CDIM == 3;
+            if (ROW3) wave_reduce_sum_8_butterfly_rows(Sx, Syy, Sxx, Cs[0], Sy, S0, Sxy, C1v, lo, hi, C2v);
+            else wave_reduce_sum_8_butterfly(Sx, Syy, Sxx, Cs[0], Sy, S0, Sxy, C1v, lo, hi);
+            if (ROW3) {
+            } else if (ABS) {
                 if (CDIM > 3) wave_reduce_sum_4(C2v, C3v, Ax, Ay);
                 else if (CDIM > 2) wave_reduce_sum_3(C2v, Ax, Ay);
                 else wave_reduce_sum_2(Ax, Ay);
@@ -1294,8 +1303,25 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
             if ((lane & 15u) == 15u) {
                 const uint32_t row = lane >> 4; // rows 0..3 hold (v0,v4) (v2,v6) (v1,v5) (v3,v7)
                 reinterpret_cast<float2 *>(acc)[row] = make_float2(lo, hi);
+                if (ROW3) acc[8 + row] = C2v; // the four row partials of C2 in the slot's third float4
             }
-            if (lane == GS_WAVE - 1) s_acc[t * ACC + 2] = make_float4(C2v, C3v, Ax, Ay);
+            if (!ROW3 && lane == GS_WAVE - 1) s_acc[t * ACC + 2] = make_float4(C2v, C3v, Ax, Ay);
+        };
+        {
+            Rec ra, rb;
+            int ta = next_slot();
+            load_rec(ta, ra);
+            while (any) {
+                any &= any - 1;
+                const int tb = next_slot();
+                load_rec(tb, rb);
+                body(ta, ra);
+                if (!any) break;
+                any &= any - 1;
+                ta = next_slot();
+                load_rec(ta, ra);
+                body(tb, rb);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (ga.packed) {
@@ -1309,6 +1335,10 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
                 // row layout: vx vy | ca cb cc | o | c0 c1 c2 c3 | ax ay   (a2 already holds c2 c3 ax ay)
                 s_acc[lane * ACC + 0] = make_float4(e_ca * a0.x + e_cb * a0.y, e_cb * a0.x + e_cc * a0.y, 0.5f * a0.z, a0.w);
                 s_acc[lane * ACC + 1] = make_float4(0.5f * a1.x, -a1.y / e_op, a1.z, a1.w);
+                if (!ABS && CDIM == 3) { // C2 arrives as four row partials
+                    const float4 a2 = s_acc[lane * ACC + 2];
+                    reinterpret_cast<float *>(&s_acc[lane * ACC + 2])[0] = (a2.x + a2.y) + (a2.z + a2.w);
+                }
             }
             __builtin_amdgcn_wave_barrier();
             const uint32_t sub = lane / 12u, comp = lane % 12u; // 5 slots x 12 components per instruction
@@ -1324,7 +1354,9 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
                 }
             }
         } else if ((touched >> lane) & 1ull) {
-            const float4 a0 = s_acc[lane * ACC + 0], a1 = s_acc[lane * ACC + 1], a2 = s_acc[lane * ACC + 2];
+            const float4 a0 = s_acc[lane * ACC + 0], a1 = s_acc[lane * ACC + 1];
+            float4 a2 = s_acc[lane * ACC + 2];
+            if (!ABS && CDIM == 3) a2.x = (a2.x + a2.y) + (a2.z + a2.w); // C2 arrives as four row partials
             // this lane staged slot `lane`: its raw conic / opacity / id are still in the record
             const float4 e2 = s_rec[lane * REC + 2], e3 = s_rec[lane * REC + 3];
             const size_t g = (size_t)__float_as_int(e3.z);
