@@ -1234,6 +1234,7 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
             if (CDIM > 2) col[CDIM > 2 ? 2 : 0] = r2.x;
             if (CDIM > 3) col[CDIM > 3 ? 3 : 0] = r2.y;
             const int32_t idx = batch_end - t;
+            const unsigned long long bit = 1ull << t;
             float S0 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Ax = 0.f, Ay = 0.f;
             float Cs[CDIM];
 #pragma unroll
@@ -1241,12 +1242,15 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
             float av_sum = 0.f; // > 0 in the lanes with a valid sample in some quadrant (one add per pass; a lane-mask "or" costs four scalar instructions per pass)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (!((qm[i] >> t) & 1ull)) continue; // wave-uniform (scalar) branch
+                if (!(qm[i] & bit)) continue; // wave-uniform (scalar) branch
                 const float dx = r0.x - (px0 + 8.f * (float)(i & 1)), dy = r0.y - (py0 + 8.f * (float)(i >> 1));
-                const float power = dx * (r0.z * dx + r0.w * dy) + r1.x * dy * dy;
-                const float araw = __builtin_amdgcn_exp2f(power + r1.y); // = o exp(-sigma)
+                // pl = power + log2(opacity) with the constant riding in the last fma; "sigma < 0" reads pl > log2(opacity)
+                // (as in the forward: the two differ only where the sign of a computed sigma is rounding noise)
+                const float lo2 = r1.y;
+                const float pl = __builtin_fmaf(dx, __builtin_fmaf(r0.w, dy, r0.z * dx), __builtin_fmaf(r1.x * dy, dy, lo2));
+                const float araw = __builtin_amdgcn_exp2f(pl); // = o exp(-sigma)
                 const float alpha = fminf(0.999f, araw);
-                const bool valid = (idx <= bin_final[i]) && !(power > 0.f) && (alpha >= ALPHA_MIN);
+                const bool valid = (idx <= bin_final[i]) && !(pl > lo2) && (alpha >= ALPHA_MIN);
                 // a rejected record gets alpha = 0: then ra = rcp(1) = 1 exactly, Tn = T and facv = 0, i.e. the
                 // transmittance and the colour sums need no select of their own (selects cost 1.5 issue units here)
                 const float av = valid ? alpha : 0.f;
@@ -1298,7 +1302,7 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
             }
             // park the totals in LDS; the atomics are issued once per batch by the lane that staged
             // the splat (full-width atomic instructions instead of 9 one-lane instructions per splat)
-            touched |= 1ull << t;
+            touched |= bit;
             float *acc = reinterpret_cast<float *>(&s_acc[t * ACC]);
             if ((lane & 15u) == 15u) {
                 const uint32_t row = lane >> 4; // rows 0..3 hold (v0,v4) (v2,v6) (v1,v5) (v3,v7)
@@ -1312,12 +1316,12 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
             int ta = next_slot();
             load_rec(ta, ra);
             while (any) {
-                any &= any - 1;
+                any &= ~(1ull << ta); // (the same 1 << t serves the quadrant tests and the `touched` set)
                 const int tb = next_slot();
                 load_rec(tb, rb);
                 body(ta, ra);
                 if (!any) break;
-                any &= any - 1;
+                any &= ~(1ull << tb);
                 ta = next_slot();
                 load_rec(ta, ra);
                 body(tb, rb);
