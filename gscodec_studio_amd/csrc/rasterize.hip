@@ -355,9 +355,11 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const float dx = c0.x - px[i], dy = c0.y - py[i];
-                const float power = dx * (c0.z * dx + c0.w * dy) + c1.x * dy * dy; // = -sigma log2(e)
-                const float alpha = fminf(0.999f, __builtin_amdgcn_exp2f(power + c1.y));
-                const bool ok = rec_ok && !(power > 0.f) && (alpha >= ALPHA_MIN);
+                // the same arithmetic as the tile kernels (exponent with log2(opacity) in its last fma, "sigma < 0" read as
+                // pl > log2(opacity)): every compositing kernel takes bit-identical accept decisions
+                const float pl = __builtin_fmaf(dx, __builtin_fmaf(c0.w, dy, c0.z * dx), __builtin_fmaf(c1.x * dy, dy, c1.y));
+                const float alpha = fminf(0.999f, __builtin_amdgcn_exp2f(pl));
+                const bool ok = rec_ok && !(pl > c1.y) && (alpha >= ALPHA_MIN);
                 const float a_eff = ok ? alpha : 0.f;
                 const float Tj = T[i];
                 const float next_T = Tj - Tj * a_eff;         // the loop-carried chain
@@ -963,10 +965,10 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const float dx = c0.x - px[i], dy = c0.y - py[i];
-                const float power = dx * (c0.z * dx + c0.w * dy) + c1.x * dy * dy;
-                const float araw = __builtin_amdgcn_exp2f(power + c1.y); // = o exp(-sigma)
+                const float pl = __builtin_fmaf(dx, __builtin_fmaf(c0.w, dy, c0.z * dx), __builtin_fmaf(c1.x * dy, dy, c1.y));
+                const float araw = __builtin_amdgcn_exp2f(pl); // = o exp(-sigma)
                 const float alpha = fminf(0.999f, araw);
-                const bool valid = (idx <= bin_final[i]) && !(power > 0.f) && (alpha >= ALPHA_MIN);
+                const bool valid = (idx <= bin_final[i]) && !(pl > c1.y) && (alpha >= ALPHA_MIN);
                 any_valid |= valid;
                 const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
                 const float Tn = T[i] * ra;
