@@ -15,7 +15,6 @@ What is different by design:
 from __future__ import annotations
 
 import math
-import os
 from typing import Optional, Tuple
 
 import torch
@@ -886,10 +885,6 @@ def isect_tiles_start(means2d, radii, depths, tile_size, tile_width, tile_height
     return isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height, sort, C, N, n_elems, camera_ids)
 
 
-# how the sorted tile lists are produced: "count" = counting + per-tile sorts (csrc/bin.hip, the default), "sort" = the depth
-# pre-sort + two stable radix passes over the pairs (csrc/isect.hip + radix_sort.hip).  Same outputs, bit for bit.
-BINNING = os.environ.get("GS_BINNING", "sort")
-
 # pinned host buffers the count kernel writes its per-block sums into: taken in isect_tiles_begin, handed back in
 # isect_tiles_finish once read (a buffer is never shared by two calls in flight; one whose finish never runs is simply
 # garbage-collected).  Re-used so that the steady state makes no pinned allocation.
@@ -926,25 +921,9 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
 
     tiles_per_gauss = torch.empty(radii.shape, dtype=torch.int32, device=dev)
     st_["tiles_per_gauss"] = tiles_per_gauss
-    st_["cum"] = st_["perm"] = st_["pinned"] = st_["event"] = st_["n_kept"] = st_["bin"] = None
+    st_["cum"] = st_["perm"] = st_["pinned"] = st_["event"] = st_["n_kept"] = None
     with _device_of(means2d):
-        n_tiles_cam = tile_width * tile_height
-        if (n_elems > 0 and sort and BINNING == "count" and camera_ids is None and N > 0
-                and 1 <= n_tiles_cam <= B.query("gs_bin_max_tiles")):
-            # binning by counting (csrc/bin.hip; unpacked [C, N] elements): per-tile counts from per-workgroup LDS histograms,
-            # tile offsets from their prefix sums; the pairs then go straight into their tile's region and every tile is
-            # sorted on its own (in finish)
-            chunks = B.query("gs_bin_chunks", N)
-            matrix = torch.empty((C, chunks, n_tiles_cam), dtype=torch.int32, device=dev)
-            totals = torch.empty((C, n_tiles_cam), dtype=torch.int32, device=dev)
-            offsets = torch.empty((C, tile_height, tile_width), dtype=torch.int32, device=dev)
-            pinned = _pinned_take(C * chunks)
-            B.call("gs_bin_count", C, N, B.ptr(means2d), B.ptr(radii), tile_size, tile_width, tile_height, B.ptr(tiles_per_gauss),
-                   B.ptr(pinned), B.ptr(matrix), B.ptr(totals), B.ptr(offsets), st)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-            st_["bin"], st_["pinned"], st_["event"] = (matrix, offsets), pinned, ev
-        elif n_elems > 0:
+        if n_elems > 0:
             cum = torch.empty(n_elems, dtype=torch.int64, device=dev)
             sb = B.query("gs_cumsum_scratch_bytes", n_elems)
             scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
@@ -998,15 +977,7 @@ def isect_tiles_finish(st_) -> Tuple[Tensor, Tensor, Tensor]:
     with _device_of(means2d):
         isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
         flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
-        if st_["bin"] is not None:
-            matrix, offsets = st_["bin"]
-            st_["isect_offsets"] = offsets  # what isect_offset_encode would derive from the ids
-            if n_isects > 0:
-                keys = torch.empty(n_isects, dtype=torch.int64, device=dev)
-                B.call("gs_bin_scatter_sort", st_["C"], st_["N"], n_isects, B.ptr(means2d), B.ptr(radii), B.ptr(depths),
-                       st_["tile_size"], st_["tile_width"], st_["tile_height"], st_["tile_n_bits"], B.ptr(matrix), B.ptr(offsets),
-                       B.ptr(keys), B.ptr(isect_ids), B.ptr(flatten_ids), st)
-        elif n_isects > 0 and st_["sort"]:
+        if n_isects > 0 and st_["sort"]:
             # compact form: (32-bit camera|tile key, flatten id) pairs = 8 B instead of 12 through the sort; its last pass
             # writes the reference's 64-bit ids (key << 32 | depth bits) and the flatten ids
             keys32 = torch.empty(n_isects, dtype=torch.int32, device=dev)

@@ -298,10 +298,7 @@ def rasterization(
             means2d, radii, depths, tile_size, tile_width, tile_height,
             packed=packed, n_cameras=C, camera_ids=camera_ids, gaussian_ids=gaussian_ids,
         )
-    if isect_state is not None and isect_state.get("isect_offsets") is not None:
-        isect_offsets = isect_state["isect_offsets"]  # the counting path knows them before the lists exist
-    else:
-        isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
+    isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
 
     meta.update(
         {

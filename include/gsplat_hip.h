@@ -264,27 +264,6 @@ int32_t gs_cumsum_gather_i32(
     uint64_t n, const int32_t *in, const int32_t *idx, const uint32_t *n_valid /* device scalar or NULL: only out[0, *n_valid) is defined (hand the same n_valid to gs_isect_emit*) */,
     int64_t *out, void *scratch, size_t scratch_bytes, gs_stream_t stream);
 
-/* The same binning by COUNTING (bin.hip) -- what rasterization() runs in unpacked mode: no global sort at all.  The order
- * inside a tile is determined by the pairs themselves (depth, ties by element index = what the reference's stable sort over
- * the emission order produces), so the pairs are written straight into their tile's region and every tile is sorted on its
- * own.  Elements are [C, N] (camera-major); the tile grid of one camera may hold at most gs_bin_max_tiles() tiles.
- *   gs_bin_count        tiles_per_gauss [C*N]; block_sums [C * gs_bin_chunks(N)] (optional; their sum is n_isects, see
- *                       gs_isect_count_keys); matrix [C, gs_bin_chunks(N), n_tiles] and totals [C, n_tiles] (scratch, kept
- *                       for gs_bin_scatter_sort); offsets [C, th, tw] = the isect_offset_encode result
- *   gs_bin_scatter_sort every pair takes the next slot of its tile (keys [n_isects] = depth bits << 32 | element, scratch),
- *                       every tile's keys are sorted (bitonic network in LDS, in global memory beyond 8192 keys) and written
- *                       out as isect_ids / flatten_ids -- bit-identical to gs_isect_emit + gs_sort_pairs_u64_i32. */
-uint32_t gs_bin_chunks(uint32_t N);
-uint32_t gs_bin_max_tiles(void);
-int32_t gs_bin_count(
-    uint32_t C, uint32_t N, const float *means2d, const int32_t *radii, uint32_t tile_size, uint32_t tile_width,
-    uint32_t tile_height, int32_t *tiles_per_gauss, int32_t *block_sums, int32_t *matrix, int32_t *totals, int32_t *offsets,
-    gs_stream_t stream);
-int32_t gs_bin_scatter_sort(
-    uint32_t C, uint32_t N, uint32_t n_isects, const float *means2d, const int32_t *radii, const float *depths,
-    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits, int32_t *matrix,
-    const int32_t *offsets, uint64_t *keys, int64_t *isect_ids, int32_t *flatten_ids, gs_stream_t stream);
-
 int32_t gs_isect_emit(
     uint32_t n_elems, uint32_t N,   /* camera of element i = i / N when camera_ids NULL */
     const int32_t *perm,            /* [n_elems] emission order or NULL (identity) */
