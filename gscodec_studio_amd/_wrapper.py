@@ -936,17 +936,20 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                 # sum there.  The kernel stores them STRAIGHT into pinned host memory (device-visible under HIP's unified
                 # addressing; a few thousand posted 4-byte writes): no device-to-host copy command in the stream.
                 pinned = _pinned_take(B.query("gs_isect_count_blocks", n_elems))
+                # (the count kernel also counts the digits of the pre-sort's first pass into the sort's temp buffer)
+                tb = B.query("gs_sort_temp_bytes", n_elems)
+                temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+                hist_ready = int(B.query("gs_sort_first_hist_applicable", n_elems))
                 B.call("gs_isect_count_keys", n_elems, B.ptr(means2d), B.ptr(radii), B.ptr(depths), tile_size, tile_width,
-                       tile_height, B.ptr(tiles_per_gauss), B.ptr(dkeys), B.ptr(dvals), B.ptr(pinned), st)
+                       tile_height, B.ptr(tiles_per_gauss), B.ptr(dkeys), B.ptr(dvals), B.ptr(pinned),
+                       B.ptr(temp) if hist_ready else None, tb if hist_ready else 0, st)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(dev))
                 # culled elements carry the maximal key: the sort drops them in its first pass
                 ko, perm = torch.empty_like(dkeys), torch.empty_like(dvals)
                 n_kept = torch.empty(1, dtype=torch.int32, device=dev)
-                tb = B.query("gs_sort_temp_bytes", n_elems)
-                temp = torch.empty(tb, dtype=torch.uint8, device=dev)
                 B.call("gs_sort_pairs_u64_i32_drop", n_elems, B.ptr(dkeys), B.ptr(dvals), B.ptr(ko), B.ptr(perm), 32, 64,
-                       0x7FFFFFFF, B.ptr(n_kept), B.ptr(temp), tb, st)
+                       0x7FFFFFFF, B.ptr(n_kept), B.ptr(temp), tb, hist_ready, st)
                 st_["perm"], st_["n_kept"] = perm, n_kept
                 B.call("gs_cumsum_gather_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(perm), B.ptr(n_kept), B.ptr(cum),
                        B.ptr(scratch), sb, st)

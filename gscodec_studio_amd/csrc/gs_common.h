@@ -40,6 +40,9 @@ void gs_set_error(const char *fmt, ...);
 
 static inline uint32_t gs_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// radix_sort.hip: slot of the first pass's [256][n_blocks] digit histogram inside a sort's temp buffer (nullptr: not applicable)
+uint32_t *sort_first_hist_slot(uint64_t n, void *temp, size_t temp_bytes, uint32_t *n_blocks);
+
 // ---------------------------------------------------------------------------
 // small linear algebra
 // ---------------------------------------------------------------------------

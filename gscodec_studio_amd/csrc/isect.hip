@@ -61,16 +61,26 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_depth_keys_kernel(
 // ~100 us of GPU work (depth pre-sort, prefix sum, SH colours) before the pipeline needs it on the host: the caller copies
 // the partial sums to pinned memory here and adds them up on the host, so the one host read-back of the pipeline
 // (isect_tiles.cu:200 in the reference) no longer leaves the GPU idle while the host wakes up and queues the rest.
+// hist (optional): the digit histogram of the depth pre-sort's FIRST pass for this block's 1024 keys (digit = low 8 bits of
+// the depth bits, culled keys not counted), in the sort's own [256][n_blocks] layout -- the sort then skips that launch.
+constexpr int COUNT_ITEMS = 4; // elements per thread: a block covers the 1024 keys of one sort block
 __global__ void __launch_bounds__(GS_BLOCK) isect_count_keys_kernel(
     uint32_t n_elems, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
     const float *__restrict__ depths, float tile_size, int32_t tw, int32_t th,
-    int32_t *__restrict__ tiles_per_gauss, int64_t *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ block_sums) {
+    int32_t *__restrict__ tiles_per_gauss, int64_t *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ block_sums,
+    uint32_t *__restrict__ hist, uint32_t n_blocks) {
     __shared__ int32_t s_sum[GS_BLOCK / GS_WAVE];
-    uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x;
-    int32_t cnt = 0;
-    if (i < n_elems) {
+    __shared__ uint32_t s_hist[256];
+    if (hist != nullptr) s_hist[threadIdx.x] = 0u;
+    __syncthreads();
+    int32_t cnt_sum = 0;
+#pragma unroll
+    for (int k = 0; k < COUNT_ITEMS; ++k) {
+        const uint32_t i = (blockIdx.x * COUNT_ITEMS + k) * GS_BLOCK + threadIdx.x;
+        if (i >= n_elems) continue;
         const int32_t r = radii[i];
         uint32_t d = 0x7fffffffu;
+        int32_t cnt = 0;
         if (r > 0) {
             float2 m = reinterpret_cast<const float2 *>(means2d)[i];
             TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
@@ -80,14 +90,20 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_count_keys_kernel(
         tiles_per_gauss[i] = cnt;
         keys[i] = (int64_t)(((uint64_t)d << 32) | (uint64_t)i);
         vals[i] = (int32_t)i;
+        cnt_sum += cnt;
+        if (hist != nullptr && d != 0x7fffffffu) atomicAdd(&s_hist[d & 0xffu], 1u);
     }
     if (block_sums != nullptr) { // (block-uniform)
-        int32_t v = cnt;
+        int32_t v = cnt_sum;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         if ((threadIdx.x & 63u) == 0u) s_sum[threadIdx.x >> 6] = v;
         __syncthreads();
         if (threadIdx.x == 0) block_sums[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    }
+    if (hist != nullptr) {
+        __syncthreads();
+        hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = s_hist[threadIdx.x];
     }
 }
 
@@ -385,18 +401,25 @@ extern "C" int32_t gs_cumsum_gather_i32(
     return 0;
 }
 
-extern "C" uint32_t gs_isect_count_blocks(uint32_t n_elems) { return gs_div_up(n_elems, GS_BLOCK); }
+extern "C" uint32_t gs_isect_count_blocks(uint32_t n_elems) { return gs_div_up(n_elems, GS_BLOCK * COUNT_ITEMS); }
 
 extern "C" int32_t gs_isect_count_keys(
     uint32_t n_elems, const float *means2d, const int32_t *radii, const float *depths, uint32_t tile_size,
     uint32_t tile_width, uint32_t tile_height, int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals, int32_t *block_sums,
-    gs_stream_t stream) {
+    void *sort_temp, size_t sort_temp_bytes, gs_stream_t stream) {
     if (n_elems == 0) return 0;
     GS_CHECK_ARG(means2d && radii && depths && tiles_per_gauss && keys && vals, "null pointer");
     GS_CHECK_ARG(tile_size > 0, "tile_size must be > 0");
-    hipLaunchKernelGGL(isect_count_keys_kernel, dim3(gs_div_up(n_elems, GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
+    uint32_t n_blocks = 0;
+    uint32_t *hist = nullptr;
+    if (sort_temp != nullptr) {
+        hist = sort_first_hist_slot(n_elems, sort_temp, sort_temp_bytes, &n_blocks);
+        GS_CHECK_ARG(hist != nullptr && n_blocks == gs_isect_count_blocks(n_elems),
+                     "sort_temp given, but gs_sort_first_hist_applicable(n_elems) is 0 or the buffer is too small");
+    }
+    hipLaunchKernelGGL(isect_count_keys_kernel, dim3(gs_isect_count_blocks(n_elems)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
                        n_elems, means2d, radii, depths, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
-                       tiles_per_gauss, keys, vals, block_sums);
+                       tiles_per_gauss, keys, vals, block_sums, hist, n_blocks);
     GS_CHECK_LAUNCH();
     return 0;
 }

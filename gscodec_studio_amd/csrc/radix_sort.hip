@@ -307,9 +307,22 @@ SortLayout sort_layout(uint64_t n) {
 
 extern "C" size_t gs_sort_temp_bytes(uint64_t n) { return sort_layout(n).total; }
 
+// Where the FIRST pass of a sort of n 64-bit keys expects its per-block digit histogram inside `temp` ([256][n_blocks],
+// blocks of 1024 consecutive keys), for a producer of the keys that can count the digits while it writes them
+// (gs_isect_count_keys): nullptr when the sort would use its 4096-key blocks or temp is too small.
+extern "C" int32_t gs_sort_first_hist_applicable(uint64_t n) { return (n > 0 && sort_rounds_for(n) == SORT_ROUNDS_SMALL) ? 1 : 0; }
+
+uint32_t *sort_first_hist_slot(uint64_t n, void *temp, size_t temp_bytes, uint32_t *n_blocks) {
+    if (n == 0 || temp == nullptr || sort_rounds_for(n) != SORT_ROUNDS_SMALL) return nullptr;
+    const SortLayout L = sort_layout(n);
+    if (temp_bytes < L.total) return nullptr;
+    *n_blocks = L.n_blocks;
+    return (uint32_t *)((char *)temp + L.off_hist);
+}
+
 static int32_t sort_impl(uint64_t n, const int64_t *keys_in, const int32_t *vals_in, int64_t *keys_out, int32_t *vals_out,
                          int32_t begin_bit, int32_t end_bit, bool drop, uint32_t drop_hi, uint32_t *n_valid_out, void *temp,
-                         size_t temp_bytes, hipStream_t st, const char *who) {
+                         size_t temp_bytes, hipStream_t st, const char *who, bool first_hist_ready = false) {
     if (n == 0) return 0;
     int passes = (end_bit - begin_bit + RADIX_BITS - 1) / RADIX_BITS;
     if (passes == 0) {
@@ -355,7 +368,9 @@ static int32_t sort_impl(uint64_t n, const int64_t *keys_in, const int32_t *vals
         d.drop_hi = drop_hi;
         uint64_t *dst_k = to_out ? (uint64_t *)keys_out : tkeys;
         int32_t *dst_v = to_out ? vals_out : tvals;
-        if (small)
+        if (p == 0 && first_hist_ready && small) {
+            // the producer of the keys counted this pass's digits already (see sort_first_hist_slot)
+        } else if (small)
             hipLaunchKernelGGL((sort_hist_kernel<uint64_t, SORT_ROUNDS_SMALL>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, hist);
         else
             hipLaunchKernelGGL((sort_hist_kernel<uint64_t, SORT_ROUNDS_BIG>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, hist);
@@ -392,13 +407,14 @@ extern "C" int32_t gs_sort_pairs_u64_i32(
 extern "C" int32_t gs_sort_pairs_u64_i32_drop(
     uint64_t n, const int64_t *keys_in, const int32_t *vals_in, int64_t *keys_out,
     int32_t *vals_out, int32_t begin_bit, int32_t end_bit, uint32_t drop_hi32, uint32_t *n_kept, void *temp,
-    size_t temp_bytes, gs_stream_t stream) {
+    size_t temp_bytes, int32_t first_hist_ready, gs_stream_t stream) {
     if (n == 0) return 0;
     GS_CHECK_ARG(keys_in && vals_in && keys_out && vals_out && n_kept, "null pointer");
     GS_CHECK_ARG(begin_bit >= 0 && end_bit <= 64 && begin_bit < end_bit, "bad bit range");
     GS_CHECK_ARG(n < (1ull << 32), "n must be < 2^32");
+    GS_CHECK_ARG(!first_hist_ready || (begin_bit == 32 && end_bit == 64), "a precomputed first histogram is defined for the bit range [32, 64)");
     int32_t rc = sort_impl(n, keys_in, vals_in, keys_out, vals_out, begin_bit, end_bit, true, drop_hi32, n_kept, temp, temp_bytes,
-                           (hipStream_t)stream, "gs_sort_pairs_u64_i32_drop");
+                           (hipStream_t)stream, "gs_sort_pairs_u64_i32_drop", first_hist_ready != 0);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;

@@ -258,6 +258,9 @@ int32_t gs_isect_count_keys(
     int32_t *block_sums /* [gs_isect_count_blocks(n_elems)] or NULL: intersections per block; their sum is n_isects,
                            known here -- before the depth pre-sort and the prefix sum -- so the host read-back of
                            isect_tiles.cu:200 can overlap them */,
+    void *sort_temp, size_t sort_temp_bytes /* NULL, 0 -- or the temp buffer the keys will be sorted with
+                           (gs_sort_pairs_u64_i32_drop over bits [32, 64)), when gs_sort_first_hist_applicable(n_elems): this
+                           kernel then also counts the digits of that sort's first pass (pass first_hist_ready = 1 there) */,
     gs_stream_t stream);
 uint32_t gs_isect_count_blocks(uint32_t n_elems);
 int32_t gs_cumsum_gather_i32(
@@ -313,7 +316,10 @@ int32_t gs_sort_pairs_u64_i32(
 int32_t gs_sort_pairs_u64_i32_drop(
     uint64_t n, const int64_t *keys_in, const int32_t *vals_in, int64_t *keys_out, int32_t *vals_out,
     int32_t begin_bit, int32_t end_bit, uint32_t drop_hi32, uint32_t *n_kept,
-    void *temp, size_t temp_bytes, gs_stream_t stream);
+    void *temp, size_t temp_bytes,
+    int32_t first_hist_ready /* != 0: the first pass's block histogram is already in temp (gs_isect_count_keys) */,
+    gs_stream_t stream);
+int32_t gs_sort_first_hist_applicable(uint64_t n);
 
 int32_t gs_isect_offset_encode(
     uint32_t n_isects, const int64_t *isect_ids_sorted,

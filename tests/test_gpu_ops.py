@@ -293,7 +293,7 @@ def test_radix_sort_drop_variant_and_gather_cumsum(ops, n):
     temp = torch.empty(tb, dtype=torch.uint8, device=k_t.device)
     st = torch.cuda.current_stream().cuda_stream
     B.call("gs_sort_pairs_u64_i32_drop", n, B.ptr(k_t), B.ptr(v_t), B.ptr(ko), B.ptr(vo), 32, 64, 0x7FFFFFFF, B.ptr(n_kept),
-           B.ptr(temp), tb, st)
+           B.ptr(temp), tb, 0, st)
     kept = np.nonzero(~drop)[0]
     assert int(n_kept.item()) == len(kept)
     order = kept[np.argsort(keys[kept] >> 32, kind="stable")]
