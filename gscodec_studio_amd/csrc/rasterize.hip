@@ -51,6 +51,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace {
 
@@ -562,27 +563,19 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
     };
 
     // ---- the record walk of one (sub-batch, quadrant) list, shared by the cooperative and the solo path
-    constexpr int G = 4; // records per iteration (lists are padded to a multiple of four)
-    struct alignas(sizeof(list_t) * G) Pack { list_t v[G]; };
-    auto walk = [&](const list_t *lst, const uint32_t cnt, uint32_t &cur_off) {
-            // FOUR records per iteration, in one basic block: a lone wave issues one instruction per
-            // ~5 cycles and a record is a ~25-deep dependent chain, so one record at a time costs
-            // ~390 cycles (measured) against ~40 instructions x 5 cycles of issue.  The four alpha
-            // evaluations are independent; only T <- T - T a (one fma) is carried from record to record.
-            // The records come from the compacted list of this (sub-batch, quadrant), padded with null records
-            // (alpha = 0) to a multiple of four: no bit scan, no validity flags.
-            // (No explicit prefetch of the next group: it cost 40 VGPRs, i.e. two waves per SIMD, and the
-            // kernel's duration is rounds of workgroups x their lifetime, not the walk of one list.)
-            Pack pk_next = *reinterpret_cast<const Pack *>(lst); // G record offsets, one broadcast read
-            for (uint32_t j = 0; j < cnt; j += G) {
+    constexpr int GW = 4; // records per iteration of the bulk loop
+    struct alignas(sizeof(list_t) * GW) Pack { list_t v[GW]; };
+    // G records in one basic block (G = 4: the bulk of a list; G = 1: its last 1-3 records -- the lists used to be walked as
+    // whole groups of four with their null-record padding, ~1.5 wasted evaluations per (sub-batch, quadrant) list = 9 % of
+    // all evaluations; the padding is still written (harmless) but no longer walked)
+    auto group = [&](auto gtag, const list_t *offs, uint32_t &cur_off) {
+        constexpr int G = decltype(gtag)::value;
                 float4 c0[G], c1[G];
                 float c2x[G], c2y[G]; // colours 2, 3 (only what CDIM needs is read)
                 uint32_t off[G];
                 {
-                    const Pack pk = pk_next;
-                    pk_next = *reinterpret_cast<const Pack *>(lst + j + G); // next group's offsets (row is 72 long: in bounds)
 #pragma unroll
-                    for (int g = 0; g < G; ++g) off[g] = pk.v[g];
+                    for (int g = 0; g < G; ++g) off[g] = offs[g];
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const float4 *r = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rec) + off[g]);
@@ -633,7 +626,23 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
                     cur_off = use ? off[g] : cur_off;
                     T = __builtin_fmaf(-Tj, a_use, Tj);
                 }
+    };
+    auto walk = [&](const list_t *lst, const uint32_t cnt, uint32_t &cur_off) {
+            // FOUR records per iteration, in one basic block: a lone wave issues one instruction per
+            // ~5 cycles and a record is a ~25-deep dependent chain, so one record at a time costs
+            // ~390 cycles (measured) against ~40 instructions x 5 cycles of issue.  The four alpha
+            // evaluations are independent; only T <- T - T a (one fma) is carried from record to record.
+            // The records come from the compacted list of this (sub-batch, quadrant): no bit scan, no validity flags.
+            // (No explicit prefetch of the next group: it cost 40 VGPRs, i.e. two waves per SIMD, and the
+            // kernel's duration is rounds of workgroups x their lifetime, not the walk of one list.)
+            const uint32_t full = cnt & ~(uint32_t)(GW - 1);
+            Pack pk_next = *reinterpret_cast<const Pack *>(lst); // GW record offsets, one broadcast read
+            for (uint32_t j = 0; j < full; j += GW) {
+                const Pack pk = pk_next;
+                pk_next = *reinterpret_cast<const Pack *>(lst + j + GW); // next group's offsets (row is 72 long: in bounds)
+                group(std::integral_constant<int, GW>{}, pk.v, cur_off);
             }
+            for (uint32_t j = full; j < cnt; ++j) group(std::integral_constant<int, 1>{}, lst + j, cur_off);
     };
 
     // ---- SOLO path for the longest lists.  A tile's lifetime under the cooperative scheme is the sum over its batches
