@@ -889,6 +889,7 @@ def isect_tiles_start(means2d, radii, depths, tile_size, tile_width, tile_height
 # isect_tiles_finish once read (a buffer is never shared by two calls in flight; one whose finish never runs is simply
 # garbage-collected).  Re-used so that the steady state makes no pinned allocation.
 _PINNED_FREE: dict = {}
+_PINNED_DIRECT_MAX = 2048  # block sums a kernel may store straight into pinned host memory (4-byte PCIe writes)
 
 
 def _pinned_take(n: int) -> Tensor:
@@ -935,14 +936,22 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                 # SH colours) before the pipeline needs it
                 # sum there.  The kernel stores them STRAIGHT into pinned host memory (device-visible under HIP's unified
                 # addressing; a few thousand posted 4-byte writes): no device-to-host copy command in the stream.
-                pinned = _pinned_take(B.query("gs_isect_count_blocks", n_elems))
+                n_sums = B.query("gs_isect_count_blocks", n_elems)
+                # (a few thousand blocks -- 983 at 1 M splats -- store straight into pinned memory; beyond that the sums are
+                # added up on the device and 8 bytes are copied, as in round 1: with 48 K block sums per step at 49 M splats,
+                # stored directly OR copied as one 192 KB block, every third or fourth forward stalled the GPU for ~85 ms)
+                direct = n_sums <= _PINNED_DIRECT_MAX
+                pinned = _pinned_take(n_sums) if direct else torch.empty(1, dtype=torch.int64, pin_memory=True)
+                bsums = pinned if direct else torch.empty(n_sums, dtype=torch.int32, device=dev)
                 # (the count kernel also counts the digits of the pre-sort's first pass into the sort's temp buffer)
                 tb = B.query("gs_sort_temp_bytes", n_elems)
                 temp = torch.empty(tb, dtype=torch.uint8, device=dev)
                 hist_ready = int(B.query("gs_sort_first_hist_applicable", n_elems))
                 B.call("gs_isect_count_keys", n_elems, B.ptr(means2d), B.ptr(radii), B.ptr(depths), tile_size, tile_width,
-                       tile_height, B.ptr(tiles_per_gauss), B.ptr(dkeys), B.ptr(dvals), B.ptr(pinned),
+                       tile_height, B.ptr(tiles_per_gauss), B.ptr(dkeys), B.ptr(dvals), B.ptr(bsums),
                        B.ptr(temp) if hist_ready else None, tb if hist_ready else 0, st)
+                if not direct:
+                    pinned.copy_(bsums.sum(dtype=torch.int64).reshape(1), non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(dev))
                 # culled elements carry the maximal key: the sort drops them in its first pass
@@ -965,6 +974,19 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
     return st_
 
 
+def _wait_event(ev) -> None:
+    """Wait for a CUDA event by POLLING it.  ``Event.synchronize()`` spins only briefly and then sleeps; when the GPU needs a
+    few milliseconds to get there (49 M splats: 3 ms per forward) the wake-up came ~17 ms late on the bench host -- the
+    forward ran at 42 FPS instead of 300.  A few milliseconds of host polling cost nothing here."""
+    import time
+
+    deadline = time.perf_counter() + 0.25
+    while not ev.query():
+        if time.perf_counter() > deadline:  # something long is queued in front: stop burning the core
+            ev.synchronize()
+            return
+
+
 @torch.no_grad()
 def isect_tiles_finish(st_) -> Tuple[Tensor, Tensor, Tensor]:
     """Second half of ``isect_tiles``: wait for n_isects, emit the (tile, depth) pairs, sort them."""
@@ -972,7 +994,7 @@ def isect_tiles_finish(st_) -> Tuple[Tensor, Tensor, Tensor]:
     st = _stream(means2d)
     n_isects = 0
     if st_["event"] is not None:
-        st_["event"].synchronize()  # the one host sync (isect_tiles.cu:200)
+        _wait_event(st_["event"])  # the one host sync (isect_tiles.cu:200)
         n_isects = int(st_["pinned"].sum(dtype=torch.int64))
         if st_["pinned"].dtype == torch.int32:
             _PINNED_FREE.setdefault(st_["pinned"].numel(), []).append(st_["pinned"])
