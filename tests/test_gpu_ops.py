@@ -540,3 +540,24 @@ def test_gather_rows_and_atomic_backward(shape):
     (out * w).sum().backward()
     (ref * w).sum().backward()
     assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_isect_count_read_back_paths_agree(ops, monkeypatch):
+    """The intersection count reaches the host in two ways: per-block sums stored straight into pinned memory (small
+    inputs) or summed on the device and copied as 8 bytes (large ones; the direct form stalled the GPU at 49 M splats).
+    Both must give the same lists."""
+    from gscodec_studio_amd import _wrapper as W
+
+    g = torch.Generator(device="cpu").manual_seed(11)
+    C, n, tw, th, ts = 2, 70_000, 40, 30, 16
+    means2d = (torch.rand(C, n, 2, generator=g) * torch.tensor([tw * ts, th * ts])).cuda()
+    radii = torch.randint(-2, 40, (C, n), generator=g, dtype=torch.int32).cuda()
+    depths = (torch.rand(C, n, generator=g) * 10 + 0.1).cuda()
+    outs = []
+    for limit in (1 << 30, 0):
+        monkeypatch.setattr(W, "_PINNED_DIRECT_MAX", limit)
+        tpg, ids, flat = ops.isect_tiles(means2d, radii, depths, ts, tw, th)
+        outs.append((N(tpg), N(ids), N(flat)))
+    assert outs[0][1].size > 0
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
