@@ -143,6 +143,8 @@ def algorithmic_bytes(stats):
     N, V, I, P, T, K = (stats[k] for k in ("N", "V", "I", "P", "T", "K"))
     return {
         "gs_projection_fwd": 40 * N + 4 * N + 24 * V,
+        "gs_projection_rows_fwd": 40 * N + 4 * N + 24 * V,
+        "gs_projection_rows_bwd": 92 * V + 40 * N + 4 * N,
         "gs_sh_fwd": (12 + 12 * K) * V + 12 * V,
         "gs_sh_view_fwd": (12 + 12 * K) * V + 12 * V + 4 * N,
         "gs_sh_view_bwd": (24 + 12 * K) * V + 12 * K * N + 12 * V + 12 * N,
@@ -153,6 +155,9 @@ def algorithmic_bytes(stats):
         "gs_cumsum_gather_i32": 8 * N + 8 * N,
         "gs_cumsum_i32": 4 * N + 8 * N,
         "gs_isect_emit": 24 * V + 12 * I,
+        "gs_isect_emit_compact": 24 * V + 12 * I,
+        "gs_sort_pairs_u64_i32_drop": 24 * V,   # the splat-level depth pre-sort: one read + one write of the live keys
+        "gs_sort_isect_pairs": 24 * I,
         "gs_sort_pairs_u64_i32": 24 * I,
         "gs_isect_offset_encode": 8 * I + 4 * T,
         "gs_rasterize_fwd": 40 * I + 20 * P,
@@ -425,7 +430,13 @@ def main():
                      P=w["width"] * w["height"], T=meta["tile_width"] * meta["tile_height"], K=(args.sh_degree + 1) ** 2)
         alg = algorithmic_bytes(stats)
         achieved = alg.get(dominant, 0) / (dom_ms * 1e-3) / 1e9
-        total_alg = sum(alg.values())
+        # whole step: SURVEY.md 8(d)'s closed form (every stage once: projection, SH, binning with the sort at its
+        # compulsory one read + one write, compositing, and the three backward stages) -- NOT the sum over every entry
+        # point the library exports (round 2 summed alternatives the step never calls and overstated this by 40 %)
+        Ns, Vs, Is, Ps, Ts, Ks_ = (stats[k] for k in ("N", "V", "I", "P", "T", "K"))
+        total_alg = (48 * Ns + (80 + 12 * Ks_) * Vs + 84 * Is + 4 * Ts + 20 * Ps) + \
+                    ((44 + 12 * Ks_) * Ns + (164 + 12 * Ks_) * Vs + 40 * Is + 24 * Ps)
+        called_alg = sum(alg[k] for k in per_step if k in alg)
         out = {
             "metric": "Msplats/s fwd+bwd @1080p (1M splats)",
             "value": N * world / (ms_per_step * 1e-3) / 1e6,
@@ -467,7 +478,9 @@ def main():
                                  "valu_wave_instr_per_launch")),
                 "algorithmic_bytes": alg.get(dominant, 0),
                 "whole_step": {"algorithmic_bytes": total_alg, "achieved": total_alg / (ms_per_step * 1e-3) / 1e9,
-                               "frac": total_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                               "frac": total_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "formula": "SURVEY 8(d): Fwd 48N+(80+12K)V+84I+4T+20P + Bwd (44+12K)N+(164+12K)V+40I+24P",
+                               "algorithmic_bytes_of_called_entry_points": called_alg},
                 "per_entry_point_ms": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
             },
         }

@@ -85,6 +85,23 @@ def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[object, List[object
     return protos
 
 
+def header_abi_version(path: str = HEADER_PATH) -> int:
+    """GS_ABI_VERSION as the header declares it."""
+    with open(path, "r") as f:
+        m = re.search(r"^\s*#\s*define\s+GS_ABI_VERSION\s+(\d+)", f.read(), flags=re.M)
+    if m is None:
+        raise ImportError(f"gscodec_studio_amd: {path} does not define GS_ABI_VERSION")
+    return int(m.group(1))
+
+
+def header_hash(path: str = HEADER_PATH) -> int:
+    """First 8 bytes (big-endian) of the SHA-256 of the header file: what the Makefile compiles into gs_header_hash()."""
+    import hashlib
+
+    with open(path, "rb") as f:
+        return int(hashlib.sha256(f.read()).hexdigest()[:16], 16)
+
+
 _LIB: Optional[ctypes.CDLL] = None
 _PROTOS: Optional[Dict] = None
 
@@ -114,8 +131,16 @@ def lib() -> ctypes.CDLL:
             raise ImportError(f"gscodec_studio_amd: {LIB_PATH} does not export {name}") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if L.gs_version() != 1:
-        raise ImportError(f"gscodec_studio_amd: ABI version mismatch: {L.gs_version()} != 1")
+    # the header the prototypes were parsed from and the library must be the SAME revision of the ABI: the version the
+    # header declares, and the hash of the header file the library was compiled against (a changed argument list behind
+    # an unchanged version number would otherwise be called through shifted arguments)
+    want = header_abi_version()
+    if L.gs_version() != want:
+        raise ImportError(f"gscodec_studio_amd: ABI version mismatch: {LIB_PATH} reports {L.gs_version()}, "
+                          f"{HEADER_PATH} declares {want}; rebuild with `make -C gscodec_studio_amd/csrc`")
+    if L.gs_header_hash() != header_hash():
+        raise ImportError(f"gscodec_studio_amd: {LIB_PATH} was compiled against a different gsplat_hip.h than {HEADER_PATH} "
+                          f"(hash {L.gs_header_hash():016x} != {header_hash():016x}); rebuild with `make -C gscodec_studio_amd/csrc`")
     _LIB = L
     return L
 

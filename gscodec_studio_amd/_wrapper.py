@@ -14,7 +14,10 @@ What is different by design:
 """
 from __future__ import annotations
 
+import ctypes
 import math
+import os
+import struct
 from typing import Optional, Tuple
 
 import torch
@@ -24,6 +27,8 @@ from typing_extensions import Literal
 from . import _backend as B
 
 _CAMERA_MODELS = {"pinhole": 0, "ortho": 1, "fisheye": 2}
+# splat rows (include/gsplat_hip.h): one 64-byte row of 16 floats per projected splat
+ROW, ROW_MEAN2D, ROW_CONIC, ROW_OPACITY, ROW_COLOR, ROW_DEPTH, ROW_RADIUS, ROW_COMP = 16, 0, 2, 5, 6, 9, 10, 11
 
 
 def _require_gpu(t: Tensor, what: str) -> None:
@@ -142,6 +147,8 @@ def _elem_strided(t: Tensor):
         raise RuntimeError(f"expected float32 tensor, got {t.dtype}")
     if t.is_contiguous():
         return t, 1
+    if t.dim() == 1 and t.stride(0) >= 1:
+        return t, t.stride(0)
     if t.dim() == 2 and t.stride(1) >= 1 and (t.shape[0] == 1 or t.stride(0) == t.shape[1] * t.stride(1)):
         return t, t.stride(1)
     return t.contiguous(), 1
@@ -299,6 +306,7 @@ def spherical_harmonics_view(
     coeffs: Tensor,  # [N, K, 3] shared by all cameras
     radii: Optional[Tensor] = None,  # [C, N] int32: evaluate only where radii > 0
     opacities: Optional[Tensor] = None,  # [N]: also return opacities.repeat(C, 1) (and sum its gradient over cameras)
+    rows: Optional[Tensor] = None,  # [C, N, 16] splat rows: the colours are written into columns 6:9 and returned as that view
 ):
     """Fused colour evaluation used by ``rasterization``:
     ``clamp_min(spherical_harmonics(deg, means[None] - campos[:, None], coeffs, radii > 0) + 0.5, 0)``
@@ -313,26 +321,31 @@ def spherical_harmonics_view(
         assert radii.shape == (C, N) and radii.dtype == torch.int32, (radii.shape, radii.dtype)
     if opacities is not None:
         assert opacities.shape == (N,), opacities.shape
+    if rows is not None:
+        assert rows.shape == (C, N, ROW) and rows.is_contiguous() and rows.dtype == torch.float32, (rows.shape, rows.dtype)
     colors, opac_cn = _SphericalHarmonicsView.apply(degrees_to_use, means.contiguous(), campos.contiguous(), coeffs.contiguous(),
                                                     radii.contiguous() if radii is not None else None,
-                                                    opacities.contiguous() if opacities is not None else None)
+                                                    opacities.contiguous() if opacities is not None else None, rows)
     return colors if opacities is None else (colors, opac_cn)
 
 
 class _SphericalHarmonicsView(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, sh_degree, means, campos, coeffs, radii, opacities):
+    def forward(ctx, sh_degree, means, campos, coeffs, radii, opacities, rows=None):
         _require_gpu(coeffs, "spherical_harmonics_view")
         means, campos, coeffs = _f32c(means), _f32c(campos), _f32c(coeffs)
         C, N, K = campos.shape[0], means.shape[0], coeffs.shape[1]
-        colors = torch.empty((C, N, 3), dtype=torch.float32, device=means.device)
+        # the colours are their own [C,N,3] tensor, or columns 6:9 of the splat rows the projection filled (written through
+        # the raw pointer: a view of a buffer that is no differentiable input of this node)
+        colors = torch.empty((C, N, 3), dtype=torch.float32, device=means.device) if rows is None else rows[..., ROW_COLOR:ROW_COLOR + 3]
+        cstride = 3 if rows is None else ROW
         opacities = _f32c(opacities) if opacities is not None else None
         opac_cn = torch.empty((C, N), dtype=torch.float32, device=means.device) if opacities is not None else None
         with _device_of(means):
             B.call("gs_sh_view_fwd", C, N, K, sh_degree, B.ptr(means), B.ptr(campos), int(campos.dim() == 3), B.ptr(coeffs), B.ptr(radii),
-                   B.ptr(colors), B.ptr(opacities), B.ptr(opac_cn), _stream(means))
+                   B.ptr(colors), cstride, B.ptr(opacities), B.ptr(opac_cn), _stream(means))
         ctx.save_for_backward(means, campos, coeffs, radii, colors)
-        ctx.sh_degree = sh_degree
+        ctx.sh_degree, ctx.cstride = sh_degree, cstride
         ctx.has_opac = opacities is not None
         ctx.set_materialize_grads(False)
         return colors, opac_cn
@@ -355,14 +368,14 @@ class _SphericalHarmonicsView(torch.autograd.Function):
                 v_opac_cn, ostride = _elem_strided(v_opac_cn)
         with _device_of(means):
             B.call("gs_sh_view_bwd", C, N, K, ctx.sh_degree, B.ptr(means), B.ptr(campos), int(campos.dim() == 3), B.ptr(coeffs), B.ptr(radii),
-                   B.ptr(colors), B.ptr(v_colors), vstride, B.ptr(v_coeffs), B.ptr(v_means),
+                   B.ptr(colors), ctx.cstride, B.ptr(v_colors), vstride, B.ptr(v_coeffs), B.ptr(v_means),
                    B.ptr(v_opac_cn) if ostride is not None else None, ostride or 0, B.ptr(v_opac) if ostride is not None else None,
                    _stream(means))
         if not ctx.needs_input_grad[3]:
             v_coeffs = None
         # campos (camera poses) gets no gradient on this path; rasterization() takes the unfused
         # route when viewmats require grad.
-        return None, v_means, None, v_coeffs, None, v_opac
+        return None, v_means, None, v_coeffs, None, v_opac, None
 
 
 class _SphericalHarmonics(torch.autograd.Function):
@@ -745,6 +758,158 @@ class _FullyFusedProjection(torch.autograd.Function):
         return (v_means, v_covars, v_quats, v_scales, v_viewmats) + (None,) * 10
 
 
+def project_rows(
+    means: Tensor,  # [N, 3]
+    covars: Optional[Tensor],  # [N, 6] or None
+    quats: Optional[Tensor],  # [N, 4] or None
+    scales: Optional[Tensor],  # [N, 3] or None
+    viewmats: Tensor,  # [C, 4, 4]
+    Ks: Tensor,  # [C, 3, 3]
+    width: int,
+    height: int,
+    opacities: Tensor,  # [N]
+    colors: Optional[Tensor] = None,  # [N, 3] post-activation colours shared by all cameras, or None
+    eps2d: float = 0.3,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    antialiased: bool = False,
+    camera_model: Literal["pinhole", "ortho", "fisheye"] = "pinhole",
+    _means_alias: bool = False,
+):
+    """``fully_fused_projection`` in ROW form, what ``rasterization`` uses for unpacked batches: the same projection, but
+    every (camera, gaussian) pair gets one 64-byte splat row (include/gsplat_hip.h) that the compositing kernels fetch
+    whole.  Folded in: the per-view opacities (``opacities.repeat(C, 1)``, times the antialias compensation) and,
+    when given, the per-view colours (``colors.expand(C, -1, -1)``) of reference rendering.py:327-335, 386.
+
+    Returns ``(radii [C,N] i32, means2d [C,N,2], depths [C,N], conics [C,N,3], opacities [C,N], colors [C,N,3] | None,
+    rows [C,N,16])``: means2d / conics / opacities / colors are COLUMN VIEWS of ``rows`` (only defined where radii > 0,
+    like the reference's means2d / conics), differentiable like the separate tensors of ``fully_fused_projection``."""
+    C, N = viewmats.size(0), means.size(0)
+    assert means.size() == (N, 3), means.size()
+    assert viewmats.size() == (C, 4, 4), viewmats.size()
+    assert Ks.size() == (C, 3, 3), Ks.size()
+    assert opacities.size() == (N,), opacities.size()
+    if covars is not None:
+        assert covars.size() == (N, 6), covars.size()
+        covars = covars.contiguous()
+    else:
+        assert quats is not None and scales is not None, "covars or (quats, scales) is required"
+        assert quats.size() == (N, 4) and scales.size() == (N, 3), (quats.size(), scales.size())
+        quats, scales = quats.contiguous(), scales.contiguous()
+    if colors is not None:
+        assert colors.size() == (N, 3), colors.size()
+        colors = colors.contiguous()
+    assert camera_model in _CAMERA_MODELS, camera_model
+    return _ProjectRows.apply(means.contiguous(), covars, quats, scales, viewmats.contiguous(), Ks.contiguous(),
+                              opacities.contiguous(), colors, width, height, eps2d, near_plane, far_plane, radius_clip,
+                              antialiased, camera_model, _means_alias)
+
+
+def _grad_rows_of(parts, shape, device):
+    """The [C,N,16] gradient-row buffer behind the gradients autograd hands to ``_ProjectRows.backward``.  ``parts`` =
+    [(gradient or None, first column, width)].  When they are the column views ``_RasterizeToPixels.backward`` returns (one
+    buffer, splat-row columns) that buffer is used IN PLACE; anything else (a loss on meta["means2d"] itself, gradients
+    autograd had to add up, missing ones) is assembled into a fresh zero-filled buffer."""
+    base = None
+    ok = True
+    lead = tuple(shape)
+    n_rows = 1
+    for d in lead:
+        n_rows *= d
+
+    def is_row_view(g, width):
+        if g.dtype != torch.float32:
+            return False
+        if g.dim() == len(lead) + 1:
+            if tuple(g.shape) != lead + (width,) or g.stride(-1) != 1:
+                return False
+        elif g.dim() != len(lead) or width != 1 or tuple(g.shape) != lead:
+            return False
+        expect = ROW
+        for d in range(len(lead) - 1, -1, -1):  # the leading dims collapse to one row index
+            if lead[d] != 1 and g.stride(d) != expect:
+                return False
+            expect *= lead[d]
+        return True
+
+    for g, col, width in parts:
+        if g is None:
+            ok = False
+            continue
+        p0 = g.data_ptr() - 4 * col
+        if n_rows > 0 and is_row_view(g, width) and (base is None or base == p0) and p0 % 16 == 0:
+            base = p0
+        else:
+            ok = False
+    if ok and base is not None:
+        return base, None
+    G = torch.zeros(tuple(shape) + (ROW,), dtype=torch.float32, device=device)
+    for g, col, width in parts:
+        if g is not None:
+            G[..., col:col + width] = g.reshape(tuple(shape) + (width,))
+    return G.data_ptr(), G
+
+
+class _ProjectRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, width, height, eps2d, near_plane,
+                far_plane, radius_clip, antialiased, camera_model="pinhole", means_alias=False):
+        _require_gpu(means, "project_rows")
+        means_in = means
+        means, covars, quats, scales = _f32c(means), _f32c(covars), _f32c(quats), _f32c(scales)
+        viewmats, Ks, opacities, colors = _f32c(viewmats), _f32c(Ks), _f32c(opacities), _f32c(colors)
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        radii = torch.empty((C, N), dtype=torch.int32, device=dev)
+        depths = torch.empty((C, N), dtype=torch.float32, device=dev)
+        rows = torch.empty((C, N, ROW), dtype=torch.float32, device=dev)  # (torch's allocator aligns to 512 bytes)
+        cm = _CAMERA_MODELS[camera_model]
+        with _device_of(means):
+            B.call("gs_projection_rows_fwd", C, N, B.ptr(means), B.ptr(covars), B.ptr(quats), B.ptr(scales),
+                   B.ptr(viewmats), B.ptr(Ks), int(width), int(height), float(eps2d), float(near_plane),
+                   float(far_plane), float(radius_clip), cm, B.ptr(opacities), B.ptr(colors), int(bool(antialiased)),
+                   B.ptr(radii), B.ptr(depths), B.ptr(rows), _stream(means))
+        ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, opacities, radii, rows)
+        ctx.width, ctx.height, ctx.eps2d, ctx.cm, ctx.antialiased = width, height, eps2d, cm, bool(antialiased)
+        ctx.has_colors = colors is not None
+        ctx.mark_non_differentiable(radii, rows)
+        ctx.set_materialize_grads(False)  # unused outputs (depths in RGB mode, ...) arrive as None, not as zero tensors
+        outs = (radii, rows[..., ROW_MEAN2D:ROW_MEAN2D + 2], depths, rows[..., ROW_CONIC:ROW_CONIC + 3], rows[..., ROW_OPACITY],
+                rows[..., ROW_COLOR:ROW_COLOR + 3] if colors is not None else None, rows)
+        # (means handed through: see _FullyFusedProjection)
+        return outs + (means_in,) if means_alias else outs
+
+    @staticmethod
+    def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_opac_cn, v_colors_cn, v_rows, v_means_add=None):
+        means, covars, quats, scales, viewmats, Ks, opacities, radii, rows = ctx.saved_tensors
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        parts = [(v_means2d, ROW_MEAN2D, 2), (v_conics, ROW_CONIC, 3), (v_opac_cn, ROW_OPACITY, 1)]
+        if ctx.has_colors:
+            parts.append((v_colors_cn, ROW_COLOR, 3))
+        g_ptr, g_keep = _grad_rows_of(parts, (C, N), dev)
+        v_depths = _f32c(v_depths) if v_depths is not None else None
+        need = ctx.needs_input_grad
+        # rows are fully written by the kernel -> empty, not zeros
+        v_means = torch.empty_like(means) if need[0] else None
+        v_covars = torch.empty_like(covars) if (covars is not None and need[1]) else None
+        v_quats = torch.empty_like(quats) if (quats is not None and need[2]) else None
+        v_scales = torch.empty_like(scales) if (scales is not None and need[3]) else None
+        v_viewmats = torch.zeros_like(viewmats) if need[4] else None
+        v_opac = torch.empty_like(opacities) if need[6] else None
+        v_colors = torch.empty((N, 3), dtype=torch.float32, device=dev) if (ctx.has_colors and need[7]) else None
+        with _device_of(means):
+            B.call("gs_projection_rows_bwd", C, N, B.ptr(means), B.ptr(covars), B.ptr(quats), B.ptr(scales),
+                   B.ptr(viewmats), B.ptr(Ks), int(ctx.width), int(ctx.height), float(ctx.eps2d), ctx.cm,
+                   B.ptr(radii), B.ptr(rows), g_ptr, B.ptr(v_depths), B.ptr(opacities), int(ctx.antialiased),
+                   B.ptr(v_means), B.ptr(v_covars), B.ptr(v_quats), B.ptr(v_scales), B.ptr(v_viewmats), B.ptr(v_opac),
+                   B.ptr(v_colors),
+                   B.ptr(_f32c(v_means_add)) if (v_means_add is not None and v_means is not None) else None, _stream(means))
+        del g_keep
+        return (v_means, v_covars, v_quats, v_scales, v_viewmats, None, v_opac, v_colors) + (None,) * 9
+
+
 class _FullyFusedProjectionPacked(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, covars, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
@@ -905,11 +1070,15 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
     GPU does not idle across the one host sync of the pipeline (reference: the blocking ``.item()`` of
     isect_tiles.cu:200)."""
     _require_gpu(means2d, "isect_tiles")
-    means2d, depths = _f32c(means2d), _f32c(depths)
+    # means2d may be the first two columns of the splat rows (row stride 16): read in place
+    means2d, s_m2 = _row_strided(means2d, 2)
+    if s_m2 % 2:
+        means2d, s_m2 = means2d.contiguous(), 2
+    depths = _f32c(depths)
     radii = radii.contiguous()
     assert radii.dtype == torch.int32, radii.dtype
     dev = means2d.device
-    st_ = dict(means2d=means2d, radii=radii, depths=depths, tile_size=tile_size, tile_width=tile_width,
+    st_ = dict(means2d=means2d, s_m2=s_m2, radii=radii, depths=depths, tile_size=tile_size, tile_width=tile_width,
                tile_height=tile_height, sort=sort, C=C, N=N, n_elems=n_elems, camera_ids=camera_ids, dev=dev)
     st = _stream(means2d)
 
@@ -947,7 +1116,7 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                 tb = B.query("gs_sort_temp_bytes", n_elems)
                 temp = torch.empty(tb, dtype=torch.uint8, device=dev)
                 hist_ready = int(B.query("gs_sort_first_hist_applicable", n_elems))
-                B.call("gs_isect_count_keys", n_elems, B.ptr(means2d), B.ptr(radii), B.ptr(depths), tile_size, tile_width,
+                B.call("gs_isect_count_keys", n_elems, B.ptr(means2d), s_m2, B.ptr(radii), B.ptr(depths), tile_size, tile_width,
                        tile_height, B.ptr(tiles_per_gauss), B.ptr(dkeys), B.ptr(dvals), B.ptr(bsums),
                        B.ptr(temp) if hist_ready else None, tb if hist_ready else 0, st)
                 if not direct:
@@ -963,7 +1132,7 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                 B.call("gs_cumsum_gather_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(perm), B.ptr(n_kept), B.ptr(cum),
                        B.ptr(scratch), sb, st)
             else:
-                B.call("gs_isect_count", n_elems, B.ptr(means2d), B.ptr(radii), tile_size, tile_width, tile_height,
+                B.call("gs_isect_count", n_elems, B.ptr(means2d), s_m2, B.ptr(radii), tile_size, tile_width, tile_height,
                        B.ptr(tiles_per_gauss), st)
                 B.call("gs_cumsum_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(cum), B.ptr(scratch), sb, st)
                 pinned = torch.empty(1, dtype=torch.int64, pin_memory=True)
@@ -987,6 +1156,20 @@ def _wait_event(ev) -> None:
             return
 
 
+def isect_tiles_abandon(st_) -> None:
+    """Drop a state ``isect_tiles_begin`` / ``isect_tiles_start`` returned WITHOUT finishing it (the sparse exchange's
+    overflow retry, an exception between begin and finish).  The count kernel stores its block sums straight into the
+    state's pinned buffer; torch's pinned caching allocator does not track kernel stores, so the buffer must not go back to
+    it (or to our free list) before the kernel has run: wait for the state's event first."""
+    if st_ is None or st_.get("event") is None:
+        return
+    _wait_event(st_["event"])
+    pinned = st_.get("pinned")
+    if pinned is not None and pinned.dtype == torch.int32:
+        _PINNED_FREE.setdefault(pinned.numel(), []).append(pinned)
+    st_["pinned"] = st_["event"] = None
+
+
 @torch.no_grad()
 def isect_tiles_finish(st_) -> Tuple[Tensor, Tensor, Tensor]:
     """Second half of ``isect_tiles``: wait for n_isects, emit the (tile, depth) pairs, sort them."""
@@ -1008,7 +1191,7 @@ def isect_tiles_finish(st_) -> Tuple[Tensor, Tensor, Tensor]:
             keys32 = torch.empty(n_isects, dtype=torch.int32, device=dev)
             vals = torch.empty(n_isects, dtype=torch.int32, device=dev)
             B.call("gs_isect_emit_compact", st_["n_elems"], max(st_["N"], 1), B.ptr(st_["perm"]), B.ptr(st_["n_kept"]),
-                   B.ptr(st_["camera_ids"]), B.ptr(means2d), B.ptr(radii), B.ptr(depths), B.ptr(st_["cum"]), st_["tile_size"],
+                   B.ptr(st_["camera_ids"]), B.ptr(means2d), st_["s_m2"], B.ptr(radii), B.ptr(depths), B.ptr(st_["cum"]), st_["tile_size"],
                    st_["tile_width"], st_["tile_height"], st_["tile_n_bits"], B.ptr(keys32), B.ptr(vals), st)
             tb = B.query("gs_sort_isect_temp_bytes", n_isects)
             temp = torch.empty(tb, dtype=torch.uint8, device=dev)
@@ -1016,7 +1199,7 @@ def isect_tiles_finish(st_) -> Tuple[Tensor, Tensor, Tensor]:
                    B.ptr(isect_ids), B.ptr(flatten_ids), B.ptr(temp), tb, st)
         elif n_isects > 0:
             B.call("gs_isect_emit", st_["n_elems"], max(st_["N"], 1), B.ptr(st_["perm"]), B.ptr(st_["n_kept"]), B.ptr(st_["camera_ids"]),
-                   B.ptr(means2d), B.ptr(radii), B.ptr(depths), B.ptr(st_["cum"]), st_["tile_size"], st_["tile_width"],
+                   B.ptr(means2d), st_["s_m2"], B.ptr(radii), B.ptr(depths), B.ptr(st_["cum"]), st_["tile_size"], st_["tile_width"],
                    st_["tile_height"], st_["tile_n_bits"], B.ptr(isect_ids), B.ptr(flatten_ids), st)
     return st_["tiles_per_gauss"], isect_ids, flatten_ids
 
@@ -1040,6 +1223,44 @@ def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile
 # ---------------------------------------------------------------------------
 # rasterize to pixels  (reference _wrapper.py:436-568, 901-1028)
 # ---------------------------------------------------------------------------
+# Launch tuning of the compositing kernels: (segment length of the backward, solo threshold of the forward, XCD group of the
+# forward / backward); -1 = the library's default (the measured MI355X optimum).  The library itself is stateless: the values
+# travel in the gs_raster_plan made for every forward and handed to its backward.  Preset from the environment, read once.
+_TUNING_KEYS = ("raster_seg", "raster_solo_min", "raster_xcd_fwd", "raster_xcd_bwd")
+_RASTER_TUNING = [int(os.environ.get(k, "-1")) for k in ("GS_RASTER_SEG", "GS_RASTER_SOLO", "GS_RASTER_XCD_FWD", "GS_RASTER_XCD_BWD")]
+
+
+def set_raster_tuning(**kv) -> dict:
+    """Set tuning values (keys: raster_seg, raster_solo_min, raster_xcd_fwd, raster_xcd_bwd; ``None`` / -1 = default) for the
+    rasterize calls that FOLLOW; returns the previous values.  A forward's values stay with its backward (they are stored
+    in its plan), so changing them between the two is harmless."""
+    prev = dict(zip(_TUNING_KEYS, _RASTER_TUNING))
+    for k, v in kv.items():
+        _RASTER_TUNING[_TUNING_KEYS.index(k)] = -1 if v is None else int(v)
+    return prev
+
+
+def _raster_plan(n_tiles_all: int, n_isects: int, channels: int):
+    """(plan buffer, scratch bytes): a gs_raster_plan (host struct, 64 bytes) for one forward / backward pair."""
+    plan = ctypes.create_string_buffer(64)
+    tun = (ctypes.c_int32 * 4)(*_RASTER_TUNING)
+    B.call("gs_rasterize_plan", n_tiles_all, n_isects, channels, ctypes.addressof(tun), ctypes.addressof(plan))
+    return plan, struct.unpack_from("<Q", plan, 32)[0]
+
+
+def _splat_layout(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor):
+    """The four per-splat arrays as the kernels take them: contiguous tensors (strides None), or -- column views of wider
+    row-major buffers, in particular of the splat rows ``project_rows`` fills -- read IN PLACE through their row strides."""
+    channels = colors.shape[-1]
+    (m2, s0), (cn, s1), (col, s2), (op, s3) = (_row_strided(means2d, 2), _row_strided(conics, 3), _row_strided(colors, channels),
+                                               _elem_strided(opacities))
+    if s0 % 2 or m2.data_ptr() % 8:  # (the kernels load a mean as one 8-byte word)
+        m2, s0 = m2.contiguous(), 2
+    if (s0, s1, s2, s3) == (2, 3, channels, 1):
+        return m2, cn, col, op, None
+    return m2, cn, col, op, (ctypes.c_uint32 * 4)(s0, s1, s2, s3)
+
+
 def rasterize_to_pixels(
     means2d: Tensor,  # [C, N, 2] or [nnz, 2]
     conics: Tensor,  # [C, N, 3] or [nnz, 3]
@@ -1091,8 +1312,9 @@ def rasterize_to_pixels(
     assert tile_width * tile_size >= image_width, f"Assert Failed: {tile_width} * {tile_size} >= {image_width}"
     assert 1 <= tile_size <= 16, f"tile_size must be in [1, 16] on the HIP backend, got {tile_size}"
 
+    # (no .contiguous() on the splat arrays: column views of the splat rows are read in place, _splat_layout)
     return _RasterizeToPixels.apply(
-        means2d.contiguous(), conics.contiguous(), colors.contiguous(), opacities.contiguous(), backgrounds,
+        means2d, conics, colors, opacities, backgrounds,
         masks, image_width, image_height, tile_size, isect_offsets.contiguous(), flatten_ids.contiguous(), absgrad,
     )
 
@@ -1102,7 +1324,7 @@ class _RasterizeToPixels(torch.autograd.Function):
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size,
                 isect_offsets, flatten_ids, absgrad):
         _require_gpu(means2d, "rasterize_to_pixels")
-        means2d, conics, colors, opacities = _f32c(means2d), _f32c(conics), _f32c(colors), _f32c(opacities)
+        means2d, conics, colors, opacities, strides = _splat_layout(means2d, conics, colors, opacities)
         backgrounds = _f32c(backgrounds)
         C, tile_height, tile_width = isect_offsets.shape
         channels = colors.shape[-1]
@@ -1118,7 +1340,7 @@ class _RasterizeToPixels(torch.autograd.Function):
         # 1080p): only ask for them when a backward can follow
         needs_bwd = any(ctx.needs_input_grad[:5])
         with _device_of(means2d):
-            sb = B.query("gs_rasterize_scratch_bytes", C * tile_height * tile_width, n_isects, channels) if needs_bwd else 0
+            plan, sb = _raster_plan(C * tile_height * tile_width, n_isects, channels) if needs_bwd else (None, 0)
             scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
             # the packed gradient rows of the backward ([n_elems,16], accumulated with atomics) are zero-filled by THIS
             # launch, as a side job of the tile workgroups: no fill pass in the backward
@@ -1126,11 +1348,14 @@ class _RasterizeToPixels(torch.autograd.Function):
             if needs_bwd and channels <= 4 and n_elems > 0:
                 grad_rows = torch.empty(opacities.shape + (16,), dtype=torch.float32, device=dev)
             B.call("gs_rasterize_fwd", C, n_elems, n_isects, channels, B.ptr(means2d), B.ptr(conics), B.ptr(colors),
-                   B.ptr(opacities), B.ptr(backgrounds), B.ptr(m8), width, height, tile_size, tile_width,
+                   B.ptr(opacities), ctypes.addressof(strides) if strides is not None else None, B.ptr(backgrounds), B.ptr(m8),
+                   width, height, tile_size, tile_width,
                    tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_colors),
-                   B.ptr(render_alphas), B.ptr(last_ids), B.ptr(scratch) if sb else None, sb,
+                   B.ptr(render_alphas), B.ptr(last_ids), ctypes.addressof(plan) if plan is not None else None,
+                   B.ptr(scratch) if plan is not None else None,
                    B.ptr(grad_rows), grad_rows.numel() * 4 if grad_rows is not None else 0, _stream(means2d))
         ctx.grad_rows = grad_rows  # consumed by the first backward; a repeated one (retain_graph) fills its own
+        ctx.plan, ctx.strides = plan, strides  # host structs: the backward runs under the forward's plan and layout
         # scratch carries the forward checkpoints of the depth-segmented backward.  The segmented backward rebuilds
         # "colour behind the segment" from the FINAL render (B = v_out . (colour_final - colour_ckpt)), so the output is
         # saved through save_for_backward: autograd then version-checks it and an in-place edit of the returned image
@@ -1176,13 +1401,15 @@ class _RasterizeToPixels(torch.autograd.Function):
             v_means2d_abs = torch.zeros_like(means2d) if ctx.absgrad else None
             out_ptrs = (B.ptr(v_means2d_abs), B.ptr(v_means2d), B.ptr(v_conics), B.ptr(v_colors), B.ptr(v_opacities))
         m8 = masks.view(torch.uint8) if masks is not None else None
+        plan, strides = ctx.plan, ctx.strides
         with _device_of(means2d):
-            sb = scratch.numel()
             B.call("gs_rasterize_bwd", C, n_elems, n_isects, channels, B.ptr(means2d), B.ptr(conics), B.ptr(colors),
-                   B.ptr(opacities), B.ptr(backgrounds), B.ptr(m8), ctx.width, ctx.height, ctx.tile_size,
+                   B.ptr(opacities), ctypes.addressof(strides) if strides is not None else None, B.ptr(backgrounds), B.ptr(m8),
+                   ctx.width, ctx.height, ctx.tile_size,
                    tile_width, tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_colors),
                    B.ptr(render_alphas), B.ptr(last_ids), B.ptr(v_render_colors), B.ptr(v_render_alphas), vrc_pix, vrc_ch, *out_ptrs,
-                   int(packed), B.ptr(scratch), sb, _stream(means2d))
+                   int(packed), ctypes.addressof(plan) if plan is not None else None,
+                   B.ptr(scratch) if plan is not None else None, _stream(means2d))
         if ctx.absgrad:
             means2d.absgrad = v_means2d_abs
         if ctx.needs_input_grad[4]:

@@ -83,9 +83,17 @@ def kmeans_decode(centroids_quant: Tensor, labels: Tensor, meta: Dict[str, Any],
     lab = labels.to(dev).to(torch.int32).contiguous()
     assert cq.dtype == torch.uint8 and cq.dim() == 2
     out = torch.empty((lab.numel(), cq.shape[1]), dtype=torch.float32, device=dev)
+    n_bad = torch.zeros(1, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        B.call("gs_kmeans_decode", lab.numel(), cq.shape[1], B.ptr(lab), B.ptr(cq), int(meta["quantization"]),
-               float(np.float32(meta["mins"])), float(np.float32(meta["maxs"])), B.ptr(out), _stream(out))
+        B.call("gs_kmeans_decode", lab.numel(), cq.shape[1], B.ptr(lab), B.ptr(cq), cq.shape[0], int(meta["quantization"]),
+               float(np.float32(meta["mins"])), float(np.float32(meta["maxs"])), B.ptr(out), B.ptr(n_bad), _stream(out))
+    # labels are file contents (shN.npz): the reference's `centroids[labels]` raises IndexError for one outside the
+    # codebook; the kernel bounds-checks and counts them, and this read-back (a decode is not on the per-step path)
+    # turns the count into the same error instead of a wild device read
+    bad = int(n_bad.item())
+    if bad:
+        raise IndexError(f"kmeans_decode: {bad} label(s) outside the codebook of {cq.shape[0]} centroids "
+                         "(truncated or mismatched shN.npz?)")
     if mask is not None:
         m = mask.to(dev).reshape(-1).to(torch.bool)
         rows = torch.nonzero_static(m, size=lab.numel()).view(-1)  # (no host synchronisation: the count is len(labels))

@@ -17,18 +17,11 @@ void gs_set_error(const char *fmt, ...) {
 }
 
 extern "C" int32_t gs_version(void) { return GS_ABI_VERSION; }
+#ifndef GS_HEADER_HASH
+#error "GS_HEADER_HASH must be defined by the build (first 8 bytes of sha256(include/gsplat_hip.h), see the Makefile)"
+#endif
+extern "C" uint64_t gs_header_hash(void) { return GS_HEADER_HASH; }
 extern "C" const char *gs_last_error(void) { return g_err; }
-
-// Run-time tuning knobs (segment length, solo threshold, XCD grouping: see rasterize.hip).  Their defaults come from the
-// environment, read once; tests use this entry point to exercise the non-default values.
-extern "C" int32_t gs_set_tuning(const char *key, int32_t value) {
-    GS_CHECK_ARG(key != nullptr, "null key");
-    if (raster_set_tuning(key, value) != 0) {
-        gs_set_error("gs_set_tuning: unknown key '%s'", key);
-        return 1;
-    }
-    return 0;
-}
 
 static int32_t check_raster_args(const RasterArgs &a) {
     if (a.channels == 0 || a.channels > 513) {
@@ -47,31 +40,56 @@ static int32_t check_raster_args(const RasterArgs &a) {
     return 0;
 }
 
-extern "C" size_t gs_rasterize_scratch_bytes(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels) {
-    return raster_wave_scratch_bytes(n_tiles_all, n_isects, channels);
+extern "C" int32_t gs_rasterize_plan(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels, const int32_t *tuning,
+                                     gs_raster_plan *plan) {
+    GS_CHECK_ARG(plan != nullptr, "null plan");
+    GS_CHECK_ARG(channels >= 1 && channels <= 513, "unsupported number of colour channels");
+    return raster_make_plan(n_tiles_all, n_isects, channels, tuning, plan);
+}
+
+// the four per-splat arrays: dense rows (NULL strides) or explicit row strides; detects the splat-row form
+static int32_t set_splat_layout(RasterArgs &a, const uint32_t *strides) {
+    a.s_xy = 2u; a.s_conic = 3u; a.s_color = a.channels; a.s_opac = 1u;
+    a.row16 = 0u;
+    if (strides != nullptr) {
+        a.s_xy = strides[0]; a.s_conic = strides[1]; a.s_color = strides[2]; a.s_opac = strides[3];
+        if (a.s_xy < 2u || a.s_conic < 3u || a.s_color < a.channels || a.s_opac < 1u || (a.s_xy & 1u)) {
+            gs_set_error("rasterize: splat_strides (%u, %u, %u, %u) too small for rows of 2 / 3 / %u / 1 floats (means2d rows must stay 8-byte aligned)",
+                         a.s_xy, a.s_conic, a.s_color, a.s_opac, a.channels);
+            return 1;
+        }
+        a.row16 = (a.channels <= 4u && a.s_xy == 16u && a.s_conic == 16u && a.s_color == 16u && a.s_opac == 16u && a.means2d != nullptr &&
+                   ((uintptr_t)a.means2d % 64u) == 0u && a.conics == a.means2d + GS_ROW_CONIC && a.opacities == a.means2d + GS_ROW_OPACITY &&
+                   a.colors == a.means2d + GS_ROW_COLOR) ? 1u : 0u;
+    }
+    return 0;
 }
 
 extern "C" int32_t gs_rasterize_fwd(
     uint32_t C, uint32_t n_elems, uint32_t n_isects, uint32_t channels, const float *means2d,
-    const float *conics, const float *colors, const float *opacities, const float *backgrounds,
+    const float *conics, const float *colors, const float *opacities, const uint32_t *splat_strides, const float *backgrounds,
     const uint8_t *masks, uint32_t image_width, uint32_t image_height, uint32_t tile_size,
     uint32_t tile_width, uint32_t tile_height, const int32_t *tile_offsets,
     const int32_t *flatten_ids, float *render_colors, float *render_alphas, int32_t *last_ids,
-    void *scratch, size_t scratch_bytes, void *zero_fill, size_t zero_fill_bytes, gs_stream_t stream) {
+    const gs_raster_plan *plan, void *scratch, void *zero_fill, size_t zero_fill_bytes, gs_stream_t stream) {
     GS_CHECK_ARG(render_colors && render_alphas && last_ids && tile_offsets, "null pointer");
     GS_CHECK_ARG(zero_fill_bytes == 0 || (zero_fill && (uintptr_t)zero_fill % 16 == 0 && zero_fill_bytes % 16 == 0),
                  "zero_fill must be 16-byte aligned and a multiple of 16 bytes long");
     GS_CHECK_ARG(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids), "null pointer");
+    GS_CHECK_ARG((plan == nullptr) == (scratch == nullptr), "plan and scratch go together (both or neither)");
     RasterArgs a = {C, n_elems, n_isects, channels, means2d, conics, colors, opacities, backgrounds, masks,
                     image_width, image_height, tile_size, tile_width, tile_height, tile_offsets, flatten_ids,
-                    render_colors, render_alphas, last_ids, 0u};
+                    render_colors, render_alphas, last_ids, 0u, 0u, 0u, 0u, 0u, 0u};
     if (int32_t rc = check_raster_args(a)) return rc;
+    if (int32_t rc = set_splat_layout(a, splat_strides)) return rc;
+    GS_CHECK_ARG(plan == nullptr || raster_plan_ok(plan, C * tile_width * tile_height, n_isects, channels),
+                 "plan was not made by gs_rasterize_plan for this (tile count, n_isects, channels)");
     if (C == 0 || image_width == 0 || image_height == 0) {
         if (zero_fill_bytes > 0 && hipMemsetAsync(zero_fill, 0, zero_fill_bytes, (hipStream_t)stream) != hipSuccess)
             { gs_set_error("rasterize: zero fill failed"); return 1; }
         return 0;
     }
-    int32_t rc = raster_wave_fwd(a, scratch, scratch_bytes, zero_fill, zero_fill_bytes, (hipStream_t)stream);
+    int32_t rc = raster_wave_fwd(a, plan, scratch, zero_fill, zero_fill_bytes, (hipStream_t)stream);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;
@@ -79,23 +97,24 @@ extern "C" int32_t gs_rasterize_fwd(
 
 extern "C" int32_t gs_rasterize_bwd(
     uint32_t C, uint32_t n_elems, uint32_t n_isects, uint32_t channels, const float *means2d,
-    const float *conics, const float *colors, const float *opacities, const float *backgrounds,
+    const float *conics, const float *colors, const float *opacities, const uint32_t *splat_strides, const float *backgrounds,
     const uint8_t *masks, uint32_t image_width, uint32_t image_height, uint32_t tile_size,
     uint32_t tile_width, uint32_t tile_height, const int32_t *tile_offsets,
     const int32_t *flatten_ids, const float *render_colors, const float *render_alphas,
     const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
     int64_t v_render_colors_pixel_stride, int64_t v_render_colors_channel_stride, float *v_means2d_abs,
     float *v_means2d, float *v_conics, float *v_colors, float *v_opacities, int32_t packed16,
-    void *scratch, size_t scratch_bytes, gs_stream_t stream) {
+    const gs_raster_plan *plan, void *scratch, gs_stream_t stream) {
     GS_CHECK_ARG(v_render_colors_pixel_stride >= 0 && v_render_colors_channel_stride >= 0, "negative gradient stride");
     GS_CHECK_ARG(render_alphas && last_ids && v_render_colors && tile_offsets, "null pointer");
     GS_CHECK_ARG(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids && v_means2d),
                  "null pointer");
     GS_CHECK_ARG(n_isects == 0 || packed16 || (v_conics && v_colors && v_opacities), "null pointer");
     GS_CHECK_ARG(!packed16 || channels <= 4, "packed16 gradients need channels <= 4");
+    GS_CHECK_ARG((plan == nullptr) == (scratch == nullptr), "plan and scratch go together (both or neither)");
     RasterArgs a = {C, n_elems, n_isects, channels, means2d, conics, colors, opacities, backgrounds, masks,
                     image_width, image_height, tile_size, tile_width, tile_height, tile_offsets, flatten_ids,
-                    nullptr, nullptr, nullptr, 0u};
+                    nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, 0u, 0u};
     RasterGradArgs ga = {render_alphas, last_ids, v_render_colors, v_render_alphas, v_means2d_abs,
                          v_means2d, v_conics, v_colors, v_opacities, 2u, 2u, 3u, channels, 1u, 0u,
                          v_render_colors_pixel_stride, v_render_colors_channel_stride};
@@ -110,8 +129,11 @@ extern "C" int32_t gs_rasterize_bwd(
         ga.packed = 1u;
     }
     if (int32_t rc = check_raster_args(a)) return rc;
+    if (int32_t rc = set_splat_layout(a, splat_strides)) return rc;
+    GS_CHECK_ARG(plan == nullptr || raster_plan_ok(plan, C * tile_width * tile_height, n_isects, channels),
+                 "plan was not made by gs_rasterize_plan for this (tile count, n_isects, channels)");
     if (C == 0 || image_width == 0 || image_height == 0 || n_isects == 0) return 0;
-    int32_t rc = raster_wave_bwd(a, ga, render_colors, scratch, scratch_bytes, (hipStream_t)stream);
+    int32_t rc = raster_wave_bwd(a, ga, render_colors, plan, scratch, (hipStream_t)stream);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;

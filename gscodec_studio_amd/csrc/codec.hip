@@ -68,13 +68,22 @@ __global__ void __launch_bounds__(GS_BLOCK) decode_splats_kernel(uint64_t n, Dec
 // K-means decode (png_compression.py:487-520): out[r, :] = centroids_quant[labels[r], :] / levels * (maxs - mins) + mins,
 // one scalar range for the whole codebook; float64 like the reference (numpy division, 0-dim fp32 range and offset).
 __global__ void __launch_bounds__(GS_BLOCK) kmeans_decode_kernel(uint64_t total, uint32_t width, const int32_t *__restrict__ labels,
-                                                                 const uint8_t *__restrict__ centroids, double levels, float mn, float mx,
-                                                                 float *__restrict__ out) {
+                                                                 const uint8_t *__restrict__ centroids, uint32_t n_centroids, double levels,
+                                                                 float mn, float mx, float *__restrict__ out, uint32_t *__restrict__ n_bad) {
     const uint64_t stride = (uint64_t)gridDim.x * GS_BLOCK;
     for (uint64_t e = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x; e < total; e += stride) {
         const uint64_t r = e / width;
         const uint32_t c = (uint32_t)(e - r * width);
-        out[e] = dequant((uint32_t)centroids[(uint64_t)labels[r] * width + c], levels, mn, mx);
+        // labels come from a file: one outside the codebook (truncated / mismatched shN.npz) must not become a wild read.
+        // The reference's centroids[labels] raises IndexError there; here the row decodes to NaN and the count of such
+        // labels is reported (n_bad), which the host wrapper turns into the same error.
+        const uint32_t lab = (uint32_t)labels[r];
+        if (lab >= n_centroids) {
+            out[e] = __builtin_nanf("");
+            if (c == 0 && n_bad != nullptr) atomicAdd(n_bad, 1u);
+            continue;
+        }
+        out[e] = dequant((uint32_t)centroids[(uint64_t)lab * width + c], levels, mn, mx);
     }
 }
 
@@ -106,14 +115,15 @@ extern "C" int32_t gs_decode_splats(
 }
 
 extern "C" int32_t gs_kmeans_decode(uint64_t n_rows, uint32_t width, const int32_t *labels, const uint8_t *centroids_quant,
-                                    uint32_t bits, float mins, float maxs, float *out, gs_stream_t stream) {
+                                    uint32_t n_centroids, uint32_t bits, float mins, float maxs, float *out, uint32_t *n_bad,
+                                    gs_stream_t stream) {
     if (n_rows == 0 || width == 0) return 0;
     GS_CHECK_ARG(labels && centroids_quant && out, "null pointer");
     GS_CHECK_ARG(bits >= 1 && bits <= 8, "bits must be in 1..8");
     const uint64_t total = n_rows * width;
     const uint32_t blocks = (uint32_t)(gs_div_up(total, GS_BLOCK) < 16384u ? gs_div_up(total, GS_BLOCK) : 16384u);
     hipLaunchKernelGGL(kmeans_decode_kernel, dim3(blocks), dim3(GS_BLOCK), 0, (hipStream_t)stream, total, width, labels, centroids_quant,
-                       (double)((1u << bits) - 1u), mins, maxs, out);
+                       n_centroids, (double)((1u << bits) - 1u), mins, maxs, out, n_bad);
     GS_CHECK_LAUNCH();
     return 0;
 }

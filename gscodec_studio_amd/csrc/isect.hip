@@ -30,14 +30,14 @@ GS_DEV TileBox tile_box(float mx, float my, int32_t radius, float tile_size, int
 }
 
 __global__ void __launch_bounds__(GS_BLOCK) isect_count_kernel(
-    uint32_t n_elems, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+    uint32_t n_elems, const float *__restrict__ means2d, uint32_t s_m2, const int32_t *__restrict__ radii,
     float tile_size, int32_t tw, int32_t th, int32_t *__restrict__ tiles_per_gauss) {
     uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x;
     if (i >= n_elems) return;
     int32_t r = radii[i];
     int32_t cnt = 0;
     if (r > 0) {
-        float2 m = reinterpret_cast<const float2 *>(means2d)[i];
+        float2 m = *reinterpret_cast<const float2 *>(means2d + (size_t)i * s_m2);
         TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
         cnt = (b.y1 - b.y0) * (b.x1 - b.x0);
     }
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_depth_keys_kernel(
 // the depth bits, culled keys not counted), in the sort's own [256][n_blocks] layout -- the sort then skips that launch.
 constexpr int COUNT_ITEMS = 4; // elements per thread: a block covers the 1024 keys of one sort block
 __global__ void __launch_bounds__(GS_BLOCK) isect_count_keys_kernel(
-    uint32_t n_elems, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+    uint32_t n_elems, const float *__restrict__ means2d, uint32_t s_m2, const int32_t *__restrict__ radii,
     const float *__restrict__ depths, float tile_size, int32_t tw, int32_t th,
     int32_t *__restrict__ tiles_per_gauss, int64_t *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ block_sums,
     uint32_t *__restrict__ hist, uint32_t n_blocks) {
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_count_keys_kernel(
         uint32_t d = 0x7fffffffu;
         int32_t cnt = 0;
         if (r > 0) {
-            float2 m = reinterpret_cast<const float2 *>(means2d)[i];
+            float2 m = *reinterpret_cast<const float2 *>(means2d + (size_t)i * s_m2);
             TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
             cnt = (b.y1 - b.y0) * (b.x1 - b.x0);
             d = (uint32_t)__float_as_int(depths[i]) & 0x7fffffffu;
@@ -140,7 +140,7 @@ template <bool COMPACT>
 __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
     uint32_t n_elems, uint32_t N, const int32_t *__restrict__ perm, const uint32_t *__restrict__ n_valid,
     const int64_t *__restrict__ camera_ids,
-    const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+    const float *__restrict__ means2d, uint32_t s_m2, const int32_t *__restrict__ radii,
     const float *__restrict__ depths, const int64_t *__restrict__ cum_tiles,
     float tile_size, int32_t tw, int32_t th, uint32_t tile_n_bits,
     int64_t *__restrict__ isect_ids, uint32_t *__restrict__ keys32, int32_t *__restrict__ flatten_ids) {
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
             const uint32_t i = has ? (perm != nullptr ? (uint32_t)perm[pos] : pos) : 0u;
             const int32_t r = has ? radii[i] : 0;
             if (r > 0) {
-                const float2 m = reinterpret_cast<const float2 *>(means2d)[i];
+                const float2 m = *reinterpret_cast<const float2 *>(means2d + (size_t)i * s_m2);
                 const TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
                 const int64_t cid = camera_ids != nullptr ? camera_ids[i] : (int64_t)(i / N);
                 // raw IEEE bits of the (positive) depth, sign-extended like the reference's
@@ -231,6 +231,9 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_offset_encode_kernel(
 // ---------------------------------------------------------------------------
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = GS_BLOCK * SCAN_ITEMS;
+// scan_apply leaves cum_tiles unwritten from the first scan block that lies entirely behind *n_valid, and an emit wave whose
+// first position is valid reads cum_tiles up to its LAST position: an emit wave must never straddle a scan block
+static_assert(SCAN_TILE % EMIT_SPW == 0, "GS_EMIT_SPW must divide the scan tile (2048)");
 
 GS_DEV int64_t wave_inclusive_scan_i64(int64_t v) {
     uint32_t lane = lane_id();
@@ -267,7 +270,10 @@ __global__ void __launch_bounds__(GS_BLOCK) scan_block_sums_kernel(
     __shared__ int64_t s_wave[GS_BLOCK / GS_WAVE];
     uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
     const uint64_t nv = n_valid != nullptr ? min(n, (uint64_t)*n_valid) : n;
-    if (n_valid != nullptr && base >= nv) return; // behind the valid prefix: nobody reads this block's sum (see scan_apply_kernel)
+    if (n_valid != nullptr && base >= nv) { // behind the valid prefix: contributes nothing (the spine still sums every block)
+        if (threadIdx.x == 0) block_sums[blockIdx.x] = 0;
+        return;
+    }
     int64_t s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
@@ -354,13 +360,14 @@ int32_t cumsum_impl(uint64_t n, const int32_t *in, const int32_t *idx, const uin
 } // namespace
 
 extern "C" int32_t gs_isect_count(
-    uint32_t n_elems, const float *means2d, const int32_t *radii, uint32_t tile_size,
+    uint32_t n_elems, const float *means2d, uint32_t means2d_stride, const int32_t *radii, uint32_t tile_size,
     uint32_t tile_width, uint32_t tile_height, int32_t *tiles_per_gauss, gs_stream_t stream) {
     if (n_elems == 0) return 0;
     GS_CHECK_ARG(means2d && radii && tiles_per_gauss, "null pointer");
     GS_CHECK_ARG(tile_size > 0, "tile_size must be > 0");
+    GS_CHECK_ARG(means2d_stride >= 2 && means2d_stride % 2 == 0, "means2d_stride must be even and >= 2");
     hipLaunchKernelGGL(isect_count_kernel, dim3(gs_div_up(n_elems, GS_BLOCK)), dim3(GS_BLOCK), 0,
-                       (hipStream_t)stream, n_elems, means2d, radii, (float)tile_size, (int32_t)tile_width,
+                       (hipStream_t)stream, n_elems, means2d, means2d_stride, radii, (float)tile_size, (int32_t)tile_width,
                        (int32_t)tile_height, tiles_per_gauss);
     GS_CHECK_LAUNCH();
     return 0;
@@ -404,12 +411,13 @@ extern "C" int32_t gs_cumsum_gather_i32(
 extern "C" uint32_t gs_isect_count_blocks(uint32_t n_elems) { return gs_div_up(n_elems, GS_BLOCK * COUNT_ITEMS); }
 
 extern "C" int32_t gs_isect_count_keys(
-    uint32_t n_elems, const float *means2d, const int32_t *radii, const float *depths, uint32_t tile_size,
+    uint32_t n_elems, const float *means2d, uint32_t means2d_stride, const int32_t *radii, const float *depths, uint32_t tile_size,
     uint32_t tile_width, uint32_t tile_height, int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals, int32_t *block_sums,
     void *sort_temp, size_t sort_temp_bytes, gs_stream_t stream) {
     if (n_elems == 0) return 0;
     GS_CHECK_ARG(means2d && radii && depths && tiles_per_gauss && keys && vals, "null pointer");
     GS_CHECK_ARG(tile_size > 0, "tile_size must be > 0");
+    GS_CHECK_ARG(means2d_stride >= 2 && means2d_stride % 2 == 0, "means2d_stride must be even and >= 2");
     uint32_t n_blocks = 0;
     uint32_t *hist = nullptr;
     if (sort_temp != nullptr) {
@@ -418,7 +426,7 @@ extern "C" int32_t gs_isect_count_keys(
                      "sort_temp given, but gs_sort_first_hist_applicable(n_elems) is 0 or the buffer is too small");
     }
     hipLaunchKernelGGL(isect_count_keys_kernel, dim3(gs_isect_count_blocks(n_elems)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
-                       n_elems, means2d, radii, depths, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
+                       n_elems, means2d, means2d_stride, radii, depths, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
                        tiles_per_gauss, keys, vals, block_sums, hist, n_blocks);
     GS_CHECK_LAUNCH();
     return 0;
@@ -444,15 +452,16 @@ extern "C" int32_t gs_gather_i32(uint32_t n, const int32_t *src, const int32_t *
 
 extern "C" int32_t gs_isect_emit(
     uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids, const float *means2d,
-    const int32_t *radii, const float *depths, const int64_t *cum_tiles_per_gauss,
+    uint32_t means2d_stride, const int32_t *radii, const float *depths, const int64_t *cum_tiles_per_gauss,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits,
     int64_t *isect_ids, int32_t *flatten_ids, gs_stream_t stream) {
     if (n_elems == 0) return 0;
     GS_CHECK_ARG(means2d && radii && depths && cum_tiles_per_gauss, "null pointer");
     GS_CHECK_ARG(camera_ids != nullptr || N > 0, "N must be > 0 when camera_ids is NULL");
     GS_CHECK_ARG(tile_n_bits < 32, "tile_n_bits must be < 32");
+    GS_CHECK_ARG(means2d_stride >= 2 && means2d_stride % 2 == 0, "means2d_stride must be even and >= 2");
     hipLaunchKernelGGL(isect_emit_kernel<false>, dim3(gs_div_up(n_elems, EMIT_WAVES * EMIT_SPW)), dim3(GS_BLOCK), 0,
-                       (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids, means2d, radii, depths,
+                       (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids, means2d, means2d_stride, radii, depths,
                        cum_tiles_per_gauss, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
                        tile_n_bits, isect_ids, (uint32_t *)nullptr, flatten_ids);
     GS_CHECK_LAUNCH();
@@ -461,15 +470,16 @@ extern "C" int32_t gs_isect_emit(
 
 extern "C" int32_t gs_isect_emit_compact(
     uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids, const float *means2d,
-    const int32_t *radii, const float *depths, const int64_t *cum_tiles_per_gauss,
+    uint32_t means2d_stride, const int32_t *radii, const float *depths, const int64_t *cum_tiles_per_gauss,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits,
     uint32_t *keys32, int32_t *flatten_ids, gs_stream_t stream) {
     if (n_elems == 0) return 0;
     GS_CHECK_ARG(means2d && radii && depths && cum_tiles_per_gauss && keys32 && flatten_ids, "null pointer");
     GS_CHECK_ARG(camera_ids != nullptr || N > 0, "N must be > 0 when camera_ids is NULL");
     GS_CHECK_ARG(tile_n_bits < 32, "tile_n_bits must be < 32");
+    GS_CHECK_ARG(means2d_stride >= 2 && means2d_stride % 2 == 0, "means2d_stride must be even and >= 2");
     hipLaunchKernelGGL(isect_emit_kernel<true>, dim3(gs_div_up(n_elems, EMIT_WAVES * EMIT_SPW)), dim3(GS_BLOCK), 0,
-                       (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids, means2d, radii, depths,
+                       (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids, means2d, means2d_stride, radii, depths,
                        cum_tiles_per_gauss, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
                        tile_n_bits, (int64_t *)nullptr, keys32, flatten_ids);
     GS_CHECK_LAUNCH();

@@ -116,6 +116,17 @@ GS_DEV Splat2D project_one(
     return out;
 }
 
+// ROWS: the outputs are splat rows (include/gsplat_hip.h): one 64-byte row per (camera, gaussian) carrying everything the
+// compositing kernels fetch -- mean2d, conic, opacity (x antialias compensation), optionally the colour -- plus depth,
+// radius and compensation; `means2d` is the row buffer, `conics` is unused.  radii / depths are ALSO written densely (what
+// the binning kernels stream through).
+struct RowExtras {
+    const float *opacities; // [N] or NULL
+    const float *colors;    // [N,3] post-activation colours or NULL
+    int antialiased;        // opacity column = opacity * compensation
+};
+
+template <bool ROWS>
 __global__ void __launch_bounds__(GS_BLOCK) projection_fwd_kernel(
     uint32_t C, uint32_t N,
     const float *__restrict__ means, const float *__restrict__ covars,
@@ -124,7 +135,7 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_fwd_kernel(
     int W, int H, float eps2d, float near_plane, float far_plane, float radius_clip,
     int camera_model,
     int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths,
-    float *__restrict__ conics, float *__restrict__ compensations) {
+    float *__restrict__ conics, float *__restrict__ compensations, RowExtras rx) {
     // grid = (ceil(N/256), C): the camera index is block-uniform => camera constants in SGPRs
     uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
     uint32_t c = blockIdx.y;
@@ -135,6 +146,23 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_fwd_kernel(
     size_t idx = (size_t)c * N + n;
     radii[idx] = s.radius;
     if (s.radius <= 0) return;
+    if (ROWS) {
+        float *row = means2d + GS_ROW_FLOATS * idx;
+        depths[idx] = s.depth;
+        float op = rx.opacities != nullptr ? rx.opacities[n] : 0.f;
+        if (rx.antialiased) op *= s.comp;
+        reinterpret_cast<float4 *>(row)[0] = make_float4(s.mx, s.my, s.ca, s.cb);
+        if (rx.colors != nullptr) {
+            const float *cp = rx.colors + 3 * (size_t)n;
+            reinterpret_cast<float4 *>(row)[1] = make_float4(s.cc, op, cp[0], cp[1]);
+            reinterpret_cast<float4 *>(row)[2] = make_float4(cp[2], s.depth, __int_as_float(s.radius), s.comp);
+        } else { // the colour columns belong to the SH kernel (gs_sh_view_fwd writes them into the same rows)
+            reinterpret_cast<float2 *>(row)[2] = make_float2(s.cc, op);
+            row[GS_ROW_DEPTH] = s.depth;
+            reinterpret_cast<float2 *>(row)[5] = make_float2(__int_as_float(s.radius), s.comp);
+        }
+        return;
+    }
     means2d[2 * idx] = s.mx;
     means2d[2 * idx + 1] = s.my;
     depths[idx] = s.depth;
@@ -296,6 +324,19 @@ GS_DEV void store_gaussian_grads(
     }
 }
 
+// Row form of the backward (rg.rows != NULL): conics / compensations come from the splat rows, the gradients of mean2d /
+// conic / opacity / colour from the compositing backward's gradient rows (same columns); this kernel then also sums the
+// opacity and colour gradients over the cameras (what autograd's `opacities.repeat(C, 1)` / `colors.expand` backward and
+// the antialias multiply did in passes of their own).
+struct RowGrads {
+    const float *rows;      // [C,N,16] or NULL (array form)
+    const float *grad_rows; // [C,N,16]
+    const float *opacities; // [N] (antialiased only)
+    float *v_opacities;     // [N] or NULL
+    float *v_colors;        // [N,3] or NULL
+    int antialiased;
+};
+
 template <bool NEED_VIEW>
 __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
     uint32_t C, uint32_t N,
@@ -309,8 +350,9 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
     const float *__restrict__ v_conics, const float *__restrict__ v_compensations,
     float *__restrict__ v_means, float *__restrict__ v_covars, float *__restrict__ v_quats,
     float *__restrict__ v_scales, float *__restrict__ v_viewmats, uint32_t s_m2, uint32_t s_cn,
-    const float *__restrict__ v_means_add) {
+    const float *__restrict__ v_means_add, RowGrads rg) {
     __shared__ float s_view[GS_BLOCK / GS_WAVE][12];
+    float v_op = 0.f, v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f;
     uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
     bool in_range = n < N;
     float px = 0.f, py = 0.f, pz = 0.f;
@@ -334,6 +376,22 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
                 loaded = true;
             }
             Camera cam = load_camera(viewmats, Ks, c);
+            if (rg.rows != nullptr) {
+                const float4 *r = reinterpret_cast<const float4 *>(rg.rows + GS_ROW_FLOATS * idx);
+                const float4 *gr = reinterpret_cast<const float4 *>(rg.grad_rows + GS_ROW_FLOATS * idx);
+                const float4 r0 = r[0], g0 = gr[0], g1 = gr[1];
+                const float cc = reinterpret_cast<const float *>(r)[GS_ROW_CONIC + 2];
+                const float comp = rg.antialiased ? reinterpret_cast<const float *>(r)[GS_ROW_COMPENSATION] : 1.f;
+                const float v_opac_cn = g1.y;
+                const float v_comp = rg.antialiased ? v_opac_cn * rg.opacities[n] : 0.f;
+                v_op += v_opac_cn * comp;
+                v_c0 += g1.z;
+                v_c1 += g1.w;
+                if (rg.v_colors != nullptr) v_c2 += reinterpret_cast<const float *>(gr)[GS_ROW_COLOR + 2];
+                project_one_vjp<NEED_VIEW>(cam, px, py, pz, S, W, H, eps2d, camera_model, r0.z, r0.w, cc, comp, v_comp,
+                                           rg.antialiased != 0, g0.x, g0.y, v_depths != nullptr ? v_depths[idx] : 0.f,
+                                           g0.z, g0.w, g1.x, g);
+            } else {
             bool has_comp = v_compensations != nullptr;
             project_one_vjp<NEED_VIEW>(
                 cam, px, py, pz, S, W, H, eps2d, camera_model,
@@ -341,6 +399,7 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
                 has_comp ? compensations[idx] : 0.f, has_comp ? v_compensations[idx] : 0.f, has_comp,
                 v_means2d[s_m2 * idx], v_means2d[s_m2 * idx + 1], v_depths != nullptr ? v_depths[idx] : 0.f,
                 v_conics[s_cn * idx], v_conics[s_cn * idx + 1], v_conics[s_cn * idx + 2], g);
+            }
             any = true;
         }
         if (NEED_VIEW) {
@@ -368,7 +427,15 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
             __syncthreads();
         }
     }
-    if (in_range) store_gaussian_grads(g, n, any, covars, quats, scales, v_means, v_covars, v_quats, v_scales, v_means_add);
+    if (in_range) {
+        store_gaussian_grads(g, n, any, covars, quats, scales, v_means, v_covars, v_quats, v_scales, v_means_add);
+        if (rg.v_opacities != nullptr) rg.v_opacities[n] = v_op;
+        if (rg.v_colors != nullptr) {
+            rg.v_colors[3 * (size_t)n] = v_c0;
+            rg.v_colors[3 * (size_t)n + 1] = v_c1;
+            rg.v_colors[3 * (size_t)n + 2] = v_c2;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -568,9 +635,63 @@ extern "C" int32_t gs_projection_fwd(
                  "exactly one of covars / (quats, scales) must be given");
     GS_CHECK_ARG(camera_model >= 0 && camera_model <= 2, "bad camera_model");
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
-    hipLaunchKernelGGL(projection_fwd_kernel, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means,
+    const RowExtras none = {nullptr, nullptr, 0};
+    hipLaunchKernelGGL(projection_fwd_kernel<false>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means,
                        covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d, near_plane,
-                       far_plane, radius_clip, camera_model, radii, means2d, depths, conics, compensations);
+                       far_plane, radius_clip, camera_model, radii, means2d, depths, conics, compensations, none);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_projection_rows_fwd(
+    uint32_t C, uint32_t N, const float *means, const float *covars, const float *quats,
+    const float *scales, const float *viewmats, const float *Ks, int32_t image_width,
+    int32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
+    int32_t camera_model, const float *opacities, const float *colors, int32_t antialiased, int32_t *radii, float *depths,
+    float *rows, gs_stream_t stream) {
+    if (C == 0 || N == 0) return 0;
+    GS_CHECK_ARG(means && viewmats && Ks && radii && depths && rows, "null pointer");
+    GS_CHECK_ARG((uintptr_t)rows % 64 == 0, "the row buffer must be 64-byte aligned");
+    GS_CHECK_ARG((covars != nullptr) != (quats != nullptr && scales != nullptr),
+                 "exactly one of covars / (quats, scales) must be given");
+    GS_CHECK_ARG(camera_model >= 0 && camera_model <= 2, "bad camera_model");
+    GS_CHECK_ARG(!antialiased || opacities != nullptr, "antialiased needs the opacities");
+    dim3 grid(gs_div_up(N, GS_BLOCK), C);
+    const RowExtras rx = {opacities, colors, antialiased};
+    hipLaunchKernelGGL(projection_fwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means,
+                       covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d, near_plane,
+                       far_plane, radius_clip, camera_model, radii, rows, depths, (float *)nullptr, (float *)nullptr, rx);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_projection_rows_bwd(
+    uint32_t C, uint32_t N, const float *means, const float *covars, const float *quats,
+    const float *scales, const float *viewmats, const float *Ks, int32_t image_width,
+    int32_t image_height, float eps2d, int32_t camera_model, const int32_t *radii, const float *rows,
+    const float *grad_rows, const float *v_depths, const float *opacities, int32_t antialiased, float *v_means,
+    float *v_covars, float *v_quats, float *v_scales, float *v_viewmats, float *v_opacities, float *v_colors,
+    const float *v_means_add, gs_stream_t stream) {
+    if (N == 0) return 0;
+    GS_CHECK_ARG(means && viewmats && Ks && radii && rows && grad_rows, "null pointer");
+    GS_CHECK_ARG((uintptr_t)rows % 16 == 0 && (uintptr_t)grad_rows % 16 == 0, "row buffers must be 16-byte aligned");
+    GS_CHECK_ARG((covars != nullptr) != (quats != nullptr && scales != nullptr),
+                 "exactly one of covars / (quats, scales) must be given");
+    GS_CHECK_ARG(!antialiased || opacities != nullptr, "antialiased needs the opacities");
+    dim3 grid(gs_div_up(N, GS_BLOCK));
+    const RowGrads rg = {rows, grad_rows, opacities, v_opacities, v_colors, antialiased};
+    const float *nul = nullptr;
+    if (v_viewmats != nullptr) {
+        hipLaunchKernelGGL(projection_bwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
+                           means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
+                           camera_model, radii, nul, nul, nul, v_depths, nul, nul, v_means, v_covars, v_quats, v_scales,
+                           v_viewmats, 16u, 16u, v_means_add, rg);
+    } else {
+        hipLaunchKernelGGL(projection_bwd_kernel<false>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
+                           means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
+                           camera_model, radii, nul, nul, nul, v_depths, nul, nul, v_means, v_covars, v_quats, v_scales,
+                           v_viewmats, 16u, 16u, v_means_add, rg);
+    }
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -592,18 +713,19 @@ extern "C" int32_t gs_projection_bwd(
     GS_CHECK_ARG((v_compensations == nullptr) || (compensations != nullptr),
                  "v_compensations given without compensations");
     dim3 grid(gs_div_up(N, GS_BLOCK));
+    const RowGrads rg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (v_viewmats != nullptr) {
         hipLaunchKernelGGL(projection_bwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
                            means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
                            camera_model, radii, conics, compensations, v_means2d, v_depths, v_conics,
                            v_compensations, v_means, v_covars, v_quats, v_scales, v_viewmats, v_means2d_stride,
-                           v_conics_stride, v_means_add);
+                           v_conics_stride, v_means_add, rg);
     } else {
         hipLaunchKernelGGL(projection_bwd_kernel<false>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
                            means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
                            camera_model, radii, conics, compensations, v_means2d, v_depths, v_conics,
                            v_compensations, v_means, v_covars, v_quats, v_scales, v_viewmats, v_means2d_stride,
-                           v_conics_stride, v_means_add);
+                           v_conics_stride, v_means_add, rg);
     }
     GS_CHECK_LAUNCH();
     return 0;

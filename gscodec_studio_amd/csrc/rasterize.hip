@@ -69,18 +69,43 @@ struct SplatRaw {
     float mx, my, ca, cb, cc, opac;
 };
 
+// One splat of the sorted list.  Row form (a.row16, include/gsplat_hip.h "splat rows"): the whole splat is ONE 64-byte line,
+// fetched with two (three with the colours) 16-byte loads; otherwise the reference's four arrays through their row strides.
+template <int CDIM>
+GS_DEV void fetch_splat(const RasterArgs &a, int32_t g, SplatRaw &s, float *col) {
+    s.g = g;
+    if (a.row16) {
+        const float4 *r = reinterpret_cast<const float4 *>(a.means2d + (size_t)g * 16u);
+        const float4 r0 = r[0], r1 = r[1];
+        s.mx = r0.x; s.my = r0.y; s.ca = r0.z; s.cb = r0.w;
+        s.cc = r1.x; s.opac = r1.y;
+        if (CDIM > 0) col[0] = r1.z;
+        if (CDIM > 1) col[CDIM > 1 ? 1 : 0] = r1.w;
+        if (CDIM == 3) col[CDIM > 2 ? 2 : 0] = reinterpret_cast<const float *>(r + 2)[0];
+        if (CDIM > 3) {
+            const float2 v = reinterpret_cast<const float2 *>(r + 2)[0];
+            col[CDIM > 2 ? 2 : 0] = v.x;
+            col[CDIM > 3 ? 3 : 0] = v.y;
+        }
+    } else {
+        const float2 xy = *reinterpret_cast<const float2 *>(a.means2d + (size_t)g * a.s_xy);
+        const float *cn = a.conics + (size_t)g * a.s_conic;
+        s.mx = xy.x; s.my = xy.y;
+        s.ca = cn[0]; s.cb = cn[1]; s.cc = cn[2];
+        s.opac = a.opacities[(size_t)g * a.s_opac];
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) col[k] = a.colors[(size_t)g * a.s_color + k];
+    }
+}
+
 GS_DEV SplatRaw gather_splat(const RasterArgs &a, int32_t idx, bool in_range) {
     SplatRaw s;
     s.g = 0;
     s.mx = s.my = s.ca = s.cb = s.cc = 0.f;
     s.opac = 0.f;
     if (in_range) {
-        s.g = a.flatten_ids[idx];
-        float2 xy = reinterpret_cast<const float2 *>(a.means2d)[s.g];
-        const float *cn = a.conics + 3 * (size_t)s.g;
-        s.mx = xy.x; s.my = xy.y;
-        s.ca = cn[0]; s.cb = cn[1]; s.cc = cn[2];
-        s.opac = a.opacities[s.g];
+        float none[1];
+        fetch_splat<0>(a, a.flatten_ids[idx], s, none);
     }
     return s;
 }
@@ -280,7 +305,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
     if (COLOR_LDS) {
 #pragma unroll
         for (int k = 0; k < CDIM; ++k)
-            ncol[k] = (in_range(base0 + (int32_t)lane) && (uint32_t)k < cnt) ? a.colors[(size_t)nxt.g * a.channels + ch_off + k] : 0.f;
+            ncol[k] = (in_range(base0 + (int32_t)lane) && (uint32_t)k < cnt) ? a.colors[(size_t)nxt.g * a.s_color + ch_off + k] : 0.f;
     }
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // next checkpoint boundary strictly inside (range_start, range_end), and its slot
@@ -331,7 +356,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
             if (COLOR_LDS) {
 #pragma unroll
                 for (int k = 0; k < CDIM; ++k)
-                    ncol[k] = (in_range(ni) && (uint32_t)k < cnt) ? a.colors[(size_t)nxt.g * a.channels + ch_off + k] : 0.f;
+                    ncol[k] = (in_range(ni) && (uint32_t)k < cnt) ? a.colors[(size_t)nxt.g * a.s_color + ch_off + k] : 0.f;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -348,7 +373,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
                 if (CDIM > 2) col[CDIM > 2 ? 2 : 0] = c2.x;
                 if (CDIM > 3) col[CDIM > 3 ? 3 : 0] = c2.y;
             } else {
-                const float *cp = a.colors + (size_t)__float_as_int(c2.w) * a.channels + ch_off;
+                const float *cp = a.colors + (size_t)__float_as_int(c2.w) * a.s_color + ch_off;
 #pragma unroll
                 for (int k = 0; k < CDIM; ++k) col[k] = ((uint32_t)k < cnt && rec_ok) ? cp[k] : 0.f;
             }
@@ -517,16 +542,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
         o.s.mx = o.s.my = o.s.ca = o.s.cb = o.s.cc = o.s.opac = 0.f;
 #pragma unroll
         for (int k = 0; k < CDIM; ++k) o.col[k] = 0.f;
-        if (g >= 0) {
-            o.s.g = g;
-            const float2 xy = reinterpret_cast<const float2 *>(a.means2d)[g];
-            const float *cn = a.conics + 3 * (size_t)g;
-            o.s.mx = xy.x; o.s.my = xy.y;
-            o.s.ca = cn[0]; o.s.cb = cn[1]; o.s.cc = cn[2];
-            o.s.opac = a.opacities[g];
-#pragma unroll
-            for (int k = 0; k < CDIM; ++k) o.col[k] = a.colors[(size_t)g * CDIM + k];
-        }
+        if (g >= 0) fetch_splat<CDIM>(a, g, o.s, o.col);
     };
     int32_t id_cur = load_id(base0 + (int32_t)tid);
     int32_t id_nxt = load_id(base0 + BATCH + (int32_t)tid);
@@ -908,7 +924,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
 #pragma unroll
         for (int k = 0; k < CDIM; ++k)
             ncol[k] = (first - (int32_t)lane >= tg.range_start && (uint32_t)k < cnt)
-                          ? a.colors[(size_t)nxt.g * a.channels + ch_off + k] : 0.f;
+                          ? a.colors[(size_t)nxt.g * a.s_color + ch_off + k] : 0.f;
     }
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
@@ -940,7 +956,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
             if (CMODE == 0) {
 #pragma unroll
                 for (int k = 0; k < CDIM; ++k)
-                    ncol[k] = (ni >= tg.range_start && (uint32_t)k < cnt) ? a.colors[(size_t)nxt.g * a.channels + ch_off + k] : 0.f;
+                    ncol[k] = (ni >= tg.range_start && (uint32_t)k < cnt) ? a.colors[(size_t)nxt.g * a.s_color + ch_off + k] : 0.f;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -954,7 +970,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
             r3 = s_rec[(j + 1) * REC + 3];
             const int32_t idx = __float_as_int(c2.z);
             const int32_t g = __float_as_int(c2.w);
-            const float *cp = a.colors + (size_t)g * a.channels + ch_off; // wave-uniform
+            const float *cp = a.colors + (size_t)g * a.s_color + ch_off; // wave-uniform
             float col[CR];
             if (CMODE == 0) {
                 col[0] = c1.z;
@@ -1123,10 +1139,11 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
     // last_ids are dropped by the per-quadrant test (idx <= q_bin_max).
     const int32_t first = tg.range_end - 1;
     auto fetch = [&](int32_t idx, SplatRaw &s, float *col) {
-        const bool ok = idx >= tg.range_start;
-        s = gather_splat(a, idx, ok);
+        s.g = 0;
+        s.mx = s.my = s.ca = s.cb = s.cc = s.opac = 0.f;
 #pragma unroll
-        for (int k = 0; k < CDIM; ++k) col[k] = ok ? a.colors[(size_t)s.g * CDIM + k] : 0.f;
+        for (int k = 0; k < CDIM; ++k) col[k] = 0.f;
+        if (idx >= tg.range_start) fetch_splat<CDIM>(a, a.flatten_ids[idx], s, col);
     };
     SplatRaw nxt;
     float ncol[CDIM];
@@ -1469,8 +1486,8 @@ __global__ void __launch_bounds__(GS_BLOCK) seg_items_build_kernel(uint32_t n_ti
 
 // ---------------------------------------------------------------------------
 // host side
-// scratch layout (the SAME buffer must be handed to gs_rasterize_fwd and to the matching
-// gs_rasterize_bwd; its contents must be preserved in between):
+// scratch layout (the SAME buffer and the SAME plan must be handed to gs_rasterize_fwd and to the matching
+// gs_rasterize_bwd; the buffer's contents must be preserved in between):
 //   [0, 256)                      item counters of the 32 cost classes (uint32) + padding
 //   [256, 256 + items)            (tile, k) work items of the segmented backward (uint2), one region per cost class
 //   [.., .. + cost)               cost of every work item as counted by the forward ([tile][4] + [boundary][4] uint32)
@@ -1479,48 +1496,24 @@ __global__ void __launch_bounds__(GS_BLOCK) seg_items_build_kernel(uint32_t n_ti
 // ---------------------------------------------------------------------------
 namespace {
 
-// Tuning knobs.  Defaults are the measured optima on MI355X (profiles/round1_notes.md); the environment is read ONCE,
-// when the library first needs them, and gs_set_tuning() changes them at run time (tests exercise the non-default
-// values through it -- nothing is looked up per launch):
-//   GS_RASTER_SEG      segment length of the depth-segmented backward in list entries (multiple of 64; 0: no segments,
-//                      the generic one-quadrant-per-wave backward runs instead).  256 since the work list is ordered
-//                      longest-first (round 2: 128 / 192 / 256 / 320 / 384 / 512 -> 0.338 / 0.317 / 0.305 / 0.312 / 0.324 /
-//                      0.331 ms backward, and half the checkpoint planes in the forward); with the list in arrival order
-//                      128 was best (round 1: 512 -> 1.14 ms, 256 -> 0.97 ms, 128 -> 0.89 ms).
-//   GS_RASTER_SOLO     list length from which a tile's four forward waves stop cooperating (0: never). 2048.
-//   GS_RASTER_XCD_FWD / GS_RASTER_XCD_BWD   work items per XCD group (xcd_remap).  16 tiles / 16 segment items.
-struct RasterTuning {
-    int32_t seg = 256, solo_min = 2048;
-    uint32_t xcd_fwd = 16, xcd_bwd = 16;
-    RasterTuning() {
-        if (const char *e = getenv("GS_RASTER_SEG")) seg = atoi(e) <= 0 ? 0 : ((atoi(e) + 63) / 64) * 64;
-        if (const char *e = getenv("GS_RASTER_SOLO")) solo_min = atoi(e);
-        if (const char *e = getenv("GS_RASTER_XCD_FWD")) xcd_fwd = (uint32_t)atoi(e);
-        if (const char *e = getenv("GS_RASTER_XCD_BWD")) xcd_bwd = (uint32_t)atoi(e);
-    }
-};
-RasterTuning &tuning() {
-    static RasterTuning t;
-    return t;
-}
-
-// Segment length for this launch: the tuned value, doubled until the checkpoint array stays below 65536 boundaries
-// (256 MB for RGB).
-int32_t seg_len(uint32_t n_isects) {
-    int32_t v = tuning().seg;
-    if (v <= 0) return 0;
-    while ((uint64_t)n_isects / (uint32_t)v > 65536u) v *= 2;
-    return v;
-}
+// Tuning defaults = the measured optima on MI355X (profiles/round1_notes.md, round2_notes.md).  They travel in the
+// caller's gs_raster_plan (gs_rasterize_plan): the library itself holds no tuning state.
+//   seg        segment length of the depth-segmented backward in list entries (multiple of 64; 0: no segments,
+//              the generic one-quadrant-per-wave backward runs instead).  256 since the work list is ordered
+//              longest-first (round 2: 128 / 192 / 256 / 320 / 384 / 512 -> 0.338 / 0.317 / 0.305 / 0.312 / 0.324 /
+//              0.331 ms backward, and half the checkpoint planes in the forward); with the list in arrival order
+//              128 was best (round 1: 512 -> 1.14 ms, 256 -> 0.97 ms, 128 -> 0.89 ms).
+//   solo_min   list length from which a tile's four forward waves stop cooperating (0: never). 2048.
+//   xcd_fwd / xcd_bwd   work items per XCD group (xcd_remap).  16 tiles / 16 segment items.
+constexpr uint32_t PLAN_MAGIC = 0x47535033u; // "GSP3"
 
 struct ScratchLayout {
     size_t off_items, off_cost_head, off_cost_body, off_body_tile, off_ckpt, total;
     uint32_t max_items, n_bounds;
 };
 
-ScratchLayout scratch_layout(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels) {
+ScratchLayout scratch_layout(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels, int32_t seg) {
     ScratchLayout L;
-    const int32_t seg = seg_len(n_isects);
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t o = 256;
     L.n_bounds = (seg > 0 ? n_isects / (uint32_t)seg : 0) + 2; // list boundaries k * seg, k < n_bounds
@@ -1539,44 +1532,66 @@ ScratchLayout scratch_layout(uint32_t n_tiles_all, uint32_t n_isects, uint32_t c
     return L;
 }
 
+ScratchLayout scratch_layout(const gs_raster_plan &p) { return scratch_layout(p.n_tiles_all, p.n_isects, p.channels, p.seg); }
+
 } // namespace
 
-int32_t raster_set_tuning(const char *key, int32_t value) {
-    RasterTuning &t = tuning();
-    if (strcmp(key, "raster_seg") == 0) t.seg = value <= 0 ? 0 : ((value + 63) / 64) * 64;
-    else if (strcmp(key, "raster_solo_min") == 0) t.solo_min = value;
-    else if (strcmp(key, "raster_xcd_fwd") == 0) t.xcd_fwd = (uint32_t)max(value, 0);
-    else if (strcmp(key, "raster_xcd_bwd") == 0) t.xcd_bwd = (uint32_t)max(value, 0);
-    else return 1;
+int32_t raster_make_plan(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels, const int32_t *tuning, gs_raster_plan *plan) {
+    memset(plan, 0, sizeof(*plan));
+    int32_t seg = 256, solo = 2048, xf = 16, xb = 16;
+    if (tuning != nullptr) {
+        if (tuning[0] >= 0) seg = ((tuning[0] + 63) / 64) * 64;
+        if (tuning[1] >= 0) solo = tuning[1];
+        if (tuning[2] >= 0) xf = tuning[2];
+        if (tuning[3] >= 0) xb = tuning[3];
+    }
+    // the segment length is doubled until the checkpoint array stays below 65536 boundaries (256 MB for RGB)
+    while (seg > 0 && (uint64_t)n_isects / (uint32_t)seg > 65536u) seg *= 2;
+    plan->magic = PLAN_MAGIC;
+    plan->n_tiles_all = n_tiles_all;
+    plan->n_isects = n_isects;
+    plan->channels = channels;
+    plan->seg = seg;
+    plan->solo_min = solo;
+    plan->xcd_fwd = (uint32_t)xf;
+    plan->xcd_bwd = (uint32_t)xb;
+    plan->scratch_bytes = scratch_layout(*plan).total;
     return 0;
 }
 
-size_t raster_wave_scratch_bytes(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels) {
-    return scratch_layout(n_tiles_all, n_isects, channels).total;
+bool raster_plan_ok(const gs_raster_plan *plan, uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels) {
+    return plan != nullptr && plan->magic == PLAN_MAGIC && plan->n_tiles_all == n_tiles_all && plan->n_isects == n_isects &&
+           plan->channels == channels && plan->seg >= 0 && plan->seg % 64 == 0 &&
+           plan->scratch_bytes == scratch_layout(*plan).total;
 }
 
-int32_t raster_wave_fwd(const RasterArgs &a_in, void *scratch, size_t scratch_bytes, void *zero_fill, size_t zero_fill_bytes,
+int32_t raster_wave_fwd(const RasterArgs &a_in, const gs_raster_plan *plan, void *scratch, void *zero_fill, size_t zero_fill_bytes,
                         hipStream_t st) {
     RasterArgs a = a_in;
     const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;
+    gs_raster_plan dflt; // no plan: default launch geometry, no checkpoints
+    if (plan == nullptr) {
+        raster_make_plan(n_tiles_all, a.n_isects, a.channels, nullptr, &dflt);
+        scratch = nullptr;
+    }
+    const gs_raster_plan &P = plan ? *plan : dflt;
+    const int32_t seg = P.seg;
+    const bool ckpt_on = a.channels <= 4 && seg > 0 && scratch != nullptr;
     // the side job: spread over the tile workgroups when each gets at most 64 KB of it, a plain fill otherwise
     ZeroFill zf = {nullptr, 0, 0u};
     if (zero_fill != nullptr && zero_fill_bytes > 0) {
         const size_t n16 = zero_fill_bytes / 16;
         const size_t per = (n16 + n_tiles_all - 1) / (n_tiles_all ? n_tiles_all : 1);
-        const bool in_kernel = a.channels <= 4 && seg_len(a.n_isects) > 0 && scratch != nullptr && n_tiles_all > 0 && per <= 4096 &&
-                               scratch_bytes >= scratch_layout(n_tiles_all, a.n_isects, a.channels).total;
+        const bool in_kernel = ckpt_on && n_tiles_all > 0 && per <= 4096;
         if (in_kernel) zf = {(float4 *)zero_fill, n16, (uint32_t)per};
         else if (hipMemsetAsync(zero_fill, 0, zero_fill_bytes, st) != hipSuccess) { gs_set_error("rasterize: zero fill failed"); return 1; }
     }
     if (a.channels <= 4) {
         // one 256-thread workgroup per tile; checkpoints for the segmented backward when the caller handed over scratch
-        const ScratchLayout L = scratch_layout(n_tiles_all, a.n_isects, a.channels);
-        const int32_t seg = seg_len(a.n_isects);
-        float *ckpt = nullptr;
-        if (seg > 0 && scratch != nullptr && scratch_bytes >= L.total) ckpt = (float *)((char *)scratch + L.off_ckpt);
-        a.xcd_group = tuning().xcd_fwd;
-        const int32_t solo = tuning().solo_min;
+        const ScratchLayout L = scratch_layout(P);
+        float *ckpt = ckpt_on ? (float *)((char *)scratch + L.off_ckpt) : nullptr;
+        a.xcd_group = P.xcd_fwd;
+        const int32_t solo = P.solo_min;
         uint32_t *ch = ckpt ? (uint32_t *)((char *)scratch + L.off_cost_head) : nullptr;
         uint32_t *cb = ckpt ? (uint32_t *)((char *)scratch + L.off_cost_body) : nullptr;
         uint32_t *bt = ckpt ? (uint32_t *)((char *)scratch + L.off_body_tile) : nullptr;
@@ -1593,7 +1608,7 @@ int32_t raster_wave_fwd(const RasterArgs &a_in, void *scratch, size_t scratch_by
         return 0;
     }
     // more than 4 channels: one quadrant per wave, exact chunks of 32 channels
-    a.xcd_group = tuning().xcd_fwd * 4u;
+    a.xcd_group = P.xcd_fwd * 4u;
     for (uint32_t off = 0; off < a.channels; off += 32) {
         uint32_t cnt = min(32u, a.channels - off);
         if (cnt <= 8) launch_fwd<8>(a, cnt, off, st);
@@ -1603,17 +1618,23 @@ int32_t raster_wave_fwd(const RasterArgs &a_in, void *scratch, size_t scratch_by
     return 0;
 }
 
-int32_t raster_wave_bwd(const RasterArgs &a_in, const RasterGradArgs &ga, const float *render_colors, void *scratch,
-                        size_t scratch_bytes, hipStream_t st) {
+int32_t raster_wave_bwd(const RasterArgs &a_in, const RasterGradArgs &ga, const float *render_colors, const gs_raster_plan *plan,
+                        void *scratch, hipStream_t st) {
     RasterArgs a = a_in;
-    a.xcd_group = tuning().xcd_bwd;
+    const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;
+    gs_raster_plan dflt;
+    if (plan == nullptr) {
+        raster_make_plan(n_tiles_all, a.n_isects, a.channels, nullptr, &dflt);
+        scratch = nullptr;
+    }
+    const gs_raster_plan &P = plan ? *plan : dflt;
+    a.xcd_group = P.xcd_bwd;
     const int use_va = ga.v_render_alphas != nullptr;
     const uint32_t c = a.channels;
-    const uint32_t n_tiles_all = a.C * a.tile_width * a.tile_height;
-    const ScratchLayout L = scratch_layout(n_tiles_all, a.n_isects, a.channels);
-    const int32_t seg = seg_len(a.n_isects);
-    // Depth-segmented backward: needs the forward's checkpoints (same scratch) and the render.
-    if (seg > 0 && c <= 4 && scratch != nullptr && scratch_bytes >= L.total && render_colors != nullptr) {
+    const int32_t seg = P.seg;
+    // Depth-segmented backward: needs the forward's checkpoints (same plan, same scratch) and the render.
+    if (seg > 0 && c <= 4 && scratch != nullptr && render_colors != nullptr) {
+        const ScratchLayout L = scratch_layout(P);
         // the work list was built by gs_rasterize_fwd (seg_items_build_kernel): ONE launch here
         SegArgs sg = {(const uint2 *)((char *)scratch + L.off_items), (const uint32_t *)scratch, L.max_items,
                       (const float *)((char *)scratch + L.off_ckpt), render_colors, seg};
@@ -1627,7 +1648,7 @@ int32_t raster_wave_bwd(const RasterArgs &a_in, const RasterGradArgs &ga, const 
     }
     // no checkpoints (forward ran without scratch, or segments are switched off) or more than 4 channels:
     // one quadrant per wave walking the whole list back to front
-    a.xcd_group = tuning().xcd_bwd * 4u;
+    a.xcd_group = P.xcd_bwd * 4u;
     if (c <= 4) {
         switch (c) {
             case 1: launch_bwd<1, 0>(a, ga, 1, 0, use_va, st); break;

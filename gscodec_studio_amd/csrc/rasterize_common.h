@@ -18,6 +18,11 @@ struct RasterArgs {
     float *render_alphas;
     int32_t *last_ids;
     uint32_t xcd_group; // XCD-aware work-item grouping (0 = off), set by the dispatcher
+    // row strides (in floats) of means2d / conics / colors / opacities: 2, 3, channels, 1 for the reference's dense
+    // arrays; all 16 when the four pointers are column views of ONE splat row (include/gsplat_hip.h, "splat rows").
+    uint32_t s_xy, s_conic, s_color, s_opac;
+    uint32_t row16; // 1: the pointers alias one 64-byte-aligned [n_elems,16] buffer at columns 0 / 2 / 6 / 5 and channels <= 4:
+                    // the kernels fetch a splat as (up to) three 16-byte loads from ONE 64-byte line
 };
 
 // a buffer the forward zero-fills on the side: n float4s, per_block of them per tile workgroup
@@ -60,9 +65,9 @@ GS_DEV float wave_reduce_sum_dpp(float v) {
     return v;
 }
 
-int32_t raster_set_tuning(const char *key, int32_t value);
-size_t raster_wave_scratch_bytes(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels);
-int32_t raster_wave_fwd(const RasterArgs &a, void *scratch, size_t scratch_bytes, void *zero_fill, size_t zero_fill_bytes,
+int32_t raster_make_plan(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels, const int32_t *tuning, gs_raster_plan *plan);
+bool raster_plan_ok(const gs_raster_plan *plan, uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels);
+int32_t raster_wave_fwd(const RasterArgs &a, const gs_raster_plan *plan, void *scratch, void *zero_fill, size_t zero_fill_bytes,
                         hipStream_t st);
-int32_t raster_wave_bwd(const RasterArgs &a, const RasterGradArgs &ga, const float *render_colors, void *scratch,
-                        size_t scratch_bytes, hipStream_t st);
+int32_t raster_wave_bwd(const RasterArgs &a, const RasterGradArgs &ga, const float *render_colors, const gs_raster_plan *plan,
+                        void *scratch, hipStream_t st);

@@ -198,6 +198,8 @@ struct ShView {
     const float *v_opac_cn;  // bwd: [C,N] rows with stride v_opac_stride floats
     uint32_t v_opac_stride;
     float *v_opac_out;       // bwd: [N] <- sum over cameras
+    uint32_t color_stride;   // row stride (floats) of the colours the forward writes / the backward reads back: 3, or 16 when
+                             // they are columns of the splat rows (include/gsplat_hip.h)
 };
 
 GS_DEV bool sh_active(const uint8_t *masks, const ShView &v, size_t e) {
@@ -258,9 +260,10 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_fwd_kernel(
         g = fmaxf(g + 0.5f, 0.f);
         b = fmaxf(b + 0.5f, 0.f);
     }
-    colors[3 * e] = r;
-    colors[3 * e + 1] = g;
-    colors[3 * e + 2] = b;
+    float *co = colors + e * view.color_stride;
+    co[0] = r;
+    co[1] = g;
+    co[2] = b;
 }
 
 // One lane per gaussian; loops over cameras.  SHARED: v_coeffs is [N,K,3] and the lane
@@ -302,9 +305,10 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
         const float *vcp = v_colors + e * v_colors_stride;
         float vr = vcp[0], vg = vcp[1], vb = vcp[2];
         if (view.clamp_half) { // gradient of clamp_min(colour + 0.5, 0): passes where the output is > 0
-            if (!(colors_out[3 * e] > 0.f)) vr = 0.f;
-            if (!(colors_out[3 * e + 1] > 0.f)) vg = 0.f;
-            if (!(colors_out[3 * e + 2] > 0.f)) vb = 0.f;
+            const float *co = colors_out + e * view.color_stride;
+            if (!(co[0] > 0.f)) vr = 0.f;
+            if (!(co[1] > 0.f)) vg = 0.f;
+            if (!(co[2] > 0.f)) vb = 0.f;
         }
         float Y[NB];
         float x = 0.f, y = 0.f, z = 1.f, inv = 1.f;
@@ -421,7 +425,7 @@ extern "C" int32_t gs_sh_fwd(
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K);
-    ShView view = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0u, nullptr};
+    ShView view = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0u, nullptr, 3u};
     switch (degree) {
         case 0: launch_fwd<0>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
         case 1: launch_fwd<1>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
@@ -450,15 +454,17 @@ extern "C" int32_t gs_camera_centers(uint32_t C, const float *viewmats, float *c
 
 extern "C" int32_t gs_sh_view_fwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos, int32_t campos_from_viewmats,
-    const float *coeffs, const int32_t *radii, float *colors, const float *opacities, float *opacities_cn, gs_stream_t stream) {
+    const float *coeffs, const int32_t *radii, float *colors, uint32_t colors_stride, const float *opacities, float *opacities_cn,
+    gs_stream_t stream) {
     if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && campos && coeffs && colors, "null pointer");
+    GS_CHECK_ARG(colors_stride >= 3, "colors_stride must be >= 3");
     GS_CHECK_ARG(degree <= 4, "degree must be <= 4");
     GS_CHECK_ARG((degree + 1) * (degree + 1) <= K, "K too small for degree");
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K);
-    ShView view = {means, campos, radii, 1, campos_from_viewmats, opacities, opacities_cn, nullptr, 0u, nullptr};
+    ShView view = {means, campos, radii, 1, campos_from_viewmats, opacities, opacities_cn, nullptr, 0u, nullptr, colors_stride};
     GS_CHECK_ARG((opacities == nullptr) == (opacities_cn == nullptr), "opacities and opacities_cn go together");
     switch (degree) {
         case 0: launch_fwd<0>(vec, grid, st, C, N, K, nullptr, coeffs, 1, nullptr, colors, view); break;
@@ -484,7 +490,7 @@ extern "C" int32_t gs_sh_bwd(
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K) && rows_vectorizable(v_coeffs, K);
     bool shared = coeffs_shared != 0;
-    ShView view = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0u, nullptr};
+    ShView view = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0u, nullptr, 3u};
     switch (degree) {
         case 0: launch_bwd<0>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
         case 1: launch_bwd<1>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
@@ -498,18 +504,18 @@ extern "C" int32_t gs_sh_bwd(
 
 extern "C" int32_t gs_sh_view_bwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos, int32_t campos_from_viewmats,
-    const float *coeffs, const int32_t *radii, const float *colors_out, const float *v_colors,
+    const float *coeffs, const int32_t *radii, const float *colors_out, uint32_t colors_out_stride, const float *v_colors,
     uint32_t v_colors_stride, float *v_coeffs, float *v_means, const float *v_opacities_cn, uint32_t v_opacities_stride,
     float *v_opacities, gs_stream_t stream) {
     if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && campos && coeffs && colors_out && v_colors && v_coeffs, "null pointer");
     GS_CHECK_ARG(degree <= 4, "degree must be <= 4");
     GS_CHECK_ARG((degree + 1) * (degree + 1) <= K, "K too small for degree");
-    GS_CHECK_ARG(v_colors_stride >= 3, "v_colors_stride must be >= 3");
+    GS_CHECK_ARG(v_colors_stride >= 3 && colors_out_stride >= 3, "colour row strides must be >= 3");
     dim3 grid(gs_div_up(N, GS_BLOCK));
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K) && rows_vectorizable(v_coeffs, K);
-    ShView view = {means, campos, radii, 1, campos_from_viewmats, nullptr, nullptr, v_opacities_cn, v_opacities_stride, v_opacities};
+    ShView view = {means, campos, radii, 1, campos_from_viewmats, nullptr, nullptr, v_opacities_cn, v_opacities_stride, v_opacities, colors_out_stride};
     GS_CHECK_ARG((v_opacities_cn == nullptr) == (v_opacities == nullptr), "v_opacities_cn and v_opacities go together");
     switch (degree) {
         case 0: launch_bwd<0>(vec, true, grid, st, C, N, K, nullptr, coeffs, nullptr, v_colors, v_coeffs, nullptr, view, colors_out, v_colors_stride, v_means); break;

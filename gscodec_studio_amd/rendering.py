@@ -25,9 +25,11 @@ from typing_extensions import Literal
 
 from ._wrapper import (
     fully_fused_projection,
+    project_rows,
     gather_rows,
     isect_offset_encode,
     isect_tiles,
+    isect_tiles_abandon,
     isect_tiles_begin,
     isect_tiles_finish,
     isect_tiles_start,
@@ -173,36 +175,59 @@ def rasterization(
                 cap_world = None
         C = len(viewmats)
 
+    # Unpacked batches on one GPU go through SPLAT ROWS: the projection writes one 64-byte row per (camera, gaussian) --
+    # mean2d, conic, opacity (x antialias compensation), colour, depth, radius -- that the compositing kernels fetch whole;
+    # means2d / conics / opacities (/ colours) below are column views of that buffer (same shapes and dtypes as the
+    # reference's separate tensors; like its means2d / conics they are only defined where radii > 0).
+    use_rows = (not packed) and (not distributed) and means.is_cuda
+    fuse_sh = (sh_degree is not None and not packed and colors.dim() == 3 and not viewmats.requires_grad and viewmats.is_cuda)
     # the fused SH route reads the means a second time (view directions): it gets them back FROM the projection, so that
     # its contribution to d/d means is added inside the projection's backward kernel
-    means_alias = (sh_degree is not None and not packed and colors.dim() == 3 and means.requires_grad
-                   and not viewmats.requires_grad and viewmats.is_cuda)
-    proj_results = fully_fused_projection(
-        means, covars, quats, scales, viewmats, Ks, width, height,
-        eps2d=eps2d, packed=packed, near_plane=near_plane, far_plane=far_plane,
-        radius_clip=radius_clip, sparse_grad=sparse_grad,
-        calc_compensations=(rasterize_mode == "antialiased"), camera_model=camera_model, _means_alias=means_alias,
-    )
-    means_sh = means
-    if means_alias:
-        means_sh, proj_results = proj_results[5], proj_results[:5]
-
-    if packed:
-        camera_ids, gaussian_ids, radii, means2d, depths, conics, compensations = proj_results
-        opacities = gather_rows(opacities, gaussian_ids)  # [nnz] = opacities[gaussian_ids], one-pass atomic backward
-    else:
-        radii, means2d, depths, conics, compensations = proj_results
+    means_alias = fuse_sh and means.requires_grad
+    rows = None
+    compensations = None
+    if use_rows:
+        row_colors = colors if (sh_degree is None and colors.dim() == 2 and colors.shape[-1] == 3) else None
+        proj_results = project_rows(
+            means, covars, quats, scales, viewmats, Ks, width, height, opacities, row_colors,
+            eps2d=eps2d, near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip,
+            antialiased=(rasterize_mode == "antialiased"), camera_model=camera_model, _means_alias=means_alias,
+        )
+        means_sh = means
+        if means_alias:
+            means_sh, proj_results = proj_results[7], proj_results[:7]
+        radii, means2d, depths, conics, opacities, colors_rows, rows = proj_results
         camera_ids, gaussian_ids = None, None
-        # classic mode + shared SH on the fused route: the per-view opacities ride along with the colour kernels
-        # (written by the SH forward, summed over cameras by its backward) instead of `.repeat` + autograd's sum
-        opacity_rider = (compensations is None and sh_degree is not None and colors.dim() == 3
-                         and not viewmats.requires_grad and viewmats.is_cuda)
-        opacities_n = opacities
-        if not opacity_rider:
-            opacities = opacities.repeat(C, 1)  # [C, N]
+        opacity_rider = False
+        if row_colors is not None:
+            colors = colors_rows  # [C, N, 3]: columns 6:9 of the rows
+    else:
+        proj_results = fully_fused_projection(
+            means, covars, quats, scales, viewmats, Ks, width, height,
+            eps2d=eps2d, packed=packed, near_plane=near_plane, far_plane=far_plane,
+            radius_clip=radius_clip, sparse_grad=sparse_grad,
+            calc_compensations=(rasterize_mode == "antialiased"), camera_model=camera_model, _means_alias=means_alias,
+        )
+        means_sh = means
+        if means_alias:
+            means_sh, proj_results = proj_results[5], proj_results[:5]
 
-    if compensations is not None:
-        opacities = opacities * compensations
+        if packed:
+            camera_ids, gaussian_ids, radii, means2d, depths, conics, compensations = proj_results
+            opacities = gather_rows(opacities, gaussian_ids)  # [nnz] = opacities[gaussian_ids], one-pass atomic backward
+        else:
+            radii, means2d, depths, conics, compensations = proj_results
+            camera_ids, gaussian_ids = None, None
+            # classic mode + shared SH on the fused route: the per-view opacities ride along with the colour kernels
+            # (written by the SH forward, summed over cameras by its backward) instead of `.repeat` + autograd's sum
+            opacity_rider = (compensations is None and sh_degree is not None and colors.dim() == 3
+                             and not viewmats.requires_grad and viewmats.is_cuda)
+            opacities_n = opacities
+            if not opacity_rider:
+                opacities = opacities.repeat(C, 1)  # [C, N]
+
+        if compensations is not None:
+            opacities = opacities * compensations
 
     meta.update(
         {
@@ -235,7 +260,7 @@ def rasterization(
                 colors = colors.expand(C, -1, -1)
     else:
         fused_sh = False
-        fuse = (not packed) and colors.dim() == 3 and not viewmats.requires_grad and viewmats.is_cuda
+        fuse = fuse_sh
         campos = None if fuse else _camera_centers(viewmats)  # [C, 3] == inverse(viewmats)[:, :3, 3]
         if packed:
             dirs = gather_rows(means, gaussian_ids) - campos[camera_ids]  # [nnz, 3]
@@ -248,8 +273,8 @@ def rasterization(
                 if opacity_rider:
                     colors, opacities = spherical_harmonics_view(sh_degree, means_sh, viewmats, colors, radii, opacities=opacities_n)
                     meta["opacities"] = opacities
-                else:
-                    colors = spherical_harmonics_view(sh_degree, means_sh, viewmats, colors, radii)  # [C, N, 3]
+                else:  # (with splat rows: written into columns 6:9 of the rows, returned as that view)
+                    colors = spherical_harmonics_view(sh_degree, means_sh, viewmats, colors, radii, rows=rows)  # [C, N, 3]
                 fused_sh = True
             else:
                 dirs = means[None, :, :] - campos[:, None, :]  # [C, N, 3]
@@ -280,6 +305,8 @@ def rasterization(
             )
             if cap_world is None or not D.exchange_overflowed():
                 break
+            isect_tiles_abandon(isect_state)  # (its pinned block-sum buffer is still being written by the count kernel)
+            isect_state = None
             cap_world = [C_world[r] * N_world[r] for r in range(world_size)]
 
     if render_mode in ["RGB+D", "RGB+ED"]:

@@ -33,7 +33,13 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 1
+/* Bumped whenever an exported signature or the meaning of an argument changes (1: round 1; 2: the round-2 additions to
+ * gs_rasterize_fwd, gs_isect_count_keys, gs_sort_pairs_u64_i32_drop, gs_projection_bwd; 3: round 3 -- the splat-row layout,
+ * gs_raster_plan, gs_kmeans_decode's bounds).  A binding must refuse a library whose gs_version() differs from the
+ * GS_ABI_VERSION of the header it was generated from, and SHOULD also compare gs_header_hash() (the first 8 bytes of the
+ * SHA-256 of the header file the library was compiled against, big-endian) with the hash of its own copy: ctypes / cgo call
+ * through shifted argument lists silently otherwise. */
+#define GS_ABI_VERSION 3
 
 /* reference: gsplat/cuda/include/bindings.h:34-38 (enum CameraModelType) */
 #define GS_CAMERA_PINHOLE 0
@@ -47,16 +53,30 @@ extern "C" {
 typedef void *gs_stream_t; /* hipStream_t */
 
 int32_t gs_version(void);
+uint64_t gs_header_hash(void);
 const char *gs_last_error(void);
 
-/* Tuning knobs of the compositing kernels (no reference counterpart: the reference fixes its launch geometry at compile
- * time).  Defaults are the measured optima on MI355X and can be preset through the environment, which is read once:
- *   "raster_seg"       GS_RASTER_SEG      backward segment length in list entries (multiple of 64; 0 = unsegmented)
- *   "raster_solo_min"  GS_RASTER_SOLO     list length from which a tile's forward waves stop cooperating (0 = never)
- *   "raster_xcd_fwd" / "raster_xcd_bwd"   GS_RASTER_XCD_FWD / _BWD   work items per XCD group (0 = identity mapping)
- * Results never depend on them beyond floating-point association of the gradient atomics; a scratch buffer must be
- * used by gs_rasterize_fwd and gs_rasterize_bwd under the SAME settings.  Returns non-zero for an unknown key. */
-int32_t gs_set_tuning(const char *key, int32_t value);
+/* ------------------------------------------------------------------------
+ * Splat rows: ONE 64-byte row of 16 floats per projected splat (camera, gaussian), the layout the compositing kernels
+ * fetch with a single L2 request (three 16-byte loads from one line) instead of four gathers from four arrays:
+ *   [0] mean2d.x  [1] mean2d.y  [2] conic.a  [3] conic.b  [4] conic.c  [5] opacity (after antialias compensation)
+ *   [6] [7] [8] colour            [9] depth   [10] radius (int32 bit pattern)   [11] compensation   [12..15] reserved
+ * The reference's tensors (means2d [C,N,2], conics [C,N,3], opacities [C,N], colours [C,N,3]; gsplat/rendering.py:337-349)
+ * are COLUMN VIEWS of the row buffer, so `meta` keeps its keys, shapes and dtypes.  gs_projection_rows_fwd fills
+ * columns 0-5 and 9-11 (and 6-8 for post-activation colours), gs_sh_view_fwd columns 6-8.  Rows of culled splats
+ * (radii == 0) are left untouched, as the reference leaves means2d / conics uninitialised there.  The gradient rows the
+ * compositing backward accumulates into (gs_rasterize_bwd, packed16) use the same columns: v_mean2d | v_conic |
+ * v_opacity | v_colour (4 channels: column 9 is the fourth) | [10] [11] absgrad.
+ * ---------------------------------------------------------------------- */
+#define GS_ROW_FLOATS 16
+#define GS_ROW_MEAN2D 0
+#define GS_ROW_CONIC 2
+#define GS_ROW_OPACITY 5
+#define GS_ROW_COLOR 6
+#define GS_ROW_DEPTH 9
+#define GS_ROW_RADIUS 10
+#define GS_ROW_COMPENSATION 11
+
 
 /* ------------------------------------------------------------------------
  * R1  fully fused projection
@@ -110,6 +130,42 @@ int32_t gs_projection_bwd(
     uint32_t v_conics_stride,  /* row stride of v_conics in floats: 3, or 16 */
     const float *v_means_add,  /* [N,3] or NULL: added to v_means (the d/d means that arrives through the SH view
                                   directions, rendering.py:381-391 in the reference; saves autograd's elementwise sum) */
+    gs_stream_t stream);
+
+/* Row form of the fused projection (what rasterization() uses for unpacked batches): same arithmetic and culling as
+ * gs_projection_fwd, but every visible (camera, gaussian) pair gets ONE splat row (see "Splat rows" above) instead of
+ * entries in three arrays.  Folded in, because the row wants them and the pass runs anyway:
+ *   opacities [N] (or NULL): column 5 = opacities[n]              -- the `opacities.repeat(C, 1)` of rendering.py:331,
+ *                            x compensation when antialiased != 0  -- and the multiply of rendering.py:334-335;
+ *   colors [N,3] (or NULL):  columns 6-8 = colors[n]               -- the `colors.expand(C, -1, -1)` of rendering.py:386.
+ * radii [C,N] and depths [C,N] are ALSO written densely (the binning kernels stream through them); rows must be 64-byte
+ * aligned; rows / depths of culled pairs are left untouched. */
+int32_t gs_projection_rows_fwd(
+    uint32_t C, uint32_t N,
+    const float *means, const float *covars, const float *quats, const float *scales,
+    const float *viewmats, const float *Ks,
+    int32_t image_width, int32_t image_height,
+    float eps2d, float near_plane, float far_plane, float radius_clip,
+    int32_t camera_model,
+    const float *opacities, const float *colors, int32_t antialiased,
+    int32_t *radii, /* [C,N] */
+    float *depths,  /* [C,N] */
+    float *rows,    /* [C,N,16] */
+    gs_stream_t stream);
+/* Its backward: grad_rows [C,N,16] holds d/d(mean2d, conic, opacity, colour) in the splat-row columns (what gs_rasterize_bwd
+ * accumulates with packed16), v_depths [C,N] or NULL.  Besides the outputs of gs_projection_bwd (all OVERWRITTEN),
+ * v_opacities [N] = sum over cameras of column 5 (x compensation when antialiased, whose own gradient then enters the
+ * projection chain) and v_colors [N,3] = sum over cameras of columns 6-8; either may be NULL. */
+int32_t gs_projection_rows_bwd(
+    uint32_t C, uint32_t N,
+    const float *means, const float *covars, const float *quats, const float *scales,
+    const float *viewmats, const float *Ks,
+    int32_t image_width, int32_t image_height, float eps2d, int32_t camera_model,
+    const int32_t *radii, const float *rows, const float *grad_rows, const float *v_depths,
+    const float *opacities /* [N]; needed when antialiased */, int32_t antialiased,
+    float *v_means, float *v_covars, float *v_quats, float *v_scales, float *v_viewmats,
+    float *v_opacities, float *v_colors,
+    const float *v_means_add, /* [N,3] or NULL, as in gs_projection_bwd */
     gs_stream_t stream);
 
 /* packed (COO) projection, replaces fully_fused_projection_packed_fwd_tensor
@@ -203,11 +259,12 @@ int32_t gs_camera_centers(uint32_t C, const float *viewmats, float *campos, gs_s
 int32_t gs_sh_view_fwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree,
     const float *means, const float *campos, int32_t campos_from_viewmats, const float *coeffs, const int32_t *radii,
-    float *colors, const float *opacities /* [N] or NULL */, float *opacities_cn /* [C,N] or NULL */, gs_stream_t stream);
+    float *colors, uint32_t colors_stride /* row stride in floats: 3, or GS_ROW_FLOATS when `colors` is column GS_ROW_COLOR of the splat rows */,
+    const float *opacities /* [N] or NULL */, float *opacities_cn /* [C,N] or NULL */, gs_stream_t stream);
 int32_t gs_sh_view_bwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree,
     const float *means, const float *campos, int32_t campos_from_viewmats, const float *coeffs, const int32_t *radii,
-    const float *colors_out, const float *v_colors, uint32_t v_colors_stride,
+    const float *colors_out, uint32_t colors_out_stride, const float *v_colors, uint32_t v_colors_stride,
     float *v_coeffs, float *v_means,
     const float *v_opacities_cn /* or NULL */, uint32_t v_opacities_stride, float *v_opacities /* [N] or NULL */,
     gs_stream_t stream);
@@ -222,7 +279,8 @@ int32_t gs_sh_view_bwd(
  * ---------------------------------------------------------------------- */
 int32_t gs_isect_count(
     uint32_t n_elems,           /* C*N or nnz */
-    const float *means2d, const int32_t *radii,
+    const float *means2d, uint32_t means2d_stride /* row stride in floats: 2, or GS_ROW_FLOATS for the splat rows */,
+    const int32_t *radii,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
     int32_t *tiles_per_gauss,   /* [n_elems] */
     gs_stream_t stream);
@@ -252,7 +310,7 @@ int32_t gs_gather_i32(uint32_t n, const int32_t *src, const int32_t *idx, int32_
 /* the same in fewer launches: gs_isect_count + gs_isect_depth_keys in one kernel, and the inclusive prefix sum
  * of in[idx[i]] (= gs_gather_i32 followed by gs_cumsum_i32) without the intermediate array */
 int32_t gs_isect_count_keys(
-    uint32_t n_elems, const float *means2d, const int32_t *radii, const float *depths,
+    uint32_t n_elems, const float *means2d, uint32_t means2d_stride, const int32_t *radii, const float *depths,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
     int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals,
     int32_t *block_sums /* [gs_isect_count_blocks(n_elems)] or NULL: intersections per block; their sum is n_isects,
@@ -272,7 +330,7 @@ int32_t gs_isect_emit(
     const int32_t *perm,            /* [n_elems] emission order or NULL (identity) */
     const uint32_t *n_valid,        /* device scalar or NULL: only perm[0 .. *n_valid) is defined (gs_sort_pairs_u64_i32_drop) */
     const int64_t *camera_ids,      /* [nnz] or NULL */
-    const float *means2d, const int32_t *radii, const float *depths,
+    const float *means2d, uint32_t means2d_stride, const int32_t *radii, const float *depths,
     const int64_t *cum_tiles_per_gauss, /* inclusive, indexed by emission position */
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
     uint32_t tile_n_bits,
@@ -288,7 +346,7 @@ int32_t gs_isect_emit(
  * destroyed.  temp: gs_sort_isect_temp_bytes(n). */
 int32_t gs_isect_emit_compact(
     uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids,
-    const float *means2d, const int32_t *radii, const float *depths, const int64_t *cum_tiles_per_gauss,
+    const float *means2d, uint32_t means2d_stride, const int32_t *radii, const float *depths, const int64_t *cum_tiles_per_gauss,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits,
     uint32_t *keys32,     /* [n_isects] */
     int32_t *flatten_ids, /* [n_isects] */
@@ -335,18 +393,39 @@ int32_t gs_isect_offset_encode(
  * channels is a runtime value (1..513); no padding is required from the caller.
  * n_elems = C*N (unpacked) or nnz (packed): size of the per-splat arrays.
  * bwd outputs are ACCUMULATED with atomics: caller zero-fills them.
- * scratch (optional, gs_rasterize_scratch_bytes(C * tile_width * tile_height, n_isects, channels)
- * bytes): the forward stores per-pixel checkpoints (transmittance, accumulated colour) at fixed
+ * scratch (optional, gs_raster_plan.scratch_bytes bytes): the forward stores per-pixel checkpoints (transmittance, accumulated colour) at fixed
  * list-index boundaries in it; when the SAME buffer (contents preserved) and the forward's
  * render_colors are handed to gs_rasterize_bwd, the backward runs depth-segmented (one wave per
  * (tile, segment), no serial walk of long lists).  Without them it falls back to one wave per
  * quadrant.  Results are the same up to fp32 rounding.
  * ---------------------------------------------------------------------- */
-size_t gs_rasterize_scratch_bytes(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels);
+/* The launch plan of one gs_rasterize_fwd / gs_rasterize_bwd pair: a HOST struct the caller owns, filled by
+ * gs_rasterize_plan and handed to both calls, so the two cannot disagree about the scratch layout and the library
+ * keeps no state of its own (no process-global tuning).  tuning: NULL (the measured MI355X optima) or 4 ints
+ *   [0] segment length of the depth-segmented backward in list entries (multiple of 64; 0 = unsegmented; default 256)
+ *   [1] list length from which a tile's four forward waves stop cooperating (0 = never; default 2048)
+ *   [2] / [3] work items per XCD group of the forward / backward (0 = identity mapping; default 16)
+ * a negative entry keeps the default.  Results never depend on the plan beyond floating-point association of the
+ * gradient atomics.  scratch_bytes: size of the scratch buffer both calls take (forward checkpoints, the backward's
+ * work list). */
+typedef struct gs_raster_plan {
+    uint32_t magic, n_tiles_all, n_isects, channels;
+    int32_t seg, solo_min;
+    uint32_t xcd_fwd, xcd_bwd;
+    uint64_t scratch_bytes;
+    uint32_t reserved[6];
+} gs_raster_plan;
+int32_t gs_rasterize_plan(uint32_t n_tiles_all /* C * tile_width * tile_height */, uint32_t n_isects, uint32_t channels,
+                          const int32_t *tuning /* [4] HOST ints or NULL */, gs_raster_plan *plan);
+
 int32_t gs_rasterize_fwd(
     uint32_t C, uint32_t n_elems, uint32_t n_isects, uint32_t channels,
     const float *means2d, const float *conics, const float *colors,
     const float *opacities,
+    const uint32_t *splat_strides, /* NULL: the reference's dense arrays (rows of 2 / 3 / channels / 1 floats); else 4 HOST
+                                      ints: row strides in floats of means2d, conics, colors, opacities.  When all four
+                                      are GS_ROW_FLOATS and the pointers are columns 0 / 2 / 6 / 5 of one 64-byte-aligned
+                                      row buffer (channels <= 4), the kernels fetch whole splat rows */
     const float *backgrounds, /* [C,channels] or NULL */
     const uint8_t *masks,     /* [C,tile_h,tile_w] or NULL */
     uint32_t image_width, uint32_t image_height, uint32_t tile_size,
@@ -355,7 +434,7 @@ int32_t gs_rasterize_fwd(
     float *render_colors, /* [C,H,W,channels] */
     float *render_alphas, /* [C,H,W,1] */
     int32_t *last_ids,    /* [C,H,W] */
-    void *scratch, size_t scratch_bytes,
+    const gs_raster_plan *plan, void *scratch, /* both NULL: no checkpoints (inference, or an unsegmented backward) */
     void *zero_fill, size_t zero_fill_bytes, /* optional side job (NULL, 0: none): a 16-byte aligned buffer this call
                                                 zero-fills, its stores spread over the tile workgroups' last instructions --
                                                 meant for the gradient rows the matching gs_rasterize_bwd accumulates into,
@@ -365,7 +444,8 @@ int32_t gs_rasterize_fwd(
 int32_t gs_rasterize_bwd(
     uint32_t C, uint32_t n_elems, uint32_t n_isects, uint32_t channels,
     const float *means2d, const float *conics, const float *colors,
-    const float *opacities, const float *backgrounds, const uint8_t *masks,
+    const float *opacities, const uint32_t *splat_strides /* as in gs_rasterize_fwd */,
+    const float *backgrounds, const uint8_t *masks,
     uint32_t image_width, uint32_t image_height, uint32_t tile_size,
     uint32_t tile_width, uint32_t tile_height,
     const int32_t *tile_offsets, const int32_t *flatten_ids,
@@ -380,12 +460,11 @@ int32_t gs_rasterize_bwd(
     float *v_conics,      /* [n_elems,3] */
     float *v_colors,      /* [n_elems,channels] */
     float *v_opacities,   /* [n_elems] */
-    int32_t packed16,     /* != 0: v_means2d is ONE zero-filled [n_elems,16] buffer receiving every gradient,
-                             row = [vx vy | ca cb cc | o | c0 c1 c2 c3 | ax ay | 4 pad]; v_conics / v_colors /
-                             v_opacities are ignored, v_means2d_abs only selects absgrad (non-NULL).
-                             One 64-byte row per splat lets the kernels add a whole splat's gradient with
-                             a single L2 request.  Requires channels <= 4. */
-    void *scratch, size_t scratch_bytes,
+    int32_t packed16,     /* != 0: v_means2d is ONE zero-filled [n_elems,16] buffer receiving every gradient (the splat-row
+                             columns, see above); v_conics / v_colors / v_opacities are ignored, v_means2d_abs only
+                             selects absgrad (non-NULL).  One 64-byte row per splat lets the kernels add a whole splat's
+                             gradient with a single L2 request.  Requires channels <= 4. */
+    const gs_raster_plan *plan, void *scratch, /* the forward's plan and scratch (contents preserved), or NULL, NULL */
     gs_stream_t stream);
 
 /* ------------------------------------------------------------------------
@@ -528,9 +607,12 @@ int32_t gs_decode_splats(
     int32_t normalize_quats, int32_t activate, float *means_out, float *scales_out, float *quats_out, float *opacities_out,
     float *sh0_out, gs_stream_t stream);
 /* K-means codebook decode of the higher SH bands (png_compression.py:487-520): out[r, :] =
- * centroids_quant[labels[r], :] / (2^bits - 1) * (maxs - mins) + mins (float64 arithmetic like the reference). */
+ * centroids_quant[labels[r], :] / (2^bits - 1) * (maxs - mins) + mins (float64 arithmetic like the reference).
+ * labels are file contents: one outside [0, n_centroids) (where the reference's centroids[labels] raises IndexError)
+ * decodes to a NaN row and is counted in *n_bad (device uint32, zero-filled by the caller; may be NULL). */
 int32_t gs_kmeans_decode(uint64_t n_rows, uint32_t width, const int32_t *labels, const uint8_t *centroids_quant,
-                         uint32_t bits, float mins, float maxs, float *out, gs_stream_t stream);
+                         uint32_t n_centroids, uint32_t bits, float mins, float maxs, float *out, uint32_t *n_bad,
+                         gs_stream_t stream);
 /* PNG scanline reconstruction, HOST code (PNG specification section 9: filter types 0..4): data = h rows of 1 + stride bytes
  * (filter type, filtered scanline), out = h rows of stride bytes, bpp = bytes per pixel.  The sequential part of reading the
  * image grids the reference writes through imageio (gsplat/compression/png_compression.py:196, 271, 344-349). */

@@ -31,11 +31,41 @@ def test_version_and_error_string():
     from gscodec_studio_amd import _backend as B
 
     L = B.lib()
-    assert L.gs_version() == 1
+    assert L.gs_version() == B.header_abi_version() == 3
+    assert L.gs_header_hash() == B.header_hash()  # the library was compiled against THIS header
     assert isinstance(L.gs_last_error(), bytes)
     assert B.query("gs_sort_temp_bytes", 1000) >= 1000 * 12
     assert B.query("gs_cumsum_scratch_bytes", 10_000) >= 8
-    assert B.query("gs_rasterize_scratch_bytes", 8160, 4_000_000, 3) > 4_000_000 // 256 * 4 * 256 * 4  # checkpoint planes every 256 entries
+    from gscodec_studio_amd import _wrapper as W
+
+    plan, sb = W._raster_plan(8160, 4_000_000, 3)
+    assert sb > 4_000_000 // 256 * 4 * 256 * 4  # checkpoint planes every 256 entries
+    import struct
+
+    magic, n_tiles, n_isects, channels, seg, solo = struct.unpack_from("<IIIIii", plan, 0)
+    assert (n_tiles, n_isects, channels, seg, solo) == (8160, 4_000_000, 3, 256, 2048)
+    prev = W.set_raster_tuning(raster_seg=100, raster_solo_min=0)  # rounded up to a multiple of 64
+    try:
+        plan2, sb2 = W._raster_plan(8160, 4_000_000, 3)
+        assert struct.unpack_from("<ii", plan2, 16) == (128, 0) and sb2 > sb
+    finally:
+        W.set_raster_tuning(**prev)
+
+
+def test_stale_header_or_library_is_refused(tmp_path):
+    """A header that does not match the library (other version, or same version but different text) must fail the import,
+    not be called through shifted argument lists."""
+    from gscodec_studio_amd import _backend as B
+
+    src = open(B.HEADER_PATH).read()
+    for name, text, expect in (("ver.h", src.replace("#define GS_ABI_VERSION 3", "#define GS_ABI_VERSION 2"), "ABI version mismatch"),
+                               ("txt.h", src.replace("gs_stream_t stream);", "gs_stream_t  stream);", 1), "different gsplat_hip.h")):
+        h = tmp_path / name
+        h.write_text(text)
+        code = "import gscodec_studio_amd._backend as B; B.lib()"
+        env = dict(os.environ, GSPLAT_HIP_HEADER=str(h), PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        assert r.returncode != 0 and expect in r.stderr, (name, r.stderr[-500:])
 
 
 def test_argument_validation_happens_before_any_launch():
@@ -47,9 +77,11 @@ def test_argument_validation_happens_before_any_launch():
     with pytest.raises(RuntimeError, match="degree must be <= 4"):
         B.call("gs_sh_fwd", 1, 1, 36, 5, 1, 1, 0, None, 1, None)
     with pytest.raises(RuntimeError, match="unsupported number of colour channels"):
-        B.call("gs_rasterize_fwd", 1, 1, 0, 600, None, None, None, None, None, None, 16, 16, 16, 1, 1, 1, None, 1, 1, 1, None, 0, None, 0, None)
+        B.call("gs_rasterize_fwd", 1, 1, 0, 600, None, None, None, None, None, None, None, 16, 16, 16, 1, 1, 1, None, 1, 1, 1, None, None, None, 0, None)
     with pytest.raises(RuntimeError, match="tile_size must be in"):
-        B.call("gs_rasterize_fwd", 1, 1, 0, 3, None, None, None, None, None, None, 16, 16, 32, 1, 1, 1, None, 1, 1, 1, None, 0, None, 0, None)
+        B.call("gs_rasterize_fwd", 1, 1, 0, 3, None, None, None, None, None, None, None, 16, 16, 32, 1, 1, 1, None, 1, 1, 1, None, None, None, 0, None)
+    with pytest.raises(RuntimeError, match="plan and scratch go together"):
+        B.call("gs_rasterize_fwd", 1, 1, 0, 3, None, None, None, None, None, None, None, 16, 16, 16, 1, 1, 1, None, 1, 1, 1, None, 1, None, 0, None)
     with pytest.raises(RuntimeError, match="temp too small"):
         B.call("gs_sort_pairs_u64_i32", 10, 1, 1, 1, 1, 0, 40, None, 0, None)
 

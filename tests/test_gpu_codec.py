@@ -144,6 +144,14 @@ def test_decode_then_render_full_size_and_kmeans_round_trip():
     assert bool((cent[same] == cent[same][0]).all())
     mean0 = shn.reshape(50_000, -1)[same].mean(0)
     assert float((cent[same][0] - mean0).abs().max()) <= 0.5 * step * 1.01 + 1e-6
+    # labels are file contents: one outside the codebook raises (as the reference's centroids[labels] does), no wild read
+    bad = labels.clone()
+    bad[17] = 256
+    with pytest.raises(IndexError):
+        kmeans_decode(cq, bad, m)
+    bad[17] = -1
+    with pytest.raises(IndexError):
+        kmeans_decode(cq, bad, m)
 
 
 def test_png_directory_written_like_the_reference_is_decoded_bit_exact(tmp_path):

@@ -85,11 +85,11 @@ ROUTES = {
 
 
 def set_tuning(**kv):
-    """gs_set_tuning for every key (None restores the defaults)."""
-    from gscodec_studio_amd import _backend as B
+    """Tuning values for the rasterize calls that follow (they travel in each forward's gs_raster_plan; the library keeps
+    no state)."""
+    from gscodec_studio_amd import _wrapper as W
 
-    for k, v in kv.items():
-        B.call("gs_set_tuning", k.encode(), int(v))
+    W.set_raster_tuning(**kv)
 
 
 class tuned:
