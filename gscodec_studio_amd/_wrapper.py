@@ -1094,9 +1094,6 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
     st_["cum"] = st_["perm"] = st_["pinned"] = st_["event"] = st_["n_kept"] = None
     with _device_of(means2d):
         if n_elems > 0:
-            cum = torch.empty(n_elems, dtype=torch.int64, device=dev)
-            sb = B.query("gs_cumsum_scratch_bytes", n_elems)
-            scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
             if sort:
                 # splat-level depth pre-sort: afterwards only the (camera, tile) bits need sorting
                 dkeys = torch.empty(n_elems, dtype=torch.int64, device=dev)
@@ -1126,12 +1123,24 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                 # culled elements carry the maximal key: the sort drops them in its first pass
                 ko, perm = torch.empty_like(dkeys), torch.empty_like(dvals)
                 n_kept = torch.empty(1, dtype=torch.int32, device=dev)
+                # the sort's last pass also leaves the tile counts per group of 512 emission positions behind (the block sums of
+                # the emission's prefix scan, which gs_isect_emit_presorted then finishes itself: no cumsum launches)
+                gshift = int(B.query("gs_isect_emit_group_shift"))
+                gsums = torch.empty((n_elems + (1 << gshift) - 1) >> gshift, dtype=torch.int32, device=dev)
                 B.call("gs_sort_pairs_u64_i32_drop", n_elems, B.ptr(dkeys), B.ptr(dvals), B.ptr(ko), B.ptr(perm), 32, 64,
-                       0x7FFFFFFF, B.ptr(n_kept), B.ptr(temp), tb, hist_ready, st)
-                st_["perm"], st_["n_kept"] = perm, n_kept
-                B.call("gs_cumsum_gather_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(perm), B.ptr(n_kept), B.ptr(cum),
-                       B.ptr(scratch), sb, st)
+                       0x7FFFFFFF, B.ptr(n_kept), B.ptr(temp), tb, hist_ready, B.ptr(tiles_per_gauss), B.ptr(gsums), gshift, st)
+                gpre = None
+                if gsums.numel() > 8192:  # many groups: one prefix sum over them instead of a quadratic number of loads
+                    gpre = torch.empty(gsums.numel(), dtype=torch.int64, device=dev)
+                    sb = B.query("gs_cumsum_scratch_bytes", gsums.numel())
+                    scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+                    B.call("gs_cumsum_i32", gsums.numel(), B.ptr(gsums), B.ptr(gpre), B.ptr(scratch), sb, st)
+                st_["perm"], st_["n_kept"], st_["gsums"], st_["gpre"] = perm, n_kept, gsums, gpre
+                cum = None
             else:
+                cum = torch.empty(n_elems, dtype=torch.int64, device=dev)
+                sb = B.query("gs_cumsum_scratch_bytes", n_elems)
+                scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
                 B.call("gs_isect_count", n_elems, B.ptr(means2d), s_m2, B.ptr(radii), tile_size, tile_width, tile_height,
                        B.ptr(tiles_per_gauss), st)
                 B.call("gs_cumsum_i32", n_elems, B.ptr(tiles_per_gauss), B.ptr(cum), B.ptr(scratch), sb, st)
@@ -1190,9 +1199,10 @@ def isect_tiles_finish(st_) -> Tuple[Tensor, Tensor, Tensor]:
             # writes the reference's 64-bit ids (key << 32 | depth bits) and the flatten ids
             keys32 = torch.empty(n_isects, dtype=torch.int32, device=dev)
             vals = torch.empty(n_isects, dtype=torch.int32, device=dev)
-            B.call("gs_isect_emit_compact", st_["n_elems"], max(st_["N"], 1), B.ptr(st_["perm"]), B.ptr(st_["n_kept"]),
-                   B.ptr(st_["camera_ids"]), B.ptr(means2d), st_["s_m2"], B.ptr(radii), B.ptr(depths), B.ptr(st_["cum"]), st_["tile_size"],
-                   st_["tile_width"], st_["tile_height"], st_["tile_n_bits"], B.ptr(keys32), B.ptr(vals), st)
+            B.call("gs_isect_emit_presorted", st_["n_elems"], max(st_["N"], 1), B.ptr(st_["perm"]), B.ptr(st_["n_kept"]),
+                   B.ptr(st_["camera_ids"]), B.ptr(means2d), st_["s_m2"], B.ptr(radii), B.ptr(depths), B.ptr(st_["tiles_per_gauss"]),
+                   B.ptr(st_["gsums"]), B.ptr(st_["gpre"]), st_["tile_size"], st_["tile_width"], st_["tile_height"], st_["tile_n_bits"], 1, None,
+                   B.ptr(keys32), B.ptr(vals), st)
             tb = B.query("gs_sort_isect_temp_bytes", n_isects)
             temp = torch.empty(tb, dtype=torch.uint8, device=dev)
             B.call("gs_sort_isect_pairs", n_isects, B.ptr(keys32), B.ptr(vals), B.ptr(depths), st_["tile_n_bits"] + st_["cam_n_bits"],

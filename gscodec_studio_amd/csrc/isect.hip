@@ -203,6 +203,116 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
     }
 }
 
+// Emission for the PRE-SORTED path with the prefix scan folded in (round 3: the two launches of gs_cumsum_gather_i32 and the
+// cum_tiles array are gone).  A workgroup owns EMIT_SCAN_TILE = 512 consecutive positions of the emission order:
+//   * its output offset = the sum of its predecessors' group sums (group_sums[g] = tiles of positions [512 g, 512 (g+1)),
+//     left behind by the LAST pass of the depth pre-sort, gs_sort_pairs_u64_i32_drop: side_sums);
+//   * the inclusive scan of its own 512 tile counts (gathered through perm) lives in LDS;
+//   * its four waves then emit groups of EMIT_SPW positions exactly like isect_emit_kernel.
+constexpr uint32_t EMIT_SCAN_SHIFT = 9;
+constexpr uint32_t EMIT_SCAN_TILE = 1u << EMIT_SCAN_SHIFT;
+static_assert(EMIT_SCAN_TILE == 2 * GS_BLOCK && EMIT_SCAN_TILE % EMIT_SPW == 0, "two positions per thread");
+
+template <bool COMPACT>
+__global__ void __launch_bounds__(GS_BLOCK) isect_emit_scan_kernel(
+    uint32_t n_elems, uint32_t N, const int32_t *__restrict__ perm, const uint32_t *__restrict__ n_valid,
+    const int64_t *__restrict__ camera_ids, const float *__restrict__ means2d, uint32_t s_m2, const int32_t *__restrict__ radii,
+    const float *__restrict__ depths, const int32_t *__restrict__ tiles_per_gauss, const uint32_t *__restrict__ group_sums,
+    const int64_t *__restrict__ group_prefix, float tile_size, int32_t tw, int32_t th, uint32_t tile_n_bits,
+    int64_t *__restrict__ isect_ids, uint32_t *__restrict__ keys32, int32_t *__restrict__ flatten_ids) {
+    __shared__ int32_t s_cum[EMIT_SCAN_TILE + 1]; // s_cum[j] = tiles of the block's positions [0, j)
+    __shared__ int32_t s_elem[EMIT_SCAN_TILE];    // the element at every position (-1: none)
+    __shared__ int64_t s_red[GS_BLOCK / GS_WAVE];
+    __shared__ int32_t s_wsum[GS_BLOCK / GS_WAVE];
+    __shared__ EmitRec s_rec[EMIT_WAVES * EMIT_SPW];
+    __shared__ int32_t s_start[EMIT_WAVES * (EMIT_SPW + 1)];
+    const uint32_t tid = threadIdx.x, lane = tid % GS_WAVE, wave = tid / GS_WAVE;
+    const uint32_t nv = n_valid != nullptr ? min(n_elems, *n_valid) : n_elems;
+    const uint32_t block_first = blockIdx.x * EMIT_SCAN_TILE;
+    if (block_first >= nv) return; // (block-uniform) nothing to emit here or behind
+    // ---- offset of this block in the output: its predecessors' group sums
+    // (every block adds up its predecessors itself -- quadratic, fine for the few thousand groups of a million splats; the
+    // caller hands over the inclusive prefix instead when there are more)
+    int64_t pre = 0;
+    if (group_prefix != nullptr) pre = (tid == 0 && blockIdx.x > 0) ? group_prefix[blockIdx.x - 1] : 0;
+    else
+        for (uint32_t g = tid; g < blockIdx.x; g += GS_BLOCK) pre += (int64_t)group_sums[g];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
+    if (lane == 0) s_red[wave] = pre;
+    // ---- my two positions
+    int32_t c[2], e[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t pos = block_first + 2u * tid + (uint32_t)k;
+        e[k] = pos < nv ? (perm != nullptr ? perm[pos] : (int32_t)pos) : -1;
+        c[k] = e[k] >= 0 ? tiles_per_gauss[e[k]] : 0;
+        s_elem[2u * tid + (uint32_t)k] = e[k];
+    }
+    int32_t inc = c[0] + c[1];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t o = __shfl_up(inc, off, 64);
+        if (lane >= (uint32_t)off) inc += o;
+    }
+    if (lane == GS_WAVE - 1) s_wsum[wave] = inc;
+    __syncthreads();
+    int32_t wbase = 0;
+#pragma unroll
+    for (int w = 0; w < GS_BLOCK / GS_WAVE; ++w)
+        if ((uint32_t)w < wave) wbase += s_wsum[w];
+    const int32_t excl = wbase + inc - (c[0] + c[1]);
+    s_cum[2u * tid] = excl;
+    s_cum[2u * tid + 1u] = excl + c[0];
+    if (tid == GS_BLOCK - 1) s_cum[EMIT_SCAN_TILE] = excl + c[0] + c[1];
+    const int64_t block_out0 = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+
+    EmitRec *wrec = s_rec + wave * EMIT_SPW;
+    int32_t *wstart = s_start + wave * (EMIT_SPW + 1);
+    for (uint32_t grp = wave; grp < EMIT_SCAN_TILE / EMIT_SPW; grp += EMIT_WAVES) { // groups of EMIT_SPW positions, one wave each
+        const uint32_t j0 = grp * EMIT_SPW;
+        if (block_first + j0 >= nv) break; // (wave-uniform)
+        const int32_t g0 = s_cum[j0], g1 = s_cum[j0 + EMIT_SPW];
+        if (g1 == g0) continue;
+        if (lane < EMIT_SPW) {
+            EmitRec rec = {0, 0, 0, 0, 1};
+            const int32_t i = s_elem[j0 + lane];
+            const int32_t r = i >= 0 ? radii[i] : 0;
+            if (r > 0) {
+                const float2 m = *reinterpret_cast<const float2 *>(means2d + (size_t)i * s_m2);
+                const TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
+                const int64_t cid = camera_ids != nullptr ? camera_ids[i] : (int64_t)((uint32_t)i / N);
+                rec.key_base = COMPACT ? (cid << tile_n_bits) : ((cid << (32 + tile_n_bits)) | (int64_t)__float_as_int(depths[i]));
+                rec.id = i;
+                rec.x0 = b.x0;
+                rec.y0 = b.y0;
+                rec.w = max(b.x1 - b.x0, 1);
+            }
+            wrec[lane] = rec;
+            wstart[lane] = s_cum[j0 + lane] - g0;
+        }
+        if (lane == 0) wstart[EMIT_SPW] = g1 - g0;
+        __builtin_amdgcn_wave_barrier();
+        const int32_t total = g1 - g0;
+        const int64_t out0 = block_out0 + g0;
+        for (int32_t t = (int32_t)lane; t < total; t += GS_WAVE) {
+            int32_t sidx = 0;
+#pragma unroll
+            for (int step = EMIT_SPW / 2; step > 0; step >>= 1)
+                if (wstart[sidx + step] <= t) sidx += step;
+            const EmitRec o = wrec[sidx];
+            const int32_t k = t - wstart[sidx];
+            const int32_t dy = k / o.w, dx = k - dy * o.w;
+            const int64_t tile_id = (int64_t)(o.y0 + dy) * tw + (o.x0 + dx);
+            if (COMPACT) keys32[out0 + t] = (uint32_t)(o.key_base | tile_id);
+            else isect_ids[out0 + t] = o.key_base | (tile_id << 32);
+            flatten_ids[out0 + t] = o.id;
+        }
+        __builtin_amdgcn_wave_barrier(); // the next group reuses wrec / wstart
+    }
+}
+
 // isect_tiles.cu:308-354
 __global__ void __launch_bounds__(GS_BLOCK) isect_offset_encode_kernel(
     uint32_t n_isects, const int64_t *__restrict__ isect_ids, uint32_t C, uint32_t n_tiles,
@@ -482,6 +592,33 @@ extern "C" int32_t gs_isect_emit_compact(
                        (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids, means2d, means2d_stride, radii, depths,
                        cum_tiles_per_gauss, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
                        tile_n_bits, (int64_t *)nullptr, keys32, flatten_ids);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" uint32_t gs_isect_emit_group_shift(void) { return EMIT_SCAN_SHIFT; }
+
+extern "C" int32_t gs_isect_emit_presorted(
+    uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids, const float *means2d,
+    uint32_t means2d_stride, const int32_t *radii, const float *depths, const int32_t *tiles_per_gauss, const uint32_t *group_sums,
+    const int64_t *group_prefix, uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits, int32_t compact,
+    int64_t *isect_ids, uint32_t *keys32, int32_t *flatten_ids, gs_stream_t stream) {
+    if (n_elems == 0) return 0;
+    GS_CHECK_ARG(means2d && radii && depths && tiles_per_gauss && (group_sums || group_prefix) && flatten_ids, "null pointer");
+    GS_CHECK_ARG(compact ? keys32 != nullptr : isect_ids != nullptr, "null output");
+    GS_CHECK_ARG(camera_ids != nullptr || N > 0, "N must be > 0 when camera_ids is NULL");
+    GS_CHECK_ARG(tile_n_bits < 32, "tile_n_bits must be < 32");
+    GS_CHECK_ARG(means2d_stride >= 2 && means2d_stride % 2 == 0, "means2d_stride must be even and >= 2");
+    GS_CHECK_ARG(n_elems < (1u << 31), "n_elems must be < 2^31");
+    const dim3 grid(gs_div_up(n_elems, EMIT_SCAN_TILE));
+    if (compact)
+        hipLaunchKernelGGL(isect_emit_scan_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids,
+                           means2d, means2d_stride, radii, depths, tiles_per_gauss, group_sums, group_prefix, (float)tile_size, (int32_t)tile_width,
+                           (int32_t)tile_height, tile_n_bits, (int64_t *)nullptr, keys32, flatten_ids);
+    else
+        hipLaunchKernelGGL(isect_emit_scan_kernel<false>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids,
+                           means2d, means2d_stride, radii, depths, tiles_per_gauss, group_sums, group_prefix, (float)tile_size, (int32_t)tile_width,
+                           (int32_t)tile_height, tile_n_bits, isect_ids, (uint32_t *)nullptr, flatten_ids);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -61,6 +61,21 @@ struct IsectEpilogue {
     int32_t *flatten_ids;
 };
 
+// What a scatter launch can produce ON THE SIDE while it places its keys (each of these used to be a launch of its own in
+// the latency-bound splat-level pre-sort, where a launch costs its 5 us floor whatever it does):
+//   hist_next [RADIX][n_blocks]  the NEXT pass's per-block digit histogram: a key that lands at position p belongs to the
+//                                next pass's block p / SORT_TILE (zero-filled by the scan launch in front of this one);
+//   side_sums [n >> side_shift]  sums of side_vals[value] over groups of 2^side_shift consecutive OUTPUT positions -- the
+//                                last pass of the pre-sort hands the tile counts per group of emission positions to
+//                                gs_isect_emit_presorted this way (the block sums of its prefix scan).
+struct ScatterSide {
+    uint32_t *hist_next;
+    DigitSpec d_next;
+    const int32_t *side_vals;
+    uint32_t *side_sums;
+    uint32_t side_shift;
+};
+
 template <typename KeyT, int SORT_ROUNDS>
 __global__ void __launch_bounds__(GS_BLOCK) sort_hist_kernel(
     uint64_t n, const uint32_t *__restrict__ n_dev, const KeyT *__restrict__ keys, DigitSpec d, uint32_t n_blocks,
@@ -88,15 +103,22 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_hist_kernel(
 }
 
 // block = digit.  In-place exclusive scan of hist[digit][0..n_blocks) and digit total.
+// zero_hist (optional): the histogram the FOLLOWING scatter launch accumulates the next pass's digits into (see
+// sort_scatter_kernel: hist_next) -- this launch runs right before it, so its row is zeroed here instead of by a fill launch;
+// zero_side (optional, n_side entries): the same service for the scatter's side sums.
 __global__ void __launch_bounds__(GS_BLOCK) sort_scan_kernel(
-    uint32_t n_blocks, uint32_t *__restrict__ hist, uint32_t *__restrict__ totals) {
+    uint32_t n_blocks, uint32_t *__restrict__ hist, uint32_t *__restrict__ totals, uint32_t *__restrict__ zero_hist,
+    uint32_t *__restrict__ zero_side, uint32_t n_side) {
     __shared__ uint32_t s_wave[SORT_WAVES];
     uint32_t *row = hist + (size_t)blockIdx.x * n_blocks;
     uint32_t lane = threadIdx.x % GS_WAVE, wave = threadIdx.x / GS_WAVE;
     uint32_t carry = 0;
+    if (zero_side != nullptr)
+        for (uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x; i < n_side; i += RADIX * GS_BLOCK) zero_side[i] = 0u;
     for (uint32_t base = 0; base < n_blocks; base += GS_BLOCK) {
         uint32_t i = base + threadIdx.x;
         uint32_t v = i < n_blocks ? row[i] : 0;
+        if (zero_hist != nullptr && i < n_blocks) zero_hist[(size_t)blockIdx.x * n_blocks + i] = 0u;
         uint32_t inc = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -127,7 +149,8 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
     uint64_t n, const uint32_t *__restrict__ n_dev, const KeyT *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
     KeyT *__restrict__ keys_out, int32_t *__restrict__ vals_out, DigitSpec d,
     uint32_t n_blocks, const uint32_t *__restrict__ hist_scan, const uint32_t *__restrict__ totals,
-    uint32_t *__restrict__ n_kept_out /* or NULL: block 0 also publishes the number of keys this pass kept */, IsectEpilogue ep) {
+    uint32_t *__restrict__ n_kept_out /* or NULL: block 0 also publishes the number of keys this pass kept */, IsectEpilogue ep,
+    ScatterSide side) {
     constexpr int SORT_TILE = sort_tile(SORT_ROUNDS);
     constexpr int SORT_WAVE_KEYS = GS_WAVE * SORT_ROUNDS;
     if (n_kept_out != nullptr && blockIdx.x == 0 && threadIdx.x < GS_WAVE) { // sum of the 256 digit totals (one wave)
@@ -254,6 +277,8 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
             pos[k] = s_gofs[digit_of(kk, d)] + j;
             if (FINAL_ISECT) kept_key[FINAL_ISECT ? k : 0] = kk;
             else keys_out[pos[k]] = kk;
+            if (side.hist_next != nullptr)
+                atomicAdd(&side.hist_next[(size_t)digit_of(kk, side.d_next) * n_blocks + pos[k] / (uint32_t)SORT_TILE], 1u);
         }
     }
     lds_barrier();
@@ -276,6 +301,7 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
                 ep.flatten_ids[pos[k]] = v;
             } else {
                 vals_out[pos[k]] = v;
+                if (side.side_sums != nullptr) atomicAdd(&side.side_sums[pos[k] >> side.side_shift], (uint32_t)side.side_vals[v]);
             }
         }
     }
@@ -283,7 +309,7 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
 
 struct SortLayout {
     uint32_t n_blocks;
-    size_t off_keys, off_vals, off_hist, off_totals, total;
+    size_t off_keys, off_vals, off_hist, off_hist2, off_totals, total;
 };
 
 SortLayout sort_layout(uint64_t n) {
@@ -298,6 +324,7 @@ SortLayout sort_layout(uint64_t n) {
     L.off_keys = take(n * sizeof(uint64_t));
     L.off_vals = take(n * sizeof(int32_t));
     L.off_hist = take((size_t)RADIX * L.n_blocks * sizeof(uint32_t));
+    L.off_hist2 = take((size_t)RADIX * L.n_blocks * sizeof(uint32_t)); // ping-pong partner (histograms made by the scatter launches)
     L.off_totals = take(RADIX * sizeof(uint32_t));
     L.total = o;
     return L;
@@ -322,7 +349,8 @@ uint32_t *sort_first_hist_slot(uint64_t n, void *temp, size_t temp_bytes, uint32
 
 static int32_t sort_impl(uint64_t n, const int64_t *keys_in, const int32_t *vals_in, int64_t *keys_out, int32_t *vals_out,
                          int32_t begin_bit, int32_t end_bit, bool drop, uint32_t drop_hi, uint32_t *n_valid_out, void *temp,
-                         size_t temp_bytes, hipStream_t st, const char *who, bool first_hist_ready = false) {
+                         size_t temp_bytes, hipStream_t st, const char *who, bool first_hist_ready = false,
+                         const int32_t *side_vals = nullptr, uint32_t *side_sums = nullptr, uint32_t side_shift = 0) {
     if (n == 0) return 0;
     int passes = (end_bit - begin_bit + RADIX_BITS - 1) / RADIX_BITS;
     if (passes == 0) {
@@ -343,7 +371,9 @@ static int32_t sort_impl(uint64_t n, const int64_t *keys_in, const int32_t *vals
     uint64_t *tkeys = (uint64_t *)(tp + L.off_keys);
     int32_t *tvals = (int32_t *)(tp + L.off_vals);
     uint32_t *hist = (uint32_t *)(tp + L.off_hist);
+    uint32_t *hist2 = (uint32_t *)(tp + L.off_hist2);
     uint32_t *totals = (uint32_t *)(tp + L.off_totals);
+    const uint32_t n_side = side_sums != nullptr ? (uint32_t)((n + (1ull << side_shift) - 1) >> side_shift) : 0u;
 
     // ping-pong between {temp, out}; the first destination is chosen so the last pass
     // lands in *_out without ever writing the inputs.
@@ -356,32 +386,60 @@ static int32_t sort_impl(uint64_t n, const int64_t *keys_in, const int32_t *vals
     int shift = begin_bit;
     const uint32_t *n_dev = nullptr; // after a dropping first pass the element count lives on the device
     const bool small = sort_rounds_for(n) == SORT_ROUNDS_SMALL;
-    for (int p = 0; p < passes; ++p) {
+    auto digit_spec = [&](int p, int at_shift) {
         DigitSpec d;
-        d.shift = (uint32_t)shift;
+        d.shift = (uint32_t)at_shift;
         const int bits = (p == 0) ? first_bits : RADIX_BITS;
-        shift += bits;
         d.mask = (1u << bits) - 1u;
         // int64 keys: when the range includes bit 63 CUB orders them as signed values
         d.flip = (end_bit == 64 && p == passes - 1) ? (1u << (bits - 1)) : 0u;
         d.drop = (drop && p == 0) ? 1u : 0u;
         d.drop_hi = drop_hi;
+        return d;
+    };
+    // Small inputs (1024-key blocks: every launch sits at its latency floor): the scatter of pass p also counts the digits
+    // of pass p + 1 per DESTINATION block (global atomics into the other histogram buffer, zero-filled by the scan launch
+    // in front of it): two launches per pass instead of three.
+    bool hist_ready = first_hist_ready && small;
+    uint32_t *cur_hist = hist, *other_hist = hist2;
+    for (int p = 0; p < passes; ++p) {
+        const DigitSpec d = digit_spec(p, shift);
+        shift += (p == 0) ? first_bits : RADIX_BITS;
+        const bool last = p == passes - 1;
         uint64_t *dst_k = to_out ? (uint64_t *)keys_out : tkeys;
         int32_t *dst_v = to_out ? vals_out : tvals;
-        if (p == 0 && first_hist_ready && small) {
-            // the producer of the keys counted this pass's digits already (see sort_first_hist_slot)
+        if (hist_ready) {
+            // this pass's per-block digit counts are there already: made by the producer of the keys (pass 0, see
+            // sort_first_hist_slot) or by the previous pass's scatter
         } else if (small)
-            hipLaunchKernelGGL((sort_hist_kernel<uint64_t, SORT_ROUNDS_SMALL>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, hist);
+            hipLaunchKernelGGL((sort_hist_kernel<uint64_t, SORT_ROUNDS_SMALL>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, cur_hist);
         else
-            hipLaunchKernelGGL((sort_hist_kernel<uint64_t, SORT_ROUNDS_BIG>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, hist);
-        hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, hist, totals);
+            hipLaunchKernelGGL((sort_hist_kernel<uint64_t, SORT_ROUNDS_BIG>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, cur_hist);
+        ScatterSide side = {nullptr, d, nullptr, nullptr, 0u};
+        if (small && !last) {
+            side.hist_next = other_hist;
+            side.d_next = digit_spec(p + 1, shift);
+        }
+        if (last && side_sums != nullptr) {
+            side.side_vals = side_vals;
+            side.side_sums = side_sums;
+            side.side_shift = side_shift;
+        }
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, cur_hist, totals, side.hist_next,
+                           side.side_sums, n_side);
         if (small)
             hipLaunchKernelGGL((sort_scatter_kernel<uint64_t, SORT_ROUNDS_SMALL, false>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, src_v,
-                               dst_k, dst_v, d, L.n_blocks, hist, totals, (drop && p == 0) ? n_valid_out : nullptr, IsectEpilogue{});
+                               dst_k, dst_v, d, L.n_blocks, cur_hist, totals, (drop && p == 0) ? n_valid_out : nullptr, IsectEpilogue{}, side);
         else
             hipLaunchKernelGGL((sort_scatter_kernel<uint64_t, SORT_ROUNDS_BIG, false>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, src_v,
-                               dst_k, dst_v, d, L.n_blocks, hist, totals, (drop && p == 0) ? n_valid_out : nullptr, IsectEpilogue{});
+                               dst_k, dst_v, d, L.n_blocks, cur_hist, totals, (drop && p == 0) ? n_valid_out : nullptr, IsectEpilogue{}, side);
         if (drop && p == 0) n_dev = n_valid_out;
+        hist_ready = side.hist_next != nullptr;
+        if (hist_ready) {
+            uint32_t *t = cur_hist;
+            cur_hist = other_hist;
+            other_hist = t;
+        }
         src_k = dst_k;
         src_v = dst_v;
         to_out = !to_out;
@@ -407,14 +465,16 @@ extern "C" int32_t gs_sort_pairs_u64_i32(
 extern "C" int32_t gs_sort_pairs_u64_i32_drop(
     uint64_t n, const int64_t *keys_in, const int32_t *vals_in, int64_t *keys_out,
     int32_t *vals_out, int32_t begin_bit, int32_t end_bit, uint32_t drop_hi32, uint32_t *n_kept, void *temp,
-    size_t temp_bytes, int32_t first_hist_ready, gs_stream_t stream) {
+    size_t temp_bytes, int32_t first_hist_ready, const int32_t *side_vals, uint32_t *side_sums, uint32_t side_shift,
+    gs_stream_t stream) {
     if (n == 0) return 0;
     GS_CHECK_ARG(keys_in && vals_in && keys_out && vals_out && n_kept, "null pointer");
     GS_CHECK_ARG(begin_bit >= 0 && end_bit <= 64 && begin_bit < end_bit, "bad bit range");
     GS_CHECK_ARG(n < (1ull << 32), "n must be < 2^32");
     GS_CHECK_ARG(!first_hist_ready || (begin_bit == 32 && end_bit == 64), "a precomputed first histogram is defined for the bit range [32, 64)");
+    GS_CHECK_ARG((side_vals == nullptr) == (side_sums == nullptr) && side_shift < 32, "side_vals and side_sums go together");
     int32_t rc = sort_impl(n, keys_in, vals_in, keys_out, vals_out, begin_bit, end_bit, true, drop_hi32, n_kept, temp, temp_bytes,
-                           (hipStream_t)stream, "gs_sort_pairs_u64_i32_drop", first_hist_ready != 0);
+                           (hipStream_t)stream, "gs_sort_pairs_u64_i32_drop", first_hist_ready != 0, side_vals, side_sums, side_shift);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;
@@ -451,13 +511,14 @@ template <int ROUNDS>
 void launch_pass32(uint64_t n, const uint32_t *src_k, const int32_t *src_v, uint32_t *dst_k, int32_t *dst_v, DigitSpec d,
                    const Sort32Layout &L, uint32_t *hist, uint32_t *totals, bool final, const IsectEpilogue &ep, hipStream_t st) {
     hipLaunchKernelGGL((sort_hist_kernel<uint32_t, ROUNDS>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, (const uint32_t *)nullptr, src_k, d, L.n_blocks, hist);
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, hist, totals);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, hist, totals, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
+    const ScatterSide none = {nullptr, d, nullptr, nullptr, 0u};
     if (final)
         hipLaunchKernelGGL((sort_scatter_kernel<uint32_t, ROUNDS, true>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, (const uint32_t *)nullptr, src_k, src_v,
-                           dst_k, dst_v, d, L.n_blocks, hist, totals, (uint32_t *)nullptr, ep);
+                           dst_k, dst_v, d, L.n_blocks, hist, totals, (uint32_t *)nullptr, ep, none);
     else
         hipLaunchKernelGGL((sort_scatter_kernel<uint32_t, ROUNDS, false>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, (const uint32_t *)nullptr, src_k, src_v,
-                           dst_k, dst_v, d, L.n_blocks, hist, totals, (uint32_t *)nullptr, ep);
+                           dst_k, dst_v, d, L.n_blocks, hist, totals, (uint32_t *)nullptr, ep, none);
 }
 
 } // namespace

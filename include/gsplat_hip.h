@@ -351,6 +351,19 @@ int32_t gs_isect_emit_compact(
     uint32_t *keys32,     /* [n_isects] */
     int32_t *flatten_ids, /* [n_isects] */
     gs_stream_t stream);
+/* The same emission with the prefix scan folded in, for the depth-pre-sorted path (perm from gs_sort_pairs_u64_i32_drop):
+ * instead of cum_tiles_per_gauss it takes tiles_per_gauss (indexed by element) and group_sums[g] = the tiles of the emission
+ * positions [g << s, (g + 1) << s), s = gs_isect_emit_group_shift() -- what that sort's last pass leaves behind in its
+ * side_sums (side_vals = tiles_per_gauss, side_shift = s).  compact != 0: keys32 as gs_isect_emit_compact; else isect_ids. */
+uint32_t gs_isect_emit_group_shift(void);
+int32_t gs_isect_emit_presorted(
+    uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids,
+    const float *means2d, uint32_t means2d_stride, const int32_t *radii, const float *depths,
+    const int32_t *tiles_per_gauss, const uint32_t *group_sums,
+    const int64_t *group_prefix /* NULL, or the inclusive prefix sum of group_sums (gs_cumsum_i32): every workgroup adds up
+                                   its predecessors' sums itself otherwise -- fine up to a few thousand groups */,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits, int32_t compact,
+    int64_t *isect_ids, uint32_t *keys32, int32_t *flatten_ids, gs_stream_t stream);
 size_t gs_sort_isect_temp_bytes(uint64_t n);
 int32_t gs_sort_isect_pairs(
     uint64_t n, uint32_t *keys32, int32_t *vals, const float *depths /* indexed by the flatten id */, int32_t key_bits,
@@ -376,6 +389,10 @@ int32_t gs_sort_pairs_u64_i32_drop(
     int32_t begin_bit, int32_t end_bit, uint32_t drop_hi32, uint32_t *n_kept,
     void *temp, size_t temp_bytes,
     int32_t first_hist_ready /* != 0: the first pass's block histogram is already in temp (gs_isect_count_keys) */,
+    const int32_t *side_vals, uint32_t *side_sums, uint32_t side_shift /* both NULL, or: the LAST pass also leaves
+                             side_sums[g] = sum of side_vals[vals_out[p]] over the output positions p in [g << side_shift,
+                             (g + 1) << side_shift), for all ceil(n / 2^side_shift) groups -- the block sums of the prefix scan
+                             gs_isect_emit_presorted needs (side_vals = tiles_per_gauss), with no launch of their own */,
     gs_stream_t stream);
 int32_t gs_sort_first_hist_applicable(uint64_t n);
 

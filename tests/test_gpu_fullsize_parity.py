@@ -102,8 +102,20 @@ def _run_case(w, sh_degree, expect_V, expect_I_oracle):
         d_rc, d_ra, d_li, bl64 = O.rasterize_fwd(d_m2, d_cn, d_cols, d_opac, W, H, 16, o_offs, o_flat, return_borderline=True)
     ok = ok32 & (bl64 == 0)
     assert ok.mean() > 0.99, ok.mean()
-    assert np.array_equal(o_li[ok], d_li[ok])
+    # the float64 chain projects in float64 too: its means2d / conics differ from the fp32 ones in the 7th digit, so a few
+    # more threshold decisions flip than either build flags on its OWN values; those pixels are excluded as well
+    same = o_li == d_li
+    assert same[ok].mean() > 0.9995, same[ok].mean()
+    ok &= same
     assert_close(N(rc)[ok], d_rc[ok], 1e-4, 1e-5, "render vs f64", max_bad_frac=2e-5)
+    # the GPU's own exp (v_exp_f32) flips a handful of threshold decisions that neither oracle build flags (the 2e-5 of the
+    # pixels the line above tolerates): a flipped decision changes which splats a pixel feeds gradient to, so those pixels
+    # get no upstream gradient either
+    agree = (np.abs(N(rc).astype(np.float64) - d_rc) <= 1e-4 * np.abs(d_rc) + 1e-5).all(-1)
+    assert (ok & ~agree).mean() <= 2e-5, (ok & ~agree).mean()
+    print(f"[full size] pixels without upstream gradient: {(~ok).sum()} flagged borderline / oracle builds differ, "
+          f"{(ok & ~agree).sum()} more where the GPU's decision differs")
+    ok &= agree
 
     rs = np.random.RandomState(11)
     v_rc = (rs.randn(*d_rc.shape) * ok[..., None]).astype(np.float32)
@@ -122,11 +134,14 @@ def _run_case(w, sh_degree, expect_V, expect_I_oracle):
             g_colors = v_coeffs.sum(0)
             g_means = g_means + v_dirs.sum(0)
     expect = dict(means=g_means, quats=g_quats, scales=g_scales, opacities=v_op.sum(0), colors=g_colors)
+    errs = {}
     for k, ref in expect.items():
         got = N(P[k].grad)
-        e = rel_l2(got, ref)
-        print(f"[full size] d/d {k:10s} rel L2 vs float64 oracle: {e:.2e}")
-        assert got.shape == ref.shape and e <= 1e-4, (k, e)
+        assert got.shape == ref.shape, k
+        errs[k] = rel_l2(got, ref)
+        print(f"[full size] d/d {k:10s} rel L2 vs float64 oracle: {errs[k]:.2e}")
+    for k, e in errs.items():
+        assert e <= 1e-4, (k, e)
     return V, I
 
 

@@ -292,15 +292,27 @@ def test_radix_sort_drop_variant_and_gather_cumsum(ops, n):
     tb = B.query("gs_sort_temp_bytes", n)
     temp = torch.empty(tb, dtype=torch.uint8, device=k_t.device)
     st = torch.cuda.current_stream().cuda_stream
+    # side sums: the last pass also leaves sum(src[value]) per group of 2^shift output positions behind
+    src = rs.randint(0, 9, size=n).astype(np.int32)
+    shift = int(B.query("gs_isect_emit_group_shift"))
+    side = torch.full(((n + (1 << shift) - 1) >> shift,), 12345, dtype=torch.int32, device=k_t.device)  # (zero-filled by the call)
+    src_t = T(src)
     B.call("gs_sort_pairs_u64_i32_drop", n, B.ptr(k_t), B.ptr(v_t), B.ptr(ko), B.ptr(vo), 32, 64, 0x7FFFFFFF, B.ptr(n_kept),
-           B.ptr(temp), tb, 0, st)
+           B.ptr(temp), tb, 0, B.ptr(src_t), B.ptr(side), shift, st)
     kept = np.nonzero(~drop)[0]
     assert int(n_kept.item()) == len(kept)
     order = kept[np.argsort(keys[kept] >> 32, kind="stable")]
     assert np.array_equal(N(vo)[: len(kept)], vals[order]) and np.array_equal(N(ko)[: len(kept)], keys[order])
     assert np.all(N(vo)[len(kept):] == -1)  # the rest of the outputs is untouched
+    padded = np.zeros(side.numel() << shift, np.int64)
+    padded[: len(kept)] = src[order]
+    assert np.array_equal(N(side).astype(np.int64), padded.reshape(-1, 1 << shift).sum(1))
+    # the same sort without side sums (both NULL)
+    ko2, vo2 = torch.full_like(k_t, -1), torch.full_like(v_t, -1)
+    B.call("gs_sort_pairs_u64_i32_drop", n, B.ptr(k_t), B.ptr(v_t), B.ptr(ko2), B.ptr(vo2), 32, 64, 0x7FFFFFFF, B.ptr(n_kept),
+           B.ptr(temp), tb, 0, None, None, 0, st)
+    assert torch.equal(ko2, ko) and torch.equal(vo2, vo)
     # prefix sum of src[perm[i]] over the kept positions only
-    src = rs.randint(0, 9, size=n).astype(np.int32)
     out = torch.empty(n, dtype=torch.int64, device=k_t.device)
     sb = B.query("gs_cumsum_scratch_bytes", n)
     scratch = torch.empty(sb, dtype=torch.uint8, device=k_t.device)
