@@ -209,9 +209,11 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
 //     left behind by the LAST pass of the depth pre-sort, gs_sort_pairs_u64_i32_drop: side_sums);
 //   * the inclusive scan of its own 512 tile counts (gathered through perm) lives in LDS;
 //   * its four waves then emit groups of EMIT_SPW positions exactly like isect_emit_kernel.
-constexpr uint32_t EMIT_SCAN_SHIFT = 9;
+constexpr uint32_t EMIT_SCAN_SHIFT = 7; // 128 positions per workgroup: two groups of EMIT_SPW per wave (512: 58 us for 572
+                                        // workgroups of eight sequential groups per wave -- too few waves in flight; the
+                                        // one-group-per-wave kernel above needed 19 us + 15 us of prefix-sum launches)
 constexpr uint32_t EMIT_SCAN_TILE = 1u << EMIT_SCAN_SHIFT;
-static_assert(EMIT_SCAN_TILE == 2 * GS_BLOCK && EMIT_SCAN_TILE % EMIT_SPW == 0, "two positions per thread");
+static_assert(EMIT_SCAN_TILE <= GS_BLOCK && EMIT_SCAN_TILE % EMIT_SPW == 0, "one position per thread");
 
 template <bool COMPACT>
 __global__ void __launch_bounds__(GS_BLOCK) isect_emit_scan_kernel(
@@ -240,16 +242,15 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_scan_kernel(
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
     if (lane == 0) s_red[wave] = pre;
-    // ---- my two positions
-    int32_t c[2], e[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const uint32_t pos = block_first + 2u * tid + (uint32_t)k;
-        e[k] = pos < nv ? (perm != nullptr ? perm[pos] : (int32_t)pos) : -1;
-        c[k] = e[k] >= 0 ? tiles_per_gauss[e[k]] : 0;
-        s_elem[2u * tid + (uint32_t)k] = e[k];
+    // ---- my position (threads beyond the tile only help with the offset above)
+    int32_t c = 0, e = -1;
+    if (tid < EMIT_SCAN_TILE) {
+        const uint32_t pos = block_first + tid;
+        e = pos < nv ? (perm != nullptr ? perm[pos] : (int32_t)pos) : -1;
+        c = e >= 0 ? tiles_per_gauss[e] : 0;
+        s_elem[tid] = e;
     }
-    int32_t inc = c[0] + c[1];
+    int32_t inc = c;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const int32_t o = __shfl_up(inc, off, 64);
@@ -261,10 +262,8 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_scan_kernel(
 #pragma unroll
     for (int w = 0; w < GS_BLOCK / GS_WAVE; ++w)
         if ((uint32_t)w < wave) wbase += s_wsum[w];
-    const int32_t excl = wbase + inc - (c[0] + c[1]);
-    s_cum[2u * tid] = excl;
-    s_cum[2u * tid + 1u] = excl + c[0];
-    if (tid == GS_BLOCK - 1) s_cum[EMIT_SCAN_TILE] = excl + c[0] + c[1];
+    if (tid < EMIT_SCAN_TILE) s_cum[tid] = wbase + inc - c;
+    if (tid == EMIT_SCAN_TILE - 1) s_cum[EMIT_SCAN_TILE] = wbase + inc;
     const int64_t block_out0 = s_red[0] + s_red[1] + s_red[2] + s_red[3];
     __syncthreads();
 

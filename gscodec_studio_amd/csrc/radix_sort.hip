@@ -277,8 +277,21 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
             pos[k] = s_gofs[digit_of(kk, d)] + j;
             if (FINAL_ISECT) kept_key[FINAL_ISECT ? k : 0] = kk;
             else keys_out[pos[k]] = kk;
-            if (side.hist_next != nullptr)
-                atomicAdd(&side.hist_next[(size_t)digit_of(kk, side.d_next) * n_blocks + pos[k] / (uint32_t)SORT_TILE], 1u);
+        }
+        // the next pass's histogram.  One atomic per key would pile hundreds of them on one counter whenever the next
+        // digit is concentrated (the upper bytes of depth bits: 293 K atomics on ~600 counters took 0.5 ms), so the lanes
+        // first merge RUNS: consecutive lanes hold consecutive positions of the block's sorted order, i.e. the same
+        // destination block and, for a concentrated digit, the same counter -- the head of a run adds its length.
+        if (side.hist_next != nullptr) { // (block-uniform)
+            const bool on = j < block_count;
+            uint32_t code = 0xffffffffu;
+            if (on) code = (digit_of(s_keys[j], side.d_next) << 22) | (pos[k] / (uint32_t)SORT_TILE);
+            const uint32_t prev = __shfl_up(code, 1, 64);
+            const bool head = lane == 0u || code != prev;
+            const unsigned long long hm = __ballot(head);
+            const unsigned long long above = lane == 63u ? 0ull : (hm >> (lane + 1u));
+            const uint32_t run = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
+            if (head && on) atomicAdd(&side.hist_next[(size_t)(code >> 22) * n_blocks + (code & 0x3fffffu)], run);
         }
     }
     lds_barrier();
@@ -301,8 +314,27 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
                 ep.flatten_ids[pos[k]] = v;
             } else {
                 vals_out[pos[k]] = v;
-                if (side.side_sums != nullptr) atomicAdd(&side.side_sums[pos[k] >> side.side_shift], (uint32_t)side.side_vals[v]);
             }
+        }
+        // side sums: consecutive lanes hold consecutive output positions inside a digit run, i.e. mostly the same group:
+        // segmented wave sums, one atomic per (wave, run of equal groups) instead of one per key on a shared counter
+        if (!FINAL_ISECT && side.side_sums != nullptr) { // (block-uniform)
+            const bool on = j < block_count;
+            const uint32_t grp = on ? (pos[k] >> side.side_shift) : 0xffffffffu;
+            uint32_t inc = on ? (uint32_t)side.side_vals[s_vals[j]] : 0u;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off, 64);
+                if (lane >= (uint32_t)off) inc += o;
+            }
+            const uint32_t prevg = __shfl_up(grp, 1, 64);
+            const bool head = lane == 0u || grp != prevg;
+            const unsigned long long hm = __ballot(head);
+            const unsigned long long above = lane == 63u ? 0ull : (hm >> (lane + 1u));
+            const uint32_t last = above ? lane + (uint32_t)__builtin_ctzll(above) : 63u; // last lane of my run
+            const uint32_t upto = __shfl(inc, (int)last, 64);
+            const uint32_t before = __shfl_up(inc, 1, 64);
+            if (head && on) atomicAdd(&side.side_sums[grp], upto - (lane == 0u ? 0u : before));
         }
     }
 }
