@@ -143,7 +143,7 @@ def algorithmic_bytes(stats):
     N, V, I, P, T, K = (stats[k] for k in ("N", "V", "I", "P", "T", "K"))
     return {
         "gs_projection_fwd": 40 * N + 4 * N + 24 * V,
-        "gs_projection_rows_fwd": 40 * N + 4 * N + 24 * V,
+        "gs_projection_rows_fwd": 40 * N + 4 * N + 24 * V + ((12 + 12 * K) * V + 12 * V if K > 0 else 0),  # (+ the SH colours)
         "gs_projection_rows_bwd": 92 * V + 40 * N + 4 * N,
         "gs_sh_fwd": (12 + 12 * K) * V + 12 * V,
         "gs_sh_view_fwd": (12 + 12 * K) * V + 12 * V + 4 * N,

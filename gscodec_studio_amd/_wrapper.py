@@ -775,12 +775,15 @@ def project_rows(
     radius_clip: float = 0.0,
     antialiased: bool = False,
     camera_model: Literal["pinhole", "ortho", "fisheye"] = "pinhole",
-    _means_alias: bool = False,
+    sh_coeffs: Optional[Tensor] = None,  # [N, K, 3] SH coefficients shared by all cameras (instead of ``colors``)
+    sh_degree: Optional[int] = None,
 ):
     """``fully_fused_projection`` in ROW form, what ``rasterization`` uses for unpacked batches: the same projection, but
     every (camera, gaussian) pair gets one 64-byte splat row (include/gsplat_hip.h) that the compositing kernels fetch
     whole.  Folded in: the per-view opacities (``opacities.repeat(C, 1)``, times the antialias compensation) and,
-    when given, the per-view colours (``colors.expand(C, -1, -1)``) of reference rendering.py:327-335, 386.
+    when given, the per-view colours (``colors.expand(C, -1, -1)``) of reference rendering.py:327-335, 386 -- or, from
+    ``sh_coeffs``, the SH colours ``clamp_min(spherical_harmonics(sh_degree, means - campos, sh_coeffs, radii > 0) + 0.5, 0)``
+    of rendering.py:368-392, evaluated in the same pass (bit-identical to ``spherical_harmonics_view``).
 
     Returns ``(radii [C,N] i32, means2d [C,N,2], depths [C,N], conics [C,N,3], opacities [C,N], colors [C,N,3] | None,
     rows [C,N,16])``: means2d / conics / opacities / colors are COLUMN VIEWS of ``rows`` (only defined where radii > 0,
@@ -800,10 +803,15 @@ def project_rows(
     if colors is not None:
         assert colors.size() == (N, 3), colors.size()
         colors = colors.contiguous()
+    if sh_coeffs is not None:
+        assert colors is None and sh_degree is not None, "sh_coeffs come with sh_degree and without colors"
+        assert sh_coeffs.dim() == 3 and sh_coeffs.shape[0] == N and sh_coeffs.shape[2] == 3, sh_coeffs.shape
+        assert (sh_degree + 1) ** 2 <= sh_coeffs.shape[1], sh_coeffs.shape
+        sh_coeffs = sh_coeffs.contiguous()
     assert camera_model in _CAMERA_MODELS, camera_model
     return _ProjectRows.apply(means.contiguous(), covars, quats, scales, viewmats.contiguous(), Ks.contiguous(),
-                              opacities.contiguous(), colors, width, height, eps2d, near_plane, far_plane, radius_clip,
-                              antialiased, camera_model, _means_alias)
+                              opacities.contiguous(), colors, sh_coeffs, width, height, eps2d, near_plane, far_plane, radius_clip,
+                              antialiased, camera_model, sh_degree)
 
 
 def _grad_rows_of(parts, shape, device):
@@ -853,12 +861,11 @@ def _grad_rows_of(parts, shape, device):
 
 class _ProjectRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, width, height, eps2d, near_plane,
-                far_plane, radius_clip, antialiased, camera_model="pinhole", means_alias=False):
+    def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, width, height, eps2d, near_plane,
+                far_plane, radius_clip, antialiased, camera_model="pinhole", sh_degree=None):
         _require_gpu(means, "project_rows")
-        means_in = means
         means, covars, quats, scales = _f32c(means), _f32c(covars), _f32c(quats), _f32c(scales)
-        viewmats, Ks, opacities, colors = _f32c(viewmats), _f32c(Ks), _f32c(opacities), _f32c(colors)
+        viewmats, Ks, opacities, colors, sh_coeffs = _f32c(viewmats), _f32c(Ks), _f32c(opacities), _f32c(colors), _f32c(sh_coeffs)
         C, N = viewmats.shape[0], means.shape[0]
         dev = means.device
         radii = torch.empty((C, N), dtype=torch.int32, device=dev)
@@ -869,28 +876,41 @@ class _ProjectRows(torch.autograd.Function):
             B.call("gs_projection_rows_fwd", C, N, B.ptr(means), B.ptr(covars), B.ptr(quats), B.ptr(scales),
                    B.ptr(viewmats), B.ptr(Ks), int(width), int(height), float(eps2d), float(near_plane),
                    float(far_plane), float(radius_clip), cm, B.ptr(opacities), B.ptr(colors), int(bool(antialiased)),
+                   B.ptr(sh_coeffs), sh_coeffs.shape[1] if sh_coeffs is not None else 0, int(sh_degree or 0),
                    B.ptr(radii), B.ptr(depths), B.ptr(rows), _stream(means))
-        ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, opacities, radii, rows)
+        ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, opacities, radii, rows, sh_coeffs)
         ctx.width, ctx.height, ctx.eps2d, ctx.cm, ctx.antialiased = width, height, eps2d, cm, bool(antialiased)
-        ctx.has_colors = colors is not None
+        ctx.has_colors, ctx.sh_degree = colors is not None, (int(sh_degree) if sh_coeffs is not None else None)
         ctx.mark_non_differentiable(radii, rows)
         ctx.set_materialize_grads(False)  # unused outputs (depths in RGB mode, ...) arrive as None, not as zero tensors
-        outs = (radii, rows[..., ROW_MEAN2D:ROW_MEAN2D + 2], depths, rows[..., ROW_CONIC:ROW_CONIC + 3], rows[..., ROW_OPACITY],
-                rows[..., ROW_COLOR:ROW_COLOR + 3] if colors is not None else None, rows)
-        # (means handed through: see _FullyFusedProjection)
-        return outs + (means_in,) if means_alias else outs
+        has_col = colors is not None or sh_coeffs is not None
+        return (radii, rows[..., ROW_MEAN2D:ROW_MEAN2D + 2], depths, rows[..., ROW_CONIC:ROW_CONIC + 3], rows[..., ROW_OPACITY],
+                rows[..., ROW_COLOR:ROW_COLOR + 3] if has_col else None, rows)
 
     @staticmethod
-    def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_opac_cn, v_colors_cn, v_rows, v_means_add=None):
-        means, covars, quats, scales, viewmats, Ks, opacities, radii, rows = ctx.saved_tensors
+    def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_opac_cn, v_colors_cn, v_rows):
+        means, covars, quats, scales, viewmats, Ks, opacities, radii, rows, sh_coeffs = ctx.saved_tensors
         C, N = viewmats.shape[0], means.shape[0]
         dev = means.device
         parts = [(v_means2d, ROW_MEAN2D, 2), (v_conics, ROW_CONIC, 3), (v_opac_cn, ROW_OPACITY, 1)]
-        if ctx.has_colors:
+        if ctx.has_colors or sh_coeffs is not None:
             parts.append((v_colors_cn, ROW_COLOR, 3))
         g_ptr, g_keep = _grad_rows_of(parts, (C, N), dev)
-        v_depths = _f32c(v_depths) if v_depths is not None else None
         need = ctx.needs_input_grad
+        v_sh = v_means_add = None
+        if sh_coeffs is not None:
+            # the colour columns of the gradient rows go back through the SH evaluation first (clamp gate from the colours
+            # in the rows); its d/d means (view directions) is added by the projection kernel below while it writes v_means
+            K = sh_coeffs.shape[1]
+            v_sh = torch.empty_like(sh_coeffs)
+            v_means_add = torch.empty_like(means) if need[0] else None
+            with _device_of(means):
+                B.call("gs_sh_view_bwd", C, N, K, ctx.sh_degree, B.ptr(means), B.ptr(viewmats), 1, B.ptr(sh_coeffs), B.ptr(radii),
+                       rows.data_ptr() + 4 * ROW_COLOR, ROW, g_ptr + 4 * ROW_COLOR, ROW, B.ptr(v_sh), B.ptr(v_means_add),
+                       None, 0, None, _stream(means))
+            if not need[8]:
+                v_sh = None
+        v_depths = _f32c(v_depths) if v_depths is not None else None
         # rows are fully written by the kernel -> empty, not zeros
         v_means = torch.empty_like(means) if need[0] else None
         v_covars = torch.empty_like(covars) if (covars is not None and need[1]) else None
@@ -904,10 +924,9 @@ class _ProjectRows(torch.autograd.Function):
                    B.ptr(viewmats), B.ptr(Ks), int(ctx.width), int(ctx.height), float(ctx.eps2d), ctx.cm,
                    B.ptr(radii), B.ptr(rows), g_ptr, B.ptr(v_depths), B.ptr(opacities), int(ctx.antialiased),
                    B.ptr(v_means), B.ptr(v_covars), B.ptr(v_quats), B.ptr(v_scales), B.ptr(v_viewmats), B.ptr(v_opac),
-                   B.ptr(v_colors),
-                   B.ptr(_f32c(v_means_add)) if (v_means_add is not None and v_means is not None) else None, _stream(means))
+                   B.ptr(v_colors), B.ptr(v_means_add) if v_means is not None else None, _stream(means))
         del g_keep
-        return (v_means, v_covars, v_quats, v_scales, v_viewmats, None, v_opac, v_colors) + (None,) * 9
+        return (v_means, v_covars, v_quats, v_scales, v_viewmats, None, v_opac, v_colors, v_sh) + (None,) * 9
 
 
 class _FullyFusedProjectionPacked(torch.autograd.Function):

@@ -15,6 +15,7 @@
 //   * All maths are written on symmetric 2x2 / 3x3 forms (6 / 3 scalars), row-major.
 #include "gs_common.h"
 #include "proj_models.h"
+#include "sh_eval.h"
 
 namespace {
 
@@ -124,6 +125,12 @@ struct RowExtras {
     const float *opacities; // [N] or NULL
     const float *colors;    // [N,3] post-activation colours or NULL
     int antialiased;        // opacity column = opacity * compensation
+    // SH colours evaluated in the same pass (what gs_sh_view_fwd would write into the rows afterwards): the visible splat's
+    // coefficient row is read here, the whole 48 bytes of the row leave in three full 16-byte stores, and the colour launch
+    // with its second pass over means / radii disappears
+    const float *sh_coeffs; // [N,K,3] or NULL
+    uint32_t sh_K, sh_degree;
+    int sh_vec;             // coefficient rows are 16-byte aligned (dwordx4 loads)
 };
 
 template <bool ROWS>
@@ -152,10 +159,34 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_fwd_kernel(
         float op = rx.opacities != nullptr ? rx.opacities[n] : 0.f;
         if (rx.antialiased) op *= s.comp;
         reinterpret_cast<float4 *>(row)[0] = make_float4(s.mx, s.my, s.ca, s.cb);
-        if (rx.colors != nullptr) {
-            const float *cp = rx.colors + 3 * (size_t)n;
-            reinterpret_cast<float4 *>(row)[1] = make_float4(s.cc, op, cp[0], cp[1]);
-            reinterpret_cast<float4 *>(row)[2] = make_float4(cp[2], s.depth, __int_as_float(s.radius), s.comp);
+        if (rx.colors != nullptr || rx.sh_coeffs != nullptr) {
+            float c0, c1, c2;
+            if (rx.sh_coeffs != nullptr) {
+                // view direction = mean - camera centre (the centre from the view matrix, wave-uniform), colour =
+                // clamp_min(SH + 0.5, 0): gsplat/rendering.py:368-392 of the reference
+                float cx, cy, cz;
+                camera_center(viewmats + 16 * c, cx, cy, cz);
+                const float *p = means + 3 * (size_t)n;
+                const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
+                const float *crow = rx.sh_coeffs + (size_t)n * rx.sh_K * 3;
+                switch ((rx.sh_degree << 1) | (rx.sh_vec ? 1u : 0u)) { // (block-uniform)
+                    case 0: sh_view_color<0, false>(dx, dy, dz, crow, true, c0, c1, c2); break;
+                    case 1: sh_view_color<0, true>(dx, dy, dz, crow, true, c0, c1, c2); break;
+                    case 2: sh_view_color<1, false>(dx, dy, dz, crow, true, c0, c1, c2); break;
+                    case 3: sh_view_color<1, true>(dx, dy, dz, crow, true, c0, c1, c2); break;
+                    case 4: sh_view_color<2, false>(dx, dy, dz, crow, true, c0, c1, c2); break;
+                    case 5: sh_view_color<2, true>(dx, dy, dz, crow, true, c0, c1, c2); break;
+                    case 6: sh_view_color<3, false>(dx, dy, dz, crow, true, c0, c1, c2); break;
+                    case 7: sh_view_color<3, true>(dx, dy, dz, crow, true, c0, c1, c2); break;
+                    case 8: sh_view_color<4, false>(dx, dy, dz, crow, true, c0, c1, c2); break;
+                    default: sh_view_color<4, true>(dx, dy, dz, crow, true, c0, c1, c2); break;
+                }
+            } else {
+                const float *cp = rx.colors + 3 * (size_t)n;
+                c0 = cp[0]; c1 = cp[1]; c2 = cp[2];
+            }
+            reinterpret_cast<float4 *>(row)[1] = make_float4(s.cc, op, c0, c1);
+            reinterpret_cast<float4 *>(row)[2] = make_float4(c2, s.depth, __int_as_float(s.radius), s.comp);
         } else { // the colour columns belong to the SH kernel (gs_sh_view_fwd writes them into the same rows)
             reinterpret_cast<float2 *>(row)[2] = make_float2(s.cc, op);
             row[GS_ROW_DEPTH] = s.depth;
@@ -635,7 +666,7 @@ extern "C" int32_t gs_projection_fwd(
                  "exactly one of covars / (quats, scales) must be given");
     GS_CHECK_ARG(camera_model >= 0 && camera_model <= 2, "bad camera_model");
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
-    const RowExtras none = {nullptr, nullptr, 0};
+    const RowExtras none = {nullptr, nullptr, 0, nullptr, 0u, 0u, 0};
     hipLaunchKernelGGL(projection_fwd_kernel<false>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means,
                        covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d, near_plane,
                        far_plane, radius_clip, camera_model, radii, means2d, depths, conics, compensations, none);
@@ -647,8 +678,8 @@ extern "C" int32_t gs_projection_rows_fwd(
     uint32_t C, uint32_t N, const float *means, const float *covars, const float *quats,
     const float *scales, const float *viewmats, const float *Ks, int32_t image_width,
     int32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
-    int32_t camera_model, const float *opacities, const float *colors, int32_t antialiased, int32_t *radii, float *depths,
-    float *rows, gs_stream_t stream) {
+    int32_t camera_model, const float *opacities, const float *colors, int32_t antialiased, const float *sh_coeffs, uint32_t sh_K,
+    uint32_t sh_degree, int32_t *radii, float *depths, float *rows, gs_stream_t stream) {
     if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && viewmats && Ks && radii && depths && rows, "null pointer");
     GS_CHECK_ARG((uintptr_t)rows % 64 == 0, "the row buffer must be 64-byte aligned");
@@ -656,8 +687,11 @@ extern "C" int32_t gs_projection_rows_fwd(
                  "exactly one of covars / (quats, scales) must be given");
     GS_CHECK_ARG(camera_model >= 0 && camera_model <= 2, "bad camera_model");
     GS_CHECK_ARG(!antialiased || opacities != nullptr, "antialiased needs the opacities");
+    GS_CHECK_ARG(sh_coeffs == nullptr || colors == nullptr, "colors and sh_coeffs exclude each other");
+    GS_CHECK_ARG(sh_coeffs == nullptr || (sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= sh_K), "bad SH degree / K");
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
-    const RowExtras rx = {opacities, colors, antialiased};
+    const int sh_vec = sh_coeffs != nullptr && ((uintptr_t)sh_coeffs % 16 == 0) && ((sh_K * 3u) % 4u == 0);
+    const RowExtras rx = {opacities, colors, antialiased, sh_coeffs, sh_K, sh_degree, sh_vec};
     hipLaunchKernelGGL(projection_fwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means,
                        covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d, near_plane,
                        far_plane, radius_clip, camera_model, radii, rows, depths, (float *)nullptr, (float *)nullptr, rx);

@@ -61,16 +61,16 @@ struct IsectEpilogue {
     int32_t *flatten_ids;
 };
 
-// What a scatter launch can produce ON THE SIDE while it places its keys (each of these used to be a launch of its own in
-// the latency-bound splat-level pre-sort, where a launch costs its 5 us floor whatever it does):
-//   hist_next [RADIX][n_blocks]  the NEXT pass's per-block digit histogram: a key that lands at position p belongs to the
-//                                next pass's block p / SORT_TILE (zero-filled by the scan launch in front of this one);
+// What a scatter launch produces ON THE SIDE while it places its keys:
 //   side_sums [n >> side_shift]  sums of side_vals[value] over groups of 2^side_shift consecutive OUTPUT positions -- the
-//                                last pass of the pre-sort hands the tile counts per group of emission positions to
-//                                gs_isect_emit_presorted this way (the block sums of its prefix scan).
+//                                last pass of the splat-level pre-sort hands the tile counts per group of emission positions
+//                                to gs_isect_emit_presorted this way (the block sums of its prefix scan: the two cumsum
+//                                launches and the cum_tiles array are gone, 34 -> 25 us for count + emit).
+// (Round 3 also had the scatter count the NEXT pass's digits per destination block, to drop the histogram launch of every
+// pass: global atomics, merged over runs of equal counters inside a wave.  Measured: the four scatter launches went from
+// 10.5 / 8.9 / 8.1 / 7.5 us to 25.0 / 23.9 / 47.8 / 10.6 us -- 293 K device-scope atomics cost more than a 6 us launch even
+// without contention, and the concentrated upper digits serialise on a few hundred counters.  Removed.)
 struct ScatterSide {
-    uint32_t *hist_next;
-    DigitSpec d_next;
     const int32_t *side_vals;
     uint32_t *side_sums;
     uint32_t side_shift;
@@ -103,12 +103,10 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_hist_kernel(
 }
 
 // block = digit.  In-place exclusive scan of hist[digit][0..n_blocks) and digit total.
-// zero_hist (optional): the histogram the FOLLOWING scatter launch accumulates the next pass's digits into (see
-// sort_scatter_kernel: hist_next) -- this launch runs right before it, so its row is zeroed here instead of by a fill launch;
-// zero_side (optional, n_side entries): the same service for the scatter's side sums.
+// zero_side (optional, n_side entries): the buffer the FOLLOWING scatter launch accumulates its side sums into -- this launch
+// runs right before it, so the buffer is zeroed here instead of by a fill launch of its own.
 __global__ void __launch_bounds__(GS_BLOCK) sort_scan_kernel(
-    uint32_t n_blocks, uint32_t *__restrict__ hist, uint32_t *__restrict__ totals, uint32_t *__restrict__ zero_hist,
-    uint32_t *__restrict__ zero_side, uint32_t n_side) {
+    uint32_t n_blocks, uint32_t *__restrict__ hist, uint32_t *__restrict__ totals, uint32_t *__restrict__ zero_side, uint32_t n_side) {
     __shared__ uint32_t s_wave[SORT_WAVES];
     uint32_t *row = hist + (size_t)blockIdx.x * n_blocks;
     uint32_t lane = threadIdx.x % GS_WAVE, wave = threadIdx.x / GS_WAVE;
@@ -118,7 +116,6 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scan_kernel(
     for (uint32_t base = 0; base < n_blocks; base += GS_BLOCK) {
         uint32_t i = base + threadIdx.x;
         uint32_t v = i < n_blocks ? row[i] : 0;
-        if (zero_hist != nullptr && i < n_blocks) zero_hist[(size_t)blockIdx.x * n_blocks + i] = 0u;
         uint32_t inc = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -278,21 +275,6 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
             if (FINAL_ISECT) kept_key[FINAL_ISECT ? k : 0] = kk;
             else keys_out[pos[k]] = kk;
         }
-        // the next pass's histogram.  One atomic per key would pile hundreds of them on one counter whenever the next
-        // digit is concentrated (the upper bytes of depth bits: 293 K atomics on ~600 counters took 0.5 ms), so the lanes
-        // first merge RUNS: consecutive lanes hold consecutive positions of the block's sorted order, i.e. the same
-        // destination block and, for a concentrated digit, the same counter -- the head of a run adds its length.
-        if (side.hist_next != nullptr) { // (block-uniform)
-            const bool on = j < block_count;
-            uint32_t code = 0xffffffffu;
-            if (on) code = (digit_of(s_keys[j], side.d_next) << 22) | (pos[k] / (uint32_t)SORT_TILE);
-            const uint32_t prev = __shfl_up(code, 1, 64);
-            const bool head = lane == 0u || code != prev;
-            const unsigned long long hm = __ballot(head);
-            const unsigned long long above = lane == 63u ? 0ull : (hm >> (lane + 1u));
-            const uint32_t run = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
-            if (head && on) atomicAdd(&side.hist_next[(size_t)(code >> 22) * n_blocks + (code & 0x3fffffu)], run);
-        }
     }
     lds_barrier();
     int32_t *s_vals = reinterpret_cast<int32_t *>(s_keys); // the same LDS, second trip for the values
@@ -341,7 +323,7 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
 
 struct SortLayout {
     uint32_t n_blocks;
-    size_t off_keys, off_vals, off_hist, off_hist2, off_totals, total;
+    size_t off_keys, off_vals, off_hist, off_totals, total;
 };
 
 SortLayout sort_layout(uint64_t n) {
@@ -356,7 +338,6 @@ SortLayout sort_layout(uint64_t n) {
     L.off_keys = take(n * sizeof(uint64_t));
     L.off_vals = take(n * sizeof(int32_t));
     L.off_hist = take((size_t)RADIX * L.n_blocks * sizeof(uint32_t));
-    L.off_hist2 = take((size_t)RADIX * L.n_blocks * sizeof(uint32_t)); // ping-pong partner (histograms made by the scatter launches)
     L.off_totals = take(RADIX * sizeof(uint32_t));
     L.total = o;
     return L;
@@ -403,7 +384,6 @@ static int32_t sort_impl(uint64_t n, const int64_t *keys_in, const int32_t *vals
     uint64_t *tkeys = (uint64_t *)(tp + L.off_keys);
     int32_t *tvals = (int32_t *)(tp + L.off_vals);
     uint32_t *hist = (uint32_t *)(tp + L.off_hist);
-    uint32_t *hist2 = (uint32_t *)(tp + L.off_hist2);
     uint32_t *totals = (uint32_t *)(tp + L.off_totals);
     const uint32_t n_side = side_sums != nullptr ? (uint32_t)((n + (1ull << side_shift) - 1) >> side_shift) : 0u;
 
@@ -429,49 +409,28 @@ static int32_t sort_impl(uint64_t n, const int64_t *keys_in, const int32_t *vals
         d.drop_hi = drop_hi;
         return d;
     };
-    // Small inputs (1024-key blocks: every launch sits at its latency floor): the scatter of pass p also counts the digits
-    // of pass p + 1 per DESTINATION block (global atomics into the other histogram buffer, zero-filled by the scan launch
-    // in front of it): two launches per pass instead of three.
-    bool hist_ready = first_hist_ready && small;
-    uint32_t *cur_hist = hist, *other_hist = hist2;
     for (int p = 0; p < passes; ++p) {
         const DigitSpec d = digit_spec(p, shift);
         shift += (p == 0) ? first_bits : RADIX_BITS;
         const bool last = p == passes - 1;
         uint64_t *dst_k = to_out ? (uint64_t *)keys_out : tkeys;
         int32_t *dst_v = to_out ? vals_out : tvals;
-        if (hist_ready) {
-            // this pass's per-block digit counts are there already: made by the producer of the keys (pass 0, see
-            // sort_first_hist_slot) or by the previous pass's scatter
+        if (p == 0 && first_hist_ready && small) {
+            // the producer of the keys counted this pass's digits already (see sort_first_hist_slot)
         } else if (small)
-            hipLaunchKernelGGL((sort_hist_kernel<uint64_t, SORT_ROUNDS_SMALL>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, cur_hist);
+            hipLaunchKernelGGL((sort_hist_kernel<uint64_t, SORT_ROUNDS_SMALL>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, hist);
         else
-            hipLaunchKernelGGL((sort_hist_kernel<uint64_t, SORT_ROUNDS_BIG>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, cur_hist);
-        ScatterSide side = {nullptr, d, nullptr, nullptr, 0u};
-        if (small && !last) {
-            side.hist_next = other_hist;
-            side.d_next = digit_spec(p + 1, shift);
-        }
-        if (last && side_sums != nullptr) {
-            side.side_vals = side_vals;
-            side.side_sums = side_sums;
-            side.side_shift = side_shift;
-        }
-        hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, cur_hist, totals, side.hist_next,
-                           side.side_sums, n_side);
+            hipLaunchKernelGGL((sort_hist_kernel<uint64_t, SORT_ROUNDS_BIG>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, d, L.n_blocks, hist);
+        ScatterSide side = {nullptr, nullptr, 0u};
+        if (last && side_sums != nullptr) side = {side_vals, side_sums, side_shift};
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, hist, totals, side.side_sums, n_side);
         if (small)
             hipLaunchKernelGGL((sort_scatter_kernel<uint64_t, SORT_ROUNDS_SMALL, false>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, src_v,
-                               dst_k, dst_v, d, L.n_blocks, cur_hist, totals, (drop && p == 0) ? n_valid_out : nullptr, IsectEpilogue{}, side);
+                               dst_k, dst_v, d, L.n_blocks, hist, totals, (drop && p == 0) ? n_valid_out : nullptr, IsectEpilogue{}, side);
         else
             hipLaunchKernelGGL((sort_scatter_kernel<uint64_t, SORT_ROUNDS_BIG, false>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, n_dev, src_k, src_v,
-                               dst_k, dst_v, d, L.n_blocks, cur_hist, totals, (drop && p == 0) ? n_valid_out : nullptr, IsectEpilogue{}, side);
+                               dst_k, dst_v, d, L.n_blocks, hist, totals, (drop && p == 0) ? n_valid_out : nullptr, IsectEpilogue{}, side);
         if (drop && p == 0) n_dev = n_valid_out;
-        hist_ready = side.hist_next != nullptr;
-        if (hist_ready) {
-            uint32_t *t = cur_hist;
-            cur_hist = other_hist;
-            other_hist = t;
-        }
         src_k = dst_k;
         src_v = dst_v;
         to_out = !to_out;
@@ -543,8 +502,8 @@ template <int ROUNDS>
 void launch_pass32(uint64_t n, const uint32_t *src_k, const int32_t *src_v, uint32_t *dst_k, int32_t *dst_v, DigitSpec d,
                    const Sort32Layout &L, uint32_t *hist, uint32_t *totals, bool final, const IsectEpilogue &ep, hipStream_t st) {
     hipLaunchKernelGGL((sort_hist_kernel<uint32_t, ROUNDS>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, (const uint32_t *)nullptr, src_k, d, L.n_blocks, hist);
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, hist, totals, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
-    const ScatterSide none = {nullptr, d, nullptr, nullptr, 0u};
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, hist, totals, (uint32_t *)nullptr, 0u);
+    const ScatterSide none = {nullptr, nullptr, 0u};
     if (final)
         hipLaunchKernelGGL((sort_scatter_kernel<uint32_t, ROUNDS, true>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, (const uint32_t *)nullptr, src_k, src_v,
                            dst_k, dst_v, d, L.n_blocks, hist, totals, (uint32_t *)nullptr, ep, none);

@@ -183,23 +183,21 @@ def rasterization(
     fuse_sh = (sh_degree is not None and not packed and colors.dim() == 3 and not viewmats.requires_grad and viewmats.is_cuda)
     # the fused SH route reads the means a second time (view directions): it gets them back FROM the projection, so that
     # its contribution to d/d means is added inside the projection's backward kernel
-    means_alias = fuse_sh and means.requires_grad
+    means_alias = fuse_sh and means.requires_grad and not use_rows
     rows = None
     compensations = None
     if use_rows:
         row_colors = colors if (sh_degree is None and colors.dim() == 2 and colors.shape[-1] == 3) else None
-        proj_results = project_rows(
+        radii, means2d, depths, conics, opacities, colors_rows, rows = project_rows(
             means, covars, quats, scales, viewmats, Ks, width, height, opacities, row_colors,
             eps2d=eps2d, near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip,
-            antialiased=(rasterize_mode == "antialiased"), camera_model=camera_model, _means_alias=means_alias,
+            antialiased=(rasterize_mode == "antialiased"), camera_model=camera_model,
+            # shared SH coefficients and fixed poses: the colours are evaluated by the projection pass itself
+            sh_coeffs=colors if fuse_sh else None, sh_degree=sh_degree if fuse_sh else None,
         )
-        means_sh = means
-        if means_alias:
-            means_sh, proj_results = proj_results[7], proj_results[:7]
-        radii, means2d, depths, conics, opacities, colors_rows, rows = proj_results
         camera_ids, gaussian_ids = None, None
         opacity_rider = False
-        if row_colors is not None:
+        if row_colors is not None or fuse_sh:
             colors = colors_rows  # [C, N, 3]: columns 6:9 of the rows
     else:
         proj_results = fully_fused_projection(
@@ -252,7 +250,9 @@ def rasterization(
                                         0 if packed else N, n_elems, camera_ids.contiguous() if packed else None)
 
     # colours -> [C, N, D] or [nnz, D]
-    if sh_degree is None:
+    if use_rows and fuse_sh:
+        pass  # evaluated by the projection pass (columns 6:9 of the splat rows)
+    elif sh_degree is None:
         if packed:
             colors = gather_rows(colors, gaussian_ids) if colors.dim() == 2 else colors[camera_ids, gaussian_ids]
         else:

@@ -137,7 +137,11 @@ int32_t gs_projection_bwd(
  * entries in three arrays.  Folded in, because the row wants them and the pass runs anyway:
  *   opacities [N] (or NULL): column 5 = opacities[n]              -- the `opacities.repeat(C, 1)` of rendering.py:331,
  *                            x compensation when antialiased != 0  -- and the multiply of rendering.py:334-335;
- *   colors [N,3] (or NULL):  columns 6-8 = colors[n]               -- the `colors.expand(C, -1, -1)` of rendering.py:386.
+ *   colors [N,3] (or NULL):  columns 6-8 = colors[n]               -- the `colors.expand(C, -1, -1)` of rendering.py:386;
+ *   sh_coeffs [N,sh_K,3] (or NULL; excludes colors): columns 6-8 = max(SH(means[n] - camera centre) + 0.5, 0) for the
+ *                            first (sh_degree + 1)^2 bands -- exactly what gs_sh_view_fwd writes (same arithmetic, bit for
+ *                            bit), without its launch and its second pass over means / radii; its gradient stays with
+ *                            gs_sh_view_bwd.
  * radii [C,N] and depths [C,N] are ALSO written densely (the binning kernels stream through them); rows must be 64-byte
  * aligned; rows / depths of culled pairs are left untouched. */
 int32_t gs_projection_rows_fwd(
@@ -148,6 +152,7 @@ int32_t gs_projection_rows_fwd(
     float eps2d, float near_plane, float far_plane, float radius_clip,
     int32_t camera_model,
     const float *opacities, const float *colors, int32_t antialiased,
+    const float *sh_coeffs, uint32_t sh_K, uint32_t sh_degree,
     int32_t *radii, /* [C,N] */
     float *depths,  /* [C,N] */
     float *rows,    /* [C,N,16] */

@@ -1,0 +1,49 @@
+"""Host-side cost of one rasterization() forward + backward: a scene so small that every kernel sits at its launch floor, so
+the wall time per step IS the host time (Python + torch dispatch + ctypes + launches).  Prints it, and cProfile's top entries."""
+import cProfile
+import io
+import os
+import pstats
+import sys
+import time
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch  # noqa: E402
+
+from gscodec_studio_amd import rasterization  # noqa: E402
+from gscodec_studio_amd._helper import sh_workload  # noqa: E402
+
+dev = torch.device("cuda:0")
+w = sh_workload(scene_grid=1, device=dev)
+n = int(os.environ.get("N", "3000"))
+params = {k: w[k][:n].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "sh")}
+vm, Ks = w["viewmats"][:1].contiguous(), w["Ks"][:1].contiguous()
+
+
+def step():
+    for p in params.values():
+        p.grad = None
+    rc, ra, meta = rasterization(params["means"], params["quats"], params["scales"], params["opacities"], params["sh"], vm, Ks,
+                                 1920, 1080, sh_degree=3, packed=False)
+    rc.sum().backward()
+
+
+for _ in range(20):
+    step()
+torch.cuda.synchronize()
+K = 200
+t0 = time.perf_counter()
+for _ in range(K):
+    step()
+torch.cuda.synchronize()
+t1 = time.perf_counter()
+print(f"host-bound step: {1e3 * (t1 - t0) / K:.3f} ms per forward + backward ({n} splats)")
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(K):
+    step()
+pr.disable()
+torch.cuda.synchronize()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
+print(s.getvalue()[:6000])
