@@ -307,6 +307,7 @@ def spherical_harmonics_view(
     radii: Optional[Tensor] = None,  # [C, N] int32: evaluate only where radii > 0
     opacities: Optional[Tensor] = None,  # [N]: also return opacities.repeat(C, 1) (and sum its gradient over cameras)
     rows: Optional[Tensor] = None,  # [C, N, 16] splat rows: the colours are written into columns 6:9 and returned as that view
+    coeffs_rest: Optional[Tensor] = None,  # SPLIT rows: ``coeffs`` is the DC band [N, 1, 3], this the higher bands [N, K-1, 3]
 ):
     """Fused colour evaluation used by ``rasterization``:
     ``clamp_min(spherical_harmonics(deg, means[None] - campos[:, None], coeffs, radii > 0) + 0.5, 0)``
@@ -316,7 +317,12 @@ def spherical_harmonics_view(
     # campos: [C, 3] camera centres, or the [C, 4, 4] world->camera matrices themselves (centre derived in-kernel)
     assert means.shape == (N, 3) and (campos.shape == (C, 3) or campos.shape == (C, 4, 4)), (means.shape, campos.shape)
     assert coeffs.dim() == 3 and coeffs.shape[0] == N and coeffs.shape[2] == 3, coeffs.shape
-    assert (degrees_to_use + 1) ** 2 <= coeffs.shape[-2], coeffs.shape
+    if coeffs_rest is not None:  # the trainer's sh0 / shN parameters as they are (no torch.cat, reference simple_trainer.py:779-786)
+        assert coeffs.shape == (N, 1, 3) and coeffs_rest.dim() == 3 and coeffs_rest.shape[0] == N and coeffs_rest.shape[2] == 3, \
+            (coeffs.shape, coeffs_rest.shape)
+        assert coeffs_rest.shape[1] >= 1, coeffs_rest.shape
+        coeffs_rest = coeffs_rest.contiguous()
+    assert (degrees_to_use + 1) ** 2 <= coeffs.shape[-2] + (coeffs_rest.shape[1] if coeffs_rest is not None else 0), coeffs.shape
     if radii is not None:
         assert radii.shape == (C, N) and radii.dtype == torch.int32, (radii.shape, radii.dtype)
     if opacities is not None:
@@ -325,16 +331,16 @@ def spherical_harmonics_view(
         assert rows.shape == (C, N, ROW) and rows.is_contiguous() and rows.dtype == torch.float32, (rows.shape, rows.dtype)
     colors, opac_cn = _SphericalHarmonicsView.apply(degrees_to_use, means.contiguous(), campos.contiguous(), coeffs.contiguous(),
                                                     radii.contiguous() if radii is not None else None,
-                                                    opacities.contiguous() if opacities is not None else None, rows)
+                                                    opacities.contiguous() if opacities is not None else None, rows, coeffs_rest)
     return colors if opacities is None else (colors, opac_cn)
 
 
 class _SphericalHarmonicsView(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, sh_degree, means, campos, coeffs, radii, opacities, rows=None):
+    def forward(ctx, sh_degree, means, campos, coeffs, radii, opacities, rows=None, coeffs_rest=None):
         _require_gpu(coeffs, "spherical_harmonics_view")
-        means, campos, coeffs = _f32c(means), _f32c(campos), _f32c(coeffs)
-        C, N, K = campos.shape[0], means.shape[0], coeffs.shape[1]
+        means, campos, coeffs, coeffs_rest = _f32c(means), _f32c(campos), _f32c(coeffs), _f32c(coeffs_rest)
+        C, N, K = campos.shape[0], means.shape[0], coeffs.shape[1] + (coeffs_rest.shape[1] if coeffs_rest is not None else 0)
         # the colours are their own [C,N,3] tensor, or columns 6:9 of the splat rows the projection filled (written through
         # the raw pointer: a view of a buffer that is no differentiable input of this node)
         colors = torch.empty((C, N, 3), dtype=torch.float32, device=means.device) if rows is None else rows[..., ROW_COLOR:ROW_COLOR + 3]
@@ -342,9 +348,9 @@ class _SphericalHarmonicsView(torch.autograd.Function):
         opacities = _f32c(opacities) if opacities is not None else None
         opac_cn = torch.empty((C, N), dtype=torch.float32, device=means.device) if opacities is not None else None
         with _device_of(means):
-            B.call("gs_sh_view_fwd", C, N, K, sh_degree, B.ptr(means), B.ptr(campos), int(campos.dim() == 3), B.ptr(coeffs), B.ptr(radii),
-                   B.ptr(colors), cstride, B.ptr(opacities), B.ptr(opac_cn), _stream(means))
-        ctx.save_for_backward(means, campos, coeffs, radii, colors)
+            B.call("gs_sh_view_fwd", C, N, K, sh_degree, B.ptr(means), B.ptr(campos), int(campos.dim() == 3), B.ptr(coeffs),
+                   B.ptr(coeffs_rest), B.ptr(radii), B.ptr(colors), cstride, B.ptr(opacities), B.ptr(opac_cn), _stream(means))
+        ctx.save_for_backward(means, campos, coeffs, radii, colors, coeffs_rest)
         ctx.sh_degree, ctx.cstride = sh_degree, cstride
         ctx.has_opac = opacities is not None
         ctx.set_materialize_grads(False)
@@ -352,12 +358,13 @@ class _SphericalHarmonicsView(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_colors, v_opac_cn):
-        means, campos, coeffs, radii, colors = ctx.saved_tensors
-        C, N, K = campos.shape[0], means.shape[0], coeffs.shape[1]
+        means, campos, coeffs, radii, colors, coeffs_rest = ctx.saved_tensors
+        C, N, K = campos.shape[0], means.shape[0], coeffs.shape[1] + (coeffs_rest.shape[1] if coeffs_rest is not None else 0)
         if v_colors is None:
             v_colors = torch.zeros_like(colors)
         v_colors, vstride = _row_strided(v_colors, 3)
         v_coeffs = torch.empty_like(coeffs)
+        v_rest = torch.empty_like(coeffs_rest) if coeffs_rest is not None else None
         v_means = torch.empty_like(means) if ctx.needs_input_grad[1] else None
         v_opac = ostride = None
         if ctx.has_opac and ctx.needs_input_grad[5]:
@@ -367,15 +374,16 @@ class _SphericalHarmonicsView(torch.autograd.Function):
             else:
                 v_opac_cn, ostride = _elem_strided(v_opac_cn)
         with _device_of(means):
-            B.call("gs_sh_view_bwd", C, N, K, ctx.sh_degree, B.ptr(means), B.ptr(campos), int(campos.dim() == 3), B.ptr(coeffs), B.ptr(radii),
-                   B.ptr(colors), ctx.cstride, B.ptr(v_colors), vstride, B.ptr(v_coeffs), B.ptr(v_means),
+            B.call("gs_sh_view_bwd", C, N, K, ctx.sh_degree, B.ptr(means), B.ptr(campos), int(campos.dim() == 3), B.ptr(coeffs),
+                   B.ptr(coeffs_rest), B.ptr(radii),
+                   B.ptr(colors), ctx.cstride, B.ptr(v_colors), vstride, B.ptr(v_coeffs), B.ptr(v_rest), B.ptr(v_means),
                    B.ptr(v_opac_cn) if ostride is not None else None, ostride or 0, B.ptr(v_opac) if ostride is not None else None,
                    _stream(means))
         if not ctx.needs_input_grad[3]:
             v_coeffs = None
         # campos (camera poses) gets no gradient on this path; rasterization() takes the unfused
         # route when viewmats require grad.
-        return None, v_means, None, v_coeffs, None, v_opac, None
+        return None, v_means, None, v_coeffs, None, v_opac, None, v_rest
 
 
 class _SphericalHarmonics(torch.autograd.Function):
@@ -777,6 +785,7 @@ def project_rows(
     camera_model: Literal["pinhole", "ortho", "fisheye"] = "pinhole",
     sh_coeffs: Optional[Tensor] = None,  # [N, K, 3] SH coefficients shared by all cameras (instead of ``colors``)
     sh_degree: Optional[int] = None,
+    sh_rest: Optional[Tensor] = None,  # SPLIT coefficients: ``sh_coeffs`` is the DC band [N, 1, 3], this [N, K-1, 3]
 ):
     """``fully_fused_projection`` in ROW form, what ``rasterization`` uses for unpacked batches: the same projection, but
     every (camera, gaussian) pair gets one 64-byte splat row (include/gsplat_hip.h) that the compositing kernels fetch
@@ -806,12 +815,20 @@ def project_rows(
     if sh_coeffs is not None:
         assert colors is None and sh_degree is not None, "sh_coeffs come with sh_degree and without colors"
         assert sh_coeffs.dim() == 3 and sh_coeffs.shape[0] == N and sh_coeffs.shape[2] == 3, sh_coeffs.shape
-        assert (sh_degree + 1) ** 2 <= sh_coeffs.shape[1], sh_coeffs.shape
+        K = sh_coeffs.shape[1]
+        if sh_rest is not None:
+            assert sh_coeffs.shape[1] == 1 and sh_rest.dim() == 3 and sh_rest.shape[0] == N and sh_rest.shape[2] == 3 \
+                and sh_rest.shape[1] >= 1, (sh_coeffs.shape, sh_rest.shape)
+            K += sh_rest.shape[1]
+            sh_rest = sh_rest.contiguous()
+        assert (sh_degree + 1) ** 2 <= K, (sh_degree, K)
         sh_coeffs = sh_coeffs.contiguous()
+    else:
+        assert sh_rest is None
     assert camera_model in _CAMERA_MODELS, camera_model
     return _ProjectRows.apply(means.contiguous(), covars, quats, scales, viewmats.contiguous(), Ks.contiguous(),
-                              opacities.contiguous(), colors, sh_coeffs, width, height, eps2d, near_plane, far_plane, radius_clip,
-                              antialiased, camera_model, sh_degree)
+                              opacities.contiguous(), colors, sh_coeffs, sh_rest, width, height, eps2d, near_plane, far_plane,
+                              radius_clip, antialiased, camera_model, sh_degree)
 
 
 def _grad_rows_of(parts, shape, device):
@@ -861,11 +878,13 @@ def _grad_rows_of(parts, shape, device):
 
 class _ProjectRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, width, height, eps2d, near_plane,
-                far_plane, radius_clip, antialiased, camera_model="pinhole", sh_degree=None):
+    def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, sh_rest, width, height, eps2d,
+                near_plane, far_plane, radius_clip, antialiased, camera_model="pinhole", sh_degree=None):
         _require_gpu(means, "project_rows")
         means, covars, quats, scales = _f32c(means), _f32c(covars), _f32c(quats), _f32c(scales)
-        viewmats, Ks, opacities, colors, sh_coeffs = _f32c(viewmats), _f32c(Ks), _f32c(opacities), _f32c(colors), _f32c(sh_coeffs)
+        viewmats, Ks, opacities, colors = _f32c(viewmats), _f32c(Ks), _f32c(opacities), _f32c(colors)
+        sh_coeffs, sh_rest = _f32c(sh_coeffs), _f32c(sh_rest)
+        sh_K = (sh_coeffs.shape[1] + (sh_rest.shape[1] if sh_rest is not None else 0)) if sh_coeffs is not None else 0
         C, N = viewmats.shape[0], means.shape[0]
         dev = means.device
         radii = torch.empty((C, N), dtype=torch.int32, device=dev)
@@ -876,9 +895,9 @@ class _ProjectRows(torch.autograd.Function):
             B.call("gs_projection_rows_fwd", C, N, B.ptr(means), B.ptr(covars), B.ptr(quats), B.ptr(scales),
                    B.ptr(viewmats), B.ptr(Ks), int(width), int(height), float(eps2d), float(near_plane),
                    float(far_plane), float(radius_clip), cm, B.ptr(opacities), B.ptr(colors), int(bool(antialiased)),
-                   B.ptr(sh_coeffs), sh_coeffs.shape[1] if sh_coeffs is not None else 0, int(sh_degree or 0),
+                   B.ptr(sh_coeffs), B.ptr(sh_rest), sh_K, int(sh_degree or 0),
                    B.ptr(radii), B.ptr(depths), B.ptr(rows), _stream(means))
-        ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, opacities, radii, rows, sh_coeffs)
+        ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, opacities, radii, rows, sh_coeffs, sh_rest)
         ctx.width, ctx.height, ctx.eps2d, ctx.cm, ctx.antialiased = width, height, eps2d, cm, bool(antialiased)
         ctx.has_colors, ctx.sh_degree = colors is not None, (int(sh_degree) if sh_coeffs is not None else None)
         ctx.mark_non_differentiable(radii, rows)
@@ -889,7 +908,7 @@ class _ProjectRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_opac_cn, v_colors_cn, v_rows):
-        means, covars, quats, scales, viewmats, Ks, opacities, radii, rows, sh_coeffs = ctx.saved_tensors
+        means, covars, quats, scales, viewmats, Ks, opacities, radii, rows, sh_coeffs, sh_rest = ctx.saved_tensors
         C, N = viewmats.shape[0], means.shape[0]
         dev = means.device
         parts = [(v_means2d, ROW_MEAN2D, 2), (v_conics, ROW_CONIC, 3), (v_opac_cn, ROW_OPACITY, 1)]
@@ -897,19 +916,22 @@ class _ProjectRows(torch.autograd.Function):
             parts.append((v_colors_cn, ROW_COLOR, 3))
         g_ptr, g_keep = _grad_rows_of(parts, (C, N), dev)
         need = ctx.needs_input_grad
-        v_sh = v_means_add = None
+        v_sh = v_rest = v_means_add = None
         if sh_coeffs is not None:
             # the colour columns of the gradient rows go back through the SH evaluation first (clamp gate from the colours
             # in the rows); its d/d means (view directions) is added by the projection kernel below while it writes v_means
-            K = sh_coeffs.shape[1]
+            K = sh_coeffs.shape[1] + (sh_rest.shape[1] if sh_rest is not None else 0)
             v_sh = torch.empty_like(sh_coeffs)
+            v_rest = torch.empty_like(sh_rest) if sh_rest is not None else None
             v_means_add = torch.empty_like(means) if need[0] else None
             with _device_of(means):
-                B.call("gs_sh_view_bwd", C, N, K, ctx.sh_degree, B.ptr(means), B.ptr(viewmats), 1, B.ptr(sh_coeffs), B.ptr(radii),
-                       rows.data_ptr() + 4 * ROW_COLOR, ROW, g_ptr + 4 * ROW_COLOR, ROW, B.ptr(v_sh), B.ptr(v_means_add),
-                       None, 0, None, _stream(means))
+                B.call("gs_sh_view_bwd", C, N, K, ctx.sh_degree, B.ptr(means), B.ptr(viewmats), 1, B.ptr(sh_coeffs), B.ptr(sh_rest),
+                       B.ptr(radii), rows.data_ptr() + 4 * ROW_COLOR, ROW, g_ptr + 4 * ROW_COLOR, ROW, B.ptr(v_sh), B.ptr(v_rest),
+                       B.ptr(v_means_add), None, 0, None, _stream(means))
             if not need[8]:
                 v_sh = None
+            if not need[9]:
+                v_rest = None
         v_depths = _f32c(v_depths) if v_depths is not None else None
         # rows are fully written by the kernel -> empty, not zeros
         v_means = torch.empty_like(means) if need[0] else None
@@ -926,7 +948,7 @@ class _ProjectRows(torch.autograd.Function):
                    B.ptr(v_means), B.ptr(v_covars), B.ptr(v_quats), B.ptr(v_scales), B.ptr(v_viewmats), B.ptr(v_opac),
                    B.ptr(v_colors), B.ptr(v_means_add) if v_means is not None else None, _stream(means))
         del g_keep
-        return (v_means, v_covars, v_quats, v_scales, v_viewmats, None, v_opac, v_colors, v_sh) + (None,) * 9
+        return (v_means, v_covars, v_quats, v_scales, v_viewmats, None, v_opac, v_colors, v_sh, v_rest) + (None,) * 9
 
 
 class _FullyFusedProjectionPacked(torch.autograd.Function):

@@ -129,6 +129,7 @@ struct RowExtras {
     // coefficient row is read here, the whole 48 bytes of the row leave in three full 16-byte stores, and the colour launch
     // with its second pass over means / radii disappears
     const float *sh_coeffs; // [N,K,3] or NULL
+    const float *sh_rest;   // split rows (sh_eval.h): sh_coeffs is [N,1,3], this [N,K-1,3]
     uint32_t sh_K, sh_degree;
     int sh_vec;             // coefficient rows are 16-byte aligned (dwordx4 loads)
 };
@@ -168,18 +169,19 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_fwd_kernel(
                 camera_center(viewmats + 16 * c, cx, cy, cz);
                 const float *p = means + 3 * (size_t)n;
                 const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
-                const float *crow = rx.sh_coeffs + (size_t)n * rx.sh_K * 3;
+                const float *crow = rx.sh_coeffs + (size_t)n * (rx.sh_rest != nullptr ? 3u : rx.sh_K * 3);
+                const float *rest = rx.sh_rest != nullptr ? rx.sh_rest + (size_t)n * (rx.sh_K - 1) * 3 : nullptr;
                 switch ((rx.sh_degree << 1) | (rx.sh_vec ? 1u : 0u)) { // (block-uniform)
-                    case 0: sh_view_color<0, false>(dx, dy, dz, crow, true, c0, c1, c2); break;
-                    case 1: sh_view_color<0, true>(dx, dy, dz, crow, true, c0, c1, c2); break;
-                    case 2: sh_view_color<1, false>(dx, dy, dz, crow, true, c0, c1, c2); break;
-                    case 3: sh_view_color<1, true>(dx, dy, dz, crow, true, c0, c1, c2); break;
-                    case 4: sh_view_color<2, false>(dx, dy, dz, crow, true, c0, c1, c2); break;
-                    case 5: sh_view_color<2, true>(dx, dy, dz, crow, true, c0, c1, c2); break;
-                    case 6: sh_view_color<3, false>(dx, dy, dz, crow, true, c0, c1, c2); break;
-                    case 7: sh_view_color<3, true>(dx, dy, dz, crow, true, c0, c1, c2); break;
-                    case 8: sh_view_color<4, false>(dx, dy, dz, crow, true, c0, c1, c2); break;
-                    default: sh_view_color<4, true>(dx, dy, dz, crow, true, c0, c1, c2); break;
+                    case 0: sh_view_color<0, false>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
+                    case 1: sh_view_color<0, true>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
+                    case 2: sh_view_color<1, false>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
+                    case 3: sh_view_color<1, true>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
+                    case 4: sh_view_color<2, false>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
+                    case 5: sh_view_color<2, true>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
+                    case 6: sh_view_color<3, false>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
+                    case 7: sh_view_color<3, true>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
+                    case 8: sh_view_color<4, false>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
+                    default: sh_view_color<4, true>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
                 }
             } else {
                 const float *cp = rx.colors + 3 * (size_t)n;
@@ -666,7 +668,7 @@ extern "C" int32_t gs_projection_fwd(
                  "exactly one of covars / (quats, scales) must be given");
     GS_CHECK_ARG(camera_model >= 0 && camera_model <= 2, "bad camera_model");
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
-    const RowExtras none = {nullptr, nullptr, 0, nullptr, 0u, 0u, 0};
+    const RowExtras none = {nullptr, nullptr, 0, nullptr, nullptr, 0u, 0u, 0};
     hipLaunchKernelGGL(projection_fwd_kernel<false>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means,
                        covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d, near_plane,
                        far_plane, radius_clip, camera_model, radii, means2d, depths, conics, compensations, none);
@@ -678,8 +680,8 @@ extern "C" int32_t gs_projection_rows_fwd(
     uint32_t C, uint32_t N, const float *means, const float *covars, const float *quats,
     const float *scales, const float *viewmats, const float *Ks, int32_t image_width,
     int32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
-    int32_t camera_model, const float *opacities, const float *colors, int32_t antialiased, const float *sh_coeffs, uint32_t sh_K,
-    uint32_t sh_degree, int32_t *radii, float *depths, float *rows, gs_stream_t stream) {
+    int32_t camera_model, const float *opacities, const float *colors, int32_t antialiased, const float *sh_coeffs, const float *sh_coeffs_rest,
+    uint32_t sh_K, uint32_t sh_degree, int32_t *radii, float *depths, float *rows, gs_stream_t stream) {
     if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && viewmats && Ks && radii && depths && rows, "null pointer");
     GS_CHECK_ARG((uintptr_t)rows % 64 == 0, "the row buffer must be 64-byte aligned");
@@ -690,8 +692,9 @@ extern "C" int32_t gs_projection_rows_fwd(
     GS_CHECK_ARG(sh_coeffs == nullptr || colors == nullptr, "colors and sh_coeffs exclude each other");
     GS_CHECK_ARG(sh_coeffs == nullptr || (sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= sh_K), "bad SH degree / K");
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
-    const int sh_vec = sh_coeffs != nullptr && ((uintptr_t)sh_coeffs % 16 == 0) && ((sh_K * 3u) % 4u == 0);
-    const RowExtras rx = {opacities, colors, antialiased, sh_coeffs, sh_K, sh_degree, sh_vec};
+    GS_CHECK_ARG(sh_coeffs_rest == nullptr || (sh_coeffs != nullptr && sh_K >= 2), "sh_coeffs_rest needs sh_coeffs and K >= 2");
+    const int sh_vec = sh_coeffs != nullptr && (sh_coeffs_rest != nullptr || (uintptr_t)sh_coeffs % 16 == 0) && ((sh_K * 3u) % 4u == 0);
+    const RowExtras rx = {opacities, colors, antialiased, sh_coeffs, sh_coeffs_rest, sh_K, sh_degree, sh_vec};
     hipLaunchKernelGGL(projection_fwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means,
                        covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d, near_plane,
                        far_plane, radius_clip, camera_model, radii, rows, depths, (float *)nullptr, (float *)nullptr, rx);

@@ -115,6 +115,8 @@ struct ShView {
     const float *v_opac_cn;  // bwd: [C,N] rows with stride v_opac_stride floats
     uint32_t v_opac_stride;
     float *v_opac_out;       // bwd: [N] <- sum over cameras
+    const float *coeffs_rest; // split rows (sh_eval.h): coeffs is [N,1,3], this is [N,K-1,3]; NULL = one [N,K,3] tensor
+    float *v_coeffs_rest;     // bwd: gradient of coeffs_rest, [N,K-1,3]
     uint32_t color_stride;   // row stride (floats) of the colours the forward writes / the backward reads back: 3, or 16 when
                              // they are columns of the splat rows (include/gsplat_hip.h)
 };
@@ -155,9 +157,11 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_fwd_kernel(
     if (!sh_active(masks, view, e)) return;
     float dx = 0.f, dy = 0.f, dz = 1.f;
     if (DEG >= 1) sh_dir(dirs, view, c, n, e, dx, dy, dz);
-    const float *row = coeffs + (shared ? (size_t)n : e) * K * 3;
+    const bool split = view.coeffs_rest != nullptr; // (uniform; shared coefficients only)
+    const float *row = coeffs + (shared ? (size_t)n : e) * (split ? 3u : K * 3);
+    const float *rest = split ? view.coeffs_rest + (size_t)n * (K - 1) * 3 : nullptr;
     float r, g, b;
-    sh_view_color<DEG, VEC>(dx, dy, dz, row, view.clamp_half != 0, r, g, b);
+    sh_view_color<DEG, VEC>(dx, dy, dz, row, rest, view.clamp_half != 0, r, g, b);
     float *co = colors + e * view.color_stride;
     co[0] = r;
     co[1] = g;
@@ -183,6 +187,7 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
         view.v_opac_out[n] = vo;
     }
     const uint32_t row_len = K * 3;
+    const bool split = SHARED && view.coeffs_rest != nullptr; // (uniform)
     float acc[NB * 3];
     if (SHARED) {
 #pragma unroll
@@ -238,7 +243,8 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
             float gx = 0.f, gy = 0.f, gz = 0.f;
             if (DEG >= 1) {
                 if (!SHARED || !have_cf) {
-                    load_floats<NB * 3, VEC>(coeffs + (SHARED ? (size_t)n : e) * row_len, cf);
+                    if (split) load_coeff_row<NB * 3, VEC>(coeffs + 3 * (size_t)n, view.coeffs_rest + (size_t)n * (K - 1) * 3, cf);
+                    else load_floats<NB * 3, VEC>(coeffs + (SHARED ? (size_t)n : e) * row_len, cf);
                     have_cf = true;
                 }
                 float w[NB];
@@ -267,6 +273,35 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
         __shared__ float4 s_tr[CAN_T ? (GS_BLOCK / GS_WAVE) * GS_WAVE * (RL / 4) : 1];
         const uint32_t lane = threadIdx.x % GS_WAVE, wave = threadIdx.x / GS_WAVE;
         const uint32_t wave_n0 = blockIdx.x * GS_BLOCK + wave * GS_WAVE;
+        if (split) {
+            // two gradient tensors: v_coeffs [N,1,3] and v_coeffs_rest [N,K-1,3].  Same idea: a full wave stages its 64 rows
+            // in LDS (row stride 3 / RL - 3 floats: odd, conflict-free) and writes each tensor's 64 rows as one contiguous block
+            constexpr int R1 = RL - 3;
+            const uint32_t rest_len = row_len - 3u;
+            if (CAN_T && R1 > 0 && rest_len == (uint32_t)R1 && wave_n0 + GS_WAVE <= N) { // wave-uniform
+                float *w = reinterpret_cast<float *>(s_tr + wave * GS_WAVE * (RL / 4));
+#pragma unroll
+                for (int i = 0; i < 3; ++i) w[lane * 3 + i] = acc[i];
+#pragma unroll
+                for (int i = 0; i < R1; ++i) w[GS_WAVE * 3 + lane * R1 + i] = acc[3 + i];
+                __builtin_amdgcn_wave_barrier();
+                const float4 *w4 = reinterpret_cast<const float4 *>(w);
+                float4 *d0 = reinterpret_cast<float4 *>(v_coeffs + (size_t)wave_n0 * 3);
+                if (lane < GS_WAVE * 3 / 4) d0[lane] = w4[lane];
+                float4 *d1 = reinterpret_cast<float4 *>(view.v_coeffs_rest + (size_t)wave_n0 * R1);
+                constexpr int N4 = GS_WAVE * R1 / 4; // (64 * R1 is a multiple of 4)
+#pragma unroll
+                for (int i = 0; i < (N4 + GS_WAVE - 1) / GS_WAVE; ++i)
+                    if (i * GS_WAVE + (int)lane < N4) d1[i * GS_WAVE + lane] = w4[GS_WAVE * 3 / 4 + i * GS_WAVE + lane];
+            } else {
+                float *o0 = v_coeffs + 3 * (size_t)n;
+                o0[0] = acc[0]; o0[1] = acc[1]; o0[2] = acc[2];
+                float *o1 = view.v_coeffs_rest + (size_t)n * rest_len;
+#pragma unroll
+                for (int i = 0; i < R1; ++i) o1[i] = acc[3 + i];
+                for (uint32_t i = R1; i < rest_len; ++i) o1[i] = 0.f;
+            }
+        } else
         if (CAN_T && row_len == (uint32_t)RL && wave_n0 + GS_WAVE <= N) { // wave-uniform
             constexpr int NV = RL / 4;
             float4 *w = s_tr + wave * GS_WAVE * NV;
@@ -323,7 +358,7 @@ extern "C" int32_t gs_sh_fwd(
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K);
-    ShView view = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0u, nullptr, 3u};
+    ShView view = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 3u};
     switch (degree) {
         case 0: launch_fwd<0>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
         case 1: launch_fwd<1>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
@@ -352,8 +387,8 @@ extern "C" int32_t gs_camera_centers(uint32_t C, const float *viewmats, float *c
 
 extern "C" int32_t gs_sh_view_fwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos, int32_t campos_from_viewmats,
-    const float *coeffs, const int32_t *radii, float *colors, uint32_t colors_stride, const float *opacities, float *opacities_cn,
-    gs_stream_t stream) {
+    const float *coeffs, const float *coeffs_rest, const int32_t *radii, float *colors, uint32_t colors_stride, const float *opacities,
+    float *opacities_cn, gs_stream_t stream) {
     if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && campos && coeffs && colors, "null pointer");
     GS_CHECK_ARG(colors_stride >= 3, "colors_stride must be >= 3");
@@ -361,8 +396,9 @@ extern "C" int32_t gs_sh_view_fwd(
     GS_CHECK_ARG((degree + 1) * (degree + 1) <= K, "K too small for degree");
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipStream_t st = (hipStream_t)stream;
-    bool vec = rows_vectorizable(coeffs, K);
-    ShView view = {means, campos, radii, 1, campos_from_viewmats, opacities, opacities_cn, nullptr, 0u, nullptr, colors_stride};
+    bool vec = coeffs_rest != nullptr ? (K * 3) % 4 == 0 : rows_vectorizable(coeffs, K);
+    GS_CHECK_ARG(coeffs_rest == nullptr || K >= 2, "split coefficients need K >= 2");
+    ShView view = {means, campos, radii, 1, campos_from_viewmats, opacities, opacities_cn, nullptr, 0u, nullptr, coeffs_rest, nullptr, colors_stride};
     GS_CHECK_ARG((opacities == nullptr) == (opacities_cn == nullptr), "opacities and opacities_cn go together");
     switch (degree) {
         case 0: launch_fwd<0>(vec, grid, st, C, N, K, nullptr, coeffs, 1, nullptr, colors, view); break;
@@ -388,7 +424,7 @@ extern "C" int32_t gs_sh_bwd(
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K) && rows_vectorizable(v_coeffs, K);
     bool shared = coeffs_shared != 0;
-    ShView view = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0u, nullptr, 3u};
+    ShView view = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 3u};
     switch (degree) {
         case 0: launch_bwd<0>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
         case 1: launch_bwd<1>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
@@ -402,8 +438,8 @@ extern "C" int32_t gs_sh_bwd(
 
 extern "C" int32_t gs_sh_view_bwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos, int32_t campos_from_viewmats,
-    const float *coeffs, const int32_t *radii, const float *colors_out, uint32_t colors_out_stride, const float *v_colors,
-    uint32_t v_colors_stride, float *v_coeffs, float *v_means, const float *v_opacities_cn, uint32_t v_opacities_stride,
+    const float *coeffs, const float *coeffs_rest, const int32_t *radii, const float *colors_out, uint32_t colors_out_stride,
+    const float *v_colors, uint32_t v_colors_stride, float *v_coeffs, float *v_coeffs_rest, float *v_means, const float *v_opacities_cn, uint32_t v_opacities_stride,
     float *v_opacities, gs_stream_t stream) {
     if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && campos && coeffs && colors_out && v_colors && v_coeffs, "null pointer");
@@ -413,7 +449,12 @@ extern "C" int32_t gs_sh_view_bwd(
     dim3 grid(gs_div_up(N, GS_BLOCK));
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K) && rows_vectorizable(v_coeffs, K);
-    ShView view = {means, campos, radii, 1, campos_from_viewmats, nullptr, nullptr, v_opacities_cn, v_opacities_stride, v_opacities, colors_out_stride};
+    GS_CHECK_ARG((coeffs_rest == nullptr) == (v_coeffs_rest == nullptr), "coeffs_rest and v_coeffs_rest go together");
+    if (coeffs_rest != nullptr) { // split rows: the staged wave stores need 16-byte aligned gradient tensors and 3K % 4 == 0
+        GS_CHECK_ARG(K >= 2, "split coefficients need K >= 2");
+        vec = (K * 3) % 4 == 0 && (uintptr_t)v_coeffs % 16 == 0 && (uintptr_t)v_coeffs_rest % 16 == 0;
+    }
+    ShView view = {means, campos, radii, 1, campos_from_viewmats, nullptr, nullptr, v_opacities_cn, v_opacities_stride, v_opacities, coeffs_rest, v_coeffs_rest, colors_out_stride};
     GS_CHECK_ARG((v_opacities_cn == nullptr) == (v_opacities == nullptr), "v_opacities_cn and v_opacities go together");
     switch (degree) {
         case 0: launch_bwd<0>(vec, true, grid, st, C, N, K, nullptr, coeffs, nullptr, v_colors, v_coeffs, nullptr, view, colors_out, v_colors_stride, v_means); break;

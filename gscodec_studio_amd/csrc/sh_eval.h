@@ -90,11 +90,40 @@ GS_DEV void camera_center(const float *__restrict__ V, float &x, float &y, float
     z = -(r20 * t0 + r21 * t1 + r22 * t2) * inv;
 }
 
+// SPLIT coefficient rows: the trainers keep the DC band and the higher bands as two parameters, sh0 [N,1,3] and shN [N,K-1,3]
+// (reference examples/simple_trainer.py:779-786 concatenates them before every render: 193 MB each way at 1 M splats, and
+// autograd splits the gradient again).  The kernels take the two tensors as they are: the first 3 floats of a row come from
+// `row`, the rest from `rest` (rows of 3 (K-1) floats: only 4-byte aligned, read with dword-aligned 16-byte loads).
+struct __attribute__((packed, aligned(4))) float4_a4 {
+    float x, y, z, w;
+};
+
+template <int CNT, bool VEC>
+GS_DEV void load_coeff_row(const float *__restrict__ row, const float *__restrict__ rest, float *dst) {
+    if (rest == nullptr) { // (uniform) one contiguous row
+        load_floats<CNT, VEC>(row, dst);
+        return;
+    }
+    dst[0] = row[0];
+    if (CNT > 1) dst[CNT > 1 ? 1 : 0] = row[1];
+    if (CNT > 2) dst[CNT > 2 ? 2 : 0] = row[2];
+    constexpr int R = CNT > 3 ? CNT - 3 : 0;
+    constexpr int NV = R / 4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4_a4 v = reinterpret_cast<const float4_a4 *>(rest)[i];
+        dst[3 + 4 * i] = v.x; dst[3 + 4 * i + 1] = v.y; dst[3 + 4 * i + 2] = v.z; dst[3 + 4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = NV * 4; i < R; ++i) dst[3 + i] = rest[i];
+}
+
 // clamp_min(SH colour + 0.5, 0) of ONE splat seen from direction (dx, dy, dz) (not normalised), coefficient row `row`
 // ([K,3], the first (DEG+1)^2 bands are used): the arithmetic of sh_fwd_kernel's view mode, shared so that the projection's
 // fused colour is bit-identical to gs_sh_view_fwd's.
 template <int DEG, bool VEC>
-GS_DEV void sh_view_color(float dx, float dy, float dz, const float *__restrict__ row, bool clamp_half, float &r, float &g, float &b) {
+GS_DEV void sh_view_color(float dx, float dy, float dz, const float *__restrict__ row, const float *__restrict__ rest, bool clamp_half,
+                          float &r, float &g, float &b) {
     constexpr int NB = ShDim<DEG>::NB;
     float Y[NB];
     if (DEG >= 1) {
@@ -104,7 +133,7 @@ GS_DEV void sh_view_color(float dx, float dy, float dz, const float *__restrict_
         sh_basis<0>(0.f, 0.f, 1.f, Y);
     }
     float cf[NB * 3];
-    load_floats<NB * 3, VEC>(row, cf);
+    load_coeff_row<NB * 3, VEC>(row, rest, cf);
     r = g = b = 0.f;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {

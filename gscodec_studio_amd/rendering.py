@@ -73,7 +73,7 @@ def rasterization(
     quats: Tensor,  # [N, 4]
     scales: Tensor,  # [N, 3]
     opacities: Tensor,  # [N]
-    colors: Tensor,  # [(C,) N, D] or [(C,) N, K, 3]
+    colors,  # Tensor [(C,) N, D] or [(C,) N, K, 3]; or the pair (sh0 [N, 1, 3], shN [N, K-1, 3]) with sh_degree
     viewmats: Tensor,  # [C, 4, 4]
     Ks: Tensor,  # [C, 3, 3]
     width: int,
@@ -132,6 +132,20 @@ def rasterization(
     assert viewmats.shape == (C, 4, 4), viewmats.shape
     assert Ks.shape == (C, 3, 3), Ks.shape
     assert render_mode in ["RGB", "D", "ED", "RGB+D", "RGB+ED"], render_mode
+    # Opt-in beyond the reference's signature: SH coefficients as the PAIR (sh0, shN) the trainers keep as separate parameters
+    # (reference examples/simple_trainer.py:779-786 concatenates them before every render: 193 MB each way at 1 M splats, and
+    # autograd splits the gradient again).  The fused route takes the two tensors as they are; every other route gets the cat.
+    sh_rest = None
+    if isinstance(colors, (tuple, list)):
+        assert sh_degree is not None and len(colors) == 2, "a (sh0, shN) pair needs sh_degree"
+        sh0, shN = colors
+        assert sh0.shape == (N, 1, 3) and shN.dim() == 3 and shN.shape[0] == N and shN.shape[2] == 3, (sh0.shape, shN.shape)
+        split_ok = ((not packed) and (not distributed) and means.is_cuda and viewmats.is_cuda and not viewmats.requires_grad
+                    and shN.shape[1] >= 1)
+        if split_ok:
+            colors, sh_rest = sh0, shN
+        else:
+            colors = torch.cat([sh0, shN], dim=1)
     # the compositing kernels map a tile onto wave64 quadrants of 8x8 pixels: tiles up to 16x16 (the reference launches
     # tile_size^2 threads per block, i.e. accepts up to 32; every caller in the reference uses 16).  Checked here, before
     # projection and binning run, instead of surfacing as a native error afterwards.
@@ -149,7 +163,7 @@ def rasterization(
         assert (colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3) or (
             colors.dim() == 4 and colors.shape[:2] == (C, N) and colors.shape[3] == 3
         ), colors.shape
-        assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
+        assert (sh_degree + 1) ** 2 <= colors.shape[-2] + (sh_rest.shape[1] if sh_rest is not None else 0), colors.shape
         if distributed:
             assert colors.dim() == 3, "Distributed mode only supports per-Gaussian colors."
 
@@ -193,7 +207,7 @@ def rasterization(
             eps2d=eps2d, near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip,
             antialiased=(rasterize_mode == "antialiased"), camera_model=camera_model,
             # shared SH coefficients and fixed poses: the colours are evaluated by the projection pass itself
-            sh_coeffs=colors if fuse_sh else None, sh_degree=sh_degree if fuse_sh else None,
+            sh_coeffs=colors if fuse_sh else None, sh_degree=sh_degree if fuse_sh else None, sh_rest=sh_rest,
         )
         camera_ids, gaussian_ids = None, None
         opacity_rider = False

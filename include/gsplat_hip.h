@@ -152,7 +152,8 @@ int32_t gs_projection_rows_fwd(
     float eps2d, float near_plane, float far_plane, float radius_clip,
     int32_t camera_model,
     const float *opacities, const float *colors, int32_t antialiased,
-    const float *sh_coeffs, uint32_t sh_K, uint32_t sh_degree,
+    const float *sh_coeffs, const float *sh_coeffs_rest /* NULL or split rows, as in gs_sh_view_fwd */, uint32_t sh_K,
+    uint32_t sh_degree,
     int32_t *radii, /* [C,N] */
     float *depths,  /* [C,N] */
     float *rows,    /* [C,N,16] */
@@ -263,14 +264,19 @@ int32_t gs_sh_bwd(
 int32_t gs_camera_centers(uint32_t C, const float *viewmats, float *campos, gs_stream_t stream);
 int32_t gs_sh_view_fwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree,
-    const float *means, const float *campos, int32_t campos_from_viewmats, const float *coeffs, const int32_t *radii,
+    const float *means, const float *campos, int32_t campos_from_viewmats, const float *coeffs,
+    const float *coeffs_rest /* NULL, or SPLIT rows: coeffs is the DC band [N,1,3] and this the higher bands [N,K-1,3] -- the
+                                trainer's sh0 / shN parameters taken as they are, without the torch.cat of
+                                examples/simple_trainer.py:779-786 (193 MB each way at 1 M splats) */,
+    const int32_t *radii,
     float *colors, uint32_t colors_stride /* row stride in floats: 3, or GS_ROW_FLOATS when `colors` is column GS_ROW_COLOR of the splat rows */,
     const float *opacities /* [N] or NULL */, float *opacities_cn /* [C,N] or NULL */, gs_stream_t stream);
 int32_t gs_sh_view_bwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree,
-    const float *means, const float *campos, int32_t campos_from_viewmats, const float *coeffs, const int32_t *radii,
+    const float *means, const float *campos, int32_t campos_from_viewmats, const float *coeffs, const float *coeffs_rest,
+    const int32_t *radii,
     const float *colors_out, uint32_t colors_out_stride, const float *v_colors, uint32_t v_colors_stride,
-    float *v_coeffs, float *v_means,
+    float *v_coeffs, float *v_coeffs_rest /* [N,K-1,3] with coeffs_rest, else NULL */, float *v_means,
     const float *v_opacities_cn /* or NULL */, uint32_t v_opacities_stride, float *v_opacities /* [N] or NULL */,
     gs_stream_t stream);
 

@@ -432,3 +432,42 @@ def test_repeated_backward_and_means_gradient_routes():
     gg, gs = torch.autograd.grad((rc_b * w).sum() + ra_b.sum(), [m_geo, m_sh])
     assert rel_l2(N(g1[0]), N(gg + gs)) < 1e-4
     assert float(gs.abs().max()) > 0
+
+
+@pytest.mark.parametrize("sh_degree,K", [(3, 16), (2, 16), (1, 4), (0, 2)])
+def test_split_sh_coefficients_match_the_concatenated_tensor(sh_degree, K):
+    """Opt-in beyond the reference's signature: ``colors=(sh0, shN)`` -- the two parameters the trainers keep (reference
+    examples/simple_trainer.py:779-786 concatenates them before every render) -- gives the image of ``torch.cat([sh0, shN], 1)``
+    bit for bit, and the gradients of the two tensors are the two slices of the concatenated tensor's gradient.  Partial
+    bands (K > (deg + 1)^2) and an N that is no multiple of the wave size exercise the unstaged store path; routes that
+    cannot take the pair (packed) fall back to the cat."""
+    from gscodec_studio_amd import rasterization
+
+    d = _inputs(n=3001, cams=2, sh_degree=3)
+    sh = d["colors"][:, :K].copy()
+    base = [T(d[k]) for k in ("means", "quats", "scales", "opacities")]
+    vm, Ks = T(d["viewmats"]), T(d["Ks"])
+    w = torch.linspace(0.5, 1.5, 2 * d["H"] * d["W"] * 3, device="cuda").reshape(2, d["H"], d["W"], 3)
+
+    def run(colors, packed=False):
+        ps = [t.clone().requires_grad_(True) for t in base]
+        rc, ra, _ = rasterization(*ps, colors, vm, Ks, d["W"], d["H"], sh_degree=sh_degree, packed=packed)
+        ((rc * w).sum() + ra.sum()).backward()
+        return rc.detach(), ra.detach(), ps
+
+    cat = T(sh).requires_grad_(True)
+    rc0, ra0, ps0 = run(cat)
+    sh0, shN = T(sh[:, :1]).requires_grad_(True), T(sh[:, 1:]).requires_grad_(True)
+    rc1, ra1, ps1 = run((sh0, shN))
+    assert torch.equal(rc1, rc0) and torch.equal(ra1, ra0)
+    # (the compositing backward adds with float atomics: its sums differ in the last bits from run to run)
+    assert rel_l2(N(sh0.grad), N(cat.grad[:, :1])) < 1e-5 and rel_l2(N(shN.grad), N(cat.grad[:, 1:])) < 1e-5
+    n_act = (sh_degree + 1) ** 2
+    assert float(shN.grad[:, n_act - 1:].abs().max() if n_act - 1 < K - 1 else 0.0) == 0.0  # inactive bands: exact zeros
+    for a, b in zip(ps1, ps0):
+        assert rel_l2(N(a.grad), N(b.grad)) < 1e-5
+    # a route that cannot take the pair falls back to the concatenation
+    sh0p, shNp = T(sh[:, :1]).requires_grad_(True), T(sh[:, 1:]).requires_grad_(True)
+    rc2, _, _ = run((sh0p, shNp), packed=True)
+    rc3, _, _ = run(T(sh).requires_grad_(True), packed=True)
+    assert torch.equal(rc2, rc3) and sh0p.grad is not None and shNp.grad is not None
