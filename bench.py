@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--quantize", action="store_true", help="run the compression-simulation hooks before each render")
+    ap.add_argument("--quantize-reference-calls", action="store_true",
+                    help="with --quantize: the reference trainer's exact call pattern (torch.exp / torch.sigmoid / torch.cat after the "
+                         "hooks, simple_trainer.py:779-786) instead of the opt-in fused form (activate=True, colors=(sh0, shN))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scene-grid", type=int, default=0,
                     help="scene_grid of the cpu_baseline sample (0 = the bench scene itself: ~3 s per pass on 128 threads)")
@@ -297,10 +300,15 @@ def main():
         def step():
             for p in params.values():
                 p.grad = None
-            if sim is not None:
+            if sim is not None and args.quantize_reference_calls:
                 q, _ = sim.simulate_compression({k: params[k] for k in ("scales", "quats", "opacities", "sh0", "shN")}, step=0)
                 quats, scales, opac = q["quats"], torch.exp(q["scales"]), torch.sigmoid(q["opacities"])
                 sh = torch.cat([q["sh0"], q["shN"]], dim=1)
+            elif sim is not None:
+                # the opt-in fused form: activations inside the quantizer kernels, sh0 / shN handed over as they are
+                q, _ = sim.simulate_compression({k: params[k] for k in ("scales", "quats", "opacities", "sh0", "shN")}, step=0,
+                                                activate=True)
+                quats, scales, opac, sh = q["quats"], q["scales"], q["opacities"], (q["sh0"], q["shN"])
             else:
                 quats, scales, opac, sh = params["quats"], params["scales"], params["opacities"], params["sh"]
             rc, ra, meta = rasterization(params["means"], quats, scales, opac, sh, viewmats, Ks,
@@ -458,7 +466,7 @@ def main():
             "config": {
                 "workload": f"BASELINE config 2: load_test_data(scene_grid={args.scene_grid}) -> {N} gaussians, "
                             f"SH degree {args.sh_degree}, {world}x1 camera {w['width']}x{w['height']}, packed=False, "
-                            f"tile 16, fwd + bwd of sum(render)" + (", quantize hooks on" if args.quantize else ""),
+                            f"tile 16, fwd + bwd of sum(render)" + ((", quantize hooks on" + (" (reference call pattern)" if args.quantize_reference_calls else " (fused activations, split SH)")) if args.quantize else ""),
                 "visible": stats["V"], "n_isects": stats["I"], "parallelism": (f"camera-sharded dp{world}" + ((", RCCL sum of splat gradients" + (" (visible rows only)" if mode == "camera_sparse" else "")) if world > 1 else "")) if mode.startswith("camera")
                 else f"gaussian-sharded x{world}, 1 camera per rank, all-to-all of projected splats + dual for gradients"
                      + (" (visible rows only)" if mode == "gaussian" else " (all rows)"),

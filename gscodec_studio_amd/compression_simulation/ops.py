@@ -30,30 +30,33 @@ def _f32(v: float) -> float:
     return float(np.float32(v))
 
 
+_ACTS = {None: 0, "exp": 1, "sigmoid": 2}  # GS_ACT_* of include/gsplat_hip.h
+
+
 class _NoiseQuant(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: Tensor, noise: Tensor, lo: float, hi: float, q_step: float) -> Tensor:
+    def forward(ctx, x: Tensor, noise: Tensor, lo: float, hi: float, q_step: float, act: int = 0) -> Tensor:
         _require_gpu(x, "fake_quantize_ste")
         if x.dtype != torch.float32:
             raise RuntimeError(f"fake_quantize_ste: expected float32, got {x.dtype}")
         xc = x.contiguous()
         out = torch.empty_like(xc)
         with _device_of(xc):
-            B.call("gs_quantize_noise_fwd", xc.numel(), B.ptr(xc), B.ptr(noise), _f32(lo), _f32(hi), _f32(q_step),
+            B.call("gs_quantize_noise_fwd", xc.numel(), B.ptr(xc), B.ptr(noise), _f32(lo), _f32(hi), _f32(q_step), act,
                    B.ptr(out), _stream(xc))
-        ctx.save_for_backward(xc)
-        ctx.bounds = (_f32(lo), _f32(hi))
+        ctx.save_for_backward(xc, out if act else None)
+        ctx.bounds, ctx.act = (_f32(lo), _f32(hi)), act
         return out.view(x.shape)
 
     @staticmethod
     def backward(ctx, v_out: Tensor):
-        (xc,) = ctx.saved_tensors
+        xc, out = ctx.saved_tensors
         lo, hi = ctx.bounds
         v_out = v_out.contiguous()
         v_x = torch.empty_like(xc)
         with _device_of(xc):
-            B.call("gs_quantize_noise_bwd", xc.numel(), B.ptr(xc), B.ptr(v_out), lo, hi, B.ptr(v_x), _stream(xc))
-        return v_x.view(v_out.shape), None, None, None, None
+            B.call("gs_quantize_noise_bwd", xc.numel(), B.ptr(xc), B.ptr(v_out), lo, hi, ctx.act, B.ptr(out), B.ptr(v_x), _stream(xc))
+        return v_x.view(v_out.shape), None, None, None, None, None
 
 
 class STE(torch.autograd.Function):
@@ -63,7 +66,7 @@ class STE(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, input: Tensor, bitdepth: int = 8, min: float = -1, max: float = 1) -> Tensor:
+    def forward(ctx, input: Tensor, bitdepth: int = 8, min: float = -1, max: float = 1, act: int = 0) -> Tensor:
         _require_gpu(input, "STE")
         if input.dtype != torch.float32:
             raise RuntimeError(f"STE: expected float32, got {input.dtype}")
@@ -73,25 +76,38 @@ class STE(torch.autograd.Function):
         rng = _f32(max - min)  # python arithmetic first, then fp32, as torch does
         qn = _f32(1 / (2**bitdepth - 1))
         with _device_of(input):
-            B.call("gs_quantize_round_fwd", input.numel(), B.ptr(input), _f32(min), _f32(max), rng, qn, B.ptr(out),
+            B.call("gs_quantize_round_fwd", input.numel(), B.ptr(input), _f32(min), _f32(max), rng, qn, act, B.ptr(out),
                    _stream(input))
-
+        ctx.act = act
+        if act:
+            ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, grad_output: Tensor):
-        return grad_output, None, None, None
+        if not ctx.act:
+            return grad_output, None, None, None, None  # identity, everywhere (ops.py:73-75)
+        (out,) = ctx.saved_tensors
+        g = grad_output.contiguous()
+        v_x = torch.empty_like(out)
+        with _device_of(out):
+            B.call("gs_quantize_round_bwd", out.numel(), B.ptr(g), ctx.act, B.ptr(out), B.ptr(v_x), _stream(out))
+        return v_x, None, None, None, None
 
 
 def fake_quantize_ste(input: Tensor, lower_bd: float, upper_bd: float, bitwidth: int = 8,
-                      q_type: str = "noise") -> Dict[str, object]:
+                      q_type: str = "noise", activation: str = None) -> Dict[str, object]:
+    """``activation`` (opt-in, not in the reference): "exp" / "sigmoid" -- the activation the trainer applies to the hooked
+    value right afterwards (reference examples/simple_trainer.py:779-786), evaluated in the quantizer's own pass; the
+    returned ``output_value`` is then ALREADY activated.  The noise is drawn exactly as without it."""
     q_step = (upper_bd - lower_bd) / (2**bitwidth - 1)
+    act = _ACTS[activation]
 
     if q_type == "round":
-        output_value = STE.apply(input, bitwidth, lower_bd, upper_bd)
+        output_value = STE.apply(input, bitwidth, lower_bd, upper_bd, act)
     elif q_type == "noise":
         noise = torch.empty_like(input, memory_format=torch.contiguous_format).uniform_(-0.5, 0.5)
-        output_value = _NoiseQuant.apply(input, noise, lower_bd, upper_bd, q_step)
+        output_value = _NoiseQuant.apply(input, noise, lower_bd, upper_bd, q_step, act)
 
     out_dict = {
         "output_value": output_value,  # UnboundLocalError for unknown q_type, like the reference

@@ -55,6 +55,11 @@ class _SimulationBase:
                 [{"params": p, "lr": 1e-4, "name": n} for n, p in m.named_parameters()])
             self.entropy_model_schedulers[k] = None
 
+    # the activations the trainers apply to the hooked values (reference examples/simple_trainer.py:779-786,
+    # simple_trainer_dyngs.py:506-521): opt-in fusion into the quantizer pass, see simulate_compression(activate=True)
+    ACTIVATIONS = {"scales": "exp", "opacities": "sigmoid"}
+    _activate = False
+
     def _quantize(self, name: str, param: Tensor, step: int = 0, as_channels=None) -> Tuple[Tensor, Optional[Tensor]]:
         """fake-quantize ``param``; past ``entropy_steps[name]`` also estimate its bits.
         ``as_channels``: reshape of the quantized value to the model's [N, C] input (and back)."""
@@ -62,19 +67,37 @@ class _SimulationBase:
         # both sides of the reference's `step < 10_000` branch select 8 bits
         # (simulation.py:242-245): the schedule is a no-op and q_bitwidth[name] is used.
         bits = self.q_bitwidth[name]
+        estimate = (self.entropy_model_enable and self.entropy_model_option.get(name, False)
+                    and step > self.entropy_steps[name] and self.entropy_models.get(name) is not None)
+        act = self.ACTIVATIONS.get(name) if self._activate else None
+        fused = act if not estimate else None  # (the bits estimator needs the quantized value itself: activate afterwards)
         if self.q_type is None:
-            out = fake_quantize_ste(param, lo, hi, bits)  # default q_type="noise"
+            out = fake_quantize_ste(param, lo, hi, bits, activation=fused)  # default q_type="noise"
         else:
-            out = fake_quantize_ste(param, lo, hi, bits, self.q_type)
+            out = fake_quantize_ste(param, lo, hi, bits, self.q_type, activation=fused)
         value = out["output_value"]
-        if (self.entropy_model_enable and self.entropy_model_option.get(name, False)
-                and step > self.entropy_steps[name] and self.entropy_models.get(name) is not None):
+        if estimate:
             x = value if as_channels is None else as_channels(value)
-            return value, self.entropy_models[name](x, out["q_step"])
+            bits_est = self.entropy_models[name](x, out["q_step"])
+            if act is not None:
+                value = torch.exp(value) if act == "exp" else torch.sigmoid(value)
+            return value, bits_est
         return value, None
 
-    def simulate_compression(self, splats: Dict[str, Tensor], step: int):
-        """Returns (new_splats, esti_bits_dict); un-simulated attributes come back as ``p + 0.``"""
+    def simulate_compression(self, splats: Dict[str, Tensor], step: int, activate: bool = False):
+        """Returns (new_splats, esti_bits_dict); un-simulated attributes come back as ``p + 0.``
+
+        ``activate=True`` (opt-in, not in the reference): ``new_splats["scales"]`` / ``["opacities"]`` come back ALREADY
+        activated (exp / sigmoid, what the trainer applies next), evaluated inside the quantizer kernels -- two elementwise
+        passes and their backward passes less per step; together with ``rasterization(colors=(sh0, shN))`` this is the
+        fused form of the reference's ``simple_trainer.py:779-800``."""
+        self._activate = bool(activate)
+        try:
+            return self._simulate(splats, step)
+        finally:
+            self._activate = False
+
+    def _simulate(self, splats: Dict[str, Tensor], step: int):
         new_splats, esti_bits = {}, {}
         for name in splats.keys():
             if self.simulation_option[name]:

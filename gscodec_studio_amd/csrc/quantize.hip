@@ -24,12 +24,29 @@ GS_DEV float q_noise(float x, float nz, float lo, float hi, float q_step) {
     return __fadd_rn(q_clamp(x, lo, hi), __fmul_rn(nz, q_step));
 }
 
+// Opt-in fusion: the activation the trainer applies right after the hook -- torch.exp for the log-scales,
+// torch.sigmoid for the opacity logits (reference examples/simple_trainer.py:779-786) -- evaluated in the quantizer's own
+// pass; the backward multiplies by its derivative, read off the activated output.  ACT 0 = none (bit-exact reference path).
+template <int ACT>
+GS_DEV float q_act(float v) {
+    if (ACT == GS_ACT_EXP) return expf(v);
+    if (ACT == GS_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    return v;
+}
+template <int ACT>
+GS_DEV float q_act_grad(float out, float v) { // d act / d pre-activation, from the activated value
+    if (ACT == GS_ACT_EXP) return v * out;
+    if (ACT == GS_ACT_SIGMOID) return v * out * (1.f - out);
+    return v;
+}
+
 GS_DEV float q_round(float xc, float lo, float range, float qn) {
     float norm = __fdiv_rn(__fsub_rn(xc, lo), range);
     float lvl = rintf(__fdiv_rn(norm, qn)); // round half to even, as torch.round
     return __fadd_rn(__fmul_rn(__fmul_rn(lvl, qn), range), lo);
 }
 
+template <int ACT>
 __global__ void __launch_bounds__(GS_BLOCK) quant_noise_fwd_kernel(
     uint64_t n, const float *__restrict__ x, const float *__restrict__ noise, float lo, float hi,
     float q_step, float *__restrict__ out, int vec_ok) {
@@ -40,13 +57,13 @@ __global__ void __launch_bounds__(GS_BLOCK) quant_noise_fwd_kernel(
         float4 a = reinterpret_cast<const float4 *>(x)[i];
         float4 z = reinterpret_cast<const float4 *>(noise)[i];
         float4 r;
-        r.x = q_noise(a.x, z.x, lo, hi, q_step);
-        r.y = q_noise(a.y, z.y, lo, hi, q_step);
-        r.z = q_noise(a.z, z.z, lo, hi, q_step);
-        r.w = q_noise(a.w, z.w, lo, hi, q_step);
+        r.x = q_act<ACT>(q_noise(a.x, z.x, lo, hi, q_step));
+        r.y = q_act<ACT>(q_noise(a.y, z.y, lo, hi, q_step));
+        r.z = q_act<ACT>(q_noise(a.z, z.z, lo, hi, q_step));
+        r.w = q_act<ACT>(q_noise(a.w, z.w, lo, hi, q_step));
         reinterpret_cast<float4 *>(out)[i] = r;
     }
-    for (uint64_t i = nv * Q_VEC + t; i < n; i += stride) out[i] = q_noise(x[i], noise[i], lo, hi, q_step);
+    for (uint64_t i = nv * Q_VEC + t; i < n; i += stride) out[i] = q_act<ACT>(q_noise(x[i], noise[i], lo, hi, q_step));
 }
 
 GS_DEV float q_mask(float x, float v, float lo, float hi) {
@@ -54,25 +71,39 @@ GS_DEV float q_mask(float x, float v, float lo, float hi) {
     return (x >= lo && x <= hi) ? v : 0.f;
 }
 
+// MASK: the clamp's gradient gate of the noise mode (the round mode passes gradients everywhere, ops.py:73-75)
+template <int ACT, bool MASK>
 __global__ void __launch_bounds__(GS_BLOCK) quant_noise_bwd_kernel(
-    uint64_t n, const float *__restrict__ x, const float *__restrict__ v_out, float lo, float hi,
+    uint64_t n, const float *__restrict__ x, const float *__restrict__ v_out, const float *__restrict__ out, float lo, float hi,
     float *__restrict__ v_x, int vec_ok) {
     uint64_t stride = (uint64_t)gridDim.x * GS_BLOCK;
     uint64_t t = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
     uint64_t nv = vec_ok ? n / Q_VEC : 0;
     for (uint64_t i = t; i < nv; i += stride) {
-        float4 a = reinterpret_cast<const float4 *>(x)[i];
+        float4 a = MASK ? reinterpret_cast<const float4 *>(x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 g = reinterpret_cast<const float4 *>(v_out)[i];
-        float4 r;
-        r.x = q_mask(a.x, g.x, lo, hi);
-        r.y = q_mask(a.y, g.y, lo, hi);
-        r.z = q_mask(a.z, g.z, lo, hi);
-        r.w = q_mask(a.w, g.w, lo, hi);
+        if (ACT != 0) {
+            const float4 o = reinterpret_cast<const float4 *>(out)[i];
+            g.x = q_act_grad<ACT>(o.x, g.x); g.y = q_act_grad<ACT>(o.y, g.y);
+            g.z = q_act_grad<ACT>(o.z, g.z); g.w = q_act_grad<ACT>(o.w, g.w);
+        }
+        float4 r = g;
+        if (MASK) {
+            r.x = q_mask(a.x, g.x, lo, hi);
+            r.y = q_mask(a.y, g.y, lo, hi);
+            r.z = q_mask(a.z, g.z, lo, hi);
+            r.w = q_mask(a.w, g.w, lo, hi);
+        }
         reinterpret_cast<float4 *>(v_x)[i] = r;
     }
-    for (uint64_t i = nv * Q_VEC + t; i < n; i += stride) v_x[i] = q_mask(x[i], v_out[i], lo, hi);
+    for (uint64_t i = nv * Q_VEC + t; i < n; i += stride) {
+        float g = v_out[i];
+        if (ACT != 0) g = q_act_grad<ACT>(out[i], g);
+        v_x[i] = MASK ? q_mask(x[i], g, lo, hi) : g;
+    }
 }
 
+template <int ACT>
 __global__ void __launch_bounds__(GS_BLOCK) quant_round_fwd_kernel(
     uint64_t n, float *__restrict__ x, float lo, float hi, float range, float qn,
     float *__restrict__ out, int vec_ok) {
@@ -85,14 +116,14 @@ __global__ void __launch_bounds__(GS_BLOCK) quant_round_fwd_kernel(
         a.z = q_clamp(a.z, lo, hi); a.w = q_clamp(a.w, lo, hi);
         reinterpret_cast<float4 *>(x)[i] = a; // in-place clamp of the parameter (ops.py:63)
         float4 r;
-        r.x = q_round(a.x, lo, range, qn); r.y = q_round(a.y, lo, range, qn);
-        r.z = q_round(a.z, lo, range, qn); r.w = q_round(a.w, lo, range, qn);
+        r.x = q_act<ACT>(q_round(a.x, lo, range, qn)); r.y = q_act<ACT>(q_round(a.y, lo, range, qn));
+        r.z = q_act<ACT>(q_round(a.z, lo, range, qn)); r.w = q_act<ACT>(q_round(a.w, lo, range, qn));
         reinterpret_cast<float4 *>(out)[i] = r;
     }
     for (uint64_t i = nv * Q_VEC + t; i < n; i += stride) {
         float a = q_clamp(x[i], lo, hi);
         x[i] = a;
-        out[i] = q_round(a, lo, range, qn);
+        out[i] = q_act<ACT>(q_round(a, lo, range, qn));
     }
 }
 
@@ -154,34 +185,62 @@ __global__ void __launch_bounds__(GS_BLOCK) grid_dequantize_kernel(uint64_t n, u
 
 } // namespace
 
+#define GS_ACT_DISPATCH(act, CALL)                                              \
+    switch (act) {                                                             \
+        case GS_ACT_NONE: { constexpr int A = GS_ACT_NONE; CALL; } break;      \
+        case GS_ACT_EXP: { constexpr int A = GS_ACT_EXP; CALL; } break;        \
+        default: { constexpr int A = GS_ACT_SIGMOID; CALL; } break;            \
+    }
+
 extern "C" int32_t gs_quantize_noise_fwd(
-    uint64_t n, const float *x, const float *noise, float lo, float hi, float q_step, float *out,
+    uint64_t n, const float *x, const float *noise, float lo, float hi, float q_step, int32_t activation, float *out,
     gs_stream_t stream) {
     if (n == 0) return 0;
     GS_CHECK_ARG(x && noise && out, "null pointer");
-    hipLaunchKernelGGL(quant_noise_fwd_kernel, dim3(stream_grid(n)), dim3(GS_BLOCK), 0, (hipStream_t)stream, n, x,
-                       noise, lo, hi, q_step, out, (int)aligned16(x, noise, out));
+    GS_CHECK_ARG(activation >= GS_ACT_NONE && activation <= GS_ACT_SIGMOID, "unknown activation");
+    const int vec = (int)aligned16(x, noise, out);
+    GS_ACT_DISPATCH(activation, hipLaunchKernelGGL(quant_noise_fwd_kernel<A>, dim3(stream_grid(n)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
+                                                   n, x, noise, lo, hi, q_step, out, vec));
     GS_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int32_t gs_quantize_noise_bwd(
-    uint64_t n, const float *x, const float *v_out, float lo, float hi, float *v_x, gs_stream_t stream) {
+    uint64_t n, const float *x, const float *v_out, float lo, float hi, int32_t activation, const float *out, float *v_x,
+    gs_stream_t stream) {
     if (n == 0) return 0;
     GS_CHECK_ARG(x && v_out && v_x, "null pointer");
-    hipLaunchKernelGGL(quant_noise_bwd_kernel, dim3(stream_grid(n)), dim3(GS_BLOCK), 0, (hipStream_t)stream, n, x,
-                       v_out, lo, hi, v_x, (int)aligned16(x, v_out, v_x));
+    GS_CHECK_ARG(activation >= GS_ACT_NONE && activation <= GS_ACT_SIGMOID, "unknown activation");
+    GS_CHECK_ARG(activation == GS_ACT_NONE || out != nullptr, "an activation's gradient needs the forward output");
+    const int vec = (int)(aligned16(x, v_out, v_x) && (out == nullptr || (uintptr_t)out % 16 == 0));
+    GS_ACT_DISPATCH(activation, hipLaunchKernelGGL((quant_noise_bwd_kernel<A, true>), dim3(stream_grid(n)), dim3(GS_BLOCK), 0,
+                                                   (hipStream_t)stream, n, x, v_out, out, lo, hi, v_x, vec));
     GS_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int32_t gs_quantize_round_fwd(
-    uint64_t n, float *x_inplace, float lo, float hi, float range, float q_step_norm, float *out,
+    uint64_t n, float *x_inplace, float lo, float hi, float range, float q_step_norm, int32_t activation, float *out,
     gs_stream_t stream) {
     if (n == 0) return 0;
     GS_CHECK_ARG(x_inplace && out, "null pointer");
-    hipLaunchKernelGGL(quant_round_fwd_kernel, dim3(stream_grid(n)), dim3(GS_BLOCK), 0, (hipStream_t)stream, n,
-                       x_inplace, lo, hi, range, q_step_norm, out, (int)aligned16(x_inplace, out, out));
+    GS_CHECK_ARG(activation >= GS_ACT_NONE && activation <= GS_ACT_SIGMOID, "unknown activation");
+    const int vec = (int)aligned16(x_inplace, out, out);
+    GS_ACT_DISPATCH(activation, hipLaunchKernelGGL(quant_round_fwd_kernel<A>, dim3(stream_grid(n)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
+                                                   n, x_inplace, lo, hi, range, q_step_norm, out, vec));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+// the round mode's backward is the identity (ops.py:73-75) -- no kernel -- unless an activation was fused in
+extern "C" int32_t gs_quantize_round_bwd(uint64_t n, const float *v_out, int32_t activation, const float *out, float *v_x,
+                                         gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(v_out && v_x && out, "null pointer");
+    GS_CHECK_ARG(activation > GS_ACT_NONE && activation <= GS_ACT_SIGMOID, "the identity gradient needs no kernel");
+    const int vec = (int)aligned16(out, v_out, v_x);
+    GS_ACT_DISPATCH(activation, hipLaunchKernelGGL((quant_noise_bwd_kernel<A, false>), dim3(stream_grid(n)), dim3(GS_BLOCK), 0,
+                                                   (hipStream_t)stream, n, (const float *)nullptr, v_out, out, 0.f, 0.f, v_x, vec));
     GS_CHECK_LAUNCH();
     return 0;
 }

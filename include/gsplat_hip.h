@@ -49,6 +49,10 @@ extern "C" {
 /* quantizer modes (reference: gsplat/compression_simulation/ops.py:39-54) */
 #define GS_QUANT_NOISE 0
 #define GS_QUANT_ROUND 1
+/* activation fused behind a quantizer (opt-in; 0 keeps the reference's bit-exact output) */
+#define GS_ACT_NONE 0
+#define GS_ACT_EXP 1
+#define GS_ACT_SIGMOID 2
 
 typedef void *gs_stream_t; /* hipStream_t */
 
@@ -505,16 +509,24 @@ int32_t gs_rasterize_bwd(
  *        out = round_half_even(((x - lo) / (hi - lo)) / q) * q * (hi - lo) + lo,
  *        q = 1/(2^bits - 1); bwd is the identity (no kernel).
  * All arithmetic is IEEE fp32 with no contraction, in the reference's op order.
+ * activation (opt-in fusion, GS_ACT_*): out = act(quantized value) -- the torch.exp / torch.sigmoid the trainer applies to
+ * the hooked log-scales / opacity logits (examples/simple_trainer.py:779-786) in the same pass; the backward multiplies by
+ * act' (read off `out`, the forward's output).  GS_ACT_NONE is the reference's bit-exact path.
  * ---------------------------------------------------------------------- */
 int32_t gs_quantize_noise_fwd(
     uint64_t n, const float *x, const float *noise,
-    float lo, float hi, float q_step, float *out, gs_stream_t stream);
+    float lo, float hi, float q_step, int32_t activation, float *out, gs_stream_t stream);
 int32_t gs_quantize_noise_bwd(
     uint64_t n, const float *x, const float *v_out,
-    float lo, float hi, float *v_x, gs_stream_t stream);
+    float lo, float hi, int32_t activation, const float *out /* forward output; NULL with GS_ACT_NONE */,
+    float *v_x, gs_stream_t stream);
 int32_t gs_quantize_round_fwd(
     uint64_t n, float *x_inplace, float lo, float hi, float range /* (float)(hi-lo) */,
-    float q_step_norm /* (float)(1/(2^bits-1)) */, float *out, gs_stream_t stream);
+    float q_step_norm /* (float)(1/(2^bits-1)) */, int32_t activation, float *out, gs_stream_t stream);
+/* round mode with a fused activation: v_x = v_out * act'(out) for every element (without an activation the gradient is the
+ * identity and there is nothing to launch) */
+int32_t gs_quantize_round_bwd(
+    uint64_t n, const float *v_out, int32_t activation, const float *out, float *v_x, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Factorized-prior bits estimator (the rate term behind the quantize hooks).

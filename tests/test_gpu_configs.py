@@ -110,6 +110,41 @@ def test_config3_hooks_render_backward_vs_oracle_chain():
         assert np.array_equal(N(P[k]), raw[k]), k
 
 
+def test_config3_fused_form_matches_the_reference_call_pattern():
+    """The opt-in fused form of the config-3 step -- simulate_compression(activate=True) + rasterization(colors=(sh0, shN)) --
+    against the reference's call pattern (hooks, torch.exp / torch.sigmoid / torch.cat, simple_trainer.py:779-800) on the
+    same generator state: same image to fp32 rounding of the two activations, same parameter gradients."""
+    from gscodec_studio_amd import rasterization
+    from gscodec_studio_amd.compression_simulation import CompressionSimulation
+
+    n, cams = 2500, 2
+    fx, raw = _raw_params(n)
+    W, H = fx["width"], fx["height"]
+    vm, Ks = T(fx["viewmats"][:cams]), T(fx["Ks"][:cams])
+    sim = CompressionSimulation(entropy_model_enable=False, entropy_steps={})
+    rs = np.random.RandomState(3)
+    v_rc = T(rs.randn(cams, H, W, 3).astype(np.float32))
+
+    def run(fused):
+        P = {k: torch.nn.Parameter(T(v)) for k, v in raw.items()}
+        torch.manual_seed(4321)
+        if fused:
+            q, _ = sim.simulate_compression(P, step=0, activate=True)
+            scales, opac, sh = q["scales"], q["opacities"], (q["sh0"], q["shN"])
+        else:
+            q, _ = sim.simulate_compression(P, step=0)
+            scales, opac, sh = torch.exp(q["scales"]), torch.sigmoid(q["opacities"]), torch.cat([q["sh0"], q["shN"]], dim=1)
+        rc, ra, _ = rasterization(q["means"], q["quats"], scales, opac, sh, vm, Ks, W, H, sh_degree=3, packed=False)
+        (rc * v_rc).sum().backward()
+        return N(rc), {k: N(p.grad) for k, p in P.items()}
+
+    rc0, g0 = run(False)
+    rc1, g1 = run(True)
+    assert_close(rc1, rc0, 1e-5, 1e-6, "fused config-3 render", max_bad_frac=1e-4)
+    for k in g0:
+        assert rel_l2(g1[k], g0[k]) < 2e-4, (k, rel_l2(g1[k], g0[k]))
+
+
 def test_config3_full_size_properties():
     """1,006,065 gaussians, SH degree 3, 1080p: hooks -> activations -> render -> backward (bench.py --quantize's step)."""
     from gscodec_studio_amd import rasterization

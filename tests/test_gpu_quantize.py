@@ -48,11 +48,11 @@ def test_noise_kernels_bit_exact(name, bits):
     q_step = float(gd[f"{name}_noise{bits}_q_step"])
     out = torch.empty_like(x)
     st = torch.cuda.current_stream().cuda_stream
-    B.call("gs_quantize_noise_fwd", x.numel(), B.ptr(x), B.ptr(noise), O.f32(lo), O.f32(hi), O.f32(q_step), B.ptr(out), st)
+    B.call("gs_quantize_noise_fwd", x.numel(), B.ptr(x), B.ptr(noise), O.f32(lo), O.f32(hi), O.f32(q_step), 0, B.ptr(out), st)
     assert bits_equal(N(out), gd[f"{name}_noise{bits}_out"])
     v_out = T(gd[f"{name}_noise{bits}_v_out"])
     v_x = torch.empty_like(x)
-    B.call("gs_quantize_noise_bwd", x.numel(), B.ptr(x), B.ptr(v_out), O.f32(lo), O.f32(hi), B.ptr(v_x), st)
+    B.call("gs_quantize_noise_bwd", x.numel(), B.ptr(x), B.ptr(v_out), O.f32(lo), O.f32(hi), 0, None, B.ptr(v_x), st)
     assert bits_equal(N(v_x), gd[f"{name}_noise{bits}_v_x"])
 
 
@@ -111,3 +111,35 @@ def test_compression_simulation_hooks():
         assert float((lv - lv.round()).abs().max()) < 1e-3
     with pytest.raises(NotImplementedError):  # the hash-grid Gaussian model is not built (the factorized prior is: test_gpu_entropy.py)
         CompressionSimulation(entropy_model_enable=True, entropy_model_type="gaussian_model", entropy_steps={"scales": 1})
+
+
+
+@pytest.mark.parametrize("q_type", ["noise", "round"])
+@pytest.mark.parametrize("act", ["exp", "sigmoid"])
+def test_fused_activation_matches_hook_then_torch_activation(q_type, act):
+    """Opt-in fusion (not in the reference): fake_quantize_ste(..., activation=act) == act(fake_quantize_ste(...)) -- the same
+    noise from the same generator state, the quantized value bit-identical underneath (recovered through the inverse
+    activation to rounding), and the gradient the chain rule of the two-step form gives."""
+    from gscodec_studio_amd.compression_simulation import fake_quantize_ste
+
+    lo, hi = (-10, 2) if act == "exp" else (-15, 15)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x0 = (torch.rand(100_003, device="cuda", generator=g) * (hi - lo) * 1.2 + lo * 1.1).contiguous()  # some values outside the bounds
+    v = torch.randn(100_003, device="cuda", generator=g)
+    f = torch.exp if act == "exp" else torch.sigmoid
+
+    xa = x0.clone().requires_grad_(True)
+    torch.manual_seed(99)
+    two = f(fake_quantize_ste(xa, lo, hi, 8, q_type)["output_value"])
+    (ga,) = torch.autograd.grad((two * v).sum(), xa)
+    xb = x0.clone().requires_grad_(True)
+    torch.manual_seed(99)
+    one = fake_quantize_ste(xb, lo, hi, 8, q_type, activation=act)["output_value"]
+    (gb,) = torch.autograd.grad((one * v).sum(), xb)
+    assert torch.allclose(one, two, rtol=2e-6, atol=1e-30)
+    assert torch.allclose(gb, ga, rtol=1e-5, atol=1e-12)
+    if q_type == "noise":  # gradient mask of the clamp: exact zeros outside the bounds
+        out_of_range = (x0 < lo) | (x0 > hi)
+        assert int(out_of_range.sum()) > 0 and float(gb[out_of_range].abs().max()) == 0.0
+    else:  # the parameter was clamped in place in both forms
+        assert torch.equal(xa.detach(), xb.detach()) and float(xb.min()) >= lo and float(xb.max()) <= hi
