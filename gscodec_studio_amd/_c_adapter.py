@@ -330,7 +330,7 @@ class HipBackend:
                    B.ptr(colors), B.ptr(opacities), None, B.ptr(backgrounds), B.ptr(m8), int(image_width), int(image_height),
                    int(tile_size), tile_width, tile_height, B.ptr(tile_offsets), B.ptr(flatten_ids), None, B.ptr(render_alphas),
                    B.ptr(last_ids), B.ptr(v_render_colors), B.ptr(v_render_alphas), channels, 1, B.ptr(v_means2d_abs),
-                   B.ptr(v_means2d), B.ptr(v_conics), B.ptr(v_colors), B.ptr(v_opacities), 0, None, None, _stream(means2d))
+                   B.ptr(v_means2d), B.ptr(v_conics), B.ptr(v_colors), B.ptr(v_opacities), 0, None, None, None, _stream(means2d))
         return v_means2d_abs, v_means2d, v_conics, v_colors, v_opacities
 
     @staticmethod

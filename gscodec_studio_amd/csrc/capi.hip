@@ -103,8 +103,9 @@ extern "C" int32_t gs_rasterize_bwd(
     const int32_t *flatten_ids, const float *render_colors, const float *render_alphas,
     const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
     int64_t v_render_colors_pixel_stride, int64_t v_render_colors_channel_stride, float *v_means2d_abs,
-    float *v_means2d, float *v_conics, float *v_colors, float *v_opacities, int32_t packed16,
+    float *v_means2d, float *v_conics, float *v_colors, float *v_opacities, int32_t packed16, int64_t *det_accum,
     const gs_raster_plan *plan, void *scratch, gs_stream_t stream) {
+    GS_CHECK_ARG(det_accum == nullptr || channels <= 4, "the deterministic backward needs channels <= 4");
     GS_CHECK_ARG(v_render_colors_pixel_stride >= 0 && v_render_colors_channel_stride >= 0, "negative gradient stride");
     GS_CHECK_ARG(render_alphas && last_ids && v_render_colors && tile_offsets, "null pointer");
     GS_CHECK_ARG(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids && v_means2d),
@@ -117,7 +118,7 @@ extern "C" int32_t gs_rasterize_bwd(
                     nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, 0u, 0u};
     RasterGradArgs ga = {render_alphas, last_ids, v_render_colors, v_render_alphas, v_means2d_abs,
                          v_means2d, v_conics, v_colors, v_opacities, 2u, 2u, 3u, channels, 1u, 0u,
-                         v_render_colors_pixel_stride, v_render_colors_channel_stride};
+                         v_render_colors_pixel_stride, v_render_colors_channel_stride, (long long *)det_accum};
     if (packed16) {
         float *P = v_means2d; // [n_elems,16]: vx vy | ca cb cc | o | c0 c1 c2 c3 | ax ay | pad
         ga.v_means2d = P;

@@ -1036,7 +1036,7 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
 #pragma unroll
                     for (int i = 0; i < NQ; ++i) c += facs[i] * (inside[i] ? ga.v_render_colors[vpix[i] + k * ga.s_vrc_ch] : 0.f);
                     c = wave_reduce_sum_dpp(c);
-                    if (lane == GS_WAVE - 1) unsafeAtomicAdd(vcol + k, c);
+                    if (lane == GS_WAVE - 1) unsafeAtomicAdd(vcol + k, c); // (more than 4 channels: no deterministic mode, checked by the caller)
                 }
             } else {
 #pragma unroll
@@ -1053,20 +1053,21 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, 
                 Ay = wave_reduce_sum_dpp(Ay);
             }
             if (lane == GS_WAVE - 1) {
+                const size_t gr = (size_t)g;
                 if (CMODE != 2) {
 #pragma unroll
                     for (int k = 0; k < CR; ++k)
-                        if ((uint32_t)k < cnt) unsafeAtomicAdd(vcol + k, Cs[k]);
+                        if ((uint32_t)k < cnt) grad_add(ga, vcol + k, gr, 6u + ch_off + (uint32_t)k, Cs[k]);
                 }
-                unsafeAtomicAdd(ga.v_means2d + ga.s_xy * (size_t)g, c3.x * Sx + c3.y * Sy);
-                unsafeAtomicAdd(ga.v_means2d + ga.s_xy * (size_t)g + 1, c3.y * Sx + c3.z * Sy);
-                unsafeAtomicAdd(ga.v_conics + ga.s_conic * (size_t)g, 0.5f * Sxx);
-                unsafeAtomicAdd(ga.v_conics + ga.s_conic * (size_t)g + 1, Sxy);
-                unsafeAtomicAdd(ga.v_conics + ga.s_conic * (size_t)g + 2, 0.5f * Syy);
-                unsafeAtomicAdd(ga.v_opacities + ga.s_opac * g, -S0 / c3.w);
+                grad_add(ga, ga.v_means2d + ga.s_xy * gr, gr, 0u, c3.x * Sx + c3.y * Sy);
+                grad_add(ga, ga.v_means2d + ga.s_xy * gr + 1, gr, 1u, c3.y * Sx + c3.z * Sy);
+                grad_add(ga, ga.v_conics + ga.s_conic * gr, gr, 2u, 0.5f * Sxx);
+                grad_add(ga, ga.v_conics + ga.s_conic * gr + 1, gr, 3u, Sxy);
+                grad_add(ga, ga.v_conics + ga.s_conic * gr + 2, gr, 4u, 0.5f * Syy);
+                grad_add(ga, ga.v_opacities + ga.s_opac * gr, gr, 5u, -S0 / c3.w);
                 if (ABS) {
-                    unsafeAtomicAdd(ga.v_means2d_abs + ga.s_abs * (size_t)g, Ax);
-                    unsafeAtomicAdd(ga.v_means2d_abs + ga.s_abs * (size_t)g + 1, Ay);
+                    grad_add(ga, ga.v_means2d_abs + ga.s_abs * gr, gr, 10u, Ax);
+                    grad_add(ga, ga.v_means2d_abs + ga.s_abs * gr + 1, gr, 11u, Ay);
                 }
             }
         }
@@ -1382,7 +1383,7 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
                 const uint32_t slot = grp * 5u + sub;
                 if (comp_on && slot < 64u && ((touched >> slot) & 1ull)) {
                     const uint32_t g = (uint32_t)__float_as_int(s_rec[slot * REC + 3].z);
-                    unsafeAtomicAdd(ga.v_means2d + (size_t)g * 16u + comp, accf[slot * (ACC * 4) + comp]);
+                    grad_add(ga, ga.v_means2d + (size_t)g * 16u + comp, (size_t)g, comp, accf[slot * (ACC * 4) + comp]);
                 }
             }
         } else if ((touched >> lane) & 1ull) {
@@ -1394,19 +1395,19 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
             const size_t g = (size_t)__float_as_int(e3.z);
             const float e_ca = e2.z, e_cb = e2.w, e_cc = e3.x, e_op = e3.y;
             float *vcol = ga.v_colors + g * CDIM;
-            unsafeAtomicAdd(vcol, a1.z);
-            if (CDIM > 1) unsafeAtomicAdd(vcol + 1, a1.w);
-            if (CDIM > 2) unsafeAtomicAdd(vcol + 2, a2.x);
-            if (CDIM > 3) unsafeAtomicAdd(vcol + 3, a2.y);
-            unsafeAtomicAdd(ga.v_means2d + ga.s_xy * g, e_ca * a0.x + e_cb * a0.y);
-            unsafeAtomicAdd(ga.v_means2d + ga.s_xy * g + 1, e_cb * a0.x + e_cc * a0.y);
-            unsafeAtomicAdd(ga.v_conics + ga.s_conic * g, 0.5f * a0.z);
-            unsafeAtomicAdd(ga.v_conics + ga.s_conic * g + 1, a0.w);
-            unsafeAtomicAdd(ga.v_conics + ga.s_conic * g + 2, 0.5f * a1.x);
-            unsafeAtomicAdd(ga.v_opacities + ga.s_opac * g, -a1.y / e_op);
+            grad_add(ga, vcol, g, 6u, a1.z);
+            if (CDIM > 1) grad_add(ga, vcol + 1, g, 7u, a1.w);
+            if (CDIM > 2) grad_add(ga, vcol + 2, g, 8u, a2.x);
+            if (CDIM > 3) grad_add(ga, vcol + 3, g, 9u, a2.y);
+            grad_add(ga, ga.v_means2d + ga.s_xy * g, g, 0u, e_ca * a0.x + e_cb * a0.y);
+            grad_add(ga, ga.v_means2d + ga.s_xy * g + 1, g, 1u, e_cb * a0.x + e_cc * a0.y);
+            grad_add(ga, ga.v_conics + ga.s_conic * g, g, 2u, 0.5f * a0.z);
+            grad_add(ga, ga.v_conics + ga.s_conic * g + 1, g, 3u, a0.w);
+            grad_add(ga, ga.v_conics + ga.s_conic * g + 2, g, 4u, 0.5f * a1.x);
+            grad_add(ga, ga.v_opacities + ga.s_opac * g, g, 5u, -a1.y / e_op);
             if (ABS) {
-                unsafeAtomicAdd(ga.v_means2d_abs + ga.s_abs * g, a2.z);
-                unsafeAtomicAdd(ga.v_means2d_abs + ga.s_abs * g + 1, a2.w);
+                grad_add(ga, ga.v_means2d_abs + ga.s_abs * g, g, 10u, a2.z);
+                grad_add(ga, ga.v_means2d_abs + ga.s_abs * g + 1, g, 11u, a2.w);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1480,6 +1481,27 @@ __global__ void __launch_bounds__(GS_BLOCK) seg_items_build_kernel(uint32_t n_ti
     }
     __syncthreads();
     if (valid) items[(size_t)cls * max_items + s_base[cls] + local] = make_uint2(tile, (uint32_t)k);
+}
+
+
+// Deterministic mode, second pass: fixed-point sums -> the float gradient outputs (every row written: no zero-fill needed)
+__global__ void __launch_bounds__(GS_BLOCK) raster_det_finalize_kernel(uint32_t n_elems, uint32_t channels, const long long *__restrict__ det,
+                                                                       RasterGradArgs ga) {
+    const uint32_t r = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (r >= n_elems) return;
+    const long long *d = det + (size_t)r * 12u;
+    auto f = [&](uint32_t c) { return (float)((double)d[c] * GS_DET_INV_SCALE); };
+    ga.v_means2d[ga.s_xy * (size_t)r] = f(0);
+    ga.v_means2d[ga.s_xy * (size_t)r + 1] = f(1);
+    ga.v_conics[ga.s_conic * (size_t)r] = f(2);
+    ga.v_conics[ga.s_conic * (size_t)r + 1] = f(3);
+    ga.v_conics[ga.s_conic * (size_t)r + 2] = f(4);
+    ga.v_opacities[ga.s_opac * (size_t)r] = f(5);
+    for (uint32_t k = 0; k < channels; ++k) ga.v_colors[ga.s_color * (size_t)r + k] = f(6u + k);
+    if (ga.v_means2d_abs != nullptr) {
+        ga.v_means2d_abs[ga.s_abs * (size_t)r] = f(10);
+        ga.v_means2d_abs[ga.s_abs * (size_t)r + 1] = f(11);
+    }
 }
 
 } // namespace
@@ -1644,6 +1666,8 @@ int32_t raster_wave_bwd(const RasterArgs &a_in, const RasterGradArgs &ga, const 
             case 3: launch_bwd_seg<3>(a, ga, L.max_items, use_va, sg, st); break;
             default: launch_bwd_seg<4>(a, ga, L.max_items, use_va, sg, st); break;
         }
+        if (ga.det != nullptr)
+            hipLaunchKernelGGL(raster_det_finalize_kernel, dim3(gs_div_up(a.n_elems, GS_BLOCK)), dim3(GS_BLOCK), 0, st, a.n_elems, c, ga.det, ga);
         return 0;
     }
     // no checkpoints (forward ran without scratch, or segments are switched off) or more than 4 channels:
@@ -1665,5 +1689,7 @@ int32_t raster_wave_bwd(const RasterArgs &a_in, const RasterGradArgs &ga, const 
     } else {
         launch_bwd<1, 2>(a, ga, c, 0, use_va, st);
     }
+    if (ga.det != nullptr)
+        hipLaunchKernelGGL(raster_det_finalize_kernel, dim3(gs_div_up(a.n_elems, GS_BLOCK)), dim3(GS_BLOCK), 0, st, a.n_elems, c, ga.det, ga);
     return 0;
 }

@@ -49,7 +49,21 @@ struct RasterGradArgs {
     // element strides of v_render_colors per pixel / per channel: (channels, 1) for a dense [C,H,W,channels] tensor,
     // (0, 0) for the broadcast gradient of sum(render) (autograd hands over an expanded scalar: nothing to materialise)
     int64_t s_vrc_pix, s_vrc_ch;
+    // Deterministic mode (opt-in): the per-splat sums are accumulated in FIXED POINT -- int64 [n_elems,12], columns as in the
+    // splat rows, value * 2^36 rounded to nearest -- because integer adds commute: the result no longer depends on the
+    // order in which the (tile, segment) work items reach a splat (float atomics make the low bits of every gradient
+    // change from run to run; so do the reference's).  A second kernel converts the sums into the float outputs.
+    long long *det;
 };
+
+constexpr float GS_DET_SCALE = 68719476736.f;            // 2^36: resolution 1.5e-11, range +-1.3e8 per gradient entry
+constexpr double GS_DET_INV_SCALE = 1.0 / 68719476736.0;
+
+// one gradient contribution: float atomic into `p`, or the fixed-point one into det[row * 12 + comp]
+GS_DEV void grad_add(const RasterGradArgs &ga, float *p, size_t row, uint32_t comp, float v) {
+    if (ga.det != nullptr) atomicAdd(reinterpret_cast<unsigned long long *>(ga.det + row * 12u + comp), (unsigned long long)__float2ll_rn(v * GS_DET_SCALE));
+    else unsafeAtomicAdd(p, v);
+}
 
 // 64-lane sum with DPP row shifts + row broadcasts (GFX9 family).  The total is valid in
 // lane 63 only.  All 64 lanes must be active.

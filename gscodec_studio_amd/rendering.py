@@ -94,6 +94,7 @@ def rasterization(
     distributed: bool = False,
     camera_model: Literal["pinhole", "ortho", "fisheye"] = "pinhole",
     covars: Optional[Tensor] = None,
+    deterministic: bool = False,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize a set of 3D Gaussians (N) to a batch of image planes (C).
 
@@ -110,6 +111,8 @@ def rasterization(
         render_mode: RGB / D / ED / RGB+D / RGB+ED.  distributed: gaussian-sharded
         multi-GPU mode of the reference (see distributed.py; the camera-sharded data
         parallel wrapper is ``distributed.rasterization_camera_sharded``).
+        deterministic (opt-in, beyond the reference's signature): bit-reproducible gradients -- the compositing
+        backward accumulates in fixed point instead of with float atomics (up to 4 render channels).
 
     Returns:
         render_colors [C,H,W,X], render_alphas [C,H,W,1], meta dict.
@@ -366,7 +369,7 @@ def rasterization(
             )
             rc_, ra_ = rasterize_to_pixels(
                 means2d, conics, colors_chunk, opacities, width, height, tile_size, isect_offsets, flatten_ids,
-                backgrounds=backgrounds_chunk, packed=packed, absgrad=absgrad,
+                backgrounds=backgrounds_chunk, packed=packed, absgrad=absgrad, deterministic=deterministic,
             )
             render_colors.append(rc_)
             render_alphas.append(ra_)
@@ -375,7 +378,7 @@ def rasterization(
     else:
         render_colors, render_alphas = rasterize_to_pixels(
             means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
-            backgrounds=backgrounds, packed=packed, absgrad=absgrad,
+            backgrounds=backgrounds, packed=packed, absgrad=absgrad, deterministic=deterministic,
         )
     if render_mode in ["ED", "RGB+ED"]:
         # accumulated depth -> expected depth
