@@ -1444,7 +1444,7 @@ class _RasterizeToPixels(torch.autograd.Function):
         # gradient is one L2 request; the tensors handed to autograd are views of it.
         packed = channels <= 4
         # deterministic mode: fixed-point sums in an int64 buffer of their own; the float rows are then WRITTEN by a second kernel
-        det = torch.zeros((n_elems, 12), dtype=torch.int64, device=means2d.device) if (ctx.deterministic and n_elems > 0) else None
+        det = torch.zeros((n_elems, 2, 12), dtype=torch.int64, device=means2d.device) if (ctx.deterministic and n_elems > 0) else None
         if packed:
             P, ctx.grad_rows = ctx.grad_rows, None
             if P is None:

@@ -1489,8 +1489,8 @@ __global__ void __launch_bounds__(GS_BLOCK) raster_det_finalize_kernel(uint32_t 
                                                                        RasterGradArgs ga) {
     const uint32_t r = blockIdx.x * GS_BLOCK + threadIdx.x;
     if (r >= n_elems) return;
-    const long long *d = det + (size_t)r * 12u;
-    auto f = [&](uint32_t c) { return (float)((double)d[c] * GS_DET_INV_SCALE); };
+    const long long *d = det + (size_t)r * 24u;
+    auto f = [&](uint32_t c) { return (float)((double)d[c] * GS_DET_INV_LO + (double)d[12u + c] * GS_DET_INV_HI); };
     ga.v_means2d[ga.s_xy * (size_t)r] = f(0);
     ga.v_means2d[ga.s_xy * (size_t)r + 1] = f(1);
     ga.v_conics[ga.s_conic * (size_t)r] = f(2);

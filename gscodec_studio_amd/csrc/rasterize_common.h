@@ -49,20 +49,31 @@ struct RasterGradArgs {
     // element strides of v_render_colors per pixel / per channel: (channels, 1) for a dense [C,H,W,channels] tensor,
     // (0, 0) for the broadcast gradient of sum(render) (autograd hands over an expanded scalar: nothing to materialise)
     int64_t s_vrc_pix, s_vrc_ch;
-    // Deterministic mode (opt-in): the per-splat sums are accumulated in FIXED POINT -- int64 [n_elems,12], columns as in the
-    // splat rows, value * 2^36 rounded to nearest -- because integer adds commute: the result no longer depends on the
-    // order in which the (tile, segment) work items reach a splat (float atomics make the low bits of every gradient
-    // change from run to run; so do the reference's).  A second kernel converts the sums into the float outputs.
+    // Deterministic mode (opt-in): the per-splat sums are accumulated in FIXED POINT, because integer adds commute: the
+    // result no longer depends on the order in which the (tile, segment) work items reach a splat (float atomics make the
+    // low bits of every gradient change from run to run; so do the reference's).  int64 [n_elems, 2, 12], columns as in the
+    // splat rows; TWO accumulators per value, because the contributions span more than 63 bits of dynamic range (conic
+    // gradients of large splats reach 1e11, position gradients of small ones 1e-8):
+    //   |v| <  2^10 : bin 0, units of 2^-38 (exact to fp32 precision down to |v| = 2^-15; up to 2^15 contributions fit)
+    //   |v| >= 2^10 : bin 1, units of 2^-6  (relative resolution <= 2^-16 per contribution; range 1.4e17)
+    // A second kernel converts bin 0 * 2^-38 + bin 1 * 2^-6 into the float outputs.
     long long *det;
 };
 
-constexpr float GS_DET_SCALE = 68719476736.f;            // 2^36: resolution 1.5e-11, range +-1.3e8 per gradient entry
-constexpr double GS_DET_INV_SCALE = 1.0 / 68719476736.0;
+constexpr float GS_DET_SPLIT = 1024.f;
+constexpr float GS_DET_SCALE_LO = 274877906944.f; // 2^38
+constexpr float GS_DET_SCALE_HI = 64.f;           // 2^6
+constexpr double GS_DET_INV_LO = 1.0 / 274877906944.0, GS_DET_INV_HI = 1.0 / 64.0;
 
-// one gradient contribution: float atomic into `p`, or the fixed-point one into det[row * 12 + comp]
+// one gradient contribution: float atomic into `p`, or the fixed-point one into det[row][bin][comp]
 GS_DEV void grad_add(const RasterGradArgs &ga, float *p, size_t row, uint32_t comp, float v) {
-    if (ga.det != nullptr) atomicAdd(reinterpret_cast<unsigned long long *>(ga.det + row * 12u + comp), (unsigned long long)__float2ll_rn(v * GS_DET_SCALE));
-    else unsafeAtomicAdd(p, v);
+    if (ga.det != nullptr) {
+        const bool hi = !(fabsf(v) < GS_DET_SPLIT);
+        const long long q = __float2ll_rn(v * (hi ? GS_DET_SCALE_HI : GS_DET_SCALE_LO));
+        atomicAdd(reinterpret_cast<unsigned long long *>(ga.det + row * 24u + (hi ? 12u : 0u) + comp), (unsigned long long)q);
+    } else {
+        unsafeAtomicAdd(p, v);
+    }
 }
 
 // 64-lane sum with DPP row shifts + row broadcasts (GFX9 family).  The total is valid in

@@ -496,12 +496,12 @@ int32_t gs_rasterize_bwd(
                              columns, see above); v_conics / v_colors / v_opacities are ignored, v_means2d_abs only
                              selects absgrad (non-NULL).  One 64-byte row per splat lets the kernels add a whole splat's
                              gradient with a single L2 request.  Requires channels <= 4. */
-    int64_t *det_accum,   /* NULL, or DETERMINISTIC mode (channels <= 4): a zero-filled int64 [n_elems,12] buffer.  The per-splat
-                             sums are then accumulated in fixed point (value * 2^36, integer atomics: the order in which the
-                             work items reach a splat no longer matters) and converted into the float outputs by a second
+    int64_t *det_accum,   /* NULL, or DETERMINISTIC mode (channels <= 4): a zero-filled int64 [n_elems,2,12] buffer.  The per-splat
+                             sums are then accumulated in fixed point with integer atomics (the order in which the work
+                             items reach a splat no longer matters; two accumulators per value: units of 2^-38 for
+                             contributions below 2^10, of 2^-6 above) and converted into the float outputs by a second
                              kernel, which OVERWRITES every row of them: two runs give bit-identical gradients.  The
-                             reference's float atomics are not reproducible either (rasterize_to_pixels_bwd.cu:243-274);
-                             resolution 1.5e-11 per contribution. */
+                             reference's float atomics are not reproducible either (rasterize_to_pixels_bwd.cu:243-274). */
     const gs_raster_plan *plan, void *scratch, /* the forward's plan and scratch (contents preserved), or NULL, NULL */
     gs_stream_t stream);
 

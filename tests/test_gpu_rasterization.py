@@ -500,4 +500,4 @@ def test_deterministic_backward_is_bit_reproducible(sh_degree):
         assert torch.equal(x, y), f"{name}: deterministic runs differ"
     c = run(False)
     for x, y, name in zip(a, c, names + ("means2d", "absgrad")):
-        assert rel_l2(N(x), N(y)) < 2e-5, (name, rel_l2(N(x), N(y)))
+        assert rel_l2(N(x), N(y)) < 5e-5, (name, rel_l2(N(x), N(y)))
