@@ -134,7 +134,11 @@ struct RowExtras {
     int sh_vec;             // coefficient rows are 16-byte aligned (dwordx4 loads)
 };
 
-template <bool ROWS>
+// SHMODE: -1 = no SH colours; else 3 * degree + kind, kind 0 = coefficient rows read with scalar loads, 1 = 16-byte aligned
+// rows (dwordx4 loads), 2 = split rows (sh0 | shN, sh_eval.h).  A template parameter, not a switch inside the kernel: the
+// register allocation of ONE kernel holding all five degrees is that of degree 4 (161 VGPRs, 3 waves per SIMD; the degree-3
+// instance needs ~100).
+template <bool ROWS, int SHMODE>
 __global__ void __launch_bounds__(GS_BLOCK) projection_fwd_kernel(
     uint32_t C, uint32_t N,
     const float *__restrict__ means, const float *__restrict__ covars,
@@ -162,7 +166,7 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_fwd_kernel(
         reinterpret_cast<float4 *>(row)[0] = make_float4(s.mx, s.my, s.ca, s.cb);
         if (rx.colors != nullptr || rx.sh_coeffs != nullptr) {
             float c0, c1, c2;
-            if (rx.sh_coeffs != nullptr) {
+            if (SHMODE >= 0) {
                 // view direction = mean - camera centre (the centre from the view matrix, wave-uniform), colour =
                 // clamp_min(SH + 0.5, 0): gsplat/rendering.py:368-392 of the reference
                 float cx, cy, cz;
@@ -171,18 +175,8 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_fwd_kernel(
                 const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
                 const float *crow = rx.sh_coeffs + (size_t)n * (rx.sh_rest != nullptr ? 3u : rx.sh_K * 3);
                 const float *rest = rx.sh_rest != nullptr ? rx.sh_rest + (size_t)n * (rx.sh_K - 1) * 3 : nullptr;
-                switch ((rx.sh_degree << 1) | (rx.sh_vec ? 1u : 0u)) { // (block-uniform)
-                    case 0: sh_view_color<0, false>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
-                    case 1: sh_view_color<0, true>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
-                    case 2: sh_view_color<1, false>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
-                    case 3: sh_view_color<1, true>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
-                    case 4: sh_view_color<2, false>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
-                    case 5: sh_view_color<2, true>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
-                    case 6: sh_view_color<3, false>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
-                    case 7: sh_view_color<3, true>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
-                    case 8: sh_view_color<4, false>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
-                    default: sh_view_color<4, true>(dx, dy, dz, crow, rest, true, c0, c1, c2); break;
-                }
+                if constexpr (SHMODE >= 0) sh_view_color<SHMODE / 3, (SHMODE % 3) == 1, (SHMODE % 3) == 2 ? 1 : 0>(dx, dy, dz, crow, rest, true, c0, c1, c2);
+                else c0 = c1 = c2 = 0.f;
             } else {
                 const float *cp = rx.colors + 3 * (size_t)n;
                 c0 = cp[0]; c1 = cp[1]; c2 = cp[2];
@@ -669,7 +663,7 @@ extern "C" int32_t gs_projection_fwd(
     GS_CHECK_ARG(camera_model >= 0 && camera_model <= 2, "bad camera_model");
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     const RowExtras none = {nullptr, nullptr, 0, nullptr, nullptr, 0u, 0u, 0};
-    hipLaunchKernelGGL(projection_fwd_kernel<false>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means,
+    hipLaunchKernelGGL((projection_fwd_kernel<false, -1>), grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means,
                        covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d, near_plane,
                        far_plane, radius_clip, camera_model, radii, means2d, depths, conics, compensations, none);
     GS_CHECK_LAUNCH();
@@ -695,9 +689,19 @@ extern "C" int32_t gs_projection_rows_fwd(
     GS_CHECK_ARG(sh_coeffs_rest == nullptr || (sh_coeffs != nullptr && sh_K >= 2), "sh_coeffs_rest needs sh_coeffs and K >= 2");
     const int sh_vec = sh_coeffs != nullptr && (sh_coeffs_rest != nullptr || (uintptr_t)sh_coeffs % 16 == 0) && ((sh_K * 3u) % 4u == 0);
     const RowExtras rx = {opacities, colors, antialiased, sh_coeffs, sh_coeffs_rest, sh_K, sh_degree, sh_vec};
-    hipLaunchKernelGGL(projection_fwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means,
-                       covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d, near_plane,
-                       far_plane, radius_clip, camera_model, radii, rows, depths, (float *)nullptr, (float *)nullptr, rx);
+    const int shmode = sh_coeffs == nullptr ? -1 : (int)sh_degree * 3 + (sh_coeffs_rest != nullptr ? 2 : (sh_vec ? 1 : 0));
+#define GS_ROWS_LAUNCH(M)                                                                                                        \
+    case M:                                                                                                                      \
+        hipLaunchKernelGGL((projection_fwd_kernel<true, M>), grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means, covars,   \
+                           quats, scales, viewmats, Ks, image_width, image_height, eps2d, near_plane, far_plane, radius_clip,    \
+                           camera_model, radii, rows, depths, (float *)nullptr, (float *)nullptr, rx);                           \
+        break;
+    switch (shmode) {
+        GS_ROWS_LAUNCH(-1) GS_ROWS_LAUNCH(0) GS_ROWS_LAUNCH(1) GS_ROWS_LAUNCH(2) GS_ROWS_LAUNCH(3) GS_ROWS_LAUNCH(4) GS_ROWS_LAUNCH(5)
+        GS_ROWS_LAUNCH(6) GS_ROWS_LAUNCH(7) GS_ROWS_LAUNCH(8) GS_ROWS_LAUNCH(9) GS_ROWS_LAUNCH(10) GS_ROWS_LAUNCH(11)
+        GS_ROWS_LAUNCH(12) GS_ROWS_LAUNCH(13) GS_ROWS_LAUNCH(14)
+    }
+#undef GS_ROWS_LAUNCH
     GS_CHECK_LAUNCH();
     return 0;
 }

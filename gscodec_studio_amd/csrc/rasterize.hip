@@ -1106,7 +1106,7 @@ void launch_bwd(const RasterArgs &a, const RasterGradArgs &ga, uint32_t cnt, uin
 #ifndef GS_SEG_WAVES
 #define GS_SEG_WAVES 5
 #endif
-template <int CDIM, bool ABS>
+template <int CDIM, bool ABS, bool DET>
 __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(RasterArgs a, RasterGradArgs ga, int use_v_alpha, SegArgs sg) {
     constexpr int REC = 4;
     constexpr int ACC = 3; // float4 per accumulator slot: (Sx', Sy', Sxx, Sxy) (Syy, S0, C0, C1) (C2, C3, Ax, Ay)
@@ -1383,7 +1383,7 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
                 const uint32_t slot = grp * 5u + sub;
                 if (comp_on && slot < 64u && ((touched >> slot) & 1ull)) {
                     const uint32_t g = (uint32_t)__float_as_int(s_rec[slot * REC + 3].z);
-                    grad_add(ga, ga.v_means2d + (size_t)g * 16u + comp, (size_t)g, comp, accf[slot * (ACC * 4) + comp]);
+                    grad_add<DET ? 1 : 0>(ga, ga.v_means2d + (size_t)g * 16u + comp, (size_t)g, comp, accf[slot * (ACC * 4) + comp]);
                 }
             }
         } else if ((touched >> lane) & 1ull) {
@@ -1395,19 +1395,19 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
             const size_t g = (size_t)__float_as_int(e3.z);
             const float e_ca = e2.z, e_cb = e2.w, e_cc = e3.x, e_op = e3.y;
             float *vcol = ga.v_colors + g * CDIM;
-            grad_add(ga, vcol, g, 6u, a1.z);
-            if (CDIM > 1) grad_add(ga, vcol + 1, g, 7u, a1.w);
-            if (CDIM > 2) grad_add(ga, vcol + 2, g, 8u, a2.x);
-            if (CDIM > 3) grad_add(ga, vcol + 3, g, 9u, a2.y);
-            grad_add(ga, ga.v_means2d + ga.s_xy * g, g, 0u, e_ca * a0.x + e_cb * a0.y);
-            grad_add(ga, ga.v_means2d + ga.s_xy * g + 1, g, 1u, e_cb * a0.x + e_cc * a0.y);
-            grad_add(ga, ga.v_conics + ga.s_conic * g, g, 2u, 0.5f * a0.z);
-            grad_add(ga, ga.v_conics + ga.s_conic * g + 1, g, 3u, a0.w);
-            grad_add(ga, ga.v_conics + ga.s_conic * g + 2, g, 4u, 0.5f * a1.x);
-            grad_add(ga, ga.v_opacities + ga.s_opac * g, g, 5u, -a1.y / e_op);
+            grad_add<DET ? 1 : 0>(ga, vcol, g, 6u, a1.z);
+            if (CDIM > 1) grad_add<DET ? 1 : 0>(ga, vcol + 1, g, 7u, a1.w);
+            if (CDIM > 2) grad_add<DET ? 1 : 0>(ga, vcol + 2, g, 8u, a2.x);
+            if (CDIM > 3) grad_add<DET ? 1 : 0>(ga, vcol + 3, g, 9u, a2.y);
+            grad_add<DET ? 1 : 0>(ga, ga.v_means2d + ga.s_xy * g, g, 0u, e_ca * a0.x + e_cb * a0.y);
+            grad_add<DET ? 1 : 0>(ga, ga.v_means2d + ga.s_xy * g + 1, g, 1u, e_cb * a0.x + e_cc * a0.y);
+            grad_add<DET ? 1 : 0>(ga, ga.v_conics + ga.s_conic * g, g, 2u, 0.5f * a0.z);
+            grad_add<DET ? 1 : 0>(ga, ga.v_conics + ga.s_conic * g + 1, g, 3u, a0.w);
+            grad_add<DET ? 1 : 0>(ga, ga.v_conics + ga.s_conic * g + 2, g, 4u, 0.5f * a1.x);
+            grad_add<DET ? 1 : 0>(ga, ga.v_opacities + ga.s_opac * g, g, 5u, -a1.y / e_op);
             if (ABS) {
-                grad_add(ga, ga.v_means2d_abs + ga.s_abs * g, g, 10u, a2.z);
-                grad_add(ga, ga.v_means2d_abs + ga.s_abs * g + 1, g, 11u, a2.w);
+                grad_add<DET ? 1 : 0>(ga, ga.v_means2d_abs + ga.s_abs * g, g, 10u, a2.z);
+                grad_add<DET ? 1 : 0>(ga, ga.v_means2d_abs + ga.s_abs * g + 1, g, 11u, a2.w);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1418,10 +1418,11 @@ __global__ void __launch_bounds__(GS_WAVE, GS_SEG_WAVES) raster_seg_bwd_kernel(R
 template <int CDIM>
 void launch_bwd_seg(const RasterArgs &a, const RasterGradArgs &ga, uint32_t max_items, int use_va, const SegArgs &sg, hipStream_t st) {
     dim3 grid(max_items, 1);
-    if (ga.v_means2d_abs != nullptr)
-        hipLaunchKernelGGL((raster_seg_bwd_kernel<CDIM, true>), grid, dim3(GS_WAVE), 0, st, a, ga, use_va, sg);
-    else
-        hipLaunchKernelGGL((raster_seg_bwd_kernel<CDIM, false>), grid, dim3(GS_WAVE), 0, st, a, ga, use_va, sg);
+    const bool abs = ga.v_means2d_abs != nullptr, det = ga.det != nullptr;
+    if (abs && det) hipLaunchKernelGGL((raster_seg_bwd_kernel<CDIM, true, true>), grid, dim3(GS_WAVE), 0, st, a, ga, use_va, sg);
+    else if (abs) hipLaunchKernelGGL((raster_seg_bwd_kernel<CDIM, true, false>), grid, dim3(GS_WAVE), 0, st, a, ga, use_va, sg);
+    else if (det) hipLaunchKernelGGL((raster_seg_bwd_kernel<CDIM, false, true>), grid, dim3(GS_WAVE), 0, st, a, ga, use_va, sg);
+    else hipLaunchKernelGGL((raster_seg_bwd_kernel<CDIM, false, false>), grid, dim3(GS_WAVE), 0, st, a, ga, use_va, sg);
 }
 
 // Work list of the segmented backward, ORDERED BY COST, longest first.  Why: a (tile, segment) item lasts 20 ... 120 us

@@ -65,9 +65,11 @@ constexpr float GS_DET_SCALE_LO = 274877906944.f; // 2^38
 constexpr float GS_DET_SCALE_HI = 64.f;           // 2^6
 constexpr double GS_DET_INV_LO = 1.0 / 274877906944.0, GS_DET_INV_HI = 1.0 / 64.0;
 
-// one gradient contribution: float atomic into `p`, or the fixed-point one into det[row][bin][comp]
+// one gradient contribution: float atomic into `p`, or the fixed-point one into det[row][bin][comp].
+// DET: 1 / 0 = decided at compile time (the hot segmented kernel: a run-time choice costs it registers), -1 = by ga.det
+template <int DET = -1>
 GS_DEV void grad_add(const RasterGradArgs &ga, float *p, size_t row, uint32_t comp, float v) {
-    if (ga.det != nullptr) {
+    if (DET == 1 || (DET < 0 && ga.det != nullptr)) {
         const bool hi = !(fabsf(v) < GS_DET_SPLIT);
         const long long q = __float2ll_rn(v * (hi ? GS_DET_SCALE_HI : GS_DET_SCALE_LO));
         atomicAdd(reinterpret_cast<unsigned long long *>(ga.det + row * 24u + (hi ? 12u : 0u) + comp), (unsigned long long)q);

@@ -143,7 +143,9 @@ GS_DEV void sh_dir(const float *dirs, const ShView &v, uint32_t c, uint32_t n, s
     }
 }
 
-template <int DEG, bool VEC>
+// SPLIT: the coefficient rows are the pair (coeffs [N,1,3], view.coeffs_rest [N,K-1,3]) -- a template parameter, because a
+// run-time choice between the two loaders costs the registers of both (60 -> 113 VGPRs at degree 3)
+template <int DEG, bool VEC, bool SPLIT>
 __global__ void __launch_bounds__(GS_BLOCK) sh_fwd_kernel(
     uint32_t C, uint32_t N, uint32_t K, const float *__restrict__ dirs,
     const float *__restrict__ coeffs, int shared, const uint8_t *__restrict__ masks,
@@ -157,11 +159,10 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_fwd_kernel(
     if (!sh_active(masks, view, e)) return;
     float dx = 0.f, dy = 0.f, dz = 1.f;
     if (DEG >= 1) sh_dir(dirs, view, c, n, e, dx, dy, dz);
-    const bool split = view.coeffs_rest != nullptr; // (uniform; shared coefficients only)
-    const float *row = coeffs + (shared ? (size_t)n : e) * (split ? 3u : K * 3);
-    const float *rest = split ? view.coeffs_rest + (size_t)n * (K - 1) * 3 : nullptr;
+    const float *row = coeffs + (shared ? (size_t)n : e) * (SPLIT ? 3u : K * 3);
+    const float *rest = SPLIT ? view.coeffs_rest + (size_t)n * (K - 1) * 3 : nullptr;
     float r, g, b;
-    sh_view_color<DEG, VEC>(dx, dy, dz, row, rest, view.clamp_half != 0, r, g, b);
+    sh_view_color<DEG, VEC, SPLIT ? 1 : 0>(dx, dy, dz, row, rest, view.clamp_half != 0, r, g, b);
     float *co = colors + e * view.color_stride;
     co[0] = r;
     co[1] = g;
@@ -325,10 +326,12 @@ bool rows_vectorizable(const void *p, uint32_t K) { return ((uintptr_t)p % 16 ==
 template <int DEG>
 void launch_fwd(bool vec, dim3 grid, hipStream_t st, uint32_t C, uint32_t N, uint32_t K, const float *dirs,
                 const float *coeffs, int shared, const uint8_t *masks, float *colors, ShView view) {
-    if (vec)
-        hipLaunchKernelGGL((sh_fwd_kernel<DEG, true>), grid, dim3(GS_BLOCK), 0, st, C, N, K, dirs, coeffs, shared, masks, colors, view);
+    if (view.coeffs_rest != nullptr)
+        hipLaunchKernelGGL((sh_fwd_kernel<DEG, false, true>), grid, dim3(GS_BLOCK), 0, st, C, N, K, dirs, coeffs, shared, masks, colors, view);
+    else if (vec)
+        hipLaunchKernelGGL((sh_fwd_kernel<DEG, true, false>), grid, dim3(GS_BLOCK), 0, st, C, N, K, dirs, coeffs, shared, masks, colors, view);
     else
-        hipLaunchKernelGGL((sh_fwd_kernel<DEG, false>), grid, dim3(GS_BLOCK), 0, st, C, N, K, dirs, coeffs, shared, masks, colors, view);
+        hipLaunchKernelGGL((sh_fwd_kernel<DEG, false, false>), grid, dim3(GS_BLOCK), 0, st, C, N, K, dirs, coeffs, shared, masks, colors, view);
 }
 
 template <int DEG>

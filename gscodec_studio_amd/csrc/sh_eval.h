@@ -98,12 +98,8 @@ struct __attribute__((packed, aligned(4))) float4_a4 {
     float x, y, z, w;
 };
 
-template <int CNT, bool VEC>
-GS_DEV void load_coeff_row(const float *__restrict__ row, const float *__restrict__ rest, float *dst) {
-    if (rest == nullptr) { // (uniform) one contiguous row
-        load_floats<CNT, VEC>(row, dst);
-        return;
-    }
+template <int CNT>
+GS_DEV void load_coeff_row_split(const float *__restrict__ row, const float *__restrict__ rest, float *dst) {
     dst[0] = row[0];
     if (CNT > 1) dst[CNT > 1 ? 1 : 0] = row[1];
     if (CNT > 2) dst[CNT > 2 ? 2 : 0] = row[2];
@@ -118,10 +114,17 @@ GS_DEV void load_coeff_row(const float *__restrict__ row, const float *__restric
     for (int i = NV * 4; i < R; ++i) dst[3 + i] = rest[i];
 }
 
+template <int CNT, bool VEC>
+GS_DEV void load_coeff_row(const float *__restrict__ row, const float *__restrict__ rest, float *dst) {
+    if (rest == nullptr) load_floats<CNT, VEC>(row, dst); // (uniform) one contiguous row
+    else load_coeff_row_split<CNT>(row, rest, dst);
+}
+
 // clamp_min(SH colour + 0.5, 0) of ONE splat seen from direction (dx, dy, dz) (not normalised), coefficient row `row`
 // ([K,3], the first (DEG+1)^2 bands are used): the arithmetic of sh_fwd_kernel's view mode, shared so that the projection's
 // fused colour is bit-identical to gs_sh_view_fwd's.
-template <int DEG, bool VEC>
+// LAYOUT: 0 = one row (VEC: 16-byte aligned), 1 = split rows, -1 = decided at run time by `rest`
+template <int DEG, bool VEC, int LAYOUT = -1>
 GS_DEV void sh_view_color(float dx, float dy, float dz, const float *__restrict__ row, const float *__restrict__ rest, bool clamp_half,
                           float &r, float &g, float &b) {
     constexpr int NB = ShDim<DEG>::NB;
@@ -133,7 +136,9 @@ GS_DEV void sh_view_color(float dx, float dy, float dz, const float *__restrict_
         sh_basis<0>(0.f, 0.f, 1.f, Y);
     }
     float cf[NB * 3];
-    load_coeff_row<NB * 3, VEC>(row, rest, cf);
+    if (LAYOUT == 0) load_floats<NB * 3, VEC>(row, cf);
+    else if (LAYOUT == 1) load_coeff_row_split<NB * 3>(row, rest, cf);
+    else load_coeff_row<NB * 3, VEC>(row, rest, cf);
     r = g = b = 0.f;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
