@@ -269,7 +269,35 @@ __global__ void __launch_bounds__(GS_BLOCK) scatter_add_rows_kernel(uint64_t tot
     unsafeAtomicAdd(v_src + (uint64_t)ids[r] * width + c, v_out[e]);
 }
 
+// Wire rows that carry their own destination: column 0 of a [n_rows, 1 + width] wire row is a global row index (int32 bit
+// pattern; negative = no row), the rest its values.  acc[map[index - lo]][1 + c] += scale * wire[r][1 + c]: the owner side of
+// the sparse gradient reduction (distributed.py) adds the rows it received for its block into the block's compact accumulator.
+__global__ void __launch_bounds__(GS_BLOCK) scatter_add_wire_rows_kernel(uint64_t total, uint32_t width, const float *__restrict__ wire,
+                                                                         const int32_t *__restrict__ map, int32_t lo, float scale,
+                                                                         float *__restrict__ acc) {
+    const uint64_t e = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (e >= total) return;
+    const uint64_t r = e / width;
+    const uint32_t c = (uint32_t)(e - r * width);
+    const float *w = wire + r * (width + 1u);
+    const int32_t idx = __float_as_int(w[0]);
+    if (idx < 0) return;
+    unsafeAtomicAdd(acc + (uint64_t)map[idx - lo] * (width + 1u) + 1u + c, w[1u + c] * scale);
+}
+
 }  // namespace
+
+extern "C" int32_t gs_scatter_add_wire_rows(uint64_t n_rows, uint32_t width, const float *wire, const int32_t *map, int32_t lo,
+                                            float scale, float *acc, gs_stream_t stream) {
+    if (n_rows == 0 || width == 0) return 0;
+    GS_CHECK_ARG(wire && map && acc, "null pointer");
+    const uint64_t total = n_rows * width;
+    GS_CHECK_ARG(total / GS_BLOCK < (1ull << 31), "too many elements");
+    hipLaunchKernelGGL(scatter_add_wire_rows_kernel, dim3((uint32_t)((total + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0,
+                       (hipStream_t)stream, total, width, wire, map, lo, scale, acc);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int32_t gs_gather_rows_f32(uint64_t n_rows, uint32_t width, const float *src, const int64_t *ids, float *out,
                                       gs_stream_t stream) {

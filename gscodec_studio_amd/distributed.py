@@ -365,7 +365,9 @@ def _unpack_rows(wire: Tensor, parts, row_index: Optional[Tensor] = None) -> Non
             src = wire[:, off:off + w].contiguous()
             src = src.view(torch.int32) if t.dtype == torch.int32 else src
             if len(part) > 2 and part[2]:
-                t.view(-1, w)[row_index.long()] = src
+                ri = row_index.long()
+                keep = ri >= 0  # a negative index = no row (as in gs_rows_unpack_indexed)
+                t.view(-1, w)[ri[keep]] = src[keep]
             else:
                 t.copy_(src.reshape(t.shape))
         off += w
@@ -610,13 +612,17 @@ def flatten_grads(params: Sequence[Tensor]) -> Tuple[Tensor, List[Tuple[int, tor
 
 class SparseGradPlan:
     """What the sparse gradient reduction needs to know, gathered in the FORWARD pass (``plan_sparse_grad_exchange``):
-    every rank's visibility mask (which splats can have a non-zero gradient there), the union mask, and -- on the host,
-    read back together with the renderer's own intersection count, so without a synchronisation of its own -- how many
-    rows every rank holds for every owner block and how many rows every block's union has."""
+    every rank's visibility mask (which splats can have a non-zero gradient there), the union mask, the index lists both
+    phases of the reduction walk -- all with static sizes, built while the forward's latency-bound binning kernels run --
+    and, on the host, read back together with the renderer's own intersection count (so without a synchronisation of its
+    own), how many rows every rank holds for every owner block and how many rows every block's union has."""
 
-    def __init__(self, N, world, rank, block, masks, union, pinned, event):
+    def __init__(self, N, world, rank, block, masks, union, send_idx, urank, uidx, pinned, event):
         self.N, self.world, self.rank, self.block = N, world, rank, block
         self.masks, self.union = masks, union  # uint8 [world, world * block], bool [world * block]
+        # int32: my visible splats in ascending order (-1 padded) [world * block]; position of every splat of MY block inside
+        # the block's union [block]; the global indices of my block's union rows, ascending (-1 padded) [block]
+        self.send_idx, self.urank, self.uidx = send_idx, urank, uidx
         self._pinned, self._event = pinned, event
         self._counts = None
 
@@ -632,8 +638,9 @@ class SparseGradPlan:
 
 def plan_sparse_grad_exchange(radii: Tensor, world_size: Optional[int] = None) -> Optional[SparseGradPlan]:
     """Call in the forward pass, right after projection (``meta["radii"]`` [C_local, N]): all-gathers the per-splat
-    visibility masks of all ranks (1 byte per splat and rank: 1 MB at 1 M splats against the 236 MB of gradients) and
-    starts the asynchronous read-back of the row counts.  Splat n belongs to owner block n // ceil(N / world)."""
+    visibility masks of all ranks (1 byte per splat and rank: 1 MB at 1 M splats against the 236 MB of gradients), builds
+    the index lists of the reduction and starts the asynchronous read-back of the row counts.  Splat n belongs to owner
+    block n // ceil(N / world)."""
     if world_size is None:
         world_size = dist.get_world_size() if dist.is_initialized() else 1
     if _single(world_size):
@@ -641,6 +648,7 @@ def plan_sparse_grad_exchange(radii: Tensor, world_size: Optional[int] = None) -
     rank = dist.get_rank()
     N = radii.shape[-1]
     block = -(-N // world_size)
+    lo = rank * block
     vis = torch.zeros(world_size * block, dtype=torch.uint8, device=radii.device)
     vis[:N] = (radii.reshape(-1, N) > 0).any(0)
     masks = torch.empty((world_size, world_size * block), dtype=torch.uint8, device=radii.device)
@@ -649,6 +657,12 @@ def plan_sparse_grad_exchange(radii: Tensor, world_size: Optional[int] = None) -
     rows = masks.view(world_size, world_size, block).sum(-1, dtype=torch.int32)      # [rank, owner]
     urows = union.view(world_size, block).sum(-1, dtype=torch.int32)                 # [owner]
     both = torch.cat([rows.reshape(-1), urows]).to(torch.int64)
+    # index lists (static sizes, -1 padded; ascending order keeps every owner's rows contiguous)
+    send_idx = torch.nonzero_static(vis, size=world_size * block, fill_value=-1).view(-1).to(torch.int32)
+    ub = union[lo:lo + block]
+    urank = torch.cumsum(ub, 0, dtype=torch.int32) - 1
+    uidx = torch.nonzero_static(ub, size=block, fill_value=-1).view(-1)
+    uidx = torch.where(uidx >= 0, uidx + lo, uidx).to(torch.int32)
     if both.is_cuda:
         pinned = torch.empty(both.numel(), dtype=torch.int64).pin_memory()
         pinned.copy_(both, non_blocking=True)
@@ -656,17 +670,38 @@ def plan_sparse_grad_exchange(radii: Tensor, world_size: Optional[int] = None) -
         ev.record(torch.cuda.current_stream(radii.device))
     else:
         pinned, ev = both.clone(), None
-    return SparseGradPlan(N, world_size, rank, block, masks, union, pinned, ev)
+    return SparseGradPlan(N, world_size, rank, block, masks, union, send_idx, urank, uidx, pinned, ev)
+
+
+def _scatter_add_wire_rows(acc: Tensor, wire: Tensor, urank: Tensor, lo: int, scale: float) -> None:
+    """acc[urank[index - lo]][1:] += scale * wire[r][1:], index = the int32 bit pattern in wire[r][0] (negative: no row)."""
+    if wire.shape[0] == 0:
+        return
+    if acc.is_cuda:
+        from . import _backend as B
+
+        with torch.cuda.device(acc.device):
+            B.call("gs_scatter_add_wire_rows", wire.shape[0], wire.shape[1] - 1, B.ptr(wire), B.ptr(urank), int(lo), float(scale),
+                   B.ptr(acc), torch.cuda.current_stream(acc.device).cuda_stream)
+        return
+    idx = wire[:, 0].contiguous().view(torch.int32).long()
+    ok = idx >= 0
+    acc[:, 1:].index_add_(0, urank[(idx[ok] - lo)].long(), wire[ok, 1:] * scale)
 
 
 def _sparse_all_reduce(plist: List[Tensor], plan: SparseGradPlan, average: bool) -> None:
-    """Sum of the splat gradients over ranks moving only the rows some camera saw.
+    """Sum of the splat gradients over ranks moving only the rows some camera saw.  Wire rows carry their splat index in
+    column 0 (an int32 bit pattern: 4 bytes on top of the 236 of a degree-3 gradient row), so neither side has to
+    reconstruct the other's order.
 
-    Phase 1 (reduce-scatter): rank r sends owner o its visible rows of block o, in index order, as one variable-split
-    all-to-all of bare values (the receiver knows every sender's mask, so no indices travel); the owner adds them into a
-    dense accumulator of its block.  Phase 2 (all-gather): every owner sends the rows of its block's UNION, padded to the
-    largest union, and every rank writes them back at the union's indices.  Rows outside the union are zero on every
-    rank and stay untouched.  No host synchronisation beyond the plan's counts (read back in the forward)."""
+    Phase 1 (reduce-scatter): rank r sends owner o its visible rows of block o as one variable-split all-to-all; the
+    owner adds them into the compact accumulator of its block's UNION (one row per splat some camera saw).  Phase 2
+    (all-gather): every owner hands out that accumulator, padded to the largest union, and every rank writes the rows back
+    at the indices they carry.  Rows outside the union are zero on every rank and stay untouched (the render loss gives
+    culled splats exactly zero gradient; a loss term that touches EVERY splat, such as an opacity regulariser, must be
+    reduced densely -- see all_reduce_splat_grads).  Local work: one pack, one scatter-add, one unpack kernel over the
+    visible rows; every index list comes from the plan built in the forward; no host synchronisation beyond the plan's
+    counts."""
     W, rank, N, block = plan.world, plan.rank, plan.N, plan.block
     rows, urows = plan.counts()
     dev = plist[0].device
@@ -681,38 +716,27 @@ def _sparse_all_reduce(plist: List[Tensor], plan: SparseGradPlan, average: bool)
         elif not p.grad.is_contiguous():
             p.grad = p.grad.contiguous()
     G = [p.grad.view(N, -1) for p in plist]
-    # ---- phase 1
+    lo = rank * block
+    # ---- phase 1: [index | values] rows of my visible splats, grouped by owner (ascending indices)
     n_mine = sum(rows[rank])
-    idx = torch.nonzero_static(plan.masks[rank], size=n_mine).view(-1)              # ascending: owner blocks are contiguous
-    parts = [(g, wdt, True) for g, wdt in zip(G, widths)]
-    send = _pack_rows(parts, n_mine, G[0], idx.to(torch.int32)) if n_mine else torch.empty((0, D), dtype=torch.float32, device=dev)
+    idx = plan.send_idx[:n_mine]
+    parts = [(idx, 1, False)] + [(g, wdt, True) for g, wdt in zip(G, widths)]
+    send = _pack_rows(parts, n_mine, G[0], idx) if n_mine else torch.empty((0, D + 1), dtype=torch.float32, device=dev)
     in_splits = [int(c) for c in rows[rank]]
     out_splits = [int(rows[r][rank]) for r in range(W)]
-    recv = send.new_empty((sum(out_splits), D))
-    _all_to_all_single(recv, send.contiguous(), out_splits, in_splits)
-    acc = torch.zeros((block, D), dtype=torch.float32, device=dev)
-    lo = rank * block
-    # rows arrive sender by sender, each sender's in index order: one compaction of the senders' masks of MY block gives
-    # all their positions at once
-    src = torch.nonzero_static(plan.masks[:, lo:lo + block].reshape(-1), size=sum(out_splits)).view(-1) % block
-    if src.numel():
-        _scatter_add_rows(acc, src, recv)
-    if average:
-        acc.mul_(1.0 / W)
-    # ---- phase 2
-    n_union = sum(int(u) for u in urows)
-    gidx = torch.nonzero_static(plan.union, size=n_union).view(-1)                   # ascending = owner order
-    u_off = sum(int(u) for u in urows[:rank])
-    uidx = gidx[u_off:u_off + int(urows[rank])] - lo
+    recv = send.new_empty((sum(out_splits), D + 1))
+    _all_to_all_single(recv, send, out_splits, in_splits)
     umax = max(int(u) for u in urows)
-    mine = acc.new_zeros((umax, D))
-    if uidx.numel():
-        mine[: uidx.numel()] = acc.index_select(0, uidx)
-    allrows = acc.new_empty((W, umax, D))
-    _all_gather_into(allrows.view(-1), mine.view(-1))
-    if n_union:
-        vals = torch.cat([allrows[o, : int(urows[o])] for o in range(W)], dim=0) if W > 1 else allrows[0, :n_union]
-        _unpack_rows(vals.contiguous(), [(g, wdt, True) for g, wdt in zip(G, widths)], gidx.to(torch.int32))
+    acc = torch.zeros((umax, D + 1), dtype=torch.float32, device=dev)
+    if umax:
+        acc[:, 0].view(torch.int32).copy_(plan.uidx[:umax]) if acc.is_cuda else acc[:, 0].copy_(plan.uidx[:umax].view(torch.float32))
+    _scatter_add_wire_rows(acc, recv, plan.urank, lo, (1.0 / W) if average else 1.0)
+    # ---- phase 2: every owner's union rows to everybody; padding rows carry index -1 and are skipped
+    allrows = acc.new_empty((W * umax, D + 1))
+    _all_gather_into(allrows.view(-1), acc.view(-1))
+    if umax:
+        back = allrows[:, 0].contiguous().view(torch.int32)
+        _unpack_rows(allrows, [(None, 1, False)] + [(g, wdt, True) for g, wdt in zip(G, widths)], back)
 
 
 def _scatter_add_rows(acc: Tensor, idx: Tensor, rows: Tensor) -> None:

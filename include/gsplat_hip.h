@@ -732,6 +732,12 @@ int32_t gs_gather_rows_f32(
     uint64_t n_rows, uint32_t width, const float *src, const int64_t *ids, float *out, gs_stream_t stream);
 int32_t gs_scatter_add_rows_f32(
     uint64_t n_rows, uint32_t width, const float *v_out, const int64_t *ids, float *v_src, gs_stream_t stream);
+/* Wire rows that carry their destination (the sparse gradient reduction of the camera-sharded mode, distributed.py): wire is
+ * [n_rows, 1 + width], column 0 a global row index as an int32 bit pattern (negative: no row).  Adds
+ * scale * wire[r][1 + c] into acc[map[index - lo]][1 + c] (acc rows are 1 + width floats wide too; float atomics). */
+int32_t gs_scatter_add_wire_rows(
+    uint64_t n_rows, uint32_t width, const float *wire, const int32_t *map, int32_t lo, float scale, float *acc,
+    gs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -187,8 +187,9 @@ def _sparse_grad_reduce(rank, world):
         rows, urows = plan.counts()
         assert rows[rank] == [int(seen[rank][o * plan.block:(o + 1) * plan.block].sum()) for o in range(world)]
         assert urows == [int(seen.any(0)[o * plan.block:(o + 1) * plan.block].sum()) for o in range(world)]
-        # wire: rows sent to the OTHER owner + the padded union block gathered to the other rank (16 floats per row)
-        assert D.WIRE["bytes"] == 4 * 16 * (rows[rank][1 - rank] + max(urows) * (world - 1))
+        # wire: rows sent to the OTHER owner + the padded union block gathered to the other rank (16 floats per row + the
+        # splat index every wire row carries in its first column)
+        assert D.WIRE["bytes"] == 4 * 17 * (rows[rank][1 - rank] + max(urows) * (world - 1))
         # averaged form
         for k in shapes:
             params[k].grad = full[k][rank] * seen[rank].reshape((N,) + (1,) * (len(shapes[k]) - 1))

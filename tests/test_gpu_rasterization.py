@@ -461,11 +461,11 @@ def test_split_sh_coefficients_match_the_concatenated_tensor(sh_degree, K):
     rc1, ra1, ps1 = run((sh0, shN))
     assert torch.equal(rc1, rc0) and torch.equal(ra1, ra0)
     # (the compositing backward adds with float atomics: its sums differ in the last bits from run to run)
-    assert rel_l2(N(sh0.grad), N(cat.grad[:, :1])) < 1e-5 and rel_l2(N(shN.grad), N(cat.grad[:, 1:])) < 1e-5
+    assert rel_l2(N(sh0.grad), N(cat.grad[:, :1])) < 1e-4 and rel_l2(N(shN.grad), N(cat.grad[:, 1:])) < 1e-4
     n_act = (sh_degree + 1) ** 2
     assert float(shN.grad[:, n_act - 1:].abs().max() if n_act - 1 < K - 1 else 0.0) == 0.0  # inactive bands: exact zeros
     for a, b in zip(ps1, ps0):
-        assert rel_l2(N(a.grad), N(b.grad)) < 1e-5
+        assert rel_l2(N(a.grad), N(b.grad)) < 1e-4  # (float atomics in the compositing backward: run-to-run noise)
     # a route that cannot take the pair falls back to the concatenation
     sh0p, shNp = T(sh[:, :1]).requires_grad_(True), T(sh[:, 1:]).requires_grad_(True)
     rc2, _, _ = run((sh0p, shNp), packed=True)
