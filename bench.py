@@ -104,6 +104,9 @@ def parse():
     ap.add_argument("--dp-mode", choices=["auto", "camera", "camera_sparse", "gaussian", "gaussian_dense"], default="auto",
                     help="multi-GPU exchange pattern (see the module docstring); ignored with one GPU")
     ap.add_argument("--calib-steps", type=int, default=5)
+    ap.add_argument("--no-dp-projection", action="store_true",
+                    help="(one GPU) skip the multi-GPU projection: the exchange modes re-timed on this GPU with their collectives "
+                         "forced through RCCL (world 1), next to the bytes a world-8 run would put on the xGMI links")
     return ap.parse_args()
 
 
@@ -209,6 +212,43 @@ def cpu_baseline(args, sh_degree):
                   f"SH deg {sh_degree}; {how}: {dt:.1f} s wall",
         "host_cpus": os.cpu_count(),
     }
+
+
+def dp_projection(args, t1_ms, stats):
+    """What can be said about N = 8 from ONE GPU (the build rounds have no multi-GPU box): every exchange mode is re-run in a
+    subprocess on this GPU with world 1 and its collectives FORCED through RCCL (GS_DIST_FORCE_COLLECTIVES=1: compaction, pack,
+    scatter-add, unpack kernels and RCCL's self-copies all run; nothing crosses a link), which gives the mode's LOCAL overhead
+    per step; next to it the payload a rank would put on the wire at world 8 with one camera per rank (closed form from N / V,
+    union of the visible sets taken as V: the bench cameras are yawed copies of camera 0) and the time the 7 xGMI links of an
+    MI355X need for it at peak.  implied_efficiency = t1 / (t1 + local overhead + wire floor): an UPPER bound on the weak-scaling
+    efficiency (links at peak, perfect overlap of nothing)."""
+    import subprocess
+
+    N, V = stats["N"], stats["V"]
+    D = 59  # floats of one degree-3 gradient row: means 3 + quats 4 + scales 3 + opacity 1 + SH 48
+    wire8 = {
+        "camera": 2 * (7 / 8) * 4 * D * N,                 # reduce-scatter + all-gather of every gradient tensor
+        "camera_sparse": (7 / 8) * 4 * (D + 1) * (V + V),   # visible rows to their owners + the union rows back (index column)
+        "gaussian": (7 / 8) * V * (52 + 44),               # projected visible rows out, their gradients back
+    }
+    out = {}
+    for mode in ("camera", "camera_sparse", "gaussian"):
+        env = dict(os.environ, GS_BENCH_PG="1", GS_DIST_FORCE_COLLECTIVES="1", MASTER_PORT=str(29600 + (os.getpid() % 300)))
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--dp-mode", mode, "--steps", "20", "--warmup", "5",
+               "--min-timed-s", "0.3", "--no-cpu-baseline", "--no-extras", "--no-dp-projection", "--scene-grid", str(args.scene_grid),
+               "--width", str(args.width), "--height", str(args.height), "--sh-degree", str(args.sh_degree)]
+        rec = {"wire_bytes_out_per_rank_world8": wire8[mode], "xgmi_floor_ms": wire8[mode] / (7 * 153e9) * 1e3}
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180)
+            ms = json.loads(r.stdout.strip().splitlines()[-1])["ms_per_step"]
+            rec["ms_per_step_world1_forced_collectives"] = ms
+            rec["local_overhead_ms"] = max(ms - t1_ms, 0.0)
+            rec["implied_efficiency_world8"] = t1_ms / (t1_ms + rec["local_overhead_ms"] + rec["xgmi_floor_ms"])
+            rec["implied_speedup_world8"] = 8 * rec["implied_efficiency_world8"]
+        except Exception as e:  # (a projection must never take the measurement down with it)
+            rec["error"] = f"{type(e).__name__}: {e}"[:200]
+        out[mode] = rec
+    return out
 
 
 def psnr_vs_oracle(dev):
@@ -494,6 +534,8 @@ def main():
         }
         if not args.no_extras and world == 1:
             out["psnr_vs_oracle"] = psnr_vs_oracle(dev)
+        if world == 1 and not use_pg and not args.no_dp_projection and not args.quantize:
+            out["multi_gpu_projection"] = dp_projection(args, ms_per_step, stats)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.sh_degree)
     if use_pg:

@@ -581,6 +581,10 @@ def rasterization_camera_sharded(
         colors = colors[sel]  # per-view colours follow their cameras
     kwargs.pop("distributed", None)
     sparse_grads = kwargs.pop("sparse_grads", False)
+    if sparse_grads and kwargs.get("packed", True):
+        # (packed COO intermediates carry no [C, N] visibility array to build the plan from; silently returning without a plan
+        # would leave the caller reducing nothing)
+        raise ValueError("rasterization_camera_sharded(sparse_grads=True) needs packed=False")
     rc, ra, meta = rasterization(means, quats, scales, opacities, colors, viewmats[sel], Ks[sel], width, height,
                                  distributed=False, **kwargs)
     if sparse_grads and not kwargs.get("packed", True):
@@ -717,6 +721,14 @@ def _sparse_all_reduce(plist: List[Tensor], plan: SparseGradPlan, average: bool)
             p.grad = p.grad.contiguous()
     G = [p.grad.view(N, -1) for p in plist]
     lo = rank * block
+    if os.environ.get("GS_DP_DEBUG", "0") == "1":
+        # the sparse form only moves rows of the union: a loss term that reaches splats NO camera saw (an opacity or scale
+        # regulariser over all splats) would be left unreduced -- catch it instead of diverging silently
+        outside = ~plan.union[:N]
+        for p, g in zip(plist, G):
+            if bool((g[outside] != 0).any()):
+                raise RuntimeError("sparse gradient exchange: non-zero gradient rows outside the union of the visibility masks "
+                                   "(a loss term over all splats?) -- reduce those parameters densely (plan=None)")
     # ---- phase 1: [index | values] rows of my visible splats, grouped by owner (ascending indices)
     n_mine = sum(rows[rank])
     idx = plan.send_idx[:n_mine]
@@ -771,7 +783,9 @@ def all_reduce_splat_grads(
       * "all_reduce": one packed bucket, single all_reduce (what "auto" uses on gloo, which has no reduce_scatter).
     ``average=True`` matches a single-process batch whose loss is a mean over all C images.
     ``plan`` (from ``plan_sparse_grad_exchange``, built in the forward): only the rows of splats that some camera saw
-    travel (``_sparse_all_reduce``); every parameter must then have one row per splat.
+    travel (``_sparse_all_reduce``); every parameter must then have one row per splat, and its gradient must be zero for
+    splats no camera saw -- true for the render loss, NOT for a regulariser over all splats (reduce such parameters with
+    ``plan=None``; ``GS_DP_DEBUG=1`` checks the assumption on every call).
     """
     if world_size is None:
         world_size = dist.get_world_size() if dist.is_initialized() else 1
