@@ -269,11 +269,157 @@ __global__ void __launch_bounds__(GS_BLOCK) scatter_add_rows_kernel(uint64_t tot
     unsafeAtomicAdd(v_src + (uint64_t)ids[r] * width + c, v_out[e]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Plan of the sparse gradient reduction of the camera-sharded mode (distributed.py: plan_sparse_grad_exchange), built in the
+// forward pass from the visibility masks of all ranks.  The torch formulation (any / sum / cat / nonzero_static x 2 / cumsum /
+// where / casts) was ~35 launches of a few microseconds each: 0.34 ms of host-bound work per step.  Here: one kernel for the
+// mask, two for everything else.
+//   masks   uint8 [world, n_pad]   (n_pad = world * block; splat n belongs to owner n / block)
+//   counts  int32 [world * world + world], zero-filled by the caller:  rows[r][o] = splats of owner o that rank r saw,
+//                                                                     then urows[o] = splats of owner o that ANY rank saw
+//   send_idx [n_pad]  my visible splats, ascending (entries behind their count: undefined)
+//   urank    [n_pad]  position of every union splat in the ascending list of ALL union splats
+//   uidx     [n_pad]  that list
+constexpr int PLAN_ITEMS = 8;
+constexpr int PLAN_TILE = GS_BLOCK * PLAN_ITEMS; // 2048 splats per workgroup
+constexpr int PLAN_MAX_WORLD = 16;
+
+__global__ void __launch_bounds__(GS_BLOCK) dp_vis_kernel(uint32_t C, uint32_t N, uint32_t n_pad, const int32_t *__restrict__ radii,
+                                                          uint8_t *__restrict__ vis) {
+    const uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (n >= n_pad) return;
+    uint8_t v = 0;
+    if (n < N)
+        for (uint32_t c = 0; c < C; ++c) v |= radii[(size_t)c * N + n] > 0 ? 1 : 0;
+    vis[n] = v;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) dp_plan_count_kernel(uint32_t world, uint32_t rank, uint32_t n_pad, uint32_t block,
+                                                                 const uint8_t *__restrict__ masks, uint2 *__restrict__ tile_counts,
+                                                                 int32_t *__restrict__ counts) {
+    __shared__ int32_t s_cnt[PLAN_MAX_WORLD + 1][PLAN_MAX_WORLD]; // [rank | union][owner]
+    __shared__ uint32_t s_red[2][GS_BLOCK / GS_WAVE];
+    for (uint32_t i = threadIdx.x; i < (PLAN_MAX_WORLD + 1) * PLAN_MAX_WORLD; i += GS_BLOCK) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t n0 = blockIdx.x * PLAN_TILE + threadIdx.x * PLAN_ITEMS;
+    uint32_t mine = 0, uni = 0;
+    for (int k = 0; k < PLAN_ITEMS; ++k) {
+        const uint32_t n = n0 + k;
+        if (n >= n_pad) break;
+        const uint32_t o = n / block;
+        bool any = false;
+        for (uint32_t r = 0; r < world; ++r) {
+            if (masks[(size_t)r * n_pad + n]) {
+                any = true;
+                atomicAdd(&s_cnt[r][o], 1);
+                if (r == rank) ++mine;
+            }
+        }
+        if (any) {
+            ++uni;
+            atomicAdd(&s_cnt[PLAN_MAX_WORLD][o], 1);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mine += __shfl_xor(mine, off, 64);
+        uni += __shfl_xor(uni, off, 64);
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        s_red[0][threadIdx.x >> 6] = mine;
+        s_red[1][threadIdx.x >> 6] = uni;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        tile_counts[blockIdx.x] = make_uint2(s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3], s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]);
+    for (uint32_t i = threadIdx.x; i < (world + 1) * world; i += GS_BLOCK) {
+        const uint32_t r = i / world, o = i % world;
+        const int32_t c = r < world ? s_cnt[r][o] : s_cnt[PLAN_MAX_WORLD][o];
+        if (c != 0) atomicAdd(&counts[i], c);
+    }
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) dp_plan_fill_kernel(uint32_t world, uint32_t rank, uint32_t n_pad, const uint8_t *__restrict__ masks,
+                                                                const uint2 *__restrict__ tile_counts, int32_t *__restrict__ send_idx,
+                                                                int32_t *__restrict__ urank, int32_t *__restrict__ uidx) {
+    __shared__ uint32_t s_pre[2][GS_BLOCK / GS_WAVE];
+    __shared__ uint32_t s_w[2][GS_BLOCK / GS_WAVE];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // offsets of this tile: its predecessors' counts (every tile adds them up itself: a few thousand tiles at most)
+    uint32_t pm = 0, pu = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += GS_BLOCK) {
+        const uint2 c = tile_counts[b];
+        pm += c.x;
+        pu += c.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        pm += __shfl_xor(pm, off, 64);
+        pu += __shfl_xor(pu, off, 64);
+    }
+    if (lane == 0) {
+        s_pre[0][wave] = pm;
+        s_pre[1][wave] = pu;
+    }
+    const uint32_t n0 = blockIdx.x * PLAN_TILE + threadIdx.x * PLAN_ITEMS;
+    uint32_t fm = 0, fu = 0; // flags of my 8 splats
+    for (int k = 0; k < PLAN_ITEMS; ++k) {
+        const uint32_t n = n0 + k;
+        if (n >= n_pad) break;
+        bool any = false;
+        for (uint32_t r = 0; r < world; ++r) any |= masks[(size_t)r * n_pad + n] != 0;
+        if (masks[(size_t)rank * n_pad + n]) fm |= 1u << k;
+        if (any) fu |= 1u << k;
+    }
+    uint32_t im = (uint32_t)__popc(fm), iu = (uint32_t)__popc(fu);
+    const uint32_t cm = im, cu = iu;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t a = __shfl_up(im, off, 64), b = __shfl_up(iu, off, 64);
+        if (lane >= (uint32_t)off) {
+            im += a;
+            iu += b;
+        }
+    }
+    if (lane == 63u) {
+        s_w[0][wave] = im;
+        s_w[1][wave] = iu;
+    }
+    __syncthreads();
+    uint32_t bm = s_pre[0][0] + s_pre[0][1] + s_pre[0][2] + s_pre[0][3] + im - cm;
+    uint32_t bu = s_pre[1][0] + s_pre[1][1] + s_pre[1][2] + s_pre[1][3] + iu - cu;
+    for (uint32_t w = 0; w < wave; ++w) {
+        bm += s_w[0][w];
+        bu += s_w[1][w];
+    }
+    for (int k = 0; k < PLAN_ITEMS; ++k) {
+        const uint32_t n = n0 + k;
+        if (n >= n_pad) break;
+        if ((fm >> k) & 1u) send_idx[bm++] = (int32_t)n;
+        if ((fu >> k) & 1u) {
+            urank[n] = (int32_t)bu;
+            uidx[bu++] = (int32_t)n;
+        }
+    }
+}
+
+// the owner's compact accumulator of the reduction: rows of 1 + width floats, column 0 = the global splat index of the
+// row (int32 bit pattern; -1 for the padding rows behind n_valid), the values zero
+__global__ void __launch_bounds__(GS_BLOCK) dp_acc_init_kernel(uint64_t total, uint32_t row_w, uint32_t n_valid, const int32_t *__restrict__ uidx,
+                                                               float *__restrict__ acc) {
+    const uint64_t e = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (e >= total) return;
+    const uint64_t r = e / row_w;
+    const uint32_t c = (uint32_t)(e - r * row_w);
+    acc[e] = c == 0u ? __int_as_float(r < n_valid ? uidx[r] : -1) : 0.f;
+}
+
 // Wire rows that carry their own destination: column 0 of a [n_rows, 1 + width] wire row is a global row index (int32 bit
-// pattern; negative = no row), the rest its values.  acc[map[index - lo]][1 + c] += scale * wire[r][1 + c]: the owner side of
-// the sparse gradient reduction (distributed.py) adds the rows it received for its block into the block's compact accumulator.
+// pattern; negative = no row), the rest its values.  acc[map[index] - map_offset][1 + c] += scale * wire[r][1 + c]: the owner
+// side of the sparse gradient reduction (distributed.py) adds the rows it received for its block into the block's compact
+// accumulator (map = position in the list of all union splats, map_offset = where this owner's part of that list starts).
 __global__ void __launch_bounds__(GS_BLOCK) scatter_add_wire_rows_kernel(uint64_t total, uint32_t width, const float *__restrict__ wire,
-                                                                         const int32_t *__restrict__ map, int32_t lo, float scale,
+                                                                         const int32_t *__restrict__ map, int32_t map_offset, float scale,
                                                                          float *__restrict__ acc) {
     const uint64_t e = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
     if (e >= total) return;
@@ -282,19 +428,56 @@ __global__ void __launch_bounds__(GS_BLOCK) scatter_add_wire_rows_kernel(uint64_
     const float *w = wire + r * (width + 1u);
     const int32_t idx = __float_as_int(w[0]);
     if (idx < 0) return;
-    unsafeAtomicAdd(acc + (uint64_t)map[idx - lo] * (width + 1u) + 1u + c, w[1u + c] * scale);
+    unsafeAtomicAdd(acc + (uint64_t)(map[idx] - map_offset) * (width + 1u) + 1u + c, w[1u + c] * scale);
 }
 
 }  // namespace
 
-extern "C" int32_t gs_scatter_add_wire_rows(uint64_t n_rows, uint32_t width, const float *wire, const int32_t *map, int32_t lo,
+extern "C" uint32_t gs_dp_plan_tiles(uint32_t n_pad) { return gs_div_up(n_pad, PLAN_TILE); }
+
+extern "C" int32_t gs_dp_visibility(uint32_t C, uint32_t N, uint32_t n_pad, const int32_t *radii, uint8_t *vis, gs_stream_t stream) {
+    if (n_pad == 0) return 0;
+    GS_CHECK_ARG(vis && (radii || C * N == 0) && n_pad >= N, "null pointer / n_pad < N");
+    hipLaunchKernelGGL(dp_vis_kernel, dim3(gs_div_up(n_pad, GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, n_pad, radii, vis);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_dp_plan(uint32_t world, uint32_t rank, uint32_t n_pad, uint32_t block, const uint8_t *masks, void *tile_counts,
+                              int32_t *counts, int32_t *send_idx, int32_t *urank, int32_t *uidx, gs_stream_t stream) {
+    if (n_pad == 0) return 0;
+    GS_CHECK_ARG(masks && tile_counts && counts && send_idx && urank && uidx, "null pointer");
+    GS_CHECK_ARG(world >= 1 && world <= (uint32_t)PLAN_MAX_WORLD && rank < world && block >= 1 && (uint64_t)block * world == n_pad,
+                 "world in 1..16, n_pad = world * block");
+    const uint32_t tiles = gs_div_up(n_pad, PLAN_TILE);
+    GS_CHECK_ARG(tiles <= 65536u, "too many splats for the two-launch plan (the caller falls back to the torch formulation)");
+    hipLaunchKernelGGL(dp_plan_count_kernel, dim3(tiles), dim3(GS_BLOCK), 0, (hipStream_t)stream, world, rank, n_pad, block, masks,
+                       (uint2 *)tile_counts, counts);
+    hipLaunchKernelGGL(dp_plan_fill_kernel, dim3(tiles), dim3(GS_BLOCK), 0, (hipStream_t)stream, world, rank, n_pad, masks,
+                       (const uint2 *)tile_counts, send_idx, urank, uidx);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_dp_acc_init(uint64_t n_rows, uint32_t width, uint32_t n_valid, const int32_t *uidx, float *acc, gs_stream_t stream) {
+    if (n_rows == 0) return 0;
+    GS_CHECK_ARG(acc && (uidx || n_valid == 0), "null pointer");
+    const uint64_t total = n_rows * (width + 1u);
+    GS_CHECK_ARG(total / GS_BLOCK < (1ull << 31), "too many elements");
+    hipLaunchKernelGGL(dp_acc_init_kernel, dim3((uint32_t)((total + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream, total,
+                       width + 1u, n_valid, uidx, acc);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_scatter_add_wire_rows(uint64_t n_rows, uint32_t width, const float *wire, const int32_t *map, int32_t map_offset,
                                             float scale, float *acc, gs_stream_t stream) {
     if (n_rows == 0 || width == 0) return 0;
     GS_CHECK_ARG(wire && map && acc, "null pointer");
     const uint64_t total = n_rows * width;
     GS_CHECK_ARG(total / GS_BLOCK < (1ull << 31), "too many elements");
     hipLaunchKernelGGL(scatter_add_wire_rows_kernel, dim3((uint32_t)((total + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0,
-                       (hipStream_t)stream, total, width, wire, map, lo, scale, acc);
+                       (hipStream_t)stream, total, width, wire, map, map_offset, scale, acc);
     GS_CHECK_LAUNCH();
     return 0;
 }

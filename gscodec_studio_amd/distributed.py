@@ -644,7 +644,8 @@ def plan_sparse_grad_exchange(radii: Tensor, world_size: Optional[int] = None) -
     """Call in the forward pass, right after projection (``meta["radii"]`` [C_local, N]): all-gathers the per-splat
     visibility masks of all ranks (1 byte per splat and rank: 1 MB at 1 M splats against the 236 MB of gradients), builds
     the index lists of the reduction and starts the asynchronous read-back of the row counts.  Splat n belongs to owner
-    block n // ceil(N / world)."""
+    block n // ceil(N / world).  On the GPU the lists come from three kernels (gs_dp_visibility, gs_dp_plan: two launches);
+    the torch formulation below (CPU / gloo tests, world > 16) is ~35 small launches."""
     if world_size is None:
         world_size = dist.get_world_size() if dist.is_initialized() else 1
     if _single(world_size):
@@ -652,45 +653,68 @@ def plan_sparse_grad_exchange(radii: Tensor, world_size: Optional[int] = None) -
     rank = dist.get_rank()
     N = radii.shape[-1]
     block = -(-N // world_size)
-    lo = rank * block
-    vis = torch.zeros(world_size * block, dtype=torch.uint8, device=radii.device)
-    vis[:N] = (radii.reshape(-1, N) > 0).any(0)
-    masks = torch.empty((world_size, world_size * block), dtype=torch.uint8, device=radii.device)
+    n_pad = world_size * block
+    dev = radii.device
+    native = radii.is_cuda and world_size <= 16 and radii.dtype == torch.int32
+    if native:
+        from . import _backend as B
+
+        r2 = radii.reshape(-1, N).contiguous()
+        vis = torch.empty(n_pad, dtype=torch.uint8, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            B.call("gs_dp_visibility", r2.shape[0], N, n_pad, B.ptr(r2), B.ptr(vis), st)
+    else:
+        vis = torch.zeros(n_pad, dtype=torch.uint8, device=dev)
+        vis[:N] = (radii.reshape(-1, N) > 0).any(0)
+    masks = torch.empty((world_size, n_pad), dtype=torch.uint8, device=dev)
     _all_gather_into(masks.view(-1), vis)
+    if native:
+        counts = torch.zeros(world_size * world_size + world_size, dtype=torch.int32, device=dev)
+        send_idx = torch.empty(n_pad, dtype=torch.int32, device=dev)
+        urank, uidx = torch.empty_like(send_idx), torch.empty_like(send_idx)
+        tiles = torch.empty(int(B.query("gs_dp_plan_tiles", n_pad)) * 2, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            B.call("gs_dp_plan", world_size, rank, n_pad, block, B.ptr(masks), B.ptr(tiles), B.ptr(counts), B.ptr(send_idx), B.ptr(urank),
+                   B.ptr(uidx), st)
+        union = None
+        pinned = torch.empty(counts.numel(), dtype=torch.int32).pin_memory()
+        pinned.copy_(counts, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        return SparseGradPlan(N, world_size, rank, block, masks, union, send_idx, urank, uidx, pinned, ev)
     union = masks.any(0)
     rows = masks.view(world_size, world_size, block).sum(-1, dtype=torch.int32)      # [rank, owner]
     urows = union.view(world_size, block).sum(-1, dtype=torch.int32)                 # [owner]
     both = torch.cat([rows.reshape(-1), urows]).to(torch.int64)
     # index lists (static sizes, -1 padded; ascending order keeps every owner's rows contiguous)
-    send_idx = torch.nonzero_static(vis, size=world_size * block, fill_value=-1).view(-1).to(torch.int32)
-    ub = union[lo:lo + block]
-    urank = torch.cumsum(ub, 0, dtype=torch.int32) - 1
-    uidx = torch.nonzero_static(ub, size=block, fill_value=-1).view(-1)
-    uidx = torch.where(uidx >= 0, uidx + lo, uidx).to(torch.int32)
+    send_idx = torch.nonzero_static(vis, size=n_pad, fill_value=-1).view(-1).to(torch.int32)
+    urank = torch.cumsum(union, 0, dtype=torch.int32) - 1                            # position in the list of ALL union splats
+    uidx = torch.nonzero_static(union, size=n_pad, fill_value=-1).view(-1).to(torch.int32)
     if both.is_cuda:
         pinned = torch.empty(both.numel(), dtype=torch.int64).pin_memory()
         pinned.copy_(both, non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(radii.device))
+        ev.record(torch.cuda.current_stream(dev))
     else:
         pinned, ev = both.clone(), None
     return SparseGradPlan(N, world_size, rank, block, masks, union, send_idx, urank, uidx, pinned, ev)
 
 
-def _scatter_add_wire_rows(acc: Tensor, wire: Tensor, urank: Tensor, lo: int, scale: float) -> None:
-    """acc[urank[index - lo]][1:] += scale * wire[r][1:], index = the int32 bit pattern in wire[r][0] (negative: no row)."""
+def _scatter_add_wire_rows(acc: Tensor, wire: Tensor, urank: Tensor, uoff: int, scale: float) -> None:
+    """acc[urank[index] - uoff][1:] += scale * wire[r][1:], index = the int32 bit pattern in wire[r][0] (negative: no row)."""
     if wire.shape[0] == 0:
         return
     if acc.is_cuda:
         from . import _backend as B
 
         with torch.cuda.device(acc.device):
-            B.call("gs_scatter_add_wire_rows", wire.shape[0], wire.shape[1] - 1, B.ptr(wire), B.ptr(urank), int(lo), float(scale),
+            B.call("gs_scatter_add_wire_rows", wire.shape[0], wire.shape[1] - 1, B.ptr(wire), B.ptr(urank), int(uoff), float(scale),
                    B.ptr(acc), torch.cuda.current_stream(acc.device).cuda_stream)
         return
     idx = wire[:, 0].contiguous().view(torch.int32).long()
     ok = idx >= 0
-    acc[:, 1:].index_add_(0, urank[(idx[ok] - lo)].long(), wire[ok, 1:] * scale)
+    acc[:, 1:].index_add_(0, urank[idx[ok]].long() - uoff, wire[ok, 1:] * scale)
 
 
 def _sparse_all_reduce(plist: List[Tensor], plan: SparseGradPlan, average: bool) -> None:
@@ -703,9 +727,9 @@ def _sparse_all_reduce(plist: List[Tensor], plan: SparseGradPlan, average: bool)
     (all-gather): every owner hands out that accumulator, padded to the largest union, and every rank writes the rows back
     at the indices they carry.  Rows outside the union are zero on every rank and stay untouched (the render loss gives
     culled splats exactly zero gradient; a loss term that touches EVERY splat, such as an opacity regulariser, must be
-    reduced densely -- see all_reduce_splat_grads).  Local work: one pack, one scatter-add, one unpack kernel over the
-    visible rows; every index list comes from the plan built in the forward; no host synchronisation beyond the plan's
-    counts."""
+    reduced densely -- see all_reduce_splat_grads).  Local work: one pack, one accumulator init, one scatter-add, one unpack
+    kernel over the visible rows; every index list comes from the plan built in the forward; no host synchronisation beyond
+    the plan's counts."""
     W, rank, N, block = plan.world, plan.rank, plan.N, plan.block
     rows, urows = plan.counts()
     dev = plist[0].device
@@ -720,11 +744,10 @@ def _sparse_all_reduce(plist: List[Tensor], plan: SparseGradPlan, average: bool)
         elif not p.grad.is_contiguous():
             p.grad = p.grad.contiguous()
     G = [p.grad.view(N, -1) for p in plist]
-    lo = rank * block
     if os.environ.get("GS_DP_DEBUG", "0") == "1":
         # the sparse form only moves rows of the union: a loss term that reaches splats NO camera saw (an opacity or scale
         # regulariser over all splats) would be left unreduced -- catch it instead of diverging silently
-        outside = ~plan.union[:N]
+        outside = ~plan.masks.any(0)[:N]
         for p, g in zip(plist, G):
             if bool((g[outside] != 0).any()):
                 raise RuntimeError("sparse gradient exchange: non-zero gradient rows outside the union of the visibility masks "
@@ -739,16 +762,26 @@ def _sparse_all_reduce(plist: List[Tensor], plan: SparseGradPlan, average: bool)
     recv = send.new_empty((sum(out_splits), D + 1))
     _all_to_all_single(recv, send, out_splits, in_splits)
     umax = max(int(u) for u in urows)
-    acc = torch.zeros((umax, D + 1), dtype=torch.float32, device=dev)
-    if umax:
-        acc[:, 0].view(torch.int32).copy_(plan.uidx[:umax]) if acc.is_cuda else acc[:, 0].copy_(plan.uidx[:umax].view(torch.float32))
-    _scatter_add_wire_rows(acc, recv, plan.urank, lo, (1.0 / W) if average else 1.0)
+    uoff, n_u = sum(int(u) for u in urows[:rank]), int(urows[rank])
+    # the owner's accumulator: one row per union splat of my block (column 0 = its index), padded to the largest union
+    if dev.type == "cuda":
+        from . import _backend as B
+
+        acc = torch.empty((umax, D + 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            B.call("gs_dp_acc_init", umax, D, n_u, B.ptr(plan.uidx[uoff:uoff + n_u]) if n_u else None, B.ptr(acc),
+                   torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        acc = torch.zeros((umax, D + 1), dtype=torch.float32, device=dev)
+        col0 = torch.full((umax,), -1, dtype=torch.int32)
+        col0[:n_u] = plan.uidx[uoff:uoff + n_u]
+        acc[:, 0] = col0.view(torch.float32)
+    _scatter_add_wire_rows(acc, recv, plan.urank, uoff, (1.0 / W) if average else 1.0)
     # ---- phase 2: every owner's union rows to everybody; padding rows carry index -1 and are skipped
     allrows = acc.new_empty((W * umax, D + 1))
     _all_gather_into(allrows.view(-1), acc.view(-1))
-    if umax:
-        back = allrows[:, 0].contiguous().view(torch.int32)
-        _unpack_rows(allrows, [(None, 1, False)] + [(g, wdt, True) for g, wdt in zip(G, widths)], back)
+    if umax:  # (the row index is column 0 of the wire rows themselves: a strided int32 view, no copy)
+        _unpack_rows(allrows, [(None, 1, False)] + [(g, wdt, True) for g, wdt in zip(G, widths)], allrows.view(torch.int32)[:, 0])
 
 
 def _scatter_add_rows(acc: Tensor, idx: Tensor, rows: Tensor) -> None:

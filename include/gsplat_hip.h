@@ -732,11 +732,26 @@ int32_t gs_gather_rows_f32(
     uint64_t n_rows, uint32_t width, const float *src, const int64_t *ids, float *out, gs_stream_t stream);
 int32_t gs_scatter_add_rows_f32(
     uint64_t n_rows, uint32_t width, const float *v_out, const int64_t *ids, float *v_src, gs_stream_t stream);
+/* Plan of the sparse gradient reduction of the camera-sharded mode (distributed.py; no reference counterpart: the reference's
+ * multi-GPU mode shards the gaussians).  gs_dp_visibility: vis[n] = any camera c with radii[c, n] > 0 (zeros behind N, up to
+ * n_pad).  gs_dp_plan, from the all-gathered masks uint8 [world, n_pad = world * block] (splat n belongs to owner n / block):
+ *   counts   int32 [world * world + world], ZERO-FILLED by the caller: rows[r][o] = splats of owner o that rank r saw, then
+ *            urows[o] = splats of owner o that any rank saw;
+ *   send_idx int32 [n_pad]: this rank's visible splats, ascending; urank int32 [n_pad]: position of every union splat in
+ *            the ascending list of all union splats; uidx int32 [n_pad]: that list (entries behind the counts: undefined);
+ *   tile_counts: scratch, 8 bytes x gs_dp_plan_tiles(n_pad).  world <= 16.
+ * gs_dp_acc_init: the owner's accumulator, n_rows x (1 + width) floats: column 0 = uidx[r] for r < n_valid, else -1 (both as
+ * int32 bit patterns), values zero. */
+uint32_t gs_dp_plan_tiles(uint32_t n_pad);
+int32_t gs_dp_visibility(uint32_t C, uint32_t N, uint32_t n_pad, const int32_t *radii, uint8_t *vis, gs_stream_t stream);
+int32_t gs_dp_plan(uint32_t world, uint32_t rank, uint32_t n_pad, uint32_t block, const uint8_t *masks, void *tile_counts,
+                   int32_t *counts, int32_t *send_idx, int32_t *urank, int32_t *uidx, gs_stream_t stream);
+int32_t gs_dp_acc_init(uint64_t n_rows, uint32_t width, uint32_t n_valid, const int32_t *uidx, float *acc, gs_stream_t stream);
 /* Wire rows that carry their destination (the sparse gradient reduction of the camera-sharded mode, distributed.py): wire is
  * [n_rows, 1 + width], column 0 a global row index as an int32 bit pattern (negative: no row).  Adds
- * scale * wire[r][1 + c] into acc[map[index - lo]][1 + c] (acc rows are 1 + width floats wide too; float atomics). */
+ * scale * wire[r][1 + c] into acc[map[index] - map_offset][1 + c] (acc rows are 1 + width floats wide too; float atomics). */
 int32_t gs_scatter_add_wire_rows(
-    uint64_t n_rows, uint32_t width, const float *wire, const int32_t *map, int32_t lo, float scale, float *acc,
+    uint64_t n_rows, uint32_t width, const float *wire, const int32_t *map, int32_t map_offset, float scale, float *acc,
     gs_stream_t stream);
 
 #ifdef __cplusplus
