@@ -460,34 +460,46 @@ __global__ void __launch_bounds__(GS_BLOCK) dp_plan_fill_kernel(uint32_t world, 
     }
 }
 
-// the owner's compact accumulator of the reduction: rows of 1 + width floats, column 0 = the global splat index of the
-// row (int32 bit pattern; -1 for the padding rows behind n_valid), the values zero
-__global__ void __launch_bounds__(GS_BLOCK) dp_acc_init_kernel(uint64_t total, uint32_t row_w, uint32_t n_valid, const int32_t *__restrict__ uidx,
-                                                               float *__restrict__ acc) {
-    const uint64_t e = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
-    if (e >= total) return;
-    const uint64_t r = e / row_w;
-    const uint32_t c = (uint32_t)(e - r * row_w);
-    acc[e] = c == 0u ? __int_as_float(r < n_valid ? uidx[r] : -1) : 0.f;
+// The owner side of the sparse gradient reduction WITHOUT atomics.  The rows an owner receives (wire, [n_recv, 1 + width],
+// column 0 = global splat index as an int32 bit pattern) come in one chunk per sender; a union splat of the owner's block gets
+// at most one row from every sender.  Scatter-adding them into a zero-filled accumulator took a 36 us fill + 82 us of float
+// atomics (17 M of them) for 293 K rows of 59 floats; instead
+//   dp_inv_kernel      notes, per (sender, accumulator row), WHICH received row belongs there (plain stores: the pair is unique),
+//   dp_reduce_kernel   then writes every accumulator row once: its index column, and the sum of its <= world received rows.
+struct ChunkStarts {
+    int64_t v[PLAN_MAX_WORLD + 1]; // first received row of every sender's chunk; v[world] = n_recv
+};
+
+__global__ void __launch_bounds__(GS_BLOCK) dp_inv_kernel(uint64_t n_recv, uint32_t row_w, uint32_t world, ChunkStarts cs, const float *__restrict__ wire,
+                                                          const int32_t *__restrict__ map, int32_t map_offset, uint64_t umax,
+                                                          int32_t *__restrict__ inv) {
+    const uint64_t r = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (r >= n_recv) return;
+    const int32_t idx = __float_as_int(wire[r * row_w]);
+    if (idx < 0) return;
+    uint32_t snd = 0;
+    for (uint32_t k = 1; k < world; ++k)
+        if ((int64_t)r >= cs.v[k]) snd = k;
+    inv[(uint64_t)snd * umax + (uint64_t)(map[idx] - map_offset)] = (int32_t)r;
 }
 
-// Wire rows that carry their own destination: column 0 of a [n_rows, 1 + width] wire row is a global row index (int32 bit
-// pattern; negative = no row), the rest its values.  acc[map[index] - map_offset][1 + c] += scale * wire[r][1 + c]: the owner
-// side of the sparse gradient reduction (distributed.py) adds the rows it received for its block into the block's compact
-// accumulator (map = position in the list of all union splats, map_offset = where this owner's part of that list starts).
-__global__ void __launch_bounds__(GS_BLOCK) scatter_add_wire_rows_kernel(uint64_t n_rows, uint32_t width, const float *__restrict__ wire,
-                                                                         const int32_t *__restrict__ map, int32_t map_offset, float scale,
-                                                                         float *__restrict__ acc) {
-    // one wave per row (lane = column, looping when a row is wider than a wave): the index and its map entry are wave-uniform
-    // loads, the adds of a row go to consecutive addresses.  (One thread per ELEMENT re-read both 59 times: 87 us for 293 K rows.)
-    const uint32_t lane = threadIdx.x & 63u;
+__global__ void __launch_bounds__(GS_BLOCK) dp_reduce_kernel(uint64_t umax, uint32_t width, uint32_t world, const float *__restrict__ wire,
+                                                             const int32_t *__restrict__ inv, const int32_t *__restrict__ uidx, uint32_t n_valid,
+                                                             float scale, float *__restrict__ acc) {
+    // one wave per accumulator row, lane = column; the per-sender row numbers are wave-uniform loads
+    const uint32_t lane = threadIdx.x & 63u, row_w = width + 1u;
     const uint64_t wave = (uint64_t)blockIdx.x * (GS_BLOCK / GS_WAVE) + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * (GS_BLOCK / GS_WAVE);
-    for (uint64_t r = wave; r < n_rows; r += n_waves) {
-        const float *w = wire + r * (width + 1u);
-        const int32_t idx = __float_as_int(w[0]);
-        if (idx < 0) continue;
-        float *dst = acc + (uint64_t)(map[idx] - map_offset) * (width + 1u) + 1u;
-        for (uint32_t c = lane; c < width; c += GS_WAVE) unsafeAtomicAdd(dst + c, w[1u + c] * scale);
+    for (uint64_t u = wave; u < umax; u += n_waves) {
+        float *dst = acc + u * row_w;
+        if (lane == 0) dst[0] = __int_as_float(u < n_valid ? uidx[u] : -1);
+        for (uint32_t c = lane; c < width; c += GS_WAVE) {
+            float sum = 0.f;
+            for (uint32_t s = 0; s < world; ++s) {
+                const int32_t r = inv[(uint64_t)s * umax + u];
+                if (r >= 0) sum += wire[(uint64_t)r * row_w + 1u + c];
+            }
+            dst[1u + c] = sum * scale;
+        }
     }
 }
 
@@ -519,24 +531,22 @@ extern "C" int32_t gs_dp_plan(uint32_t world, uint32_t rank, uint32_t n_pad, uin
     return 0;
 }
 
-extern "C" int32_t gs_dp_acc_init(uint64_t n_rows, uint32_t width, uint32_t n_valid, const int32_t *uidx, float *acc, gs_stream_t stream) {
-    if (n_rows == 0) return 0;
-    GS_CHECK_ARG(acc && (uidx || n_valid == 0), "null pointer");
-    const uint64_t total = n_rows * (width + 1u);
-    GS_CHECK_ARG(total / GS_BLOCK < (1ull << 31), "too many elements");
-    hipLaunchKernelGGL(dp_acc_init_kernel, dim3((uint32_t)((total + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream, total,
-                       width + 1u, n_valid, uidx, acc);
-    GS_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int32_t gs_scatter_add_wire_rows(uint64_t n_rows, uint32_t width, const float *wire, const int32_t *map, int32_t map_offset,
-                                            float scale, float *acc, gs_stream_t stream) {
-    if (n_rows == 0 || width == 0) return 0;
-    GS_CHECK_ARG(wire && map && acc, "null pointer");
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_rows + 3) / 4, 256ull * 16ull);
-    hipLaunchKernelGGL(scatter_add_wire_rows_kernel, dim3(blocks), dim3(GS_BLOCK), 0, (hipStream_t)stream, n_rows, width, wire, map,
-                       map_offset, scale, acc);
+extern "C" int32_t gs_dp_reduce_rows(uint64_t n_recv, uint32_t width, uint32_t world, const float *wire, const int64_t *chunk_starts,
+                                     const int32_t *map, int32_t map_offset, uint64_t umax, uint32_t n_valid, const int32_t *uidx, float scale,
+                                     int32_t *inv, float *acc, gs_stream_t stream) {
+    if (umax == 0) return 0;
+    GS_CHECK_ARG(acc && inv && chunk_starts && (wire || n_recv == 0) && (map || n_recv == 0) && (uidx || n_valid == 0), "null pointer");
+    GS_CHECK_ARG(world >= 1 && world <= (uint32_t)PLAN_MAX_WORLD && width >= 1, "world in 1..16");
+    GS_CHECK_ARG(n_recv < (1ull << 31) && umax < (1ull << 31), "too many rows");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(inv, 0xff, (size_t)world * umax * sizeof(int32_t), st) != hipSuccess) { gs_set_error("gs_dp_reduce_rows: memset failed"); return 1; }
+    ChunkStarts cs;
+    for (uint32_t k = 0; k <= world; ++k) cs.v[k] = chunk_starts[k];
+    if (n_recv > 0)
+        hipLaunchKernelGGL(dp_inv_kernel, dim3(gs_div_up(n_recv, GS_BLOCK)), dim3(GS_BLOCK), 0, st, n_recv, width + 1u, world, cs, wire, map, map_offset,
+                           umax, inv);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((umax + 3) / 4, 256ull * 16ull);
+    hipLaunchKernelGGL(dp_reduce_kernel, dim3(blocks), dim3(GS_BLOCK), 0, st, umax, width, world, wire, inv, uidx, n_valid, scale, acc);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -701,20 +701,36 @@ def plan_sparse_grad_exchange(radii: Tensor, world_size: Optional[int] = None) -
     return SparseGradPlan(N, world_size, rank, block, masks, union, send_idx, urank, uidx, pinned, ev)
 
 
-def _scatter_add_wire_rows(acc: Tensor, wire: Tensor, urank: Tensor, uoff: int, scale: float) -> None:
-    """acc[urank[index] - uoff][1:] += scale * wire[r][1:], index = the int32 bit pattern in wire[r][0] (negative: no row)."""
-    if wire.shape[0] == 0:
-        return
-    if acc.is_cuda:
+def _reduce_received_rows(recv: Tensor, out_splits: List[int], urank: Tensor, uoff: int, uidx_mine: Tensor, umax: int,
+                          scale: float) -> Tensor:
+    """The owner's accumulator [umax, 1 + D]: row u = (index of the u-th union splat of my block, or -1 for padding |
+    scale * sum over senders of the received row of that splat).  ``recv`` holds one chunk per sender; column 0 of a row is
+    its splat index (int32 bit pattern)."""
+    D1 = recv.shape[1]
+    n_u = int(uidx_mine.numel())
+    if recv.is_cuda:
+        import ctypes
+
         from . import _backend as B
 
-        with torch.cuda.device(acc.device):
-            B.call("gs_scatter_add_wire_rows", wire.shape[0], wire.shape[1] - 1, B.ptr(wire), B.ptr(urank), int(uoff), float(scale),
-                   B.ptr(acc), torch.cuda.current_stream(acc.device).cuda_stream)
-        return
-    idx = wire[:, 0].contiguous().view(torch.int32).long()
-    ok = idx >= 0
-    acc[:, 1:].index_add_(0, urank[idx[ok]].long() - uoff, wire[ok, 1:] * scale)
+        W = len(out_splits)
+        acc = torch.empty((umax, D1), dtype=torch.float32, device=recv.device)
+        inv = torch.empty(W * umax, dtype=torch.int32, device=recv.device)
+        starts = (ctypes.c_int64 * (W + 1))(*([0] + [sum(out_splits[: k + 1]) for k in range(W)]))
+        with torch.cuda.device(recv.device):
+            B.call("gs_dp_reduce_rows", recv.shape[0], D1 - 1, W, B.ptr(recv), ctypes.addressof(starts), B.ptr(urank), int(uoff), umax,
+                   n_u, B.ptr(uidx_mine) if n_u else None, float(scale), B.ptr(inv), B.ptr(acc),
+                   torch.cuda.current_stream(recv.device).cuda_stream)
+        return acc
+    acc = torch.zeros((umax, D1), dtype=torch.float32, device=recv.device)
+    col0 = torch.full((umax,), -1, dtype=torch.int32)
+    col0[:n_u] = uidx_mine
+    acc[:, 0] = col0.view(torch.float32)
+    if recv.shape[0]:
+        idx = recv[:, 0].contiguous().view(torch.int32).long()
+        ok = idx >= 0
+        acc[:, 1:].index_add_(0, urank[idx[ok]].long() - uoff, recv[ok, 1:] * scale)
+    return acc
 
 
 def _sparse_all_reduce(plist: List[Tensor], plan: SparseGradPlan, average: bool) -> None:
@@ -727,8 +743,8 @@ def _sparse_all_reduce(plist: List[Tensor], plan: SparseGradPlan, average: bool)
     (all-gather): every owner hands out that accumulator, padded to the largest union, and every rank writes the rows back
     at the indices they carry.  Rows outside the union are zero on every rank and stay untouched (the render loss gives
     culled splats exactly zero gradient; a loss term that touches EVERY splat, such as an opacity regulariser, must be
-    reduced densely -- see all_reduce_splat_grads).  Local work: one pack, one accumulator init, one scatter-add, one unpack
-    kernel over the visible rows; every index list comes from the plan built in the forward; no host synchronisation beyond
+    reduced densely -- see all_reduce_splat_grads).  Local work: one pack, one gather-reduce, one unpack kernel over the
+    visible rows; every index list comes from the plan built in the forward; no host synchronisation beyond
     the plan's counts."""
     W, rank, N, block = plan.world, plan.rank, plan.N, plan.block
     rows, urows = plan.counts()
@@ -763,20 +779,9 @@ def _sparse_all_reduce(plist: List[Tensor], plan: SparseGradPlan, average: bool)
     _all_to_all_single(recv, send, out_splits, in_splits)
     umax = max(int(u) for u in urows)
     uoff, n_u = sum(int(u) for u in urows[:rank]), int(urows[rank])
-    # the owner's accumulator: one row per union splat of my block (column 0 = its index), padded to the largest union
-    if dev.type == "cuda":
-        from . import _backend as B
-
-        acc = torch.empty((umax, D + 1), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            B.call("gs_dp_acc_init", umax, D, n_u, B.ptr(plan.uidx[uoff:uoff + n_u]) if n_u else None, B.ptr(acc),
-                   torch.cuda.current_stream(dev).cuda_stream)
-    else:
-        acc = torch.zeros((umax, D + 1), dtype=torch.float32, device=dev)
-        col0 = torch.full((umax,), -1, dtype=torch.int32)
-        col0[:n_u] = plan.uidx[uoff:uoff + n_u]
-        acc[:, 0] = col0.view(torch.float32)
-    _scatter_add_wire_rows(acc, recv, plan.urank, uoff, (1.0 / W) if average else 1.0)
+    # the owner's accumulator: one row per union splat of my block (column 0 = its index), padded to the largest union; every
+    # row is the sum of the <= world rows received for it (gather-reduce: no atomics, no zero-fill)
+    acc = _reduce_received_rows(recv, out_splits, plan.urank, uoff, plan.uidx[uoff:uoff + n_u], umax, (1.0 / W) if average else 1.0)
     # ---- phase 2: every owner's union rows to everybody; padding rows carry index -1 and are skipped
     allrows = acc.new_empty((W * umax, D + 1))
     _all_gather_into(allrows.view(-1), acc.view(-1))

@@ -740,19 +740,18 @@ int32_t gs_scatter_add_rows_f32(
  *   send_idx int32 [n_pad]: this rank's visible splats, ascending; urank int32 [n_pad]: position of every union splat in
  *            the ascending list of all union splats; uidx int32 [n_pad]: that list (entries behind the counts: undefined);
  *   tile_counts: scratch, 8 bytes x gs_dp_plan_tiles(n_pad).  world <= 16.
- * gs_dp_acc_init: the owner's accumulator, n_rows x (1 + width) floats: column 0 = uidx[r] for r < n_valid, else -1 (both as
- * int32 bit patterns), values zero. */
+ * gs_dp_reduce_rows: the owner side of the reduction.  wire [n_recv, 1 + width] = the rows received from all senders (chunk
+ * of sender k = rows [chunk_starts[k], chunk_starts[k + 1]), HOST array of world + 1 entries), column 0 the global splat index
+ * as an int32 bit pattern (negative: no row).  Writes acc [umax, 1 + width]: row u = (uidx[u] for u < n_valid else -1 | scale *
+ * sum of the received rows whose index maps to u, u = map[index] - map_offset) -- every row written once, no atomics, no
+ * zero-fill.  inv: scratch, int32 [world * umax]. */
 uint32_t gs_dp_plan_tiles(uint32_t n_pad);
 int32_t gs_dp_visibility(uint32_t C, uint32_t N, uint32_t n_pad, const int32_t *radii, uint8_t *vis, gs_stream_t stream);
 int32_t gs_dp_plan(uint32_t world, uint32_t rank, uint32_t n_pad, uint32_t block, const uint8_t *masks, void *tile_counts,
                    int32_t *counts, int32_t *send_idx, int32_t *urank, int32_t *uidx, gs_stream_t stream);
-int32_t gs_dp_acc_init(uint64_t n_rows, uint32_t width, uint32_t n_valid, const int32_t *uidx, float *acc, gs_stream_t stream);
-/* Wire rows that carry their destination (the sparse gradient reduction of the camera-sharded mode, distributed.py): wire is
- * [n_rows, 1 + width], column 0 a global row index as an int32 bit pattern (negative: no row).  Adds
- * scale * wire[r][1 + c] into acc[map[index] - map_offset][1 + c] (acc rows are 1 + width floats wide too; float atomics). */
-int32_t gs_scatter_add_wire_rows(
-    uint64_t n_rows, uint32_t width, const float *wire, const int32_t *map, int32_t map_offset, float scale, float *acc,
-    gs_stream_t stream);
+int32_t gs_dp_reduce_rows(uint64_t n_recv, uint32_t width, uint32_t world, const float *wire, const int64_t *chunk_starts,
+                          const int32_t *map, int32_t map_offset, uint64_t umax, uint32_t n_valid, const int32_t *uidx, float scale,
+                          int32_t *inv, float *acc, gs_stream_t stream);
 
 #ifdef __cplusplus
 }
