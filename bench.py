@@ -53,7 +53,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # PMC traffic (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 correction applied)
 # measured for this workload and committed under profiles/; bench.py cannot run rocprof on itself.
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 KERNEL_OF_ENTRY = {"gs_rasterize_bwd": "raster_seg_bwd_kernel", "gs_rasterize_fwd": "raster_tile_fwd_kernel",
                    "gs_sh_view_bwd": "sh_bwd_kernel", "gs_sort_isect_pairs": "sort_scatter_kernel<unsigned int, 16, true>"}
 

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
     rm -rf /tmp/pmc_$c
     timeout -k 5 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- \
-        python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras --min-timed-s 0 > /tmp/pmc_$c.log 2>&1 < /dev/null
+        python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-dp-projection --min-timed-s 0 > /tmp/pmc_$c.log 2>&1 < /dev/null
     echo "$c rc=$?"
 done
 f=$(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)

@@ -9,7 +9,7 @@ out=/tmp/prof_$tag
 mkdir -p "$root/gpurun_out" "$out"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o p -- \
-    python "$root/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-extras --min-timed-s 0 "$@" > "$out/bench.log" 2>&1 < /dev/null
+    python "$root/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-dp-projection --min-timed-s 0 "$@" > "$out/bench.log" 2>&1 < /dev/null
 echo "rocprof rc=$?"
 f=$(find "$out" -name "*kernel_stats.csv" 2>/dev/null | head -1)
 if [ -n "$f" ]; then
