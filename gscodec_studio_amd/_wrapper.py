@@ -378,7 +378,7 @@ class _SphericalHarmonicsView(torch.autograd.Function):
                    B.ptr(coeffs_rest), B.ptr(radii),
                    B.ptr(colors), ctx.cstride, B.ptr(v_colors), vstride, B.ptr(v_coeffs), B.ptr(v_rest), B.ptr(v_means),
                    B.ptr(v_opac_cn) if ostride is not None else None, ostride or 0, B.ptr(v_opac) if ostride is not None else None,
-                   _stream(means))
+                   0, _stream(means))
         if not ctx.needs_input_grad[3]:
             v_coeffs = None
         # campos (camera poses) gets no gradient on this path; rasterization() takes the unfused
@@ -766,6 +766,44 @@ class _FullyFusedProjection(torch.autograd.Function):
         return (v_means, v_covars, v_quats, v_scales, v_viewmats) + (None,) * 10
 
 
+class GradPrefill:
+    """Hand-over between the two autograd nodes of ONE ``rasterization()`` call (not in the reference).
+
+    The per-gaussian gradients the projection backward returns (``v_sh`` 192 B per gaussian at degree 3, means / quats /
+    scales / opacities 44 B) are dense tensors whose rows are exact zeros for every gaussian no camera sees -- 71 % of
+    them at BASELINE config 2, 137 of the 193 MB the SH backward writes.  With a ``GradPrefill`` the projection node lists
+    in its FORWARD what its backward will return (``request``), the compositing forward allocates those tensors behind
+    its own gradient rows in one buffer and zero-fills the lot as the side job of its tile workgroups (``zero_fill`` of
+    ``gs_rasterize_fwd``: the memory pipes idle while the chip composites), and the projection backward then stores
+    only the rows of visible gaussians (``outputs_prefilled`` of ``gs_sh_view_bwd`` / ``gs_projection_rows_bwd``).
+    ``parts`` is consumed by the first backward; a repeated one (retain_graph) allocates and writes everything itself."""
+
+    __slots__ = ("request", "parts")
+
+    def __init__(self):
+        self.request = []  # [(key, shape)] filled by _ProjectRows.forward
+        self.parts = {}  # key -> zero-filled tensor, made by _RasterizeToPixels.forward
+
+    def floats(self) -> int:
+        return sum(_pad64(math.prod(shape)) for _, shape in self.request)
+
+    def carve(self, buf: Tensor, offset: int) -> None:
+        """Cut the requested tensors out of the flat fp32 ``buf`` starting at ``offset`` (256-byte aligned pieces)."""
+        self.parts = {}
+        for key, shape in self.request:
+            n = math.prod(shape)
+            self.parts[key] = buf[offset:offset + n].view(shape)
+            offset += _pad64(n)
+
+    def take(self) -> dict:
+        parts, self.parts = self.parts, {}
+        return parts
+
+
+def _pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
 def project_rows(
     means: Tensor,  # [N, 3]
     covars: Optional[Tensor],  # [N, 6] or None
@@ -786,6 +824,7 @@ def project_rows(
     sh_coeffs: Optional[Tensor] = None,  # [N, K, 3] SH coefficients shared by all cameras (instead of ``colors``)
     sh_degree: Optional[int] = None,
     sh_rest: Optional[Tensor] = None,  # SPLIT coefficients: ``sh_coeffs`` is the DC band [N, 1, 3], this [N, K-1, 3]
+    prefill: Optional[GradPrefill] = None,  # see GradPrefill; hand the same object to ``rasterize_to_pixels``
 ):
     """``fully_fused_projection`` in ROW form, what ``rasterization`` uses for unpacked batches: the same projection, but
     every (camera, gaussian) pair gets one 64-byte splat row (include/gsplat_hip.h) that the compositing kernels fetch
@@ -828,7 +867,7 @@ def project_rows(
     assert camera_model in _CAMERA_MODELS, camera_model
     return _ProjectRows.apply(means.contiguous(), covars, quats, scales, viewmats.contiguous(), Ks.contiguous(),
                               opacities.contiguous(), colors, sh_coeffs, sh_rest, width, height, eps2d, near_plane, far_plane,
-                              radius_clip, antialiased, camera_model, sh_degree)
+                              radius_clip, antialiased, camera_model, sh_degree, prefill)
 
 
 def _grad_rows_of(parts, shape, device):
@@ -879,7 +918,7 @@ def _grad_rows_of(parts, shape, device):
 class _ProjectRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, sh_rest, width, height, eps2d,
-                near_plane, far_plane, radius_clip, antialiased, camera_model="pinhole", sh_degree=None):
+                near_plane, far_plane, radius_clip, antialiased, camera_model="pinhole", sh_degree=None, prefill=None):
         _require_gpu(means, "project_rows")
         means, covars, quats, scales = _f32c(means), _f32c(covars), _f32c(quats), _f32c(scales)
         viewmats, Ks, opacities, colors = _f32c(viewmats), _f32c(Ks), _f32c(opacities), _f32c(colors)
@@ -900,6 +939,18 @@ class _ProjectRows(torch.autograd.Function):
         ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, opacities, radii, rows, sh_coeffs, sh_rest)
         ctx.width, ctx.height, ctx.eps2d, ctx.cm, ctx.antialiased = width, height, eps2d, cm, bool(antialiased)
         ctx.has_colors, ctx.sh_degree = colors is not None, (int(sh_degree) if sh_coeffs is not None else None)
+        ctx.prefill = None
+        need = ctx.needs_input_grad
+        if prefill is not None and any(need[:10]) and not need[4] and N > 0:
+            # what the backward will return per gaussian, for the compositing forward to allocate and zero-fill
+            req = []
+            for key, t, flag in (("means", means, need[0]), ("covars", covars, need[1]), ("quats", quats, need[2]),
+                                 ("scales", scales, need[3]), ("opacities", opacities, need[6]),
+                                 ("colors", colors, need[7]), ("sh", sh_coeffs, need[8]), ("sh_rest", sh_rest, need[9])):
+                if t is not None and flag:
+                    req.append((key, tuple(t.shape)))
+            prefill.request = req
+            ctx.prefill = prefill
         ctx.mark_non_differentiable(radii, rows)
         ctx.set_materialize_grads(False)  # unused outputs (depths in RGB mode, ...) arrive as None, not as zero tensors
         has_col = colors is not None or sh_coeffs is not None
@@ -916,39 +967,52 @@ class _ProjectRows(torch.autograd.Function):
             parts.append((v_colors_cn, ROW_COLOR, 3))
         g_ptr, g_keep = _grad_rows_of(parts, (C, N), dev)
         need = ctx.needs_input_grad
+        # outputs the compositing forward allocated and zero-filled for this node (GradPrefill): all of them or none
+        pre = ctx.prefill.take() if ctx.prefill is not None else {}
+        want = [k for k, t, f in (("means", means, need[0]), ("covars", covars, need[1]), ("quats", quats, need[2]),
+                                  ("scales", scales, need[3]), ("opacities", opacities, need[6]),
+                                  ("colors", True if ctx.has_colors else None, need[7]), ("sh", sh_coeffs, need[8]),
+                                  ("sh_rest", sh_rest, need[9])) if t is not None and f]
+        prefilled = bool(pre) and all(k in pre for k in want) and (sh_coeffs is None or (need[8] and (sh_rest is None or need[9])))
+        if not prefilled:
+            pre = {}
+
+        def out(key, like):
+            return pre[key] if prefilled else torch.empty_like(like)
+
         v_sh = v_rest = v_means_add = None
         if sh_coeffs is not None:
             # the colour columns of the gradient rows go back through the SH evaluation first (clamp gate from the colours
             # in the rows); its d/d means (view directions) is added by the projection kernel below while it writes v_means
             K = sh_coeffs.shape[1] + (sh_rest.shape[1] if sh_rest is not None else 0)
-            v_sh = torch.empty_like(sh_coeffs)
-            v_rest = torch.empty_like(sh_rest) if sh_rest is not None else None
+            v_sh = out("sh", sh_coeffs)
+            v_rest = out("sh_rest", sh_rest) if sh_rest is not None else None
             v_means_add = torch.empty_like(means) if need[0] else None
             with _device_of(means):
                 B.call("gs_sh_view_bwd", C, N, K, ctx.sh_degree, B.ptr(means), B.ptr(viewmats), 1, B.ptr(sh_coeffs), B.ptr(sh_rest),
                        B.ptr(radii), rows.data_ptr() + 4 * ROW_COLOR, ROW, g_ptr + 4 * ROW_COLOR, ROW, B.ptr(v_sh), B.ptr(v_rest),
-                       B.ptr(v_means_add), None, 0, None, _stream(means))
+                       B.ptr(v_means_add), None, 0, None, int(prefilled), _stream(means))
             if not need[8]:
                 v_sh = None
             if not need[9]:
                 v_rest = None
         v_depths = _f32c(v_depths) if v_depths is not None else None
-        # rows are fully written by the kernel -> empty, not zeros
-        v_means = torch.empty_like(means) if need[0] else None
-        v_covars = torch.empty_like(covars) if (covars is not None and need[1]) else None
-        v_quats = torch.empty_like(quats) if (quats is not None and need[2]) else None
-        v_scales = torch.empty_like(scales) if (scales is not None and need[3]) else None
+        # rows are fully written by the kernel -> empty, not zeros (prefilled: only the visible gaussians' rows are)
+        v_means = out("means", means) if need[0] else None
+        v_covars = out("covars", covars) if (covars is not None and need[1]) else None
+        v_quats = out("quats", quats) if (quats is not None and need[2]) else None
+        v_scales = out("scales", scales) if (scales is not None and need[3]) else None
         v_viewmats = torch.zeros_like(viewmats) if need[4] else None
-        v_opac = torch.empty_like(opacities) if need[6] else None
-        v_colors = torch.empty((N, 3), dtype=torch.float32, device=dev) if (ctx.has_colors and need[7]) else None
+        v_opac = out("opacities", opacities) if need[6] else None
+        v_colors = (pre["colors"] if prefilled else torch.empty((N, 3), dtype=torch.float32, device=dev)) if (ctx.has_colors and need[7]) else None
         with _device_of(means):
             B.call("gs_projection_rows_bwd", C, N, B.ptr(means), B.ptr(covars), B.ptr(quats), B.ptr(scales),
                    B.ptr(viewmats), B.ptr(Ks), int(ctx.width), int(ctx.height), float(ctx.eps2d), ctx.cm,
                    B.ptr(radii), B.ptr(rows), g_ptr, B.ptr(v_depths), B.ptr(opacities), int(ctx.antialiased),
                    B.ptr(v_means), B.ptr(v_covars), B.ptr(v_quats), B.ptr(v_scales), B.ptr(v_viewmats), B.ptr(v_opac),
-                   B.ptr(v_colors), B.ptr(v_means_add) if v_means is not None else None, _stream(means))
+                   B.ptr(v_colors), B.ptr(v_means_add) if v_means is not None else None, int(prefilled), _stream(means))
         del g_keep
-        return (v_means, v_covars, v_quats, v_scales, v_viewmats, None, v_opac, v_colors, v_sh, v_rest) + (None,) * 9
+        return (v_means, v_covars, v_quats, v_scales, v_viewmats, None, v_opac, v_colors, v_sh, v_rest) + (None,) * 10
 
 
 class _FullyFusedProjectionPacked(torch.autograd.Function):
@@ -1327,6 +1391,7 @@ def rasterize_to_pixels(
     packed: bool = False,
     absgrad: bool = False,
     deterministic: bool = False,
+    prefill: Optional["GradPrefill"] = None,
 ) -> Tuple[Tensor, Tensor]:
     """Rasterizes Gaussians to pixels.
 
@@ -1370,14 +1435,14 @@ def rasterize_to_pixels(
     return _RasterizeToPixels.apply(
         means2d, conics, colors, opacities, backgrounds,
         masks, image_width, image_height, tile_size, isect_offsets.contiguous(), flatten_ids.contiguous(), absgrad,
-        bool(deterministic),
+        bool(deterministic), prefill,
     )
 
 
 class _RasterizeToPixels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size,
-                isect_offsets, flatten_ids, absgrad, deterministic=False):
+                isect_offsets, flatten_ids, absgrad, deterministic=False, prefill=None):
         _require_gpu(means2d, "rasterize_to_pixels")
         means2d, conics, colors, opacities, strides = _splat_layout(means2d, conics, colors, opacities)
         backgrounds = _f32c(backgrounds)
@@ -1399,16 +1464,21 @@ class _RasterizeToPixels(torch.autograd.Function):
             scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
             # the packed gradient rows of the backward ([n_elems,16], accumulated with atomics) are zero-filled by THIS
             # launch, as a side job of the tile workgroups: no fill pass in the backward
-            grad_rows = None
+            grad_rows = fill = None
             if needs_bwd and channels <= 4 and n_elems > 0:
-                grad_rows = torch.empty(opacities.shape + (16,), dtype=torch.float32, device=dev)
+                # (+ the per-gaussian gradient tensors the projection node asked for, GradPrefill: one buffer, one fill)
+                extra = prefill.floats() if prefill is not None else 0
+                fill = torch.empty(n_elems * 16 + extra, dtype=torch.float32, device=dev)
+                grad_rows = fill[:n_elems * 16].view(opacities.shape + (16,))
+                if extra:
+                    prefill.carve(fill, n_elems * 16)
             B.call("gs_rasterize_fwd", C, n_elems, n_isects, channels, B.ptr(means2d), B.ptr(conics), B.ptr(colors),
                    B.ptr(opacities), ctypes.addressof(strides) if strides is not None else None, B.ptr(backgrounds), B.ptr(m8),
                    width, height, tile_size, tile_width,
                    tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_colors),
                    B.ptr(render_alphas), B.ptr(last_ids), ctypes.addressof(plan) if plan is not None else None,
                    B.ptr(scratch) if plan is not None else None,
-                   B.ptr(grad_rows), grad_rows.numel() * 4 if grad_rows is not None else 0, _stream(means2d))
+                   B.ptr(fill), fill.numel() * 4 if fill is not None else 0, _stream(means2d))
         ctx.grad_rows = grad_rows  # consumed by the first backward; a repeated one (retain_graph) fills its own
         ctx.plan, ctx.strides = plan, strides  # host structs: the backward runs under the forward's plan and layout
         # scratch carries the forward checkpoints of the depth-segmented backward.  The segmented backward rebuilds
@@ -1476,4 +1546,4 @@ class _RasterizeToPixels(torch.autograd.Function):
             v_backgrounds = (v_render_colors * (1.0 - render_alphas).float()).sum(dim=(1, 2))
         else:
             v_backgrounds = None
-        return (v_means2d, v_conics, v_colors, v_opacities, v_backgrounds) + (None,) * 8
+        return (v_means2d, v_conics, v_colors, v_opacities, v_backgrounds) + (None,) * 9

@@ -362,6 +362,7 @@ struct RowGrads {
     float *v_opacities;     // [N] or NULL
     float *v_colors;        // [N,3] or NULL
     int antialiased;
+    int prefilled;          // every per-gaussian output holds zeros already: gaussians no camera sees are not stored
 };
 
 template <bool NEED_VIEW>
@@ -454,7 +455,7 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
             __syncthreads();
         }
     }
-    if (in_range) {
+    if (in_range && (any || !rg.prefilled)) {
         store_gaussian_grads(g, n, any, covars, quats, scales, v_means, v_covars, v_quats, v_scales, v_means_add);
         if (rg.v_opacities != nullptr) rg.v_opacities[n] = v_op;
         if (rg.v_colors != nullptr) {
@@ -712,7 +713,7 @@ extern "C" int32_t gs_projection_rows_bwd(
     int32_t image_height, float eps2d, int32_t camera_model, const int32_t *radii, const float *rows,
     const float *grad_rows, const float *v_depths, const float *opacities, int32_t antialiased, float *v_means,
     float *v_covars, float *v_quats, float *v_scales, float *v_viewmats, float *v_opacities, float *v_colors,
-    const float *v_means_add, gs_stream_t stream) {
+    const float *v_means_add, int32_t outputs_prefilled, gs_stream_t stream) {
     if (N == 0) return 0;
     GS_CHECK_ARG(means && viewmats && Ks && radii && rows && grad_rows, "null pointer");
     GS_CHECK_ARG((uintptr_t)rows % 16 == 0 && (uintptr_t)grad_rows % 16 == 0, "row buffers must be 16-byte aligned");
@@ -720,7 +721,7 @@ extern "C" int32_t gs_projection_rows_bwd(
                  "exactly one of covars / (quats, scales) must be given");
     GS_CHECK_ARG(!antialiased || opacities != nullptr, "antialiased needs the opacities");
     dim3 grid(gs_div_up(N, GS_BLOCK));
-    const RowGrads rg = {rows, grad_rows, opacities, v_opacities, v_colors, antialiased};
+    const RowGrads rg = {rows, grad_rows, opacities, v_opacities, v_colors, antialiased, outputs_prefilled != 0};
     const float *nul = nullptr;
     if (v_viewmats != nullptr) {
         hipLaunchKernelGGL(projection_bwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
@@ -754,7 +755,7 @@ extern "C" int32_t gs_projection_bwd(
     GS_CHECK_ARG((v_compensations == nullptr) || (compensations != nullptr),
                  "v_compensations given without compensations");
     dim3 grid(gs_div_up(N, GS_BLOCK));
-    const RowGrads rg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    const RowGrads rg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (v_viewmats != nullptr) {
         hipLaunchKernelGGL(projection_bwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
                            means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,

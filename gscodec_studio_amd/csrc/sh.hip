@@ -119,6 +119,8 @@ struct ShView {
     float *v_coeffs_rest;     // bwd: gradient of coeffs_rest, [N,K-1,3]
     uint32_t color_stride;   // row stride (floats) of the colours the forward writes / the backward reads back: 3, or 16 when
                              // they are columns of the splat rows (include/gsplat_hip.h)
+    int prefilled;           // bwd, shared coefficients: v_coeffs (/ v_coeffs_rest) hold zeros already -- rows of gaussians no
+                             // camera sees are not stored, v_means is only written for the others
 };
 
 GS_DEV bool sh_active(const uint8_t *masks, const ShView &v, size_t e) {
@@ -196,9 +198,11 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
     }
     float cf[NB * 3];
     bool have_cf = false;
+    bool any_on = false;
     for (uint32_t c = 0; c < C; ++c) {
         size_t e = (size_t)c * N + n;
         bool on = sh_active(masks, view, e);
+        any_on |= on;
         if (!on) {
             if (!SHARED) zero_row<VEC>(v_coeffs + e * row_len, row_len);
             if (v_dirs != nullptr) {
@@ -274,6 +278,14 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
         __shared__ float4 s_tr[CAN_T ? (GS_BLOCK / GS_WAVE) * GS_WAVE * (RL / 4) : 1];
         const uint32_t lane = threadIdx.x % GS_WAVE, wave = threadIdx.x / GS_WAVE;
         const uint32_t wave_n0 = blockIdx.x * GS_BLOCK + wave * GS_WAVE;
+        // prefilled outputs: rows of lanes that saw no camera hold zeros already.  The staged block stores below skip every
+        // 16-byte piece whose rows are all such rows (what a piece of a live row's neighbour carries along is its exact zeros)
+        const bool keep = any_on || !view.prefilled;
+        const unsigned long long live = view.prefilled ? __ballot(any_on) : ~0ull;
+        auto piece_live = [&](uint32_t j, uint32_t row_floats) { // float4 j of a block of 64 rows of row_floats floats
+            const uint32_t r0 = (4u * j) / row_floats, r1 = (4u * j + 3u) / row_floats;
+            return (((live >> r0) | (live >> (r1 < 64u ? r1 : 63u))) & 1ull) != 0ull;
+        };
         if (split) {
             // two gradient tensors: v_coeffs [N,1,3] and v_coeffs_rest [N,K-1,3].  Same idea: a full wave stages its 64 rows
             // in LDS (row stride 3 / RL - 3 floats: odd, conflict-free) and writes each tensor's 64 rows as one contiguous block
@@ -288,13 +300,14 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
                 __builtin_amdgcn_wave_barrier();
                 const float4 *w4 = reinterpret_cast<const float4 *>(w);
                 float4 *d0 = reinterpret_cast<float4 *>(v_coeffs + (size_t)wave_n0 * 3);
-                if (lane < GS_WAVE * 3 / 4) d0[lane] = w4[lane];
+                if (lane < GS_WAVE * 3 / 4 && piece_live(lane, 3u)) d0[lane] = w4[lane];
                 float4 *d1 = reinterpret_cast<float4 *>(view.v_coeffs_rest + (size_t)wave_n0 * R1);
                 constexpr int N4 = GS_WAVE * R1 / 4; // (64 * R1 is a multiple of 4)
 #pragma unroll
                 for (int i = 0; i < (N4 + GS_WAVE - 1) / GS_WAVE; ++i)
-                    if (i * GS_WAVE + (int)lane < N4) d1[i * GS_WAVE + lane] = w4[GS_WAVE * 3 / 4 + i * GS_WAVE + lane];
-            } else {
+                    if (i * GS_WAVE + (int)lane < N4 && piece_live(i * GS_WAVE + lane, (uint32_t)R1))
+                        d1[i * GS_WAVE + lane] = w4[GS_WAVE * 3 / 4 + i * GS_WAVE + lane];
+            } else if (keep) {
                 float *o0 = v_coeffs + 3 * (size_t)n;
                 o0[0] = acc[0]; o0[1] = acc[1]; o0[2] = acc[2];
                 float *o1 = view.v_coeffs_rest + (size_t)n * rest_len;
@@ -311,12 +324,15 @@ __global__ void __launch_bounds__(GS_BLOCK) sh_bwd_kernel(
             __builtin_amdgcn_wave_barrier();
             float4 *dst = reinterpret_cast<float4 *>(v_coeffs + (size_t)wave_n0 * RL);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) dst[i * GS_WAVE + lane] = w[i * GS_WAVE + lane];
-        } else {
+            for (int i = 0; i < NV; ++i)
+                if (piece_live(i * GS_WAVE + lane, (uint32_t)RL)) {
+                    dst[i * GS_WAVE + lane] = w[i * GS_WAVE + lane];
+                }
+        } else if (keep) {
             store_row<NB * 3, VEC>(v_coeffs + (size_t)n * row_len, acc, row_len);
         }
     }
-    if (v_means != nullptr) {
+    if (v_means != nullptr && (any_on || !view.prefilled)) {
         v_means[3 * (size_t)n] = vmx; v_means[3 * (size_t)n + 1] = vmy; v_means[3 * (size_t)n + 2] = vmz;
     }
 }
@@ -361,7 +377,7 @@ extern "C" int32_t gs_sh_fwd(
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K);
-    ShView view = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 3u};
+    ShView view = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 3u, 0};
     switch (degree) {
         case 0: launch_fwd<0>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
         case 1: launch_fwd<1>(vec, grid, st, C, N, K, dirs, coeffs, coeffs_shared, masks, colors, view); break;
@@ -401,7 +417,7 @@ extern "C" int32_t gs_sh_view_fwd(
     hipStream_t st = (hipStream_t)stream;
     bool vec = coeffs_rest != nullptr ? (K * 3) % 4 == 0 : rows_vectorizable(coeffs, K);
     GS_CHECK_ARG(coeffs_rest == nullptr || K >= 2, "split coefficients need K >= 2");
-    ShView view = {means, campos, radii, 1, campos_from_viewmats, opacities, opacities_cn, nullptr, 0u, nullptr, coeffs_rest, nullptr, colors_stride};
+    ShView view = {means, campos, radii, 1, campos_from_viewmats, opacities, opacities_cn, nullptr, 0u, nullptr, coeffs_rest, nullptr, colors_stride, 0};
     GS_CHECK_ARG((opacities == nullptr) == (opacities_cn == nullptr), "opacities and opacities_cn go together");
     switch (degree) {
         case 0: launch_fwd<0>(vec, grid, st, C, N, K, nullptr, coeffs, 1, nullptr, colors, view); break;
@@ -427,7 +443,7 @@ extern "C" int32_t gs_sh_bwd(
     hipStream_t st = (hipStream_t)stream;
     bool vec = rows_vectorizable(coeffs, K) && rows_vectorizable(v_coeffs, K);
     bool shared = coeffs_shared != 0;
-    ShView view = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 3u};
+    ShView view = {nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 3u, 0};
     switch (degree) {
         case 0: launch_bwd<0>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
         case 1: launch_bwd<1>(vec, shared, grid, st, C, N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, view, nullptr, 3, nullptr); break;
@@ -443,7 +459,7 @@ extern "C" int32_t gs_sh_view_bwd(
     uint32_t C, uint32_t N, uint32_t K, uint32_t degree, const float *means, const float *campos, int32_t campos_from_viewmats,
     const float *coeffs, const float *coeffs_rest, const int32_t *radii, const float *colors_out, uint32_t colors_out_stride,
     const float *v_colors, uint32_t v_colors_stride, float *v_coeffs, float *v_coeffs_rest, float *v_means, const float *v_opacities_cn, uint32_t v_opacities_stride,
-    float *v_opacities, gs_stream_t stream) {
+    float *v_opacities, int32_t outputs_prefilled, gs_stream_t stream) {
     if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && campos && coeffs && colors_out && v_colors && v_coeffs, "null pointer");
     GS_CHECK_ARG(degree <= 4, "degree must be <= 4");
@@ -457,7 +473,7 @@ extern "C" int32_t gs_sh_view_bwd(
         GS_CHECK_ARG(K >= 2, "split coefficients need K >= 2");
         vec = (K * 3) % 4 == 0 && (uintptr_t)v_coeffs % 16 == 0 && (uintptr_t)v_coeffs_rest % 16 == 0;
     }
-    ShView view = {means, campos, radii, 1, campos_from_viewmats, nullptr, nullptr, v_opacities_cn, v_opacities_stride, v_opacities, coeffs_rest, v_coeffs_rest, colors_out_stride};
+    ShView view = {means, campos, radii, 1, campos_from_viewmats, nullptr, nullptr, v_opacities_cn, v_opacities_stride, v_opacities, coeffs_rest, v_coeffs_rest, colors_out_stride, outputs_prefilled != 0};
     GS_CHECK_ARG((v_opacities_cn == nullptr) == (v_opacities == nullptr), "v_opacities_cn and v_opacities go together");
     switch (degree) {
         case 0: launch_bwd<0>(vec, true, grid, st, C, N, K, nullptr, coeffs, nullptr, v_colors, v_coeffs, nullptr, view, colors_out, v_colors_stride, v_means); break;

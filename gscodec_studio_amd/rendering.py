@@ -26,6 +26,7 @@ from typing_extensions import Literal
 from ._wrapper import (
     fully_fused_projection,
     project_rows,
+    GradPrefill,
     gather_rows,
     isect_offset_encode,
     isect_tiles,
@@ -203,14 +204,19 @@ def rasterization(
     means_alias = fuse_sh and means.requires_grad and not use_rows
     rows = None
     compensations = None
+    prefill = None
     if use_rows:
         row_colors = colors if (sh_degree is None and colors.dim() == 2 and colors.shape[-1] == 3) else None
+        # the dense per-gaussian gradients of the projection node are allocated and zero-filled by the compositing
+        # forward's side job; its backward then writes the visible gaussians' rows only (_wrapper.GradPrefill)
+        prefill = GradPrefill() if torch.is_grad_enabled() else None
         radii, means2d, depths, conics, opacities, colors_rows, rows = project_rows(
             means, covars, quats, scales, viewmats, Ks, width, height, opacities, row_colors,
             eps2d=eps2d, near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip,
             antialiased=(rasterize_mode == "antialiased"), camera_model=camera_model,
             # shared SH coefficients and fixed poses: the colours are evaluated by the projection pass itself
             sh_coeffs=colors if fuse_sh else None, sh_degree=sh_degree if fuse_sh else None, sh_rest=sh_rest,
+            prefill=prefill,
         )
         camera_ids, gaussian_ids = None, None
         opacity_rider = False
@@ -378,7 +384,7 @@ def rasterization(
     else:
         render_colors, render_alphas = rasterize_to_pixels(
             means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
-            backgrounds=backgrounds, packed=packed, absgrad=absgrad, deterministic=deterministic,
+            backgrounds=backgrounds, packed=packed, absgrad=absgrad, deterministic=deterministic, prefill=prefill,
         )
     if render_mode in ["ED", "RGB+ED"]:
         # accumulated depth -> expected depth

@@ -165,7 +165,10 @@ int32_t gs_projection_rows_fwd(
 /* Its backward: grad_rows [C,N,16] holds d/d(mean2d, conic, opacity, colour) in the splat-row columns (what gs_rasterize_bwd
  * accumulates with packed16), v_depths [C,N] or NULL.  Besides the outputs of gs_projection_bwd (all OVERWRITTEN),
  * v_opacities [N] = sum over cameras of column 5 (x compensation when antialiased, whose own gradient then enters the
- * projection chain) and v_colors [N,3] = sum over cameras of columns 6-8; either may be NULL. */
+ * projection chain) and v_colors [N,3] = sum over cameras of columns 6-8; either may be NULL.
+ * outputs_prefilled != 0: the caller guarantees that every per-gaussian output already holds zeros (e.g. through the
+ * zero_fill of gs_rasterize_fwd); the rows of gaussians that no camera sees (71 % at BASELINE config 2) are then not
+ * written at all, and v_means_add is only read where some camera sees the gaussian. */
 int32_t gs_projection_rows_bwd(
     uint32_t C, uint32_t N,
     const float *means, const float *covars, const float *quats, const float *scales,
@@ -176,6 +179,7 @@ int32_t gs_projection_rows_bwd(
     float *v_means, float *v_covars, float *v_quats, float *v_scales, float *v_viewmats,
     float *v_opacities, float *v_colors,
     const float *v_means_add, /* [N,3] or NULL, as in gs_projection_bwd */
+    int32_t outputs_prefilled,
     gs_stream_t stream);
 
 /* packed (COO) projection, replaces fully_fused_projection_packed_fwd_tensor
@@ -262,7 +266,10 @@ int32_t gs_sh_bwd(
  * v_coeffs [N,K,3] and v_means [N,3] (= sum over cameras of d/d dirs; may be NULL) are OVERWRITTEN.
  * Optional riders (both NULL to disable): fwd writes opacities_cn[c,n] = opacities[n] for EVERY element (the
  * `opacities.repeat(C, 1)` of rendering.py:331); bwd writes v_opacities[n] = sum_c v_opacities_cn[c,n] (row stride
- * v_opacities_stride floats) -- the two extra torch kernels of the pipeline disappear into passes that run anyway. */
+ * v_opacities_stride floats) -- the two extra torch kernels of the pipeline disappear into passes that run anyway.
+ * bwd, outputs_prefilled != 0: the caller guarantees v_coeffs (and v_coeffs_rest) already hold zeros; the rows of
+ * gaussians no camera sees are then not written (137 of the 193 MB at BASELINE config 2), and v_means is only DEFINED
+ * for gaussians some camera sees. */
 /* campos[c] = inverse(viewmats[c])[:3, 3] for affine world->camera matrices, closed form
  * (replaces torch.inverse(viewmats) of gsplat/rendering.py:370, which host-synchronises on ROCm). */
 int32_t gs_camera_centers(uint32_t C, const float *viewmats, float *campos, gs_stream_t stream);
@@ -282,6 +289,7 @@ int32_t gs_sh_view_bwd(
     const float *colors_out, uint32_t colors_out_stride, const float *v_colors, uint32_t v_colors_stride,
     float *v_coeffs, float *v_coeffs_rest /* [N,K-1,3] with coeffs_rest, else NULL */, float *v_means,
     const float *v_opacities_cn /* or NULL */, uint32_t v_opacities_stride, float *v_opacities /* [N] or NULL */,
+    int32_t outputs_prefilled,
     gs_stream_t stream);
 
 /* ------------------------------------------------------------------------

@@ -501,3 +501,46 @@ def test_deterministic_backward_is_bit_reproducible(sh_degree):
     c = run(False)
     for x, y, name in zip(a, c, names + ("means2d", "absgrad")):
         assert rel_l2(N(x), N(y)) < 5e-5, (name, rel_l2(N(x), N(y)))
+
+
+@pytest.mark.parametrize("mode", ["sh", "sh_split", "colors"])
+def test_prefilled_gradients_equal_full_writes(mode):
+    """``GradPrefill``: the per-gaussian gradients of the projection node are allocated behind the compositing gradient rows,
+    zero-filled by the compositing FORWARD, and its backward stores the visible gaussians' rows only.  A second backward
+    through the same graph (retain_graph) finds the hand-over consumed and takes the path that allocates and writes every
+    row itself: with ``deterministic=True`` both must give bit-identical gradients for every parameter, and a gaussian no
+    camera sees must get exact zeros from both."""
+    from gscodec_studio_amd import rasterization
+
+    sh_degree = None if mode == "colors" else 3
+    d = _inputs(n=5000, cams=2, sh_degree=sh_degree, scale_mult=6.0)
+    d["means"] = d["means"].copy()
+    d["means"][::3] += 100.0  # a third of the gaussians far outside every frustum
+    names = ["means", "quats", "scales", "opacities"]
+    ps = [T(d[k]).requires_grad_(True) for k in names]
+    if mode == "sh_split":
+        sh = T(d["colors"])
+        cols = [sh[:, :1].clone().requires_grad_(True), sh[:, 1:].clone().requires_grad_(True)]
+        colors = (cols[0], cols[1])
+    else:
+        cols = [T(d["colors"]).requires_grad_(True)]
+        colors = cols[0]
+    w = torch.linspace(0.5, 1.5, 2 * d["H"] * d["W"] * 3, device="cuda").reshape(2, d["H"], d["W"], 3)
+    rc, ra, meta = rasterization(ps[0], ps[1], ps[2], ps[3], colors, T(d["viewmats"]), T(d["Ks"]), d["W"], d["H"],
+                                 sh_degree=sh_degree, packed=False, deterministic=True)
+    loss = (rc * w).sum() + 0.3 * ra.sum()
+    loss.backward(retain_graph=True)
+    first = [p.grad.clone() for p in ps + cols]
+    # the gradients handed out by the first backward are views of ONE buffer behind the compositing gradient rows
+    assert len({p.grad.untyped_storage().data_ptr() for p in ps + cols}) == 1
+    for p in ps + cols:
+        p.grad = None
+    loss.backward()
+    second = [p.grad.clone() for p in ps + cols]
+    assert len({p.grad.untyped_storage().data_ptr() for p in ps + cols}) > 1
+    unseen = (meta["radii"] <= 0).all(dim=0)
+    assert int(unseen.sum()) >= 5000 // 3 and int((~unseen).sum()) > 500
+    for a, b, name in zip(first, second, names + ["colors0", "colors1"]):
+        assert torch.equal(a, b), f"{name}: prefilled and fully written gradients differ"
+        assert float(a[unseen].abs().max()) == 0.0, name
+        assert float(a.abs().max()) > 0.0, name
