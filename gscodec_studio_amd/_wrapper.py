@@ -299,6 +299,28 @@ def exchange_compact(radii: Tensor, C_local: int, world: int, cap: int, N_total:
     return src_index, hdr, counters, stats
 
 
+def rows16_gather(n_rows: int, index: Tensor, index_stride: int, src_rows: Tensor, tag: Optional[Tensor] = None) -> Tensor:
+    """``out[r] = src_rows[index[r * index_stride]]`` over 64-byte splat rows (zeros for a negative index); ``tag`` [n_rows, 2]
+    int32 goes into columns 12 / 13 (gs_rows16_gather).  ``index`` may be a column of another row buffer."""
+    _require_gpu(src_rows, "rows16_gather")
+    assert index.dtype == torch.int32 and src_rows.dtype == torch.float32 and src_rows.is_contiguous() and src_rows.shape[-1] == ROW
+    out = torch.empty((n_rows, ROW), dtype=torch.float32, device=src_rows.device)
+    with _device_of(src_rows):
+        B.call("gs_rows16_gather", n_rows, index.data_ptr(), index_stride, B.ptr(src_rows), B.ptr(tag), B.ptr(out), _stream(src_rows))
+    return out
+
+
+def rows16_scatter(n_rows: int, index: Tensor, index_stride: int, wire: Tensor, dst_rows: Tensor, radii: Optional[Tensor] = None,
+                   depths: Optional[Tensor] = None) -> None:
+    """``dst_rows[index[r * index_stride]] = wire[r]`` where the index is >= 0; ``radii`` / ``depths`` receive the rows' columns
+    10 / 9 at the same element (gs_rows16_scatter)."""
+    _require_gpu(wire, "rows16_scatter")
+    assert index.dtype == torch.int32 and wire.is_contiguous() and dst_rows.is_contiguous() and dst_rows.shape[-1] == ROW
+    with _device_of(wire):
+        B.call("gs_rows16_scatter", n_rows, index.data_ptr(), index_stride, B.ptr(wire), B.ptr(dst_rows), B.ptr(radii), B.ptr(depths),
+               _stream(wire))
+
+
 def spherical_harmonics_view(
     degrees_to_use: int,
     means: Tensor,  # [N, 3]

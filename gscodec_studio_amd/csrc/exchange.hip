@@ -248,7 +248,68 @@ __global__ void exchange_flags_kernel(uint32_t world, const int32_t *__restrict_
     }
 }
 
+// Splat rows (16 floats, include/gsplat_hip.h) around the exchange: four lanes move one 64-byte row as four float4.
+// gather: out[r] = src[index[r]] (zeros for a negative index); columns 12 / 13 carry tag[r] (the destination row and the
+// chunk header of gs_exchange_compact) when given.
+__global__ void __launch_bounds__(GS_BLOCK) rows16_gather_kernel(uint64_t n_rows, const int32_t *__restrict__ index, int64_t index_stride,
+                                                                 const float4 *__restrict__ src, const int2 *__restrict__ tag,
+                                                                 float4 *__restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    const uint64_t r = t >> 2;
+    const uint32_t q = (uint32_t)t & 3u;
+    if (r >= n_rows) return;
+    const int32_t i = index[r * index_stride];
+    float4 v = (i >= 0 && src != nullptr) ? src[(size_t)i * 4u + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q == 3u && tag != nullptr) {
+        const int2 g = tag[r];
+        v.x = __int_as_float(g.x);
+        v.y = __int_as_float(g.y);
+    }
+    out[r * 4u + q] = v;
+}
+
+// scatter: dst[index[r]] = wire[r] for index[r] >= 0 (index may be a column of the wire itself); radii / depths (optional) get
+// the row's columns 10 / 9 at the same element -- the dense arrays the binning kernels stream through.
+__global__ void __launch_bounds__(GS_BLOCK) rows16_scatter_kernel(uint64_t n_rows, const int32_t *__restrict__ index, int64_t index_stride,
+                                                                  const float4 *__restrict__ wire, float4 *__restrict__ dst,
+                                                                  int32_t *__restrict__ radii, float *__restrict__ depths) {
+    const uint64_t t = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    const uint64_t r = t >> 2;
+    const uint32_t q = (uint32_t)t & 3u;
+    if (r >= n_rows) return;
+    const int32_t i = index[r * index_stride];
+    if (i < 0 || dst == nullptr) return;
+    const float4 v = wire[r * 4u + q];
+    dst[(size_t)i * 4u + q] = v;
+    if (q == 2u) { // columns 8..11: colour 2 | depth | radius bits | compensation
+        if (radii != nullptr) radii[i] = __float_as_int(v.z);
+        if (depths != nullptr) depths[i] = v.y;
+    }
+}
+
 }  // namespace
+
+extern "C" int32_t gs_rows16_gather(uint64_t n_rows, const int32_t *index, int64_t index_stride, const float *src_rows,
+                                    const int32_t *tag, float *out_rows, gs_stream_t stream) {
+    if (n_rows == 0) return 0;
+    GS_CHECK_ARG(index && out_rows && index_stride >= 1, "null pointer / index stride"); // (src_rows NULL: an empty shard, every index negative)
+    GS_CHECK_ARG((uintptr_t)src_rows % 16 == 0 && (uintptr_t)out_rows % 16 == 0 && (uintptr_t)tag % 8 == 0, "rows must be 16-byte aligned");
+    hipLaunchKernelGGL(rows16_gather_kernel, dim3((uint32_t)gs_div_up(n_rows * 4u, (uint64_t)GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
+                       n_rows, index, index_stride, (const float4 *)src_rows, (const int2 *)tag, (float4 *)out_rows);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_rows16_scatter(uint64_t n_rows, const int32_t *index, int64_t index_stride, const float *wire_rows,
+                                     float *dst_rows, int32_t *radii, float *depths, gs_stream_t stream) {
+    if (n_rows == 0) return 0;
+    GS_CHECK_ARG(index && wire_rows && index_stride >= 1, "null pointer / index stride"); // (dst_rows NULL: an empty shard)
+    GS_CHECK_ARG((uintptr_t)wire_rows % 16 == 0 && (uintptr_t)dst_rows % 16 == 0, "rows must be 16-byte aligned");
+    hipLaunchKernelGGL(rows16_scatter_kernel, dim3((uint32_t)gs_div_up(n_rows * 4u, (uint64_t)GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
+                       n_rows, index, index_stride, (const float4 *)wire_rows, (float4 *)dst_rows, radii, depths);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int32_t gs_exchange_flags(uint32_t world, const int32_t *recv, uint32_t row_width, const int64_t *hdr_rows,
                                      const uint32_t *stats, int32_t *out3, gs_stream_t stream) {

@@ -53,6 +53,37 @@ def _wire(nbytes: float) -> None:
     WIRE["bytes"] += int(nbytes)
 
 
+# GS_DIST_TIME_COLLECTIVES=1 (bench.py's one-GPU projection): every device collective is bracketed by events on its stream,
+# so that the time RCCL's self-copies take at world 1 -- the stand-in for the wire -- can be told apart from the rest.
+TIMED = {"on": os.environ.get("GS_DIST_TIME_COLLECTIVES", "0") == "1", "events": []}
+
+
+class _timed:
+    def __init__(self, t: Tensor):
+        self.on = TIMED["on"] and t.is_cuda
+        self.dev = t.device
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.dev))
+
+    def __exit__(self, *exc):
+        if self.on:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream(self.dev))
+            TIMED["events"].append((self.e0, e1))
+        return False
+
+
+def collective_time_ms(reset: bool = True) -> float:
+    """Device time of the collectives queued since the last reset (call after a synchronisation)."""
+    ms = sum(a.elapsed_time(b) for a, b in TIMED["events"])
+    if reset:
+        TIMED["events"] = []
+    return ms
+
+
 def _single(world_size: int) -> bool:
     """World-1 short cut of every collective; GS_DIST_FORCE_COLLECTIVES=1 disables it so that a one-rank run
     still drives RCCL (used by the tests on single-GPU boxes)."""
@@ -72,7 +103,8 @@ def _all_gather_into(out: Tensor, inp: Tensor) -> None:
         dist.all_gather_into_tensor(o, inp.cpu())
         out.copy_(o)
     else:
-        dist.all_gather_into_tensor(out, inp)
+        with _timed(inp):
+            dist.all_gather_into_tensor(out, inp)
 
 
 def _all_reduce_sum(t: Tensor) -> None:
@@ -83,7 +115,8 @@ def _all_reduce_sum(t: Tensor) -> None:
         dist.all_reduce(h, op=dist.ReduceOp.SUM)
         t.copy_(h)
     else:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        with _timed(t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
 def _all_to_all_single(out: Tensor, inp: Tensor, out_splits: List[int], in_splits: List[int]) -> None:
@@ -92,7 +125,8 @@ def _all_to_all_single(out: Tensor, inp: Tensor, out_splits: List[int], in_split
         row = inp.element_size() * (inp.numel() // max(inp.shape[0], 1))
         _wire(row * (sum(in_splits) - in_splits[dist.get_rank()]))
     if "nccl" in _backend_name():
-        dist.all_to_all_single(out, inp, out_splits, in_splits)
+        with _timed(inp):
+            dist.all_to_all_single(out, inp, out_splits, in_splits)
         return
     if _staged(inp):
         o = torch.empty(out.shape, dtype=out.dtype)
@@ -192,30 +226,41 @@ def _host_group():
     return _HOST_GROUP[key]
 
 
-def gather_shard_meta(world_size: int, N: int, viewmats: Tensor, Ks: Tensor, cap: int = 0
-                      ) -> Tuple[List[int], List[int], Tensor, Tensor]:
+def gather_shard_meta(world_size: int, N: int, viewmats: Tensor, Ks: Tensor, cap: int = 0):
     """What the gaussian-sharded mode needs from the other ranks before it can project (reference rendering.py:283-291:
     three collectives and a read-back): the shard sizes and ALL cameras -- plus, for the sparse exchange, the chunk
     capacity every rank is going to use (``cap``, see ``sparse_capacity``).  The integers are host values and travel over
-    the host group (no GPU synchronisation); the cameras take ONE device all-gather of [viewmats | Ks] per rank.
-    Returns (N_world, cap_world, viewmats [C_total,4,4], Ks [C_total,3,3]); cameras carry no gradient here."""
+    the host group (no GPU synchronisation), ASYNCHRONOUSLY: the all-gather is started here and only waited for when the
+    sizes are first needed (``sizes()``, at the exchange -- the projection is queued in between); the cameras take ONE
+    device all-gather of [viewmats | Ks] per rank.
+    Returns (sizes, viewmats [C_total,4,4], Ks [C_total,3,3]) with ``sizes() -> (N_world, cap_world)``; cameras carry no
+    gradient here."""
     C = viewmats.shape[0]
     hg = _host_group()
     cams = torch.cat([viewmats.detach().reshape(-1).float(), Ks.detach().reshape(-1).float()])
+    work = ints = None
     if hg is not None:
         ints = torch.empty(2 * world_size, dtype=torch.int64)
-        dist.all_gather_into_tensor(ints, torch.tensor([N, cap], dtype=torch.int64), group=hg)
-        ints = ints.view(world_size, 2)
+        work = dist.all_gather_into_tensor(ints, torch.tensor([N, cap], dtype=torch.int64), group=hg, async_op=True)
         buf = cams
     else:
         n = torch.tensor([N, cap], dtype=torch.int32, device=viewmats.device).view(torch.float32)
         buf = torch.cat([cams, n])
     out = buf.new_empty((world_size, buf.numel()))
     _all_gather_into(out.view(-1), buf)
-    if hg is None:
-        ints = out[:, 25 * C:25 * C + 2].contiguous().view(torch.int32)
-    N_world, cap_world = ints[:, 0].tolist(), ints[:, 1].tolist()
-    return (N_world, cap_world, out[:, :16 * C].reshape(world_size * C, 4, 4).contiguous(),
+    cache: List[Any] = []
+
+    def sizes() -> Tuple[List[int], List[int]]:
+        if not cache:
+            if work is not None:
+                work.wait()
+                t = ints.view(world_size, 2)
+            else:
+                t = out[:, 25 * C:25 * C + 2].contiguous().view(torch.int32)  # (device path: this read-back synchronises)
+            cache.append((t[:, 0].tolist(), t[:, 1].tolist()))
+        return cache[0]
+
+    return (sizes, out[:, :16 * C].reshape(world_size * C, 4, 4).contiguous(),
             out[:, 16 * C:25 * C].reshape(world_size * C, 3, 3).contiguous())
 
 
@@ -546,6 +591,97 @@ class _ExchangeSparse(torch.autograd.Function):
         return (None, g_m2, None if v_depths is None else g_d.squeeze(-1), g_cn, g_op.squeeze(-1), g_col) + (None,) * 5
 
 
+class _ExchangeRows(torch.autograd.Function):
+    """`_ExchangeSparse` for SPLAT ROWS (``project_rows``): the 64-byte row of a visible (camera, gaussian) pair IS the wire
+    row -- it already holds mean2d, conic, opacity, colour, depth and radius, and its padding columns 12 / 13 carry the
+    destination row and the chunk header of ``gs_exchange_compact`` -- so nothing is packed or split on either side:
+    ``gs_rows16_gather`` lists the visible rows into the send chunks, one all-to-all, ``gs_rows16_scatter`` puts them at
+    their [C_local, N_total] places (and fills the dense radii / depths the binning streams through).  Backward: the
+    gradient rows of ``gs_rasterize_bwd`` are gathered at the received rows' places, the dual all-to-all returns them, and
+    they are scattered into a [C_total, N, 16] gradient-row buffer that ``gs_projection_rows_bwd`` / ``gs_sh_view_bwd`` read
+    in place (rows that never travelled are never read: their radii are 0).  Capacity / overflow protocol as in
+    `_ExchangeSparse`.  Inputs: the column views of ``rows`` [C_total, N, 16] (for autograd), depths, radii, rows."""
+
+    @staticmethod
+    def forward(ctx, means2d, conics, opacities, colors, depths, radii, rows, N, N_world, C_world, rank, cap_world):
+        from ._wrapper import ROW, ROW_COLOR, ROW_CONIC, ROW_MEAN2D, ROW_OPACITY, exchange_compact, rows16_gather, rows16_scatter
+        from . import _backend as B
+
+        ctx.set_materialize_grads(False)
+        world = len(C_world)
+        C_total, C_local = sum(C_world), C_world[rank]
+        N_total, N_off, cap = sum(N_world), sum(N_world[:rank]), int(cap_world[rank])
+        dev = rows.device
+        src_index, hdr, counters, stats = exchange_compact(radii.contiguous(), C_local, world, cap, N_total, N_off)
+        n_send = world * (cap + 1)
+        send = rows16_gather(n_send, src_index, 1, rows.view(-1, ROW), hdr)
+        send_splits = [cap + 1] * world
+        recv_splits = [int(c) + 1 for c in cap_world]
+        n_recv = sum(recv_splits)
+        recv = send.new_empty((n_recv, ROW))
+        _all_to_all_single(recv, send, recv_splits, send_splits)
+        dst_recv = recv.view(torch.int32)[:, 12]  # a column of the wire: read in place, kept for the backward
+        radii_l = torch.zeros((C_local, N_total), dtype=torch.int32, device=dev)
+        depths_l = torch.empty((C_local, N_total), dtype=torch.float32, device=dev)
+        rows_l = torch.empty((C_local, N_total, ROW), dtype=torch.float32, device=dev)
+        rows16_scatter(n_recv, dst_recv, ROW, recv, rows_l, radii_l, depths_l)
+        key = (tuple(recv_splits), dev)
+        if key not in _HDR_ROWS:
+            _HDR_ROWS[key] = (torch.tensor(recv_splits, dtype=torch.int64).cumsum(0) - 1).to(dev)
+        if _SPARSE.get("pinned") is None:
+            _SPARSE["pinned"] = torch.empty(3, dtype=torch.int32).pin_memory()
+        p3 = _SPARSE["pinned"]
+        with torch.cuda.device(dev):  # (the header ints sit in columns 12 / 13 of the rows)
+            B.call("gs_exchange_flags", world, dst_recv.data_ptr(), ROW, B.ptr(_HDR_ROWS[key]), B.ptr(stats), B.ptr(p3),
+                   torch.cuda.current_stream(dev).cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        _SPARSE["overflow"], _SPARSE["stats"] = (p3, ev), (p3, ev, C_local * N)
+        ctx.meta = (N, C_total, C_local, N_total, send_splits, recv_splits, colors is not None)
+        ctx.save_for_backward(src_index, recv)
+        ctx.mark_non_differentiable(radii_l, rows_l)
+        return (radii_l, rows_l[..., ROW_MEAN2D:ROW_MEAN2D + 2], depths_l, rows_l[..., ROW_CONIC:ROW_CONIC + 3], rows_l[..., ROW_OPACITY],
+                rows_l[..., ROW_COLOR:ROW_COLOR + 3] if colors is not None else None, rows_l)
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_opacities, v_colors, _v_rows):
+        from ._wrapper import ROW, ROW_COLOR, ROW_CONIC, ROW_DEPTH, ROW_MEAN2D, ROW_OPACITY, _grad_rows_of, rows16_gather, rows16_scatter
+
+        N, C_total, C_local, N_total, send_splits, recv_splits, has_colors = ctx.meta
+        src_index, recv = ctx.saved_tensors
+        dev = recv.device
+        parts = [(v_means2d, ROW_MEAN2D, 2), (v_conics, ROW_CONIC, 3), (v_opacities, ROW_OPACITY, 1)]
+        if has_colors:
+            parts.append((v_colors, ROW_COLOR, 3))
+        if v_depths is not None:
+            parts.append((v_depths, ROW_DEPTH, 1))
+        g_ptr, g_keep = _grad_rows_of(parts, (C_local, N_total), dev)
+        n_recv, n_send = recv.shape[0], int(src_index.numel())
+        v_wire = torch.empty((n_recv, ROW), dtype=torch.float32, device=dev)
+        from . import _backend as B
+
+        with torch.cuda.device(dev):  # (g_ptr: the gradient rows in place, or the buffer g_keep assembled from the parts)
+            B.call("gs_rows16_gather", n_recv, recv.view(torch.int32)[:, 12].data_ptr(), ROW, g_ptr, None, B.ptr(v_wire),
+                   torch.cuda.current_stream(dev).cuda_stream)
+        del g_keep
+        v_back = v_wire.new_empty((n_send, ROW))
+        _all_to_all_single(v_back, v_wire, send_splits, recv_splits)
+        g_src = torch.empty((C_total, N, ROW), dtype=torch.float32, device=dev)  # rows that never left are never read (radii 0)
+        rows16_scatter(n_send, src_index, 1, v_back, g_src)
+        return (g_src[..., ROW_MEAN2D:ROW_MEAN2D + 2], g_src[..., ROW_CONIC:ROW_CONIC + 3], g_src[..., ROW_OPACITY],
+                g_src[..., ROW_COLOR:ROW_COLOR + 3] if has_colors else None,
+                g_src[..., ROW_DEPTH] if v_depths is not None else None) + (None,) * 7
+
+
+def exchange_rows(world_rank: int, N: int, N_world: Sequence[int], C_world: Sequence[int], cap_world: Sequence[int],
+                  radii: Tensor, means2d: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor, colors: Optional[Tensor], rows: Tensor):
+    """Gaussian-sharded -> camera-sharded redistribution of splat rows (`_ExchangeRows`).  Returns
+    (C_local, radii, means2d, depths, conics, opacities, colors, rows) in the receiver's [C_local, N_total] layout."""
+    out = _ExchangeRows.apply(means2d, conics, opacities, colors, depths, radii, rows, N, tuple(N_world), tuple(C_world), world_rank,
+                              tuple(cap_world))
+    return (C_world[world_rank],) + tuple(out)
+
+
 # ---------------------------------------------------------------------------
 # camera-sharded data parallelism (north-star design)
 # ---------------------------------------------------------------------------
@@ -849,10 +985,12 @@ def all_reduce_splat_grads(
             if n % world_size == 0 and n * flat.element_size() >= _DIRECT_RS_AG_MIN_BYTES and "nccl" in _backend_name():
                 shard = flat.new_empty(n // world_size)
                 _wire(2.0 * n * flat.element_size() * (world_size - 1) / world_size)
-                dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+                with _timed(flat):
+                    dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
                 if average:
                     shard.mul_(scale)
-                dist.all_gather_into_tensor(flat, shard)
+                with _timed(flat):
+                    dist.all_gather_into_tensor(flat, shard)
             else:
                 _all_reduce_sum(flat)
                 if average:
@@ -867,10 +1005,12 @@ def all_reduce_splat_grads(
         if pad:
             bucket = torch.cat([bucket, bucket.new_zeros(pad)])
         shard = bucket.new_empty(bucket.numel() // world_size)
-        dist.reduce_scatter_tensor(shard, bucket, op=dist.ReduceOp.SUM)
+        with _timed(bucket):
+            dist.reduce_scatter_tensor(shard, bucket, op=dist.ReduceOp.SUM)
         if average:
             shard.mul_(1.0 / world_size)
-        dist.all_gather_into_tensor(bucket, shard)
+        with _timed(bucket):
+            dist.all_gather_into_tensor(bucket, shard)
         bucket = bucket[:n]
     elif algorithm == "all_reduce":
         _all_reduce_sum(bucket)

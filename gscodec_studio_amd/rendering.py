@@ -187,18 +187,22 @@ def rasterization(
             viewmats, Ks = D.all_gather_tensor_list(world_size, [viewmats, Ks])
         else:
             sparse = (not packed) and D.sparse_enabled(means, C_world)
-            N_world, cap_world, viewmats, Ks = D.gather_shard_meta(world_size, N, viewmats, Ks,
-                                                                   D.sparse_capacity(C, N) if sparse else 0)
-            if not sparse:
-                cap_world = None
+            # (the shard sizes travel over the host group while the projection is queued: resolved at the exchange)
+            shard_sizes, viewmats, Ks = D.gather_shard_meta(world_size, N, viewmats, Ks, D.sparse_capacity(C, N) if sparse else 0)
+            N_world = None
+            cap_world = () if sparse else None  # chunk capacities: known to be in use, values still in flight
         C = len(viewmats)
 
     # Unpacked batches on one GPU go through SPLAT ROWS: the projection writes one 64-byte row per (camera, gaussian) --
     # mean2d, conic, opacity (x antialias compensation), colour, depth, radius -- that the compositing kernels fetch whole;
     # means2d / conics / opacities (/ colours) below are column views of that buffer (same shapes and dtypes as the
     # reference's separate tensors; like its means2d / conics they are only defined where radii > 0).
-    use_rows = (not packed) and (not distributed) and means.is_cuda
     fuse_sh = (sh_degree is not None and not packed and colors.dim() == 3 and not viewmats.requires_grad and viewmats.is_cuda)
+    # (gaussian-sharded: when the colours sit in the rows and the sparse exchange is on, the rows themselves travel --
+    # distributed._ExchangeRows; otherwise the separate arrays of the reference's layout do)
+    dist_rows = (distributed and cap_world is not None and means.is_cuda
+                 and (fuse_sh or (sh_degree is None and colors.dim() == 2 and colors.shape[-1] == 3)))
+    use_rows = (not packed) and means.is_cuda and (not distributed or dist_rows)
     # the fused SH route reads the means a second time (view directions): it gets them back FROM the projection, so that
     # its contribution to d/d means is added inside the projection's backward kernel
     means_alias = fuse_sh and means.requires_grad and not use_rows
@@ -316,10 +320,18 @@ def rasterization(
         # redistribute, then bin.  The sparse exchange sizes its chunks from earlier steps without a read-back; should a
         # chunk have been too small (every rank learns it at the tile-count read-back), repeat once at full capacity.
         pre = (radii, means2d, depths, conics, opacities, colors, camera_ids, gaussian_ids)
+        pre_rows = rows
+        if N_world is None:
+            N_world, caps = shard_sizes()
+            cap_world = caps if cap_world is not None else None
         for attempt in range(2):
-            (C, radii, means2d, depths, conics, opacities, colors, camera_ids, gaussian_ids) = D.exchange_projected(
-                world_rank, world_size, N, N_world, C_world, packed, *pre, cap_world=cap_world,
-            )
+            if use_rows:
+                C, radii, means2d, depths, conics, opacities, colors, rows = D.exchange_rows(
+                    world_rank, N, N_world, C_world, cap_world, *pre[:6], pre_rows)
+            else:
+                (C, radii, means2d, depths, conics, opacities, colors, camera_ids, gaussian_ids) = D.exchange_projected(
+                    world_rank, world_size, N, N_world, C_world, packed, *pre, cap_world=cap_world,
+                )
             # binning up to its read-back; the depth pre-sort queued behind the count keeps the GPU busy while the host
             # looks at the overflow flags (stored to pinned memory before the count) and comes back for the rest
             isect_state = isect_tiles_start(

@@ -725,6 +725,20 @@ int32_t gs_rows_unpack_indexed(
 int32_t gs_exchange_compact(
     uint32_t C_total, uint32_t N, uint32_t C_local, uint32_t world, uint32_t cap, uint32_t N_total, uint32_t N_off,
     const int32_t *radii, int32_t *src_index, int32_t *hdr, uint32_t *counters, uint32_t *stats, gs_stream_t stream);
+/* The same exchange for SPLAT ROWS (gs_projection_rows_fwd): the 64-byte row IS the wire row, so nothing is packed or
+ * split -- a row carries its radius (column 10) and depth (column 9), and columns 12 / 13 (padding) carry the two ints of
+ * gs_exchange_compact's `hdr` (destination row | chunk header).
+ * gs_rows16_gather: out_rows[r] = src_rows[index[r * index_stride]] (a negative index gives zeros); tag [n_rows,2] or NULL
+ *   is stored into columns 12 / 13.  Forward: index = src_index, tag = hdr; backward: index = column 12 of the received
+ *   rows (index_stride 16), src_rows = the gradient rows of gs_rasterize_bwd, tag = NULL.
+ * gs_rows16_scatter: dst_rows[index[r * index_stride]] = wire_rows[r] where the index is >= 0; radii / depths (optional)
+ *   receive columns 10 / 9 at the same element.  Forward: index = column 12 of the received rows; backward: src_index. */
+int32_t gs_rows16_gather(
+    uint64_t n_rows, const int32_t *index, int64_t index_stride, const float *src_rows, const int32_t *tag, float *out_rows,
+    gs_stream_t stream);
+int32_t gs_rows16_scatter(
+    uint64_t n_rows, const int32_t *index, int64_t index_stride, const float *wire_rows, float *dst_rows, int32_t *radii,
+    float *depths, gs_stream_t stream);
 /* After the all-to-all of those chunks: out3 = (some sender overflowed (bit 30 of the count in the header row hdr_rows[d] of
  * every received chunk; recv rows are row_width ints wide), stats[0], stats[1]).  out3 may be pinned HOST memory: the flags
  * then reach the host with the renderer's own tile-count read-back, without a copy command or a sync of their own. */

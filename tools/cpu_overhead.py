@@ -14,6 +14,13 @@ from gscodec_studio_amd import rasterization  # noqa: E402
 from gscodec_studio_amd._helper import sh_workload  # noqa: E402
 
 dev = torch.device("cuda:0")
+DIST = os.environ.get("DIST", "0") == "1"  # gaussian-sharded mode at world 1, collectives forced through RCCL
+if DIST:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29733")
+    os.environ["GS_DIST_FORCE_COLLECTIVES"] = "1"
+    torch.cuda.set_device(dev)
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1)
 w = sh_workload(scene_grid=1, device=dev)
 n = int(os.environ.get("N", "3000"))
 params = {k: w[k][:n].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "sh")}
@@ -24,7 +31,7 @@ def step():
     for p in params.values():
         p.grad = None
     rc, ra, meta = rasterization(params["means"], params["quats"], params["scales"], params["opacities"], params["sh"], vm, Ks,
-                                 1920, 1080, sh_degree=3, packed=False)
+                                 1920, 1080, sh_degree=3, packed=False, distributed=DIST)
     rc.sum().backward()
 
 
@@ -45,5 +52,5 @@ for _ in range(K):
 pr.disable()
 torch.cuda.synchronize()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
-print(s.getvalue()[:6000])
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45)
+print(s.getvalue()[:9000])
