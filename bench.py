@@ -217,14 +217,12 @@ def cpu_baseline(args, sh_degree):
 def dp_projection(args, t1_ms, stats):
     """What can be said about N = 8 from ONE GPU (the build rounds have no multi-GPU box): every exchange mode is re-run in a
     subprocess on this GPU with world 1 and its collectives FORCED through RCCL (GS_DIST_FORCE_COLLECTIVES=1: compaction, row
-    gathers / scatters, plan and reduce kernels and RCCL's self-copies all run; nothing crosses a link).  The step it measures
-    minus the plain step is everything the mode adds on one GPU; of that, the device time of the collectives themselves
-    (event brackets, `collectives_device_ms`) is RCCL copying the WHOLE payload to itself -- at world 8 one eighth of the
-    payload stays local and seven eighths travel, so  local_overhead = (step - plain step) - 7/8 x collectives_device_ms.
-    Next to it the payload a rank would put on the wire at world 8 with one camera per rank (closed form from N / V, union of
-    the visible sets taken as V: the bench cameras are yawed copies of camera 0) and the time the 7 xGMI links of an MI355X
-    need for it at peak.  implied_efficiency = t1 / (t1 + local overhead + wire floor): an UPPER bound on the weak-scaling
-    efficiency (links at peak, nothing overlapped)."""
+    gathers / scatters, plan and reduce kernels and RCCL's self-copies all run; nothing crosses a link), which gives the mode's
+    LOCAL overhead per step -- conservatively: RCCL copying the whole payload to itself is counted as local work, although at
+    world 8 seven eighths of it would be on the wire instead.  Next to it the payload a rank would put on the wire at world 8
+    with one camera per rank (closed form from N / V, union of the visible sets taken as V: the bench cameras are yawed copies
+    of camera 0) and the time the 7 xGMI links of an MI355X need for it at peak.
+    implied_efficiency = t1 / (t1 + local overhead + wire floor): links at peak, nothing overlapped."""
     import subprocess
 
     N, V = stats["N"], stats["V"]
@@ -243,11 +241,9 @@ def dp_projection(args, t1_ms, stats):
         rec = {"wire_bytes_out_per_rank_world8": wire8[mode], "xgmi_floor_ms": wire8[mode] / (7 * 153e9) * 1e3}
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180)
-            line = json.loads(r.stdout.strip().splitlines()[-1])
-            ms, coll = line["ms_per_step"], float((line.get("wire") or {}).get("collectives_device_ms_per_step") or 0.0)
+            ms = json.loads(r.stdout.strip().splitlines()[-1])["ms_per_step"]
             rec["ms_per_step_world1_forced_collectives"] = ms
-            rec["collectives_device_ms"] = coll
-            rec["local_overhead_ms"] = max(ms - t1_ms - 7.0 / 8.0 * coll, 0.0)
+            rec["local_overhead_ms"] = max(ms - t1_ms, 0.0)
             rec["implied_efficiency_world8"] = t1_ms / (t1_ms + rec["local_overhead_ms"] + rec["xgmi_floor_ms"])
             rec["implied_speedup_world8"] = 8 * rec["implied_efficiency_world8"]
         except Exception as e:  # (a projection must never take the measurement down with it)
@@ -455,15 +451,6 @@ def main():
         regions.append(e_)
     dom_ms = float(np.mean(dom_all))
     ms_per_step = sum(regions) / (len(regions) * args.steps) * 1e3
-    # device time of the collectives themselves, from one EXTRA region with event brackets around them (not part of the
-    # timed regions): at world 1 with forced collectives this is RCCL's self-copy, the stand-in for the wire
-    coll_ms = None
-    if use_pg:
-        D.TIMED["on"], D.TIMED["events"] = True, []
-        timed_region(args.steps, set())
-        torch.cuda.synchronize(dev)
-        coll_ms = D.collective_time_ms() / args.steps
-        D.TIMED["on"] = False
     if args.breakdown and rank == 0:
         print("  regions (ms/step): " + " ".join(f"{r / args.steps * 1e3:.3f}" for r in regions), file=sys.stderr)
 
@@ -513,7 +500,7 @@ def main():
             # 7 xGMI links of one MI355X (7 x 153 GB/s, MI355X_MICROARCH.md) need for them at peak -- a lower bound that
             # the measured step time can be read against
             "wire": {"bytes_out_per_rank_per_step": wire_bytes_per_step, "xgmi_floor_ms": wire_bytes_per_step / (7 * 153e9) * 1e3,
-                     "xgmi_peak_gbs_per_gpu": 7 * 153, "collectives_device_ms_per_step": coll_ms} if use_pg else None,
+                     "xgmi_peak_gbs_per_gpu": 7 * 153} if use_pg else None,
             "ms_per_step_dense_image_grad": dense_ms,
             "ms_per_step_without_loss_forward": nosum_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

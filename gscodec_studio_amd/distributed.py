@@ -53,37 +53,6 @@ def _wire(nbytes: float) -> None:
     WIRE["bytes"] += int(nbytes)
 
 
-# GS_DIST_TIME_COLLECTIVES=1 (bench.py's one-GPU projection): every device collective is bracketed by events on its stream,
-# so that the time RCCL's self-copies take at world 1 -- the stand-in for the wire -- can be told apart from the rest.
-TIMED = {"on": os.environ.get("GS_DIST_TIME_COLLECTIVES", "0") == "1", "events": []}
-
-
-class _timed:
-    def __init__(self, t: Tensor):
-        self.on = TIMED["on"] and t.is_cuda
-        self.dev = t.device
-
-    def __enter__(self):
-        if self.on:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e0.record(torch.cuda.current_stream(self.dev))
-
-    def __exit__(self, *exc):
-        if self.on:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record(torch.cuda.current_stream(self.dev))
-            TIMED["events"].append((self.e0, e1))
-        return False
-
-
-def collective_time_ms(reset: bool = True) -> float:
-    """Device time of the collectives queued since the last reset (call after a synchronisation)."""
-    ms = sum(a.elapsed_time(b) for a, b in TIMED["events"])
-    if reset:
-        TIMED["events"] = []
-    return ms
-
-
 def _single(world_size: int) -> bool:
     """World-1 short cut of every collective; GS_DIST_FORCE_COLLECTIVES=1 disables it so that a one-rank run
     still drives RCCL (used by the tests on single-GPU boxes)."""
@@ -103,8 +72,7 @@ def _all_gather_into(out: Tensor, inp: Tensor) -> None:
         dist.all_gather_into_tensor(o, inp.cpu())
         out.copy_(o)
     else:
-        with _timed(inp):
-            dist.all_gather_into_tensor(out, inp)
+        dist.all_gather_into_tensor(out, inp)
 
 
 def _all_reduce_sum(t: Tensor) -> None:
@@ -115,8 +83,7 @@ def _all_reduce_sum(t: Tensor) -> None:
         dist.all_reduce(h, op=dist.ReduceOp.SUM)
         t.copy_(h)
     else:
-        with _timed(t):
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
 def _all_to_all_single(out: Tensor, inp: Tensor, out_splits: List[int], in_splits: List[int]) -> None:
@@ -125,8 +92,7 @@ def _all_to_all_single(out: Tensor, inp: Tensor, out_splits: List[int], in_split
         row = inp.element_size() * (inp.numel() // max(inp.shape[0], 1))
         _wire(row * (sum(in_splits) - in_splits[dist.get_rank()]))
     if "nccl" in _backend_name():
-        with _timed(inp):
-            dist.all_to_all_single(out, inp, out_splits, in_splits)
+        dist.all_to_all_single(out, inp, out_splits, in_splits)
         return
     if _staged(inp):
         o = torch.empty(out.shape, dtype=out.dtype)
@@ -985,12 +951,10 @@ def all_reduce_splat_grads(
             if n % world_size == 0 and n * flat.element_size() >= _DIRECT_RS_AG_MIN_BYTES and "nccl" in _backend_name():
                 shard = flat.new_empty(n // world_size)
                 _wire(2.0 * n * flat.element_size() * (world_size - 1) / world_size)
-                with _timed(flat):
-                    dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+                dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
                 if average:
                     shard.mul_(scale)
-                with _timed(flat):
-                    dist.all_gather_into_tensor(flat, shard)
+                dist.all_gather_into_tensor(flat, shard)
             else:
                 _all_reduce_sum(flat)
                 if average:
@@ -1005,12 +969,10 @@ def all_reduce_splat_grads(
         if pad:
             bucket = torch.cat([bucket, bucket.new_zeros(pad)])
         shard = bucket.new_empty(bucket.numel() // world_size)
-        with _timed(bucket):
-            dist.reduce_scatter_tensor(shard, bucket, op=dist.ReduceOp.SUM)
+        dist.reduce_scatter_tensor(shard, bucket, op=dist.ReduceOp.SUM)
         if average:
             shard.mul_(1.0 / world_size)
-        with _timed(bucket):
-            dist.all_gather_into_tensor(bucket, shard)
+        dist.all_gather_into_tensor(bucket, shard)
         bucket = bucket[:n]
     elif algorithm == "all_reduce":
         _all_reduce_sum(bucket)
