@@ -535,6 +535,44 @@ def test_exchange_compact_lists_and_overflow_flag():
             assert torch.equal(dst.sort().values, ((cam % C_local) * N_total + N_off + gau).to(torch.int32).sort().values)
 
 
+def test_rows16_gather_scatter_round_trip():
+    """gs_rows16_gather / gs_rows16_scatter (the exchange of splat rows): gathered rows equal the indexed source rows bit for
+    bit with the two tag ints in columns 12 / 13, a negative index gives a zero row carrying only its tag; the scatter puts
+    every row with a non-negative index (read from column 12 of the wire itself) at its place, fills radii / depths from
+    columns 10 / 9, and touches nothing else."""
+    from gscodec_studio_amd._wrapper import ROW, ROW_DEPTH, ROW_RADIUS, rows16_gather, rows16_scatter
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n_src, n_wire, n_dst = 7000, 3001, 9000
+    src = torch.randn(n_src, ROW, device="cuda", generator=g)
+    src.view(torch.int32)[:, ROW_RADIUS] = torch.randint(1, 50, (n_src,), device="cuda", generator=g, dtype=torch.int32)
+    index = torch.randint(0, n_src, (n_wire,), device="cuda", generator=g, dtype=torch.int32)
+    index[::7] = -1
+    dst_rows = torch.randperm(n_dst, device="cuda", generator=g)[:n_wire].to(torch.int32)  # distinct destinations
+    dst_rows[::7] = -1
+    tag = torch.stack([dst_rows, torch.arange(n_wire, device="cuda", dtype=torch.int32)], dim=1).contiguous()
+    wire = rows16_gather(n_wire, index, 1, src, tag)
+    ref = torch.zeros(n_wire, ROW, device="cuda")
+    ok = index >= 0
+    ref[ok] = src[index[ok].long()]
+    ref.view(torch.int32)[:, 12:14] = tag
+    assert torch.equal(wire.view(torch.int32), ref.view(torch.int32))
+    # strided index: a column of another row buffer
+    wire2 = rows16_gather(n_wire, wire.view(torch.int32)[:, 13], ROW, wire, None)  # column 13 = arange: the identity gather
+    assert torch.equal(wire2.view(torch.int32), wire.view(torch.int32))
+
+    out = torch.full((n_dst, ROW), 7.0, device="cuda")
+    radii = torch.full((n_dst,), -5, dtype=torch.int32, device="cuda")
+    depths = torch.full((n_dst,), -1.0, device="cuda")
+    rows16_scatter(n_wire, wire.view(torch.int32)[:, 12], ROW, wire, out, radii, depths)
+    ref_out, ref_r, ref_d = torch.full_like(out, 7.0), torch.full_like(radii, -5), torch.full_like(depths, -1.0)
+    d = dst_rows[ok].long()
+    ref_out[d] = wire[ok]
+    ref_r[d] = wire.view(torch.int32)[ok, ROW_RADIUS]
+    ref_d[d] = wire[ok, ROW_DEPTH]
+    assert torch.equal(out.view(torch.int32), ref_out.view(torch.int32)) and torch.equal(radii, ref_r) and torch.equal(depths, ref_d)
+
+
 @pytest.mark.parametrize("shape", [(5000,), (5000, 3), (5000, 16, 3)])
 def test_gather_rows_and_atomic_backward(shape):
     """gather_rows == src[ids] with the same gradient (ids repeat: a splat seen by several cameras)."""
