@@ -55,7 +55,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # measured for this workload and committed under profiles/; bench.py cannot run rocprof on itself.
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 KERNEL_OF_ENTRY = {"gs_rasterize_bwd": "raster_seg_bwd_kernel", "gs_rasterize_fwd": "raster_tile_fwd_kernel",
-                   "gs_sh_view_bwd": "sh_bwd_kernel", "gs_sort_isect_pairs": "sort_scatter_kernel<unsigned int, 16, true>"}
+                   "gs_sh_view_bwd": "sh_bwd_kernel", "gs_projection_rows_bwd": "projection_bwd_kernel<false, 3>", "gs_sort_isect_pairs": "sort_scatter_kernel<unsigned int, 16, true>"}
 
 
 def measured_pmc(entry, workload_key, field="traffic_bytes_per_launch"):
@@ -150,7 +150,7 @@ def algorithmic_bytes(stats):
     return {
         "gs_projection_fwd": 40 * N + 4 * N + 24 * V,
         "gs_projection_rows_fwd": 40 * N + 4 * N + 24 * V + ((12 + 12 * K) * V + 12 * V if K > 0 else 0),  # (+ the SH colours)
-        "gs_projection_rows_bwd": 92 * V + 40 * N + 4 * N,
+        "gs_projection_rows_bwd": 92 * V + 40 * N + 4 * N + ((24 + 12 * K) * V + 12 * K * N if K > 0 else 0),  # (+ the SH backward)
         "gs_sh_fwd": (12 + 12 * K) * V + 12 * V,
         "gs_sh_view_fwd": (12 + 12 * K) * V + 12 * V + 4 * N,
         "gs_sh_view_bwd": (24 + 12 * K) * V + 12 * K * N + 12 * V + 12 * N,

@@ -788,6 +788,9 @@ class _FullyFusedProjection(torch.autograd.Function):
         return (v_means, v_covars, v_quats, v_scales, v_viewmats) + (None,) * 10
 
 
+_FUSE_SH_BWD = os.environ.get("GS_FUSE_SH_BWD", "1") == "1"  # (A/B switch: 0 = gs_sh_view_bwd + gs_projection_rows_bwd as two launches)
+
+
 class GradPrefill:
     """Hand-over between the two autograd nodes of ONE ``rasterization()`` call (not in the reference).
 
@@ -1003,21 +1006,25 @@ class _ProjectRows(torch.autograd.Function):
             return pre[key] if prefilled else torch.empty_like(like)
 
         v_sh = v_rest = v_means_add = None
+        sh_args = (None, None, 0, 0, None, None)
         if sh_coeffs is not None:
-            # the colour columns of the gradient rows go back through the SH evaluation first (clamp gate from the colours
-            # in the rows); its d/d means (view directions) is added by the projection kernel below while it writes v_means
+            # the colour columns of the gradient rows go back through the SH evaluation (clamp gate from the colours in the
+            # rows); its d/d means (view directions) is added to v_means.  Vectorisable rows and fixed poses: inside the
+            # projection backward's own pass (one launch, one pass over radii / means / the two row buffers); otherwise by
+            # gs_sh_view_bwd first, whose v_means the projection kernel then adds while it writes its own
             K = sh_coeffs.shape[1] + (sh_rest.shape[1] if sh_rest is not None else 0)
             v_sh = out("sh", sh_coeffs)
             v_rest = out("sh_rest", sh_rest) if sh_rest is not None else None
-            v_means_add = torch.empty_like(means) if need[0] else None
-            with _device_of(means):
-                B.call("gs_sh_view_bwd", C, N, K, ctx.sh_degree, B.ptr(means), B.ptr(viewmats), 1, B.ptr(sh_coeffs), B.ptr(sh_rest),
-                       B.ptr(radii), rows.data_ptr() + 4 * ROW_COLOR, ROW, g_ptr + 4 * ROW_COLOR, ROW, B.ptr(v_sh), B.ptr(v_rest),
-                       B.ptr(v_means_add), None, 0, None, int(prefilled), _stream(means))
-            if not need[8]:
-                v_sh = None
-            if not need[9]:
-                v_rest = None
+            fused = (_FUSE_SH_BWD and (3 * K) % 4 == 0 and not need[4] and v_sh.data_ptr() % 16 == 0 and (v_rest is None or v_rest.data_ptr() % 16 == 0)
+                     and (sh_rest is not None or sh_coeffs.data_ptr() % 16 == 0))
+            if fused:
+                sh_args = (B.ptr(sh_coeffs), B.ptr(sh_rest), K, ctx.sh_degree, B.ptr(v_sh), B.ptr(v_rest))
+            else:
+                v_means_add = torch.empty_like(means) if need[0] else None
+                with _device_of(means):
+                    B.call("gs_sh_view_bwd", C, N, K, ctx.sh_degree, B.ptr(means), B.ptr(viewmats), 1, B.ptr(sh_coeffs), B.ptr(sh_rest),
+                           B.ptr(radii), rows.data_ptr() + 4 * ROW_COLOR, ROW, g_ptr + 4 * ROW_COLOR, ROW, B.ptr(v_sh), B.ptr(v_rest),
+                           B.ptr(v_means_add), None, 0, None, int(prefilled), _stream(means))
         v_depths = _f32c(v_depths) if v_depths is not None else None
         # rows are fully written by the kernel -> empty, not zeros (prefilled: only the visible gaussians' rows are)
         v_means = out("means", means) if need[0] else None
@@ -1032,7 +1039,12 @@ class _ProjectRows(torch.autograd.Function):
                    B.ptr(viewmats), B.ptr(Ks), int(ctx.width), int(ctx.height), float(ctx.eps2d), ctx.cm,
                    B.ptr(radii), B.ptr(rows), g_ptr, B.ptr(v_depths), B.ptr(opacities), int(ctx.antialiased),
                    B.ptr(v_means), B.ptr(v_covars), B.ptr(v_quats), B.ptr(v_scales), B.ptr(v_viewmats), B.ptr(v_opac),
-                   B.ptr(v_colors), B.ptr(v_means_add) if v_means is not None else None, int(prefilled), _stream(means))
+                   B.ptr(v_colors), B.ptr(v_means_add) if v_means is not None else None, *sh_args, int(prefilled), _stream(means))
+        if sh_coeffs is not None:
+            if not need[8]:
+                v_sh = None
+            if not need[9]:
+                v_rest = None
         del g_keep
         return (v_means, v_covars, v_quats, v_scales, v_viewmats, None, v_opac, v_colors, v_sh, v_rest) + (None,) * 10
 

@@ -16,6 +16,7 @@
 #include "gs_common.h"
 #include "proj_models.h"
 #include "sh_eval.h"
+#include "sh_bwd_lane.h"
 
 namespace {
 
@@ -363,9 +364,19 @@ struct RowGrads {
     float *v_colors;        // [N,3] or NULL
     int antialiased;
     int prefilled;          // every per-gaussian output holds zeros already: gaussians no camera sees are not stored
+    // SH colours evaluated by the forward (gs_projection_rows_fwd with sh_coeffs): their backward runs in this pass too
+    const float *sh_coeffs; // [N,K,3], or the DC band [N,1,3] with sh_rest
+    const float *sh_rest;   // [N,K-1,3] or NULL
+    uint32_t sh_K;
+    float *v_sh;            // gradient of sh_coeffs
+    float *v_sh_rest;       // gradient of sh_rest
 };
 
-template <bool NEED_VIEW>
+// SHDEG >= 0 (row form, shared coefficients, fixed poses): the SH backward of the colours the forward evaluated runs FIRST in
+// the same lane (sh_bwd_lane.h: v_sh rows out, d/d view direction kept in three registers), then the projection chain --
+// one pass over radii / means / the two row buffers instead of two, and no [N,3] round trip for the direction gradient
+// (sh_bwd_kernel 40.4 us + projection_bwd_kernel 20.4 us -> 52.3 us at BASELINE config 2).
+template <bool NEED_VIEW, int SHDEG = -1>
 __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
     uint32_t C, uint32_t N,
     const float *__restrict__ means, const float *__restrict__ covars,
@@ -383,6 +394,15 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
     float v_op = 0.f, v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f;
     uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
     bool in_range = n < N;
+    float shx = 0.f, shy = 0.f, shz = 0.f; // d/d means through the SH view directions
+    if (SHDEG >= 0) {
+        const ShView view = {means, viewmats, radii, 1, 1, nullptr, nullptr, nullptr, 0u, nullptr, rg.sh_rest, rg.v_sh_rest,
+                             (uint32_t)GS_ROW_FLOATS, rg.prefilled};
+        bool any_sh;
+        sh_bwd_lane<(SHDEG >= 0 ? SHDEG : 0), true, true>(C, N, rg.sh_K, n, in_range, nullptr, rg.sh_coeffs, nullptr, rg.grad_rows + GS_ROW_COLOR,
+                                                          rg.v_sh, nullptr, view, rg.rows + GS_ROW_COLOR, (uint32_t)GS_ROW_FLOATS,
+                                                          v_means != nullptr, shx, shy, shz, any_sh);
+    }
     float px = 0.f, py = 0.f, pz = 0.f;
     Sym3 S = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bool loaded = false;
@@ -456,6 +476,7 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
         }
     }
     if (in_range && (any || !rg.prefilled)) {
+        if (SHDEG >= 0) { g.v_px += shx; g.v_py += shy; g.v_pz += shz; }
         store_gaussian_grads(g, n, any, covars, quats, scales, v_means, v_covars, v_quats, v_scales, v_means_add);
         if (rg.v_opacities != nullptr) rg.v_opacities[n] = v_op;
         if (rg.v_colors != nullptr) {
@@ -713,7 +734,8 @@ extern "C" int32_t gs_projection_rows_bwd(
     int32_t image_height, float eps2d, int32_t camera_model, const int32_t *radii, const float *rows,
     const float *grad_rows, const float *v_depths, const float *opacities, int32_t antialiased, float *v_means,
     float *v_covars, float *v_quats, float *v_scales, float *v_viewmats, float *v_opacities, float *v_colors,
-    const float *v_means_add, int32_t outputs_prefilled, gs_stream_t stream) {
+    const float *v_means_add, const float *sh_coeffs, const float *sh_coeffs_rest, uint32_t sh_K, uint32_t sh_degree,
+    float *v_sh_coeffs, float *v_sh_coeffs_rest, int32_t outputs_prefilled, gs_stream_t stream) {
     if (N == 0) return 0;
     GS_CHECK_ARG(means && viewmats && Ks && radii && rows && grad_rows, "null pointer");
     GS_CHECK_ARG((uintptr_t)rows % 16 == 0 && (uintptr_t)grad_rows % 16 == 0, "row buffers must be 16-byte aligned");
@@ -721,9 +743,26 @@ extern "C" int32_t gs_projection_rows_bwd(
                  "exactly one of covars / (quats, scales) must be given");
     GS_CHECK_ARG(!antialiased || opacities != nullptr, "antialiased needs the opacities");
     dim3 grid(gs_div_up(N, GS_BLOCK));
-    const RowGrads rg = {rows, grad_rows, opacities, v_opacities, v_colors, antialiased, outputs_prefilled != 0};
+    RowGrads rg = {rows, grad_rows, opacities, v_opacities, v_colors, antialiased, outputs_prefilled != 0, nullptr, nullptr, 0u, nullptr, nullptr};
     const float *nul = nullptr;
-    if (v_viewmats != nullptr) {
+    if (sh_coeffs != nullptr) {
+        // the SH backward in the same pass: the vectorised row form only (what gs_sh_view_bwd stages through LDS), fixed poses
+        GS_CHECK_ARG(v_viewmats == nullptr && v_colors == nullptr, "fused SH backward: no camera-pose / per-gaussian colour gradients");
+        GS_CHECK_ARG(v_sh_coeffs != nullptr && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= sh_K, "fused SH backward: v_sh_coeffs, degree <= 4, K >= (degree + 1)^2");
+        GS_CHECK_ARG((sh_coeffs_rest == nullptr) == (v_sh_coeffs_rest == nullptr), "sh_coeffs_rest and v_sh_coeffs_rest go together");
+        GS_CHECK_ARG((sh_K * 3u) % 4u == 0 && (uintptr_t)v_sh_coeffs % 16 == 0 && (uintptr_t)v_sh_coeffs_rest % 16 == 0 &&
+                         (sh_coeffs_rest != nullptr ? sh_K >= 2 : (uintptr_t)sh_coeffs % 16 == 0),
+                     "fused SH backward needs 3 K % 4 == 0 and 16-byte aligned rows (gs_projection_rows_bwd_sh_ok); call gs_sh_view_bwd instead");
+        rg.sh_coeffs = sh_coeffs; rg.sh_rest = sh_coeffs_rest; rg.sh_K = sh_K; rg.v_sh = v_sh_coeffs; rg.v_sh_rest = v_sh_coeffs_rest;
+#define GS_ROWS_BWD_SH(D)                                                                                                        \
+    case D:                                                                                                                      \
+        hipLaunchKernelGGL((projection_bwd_kernel<false, D>), grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means, covars,  \
+                           quats, scales, viewmats, Ks, image_width, image_height, eps2d, camera_model, radii, nul, nul, nul,     \
+                           v_depths, nul, nul, v_means, v_covars, v_quats, v_scales, v_viewmats, 16u, 16u, v_means_add, rg);      \
+        break;
+        switch (sh_degree) { GS_ROWS_BWD_SH(0) GS_ROWS_BWD_SH(1) GS_ROWS_BWD_SH(2) GS_ROWS_BWD_SH(3) GS_ROWS_BWD_SH(4) }
+#undef GS_ROWS_BWD_SH
+    } else if (v_viewmats != nullptr) {
         hipLaunchKernelGGL(projection_bwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
                            means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,
                            camera_model, radii, nul, nul, nul, v_depths, nul, nul, v_means, v_covars, v_quats, v_scales,
@@ -755,7 +794,7 @@ extern "C" int32_t gs_projection_bwd(
     GS_CHECK_ARG((v_compensations == nullptr) || (compensations != nullptr),
                  "v_compensations given without compensations");
     dim3 grid(gs_div_up(N, GS_BLOCK));
-    const RowGrads rg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const RowGrads rg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0u, nullptr, nullptr};
     if (v_viewmats != nullptr) {
         hipLaunchKernelGGL(projection_bwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
                            means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,

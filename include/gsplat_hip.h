@@ -168,7 +168,12 @@ int32_t gs_projection_rows_fwd(
  * projection chain) and v_colors [N,3] = sum over cameras of columns 6-8; either may be NULL.
  * outputs_prefilled != 0: the caller guarantees that every per-gaussian output already holds zeros (e.g. through the
  * zero_fill of gs_rasterize_fwd); the rows of gaussians that no camera sees (71 % at BASELINE config 2) are then not
- * written at all, and v_means_add is only read where some camera sees the gaussian. */
+ * written at all, and v_means_add is only read where some camera sees the gaussian.
+ * sh_coeffs != NULL (the forward evaluated the colours from them): the SH backward of gs_sh_view_bwd runs IN THE SAME PASS --
+ * v_sh_coeffs [N,K,3] (or the pair v_sh_coeffs [N,1,3] / v_sh_coeffs_rest [N,K-1,3] for split coefficients) is written, and
+ * the gradient that reaches the means through the view directions is added to v_means without leaving the lane.  Needs
+ * 3 K % 4 == 0, 16-byte aligned coefficient / gradient rows, v_viewmats == NULL and v_colors == NULL; otherwise call
+ * gs_sh_view_bwd first and hand its v_means over as v_means_add. */
 int32_t gs_projection_rows_bwd(
     uint32_t C, uint32_t N,
     const float *means, const float *covars, const float *quats, const float *scales,
@@ -179,6 +184,8 @@ int32_t gs_projection_rows_bwd(
     float *v_means, float *v_covars, float *v_quats, float *v_scales, float *v_viewmats,
     float *v_opacities, float *v_colors,
     const float *v_means_add, /* [N,3] or NULL, as in gs_projection_bwd */
+    const float *sh_coeffs, const float *sh_coeffs_rest, uint32_t sh_K, uint32_t sh_degree,
+    float *v_sh_coeffs, float *v_sh_coeffs_rest,
     int32_t outputs_prefilled,
     gs_stream_t stream);
 

@@ -544,3 +544,30 @@ def test_prefilled_gradients_equal_full_writes(mode):
         assert torch.equal(a, b), f"{name}: prefilled and fully written gradients differ"
         assert float(a[unseen].abs().max()) == 0.0, name
         assert float(a.abs().max()) > 0.0, name
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_fused_sh_projection_backward_equals_two_launches(split, monkeypatch):
+    """The SH backward fused behind the projection backward (one launch, `gs_projection_rows_bwd(sh_coeffs=...)`) against the
+    two-launch form (`gs_sh_view_bwd`, then `gs_projection_rows_bwd(v_means_add=...)`): the same per-lane arithmetic, so with
+    the deterministic compositing backward every parameter gradient must be bit-identical."""
+    from gscodec_studio_amd import _wrapper as W
+    from gscodec_studio_amd import rasterization
+
+    d = _inputs(n=5000, cams=2, sh_degree=3, scale_mult=6.0)
+    w = torch.linspace(0.5, 1.5, 2 * d["H"] * d["W"] * 3, device="cuda").reshape(2, d["H"], d["W"], 3)
+
+    def run(fused):
+        monkeypatch.setattr(W, "_FUSE_SH_BWD", fused)
+        ps = [T(d[k]).requires_grad_(True) for k in ("means", "quats", "scales", "opacities")]
+        sh = T(d["colors"])
+        cols = [sh[:, :1].clone().requires_grad_(True), sh[:, 1:].clone().requires_grad_(True)] if split else [sh.clone().requires_grad_(True)]
+        rc, ra, _ = rasterization(*ps, tuple(cols) if split else cols[0], T(d["viewmats"]), T(d["Ks"]), d["W"], d["H"], sh_degree=3,
+                                  packed=False, deterministic=True)
+        ((rc * w).sum() + 0.3 * ra.sum()).backward()
+        return [p.grad.clone() for p in ps + cols]
+
+    a, b = run(True), run(False)
+    for x, y, name in zip(a, b, ["means", "quats", "scales", "opacities", "sh0", "shN"]):
+        assert torch.equal(x, y), f"{name}: fused and two-launch backward differ"
+        assert float(x.abs().max()) > 0
