@@ -1393,12 +1393,13 @@ def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile
 # Launch tuning of the compositing kernels: (segment length of the backward, solo threshold of the forward, XCD group of the
 # forward / backward); -1 = the library's default (the measured MI355X optimum).  The library itself is stateless: the values
 # travel in the gs_raster_plan made for every forward and handed to its backward.  Preset from the environment, read once.
-_TUNING_KEYS = ("raster_seg", "raster_solo_min", "raster_xcd_fwd", "raster_xcd_bwd")
-_RASTER_TUNING = [int(os.environ.get(k, "-1")) for k in ("GS_RASTER_SEG", "GS_RASTER_SOLO", "GS_RASTER_XCD_FWD", "GS_RASTER_XCD_BWD")]
+_TUNING_KEYS = ("raster_seg", "raster_solo_min", "raster_xcd_fwd", "raster_xcd_bwd", "raster_order_fwd")
+_RASTER_TUNING = [int(os.environ.get(k, "-1")) for k in ("GS_RASTER_SEG", "GS_RASTER_SOLO", "GS_RASTER_XCD_FWD", "GS_RASTER_XCD_BWD",
+                                                         "GS_RASTER_ORDER_FWD")]
 
 
 def set_raster_tuning(**kv) -> dict:
-    """Set tuning values (keys: raster_seg, raster_solo_min, raster_xcd_fwd, raster_xcd_bwd; ``None`` / -1 = default) for the
+    """Set tuning values (keys: raster_seg, raster_solo_min, raster_xcd_fwd, raster_xcd_bwd, raster_order_fwd; ``None`` / -1 = default) for the
     rasterize calls that FOLLOW; returns the previous values.  A forward's values stay with its backward (they are stored
     in its plan), so changing them between the two is harmless."""
     prev = dict(zip(_TUNING_KEYS, _RASTER_TUNING))
@@ -1407,10 +1408,14 @@ def set_raster_tuning(**kv) -> dict:
     return prev
 
 
-def _raster_plan(n_tiles_all: int, n_isects: int, channels: int):
-    """(plan buffer, scratch bytes): a gs_raster_plan (host struct, 64 bytes) for one forward / backward pair."""
+def _raster_plan(n_tiles_all: int, n_isects: int, channels: int, forward_only: bool = False):
+    """(plan buffer, scratch bytes): a gs_raster_plan (host struct, 64 bytes) for one forward / backward pair.
+    ``forward_only``: no backward will follow -- segment length 0, i.e. no checkpoints (the scratch then only holds the
+    forward's tile order and cost counters)."""
     plan = ctypes.create_string_buffer(64)
-    tun = (ctypes.c_int32 * 4)(*_RASTER_TUNING)
+    tun = (ctypes.c_int32 * 5)(*_RASTER_TUNING)
+    if forward_only:
+        tun[0] = 0
     B.call("gs_rasterize_plan", n_tiles_all, n_isects, channels, ctypes.addressof(tun), ctypes.addressof(plan))
     return plan, struct.unpack_from("<Q", plan, 32)[0]
 
@@ -1512,7 +1517,7 @@ class _RasterizeToPixels(torch.autograd.Function):
         # 1080p): only ask for them when a backward can follow
         needs_bwd = any(ctx.needs_input_grad[:5])
         with _device_of(means2d):
-            plan, sb = _raster_plan(C * tile_height * tile_width, n_isects, channels) if needs_bwd else (None, 0)
+            plan, sb = _raster_plan(C * tile_height * tile_width, n_isects, channels, forward_only=not needs_bwd)
             scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
             # the packed gradient rows of the backward ([n_elems,16], accumulated with atomics) are zero-filled by THIS
             # launch, as a side job of the tile workgroups: no fill pass in the backward

@@ -23,6 +23,7 @@ struct RasterArgs {
     uint32_t s_xy, s_conic, s_color, s_opac;
     uint32_t row16; // 1: the pointers alias one 64-byte-aligned [n_elems,16] buffer at columns 0 / 2 / 6 / 5 and channels <= 4:
                     // the kernels fetch a splat as (up to) three 16-byte loads from ONE 64-byte line
+    const uint32_t *tile_order; // forward: workgroup b composites tile tile_order[b] (NULL: the XCD remap of b), set by the dispatcher
 };
 
 // a buffer the forward zero-fills on the side: n float4s, per_block of them per tile workgroup

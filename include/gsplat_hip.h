@@ -475,7 +475,7 @@ typedef struct gs_raster_plan {
     uint32_t reserved[6];
 } gs_raster_plan;
 int32_t gs_rasterize_plan(uint32_t n_tiles_all /* C * tile_width * tile_height */, uint32_t n_isects, uint32_t channels,
-                          const int32_t *tuning /* [4] HOST ints or NULL */, gs_raster_plan *plan);
+                          const int32_t *tuning /* [5] HOST ints or NULL */, gs_raster_plan *plan);
 
 int32_t gs_rasterize_fwd(
     uint32_t C, uint32_t n_elems, uint32_t n_isects, uint32_t channels,

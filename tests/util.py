@@ -72,7 +72,7 @@ def rel_l2(a, e):
     return float(np.linalg.norm(a - e) / max(np.linalg.norm(e), 1e-30))
 
 
-TUNING_DEFAULTS = {"raster_seg": 256, "raster_solo_min": 2048, "raster_xcd_fwd": 16, "raster_xcd_bwd": 16}
+TUNING_DEFAULTS = {"raster_seg": 256, "raster_solo_min": 2048, "raster_xcd_fwd": 16, "raster_xcd_bwd": 16, "raster_order_fwd": 1}
 # kernel routes a tuning value selects (all must give the reference's results; the fuzz tests run every one of them)
 ROUTES = {
     "default": {},
@@ -81,6 +81,7 @@ ROUTES = {
     "seg128": {"raster_seg": 128},             # shorter backward segments (more checkpoints)
     "unsegmented": {"raster_seg": 0},          # no checkpoints: one quadrant per wave walks the whole list backwards
     "xcd_identity": {"raster_xcd_fwd": 0, "raster_xcd_bwd": 0},
+    "tile_order_off": {"raster_order_fwd": 0},  # forward workgroups in (XCD-remapped) tile order instead of longest list first
 }
 
 

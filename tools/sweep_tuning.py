@@ -37,17 +37,23 @@ def timed(n=40):
 
 
 settings = [{}]
-for v in (192, 320, 384, 512):
-    settings.append({"raster_seg": v})
-for v in (1024, 1536, 3072, 4096):
-    settings.append({"raster_solo_min": v})
-for v in (8, 32, 64):
-    settings.append({"raster_xcd_fwd": v})
-for v in (8, 32, 64):
-    settings.append({"raster_xcd_bwd": v})
-settings.append({"raster_seg": 320, "raster_solo_min": 1024})
-settings.append({"raster_seg": 320, "raster_xcd_fwd": 32})
-default = {"raster_seg": None, "raster_solo_min": None, "raster_xcd_fwd": None, "raster_xcd_bwd": None}
+if os.environ.get("SWEEP", "all") == "order":  # the knobs that interact with the forward's longest-first tile order
+    settings.append({"raster_order_fwd": 0})
+    for v in (512, 1024, 1536, 3072, 4096, 100000):
+        settings.append({"raster_solo_min": v})
+    settings.append({"raster_order_fwd": 0, "raster_solo_min": 4096})
+else:
+    for v in (192, 320, 384, 512):
+        settings.append({"raster_seg": v})
+    for v in (1024, 1536, 3072, 4096):
+        settings.append({"raster_solo_min": v})
+    for v in (8, 32, 64):
+        settings.append({"raster_xcd_fwd": v})
+    for v in (8, 32, 64):
+        settings.append({"raster_xcd_bwd": v})
+    settings.append({"raster_seg": 320, "raster_solo_min": 1024})
+    settings.append({"raster_seg": 320, "raster_xcd_fwd": 32})
+default = {"raster_seg": None, "raster_solo_min": None, "raster_xcd_fwd": None, "raster_xcd_bwd": None, "raster_order_fwd": None}
 for _ in range(60):
     step()
 res = {i: [] for i in range(len(settings))}
