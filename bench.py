@@ -166,6 +166,7 @@ def algorithmic_bytes(stats):
         "gs_sort_isect_pairs": 24 * I,
         "gs_sort_pairs_u64_i32": 24 * I,
         "gs_isect_offset_encode": 8 * I + 4 * T,
+        "gs_isect_finish_presorted": (24 * V + 12 * I) + 24 * I + (8 * I + 4 * T),  # emit + pair sort + offsets in one call
         "gs_rasterize_fwd": 40 * I + 20 * P,
         "gs_rasterize_bwd": 40 * I + 24 * P + 36 * V,
         "gs_sh_bwd": (24 + 12 * K) * V + 12 * K * N + 12 * V,
