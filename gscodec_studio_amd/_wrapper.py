@@ -1525,6 +1525,8 @@ class _RasterizeToPixels(torch.autograd.Function):
             if needs_bwd and channels <= 4 and n_elems > 0:
                 # (+ the per-gaussian gradient tensors the projection node asked for, GradPrefill: one buffer, one fill)
                 extra = prefill.floats() if prefill is not None else 0
+                if extra:
+                    extra += 64  # slack behind the last piece (a multi-GPU reduction rounds the span of all pieces up into it)
                 fill = torch.empty(n_elems * 16 + extra, dtype=torch.float32, device=dev)
                 grad_rows = fill[:n_elems * 16].view(opacities.shape + (16,))
                 if extra:

@@ -940,6 +940,23 @@ def all_reduce_splat_grads(
         algorithm = os.environ.get("GS_DP_ALGO", "direct" if "nccl" in _backend_name() else "all_reduce")
     if algorithm == "direct":
         scale = 1.0 / world_size
+        span = _one_span(plist, world_size)
+        if span is not None and "nccl" not in _backend_name():  # (gloo: no reduce_scatter_tensor; the tests' route)
+            _all_reduce_sum(span)
+            if average:
+                span.mul_(scale)
+            return
+        if span is not None:
+            # every gradient is a piece of ONE buffer (what rasterization() hands out, _wrapper.GradPrefill): one
+            # reduce-scatter + one all-gather over the whole span instead of a pair (or an all-reduce) per tensor -- fewer,
+            # larger collectives; the alignment padding between and behind the pieces is summed along and never read
+            shard = span.new_empty(span.numel() // world_size)
+            _wire(2.0 * span.numel() * span.element_size() * (world_size - 1) / world_size)
+            dist.reduce_scatter_tensor(shard, span, op=dist.ReduceOp.SUM)
+            if average:
+                shard.mul_(scale)
+            dist.all_gather_into_tensor(span, shard)
+            return
         for p in plist:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
@@ -986,6 +1003,28 @@ def all_reduce_splat_grads(
             p.grad = g.clone()
         else:
             p.grad.copy_(g)
+
+
+def _one_span(plist: List[Tensor], world_size: int) -> Optional[Tensor]:
+    """The flat fp32 tensor covering every ``p.grad`` when they are all dense, contiguous pieces of ONE storage lying close
+    together (at most 10 % padding), its length rounded up to a multiple of the world size; None otherwise."""
+    grads = [p.grad for p in plist]
+    if any(g is None or g.is_sparse or g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda for g in grads):
+        return None
+    st = grads[0].untyped_storage()
+    if any(g.untyped_storage().data_ptr() != st.data_ptr() for g in grads[1:]):
+        return None
+    lo = min(g.storage_offset() for g in grads)
+    hi = max(g.storage_offset() + g.numel() for g in grads)
+    used = sum(g.numel() for g in grads)
+    if used * 4 < _DIRECT_RS_AG_MIN_BYTES or (hi - lo) > 1.1 * used + 1024:
+        return None
+    # (rounded up into the slack rasterization() leaves behind the last piece -- never downwards: the compositing gradient
+    # rows, which meta["means2d"].grad / .absgrad may still view, lie in front of the first piece)
+    hi += (-(hi - lo)) % world_size
+    if hi > st.nbytes() // 4:
+        return None
+    return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, lo, (hi - lo,), (1,))
 
 
 # below this an in-place all_reduce (latency-bound anyway); GS_DP_RS_AG_MIN_BYTES overrides (tests)
