@@ -645,3 +645,23 @@ extern "C" int32_t gs_scatter_add_rows_f32(uint64_t n_rows, uint32_t width, cons
     GS_CHECK_LAUNCH();
     return 0;
 }
+
+extern "C" int32_t gs_exchange_rows_send(uint32_t C_total, uint32_t N, uint32_t C_local, uint32_t world, uint32_t cap, uint32_t N_total,
+                                         uint32_t N_off, const int32_t *radii, const float *rows, int32_t *src_index, int32_t *hdr,
+                                         uint32_t *counters, uint32_t *stats, float *send_rows, gs_stream_t stream) {
+    if (int32_t rc = gs_exchange_compact(C_total, N, C_local, world, cap, N_total, N_off, radii, src_index, hdr, counters, stats, stream)) return rc;
+    return gs_rows16_gather((uint64_t)world * (cap + 1), src_index, 1, rows, hdr, send_rows, stream);
+}
+
+extern "C" int32_t gs_exchange_rows_recv(uint64_t n_recv, const float *recv_rows, uint64_t n_dst, float *dst_rows, int32_t *radii,
+                                         float *depths, uint32_t world, const int64_t *hdr_rows, const uint32_t *stats, int32_t *out3,
+                                         gs_stream_t stream) {
+    GS_CHECK_ARG(recv_rows != nullptr || n_recv == 0, "null pointer");
+    if (n_dst > 0) {
+        GS_CHECK_ARG(radii != nullptr, "null pointer");
+        if (hipMemsetAsync(radii, 0, n_dst * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) { gs_set_error("gs_exchange_rows_recv: memset failed"); return 1; }
+    }
+    const int32_t *index = reinterpret_cast<const int32_t *>(recv_rows) + 12;
+    if (int32_t rc = gs_rows16_scatter(n_recv, index, 16, recv_rows, dst_rows, radii, depths, stream)) return rc;
+    return gs_exchange_flags(world, index, 16u, hdr_rows, stats, out3, stream);
+}

@@ -570,7 +570,7 @@ class _ExchangeRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, opacities, colors, depths, radii, rows, N, N_world, C_world, rank, cap_world):
-        from ._wrapper import ROW, ROW_COLOR, ROW_CONIC, ROW_MEAN2D, ROW_OPACITY, exchange_compact, rows16_gather, rows16_scatter
+        from ._wrapper import ROW, ROW_COLOR, ROW_CONIC, ROW_MEAN2D, ROW_OPACITY
         from . import _backend as B
 
         ctx.set_materialize_grads(False)
@@ -578,28 +578,34 @@ class _ExchangeRows(torch.autograd.Function):
         C_total, C_local = sum(C_world), C_world[rank]
         N_total, N_off, cap = sum(N_world), sum(N_world[:rank]), int(cap_world[rank])
         dev = rows.device
-        src_index, hdr, counters, stats = exchange_compact(radii.contiguous(), C_local, world, cap, N_total, N_off)
         n_send = world * (cap + 1)
-        send = rows16_gather(n_send, src_index, 1, rows.view(-1, ROW), hdr)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        # compaction + gather of the visible rows into the send chunks: one native call (src_index stays for the backward)
+        src_index = torch.empty(n_send, dtype=torch.int32, device=dev)
+        aux = torch.empty(n_send * 2 + world + 2, dtype=torch.int32, device=dev)  # hdr [n_send, 2] | counters [world] | stats [2]
+        hdr, counters, stats = aux[:n_send * 2], aux[n_send * 2:n_send * 2 + world], aux[n_send * 2 + world:]
+        send = torch.empty((n_send, ROW), dtype=torch.float32, device=dev)
+        radii = radii.contiguous()
+        with torch.cuda.device(dev):
+            B.call("gs_exchange_rows_send", C_total, N, C_local, world, cap, N_total, N_off, B.ptr(radii), B.ptr(rows), B.ptr(src_index),
+                   B.ptr(hdr), B.ptr(counters), B.ptr(stats), B.ptr(send), st)
         send_splits = [cap + 1] * world
         recv_splits = [int(c) + 1 for c in cap_world]
         n_recv = sum(recv_splits)
         recv = send.new_empty((n_recv, ROW))
         _all_to_all_single(recv, send, recv_splits, send_splits)
-        dst_recv = recv.view(torch.int32)[:, 12]  # a column of the wire: read in place, kept for the backward
-        radii_l = torch.zeros((C_local, N_total), dtype=torch.int32, device=dev)
+        radii_l = torch.empty((C_local, N_total), dtype=torch.int32, device=dev)  # (zero-filled by the call below)
         depths_l = torch.empty((C_local, N_total), dtype=torch.float32, device=dev)
         rows_l = torch.empty((C_local, N_total, ROW), dtype=torch.float32, device=dev)
-        rows16_scatter(n_recv, dst_recv, ROW, recv, rows_l, radii_l, depths_l)
         key = (tuple(recv_splits), dev)
         if key not in _HDR_ROWS:
             _HDR_ROWS[key] = (torch.tensor(recv_splits, dtype=torch.int64).cumsum(0) - 1).to(dev)
         if _SPARSE.get("pinned") is None:
             _SPARSE["pinned"] = torch.empty(3, dtype=torch.int32).pin_memory()
         p3 = _SPARSE["pinned"]
-        with torch.cuda.device(dev):  # (the header ints sit in columns 12 / 13 of the rows)
-            B.call("gs_exchange_flags", world, dst_recv.data_ptr(), ROW, B.ptr(_HDR_ROWS[key]), B.ptr(stats), B.ptr(p3),
-                   torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):  # zero radii, scatter the rows to their places, collect the overflow flags: one call
+            B.call("gs_exchange_rows_recv", n_recv, B.ptr(recv), C_local * N_total, B.ptr(rows_l), B.ptr(radii_l), B.ptr(depths_l), world,
+                   B.ptr(_HDR_ROWS[key]), B.ptr(stats), B.ptr(p3), st)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         _SPARSE["overflow"], _SPARSE["stats"] = (p3, ev), (p3, ev, C_local * N)

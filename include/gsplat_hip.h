@@ -758,6 +758,18 @@ int32_t gs_rows16_gather(
 int32_t gs_rows16_scatter(
     uint64_t n_rows, const int32_t *index, int64_t index_stride, const float *wire_rows, float *dst_rows, int32_t *radii,
     float *depths, gs_stream_t stream);
+/* The two sides of that exchange as ONE call each (what distributed._ExchangeRows issues: the gaussian-sharded step is bound
+ * by the host's launch work, every native call less counts):
+ * gs_exchange_rows_send = gs_exchange_compact + gs_rows16_gather(src_index, hdr) into send_rows [world * (cap + 1), 16];
+ *   src_index is kept for the backward, hdr / counters are scratch of the call.
+ * gs_exchange_rows_recv = zero-fill of radii [n_dst] + gs_rows16_scatter(index = column 12 of recv_rows) + gs_exchange_flags. */
+int32_t gs_exchange_rows_send(
+    uint32_t C_total, uint32_t N, uint32_t C_local, uint32_t world, uint32_t cap, uint32_t N_total, uint32_t N_off,
+    const int32_t *radii, const float *rows, int32_t *src_index, int32_t *hdr, uint32_t *counters, uint32_t *stats,
+    float *send_rows, gs_stream_t stream);
+int32_t gs_exchange_rows_recv(
+    uint64_t n_recv, const float *recv_rows, uint64_t n_dst, float *dst_rows, int32_t *radii, float *depths,
+    uint32_t world, const int64_t *hdr_rows, const uint32_t *stats, int32_t *out3, gs_stream_t stream);
 /* After the all-to-all of those chunks: out3 = (some sender overflowed (bit 30 of the count in the header row hdr_rows[d] of
  * every received chunk; recv rows are row_width ints wide), stats[0], stats[1]).  out3 may be pinned HOST memory: the flags
  * then reach the host with the renderer's own tile-count read-back, without a copy command or a sync of their own. */
