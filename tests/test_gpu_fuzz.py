@@ -2,6 +2,7 @@
 the tile, tile sizes 4..16, 1..9 channels, 1..3 cameras, backgrounds / tile masks on and off, dense and sparse scenes,
 saturating opacities (early termination) and depth ties -- configurations the hand-written cases do not enumerate."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -41,6 +42,9 @@ def _scene(rs):
                 colors=colors, bg=bg, masks=masks, tw=tw, th=thh)
 
 
+# GS_FUZZ_SEED_OFFSET=k shifts every scene's seed: extra fuzz sessions beyond the 24 + 16 scenes of the default suite
+_SEED_OFFSET = int(os.environ.get("GS_FUZZ_SEED_OFFSET", "0"))
+
 # every kernel route the tuning knobs can select runs in the suite: the default over 24 scenes, the others over 8 each
 _FUZZ = [("default", s) for s in range(24)] + [(r, s) for r in ROUTES if r != "default" for s in range(8)]
 
@@ -56,7 +60,7 @@ def _compositing_fuzz(seed):
 
     from gscodec_studio_amd import _wrapper as ops
 
-    rs = np.random.RandomState(1000 + seed)
+    rs = np.random.RandomState(1000 + seed + _SEED_OFFSET)
     c = _scene(rs)
     tpg, ids, flat = O.isect_tiles(c["means2d"], c["radii"], c["depths"], c["ts"], c["tw"], c["th"])
     offs = O.isect_offset_encode(ids, c["C"], c["tw"], c["th"])
@@ -102,7 +106,7 @@ def test_pipeline_fuzz_vs_oracle(seed):
 
     from gscodec_studio_amd import rasterization
 
-    rs = np.random.RandomState(7000 + seed)
+    rs = np.random.RandomState(7000 + seed + _SEED_OFFSET)
     C, n = int(rs.randint(1, 4)), int(rs.choice([200, 1500, 5000]))
     W, H = int(rs.randint(33, 320)), int(rs.randint(33, 240))
     cm = str(rs.choice(["pinhole", "pinhole", "ortho", "fisheye"]))
