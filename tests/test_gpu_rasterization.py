@@ -572,3 +572,28 @@ def test_fused_sh_projection_backward_equals_two_launches(split, monkeypatch):
     for x, y, name in zip(a, b, ["means", "quats", "scales", "opacities", "sh0", "shN"]):
         assert rel_l2(N(x), N(y)) < 1e-6, (name, rel_l2(N(x), N(y)))
         assert float(x.abs().max()) > 0
+
+
+@pytest.mark.parametrize("subset", [("means",), ("colors",), ("quats", "opacities"), ("means", "scales", "colors")])
+def test_partial_requires_grad_matches_full(subset):
+    """Only SOME inputs require a gradient (frozen SH, frozen geometry, ...): the prefilled-gradient hand-over, the fused
+    SH + projection backward and their fall-backs must give those inputs the gradients of the all-inputs run (deterministic
+    compositing backward: agreement to 1e-6), and leave the others without one."""
+    from gscodec_studio_amd import rasterization
+
+    d = _inputs(n=4000, cams=2, sh_degree=3, scale_mult=6.0)
+    names = ("means", "quats", "scales", "opacities", "colors")
+    w = torch.linspace(0.5, 1.5, 2 * d["H"] * d["W"] * 3, device="cuda").reshape(2, d["H"], d["W"], 3)
+
+    def run(req):
+        ps = [T(d[k]).requires_grad_(k in req) for k in names]
+        rc, ra, _ = rasterization(*ps, T(d["viewmats"]), T(d["Ks"]), d["W"], d["H"], sh_degree=3, packed=False, deterministic=True)
+        ((rc * w).sum() + 0.3 * ra.sum()).backward()
+        return {k: (p.grad.clone() if p.grad is not None else None) for k, p in zip(names, ps)}
+
+    full, part = run(names), run(subset)
+    for k in names:
+        if k in subset:
+            assert part[k] is not None and rel_l2(N(part[k]), N(full[k])) < 1e-6, (k, rel_l2(N(part[k]), N(full[k])))
+        else:
+            assert part[k] is None, k
