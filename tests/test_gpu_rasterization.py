@@ -597,3 +597,29 @@ def test_partial_requires_grad_matches_full(subset):
             assert part[k] is not None and rel_l2(N(part[k]), N(full[k])) < 1e-6, (k, rel_l2(N(part[k]), N(full[k])))
         else:
             assert part[k] is None, k
+
+
+@pytest.mark.parametrize("sh_degree", [None, 3])
+def test_empty_and_invisible_inputs(sh_degree):
+    """Edge cases of the row pipeline (reference tests/test_basic.py keeps none; its kernels return empty tensors): zero
+    gaussians, and gaussians that no camera sees (everything behind the cameras) -- forward gives the background, every
+    gradient is defined and exactly zero, `meta` keeps its shapes."""
+    from gscodec_studio_amd import rasterization
+
+    d = _inputs(n=500, cams=2, sh_degree=sh_degree)
+    bg = torch.tensor([[0.2, 0.4, 0.6], [0.1, 0.1, 0.9]], device="cuda")
+    for case in ("none_visible", "zero_gaussians"):
+        sel = slice(0, 0) if case == "zero_gaussians" else slice(None)
+        means = d["means"].copy()[sel]
+        if case == "none_visible":
+            means = means + 1000.0  # far outside every frustum
+        ps = [T(means).requires_grad_(True)] + [T(d[k][sel]).requires_grad_(True) for k in ("quats", "scales", "opacities", "colors")]
+        rc, ra, meta = rasterization(*ps, T(d["viewmats"]), T(d["Ks"]), d["W"], d["H"], sh_degree=sh_degree, packed=False, backgrounds=bg)
+        assert rc.shape == (2, d["H"], d["W"], 3) and ra.shape == (2, d["H"], d["W"], 1)
+        assert float(ra.detach().abs().max()) == 0.0
+        assert torch.equal(rc, bg[:, None, None, :].expand_as(rc)), case
+        assert meta["radii"].shape == (2, means.shape[0]) and int(meta["flatten_ids"].numel()) == 0
+        assert int(meta["isect_offsets"].abs().max()) == 0
+        (rc.sum() + ra.sum()).backward()
+        for p in ps:
+            assert p.grad is not None and p.grad.shape == p.shape and (p.numel() == 0 or float(p.grad.abs().max()) == 0.0), case
