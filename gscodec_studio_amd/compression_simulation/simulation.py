@@ -6,7 +6,12 @@ and bit widths, and the ``simulate_compression(splats, step) -> (new_splats, est
 contract.  ``entropy_model_enable=True`` with the factorized prior attaches the fused bits
 estimator (entropy_model.py, reference wiring simulation.py:87-149, 247-316, 576-608); the
 hash-grid Gaussian model needs the reference's CUDA-only ``_gridencoder`` and raises
-NotImplementedError.
+NotImplementedError.  ``ada_mask_opt=True`` attaches the learnable shN mask (ada_mask.py; reference
+simulation.py:38-41, 151-168, 319-324, 611-620) or, with ``ada_mask_strategy="gradient"``, the
+gradient threshold (simulation.py:327-348).  Every attribute the reference's trainers read
+(``shN_ada_mask_opt``, ``shN_ada_mask_step``, ``shN_ada_mask_strategy``, ``shN_qat``, ``shN_ada_mask``,
+``shN_ada_mask_optimizer``, ``entropy_models``, ``entropy_model_optimizers``, ``entropy_model_schedulers``;
+examples/simple_trainer.py:619-632, 906-907, 991-1007, 1046-1050, 1070-1074, 1093-1103, 1150-1162) exists.
 """
 from __future__ import annotations
 
@@ -16,6 +21,8 @@ import torch
 from torch import Tensor
 from typing_extensions import Literal
 
+from .ada_mask import AnnealingMask
+from .ada_mask import shN_gradient_threshold as _shN_gradient_threshold
 from .entropy_model import Entropy_factorized_optimized_refactor
 from .ops import fake_quantize_ste
 
@@ -54,6 +61,25 @@ class _SimulationBase:
             self.entropy_model_optimizers[k] = None if m is None else torch.optim.Adam(
                 [{"params": p, "lr": 1e-4, "name": n} for n, p in m.named_parameters()])
             self.entropy_model_schedulers[k] = None
+
+    def _setup_ada_mask(self, ada_mask_opt: bool, ada_mask_step: int, strategy: Optional[str], kwargs: dict) -> None:
+        """reference simulation.py:38-41, 151-168 (static) / 548-550, 611-620 (dynamic; always "learnable" there)."""
+        self.shN_qat = False  # the K-means QAT branch of the reference is dead code behind this constant (simulation.py:38, 76)
+        self.shN_ada_mask_opt = ada_mask_opt
+        self.shN_ada_mask_step = ada_mask_step
+        self.shN_ada_mask_strategy = strategy
+        if not ada_mask_opt:
+            return
+        if strategy == "learnable":
+            cap_max = kwargs.get("cap_max", 1_000_000)
+            self.shN_ada_mask = AnnealingMask(input_shape=[cap_max, 1, 1], device=self.device, annealing_start_iter=ada_mask_step)
+            self.shN_ada_mask_optimizer = torch.optim.Adam([{"params": self.shN_ada_mask.parameters(), "lr": 0.01}])
+        elif strategy == "gradient":
+            pass
+        elif strategy is None:
+            raise ValueError("'shN_ada_mask_strategy' should not be None")
+        else:
+            raise NotImplementedError(f"'shN_ada_mask_strategy': {strategy} has not been implemented.")
 
     # the activations the trainers apply to the hooked values (reference examples/simple_trainer.py:779-786,
     # simple_trainer_dyngs.py:506-521): opt-in fusion into the quantizer pass, see simulate_compression(activate=True)
@@ -107,6 +133,9 @@ class _SimulationBase:
                 new_splats[name], esti_bits[name] = fn(splats[name], step)[:2]
             else:
                 new_splats[name] = splats[name] + 0.0
+                act = self.ACTIVATIONS.get(name) if self._activate else None
+                if act is not None:  # activate=True promises activated scales / opacities whether or not they are simulated
+                    new_splats[name] = torch.exp(new_splats[name]) if act == "exp" else torch.sigmoid(new_splats[name])
                 esti_bits[name] = None
         return new_splats, esti_bits
 
@@ -120,8 +149,6 @@ class CompressionSimulation(_SimulationBase):
                  entropy_model_type: Literal["factorized_model", "gaussian_model"] = "factorized_model",
                  entropy_steps: Optional[Dict[str, int]] = None, device=None, ada_mask_opt: bool = False,
                  ada_mask_step: int = 10_000, ada_mask_strategy: Optional[str] = "learnable", **kwargs) -> None:
-        if ada_mask_opt:
-            raise NotImplementedError("learnable shN mask (ada_mask_opt) is outside the hot path")
         self.entropy_model_type = entropy_model_type
         self.entropy_steps = entropy_steps
         self.device = device
@@ -136,6 +163,7 @@ class CompressionSimulation(_SimulationBase):
         self.q_bitwidth = {"means": None, "scales": 8, "quats": 8, "opacities": 8, "sh0": 8, "shN": None}
         self.bds = {"means": None, "scales": [-10, 2], "quats": [-1, 1], "opacities": [-15, 15], "sh0": [-2, 4],
                     "shN": None}
+        self._setup_ada_mask(ada_mask_opt, ada_mask_step, ada_mask_strategy, kwargs)
 
     def simulate_compression_scales(self, param, step, *_): return self._quantize("scales", param, step)
     def simulate_compression_quats(self, param, step, *_): return self._quantize("quats", param, step)
@@ -147,7 +175,14 @@ class CompressionSimulation(_SimulationBase):
         return self._quantize("sh0", param, step, lambda v: v.squeeze(1))
 
     def simulate_compression_shN(self, param, step, *_):
-        return param, None  # reference simulation.py:319-324 without the optional mask
+        """reference simulation.py:319-324: past ``ada_mask_step`` the learnable mask multiplies the higher bands."""
+        if self.shN_ada_mask_opt and self.shN_ada_mask_strategy == "learnable" and step > self.shN_ada_mask_step:
+            param = self.shN_ada_mask(param, step)
+        return param, None
+
+    def shN_gradient_threshold(self, param: torch.nn.Parameter, step: int) -> None:
+        """reference simulation.py:327-348 (the "gradient" strategy; edits ``param.grad`` in place)."""
+        _shN_gradient_threshold(param.data, param.grad)
 
 
 class STGCompressionSimulation(_SimulationBase):
@@ -181,6 +216,9 @@ class STGCompressionSimulation(_SimulationBase):
             "means": None, "scales": dict(channel=3), "quats": dict(channel=4), "opacities": None,
             "colors": dict(channel=3, filters=(3, 3)), "features_dir": dict(channel=3, filters=(3, 3)),
             "features_time": dict(channel=3, filters=(3, 3))})
+        # the dynamic trainer constructs the mask and its optimizer (simulation.py:611-620) although its splats carry no shN and
+        # no simulate function consumes it: the attributes exist, as in the reference
+        self._setup_ada_mask(ada_mask_opt, ada_mask_step, "learnable", kwargs)
 
     def simulate_compression_scales(self, param, step, *_): return self._quantize("scales", param, step)
     def simulate_compression_quats(self, param, step, *_): return self._quantize("quats", param, step)

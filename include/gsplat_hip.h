@@ -35,11 +35,11 @@ extern "C" {
 
 /* Bumped whenever an exported signature or the meaning of an argument changes (1: round 1; 2: the round-2 additions to
  * gs_rasterize_fwd, gs_isect_count_keys, gs_sort_pairs_u64_i32_drop, gs_projection_bwd; 3: round 3 -- the splat-row layout,
- * gs_raster_plan, gs_kmeans_decode's bounds).  A binding must refuse a library whose gs_version() differs from the
+ * gs_raster_plan, gs_kmeans_decode's bounds; 4: round 4 -- the shN mask entry points, ...).  A binding must refuse a library whose gs_version() differs from the
  * GS_ABI_VERSION of the header it was generated from, and SHOULD also compare gs_header_hash() (the first 8 bytes of the
  * SHA-256 of the header file the library was compiled against, big-endian) with the hash of its own copy: ctypes / cgo call
  * through shifted argument lists silently otherwise. */
-#define GS_ABI_VERSION 3
+#define GS_ABI_VERSION 4
 
 /* reference: gsplat/cuda/include/bindings.h:34-38 (enum CameraModelType) */
 #define GS_CAMERA_PINHOLE 0
@@ -560,6 +560,45 @@ int32_t gs_quantize_round_fwd(
  * identity and there is nothing to launch) */
 int32_t gs_quantize_round_bwd(
     uint64_t n, const float *v_out, int32_t activation, const float *out, float *v_x, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Q3  learnable per-splat mask on the higher SH bands ("shN adaptive mask") of the compression-simulation hooks
+ * replaces the torch ops of AnnealingMask (gsplat/compression_simulation/ada_mask.py:6-62), applied by
+ * CompressionSimulation.simulate_compression_shN (simulation.py:319-324), and of the "gradient" strategy's
+ * shN_gradient_threshold (simulation.py:327-348).
+ *   x [n, row]: the shN parameter, row = 3 (K - 1) floats per splat (45 at SH degree 3); mask_logits [n].
+ *   training (binary = 0): mask = sigmoid(logit / temperature); eval (binary = 1): mask = sigmoid(logit) >= 0.5 (ada_mask.py:39)
+ *   fwd: out = x * mask.
+ *   bwd: v_x = v_out * mask (NULL: not wanted); v_mask_logits[n] = (sum_j v_out[n,j] x[n,j]) * mask (1 - mask) / temperature
+ *        (NULL: not wanted; must be NULL with binary = 1), every row written, reduced without atomics (deterministic).
+ * IEEE fp32, no contraction, torch's operation order (true division by the temperature, sigmoid = 1 / (1 + exp(-v))).
+ * ---------------------------------------------------------------------- */
+int32_t gs_shn_mask_fwd(
+    uint64_t n, uint32_t row, const float *x, const float *mask_logits, float temperature, int32_t binary,
+    float *out, gs_stream_t stream);
+int32_t gs_shn_mask_bwd(
+    uint64_t n, uint32_t row, const float *x, const float *mask_logits, float temperature, int32_t binary,
+    const float *v_out, float *v_x, float *v_mask_logits, gs_stream_t stream);
+/* the mask itself, one float per splat (binary = 1: get_binary_mask, ada_mask.py:42-44) */
+int32_t gs_mask_values(
+    uint64_t n, const float *mask_logits, float temperature, int32_t binary, float *out, gs_stream_t stream);
+/* out[0] = (sum_i mask_i) / divisor in fp32 -- the mean of the soft mask behind get_sparsity_loss (ada_mask.py:46-58:
+ * divisor = n) or, with binary = 1, get_mask_ratio's count / shape[0] (ada_mask.py:60-62).  temp: gs_mask_sum_temp_bytes()
+ * bytes of scratch; the sum is accumulated in double in a fixed order (deterministic). */
+size_t gs_mask_sum_temp_bytes(void);
+int32_t gs_mask_sum(
+    uint64_t n, const float *mask_logits, float temperature, int32_t binary, float divisor, void *temp, float *out,
+    gs_stream_t stream);
+/* gradient of that mean (binary = 0): v_mask_logits[i] = (v_mean[0] / divisor) * (1 - y) y / temperature, y = sigmoid(logit_i / T) */
+int32_t gs_mask_mean_bwd(
+    uint64_t n, const float *mask_logits, float temperature, const float *v_mean /* device scalar */, float divisor,
+    float *v_mask_logits, gs_stream_t stream);
+/* "gradient" strategy (simulation.py:327-348), two launches, no host read-back: zero_rows[n] <- 1 where every value of x's
+ * row is exactly 0, *n_zero <- their count; threshold = 2e-3 when 1 - n_zero / n < 0.10, else 100; the rows of grad_inplace
+ * whose x row is all zero AND whose Frobenius norm is below the threshold are set to 0. */
+int32_t gs_shn_grad_threshold(
+    uint64_t n, uint32_t row, const float *x, float *grad_inplace, uint8_t *zero_rows /* [n] scratch / output */,
+    uint64_t *n_zero /* device scalar, output */, gs_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Factorized-prior bits estimator (the rate term behind the quantize hooks).
