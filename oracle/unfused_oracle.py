@@ -118,8 +118,9 @@ def rasterize_to_indices_in_range(range_start, range_end, transmittances, means2
 
 def temporal_slice(means, motion, quats, omega, opacities, trbf_center, trbf_scale, timestamp):
     """examples/simple_trainer_dyngs.py:506-521 restated (float64 torch; ``tau`` detached where the trainer detaches
-    ``tforpoly``).  PARITY UNPINNED by executable reference code: the trainer script cannot be imported here
-    (tyro / nerfview / datasets missing); the formula is short and is also checked by finite differences."""
+    ``tforpoly``).  Pinned by tests/golden/make_golden_dynamic.py: the trainer script cannot be imported here
+    (tyro / nerfview / datasets missing), so that script extracts the method's statements with ``ast``, executes them on CPU
+    tensors and asserts this function reproduces outputs and gradients (1e-12 in float64); tests/golden/dynamic.npz."""
     tau = timestamp - trbf_center.reshape(-1)
     trbf = torch.exp(-((tau / (2.0 ** 0.5 * trbf_scale.reshape(-1))) ** 2))
     opacity = opacities * trbf

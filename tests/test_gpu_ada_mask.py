@@ -230,8 +230,10 @@ def test_full_size_properties():
     y = m(x, step)
     assert torch.equal(m(2 * x, step), 2 * y)  # exact: scaling by a power of two commutes with the rounding
     T_ = m.get_temperature(step)
-    ref = x * torch.sigmoid(m.mask_logits.detach() / T_)
-    assert float(((y - ref).abs() / ref.abs().clamp_min(1e-12)).max()) < 2e-6
+    # float64 evaluation of the same expression; the fp32 rounding of logit / T is amplified by |logit / T| (up to ~20 here)
+    mask64 = torch.sigmoid(m.mask_logits.detach().double() / T_)
+    ref = x.double() * mask64
+    assert float(((y.detach().double() - ref).abs() / ref.abs().clamp_min(1e-30)).max()) < 4e-6
     m.eval()
     yb = m(x, step)
     b = m.get_binary_mask()
@@ -246,8 +248,8 @@ def test_full_size_properties():
     want = (v[sel].double() * x[sel].double()).sum((1, 2)) * mk * (1 - mk) / T_
     got = m.mask_logits.grad.reshape(-1)[sel].double()
     assert float((got - want).abs().max()) < 2e-6 * float(want.abs().max()) + 1e-7
-    assert torch.equal(xg.grad, v * torch.sigmoid(m.mask_logits.detach() / T_)) or \
-        float(((xg.grad - v * torch.sigmoid(m.mask_logits.detach() / T_)).abs()).max()) < 1e-6
+    ref = v.double() * mask64
+    assert float(((xg.grad.double() - ref).abs() / ref.abs().clamp_min(1e-30)).max()) < 4e-6
     # gradient threshold: 95 % zero rows -> threshold 2e-3
     p = x.clone()
     zero = torch.rand(n, device=dev(), generator=gen) < 0.95

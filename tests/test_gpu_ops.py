@@ -60,11 +60,21 @@ def test_projection_vs_golden_and_oracle(ops, camera_model, calc_compensations):
     if calc_compensations:
         loss = loss + (comps * T(gd["v_comp"]) * vmask).sum()
     g_m, g_q, g_s, g_v = torch.autograd.grad(loss, (means, quats, scales, viewmats))
-    for name, got, ref in (("v_means", g_m, gd[f"{tag}_v_means"]), ("v_quats", g_q, gd[f"{tag}_v_quats"]),
-                           ("v_scales", g_s, gd[f"{tag}_v_scales"]), ("v_viewmats", g_v, gd[f"{tag}_v_viewmats"])):
-        # fp32 chains with cancellation: compare in relative L2 (1e-3) and elementwise with a scale-aware floor
-        assert rel_l2(N(got), ref) < 2e-3, (name, rel_l2(N(got), ref))
-        assert_close(N(got), ref, 5e-3, 5e-3 * np.abs(ref).max(), name)
+    # Ground truth: the REFERENCE's projection evaluated in float64 on the same inputs / cotangents / visibility
+    # (tests/golden/make_golden_projection_f64.py).  Measured on MI355X (round 4): HIP 6e-8 ... 3.7e-5 relative L2 from it, the
+    # reference's own fp32 run (the golden vectors) 6e-8 ... 1.05e-4 (fisheye v_scales).  Asserted: the north-star 1e-4 against
+    # float64; against the fp32 golden vectors 1e-4 + their own distance from float64; elementwise (small entries are
+    # differences of large terms in both implementations: the reference's fp32 run is off by up to 1.4 % of |entry| + 1e-4
+    # max|entry| there) no worse than 3x the reference's own worst entry.
+    g64 = golden("projection_f64.npz")
+    for name, got in (("v_means", g_m), ("v_quats", g_q), ("v_scales", g_s), ("v_viewmats", g_v)):
+        want, ref32 = g64[f"{tag}_{name}"], gd[f"{tag}_{name}"]
+        e_hip, e_ref = rel_l2(N(got), want), rel_l2(ref32, want)
+        assert e_hip < 1e-4, (name, e_hip)
+        assert rel_l2(N(got), ref32) < 1e-4 + e_ref, (name, rel_l2(N(got), ref32), e_ref)
+        denom = np.abs(want) + 1e-4 * np.abs(want).max()
+        el_hip, el_ref = (np.abs(N(got) - want) / denom).max(), (np.abs(ref32 - want) / denom).max()
+        assert el_hip <= max(3 * el_ref, 1e-4), (name, el_hip, el_ref)
 
 
 def test_projection_covars_path_and_radius_clip(ops):

@@ -96,3 +96,24 @@ def test_temporal_slice_oracle_finite_differences():
     d = tau / (2 ** 0.5 * ins[6].reshape(-1))
     want = torch.tensor(vo) * ins[4] * torch.exp(-d * d) * (-2 * d) * (-1 / (2 ** 0.5 * ins[6].reshape(-1)))
     assert np.allclose(grads[5].reshape(-1), want.numpy(), rtol=1e-9, atol=1e-12)
+
+
+def test_temporal_slice_oracle_vs_reference_statements():
+    """oracle/unfused_oracle.py:temporal_slice against tests/golden/dynamic.npz -- outputs and autograd gradients of the
+    reference trainer's own statements (examples/simple_trainer_dyngs.py:506-536, executed by make_golden_dynamic.py)."""
+    from util import golden
+
+    gd = golden("dynamic.npz")
+    keys = ["means", "motion", "quats", "omega", "opacities", "trbf_center", "trbf_scale"]
+    vs = (gd["v_means_t"], gd["v_quats_t"], gd["v_opacity_t"])
+    for ti, ts in enumerate(gd["timestamps"]):
+        outs, grads = UO.with_grads(lambda *a: UO.temporal_slice(*a, float(ts))[:3], [gd[k] for k in keys], vs)
+        for name, o in zip(("means_t", "quats_t", "opacity_t"), outs):
+            assert np.abs(o - gd[f"f64_t{ti}_{name}"]).max() <= 1e-12 * max(1.0, np.abs(o).max()), name
+            assert np.abs(o - gd[f"f32_t{ti}_{name}"]).max() <= 3e-5 * max(1.0, np.abs(o).max()), name
+        for k, g in zip(keys, grads):
+            want = gd[f"f64_t{ti}_v_{k}"]
+            assert np.abs(g.reshape(want.shape) - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), k
+    tr = UO.temporal_slice(*[torch.tensor(gd[k], dtype=torch.float64) for k in keys], 0.3125)[3].numpy()
+    sure = np.abs(tr - 0.05) > 1e-6
+    assert np.array_equal((tr > 0.05)[sure], gd["vis_mask"][sure]) and int(gd["vis_count"]) == int(gd["vis_mask"].sum())
