@@ -1577,7 +1577,10 @@ class _RasterizeToPixels(torch.autograd.Function):
         if packed:
             P, ctx.grad_rows = ctx.grad_rows, None
             if P is None:
-                P = (torch.empty if det is not None else torch.zeros)(opacities.shape + (16,), dtype=torch.float32, device=means2d.device)
+                # (the deterministic route's finalize kernel WRITES every row -- except when there is nothing to composite:
+                # gs_rasterize_bwd returns before it with n_isects == 0, and the rows must then be zeros, not stale memory)
+                P = (torch.empty if (det is not None and n_isects > 0) else torch.zeros)(
+                    opacities.shape + (16,), dtype=torch.float32, device=means2d.device)
             v_means2d, v_conics, v_opacities = P[..., 0:2], P[..., 2:5], P[..., 5]
             v_colors = P[..., 6:6 + channels]
             v_means2d_abs = P[..., 10:12] if ctx.absgrad else None

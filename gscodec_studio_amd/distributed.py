@@ -767,6 +767,9 @@ def plan_sparse_grad_exchange(radii: Tensor, world_size: Optional[int] = None) -
     if native:
         from . import _backend as B
 
+        # gs_dp_plan's two-launch scan covers 65536 tiles (134 M padded splats); beyond that the torch formulation below
+        native = int(B.query("gs_dp_plan_tiles", n_pad)) <= 65536
+    if native:
         r2 = radii.reshape(-1, N).contiguous()
         vis = torch.empty(n_pad, dtype=torch.uint8, device=dev)
         st = torch.cuda.current_stream(dev).cuda_stream
@@ -946,22 +949,34 @@ def all_reduce_splat_grads(
         algorithm = os.environ.get("GS_DP_ALGO", "direct" if "nccl" in _backend_name() else "all_reduce")
     if algorithm == "direct":
         scale = 1.0 / world_size
-        span = _one_span(plist, world_size)
-        if span is not None and "nccl" not in _backend_name():  # (gloo: no reduce_scatter_tensor; the tests' route)
-            _all_reduce_sum(span)
-            if average:
-                span.mul_(scale)
-            return
-        if span is not None:
-            # every gradient is a piece of ONE buffer (what rasterization() hands out, _wrapper.GradPrefill): one
-            # reduce-scatter + one all-gather over the whole span instead of a pair (or an all-reduce) per tensor -- fewer,
-            # larger collectives; the alignment padding between and behind the pieces is summed along and never read
-            shard = span.new_empty(span.numel() // world_size)
-            _wire(2.0 * span.numel() * span.element_size() * (world_size - 1) / world_size)
-            dist.reduce_scatter_tensor(shard, span, op=dist.ReduceOp.SUM)
-            if average:
-                shard.mul_(scale)
-            dist.all_gather_into_tensor(span, shard)
+        # WHICH collectives are issued depends on rank-invariant facts only (the parameters' sizes, the world size, the
+        # backend): a rank whose gradients do not lie in one buffer (its forward did not carve them: no camera of its own,
+        # a repeated backward, a user-made .grad) stages them through a scratch span of the same canonical length and joins
+        # the same reduce-scatter + all-gather as its peers.
+        numels = [p.numel() for p in plist]
+        used = sum(numels)
+        if used * 4 >= _DIRECT_RS_AG_MIN_BYTES and all(p.dtype == torch.float32 for p in plist):
+            length = _span_length(numels, world_size)
+            span = _one_span(plist, length)
+            staged = span is None
+            if staged:
+                span = _stage_span(plist, length)
+            if "nccl" not in _backend_name():  # (gloo: no reduce_scatter_tensor; the tests' route)
+                _all_reduce_sum(span)
+                if average:
+                    span.mul_(scale)
+            else:
+                # every gradient is a piece of ONE buffer (what rasterization() hands out, _wrapper.GradPrefill): one
+                # reduce-scatter + one all-gather over the whole span instead of a pair (or an all-reduce) per tensor --
+                # fewer, larger collectives; the alignment padding between and behind the pieces is summed along and never read
+                shard = span.new_empty(length // world_size)
+                _wire(2.0 * length * span.element_size() * (world_size - 1) / world_size)
+                dist.reduce_scatter_tensor(shard, span, op=dist.ReduceOp.SUM)
+                if average:
+                    shard.mul_(scale)
+                dist.all_gather_into_tensor(span, shard)
+            if staged:
+                _unstage_span(plist, span)
             return
         for p in plist:
             if p.grad is None:
@@ -970,18 +985,9 @@ def all_reduce_splat_grads(
                 p.grad = p.grad.to_dense()
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
             flat = g.view(-1)
-            n = flat.numel()
-            if n % world_size == 0 and n * flat.element_size() >= _DIRECT_RS_AG_MIN_BYTES and "nccl" in _backend_name():
-                shard = flat.new_empty(n // world_size)
-                _wire(2.0 * n * flat.element_size() * (world_size - 1) / world_size)
-                dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
-                if average:
-                    shard.mul_(scale)
-                dist.all_gather_into_tensor(flat, shard)
-            else:
-                _all_reduce_sum(flat)
-                if average:
-                    flat.mul_(scale)
+            _all_reduce_sum(flat)
+            if average:
+                flat.mul_(scale)
             if g is not p.grad:
                 p.grad = g
         return
@@ -1011,9 +1017,18 @@ def all_reduce_splat_grads(
             p.grad.copy_(g)
 
 
-def _one_span(plist: List[Tensor], world_size: int) -> Optional[Tensor]:
-    """The flat fp32 tensor covering every ``p.grad`` when they are all dense, contiguous pieces of ONE storage lying close
-    together (at most 10 % padding), its length rounded up to a multiple of the world size; None otherwise."""
+def _span_length(numels: List[int], world_size: int) -> int:
+    """Length (floats) of the canonical gradient span: every piece padded to 256 bytes (the carving rule of
+    _wrapper.GradPrefill), the total rounded up to a multiple of the world size.  Rank-invariant."""
+    n = sum((k + 63) // 64 * 64 for k in numels)
+    return n + (-n) % world_size
+
+
+def _one_span(plist: List[Tensor], length: int) -> Optional[Tensor]:
+    """The flat fp32 tensor of ``length`` floats covering every ``p.grad`` IN PLACE, when they are all dense contiguous
+    pieces of ONE storage and the gaps between them are nothing but the 256-byte alignment padding of GradPrefill's
+    carving (``hi - lo == sum of the padded sizes``: no foreign data -- e.g. the gradient of a parameter that is not in
+    ``plist`` -- can sit inside the span, so reducing the span touches only what was asked for); None otherwise."""
     grads = [p.grad for p in plist]
     if any(g is None or g.is_sparse or g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda for g in grads):
         return None
@@ -1021,16 +1036,43 @@ def _one_span(plist: List[Tensor], world_size: int) -> Optional[Tensor]:
     if any(g.untyped_storage().data_ptr() != st.data_ptr() for g in grads[1:]):
         return None
     lo = min(g.storage_offset() for g in grads)
-    hi = max(g.storage_offset() + g.numel() for g in grads)
-    used = sum(g.numel() for g in grads)
-    if used * 4 < _DIRECT_RS_AG_MIN_BYTES or (hi - lo) > 1.1 * used + 1024:
+    if lo % 64 or any((g.storage_offset() - lo) % 64 for g in grads):
         return None
-    # (rounded up into the slack rasterization() leaves behind the last piece -- never downwards: the compositing gradient
-    # rows, which meta["means2d"].grad / .absgrad may still view, lie in front of the first piece)
-    hi += (-(hi - lo)) % world_size
-    if hi > st.nbytes() // 4:
+    ends = sorted((g.storage_offset(), g.storage_offset() + g.numel()) for g in grads)
+    pos = lo
+    for a, b in ends:  # back to back at 64-float granularity: every piece starts where the previous one's padding ends
+        if a != pos:
+            return None
+        pos = a + (b - a + 63) // 64 * 64
+    # (the world-size rounding reaches into the slack rasterization() leaves behind the last piece -- never downwards: the
+    # compositing gradient rows, which meta["means2d"].grad / .absgrad may still view, lie in front of the first piece)
+    if lo + length > st.nbytes() // 4:
         return None
-    return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, lo, (hi - lo,), (1,))
+    return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, lo, (length,), (1,))
+
+
+def _stage_span(plist: List[Tensor], length: int) -> Tensor:
+    """Scratch span of the canonical layout holding a copy of every ``p.grad`` (zeros where a parameter has none)."""
+    dev = next((p.grad.device for p in plist if p.grad is not None), plist[0].device)
+    span = torch.zeros(length, dtype=torch.float32, device=dev)
+    off = 0
+    for p in plist:
+        if p.grad is not None:
+            g = p.grad.to_dense() if p.grad.is_sparse else p.grad
+            span[off:off + p.numel()].view(p.shape).copy_(g)
+        off += (p.numel() + 63) // 64 * 64
+    return span
+
+
+def _unstage_span(plist: List[Tensor], span: Tensor) -> None:
+    off = 0
+    for p in plist:
+        piece = span[off:off + p.numel()].view(p.shape)
+        if p.grad is None or p.grad.is_sparse or p.grad.dtype != torch.float32:
+            p.grad = piece
+        else:
+            p.grad.copy_(piece)
+        off += (p.numel() + 63) // 64 * 64
 
 
 # below this an in-place all_reduce (latency-bound anyway); GS_DP_RS_AG_MIN_BYTES overrides (tests)

@@ -154,6 +154,47 @@ def test_splat_grad_reduction_world2():
     _run("_grad_reduce")
 
 
+def _grad_reduce_span(rank, world):
+    """The one-span route of algorithm="direct" (forced at toy size): the collective's length depends on the parameters'
+    sizes only, so a rank whose gradients are missing / sparse / separately allocated joins the same collective as a rank
+    whose gradients lie in one buffer; a SUBSET of the parameters leaves the others' gradients alone."""
+    os.environ["GS_DP_RS_AG_MIN_BYTES"] = "64"
+    from gscodec_studio_amd import distributed as D
+
+    assert D._DIRECT_RS_AG_MIN_BYTES == 64
+    assert D._span_length([7 * 3, 100, 64, 1], 2) == 64 + 128 + 64 + 64 and D._span_length([5], 3) == 66
+    torch.manual_seed(0)
+    shapes = {"means": (7, 3), "sh": (50, 2), "quats": (16, 4), "opac": (1,)}
+    params = {k: torch.nn.Parameter(torch.randn(*s)) for k, s in shapes.items()}
+    if rank == 0:  # one buffer, carved like _wrapper.GradPrefill (256-byte aligned pieces)
+        buf = torch.zeros(D._span_length([p.numel() for p in params.values()], world) + 64)
+        off = 0
+        for p in params.values():
+            p.grad = buf[off:off + p.numel()].view(p.shape)
+            p.grad.fill_(1.0)
+            off += (p.numel() + 63) // 64 * 64
+    else:  # separate tensors, one missing
+        for k, p in params.items():
+            p.grad = None if k == "quats" else torch.full_like(p, 2.0)
+    D.all_reduce_splat_grads(params, average=False, algorithm="direct")
+    for k, p in params.items():
+        want = 1.0 if (k == "quats") else 3.0
+        assert torch.equal(p.grad, torch.full(shapes[k], want)), (k, p.grad.flatten()[:4])
+    # a subset, averaged; then the rest, summed: the rest must not have been touched by the first call
+    for p in params.values():
+        p.grad.fill_(float(rank + 1))
+    D.all_reduce_splat_grads([params["means"], params["quats"]], average=True, algorithm="direct")
+    assert torch.equal(params["means"].grad, torch.full(shapes["means"], 1.5))
+    assert torch.equal(params["sh"].grad, torch.full(shapes["sh"], float(rank + 1)))
+    D.all_reduce_splat_grads([params["sh"], params["opac"]], average=False, algorithm="direct")
+    assert torch.equal(params["sh"].grad, torch.full(shapes["sh"], 3.0)) and torch.equal(params["opac"].grad, torch.full((1,), 3.0))
+    assert torch.equal(params["quats"].grad, torch.full(shapes["quats"], 1.5))
+
+
+def test_splat_grad_reduction_one_span_world2():
+    _run("_grad_reduce_span")
+
+
 # --------------------------------------------------------------------------- sparse gradient reduction (camera-sharded)
 def _sparse_grad_reduce(rank, world):
     """plan_sparse_grad_exchange + all_reduce_splat_grads(plan=...) equals the dense sum: ragged N (not a multiple of the

@@ -164,6 +164,64 @@ def _gaussian_sharded(rank, world, port, backend, packed, sparse=True, cpr=1, em
         dist.destroy_process_group()
 
 
+def _span_reduce(rank, world, port, backend):
+    """all_reduce_splat_grads(algorithm="direct") on device tensors: rank 0's gradients are pieces of ONE buffer (reduced in
+    place), rank 1's are separate tensors / missing (staged through a scratch span of the same length): same collective on
+    both, the right sums on both; reducing a SUBSET of the pieces must not touch the gradients lying between them in the
+    buffer (round-3 advisor finding: a later reduce of those would have returned world-times-too-large values)."""
+    os.environ["GS_DP_RS_AG_MIN_BYTES"] = "1024"
+    dev = _setup(rank, world, port, backend)
+    try:
+        from gscodec_studio_amd import distributed as D
+
+        shapes = {"means": (1000, 3), "quats": (1000, 4), "scales": (1000, 3), "opacities": (1000,), "sh": (1000, 16, 3)}
+        params = {k: torch.nn.Parameter(torch.randn(*s, device=dev)) for k, s in shapes.items()}
+        length = D._span_length([p.numel() for p in params.values()], world)
+
+        def carve(value):
+            buf = torch.zeros(length + 4096, device=dev)
+            off = 1024  # (something else -- the compositing gradient rows -- lies in front)
+            buf[:off] = -7.0
+            for p in params.values():
+                p.grad = buf[off:off + p.numel()].view(p.shape)
+                p.grad.fill_(value)
+                off += (p.numel() + 63) // 64 * 64
+            return buf
+
+        if rank == 0:
+            buf = carve(1.0)
+            assert D._one_span(list(params.values()), length) is not None
+            assert D._one_span([params["means"], params["scales"], params["sh"]], D._span_length([3000, 3000, 48000], world)) is None
+        else:
+            for k, p in params.items():
+                p.grad = None if k == "quats" else torch.full_like(p, 2.0)
+        D.all_reduce_splat_grads(params, average=False)
+        for k, p in params.items():
+            want = 1.0 if k == "quats" and world > 1 else float(sum(range(1, world + 1)))
+            if world == 1:
+                want = 1.0
+            assert torch.equal(p.grad, torch.full(shapes[k], want, device=dev)), (k, p.grad.flatten()[:3])
+        if rank == 0:
+            assert bool((buf[:1024] == -7.0).all())
+        # subset, averaged -- then the pieces in between, summed
+        if rank == 0:
+            buf = carve(1.0)
+        else:
+            for p in params.values():
+                p.grad = torch.full_like(p, 2.0)
+        D.all_reduce_splat_grads([params["means"], params["scales"], params["sh"]], average=True)
+        mine = 1.0 if rank == 0 else 2.0
+        avg = sum(range(1, world + 1)) / world
+        assert torch.equal(params["quats"].grad, torch.full(shapes["quats"], mine, device=dev))
+        assert torch.equal(params["opacities"].grad, torch.full(shapes["opacities"], mine, device=dev))
+        assert torch.allclose(params["sh"].grad, torch.full(shapes["sh"], avg, device=dev))
+        D.all_reduce_splat_grads([params["quats"], params["opacities"]], average=False)
+        assert torch.equal(params["quats"].grad, torch.full(shapes["quats"], float(sum(range(1, world + 1))), device=dev))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
 def _spawn(fn, args, nprocs, deadline_s=150):
     """mp.spawn with a deadline: a rank stuck in a collective (its peer died) must not hang the suite."""
     import time
@@ -180,6 +238,14 @@ def _spawn(fn, args, nprocs, deadline_s=150):
 
 def _backend_for(world):
     return "nccl" if torch.cuda.device_count() >= world else "gloo"
+
+
+def test_span_gradient_reduction_world2():
+    _spawn(_span_reduce, (2, _free_port(), _backend_for(2)), 2)
+
+
+def test_span_gradient_reduction_rccl_world1():
+    _spawn(_span_reduce, (1, _free_port(), "nccl"), 1)
 
 
 def test_camera_sharded_world2():
