@@ -1196,6 +1196,11 @@ _PINNED_FREE: dict = {}
 _PINNED_DIRECT_MAX = 2048  # block sums a kernel may store straight into pinned host memory (4-byte PCIe writes)
 
 
+# the depth pre-sort's route: "on" = the bucketed form where it applies (GS_PRESORT=0: always the LSD radix sort);
+# "lds_capacity": keys a local sort may hold in LDS (0 = the library's 4096; tests lower it to drive the global-memory route)
+_PRESORT = {"on": os.environ.get("GS_PRESORT", "1") != "0", "lds_capacity": 0}
+
+
 def _pinned_take(n: int) -> Tensor:
     free = _PINNED_FREE.get(n)
     return free.pop() if free else torch.empty(n, dtype=torch.int32, pin_memory=True)
@@ -1248,26 +1253,38 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                 direct = n_sums <= _PINNED_DIRECT_MAX
                 pinned = _pinned_take(n_sums) if direct else torch.empty(1, dtype=torch.int64, pin_memory=True)
                 bsums = pinned if direct else torch.empty(n_sums, dtype=torch.int32, device=dev)
-                # (the count kernel also counts the digits of the pre-sort's first pass into the sort's temp buffer)
-                tb = B.query("gs_sort_temp_bytes", n_elems)
+                # the depth pre-sort: up to 2 M elements the BUCKETED form (sampled splitters -> one partition pass -> local
+                # sorts in LDS: 4 launches), above that the plain LSD radix sort (4 passes, bandwidth-bound there); the count
+                # kernel counts the digits of the first (only) partition pass into the sort's temp buffer either way
+                bucketed = _PRESORT["on"] and bool(B.query("gs_presort_applicable", n_elems))
+                tb = B.query("gs_presort_temp_bytes" if bucketed else "gs_sort_temp_bytes", n_elems)
                 temp = torch.empty(tb, dtype=torch.uint8, device=dev)
                 hist_ready = int(B.query("gs_sort_first_hist_applicable", n_elems))
+                split = None
+                if bucketed:
+                    split = torch.empty(256, dtype=torch.int64, device=dev)
+                    B.call("gs_presort_split", n_elems, B.ptr(radii), B.ptr(depths), B.ptr(split), st)
                 B.call("gs_isect_count_keys", n_elems, B.ptr(means2d), s_m2, B.ptr(radii), B.ptr(depths), tile_size, tile_width,
                        tile_height, B.ptr(tiles_per_gauss), B.ptr(dkeys), B.ptr(dvals), B.ptr(bsums),
-                       B.ptr(temp) if hist_ready else None, tb if hist_ready else 0, st)
+                       B.ptr(temp) if hist_ready else None, tb if hist_ready else 0, B.ptr(split), st)
                 if not direct:
                     pinned.copy_(bsums.sum(dtype=torch.int64).reshape(1), non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(dev))
                 # culled elements carry the maximal key: the sort drops them in its first pass
-                ko, perm = torch.empty_like(dkeys), torch.empty_like(dvals)
+                perm = torch.empty_like(dvals)
                 n_kept = torch.empty(1, dtype=torch.int32, device=dev)
-                # the sort's last pass also leaves the tile counts per group of 512 emission positions behind (the block sums of
-                # the emission's prefix scan, which gs_isect_emit_presorted then finishes itself: no cumsum launches)
+                # the sort's last launch also leaves the tile counts per group of 2^gshift emission positions behind (the block
+                # sums of the emission's prefix scan, which gs_isect_emit_presorted then finishes itself: no cumsum launches)
                 gshift = int(B.query("gs_isect_emit_group_shift"))
                 gsums = torch.empty((n_elems + (1 << gshift) - 1) >> gshift, dtype=torch.int32, device=dev)
-                B.call("gs_sort_pairs_u64_i32_drop", n_elems, B.ptr(dkeys), B.ptr(dvals), B.ptr(ko), B.ptr(perm), 32, 64,
-                       0x7FFFFFFF, B.ptr(n_kept), B.ptr(temp), tb, hist_ready, B.ptr(tiles_per_gauss), B.ptr(gsums), gshift, st)
+                if bucketed:
+                    B.call("gs_presort_buckets", n_elems, B.ptr(dkeys), B.ptr(dvals), B.ptr(split), B.ptr(perm), B.ptr(n_kept),
+                           B.ptr(temp), tb, B.ptr(tiles_per_gauss), B.ptr(gsums), gshift, _PRESORT["lds_capacity"], st)
+                else:
+                    ko = torch.empty_like(dkeys)
+                    B.call("gs_sort_pairs_u64_i32_drop", n_elems, B.ptr(dkeys), B.ptr(dvals), B.ptr(ko), B.ptr(perm), 32, 64,
+                           0x7FFFFFFF, B.ptr(n_kept), B.ptr(temp), tb, hist_ready, B.ptr(tiles_per_gauss), B.ptr(gsums), gshift, st)
                 gpre = None
                 if gsums.numel() > 8192:  # many groups: one prefix sum over them instead of a quadratic number of loads
                     gpre = torch.empty(gsums.numel(), dtype=torch.int64, device=dev)

@@ -40,6 +40,19 @@ void gs_set_error(const char *fmt, ...);
 
 static inline uint32_t gs_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// Bucketed depth pre-sort (radix_sort.hip, isect.hip): bucket of a 64-bit (depth bits << 32 | element) key = the number of
+// splitters <= key, over a table of 255 ascending splitters padded with UINT64_MAX (slot 255 is never read): 8 LDS reads.
+#define GS_PRESORT_BUCKETS 256
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t gs_bucket_of(const uint64_t *s_split, uint64_t key) {
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t step = GS_PRESORT_BUCKETS / 2; step >= 1; step >>= 1)
+        if (s_split[lo + step - 1] <= key) lo += step;
+    return lo;
+}
+#endif
+
 // radix_sort.hip: slot of the first pass's [256][n_blocks] digit histogram inside a sort's temp buffer (nullptr: not applicable)
 uint32_t *sort_first_hist_slot(uint64_t n, void *temp, size_t temp_bytes, uint32_t *n_blocks);
 

@@ -68,10 +68,12 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_count_keys_kernel(
     uint32_t n_elems, const float *__restrict__ means2d, uint32_t s_m2, const int32_t *__restrict__ radii,
     const float *__restrict__ depths, float tile_size, int32_t tw, int32_t th,
     int32_t *__restrict__ tiles_per_gauss, int64_t *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ block_sums,
-    uint32_t *__restrict__ hist, uint32_t n_blocks) {
+    uint32_t *__restrict__ hist, uint32_t n_blocks, const uint64_t *__restrict__ split) {
     __shared__ int32_t s_sum[GS_BLOCK / GS_WAVE];
     __shared__ uint32_t s_hist[256];
+    __shared__ uint64_t s_split[GS_PRESORT_BUCKETS];
     if (hist != nullptr) s_hist[threadIdx.x] = 0u;
+    if (split != nullptr) s_split[threadIdx.x] = split[threadIdx.x]; // bucketed pre-sort: digit = bucket of the whole key
     __syncthreads();
     int32_t cnt_sum = 0;
 #pragma unroll
@@ -88,10 +90,11 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_count_keys_kernel(
             d = (uint32_t)__float_as_int(depths[i]) & 0x7fffffffu;
         }
         tiles_per_gauss[i] = cnt;
-        keys[i] = (int64_t)(((uint64_t)d << 32) | (uint64_t)i);
+        const uint64_t key = ((uint64_t)d << 32) | (uint64_t)i;
+        keys[i] = (int64_t)key;
         vals[i] = (int32_t)i;
         cnt_sum += cnt;
-        if (hist != nullptr && d != 0x7fffffffu) atomicAdd(&s_hist[d & 0xffu], 1u);
+        if (hist != nullptr && d != 0x7fffffffu) atomicAdd(&s_hist[split != nullptr ? gs_bucket_of(s_split, key) : (d & 0xffu)], 1u);
     }
     if (block_sums != nullptr) { // (block-uniform)
         int32_t v = cnt_sum;
@@ -522,9 +525,10 @@ extern "C" uint32_t gs_isect_count_blocks(uint32_t n_elems) { return gs_div_up(n
 extern "C" int32_t gs_isect_count_keys(
     uint32_t n_elems, const float *means2d, uint32_t means2d_stride, const int32_t *radii, const float *depths, uint32_t tile_size,
     uint32_t tile_width, uint32_t tile_height, int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals, int32_t *block_sums,
-    void *sort_temp, size_t sort_temp_bytes, gs_stream_t stream) {
+    void *sort_temp, size_t sort_temp_bytes, const int64_t *bucket_splitters, gs_stream_t stream) {
     if (n_elems == 0) return 0;
     GS_CHECK_ARG(means2d && radii && depths && tiles_per_gauss && keys && vals, "null pointer");
+    GS_CHECK_ARG(bucket_splitters == nullptr || sort_temp != nullptr, "bucket_splitters come with sort_temp (the histogram's place)");
     GS_CHECK_ARG(tile_size > 0, "tile_size must be > 0");
     GS_CHECK_ARG(means2d_stride >= 2 && means2d_stride % 2 == 0, "means2d_stride must be even and >= 2");
     uint32_t n_blocks = 0;
@@ -536,7 +540,7 @@ extern "C" int32_t gs_isect_count_keys(
     }
     hipLaunchKernelGGL(isect_count_keys_kernel, dim3(gs_isect_count_blocks(n_elems)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
                        n_elems, means2d, means2d_stride, radii, depths, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height,
-                       tiles_per_gauss, keys, vals, block_sums, hist, n_blocks);
+                       tiles_per_gauss, keys, vals, block_sums, hist, n_blocks, (const uint64_t *)bucket_splitters);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -44,6 +44,7 @@ struct DigitSpec {
     uint32_t flip; // xor applied to the digit (sign bit handling when end_bit == 64)
     uint32_t drop; // != 0: keys whose upper 32 bits equal drop_hi are DROPPED by this pass (not counted, not written)
     uint32_t drop_hi;
+    const uint64_t *split; // bucketed pre-sort (BUCKET kernels only): digit = gs_bucket_of(split, key) instead of key bits
 };
 
 GS_DEV bool key_kept(uint64_t key, DigitSpec d) { return !(d.drop != 0u && (uint32_t)(key >> 32) == d.drop_hi); }
@@ -158,7 +159,9 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scan_kernel(
 // STORES of the keys to be acknowledged before the values may be staged.
 GS_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <typename KeyT, int SORT_ROUNDS, bool FINAL_ISECT>
+// BUCKET: the one partition pass of the bucketed depth pre-sort -- the digit of a (64-bit) key is its bucket among 255
+// sampled splitters (table in LDS, 8 reads per lookup) instead of 8 key bits; everything else is the same stable scatter.
+template <typename KeyT, int SORT_ROUNDS, bool FINAL_ISECT, bool BUCKET = false>
 __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
     uint64_t n, const uint32_t *__restrict__ n_dev, const KeyT *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
     KeyT *__restrict__ keys_out, int32_t *__restrict__ vals_out, DigitSpec d,
@@ -179,12 +182,18 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
     __shared__ uint32_t s_scan[SORT_WAVES];
     __shared__ KeyT s_keys[SORT_TILE];            // staging (keys, then values): 32 KB for 4096 64-bit keys
     __shared__ uint32_t s_count;
+    __shared__ uint64_t s_split[BUCKET ? GS_PRESORT_BUCKETS : 1];
     const uint32_t tid = threadIdx.x, lane = tid % GS_WAVE, wave = tid / GS_WAVE;
     if (n_dev != nullptr) n = min(n, (uint64_t)*n_dev);
     if ((uint64_t)blockIdx.x * SORT_TILE >= n) return; // block-uniform
 #pragma unroll
     for (int w = 0; w < SORT_WAVES; ++w) s_cnt[w][tid] = 0;
+    if (BUCKET) s_split[BUCKET ? tid : 0] = d.split[tid];
     __syncthreads();
+    auto digit = [&](KeyT k) -> uint32_t {
+        if constexpr (BUCKET) return gs_bucket_of(s_split, (uint64_t)k);
+        else return digit_of(k, d);
+    };
 
     const uint64_t wave_base = (uint64_t)blockIdx.x * SORT_TILE + (uint64_t)wave * SORT_WAVE_KEYS;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -206,16 +215,18 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
     }
     const uint32_t my_total = totals[tid], my_hist = hist_scan[(size_t)tid * n_blocks + blockIdx.x];
     uint32_t leader[SORT_ROUNDS];
+    uint8_t dgv[BUCKET ? SORT_ROUNDS : 1]; // (a bucket lookup costs 8 LDS reads: kept for the placement below)
 #pragma unroll
     for (int r = 0; r < SORT_ROUNDS; ++r) {
         const uint64_t i = wave_base + (uint64_t)r * GS_WAVE + lane;
         const bool valid = i < n && key_kept(key[r], d);
         kept |= valid ? (1u << r) : 0u;
-        const uint32_t dg = digit_of(key[r], d);
+        const uint32_t dg = digit(key[r]);
+        if (BUCKET) dgv[BUCKET ? r : 0] = (uint8_t)dg;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < RADIX_BITS; ++b) {
-            if (((d.mask >> b) & 1u) == 0u) break; // (uniform) narrower first digit: fewer ballots
+            if (!BUCKET && ((d.mask >> b) & 1u) == 0u) break; // (uniform) narrower first digit: fewer ballots
             const bool bit = (dg >> b) & 1u;
             const unsigned long long m = __ballot(bit);
             peers &= bit ? m : ~m;
@@ -275,7 +286,7 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
     uint32_t lp[SORT_ROUNDS];
 #pragma unroll
     for (int r = 0; r < SORT_ROUNDS; ++r) {
-        uint32_t dg = digit_of(key[r], d);
+        uint32_t dg = BUCKET ? (uint32_t)dgv[BUCKET ? r : 0] : digit_of(key[r], d);
         lp[r] = s_lbase[dg] + s_cnt[wave][dg] + rank[r];
         if ((kept >> r) & 1u) s_keys[lp[r]] = key[r];
     }
@@ -288,7 +299,7 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
         pos[k] = 0;
         if (j < block_count) {
             const KeyT kk = s_keys[j];
-            pos[k] = s_gofs[digit_of(kk, d)] + j;
+            pos[k] = s_gofs[digit(kk)] + j;
             if (FINAL_ISECT) kept_key[FINAL_ISECT ? k : 0] = kk;
             else keys_out[pos[k]] = kk;
         }
@@ -424,6 +435,7 @@ static int32_t sort_impl(uint64_t n, const int64_t *keys_in, const int32_t *vals
         d.flip = (end_bit == 64 && p == passes - 1) ? (1u << (bits - 1)) : 0u;
         d.drop = (drop && p == 0) ? 1u : 0u;
         d.drop_hi = drop_hi;
+        d.split = nullptr;
         return d;
     };
     for (int p = 0; p < passes; ++p) {
@@ -566,6 +578,7 @@ extern "C" int32_t gs_sort_isect_pairs(uint64_t n, uint32_t *keys32, int32_t *va
         shift += bits;
         d.mask = (1u << bits) - 1u;
         d.drop = d.drop_hi = 0u;
+        d.split = nullptr;
         // with all 32 key bits in use the id's bit 63 is set for the upper half of the cameras: the reference sorts int64
         // keys as SIGNED values (cub::DeviceRadixSort over [0, 64)), i.e. those come first
         d.flip = (key_bits == 32 && final) ? (1u << (bits - 1)) : 0u;
@@ -579,3 +592,438 @@ extern "C" int32_t gs_sort_isect_pairs(uint64_t n, uint32_t *keys32, int32_t *va
     GS_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Bucketed depth pre-sort (round 4).  The splat-level depth pre-sort of the binning orders the ~0.3 M visible (depth, element)
+// keys of a 1 M-splat frame.  As four 8-bit LSD passes that is 11 launches, each sitting at its ~5-10 us latency floor
+// (76 us at BASELINE config 2, whatever the number of live keys).  Here it is ONE partition pass plus ONE launch of local sorts:
+//   1. presort_split_kernel (1 workgroup): up to 4096 keys sampled at a regular stride are sorted in LDS and 255 of them, at
+//      equal ranks, become SPLITTERS -- whatever the depth distribution, every bucket then holds ~n_kept / 256 keys (the gap
+//      between splitters is a sum of ~15 sample gaps: more than 2.6x the mean happens about once in 10^6 buckets);
+//   2. gs_isect_count_keys counts the keys of every 1024-element block per BUCKET (digit = number of splitters <= key);
+//      sort_scan_kernel + sort_scatter_kernel<BUCKET> place them: a stable partition, the culled keys dropped;
+//   3. presort_local_kernel: workgroup w finishes the buckets that START inside [1024 w, 1024 (w + 1)) of the partitioned
+//      order -- a contiguous range, on average one bucket -- with a stable LSD sort on the depth bits that differ inside the
+//      range (typically 18: three 6-bit passes), entirely in LDS; it writes the permutation and the emission's group sums.
+//      A range that does not fit LDS (capacity 4096 keys: cannot happen with sampled splitters short of adversarial input) is
+//      sorted by the same workgroup through global memory -- slower, same result.
+// The order produced is exactly that of the stable radix sort: ascending depth bits, ties by element index.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int PS_MAX_ROUNDS = 16;                   // LDS capacity of a local sort: 16 rounds of 256 keys
+constexpr uint32_t PS_CAP = GS_BLOCK * PS_MAX_ROUNDS; // 4096
+constexpr uint32_t PS_CHUNK = 1024;                 // sorted positions per local-sort workgroup
+constexpr uint32_t PS_SAMPLES = 4096;
+constexpr uint32_t PS_PROBE = 8;                    // a sample slot takes the first visible of up to 8 consecutive elements
+
+struct LdsSort {
+    uint2 *a, *b;          // [PS_CAP] each: (depth bits, element)
+    uint32_t (*cnt)[RADIX]; // [SORT_WAVES][RADIX]
+    uint32_t *lbase;       // [RADIX]
+    uint32_t *red;         // [2 * SORT_WAVES + 2] reductions / scan scratch
+};
+
+// exclusive scan of one value per thread over the 256 threads of the workgroup
+GS_DEV uint32_t ps_block_excl_scan(uint32_t t, uint32_t *s_scan, uint32_t *total) {
+    const uint32_t lane = threadIdx.x % GS_WAVE, wave = threadIdx.x / GS_WAVE;
+    uint32_t inc = t;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= (uint32_t)off) inc += o;
+    }
+    __syncthreads();
+    if (lane == GS_WAVE - 1) s_scan[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) {
+        if ((uint32_t)w < wave) wbase += s_scan[w];
+        tot += s_scan[w];
+    }
+    if (total != nullptr) *total = tot;
+    return wbase + inc - t;
+}
+
+// Stable sort of the m <= PS_CAP pairs in L.a by their .x, in LDS; returns the buffer holding the result (L.a or L.b).
+// Only the bits in which the keys differ are sorted (range taken over the m keys), in passes of equal width <= 8 bits.
+// Same ranking as sort_scatter_kernel: wave w owns a contiguous quarter of the keys and walks it in rounds of 64, so
+// (wave, round, lane) order is index order and the ballot-matched rank inside (wave, digit) is stable.
+GS_DEV uint2 *lds_stable_sort(const LdsSort &L, uint32_t m) {
+    const uint32_t tid = threadIdx.x, lane = tid % GS_WAVE, wave = tid / GS_WAVE;
+    const uint32_t rounds = (m + GS_BLOCK - 1) / GS_BLOCK; // <= PS_MAX_ROUNDS (uniform)
+    const uint32_t wave_base = wave * rounds * GS_WAVE;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // key range
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+    for (uint32_t j = tid; j < m; j += GS_BLOCK) {
+        const uint32_t k = L.a[j].x;
+        kmin = min(kmin, k);
+        kmax = max(kmax, k);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor(kmin, off, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor(kmax, off, 64));
+    }
+    __syncthreads();
+    if (lane == 0) {
+        L.red[wave] = kmin;
+        L.red[SORT_WAVES + wave] = kmax;
+    }
+    __syncthreads();
+    kmin = min(min(L.red[0], L.red[1]), min(L.red[2], L.red[3]));
+    kmax = max(max(L.red[4], L.red[5]), max(L.red[6], L.red[7]));
+    const uint32_t span = kmax - kmin;
+    const uint32_t nb = span == 0u ? 0u : 32u - (uint32_t)__builtin_clz(span);
+    const uint32_t passes = (nb + RADIX_BITS - 1) / RADIX_BITS;
+    const uint32_t wbits = passes ? (nb + passes - 1) / passes : 0u;
+    const uint32_t mask = (1u << wbits) - 1u;
+    uint2 *src = L.a, *dst = L.b;
+    for (uint32_t p = 0; p < passes; ++p) {
+        const uint32_t shift = p * wbits;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) L.cnt[w][tid] = 0;
+        __syncthreads();
+        uint2 kv[PS_MAX_ROUNDS];
+        uint32_t rank[PS_MAX_ROUNDS], leader[PS_MAX_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < PS_MAX_ROUNDS; ++r) {
+            if ((uint32_t)r < rounds) { // (uniform; guarded, not `break`: the loop must unroll or the arrays go to scratch)
+            const uint32_t j = wave_base + (uint32_t)r * GS_WAVE + lane;
+            const bool valid = j < m;
+            kv[r] = valid ? src[j] : make_uint2(0u, 0u);
+            const uint32_t dg = ((kv[r].x - kmin) >> shift) & mask;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < RADIX_BITS; ++b) {
+                if ((uint32_t)b < wbits) { // (uniform)
+                    const bool bit = (dg >> b) & 1u;
+                    const unsigned long long mm = __ballot(bit);
+                    peers &= bit ? mm : ~mm;
+                }
+            }
+            const uint32_t before = __popcll(peers & lt_mask);
+            leader[r] = valid ? (uint32_t)__builtin_ctzll(peers) : lane;
+            uint32_t base = 0;
+            if (valid && before == 0) base = atomicAdd(&L.cnt[wave][dg], (uint32_t)__popcll(peers));
+            rank[r] = base + before;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PS_MAX_ROUNDS; ++r) {
+            if ((uint32_t)r < rounds) {
+                const uint32_t lead_rank = __shfl(rank[r], (int)leader[r], 64);
+                if (leader[r] != lane) rank[r] += lead_rank;
+            }
+        }
+        __syncthreads();
+        {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES; ++w) {
+                const uint32_t c = L.cnt[w][tid];
+                L.cnt[w][tid] = run;
+                run += c;
+            }
+            L.lbase[tid] = ps_block_excl_scan(run, L.red, nullptr);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PS_MAX_ROUNDS; ++r) {
+            const uint32_t j = wave_base + (uint32_t)r * GS_WAVE + lane;
+            if ((uint32_t)r < rounds && j < m) {
+                const uint32_t dg = ((kv[r].x - kmin) >> shift) & mask;
+                dst[L.lbase[dg] + L.cnt[wave][dg] + rank[r]] = kv[r];
+            }
+        }
+        __syncthreads();
+        uint2 *t = src;
+        src = dst;
+        dst = t;
+    }
+    return src;
+}
+
+// 1. splitters.  radii / depths: the projection's dense outputs; split [256]: 255 ascending keys (depth bits << 32 | element),
+// padded with UINT64_MAX.
+__global__ void __launch_bounds__(GS_BLOCK) presort_split_kernel(uint32_t n_elems, const int32_t *__restrict__ radii,
+                                                                 const float *__restrict__ depths, uint64_t *__restrict__ split) {
+    extern __shared__ __align__(16) unsigned char ps_lds[];
+    LdsSort L;
+    L.a = reinterpret_cast<uint2 *>(ps_lds);
+    L.b = L.a + PS_CAP;
+    L.cnt = reinterpret_cast<uint32_t(*)[RADIX]>(L.b + PS_CAP);
+    L.lbase = reinterpret_cast<uint32_t *>(L.cnt + SORT_WAVES);
+    L.red = L.lbase + RADIX;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t stride = (n_elems + PS_SAMPLES - 1) / PS_SAMPLES; // >= 1
+    // invalid slots get the key 0xffffffff: they sort behind every depth (depth bits are < 2^31)
+    uint32_t n_valid = 0;
+    for (uint32_t sl = tid; sl < PS_SAMPLES; sl += GS_BLOCK) {
+        const uint64_t base = (uint64_t)sl * stride;
+        uint2 smp = make_uint2(0xffffffffu, 0xffffffffu);
+        for (uint32_t q = 0; q < PS_PROBE && q < stride; ++q) {
+            const uint64_t i = base + q;
+            if (i >= n_elems) break;
+            if (radii[i] > 0) {
+                smp = make_uint2((uint32_t)__float_as_int(depths[i]) & 0x7fffffffu, (uint32_t)i);
+                ++n_valid;
+                break;
+            }
+        }
+        L.a[sl] = smp;
+    }
+    __syncthreads();
+    // (slots are in element order, so equal depths keep ascending elements: the stable sort orders the composite keys;
+    //  the 0xffffffff of the invalid slots widens the sorted bit range to 32: four 8-bit passes over 4096 keys)
+    const uint2 *sorted = lds_stable_sort(L, PS_SAMPLES);
+    uint32_t nv;
+    (void)ps_block_excl_scan(n_valid, L.red, &nv);
+    uint64_t out = ~0ull;
+    if (tid < GS_PRESORT_BUCKETS - 1 && nv > 0) {
+        if (nv <= GS_PRESORT_BUCKETS - 1) {
+            if (tid < nv) out = ((uint64_t)sorted[tid].x << 32) | sorted[tid].y;
+        } else {
+            const uint2 v = sorted[(uint32_t)(((uint64_t)(tid + 1) * nv) / GS_PRESORT_BUCKETS)];
+            out = ((uint64_t)v.x << 32) | v.y;
+        }
+    }
+    split[tid] = out;
+}
+
+// segmented wave sums of `inc` over runs of equal `grp` among consecutive lanes, one atomic per run (as in the scatter's side job)
+GS_DEV void ps_side_add(uint32_t *side_sums, bool on, uint32_t grp, uint32_t inc) {
+    const uint32_t lane = threadIdx.x % GS_WAVE;
+    if (!on) { grp = 0xffffffffu; inc = 0u; }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= (uint32_t)off) inc += o;
+    }
+    const uint32_t prevg = __shfl_up(grp, 1, 64);
+    const bool head = lane == 0u || grp != prevg;
+    const unsigned long long hm = __ballot(head);
+    const unsigned long long above = lane == 63u ? 0ull : (hm >> (lane + 1u));
+    const uint32_t last = above ? lane + (uint32_t)__builtin_ctzll(above) : 63u;
+    const uint32_t upto = __shfl(inc, (int)last, 64);
+    const uint32_t before = __shfl_up(inc, 1, 64);
+    if (head && on) atomicAdd(&side_sums[grp], upto - (lane == 0u ? 0u : before));
+}
+
+// 3. local sorts.  keys [*n_kept]: the partitioned keys (bucket order, stable); totals [256]: keys per bucket; alt [n]: scratch
+// for a range that does not fit LDS.  perm [*n_kept] out; side_sums[p >> side_shift] += side_vals[perm[p]].
+__global__ void __launch_bounds__(GS_BLOCK) presort_local_kernel(const uint32_t *__restrict__ n_kept_p, const uint32_t *__restrict__ totals,
+                                                                 uint64_t *__restrict__ keys, uint64_t *__restrict__ alt,
+                                                                 int32_t *__restrict__ perm, const int32_t *__restrict__ side_vals,
+                                                                 uint32_t *__restrict__ side_sums, uint32_t side_shift, uint32_t cap) {
+    extern __shared__ __align__(16) unsigned char ps_lds[];
+    LdsSort L;
+    L.a = reinterpret_cast<uint2 *>(ps_lds);
+    L.b = L.a + PS_CAP;
+    L.cnt = reinterpret_cast<uint32_t(*)[RADIX]>(L.b + PS_CAP);
+    L.lbase = reinterpret_cast<uint32_t *>(L.cnt + SORT_WAVES);
+    L.red = L.lbase + RADIX;
+    uint32_t *s_start = L.red + 16; // [257]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_kept = *n_kept_p;
+    const uint32_t want_lo = blockIdx.x * PS_CHUNK;
+    if (want_lo >= n_kept) return; // (uniform; the grid is sized for the host's upper bound)
+    s_start[tid] = ps_block_excl_scan(totals[tid], L.red, nullptr);
+    if (tid == 0) s_start[GS_PRESORT_BUCKETS] = n_kept;
+    __syncthreads();
+    // my range: the buckets whose start lies in [want_lo, want_lo + PS_CHUNK)
+    auto first_start_at_least = [&](uint32_t x) { // smallest start >= x (starts are non-decreasing, the last one is n_kept)
+        uint32_t lo = 0, hi = GS_PRESORT_BUCKETS; // s_start[hi] = n_kept >= x whenever x <= n_kept
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_start[mid] >= x) hi = mid;
+            else lo = mid + 1;
+        }
+        return s_start[lo];
+    };
+    const uint32_t lo = first_start_at_least(want_lo);
+    const uint32_t hi = want_lo + PS_CHUNK >= n_kept ? n_kept : first_start_at_least(want_lo + PS_CHUNK);
+    const uint32_t m = hi - lo;
+    if (m == 0) return;
+    if (m <= cap) {
+        for (uint32_t j = tid; j < m; j += GS_BLOCK) {
+            const uint64_t k = keys[lo + j];
+            L.a[j] = make_uint2((uint32_t)(k >> 32), (uint32_t)k);
+        }
+        __syncthreads();
+        const uint2 *sorted = lds_stable_sort(L, m);
+        for (uint32_t j0 = 0; j0 < m; j0 += GS_BLOCK) { // (whole waves take part in the segmented sums)
+            const uint32_t j = j0 + tid;
+            const bool on = j < m;
+            const uint32_t e = on ? sorted[j].y : 0u;
+            if (on) perm[lo + j] = (int32_t)e;
+            if (side_sums != nullptr) ps_side_add(side_sums, on, (lo + j) >> side_shift, on ? (uint32_t)side_vals[e] : 0u);
+        }
+        return;
+    }
+    // The range does not fit LDS: the same stable LSD sort, by this workgroup alone, through global memory -- per pass a digit
+    // histogram over the range, then 1024-key tiles in order, each ranked like a scatter block and placed behind its
+    // predecessors.  keys <-> alt ping-pong inside [lo, hi) (nobody else touches that range).
+    uint32_t *s_hist = L.lbase;
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+    for (uint32_t j = tid; j < m; j += GS_BLOCK) {
+        const uint32_t k = (uint32_t)(keys[lo + j] >> 32);
+        kmin = min(kmin, k);
+        kmax = max(kmax, k);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor(kmin, off, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor(kmax, off, 64));
+    }
+    const uint32_t lane = tid % GS_WAVE, wave = tid / GS_WAVE;
+    __syncthreads();
+    if (lane == 0) {
+        L.red[wave] = kmin;
+        L.red[SORT_WAVES + wave] = kmax;
+    }
+    __syncthreads();
+    kmin = min(min(L.red[0], L.red[1]), min(L.red[2], L.red[3]));
+    kmax = max(max(L.red[4], L.red[5]), max(L.red[6], L.red[7]));
+    __syncthreads();
+    const uint32_t span = kmax - kmin;
+    const uint32_t nb = span == 0u ? 0u : 32u - (uint32_t)__builtin_clz(span);
+    const uint32_t passes = (nb + RADIX_BITS - 1) / RADIX_BITS;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint64_t *src = keys, *dst = alt;
+    for (uint32_t p = 0; p < passes; ++p) {
+        const uint32_t shift = p * RADIX_BITS;
+        s_hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t j = tid; j < m; j += GS_BLOCK) atomicAdd(&s_hist[(((uint32_t)(src[lo + j] >> 32) - kmin) >> shift) & 0xffu], 1u);
+        __syncthreads();
+        const uint32_t mine = s_hist[tid];
+        const uint32_t base0 = ps_block_excl_scan(mine, L.red, nullptr);
+        __syncthreads();
+        s_hist[tid] = base0; // running base of digit tid
+        __syncthreads();
+        for (uint32_t t0 = 0; t0 < m; t0 += GS_BLOCK * 4) {
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES; ++w) L.cnt[w][tid] = 0;
+            __syncthreads();
+            uint64_t kk[4];
+            uint32_t rank[4], leader[4], dgs[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t j = t0 + wave * 256u + (uint32_t)r * GS_WAVE + lane;
+                const bool valid = j < m;
+                kk[r] = valid ? src[lo + j] : 0ull;
+                const uint32_t dg = (((uint32_t)(kk[r] >> 32) - kmin) >> shift) & 0xffu;
+                dgs[r] = dg;
+                unsigned long long peers = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < RADIX_BITS; ++b) {
+                    const bool bit = (dg >> b) & 1u;
+                    const unsigned long long mm = __ballot(bit);
+                    peers &= bit ? mm : ~mm;
+                }
+                const uint32_t before = __popcll(peers & lt_mask);
+                leader[r] = valid ? (uint32_t)__builtin_ctzll(peers) : lane;
+                uint32_t base = 0;
+                if (valid && before == 0) base = atomicAdd(&L.cnt[wave][dg], (uint32_t)__popcll(peers));
+                rank[r] = base + before;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t lead_rank = __shfl(rank[r], (int)leader[r], 64);
+                if (leader[r] != lane) rank[r] += lead_rank;
+            }
+            __syncthreads();
+            {
+                uint32_t run = s_hist[tid];
+#pragma unroll
+                for (int w = 0; w < SORT_WAVES; ++w) {
+                    const uint32_t c = L.cnt[w][tid];
+                    L.cnt[w][tid] = run;
+                    run += c;
+                }
+                s_hist[tid] = run;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t j = t0 + wave * 256u + (uint32_t)r * GS_WAVE + lane;
+                if (j < m) dst[lo + L.cnt[wave][dgs[r]] + rank[r]] = kk[r];
+            }
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+        uint64_t *t = src;
+        src = dst;
+        dst = t;
+    }
+    for (uint32_t j0 = 0; j0 < m; j0 += GS_BLOCK) {
+        const uint32_t j = j0 + tid;
+        const bool on = j < m;
+        const uint32_t e = on ? (uint32_t)src[lo + j] : 0u;
+        if (on) perm[lo + j] = (int32_t)e;
+        if (side_sums != nullptr) ps_side_add(side_sums, on, (lo + j) >> side_shift, on ? (uint32_t)side_vals[e] : 0u);
+    }
+}
+
+constexpr size_t PS_LDS_BYTES = 2 * PS_CAP * sizeof(uint2) + SORT_WAVES * RADIX * 4 + RADIX * 4 + 16 * 4 + (GS_PRESORT_BUCKETS + 1) * 4 + 64;
+
+} // namespace
+
+// the bucketed pre-sort serves the sizes the 1024-key sort blocks serve (its partition pass is one of them); above that the
+// passes of the plain radix sort are bandwidth-bound and there is nothing to gain
+extern "C" int32_t gs_presort_applicable(uint64_t n) { return (n > 0 && sort_rounds_for(n) == SORT_ROUNDS_SMALL) ? 1 : 0; }
+extern "C" uint32_t gs_presort_capacity(void) { return PS_CAP; }
+
+extern "C" int32_t gs_presort_split(uint32_t n_elems, const int32_t *radii, const float *depths, int64_t *splitters, gs_stream_t stream) {
+    GS_CHECK_ARG(radii && depths && splitters, "null pointer");
+    GS_CHECK_ARG(n_elems > 0, "n_elems must be > 0");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(presort_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)PS_LDS_BYTES);
+    GS_CHECK_ARG(e == hipSuccess, "cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL(presort_split_kernel, dim3(1), dim3(GS_BLOCK), PS_LDS_BYTES, (hipStream_t)stream, n_elems, radii, depths,
+                       (uint64_t *)splitters);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_presort_buckets(uint64_t n, const int64_t *keys_in, const int32_t *vals_in, const int64_t *splitters,
+                                      int32_t *perm, uint32_t *n_kept, void *temp, size_t temp_bytes, const int32_t *side_vals,
+                                      uint32_t *side_sums, uint32_t side_shift, uint32_t lds_capacity, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(keys_in && vals_in && splitters && perm && n_kept, "null pointer");
+    GS_CHECK_ARG(gs_presort_applicable(n), "gs_presort_applicable(n) is 0: use gs_sort_pairs_u64_i32_drop");
+    GS_CHECK_ARG((side_vals == nullptr) == (side_sums == nullptr) && side_shift < 32, "side_vals and side_sums go together");
+    GS_CHECK_ARG(lds_capacity <= PS_CAP, "lds_capacity exceeds gs_presort_capacity()");
+    const SortLayout L = sort_layout(n);
+    // temp: the radix sort's layout (keys | vals | hist | totals: the histogram is where gs_isect_count_keys put it) + n more keys
+    const size_t alt_off = (L.total + 255) & ~(size_t)255;
+    GS_CHECK_ARG(temp != nullptr && temp_bytes >= alt_off + n * sizeof(uint64_t), "temp too small (gs_presort_temp_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    char *tp = (char *)temp;
+    uint64_t *tkeys = (uint64_t *)(tp + L.off_keys);
+    int32_t *tvals = (int32_t *)(tp + L.off_vals);
+    uint32_t *hist = (uint32_t *)(tp + L.off_hist), *totals = (uint32_t *)(tp + L.off_totals);
+    uint64_t *alt = (uint64_t *)(tp + alt_off);
+    const uint32_t n_side = side_sums != nullptr ? (uint32_t)((n + (1ull << side_shift) - 1) >> side_shift) : 0u;
+    DigitSpec d;
+    d.shift = 32; d.mask = 0xffu; d.flip = 0u; d.drop = 1u; d.drop_hi = 0x7fffffffu;
+    d.split = (const uint64_t *)splitters;
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, hist, totals, side_sums, n_side);
+    hipLaunchKernelGGL((sort_scatter_kernel<uint64_t, SORT_ROUNDS_SMALL, false, true>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n,
+                       (const uint32_t *)nullptr, (const uint64_t *)keys_in, vals_in, tkeys, tvals, d, L.n_blocks, hist, totals, n_kept,
+                       IsectEpilogue{}, ScatterSide{nullptr, nullptr, 0u});
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(presort_local_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)PS_LDS_BYTES);
+    GS_CHECK_ARG(e == hipSuccess, "cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL(presort_local_kernel, dim3(gs_div_up(n, PS_CHUNK)), dim3(GS_BLOCK), PS_LDS_BYTES, st, n_kept, totals, tkeys, alt, perm,
+                       side_vals, side_sums, side_shift, lds_capacity ? lds_capacity : PS_CAP);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t gs_presort_temp_bytes(uint64_t n) { return ((sort_layout(n).total + 255) & ~(size_t)255) + n * sizeof(uint64_t); }

@@ -35,7 +35,7 @@ extern "C" {
 
 /* Bumped whenever an exported signature or the meaning of an argument changes (1: round 1; 2: the round-2 additions to
  * gs_rasterize_fwd, gs_isect_count_keys, gs_sort_pairs_u64_i32_drop, gs_projection_bwd; 3: round 3 -- the splat-row layout,
- * gs_raster_plan, gs_kmeans_decode's bounds; 4: round 4 -- the shN mask entry points, ...).  A binding must refuse a library whose gs_version() differs from the
+ * gs_raster_plan, gs_kmeans_decode's bounds; 4: round 4 -- the shN mask entry points, gs_isect_count_keys' bucket_splitters, the bucketed pre-sort).  A binding must refuse a library whose gs_version() differs from the
  * GS_ABI_VERSION of the header it was generated from, and SHOULD also compare gs_header_hash() (the first 8 bytes of the
  * SHA-256 of the header file the library was compiled against, big-endian) with the hash of its own copy: ctypes / cgo call
  * through shifted argument lists silently otherwise. */
@@ -349,6 +349,8 @@ int32_t gs_isect_count_keys(
     void *sort_temp, size_t sort_temp_bytes /* NULL, 0 -- or the temp buffer the keys will be sorted with
                            (gs_sort_pairs_u64_i32_drop over bits [32, 64)), when gs_sort_first_hist_applicable(n_elems): this
                            kernel then also counts the digits of that sort's first pass (pass first_hist_ready = 1 there) */,
+    const int64_t *bucket_splitters /* NULL, or the table of gs_presort_split (with sort_temp = the temp buffer of
+                           gs_presort_buckets): the histogram is then counted per BUCKET, for the bucketed pre-sort below */,
     gs_stream_t stream);
 uint32_t gs_isect_count_blocks(uint32_t n_elems);
 int32_t gs_cumsum_gather_i32(
@@ -437,6 +439,29 @@ int32_t gs_sort_pairs_u64_i32_drop(
                              gs_isect_emit_presorted needs (side_vals = tiles_per_gauss), with no launch of their own */,
     gs_stream_t stream);
 int32_t gs_sort_first_hist_applicable(uint64_t n);
+
+/* Bucketed depth pre-sort (round 4): the same result as gs_sort_pairs_u64_i32_drop over bits [32, 64) with drop_hi32 =
+ * 0x7fffffff on the keys of gs_isect_count_keys -- perm = the elements in (depth bits, element) order, culled ones dropped --
+ * in 4 launches instead of 11 for the sizes where every radix launch sits at its latency floor (gs_presort_applicable(n):
+ * n <= 2 M elements):
+ *   gs_presort_split     255 splitters at equal ranks among up to 4096 regularly sampled visible keys (one workgroup; an LDS sort)
+ *   gs_isect_count_keys  (bucket_splitters = the table, sort_temp = temp) counts every 1024-element block's keys per bucket
+ *   gs_presort_buckets   scan + ONE stable partition pass by bucket + local sorts: workgroup w finishes the buckets starting in
+ *                        positions [1024 w, 1024 (w + 1)) with an LSD sort in LDS on the depth bits that differ inside its range.
+ * A range above lds_capacity keys (0 = gs_presort_capacity() = 4096; smaller values are for tests) is sorted by its workgroup
+ * through global memory: slower, same result -- with sampled splitters that takes adversarial input.
+ * temp: gs_presort_temp_bytes(n).  side_vals / side_sums / side_shift: as in gs_sort_pairs_u64_i32_drop (side_sums is zeroed
+ * by the call). */
+int32_t gs_presort_applicable(uint64_t n);
+uint32_t gs_presort_capacity(void);
+size_t gs_presort_temp_bytes(uint64_t n);
+int32_t gs_presort_split(
+    uint32_t n_elems, const int32_t *radii, const float *depths, int64_t *splitters /* [256] */, gs_stream_t stream);
+int32_t gs_presort_buckets(
+    uint64_t n, const int64_t *keys_in, const int32_t *vals_in, const int64_t *splitters,
+    int32_t *perm /* [n]; [0, *n_kept) written */, uint32_t *n_kept /* device scalar, written */,
+    void *temp, size_t temp_bytes, const int32_t *side_vals, uint32_t *side_sums, uint32_t side_shift,
+    uint32_t lds_capacity, gs_stream_t stream);
 
 int32_t gs_isect_offset_encode(
     uint32_t n_isects, const int64_t *isect_ids_sorted,

@@ -1,0 +1,91 @@
+"""The bucketed depth pre-sort (gs_presort_split / gs_isect_count_keys(bucket_splitters) / gs_presort_buckets) against the LSD
+radix sort it replaces (gs_sort_pairs_u64_i32_drop, itself pinned bit-exact against the reference-generated isect fixtures) and
+against numpy's stable argsort: the permutation, the kept count and the emission's group sums must be IDENTICAL, for the LDS
+route, the global-memory route of oversized ranges (forced through the lds_capacity knob) and adversarial key distributions."""
+import numpy as np
+import pytest
+import torch
+
+from util import N, T, dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(means2d, radii, depths, on, cap=0):
+    from gscodec_studio_amd import _wrapper as W
+
+    prev = dict(W._PRESORT)
+    W._PRESORT.update(on=on, lds_capacity=cap)
+    try:
+        C, n = radii.shape
+        st = W.isect_tiles_begin(means2d, radii, depths, 16, 120, 68, True, C, n, C * n, None)
+        torch.cuda.synchronize()
+        k = int(st["n_kept"])
+        out = (N(st["perm"])[:k].copy(), k, N(st["gsums"]).copy(), N(st["tiles_per_gauss"]).copy())
+        W.isect_tiles_abandon(st)
+        return out
+    finally:
+        W._PRESORT.update(prev)
+
+
+def _case(n, kind, seed, vis=0.3, C=1):
+    rs = np.random.RandomState(seed)
+    if kind == "uniform":
+        d = rs.uniform(0.2, 9.0, (C, n))
+    elif kind == "clustered":  # most splats on two fronto-parallel planes: thousands of nearly (or exactly) equal depths
+        d = np.where(rs.rand(C, n) < 0.8, 2.5 + 1e-6 * rs.randn(C, n), rs.uniform(0.3, 30.0, (C, n)))
+        d = np.where(rs.rand(C, n) < 0.3, 2.5, d)
+    elif kind == "equal":
+        d = np.full((C, n), 1.75)
+    elif kind == "ascending":
+        d = np.sort(rs.uniform(0.2, 9.0, (C, n)), axis=1)
+    elif kind == "descending":
+        d = -np.sort(-rs.uniform(0.2, 9.0, (C, n)), axis=1)
+    elif kind == "periodic":  # depth correlated with the sampling stride
+        d = 1.0 + (np.arange(C * n).reshape(C, n) % 128) * 0.01
+    else:
+        raise ValueError(kind)
+    d = d.astype(np.float32)
+    radii = np.where(rs.rand(C, n) < vis, rs.randint(1, 40, (C, n)), 0).astype(np.int32)
+    m2 = np.stack([rs.uniform(-50, 1970, (C, n)), rs.uniform(-50, 1130, (C, n))], -1).astype(np.float32)
+    return m2, radii, d
+
+
+@pytest.mark.parametrize("n,kind,vis", [
+    (1, "uniform", 1.0), (63, "uniform", 0.5), (1000, "uniform", 0.0), (5000, "clustered", 0.3), (100_000, "uniform", 0.3),
+    (100_000, "equal", 0.9), (300_000, "clustered", 0.6), (1_006_065, "uniform", 0.29), (1_006_065, "clustered", 1.0),
+    (1_006_065, "ascending", 0.3), (700_001, "descending", 0.3), (1_000_000, "periodic", 0.5), (2_000_000, "uniform", 0.2)])
+def test_bucketed_presort_equals_radix_sort(n, kind, vis):
+    m2, radii, d = _case(n, kind, seed=n % 1000 + len(kind), vis=vis)
+    args = (T(m2), T(radii), T(d))
+    ref_perm, ref_k, ref_g, ref_t = _state(*args, on=False)
+    # ground truth: stable argsort of the depth bits over the visible elements
+    flat_r, flat_d = radii.reshape(-1), d.reshape(-1)
+    idx = np.nonzero(flat_r > 0)[0]
+    want = idx[np.argsort(flat_d[idx].view(np.uint32), kind="stable")]
+    assert ref_k == len(idx) and np.array_equal(ref_perm, want)
+    for cap in (0, 64):  # LDS route / every range through the global-memory route
+        perm, k, g, t = _state(*args, on=True, cap=cap)
+        assert k == ref_k and np.array_equal(perm, want), (kind, cap)
+        assert np.array_equal(t, ref_t) and np.array_equal(g, ref_g), (kind, cap)
+
+
+def test_bucketed_presort_multi_camera_and_full_pipeline():
+    """C = 2 (elements of both cameras interleave in depth order) and the whole isect_tiles against the radix route."""
+    from gscodec_studio_amd import _wrapper as W
+
+    m2, radii, d = _case(200_000, "clustered", seed=5, vis=0.4, C=2)
+    args = (T(m2), T(radii), T(d))
+    a = _state(*args, on=True)
+    b = _state(*args, on=False)
+    assert a[1] == b[1] and np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+    outs = {}
+    for on in (True, False):
+        prev = dict(W._PRESORT)
+        W._PRESORT.update(on=on)
+        try:
+            outs[on] = W.isect_tiles(*args, 16, 120, 68)
+        finally:
+            W._PRESORT.update(prev)
+    for x, y in zip(outs[True], outs[False]):
+        assert torch.equal(x, y)
