@@ -1202,8 +1202,32 @@ _PRESORT = {"on": os.environ.get("GS_PRESORT", "1") != "0", "lds_capacity": 0}
 
 
 def _pinned_take(n: int) -> Tensor:
+    """A pinned int32 buffer the count kernel stores its block sums into, PRE-SET to -1: every sum is >= 0, so the host sees
+    the kernel's progress in the buffer itself (``_SentinelEvent``) and no event has to be recorded behind the kernel -- a
+    recorded event is a barrier packet in the queue, ~6 us of idle GPU between the count kernel and the pre-sort."""
     free = _PINNED_FREE.get(n)
-    return free.pop() if free else torch.empty(n, dtype=torch.int32, pin_memory=True)
+    buf = free.pop() if free else torch.empty(n, dtype=torch.int32, pin_memory=True)
+    buf.fill_(-1)
+    return buf
+
+
+class _SentinelEvent:
+    """``query`` / ``synchronize`` of an event over a pinned buffer whose entries go from -1 to >= 0 as the kernel stores them
+    (posted 4-byte writes of independent workgroups into host-coherent memory: each becomes visible on its own)."""
+
+    __slots__ = ("buf",)
+
+    def __init__(self, buf: Tensor):
+        self.buf = buf
+
+    def query(self) -> bool:
+        return int(self.buf.min()) >= 0
+
+    def synchronize(self) -> None:
+        import time
+
+        while not self.query():
+            time.sleep(0)
 
 
 @torch.no_grad()
@@ -1267,10 +1291,12 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                 B.call("gs_isect_count_keys", n_elems, B.ptr(means2d), s_m2, B.ptr(radii), B.ptr(depths), tile_size, tile_width,
                        tile_height, B.ptr(tiles_per_gauss), B.ptr(dkeys), B.ptr(dvals), B.ptr(bsums),
                        B.ptr(temp) if hist_ready else None, tb if hist_ready else 0, B.ptr(split), st)
-                if not direct:
+                if direct:
+                    ev = _SentinelEvent(pinned)
+                else:
                     pinned.copy_(bsums.sum(dtype=torch.int64).reshape(1), non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(dev))
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
                 # culled elements carry the maximal key: the sort drops them in its first pass
                 perm = torch.empty_like(dvals)
                 n_kept = torch.empty(1, dtype=torch.int32, device=dev)

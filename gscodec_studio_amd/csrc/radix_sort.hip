@@ -603,43 +603,66 @@ extern "C" int32_t gs_sort_isect_pairs(uint64_t n, uint32_t *keys32, int32_t *va
 //      between splitters is a sum of ~15 sample gaps: more than 2.6x the mean happens about once in 10^6 buckets);
 //   2. gs_isect_count_keys counts the keys of every 1024-element block per BUCKET (digit = number of splitters <= key);
 //      sort_scan_kernel + sort_scatter_kernel<BUCKET> place them: a stable partition, the culled keys dropped;
-//   3. presort_local_kernel: workgroup w finishes the buckets that START inside [1024 w, 1024 (w + 1)) of the partitioned
-//      order -- a contiguous range, on average one bucket -- with a stable LSD sort on the depth bits that differ inside the
-//      range (typically 18: three 6-bit passes), entirely in LDS; it writes the permutation and the emission's group sums.
-//      A range that does not fit LDS (capacity 4096 keys: cannot happen with sampled splitters short of adversarial input) is
-//      sorted by the same workgroup through global memory -- slower, same result.
+//   3. presort_local_kernel: workgroup b (256 of them: one per CU) finishes bucket b with a stable LSD sort on the depth bits
+//      that differ inside the bucket (typically 18: three 6-bit passes), entirely in LDS; it writes the permutation and the
+//      emission's group sums.  A bucket that does not fit LDS (capacity 4096 keys against ~1150 expected: thousands of keys
+//      within 2^-16 of the depth range, or adversarial input) is sorted by the same workgroup through global memory --
+//      slower, same result.
 // The order produced is exactly that of the stable radix sort: ascending depth bits, ties by element index.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int PS_MAX_ROUNDS = 16;                   // LDS capacity of a local sort: 16 rounds of 256 keys
-constexpr uint32_t PS_CAP = GS_BLOCK * PS_MAX_ROUNDS; // 4096
-constexpr uint32_t PS_CHUNK = 1024;                 // sorted positions per local-sort workgroup
-constexpr uint32_t PS_SAMPLES = 4096;
-constexpr uint32_t PS_PROBE = 8;                    // a sample slot takes the first visible of up to 8 consecutive elements
+constexpr uint32_t PS_CAP = 4096;                   // LDS capacity of a local sort (keys)
+
+#ifdef PS_PROFILE
+__device__ unsigned long long ps_stamps[64];
+#define PS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == PS_PROFILE_BLOCK) ps_stamps[k] = wall_clock64(); } while (0)
+#else
+#define PS_STAMP(k) do { } while (0)
+#endif
+
+// The two kernels below are latency-bound workgroups (the splitter kernel is a single one): 16 waves each, four per SIMD, so
+// that the serial chains of the ranking (LDS read -> ballots -> returning atomic -> shuffle) of different waves interleave.
+constexpr int PS_WAVES = 16;
+constexpr int PS_THREADS = PS_WAVES * GS_WAVE; // 1024
 
 struct LdsSort {
-    uint2 *a, *b;          // [PS_CAP] each: (depth bits, element)
-    uint32_t (*cnt)[RADIX]; // [SORT_WAVES][RADIX]
-    uint32_t *lbase;       // [RADIX]
-    uint32_t *red;         // [2 * SORT_WAVES + 2] reductions / scan scratch
+    uint2 *a, *b;           // [capacity] each: (depth bits, element)
+    uint16_t *rank;         // [capacity] rank of a key inside its (wave, digit) group
+    uint32_t (*cnt)[RADIX]; // [PS_WAVES][RADIX]
+    uint32_t *lbase;        // [RADIX]
+    uint32_t *red;          // [2 * PS_WAVES + 8] reductions / scan scratch
 };
 
-// exclusive scan of one value per thread over the 256 threads of the workgroup
-GS_DEV uint32_t ps_block_excl_scan(uint32_t t, uint32_t *s_scan, uint32_t *total) {
+GS_DEV LdsSort lds_sort_carve(unsigned char *lds, uint32_t capacity) {
+    LdsSort L;
+    L.a = reinterpret_cast<uint2 *>(lds);
+    L.b = L.a + capacity;
+    L.cnt = reinterpret_cast<uint32_t(*)[RADIX]>(L.b + capacity);
+    L.lbase = reinterpret_cast<uint32_t *>(L.cnt + PS_WAVES);
+    L.red = L.lbase + RADIX;
+    L.rank = reinterpret_cast<uint16_t *>(L.red + 2 * PS_WAVES + 8);
+    return L;
+}
+constexpr size_t lds_sort_bytes(uint32_t capacity) {
+    return (size_t)capacity * (2 * sizeof(uint2) + 2) + PS_WAVES * RADIX * 4 + RADIX * 4 + (2 * PS_WAVES + 8) * 4 + 64;
+}
+
+// exclusive scan of one value per thread over the FIRST 256 threads of the workgroup (the digits); every thread calls it
+GS_DEV uint32_t ps_scan256(uint32_t t, uint32_t *s_scan, uint32_t *total) {
     const uint32_t lane = threadIdx.x % GS_WAVE, wave = threadIdx.x / GS_WAVE;
-    uint32_t inc = t;
+    uint32_t inc = wave < 4u ? t : 0u;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = __shfl_up(inc, off, 64);
         if (lane >= (uint32_t)off) inc += o;
     }
     __syncthreads();
-    if (lane == GS_WAVE - 1) s_scan[wave] = inc;
+    if (lane == GS_WAVE - 1 && wave < 4u) s_scan[wave] = inc;
     __syncthreads();
     uint32_t wbase = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < SORT_WAVES; ++w) {
+    for (int w = 0; w < 4; ++w) {
         if ((uint32_t)w < wave) wbase += s_scan[w];
         tot += s_scan[w];
     }
@@ -647,18 +670,21 @@ GS_DEV uint32_t ps_block_excl_scan(uint32_t t, uint32_t *s_scan, uint32_t *total
     return wbase + inc - t;
 }
 
-// Stable sort of the m <= PS_CAP pairs in L.a by their .x, in LDS; returns the buffer holding the result (L.a or L.b).
+// Stable sort of the m pairs in L.a by their .x, in LDS; returns the buffer holding the result (L.a or L.b).
 // Only the bits in which the keys differ are sorted (range taken over the m keys), in passes of equal width <= 8 bits.
-// Same ranking as sort_scatter_kernel: wave w owns a contiguous quarter of the keys and walks it in rounds of 64, so
-// (wave, round, lane) order is index order and the ballot-matched rank inside (wave, digit) is stable.
-GS_DEV uint2 *lds_stable_sort(const LdsSort &L, uint32_t m) {
+// Same ranking as sort_scatter_kernel: wave w owns a contiguous share of the keys and walks it in rounds of 64, so
+// (wave, round, lane) order is index order and the ballot-matched rank inside (wave, digit) is stable.  The ranks of a pass
+// are parked in LDS (2 bytes per key) instead of registers: the round loops stay rolled and the routine serves any capacity.
+// max_bits < 32: only the TOP max_bits of the differing bits are sorted (keys equal in them keep their order); *low_mask gets
+// the mask of the ignored low bits.
+GS_DEV uint2 *lds_stable_sort(const LdsSort &L, uint32_t m, uint32_t max_bits = 32, uint32_t *low_mask = nullptr) {
     const uint32_t tid = threadIdx.x, lane = tid % GS_WAVE, wave = tid / GS_WAVE;
-    const uint32_t rounds = (m + GS_BLOCK - 1) / GS_BLOCK; // <= PS_MAX_ROUNDS (uniform)
+    const uint32_t rounds = (m + PS_THREADS - 1) / PS_THREADS; // (uniform)
     const uint32_t wave_base = wave * rounds * GS_WAVE;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // key range
     uint32_t kmin = 0xffffffffu, kmax = 0u;
-    for (uint32_t j = tid; j < m; j += GS_BLOCK) {
+    for (uint32_t j = tid; j < m; j += PS_THREADS) {
         const uint32_t k = L.a[j].x;
         kmin = min(kmin, k);
         kmax = max(kmax, k);
@@ -671,31 +697,37 @@ GS_DEV uint2 *lds_stable_sort(const LdsSort &L, uint32_t m) {
     __syncthreads();
     if (lane == 0) {
         L.red[wave] = kmin;
-        L.red[SORT_WAVES + wave] = kmax;
+        L.red[PS_WAVES + wave] = kmax;
     }
     __syncthreads();
-    kmin = min(min(L.red[0], L.red[1]), min(L.red[2], L.red[3]));
-    kmax = max(max(L.red[4], L.red[5]), max(L.red[6], L.red[7]));
-    const uint32_t span = kmax - kmin;
-    const uint32_t nb = span == 0u ? 0u : 32u - (uint32_t)__builtin_clz(span);
+    kmin = 0xffffffffu;
+    kmax = 0u;
+#pragma unroll
+    for (int w = 0; w < PS_WAVES; ++w) {
+        kmin = min(kmin, L.red[w]);
+        kmax = max(kmax, L.red[PS_WAVES + w]);
+    }
+    const uint32_t span = kmax >= kmin ? kmax - kmin : 0u;
+    const uint32_t nb_all = span == 0u ? 0u : 32u - (uint32_t)__builtin_clz(span);
+    const uint32_t drop = nb_all > max_bits ? nb_all - max_bits : 0u;
+    const uint32_t nb = nb_all - drop;
+    if (low_mask != nullptr) *low_mask = (1u << drop) - 1u;
     const uint32_t passes = (nb + RADIX_BITS - 1) / RADIX_BITS;
     const uint32_t wbits = passes ? (nb + passes - 1) / passes : 0u;
     const uint32_t mask = (1u << wbits) - 1u;
     uint2 *src = L.a, *dst = L.b;
+    PS_STAMP(16);
     for (uint32_t p = 0; p < passes; ++p) {
-        const uint32_t shift = p * wbits;
-#pragma unroll
-        for (int w = 0; w < SORT_WAVES; ++w) L.cnt[w][tid] = 0;
+        const uint32_t shift = drop + p * wbits;
+        PS_STAMP(17 + 4 * p);
+        __syncthreads(); // (L.red / the previous pass's counters are still being read)
+        for (uint32_t c = tid; c < PS_WAVES * RADIX; c += PS_THREADS) (&L.cnt[0][0])[c] = 0;
         __syncthreads();
-        uint2 kv[PS_MAX_ROUNDS];
-        uint32_t rank[PS_MAX_ROUNDS], leader[PS_MAX_ROUNDS];
-#pragma unroll
-        for (int r = 0; r < PS_MAX_ROUNDS; ++r) {
-            if ((uint32_t)r < rounds) { // (uniform; guarded, not `break`: the loop must unroll or the arrays go to scratch)
-            const uint32_t j = wave_base + (uint32_t)r * GS_WAVE + lane;
+#pragma unroll 1
+        for (uint32_t r = 0; r < rounds; ++r) {
+            const uint32_t j = wave_base + r * GS_WAVE + lane;
             const bool valid = j < m;
-            kv[r] = valid ? src[j] : make_uint2(0u, 0u);
-            const uint32_t dg = ((kv[r].x - kmin) >> shift) & mask;
+            const uint32_t dg = valid ? ((src[j].x - kmin) >> shift) & mask : 0u;
             unsigned long long peers = __ballot(valid);
 #pragma unroll
             for (int b = 0; b < RADIX_BITS; ++b) {
@@ -706,37 +738,38 @@ GS_DEV uint2 *lds_stable_sort(const LdsSort &L, uint32_t m) {
                 }
             }
             const uint32_t before = __popcll(peers & lt_mask);
-            leader[r] = valid ? (uint32_t)__builtin_ctzll(peers) : lane;
+            const uint32_t leader = valid ? (uint32_t)__builtin_ctzll(peers) : lane;
             uint32_t base = 0;
             if (valid && before == 0) base = atomicAdd(&L.cnt[wave][dg], (uint32_t)__popcll(peers));
-            rank[r] = base + before;
-            }
+            base = __shfl(base, (int)leader, 64);
+            if (valid) L.rank[j] = (uint16_t)(base + before);
         }
-#pragma unroll
-        for (int r = 0; r < PS_MAX_ROUNDS; ++r) {
-            if ((uint32_t)r < rounds) {
-                const uint32_t lead_rank = __shfl(rank[r], (int)leader[r], 64);
-                if (leader[r] != lane) rank[r] += lead_rank;
-            }
-        }
+        PS_STAMP(18 + 4 * p);
         __syncthreads();
         {
             uint32_t run = 0;
+            if (tid < RADIX) { // (all 16 counts requested at once: as a read-modify-write chain this was 1.2 us per pass)
+                uint32_t c[PS_WAVES];
 #pragma unroll
-            for (int w = 0; w < SORT_WAVES; ++w) {
-                const uint32_t c = L.cnt[w][tid];
-                L.cnt[w][tid] = run;
-                run += c;
+                for (int w = 0; w < PS_WAVES; ++w) c[w] = L.cnt[w][tid];
+#pragma unroll
+                for (int w = 0; w < PS_WAVES; ++w) {
+                    L.cnt[w][tid] = run;
+                    run += c[w];
+                }
             }
-            L.lbase[tid] = ps_block_excl_scan(run, L.red, nullptr);
+            const uint32_t lb = ps_scan256(run, L.red, nullptr);
+            if (tid < RADIX) L.lbase[tid] = lb;
         }
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < PS_MAX_ROUNDS; ++r) {
-            const uint32_t j = wave_base + (uint32_t)r * GS_WAVE + lane;
-            if ((uint32_t)r < rounds && j < m) {
-                const uint32_t dg = ((kv[r].x - kmin) >> shift) & mask;
-                dst[L.lbase[dg] + L.cnt[wave][dg] + rank[r]] = kv[r];
+        PS_STAMP(19 + 4 * p);
+#pragma unroll 2
+        for (uint32_t r = 0; r < rounds; ++r) {
+            const uint32_t j = wave_base + r * GS_WAVE + lane;
+            if (j < m) {
+                const uint2 kv = src[j];
+                const uint32_t dg = ((kv.x - kmin) >> shift) & mask;
+                dst[L.lbase[dg] + L.cnt[wave][dg] + (uint32_t)L.rank[j]] = kv;
             }
         }
         __syncthreads();
@@ -747,51 +780,113 @@ GS_DEV uint2 *lds_stable_sort(const LdsSort &L, uint32_t m) {
     return src;
 }
 
-// 1. splitters.  radii / depths: the projection's dense outputs; split [256]: 255 ascending keys (depth bits << 32 | element),
-// padded with UINT64_MAX.
-__global__ void __launch_bounds__(GS_BLOCK) presort_split_kernel(uint32_t n_elems, const int32_t *__restrict__ radii,
-                                                                 const float *__restrict__ depths, uint64_t *__restrict__ split) {
+// 1. splitters.  radii / depths: the projection's dense outputs; split [256]: 255 ascending keys (depth bits << 32), padded with
+// UINT64_MAX.  Candidates: 1024 runs of 16 consecutive elements at regular positions (16 K elements in 2 K cache lines, read by
+// consecutive lanes: one workgroup has to fetch them); the visible ones, thinned evenly to at most PS_SPLIT_CAP, are the
+// samples (every visible element has the same chance: the balance of the buckets does not depend on how visibility is
+// distributed over the array).
+constexpr uint32_t PS_RUN = 16, PS_RUNS = 1024, PS_ROUNDS = PS_RUN * PS_RUNS / PS_THREADS, PS_SPLIT_CAP = 2048;
+
+__global__ void __launch_bounds__(PS_THREADS) presort_split_kernel(uint32_t n_elems, const int32_t *__restrict__ radii,
+                                                                   const float *__restrict__ depths, uint64_t *__restrict__ split) {
     extern __shared__ __align__(16) unsigned char ps_lds[];
-    LdsSort L;
-    L.a = reinterpret_cast<uint2 *>(ps_lds);
-    L.b = L.a + PS_CAP;
-    L.cnt = reinterpret_cast<uint32_t(*)[RADIX]>(L.b + PS_CAP);
-    L.lbase = reinterpret_cast<uint32_t *>(L.cnt + SORT_WAVES);
-    L.red = L.lbase + RADIX;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t stride = (n_elems + PS_SAMPLES - 1) / PS_SAMPLES; // >= 1
-    // invalid slots get the key 0xffffffff: they sort behind every depth (depth bits are < 2^31)
-    uint32_t n_valid = 0;
-    for (uint32_t sl = tid; sl < PS_SAMPLES; sl += GS_BLOCK) {
-        const uint64_t base = (uint64_t)sl * stride;
-        uint2 smp = make_uint2(0xffffffffu, 0xffffffffu);
-        for (uint32_t q = 0; q < PS_PROBE && q < stride; ++q) {
-            const uint64_t i = base + q;
-            if (i >= n_elems) break;
-            if (radii[i] > 0) {
-                smp = make_uint2((uint32_t)__float_as_int(depths[i]) & 0x7fffffffu, (uint32_t)i);
-                ++n_valid;
-                break;
-            }
+    const LdsSort L = lds_sort_carve(ps_lds, PS_SPLIT_CAP);
+    const uint32_t tid = threadIdx.x, lane = tid % GS_WAVE, wave = tid / GS_WAVE;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    PS_STAMP(0);
+    uint32_t vis = 0u;
+    float dd[PS_ROUNDS];
+    uint32_t el[PS_ROUNDS];
+    {
+        int32_t rr[PS_ROUNDS];
+#pragma unroll
+        for (uint32_t r = 0; r < PS_ROUNDS; ++r) { // candidate c = 1024 r + tid: run c / 16, element c % 16 of it
+            const uint32_t c = r * PS_THREADS + tid;
+            const uint32_t i = (uint32_t)(((uint64_t)(c / PS_RUN) * n_elems) / PS_RUNS) + c % PS_RUN;
+            const uint32_t ic = i < n_elems ? i : 0u;
+            el[r] = i;
+            rr[r] = radii[ic];
+            dd[r] = depths[ic]; // (undefined where culled: never used there)
+            if (i >= n_elems) rr[r] = 0;
         }
-        L.a[sl] = smp;
+#pragma unroll
+        for (uint32_t r = 0; r < PS_ROUNDS; ++r)
+            if (rr[r] > 0) vis |= 1u << r;
+    }
+    PS_STAMP(1);
+    // number of visible candidates -> thinning step (every keep-th visible candidate of a thread, phase tid % keep)
+    uint32_t cnt = (uint32_t)__popc(vis);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) L.red[wave] = cnt;
+    __syncthreads();
+    uint32_t nv = 0;
+#pragma unroll
+    for (int w = 0; w < PS_WAVES; ++w) nv += L.red[w];
+    const uint32_t keep = nv ? (nv + (PS_SPLIT_CAP - PS_THREADS) - 1) / (PS_SPLIT_CAP - PS_THREADS) : 1u;
+    uint32_t kept = 0u;
+    {
+        uint32_t phase = tid % keep;
+#pragma unroll
+        for (uint32_t r = 0; r < PS_ROUNDS; ++r)
+            if ((vis >> r) & 1u) {
+                if (phase == 0u) kept |= 1u << r;
+                if (++phase == keep) phase = 0u;
+            }
+    }
+    // slots: waves in order, rounds in order, lanes in order (any order would do; this one needs no atomics)
+    uint32_t wave_kept = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < PS_ROUNDS; ++r) wave_kept += (uint32_t)__popcll(__ballot((kept >> r) & 1u));
+    __syncthreads();
+    if (lane == 0) L.red[wave] = wave_kept;
+    __syncthreads();
+    uint32_t slot = 0, m = 0;
+#pragma unroll
+    for (int w = 0; w < PS_WAVES; ++w) {
+        if ((uint32_t)w < wave) slot += L.red[w];
+        m += L.red[w];
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < PS_ROUNDS; ++r) {
+        const bool k = (kept >> r) & 1u;
+        const unsigned long long bl = __ballot(k);
+        if (k) L.a[slot + (uint32_t)__popcll(bl & lt_mask)] = make_uint2((uint32_t)__float_as_int(dd[r]) & 0x7fffffffu, el[r]);
+        slot += (uint32_t)__popcll(bl);
     }
     __syncthreads();
-    // (slots are in element order, so equal depths keep ascending elements: the stable sort orders the composite keys;
-    //  the 0xffffffff of the invalid slots widens the sorted bit range to 32: four 8-bit passes over 4096 keys)
-    const uint2 *sorted = lds_stable_sort(L, PS_SAMPLES);
-    uint32_t nv;
-    (void)ps_block_excl_scan(n_valid, L.red, &nv);
-    uint64_t out = ~0ull;
-    if (tid < GS_PRESORT_BUCKETS - 1 && nv > 0) {
-        if (nv <= GS_PRESORT_BUCKETS - 1) {
-            if (tid < nv) out = ((uint64_t)sorted[tid].x << 32) | sorted[tid].y;
-        } else {
-            const uint2 v = sorted[(uint32_t)(((uint64_t)(tid + 1) * nv) / GS_PRESORT_BUCKETS)];
-            out = ((uint64_t)v.x << 32) | v.y;
+    PS_STAMP(2);
+    // The samples are sorted on the top 16 of their differing depth bits only (two LDS passes instead of four: this is one
+    // workgroup, every pass is serial latency) and a splitter is its sample's depth with the unsorted low bits cleared and element
+    // 0: the table is ascending whatever the order of the samples inside a 16-bit cell, which is all the bucket function needs
+    // (splitters that coincide just leave buckets empty; it takes thousands of keys within 2^-16 of the depth range to overfill one).
+    uint32_t low_mask = 0u;
+    uint32_t smin = 0xffffffffu; // (the sort's own minimum: recomputed here to truncate relative to it)
+    for (uint32_t j = tid; j < m; j += PS_THREADS) smin = min(smin, L.a[j].x);
+    const uint2 *sorted = lds_stable_sort(L, m, 16, &low_mask);
+    PS_STAMP(3);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) smin = min(smin, (uint32_t)__shfl_xor(smin, off, 64));
+    __syncthreads();
+    if (lane == 0) L.red[wave] = smin;
+    __syncthreads();
+    smin = 0xffffffffu;
+#pragma unroll
+    for (int w = 0; w < PS_WAVES; ++w) smin = min(smin, L.red[w]);
+    if (tid < GS_PRESORT_BUCKETS) {
+        uint64_t out = ~0ull;
+        if (tid < GS_PRESORT_BUCKETS - 1 && m > 0) {
+            uint32_t pick = 0xffffffffu;
+            if (m <= GS_PRESORT_BUCKETS - 1) {
+                if (tid < m) pick = tid;
+            } else {
+                pick = (uint32_t)(((uint64_t)(tid + 1) * m) / GS_PRESORT_BUCKETS);
+            }
+            if (pick != 0xffffffffu) out = (uint64_t)(smin + ((sorted[pick].x - smin) & ~low_mask)) << 32;
         }
+        split[tid] = out;
     }
-    split[tid] = out;
+    PS_STAMP(4);
 }
 
 // segmented wave sums of `inc` over runs of equal `grp` among consecutive lanes, one atomic per run (as in the scatter's side job)
@@ -815,61 +910,54 @@ GS_DEV void ps_side_add(uint32_t *side_sums, bool on, uint32_t grp, uint32_t inc
 
 // 3. local sorts.  keys [*n_kept]: the partitioned keys (bucket order, stable); totals [256]: keys per bucket; alt [n]: scratch
 // for a range that does not fit LDS.  perm [*n_kept] out; side_sums[p >> side_shift] += side_vals[perm[p]].
-__global__ void __launch_bounds__(GS_BLOCK) presort_local_kernel(const uint32_t *__restrict__ n_kept_p, const uint32_t *__restrict__ totals,
-                                                                 uint64_t *__restrict__ keys, uint64_t *__restrict__ alt,
-                                                                 int32_t *__restrict__ perm, const int32_t *__restrict__ side_vals,
-                                                                 uint32_t *__restrict__ side_sums, uint32_t side_shift, uint32_t cap) {
+__global__ void __launch_bounds__(PS_THREADS) presort_local_kernel(const uint32_t *__restrict__ n_kept_p, const uint32_t *__restrict__ totals,
+                                                                   uint64_t *__restrict__ keys, uint64_t *__restrict__ alt,
+                                                                   int32_t *__restrict__ perm, const int32_t *__restrict__ side_vals,
+                                                                   uint32_t *__restrict__ side_sums, uint32_t side_shift, uint32_t cap) {
     extern __shared__ __align__(16) unsigned char ps_lds[];
-    LdsSort L;
-    L.a = reinterpret_cast<uint2 *>(ps_lds);
-    L.b = L.a + PS_CAP;
-    L.cnt = reinterpret_cast<uint32_t(*)[RADIX]>(L.b + PS_CAP);
-    L.lbase = reinterpret_cast<uint32_t *>(L.cnt + SORT_WAVES);
-    L.red = L.lbase + RADIX;
-    uint32_t *s_start = L.red + 16; // [257]
-    const uint32_t tid = threadIdx.x;
-    const uint32_t n_kept = *n_kept_p;
-    const uint32_t want_lo = blockIdx.x * PS_CHUNK;
-    if (want_lo >= n_kept) return; // (uniform; the grid is sized for the host's upper bound)
-    s_start[tid] = ps_block_excl_scan(totals[tid], L.red, nullptr);
-    if (tid == 0) s_start[GS_PRESORT_BUCKETS] = n_kept;
-    __syncthreads();
-    // my range: the buckets whose start lies in [want_lo, want_lo + PS_CHUNK)
-    auto first_start_at_least = [&](uint32_t x) { // smallest start >= x (starts are non-decreasing, the last one is n_kept)
-        uint32_t lo = 0, hi = GS_PRESORT_BUCKETS; // s_start[hi] = n_kept >= x whenever x <= n_kept
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_start[mid] >= x) hi = mid;
-            else lo = mid + 1;
+    const LdsSort L = lds_sort_carve(ps_lds, PS_CAP);
+    uint32_t *s_start = reinterpret_cast<uint32_t *>(ps_lds + lds_sort_bytes(PS_CAP)); // [257]
+    const uint32_t tid = threadIdx.x, lane = tid % GS_WAVE, wave = tid / GS_WAVE;
+    PS_STAMP(8);
+    // workgroup b finishes bucket b: 256 buckets, one workgroup per CU, all of them resident at once
+    {
+        const uint32_t tot = tid < GS_PRESORT_BUCKETS ? totals[tid] : 0u;
+        const uint32_t st = ps_scan256(tot, L.red, nullptr);
+        if (tid < GS_PRESORT_BUCKETS) {
+            s_start[tid] = st;
+            if (tid == GS_PRESORT_BUCKETS - 1) s_start[GS_PRESORT_BUCKETS] = st + tot;
         }
-        return s_start[lo];
-    };
-    const uint32_t lo = first_start_at_least(want_lo);
-    const uint32_t hi = want_lo + PS_CHUNK >= n_kept ? n_kept : first_start_at_least(want_lo + PS_CHUNK);
+    }
+    __syncthreads();
+    const uint32_t lo = s_start[blockIdx.x], hi = s_start[blockIdx.x + 1];
     const uint32_t m = hi - lo;
+    PS_STAMP(9);
     if (m == 0) return;
     if (m <= cap) {
-        for (uint32_t j = tid; j < m; j += GS_BLOCK) {
+        for (uint32_t j = tid; j < m; j += PS_THREADS) {
             const uint64_t k = keys[lo + j];
             L.a[j] = make_uint2((uint32_t)(k >> 32), (uint32_t)k);
         }
         __syncthreads();
+        PS_STAMP(10);
         const uint2 *sorted = lds_stable_sort(L, m);
-        for (uint32_t j0 = 0; j0 < m; j0 += GS_BLOCK) { // (whole waves take part in the segmented sums)
+        PS_STAMP(11);
+        for (uint32_t j0 = 0; j0 < m; j0 += PS_THREADS) { // (whole waves take part in the segmented sums)
             const uint32_t j = j0 + tid;
             const bool on = j < m;
             const uint32_t e = on ? sorted[j].y : 0u;
             if (on) perm[lo + j] = (int32_t)e;
             if (side_sums != nullptr) ps_side_add(side_sums, on, (lo + j) >> side_shift, on ? (uint32_t)side_vals[e] : 0u);
         }
+        PS_STAMP(12);
         return;
     }
     // The range does not fit LDS: the same stable LSD sort, by this workgroup alone, through global memory -- per pass a digit
-    // histogram over the range, then 1024-key tiles in order, each ranked like a scatter block and placed behind its
-    // predecessors.  keys <-> alt ping-pong inside [lo, hi) (nobody else touches that range).
+    // histogram over the range, then 1024-key tiles in order (one key per thread), each ranked like a scatter block and placed
+    // behind its predecessors.  keys <-> alt ping-pong inside [lo, hi) (nobody else touches that range).
     uint32_t *s_hist = L.lbase;
     uint32_t kmin = 0xffffffffu, kmax = 0u;
-    for (uint32_t j = tid; j < m; j += GS_BLOCK) {
+    for (uint32_t j = tid; j < m; j += PS_THREADS) {
         const uint32_t k = (uint32_t)(keys[lo + j] >> 32);
         kmin = min(kmin, k);
         kmax = max(kmax, k);
@@ -879,15 +967,19 @@ __global__ void __launch_bounds__(GS_BLOCK) presort_local_kernel(const uint32_t 
         kmin = min(kmin, (uint32_t)__shfl_xor(kmin, off, 64));
         kmax = max(kmax, (uint32_t)__shfl_xor(kmax, off, 64));
     }
-    const uint32_t lane = tid % GS_WAVE, wave = tid / GS_WAVE;
     __syncthreads();
     if (lane == 0) {
         L.red[wave] = kmin;
-        L.red[SORT_WAVES + wave] = kmax;
+        L.red[PS_WAVES + wave] = kmax;
     }
     __syncthreads();
-    kmin = min(min(L.red[0], L.red[1]), min(L.red[2], L.red[3]));
-    kmax = max(max(L.red[4], L.red[5]), max(L.red[6], L.red[7]));
+    kmin = 0xffffffffu;
+    kmax = 0u;
+#pragma unroll
+    for (int w = 0; w < PS_WAVES; ++w) {
+        kmin = min(kmin, L.red[w]);
+        kmax = max(kmax, L.red[PS_WAVES + w]);
+    }
     __syncthreads();
     const uint32_t span = kmax - kmin;
     const uint32_t nb = span == 0u ? 0u : 32u - (uint32_t)__builtin_clz(span);
@@ -896,63 +988,49 @@ __global__ void __launch_bounds__(GS_BLOCK) presort_local_kernel(const uint32_t 
     uint64_t *src = keys, *dst = alt;
     for (uint32_t p = 0; p < passes; ++p) {
         const uint32_t shift = p * RADIX_BITS;
-        s_hist[tid] = 0;
+        if (tid < RADIX) s_hist[tid] = 0;
         __syncthreads();
-        for (uint32_t j = tid; j < m; j += GS_BLOCK) atomicAdd(&s_hist[(((uint32_t)(src[lo + j] >> 32) - kmin) >> shift) & 0xffu], 1u);
+        for (uint32_t j = tid; j < m; j += PS_THREADS) atomicAdd(&s_hist[(((uint32_t)(src[lo + j] >> 32) - kmin) >> shift) & 0xffu], 1u);
         __syncthreads();
-        const uint32_t mine = s_hist[tid];
-        const uint32_t base0 = ps_block_excl_scan(mine, L.red, nullptr);
+        const uint32_t mine = tid < RADIX ? s_hist[tid] : 0u;
+        const uint32_t base0 = ps_scan256(mine, L.red, nullptr);
         __syncthreads();
-        s_hist[tid] = base0; // running base of digit tid
+        if (tid < RADIX) s_hist[tid] = base0; // running base of digit tid
         __syncthreads();
-        for (uint32_t t0 = 0; t0 < m; t0 += GS_BLOCK * 4) {
-#pragma unroll
-            for (int w = 0; w < SORT_WAVES; ++w) L.cnt[w][tid] = 0;
+        for (uint32_t t0 = 0; t0 < m; t0 += PS_THREADS) {
+            for (uint32_t c = tid; c < PS_WAVES * RADIX; c += PS_THREADS) (&L.cnt[0][0])[c] = 0;
             __syncthreads();
-            uint64_t kk[4];
-            uint32_t rank[4], leader[4], dgs[4];
+            const uint32_t j = t0 + tid; // (wave, lane) order is index order inside the tile
+            const bool valid = j < m;
+            const uint64_t kk = valid ? src[lo + j] : 0ull;
+            const uint32_t dg = (((uint32_t)(kk >> 32) - kmin) >> shift) & 0xffu;
+            unsigned long long peers = __ballot(valid);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t j = t0 + wave * 256u + (uint32_t)r * GS_WAVE + lane;
-                const bool valid = j < m;
-                kk[r] = valid ? src[lo + j] : 0ull;
-                const uint32_t dg = (((uint32_t)(kk[r] >> 32) - kmin) >> shift) & 0xffu;
-                dgs[r] = dg;
-                unsigned long long peers = __ballot(valid);
-#pragma unroll
-                for (int b = 0; b < RADIX_BITS; ++b) {
-                    const bool bit = (dg >> b) & 1u;
-                    const unsigned long long mm = __ballot(bit);
-                    peers &= bit ? mm : ~mm;
-                }
-                const uint32_t before = __popcll(peers & lt_mask);
-                leader[r] = valid ? (uint32_t)__builtin_ctzll(peers) : lane;
-                uint32_t base = 0;
-                if (valid && before == 0) base = atomicAdd(&L.cnt[wave][dg], (uint32_t)__popcll(peers));
-                rank[r] = base + before;
+            for (int b = 0; b < RADIX_BITS; ++b) {
+                const bool bit = (dg >> b) & 1u;
+                const unsigned long long mm = __ballot(bit);
+                peers &= bit ? mm : ~mm;
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t lead_rank = __shfl(rank[r], (int)leader[r], 64);
-                if (leader[r] != lane) rank[r] += lead_rank;
-            }
+            const uint32_t before = __popcll(peers & lt_mask);
+            const uint32_t leader = valid ? (uint32_t)__builtin_ctzll(peers) : lane;
+            uint32_t base = 0;
+            if (valid && before == 0) base = atomicAdd(&L.cnt[wave][dg], (uint32_t)__popcll(peers));
+            const uint32_t rank = __shfl(base, (int)leader, 64) + before;
             __syncthreads();
-            {
+            if (tid < RADIX) {
                 uint32_t run = s_hist[tid];
+                uint32_t c[PS_WAVES];
 #pragma unroll
-                for (int w = 0; w < SORT_WAVES; ++w) {
-                    const uint32_t c = L.cnt[w][tid];
+                for (int w = 0; w < PS_WAVES; ++w) c[w] = L.cnt[w][tid];
+#pragma unroll
+                for (int w = 0; w < PS_WAVES; ++w) {
                     L.cnt[w][tid] = run;
-                    run += c;
+                    run += c[w];
                 }
                 s_hist[tid] = run;
             }
             __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t j = t0 + wave * 256u + (uint32_t)r * GS_WAVE + lane;
-                if (j < m) dst[lo + L.cnt[wave][dgs[r]] + rank[r]] = kk[r];
-            }
+            if (valid) dst[lo + L.cnt[wave][dg] + rank] = kk;
             __syncthreads();
         }
         __threadfence_block();
@@ -961,7 +1039,7 @@ __global__ void __launch_bounds__(GS_BLOCK) presort_local_kernel(const uint32_t 
         src = dst;
         dst = t;
     }
-    for (uint32_t j0 = 0; j0 < m; j0 += GS_BLOCK) {
+    for (uint32_t j0 = 0; j0 < m; j0 += PS_THREADS) {
         const uint32_t j = j0 + tid;
         const bool on = j < m;
         const uint32_t e = on ? (uint32_t)src[lo + j] : 0u;
@@ -970,7 +1048,8 @@ __global__ void __launch_bounds__(GS_BLOCK) presort_local_kernel(const uint32_t 
     }
 }
 
-constexpr size_t PS_LDS_BYTES = 2 * PS_CAP * sizeof(uint2) + SORT_WAVES * RADIX * 4 + RADIX * 4 + 16 * 4 + (GS_PRESORT_BUCKETS + 1) * 4 + 64;
+constexpr size_t PS_LOCAL_LDS = lds_sort_bytes(PS_CAP) + (GS_PRESORT_BUCKETS + 1) * 4 + 60;
+constexpr size_t PS_SPLIT_LDS = lds_sort_bytes(PS_SPLIT_CAP);
 
 } // namespace
 
@@ -983,9 +1062,9 @@ extern "C" int32_t gs_presort_split(uint32_t n_elems, const int32_t *radii, cons
     GS_CHECK_ARG(radii && depths && splitters, "null pointer");
     GS_CHECK_ARG(n_elems > 0, "n_elems must be > 0");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(presort_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)PS_LDS_BYTES);
+                                       (int)PS_SPLIT_LDS);
     GS_CHECK_ARG(e == hipSuccess, "cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL(presort_split_kernel, dim3(1), dim3(GS_BLOCK), PS_LDS_BYTES, (hipStream_t)stream, n_elems, radii, depths,
+    hipLaunchKernelGGL(presort_split_kernel, dim3(1), dim3(PS_THREADS), PS_SPLIT_LDS, (hipStream_t)stream, n_elems, radii, depths,
                        (uint64_t *)splitters);
     GS_CHECK_LAUNCH();
     return 0;
@@ -1018,9 +1097,9 @@ extern "C" int32_t gs_presort_buckets(uint64_t n, const int64_t *keys_in, const 
                        (const uint32_t *)nullptr, (const uint64_t *)keys_in, vals_in, tkeys, tvals, d, L.n_blocks, hist, totals, n_kept,
                        IsectEpilogue{}, ScatterSide{nullptr, nullptr, 0u});
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(presort_local_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)PS_LDS_BYTES);
+                                       (int)PS_LOCAL_LDS);
     GS_CHECK_ARG(e == hipSuccess, "cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL(presort_local_kernel, dim3(gs_div_up(n, PS_CHUNK)), dim3(GS_BLOCK), PS_LDS_BYTES, st, n_kept, totals, tkeys, alt, perm,
+    hipLaunchKernelGGL(presort_local_kernel, dim3(GS_PRESORT_BUCKETS), dim3(PS_THREADS), PS_LOCAL_LDS, st, n_kept, totals, tkeys, alt, perm,
                        side_vals, side_sums, side_shift, lds_capacity ? lds_capacity : PS_CAP);
     GS_CHECK_LAUNCH();
     return 0;
