@@ -53,24 +53,42 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # PMC traffic (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 correction applied)
 # measured for this workload and committed under profiles/; bench.py cannot run rocprof on itself.
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-KERNEL_OF_ENTRY = {"gs_rasterize_bwd": "raster_seg_bwd_kernel", "gs_rasterize_fwd": "raster_tile_fwd_kernel",
-                   "gs_sh_view_bwd": "sh_bwd_kernel", "gs_projection_rows_bwd": "projection_bwd_kernel<false, 3>", "gs_sort_isect_pairs": "sort_scatter_kernel<unsigned int, 16, true>"}
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+# entry point -> (kernel name fragment, the source file the kernel lives in)
+KERNEL_OF_ENTRY = {"gs_rasterize_bwd": ("raster_seg_bwd_kernel", "rasterize.hip"), "gs_rasterize_fwd": ("raster_tile_fwd_kernel", "rasterize.hip"),
+                   "gs_sh_view_bwd": ("sh_bwd_kernel", "sh.hip"), "gs_projection_rows_bwd": ("projection_bwd_kernel<false, 3>", "projection.hip"),
+                   "gs_sort_isect_pairs": ("sort_scatter_kernel<unsigned int, 16, true", "radix_sort.hip")}
+
+
+def _source_hash(name):
+    import hashlib
+
+    with open(os.path.join(ROOT, "gscodec_studio_amd", "csrc", name), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def measured_pmc(entry, workload_key, field="traffic_bytes_per_launch"):
-    """A per-launch PMC figure of the kernel behind `entry` from the committed summary (HBM bytes by default), or None."""
+    """A per-launch PMC figure of the kernel behind `entry` from the committed summary (HBM bytes by default), or None --
+    also None when the kernel's source file has changed since the counters were collected (the JSON carries the hashes of
+    the sources it was taken from: a stale figure is not reported)."""
     try:
         d = json.load(open(TRAFFIC_JSON))
         if d.get("workload_key") != workload_key:
             return None
-        frag = KERNEL_OF_ENTRY.get(entry)
+        frag, src = KERNEL_OF_ENTRY.get(entry, (None, None))
+        if src is not None and d.get("source_hashes", {}).get(src) != _source_hash(src):
+            return None
         for name, v in d["kernels"].items():
             if frag and frag in name:
                 return v.get(field)
     except Exception:
         pass
     return None
+
+
+BINNING_ENTRIES = {"gs_presort_split", "gs_isect_count_keys", "gs_presort_buckets", "gs_sort_pairs_u64_i32_drop", "gs_isect_count",
+                   "gs_cumsum_i32", "gs_isect_finish_presorted", "gs_isect_emit_presorted", "gs_isect_emit", "gs_isect_emit_compact",
+                   "gs_sort_isect_pairs", "gs_sort_pairs_u64_i32", "gs_isect_offset_encode"}
 
 
 def measured_traffic(entry, workload_key):
@@ -163,6 +181,8 @@ def algorithmic_bytes(stats):
         "gs_isect_emit": 24 * V + 12 * I,
         "gs_isect_emit_compact": 24 * V + 12 * I,
         "gs_sort_pairs_u64_i32_drop": 24 * V,   # the splat-level depth pre-sort: one read + one write of the live keys
+        "gs_presort_split": 0,                  # (16 K sampled elements)
+        "gs_presort_buckets": 24 * V,           # the same pre-sort, bucketed: partition pass + local sorts
         "gs_sort_isect_pairs": 24 * I,
         "gs_sort_pairs_u64_i32": 24 * I,
         "gs_isect_offset_encode": 8 * I + 4 * T,
@@ -532,6 +552,14 @@ def main():
                                "formula": "SURVEY 8(d): Fwd 48N+(80+12K)V+84I+4T+20P + Bwd (44+12K)N+(164+12K)V+40I+24P",
                                "algorithmic_bytes_of_called_entry_points": called_alg},
                 "per_entry_point_ms": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+                # the binning chain (count -> depth pre-sort -> emit -> pair sort -> offsets), the stage whose OWN bound is HBM:
+                # SURVEY 8(d)'s bytes of isect (32V + 4N + 12I) + sort (24I) + offsets (8I + 4T) over the sum of its entry
+                # points' event times (pass A above)
+                "binning": (lambda ms_, by_: {"ms": ms_, "algorithmic_bytes": by_, "achieved": by_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else None,
+                                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_ > 0 else None,
+                                               "entry_points": sorted(k for k in per_step if k in BINNING_ENTRIES)})(
+                    sum(v for k, v in per_step.items() if k in BINNING_ENTRIES),
+                    (32 * Vs + 4 * Ns + 12 * Is) + 24 * Is + (8 * Is + 4 * Ts)),
             },
         }
         if not args.no_extras and world == 1:

@@ -15,7 +15,9 @@ Same functions as the reference's ``gsplat/compression_simulation/ops.py`` (39-7
 """
 from __future__ import annotations
 
-from typing import Dict
+import ctypes
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -93,6 +95,92 @@ class STE(torch.autograd.Function):
         with _device_of(out):
             B.call("gs_quantize_round_bwd", out.numel(), B.ptr(g), ctx.act, B.ptr(out), B.ptr(v_x), _stream(out))
         return v_x, None, None, None, None
+
+
+class _QuantDesc(ctypes.Structure):  # gs_quant_desc of include/gsplat_hip.h
+    _fields_ = [("n", ctypes.c_uint64), ("x", ctypes.c_void_p), ("out", ctypes.c_void_p), ("v_out", ctypes.c_void_p),
+                ("v_x", ctypes.c_void_p), ("lo", ctypes.c_float), ("hi", ctypes.c_float), ("q_step", ctypes.c_float),
+                ("activation", ctypes.c_int32), ("philox_offset", ctypes.c_uint64)]
+
+
+QUANT_MULTI_MAX = 8
+_GRID_CAP: Dict[int, int] = {}
+
+
+def _grid_cap(device: torch.device) -> int:
+    """What torch caps the grid of its random kernels at: CUs * (max threads per CU / 256)."""
+    i = device.index if device.index is not None else torch.cuda.current_device()
+    if i not in _GRID_CAP:
+        p = torch.cuda.get_device_properties(i)
+        _GRID_CAP[i] = p.multi_processor_count * (p.max_threads_per_multi_processor // 256)
+    return _GRID_CAP[i]
+
+
+class _NoiseQuantMulti(torch.autograd.Function):
+    """``fake_quantize_ste(x_i, lo_i, hi_i, bits_i, "noise")`` for several tensors in ONE launch each way, the noise generated in
+    the kernel from the device's default generator exactly as the tensors' ``uniform_`` calls would have drawn it, in order
+    (the generator is advanced by the same amounts): bit-identical outputs, same RNG stream afterwards."""
+
+    @staticmethod
+    def forward(ctx, specs: Sequence[Tuple[float, float, float, int]], *xs: Tensor):
+        dev = xs[0].device
+        for x in xs:
+            _require_gpu(x, "fake_quantize_ste")
+            if x.dtype != torch.float32 or x.device != dev:
+                raise RuntimeError("fake_quantize_ste (multi): float32 tensors on one device")
+        xc = [x.contiguous() for x in xs]
+        outs = [torch.empty_like(x) for x in xc]
+        gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+        seed, off = gen.initial_seed(), gen.get_offset()
+        cap = _grid_cap(dev)
+        descs = (_QuantDesc * len(xc))()
+        for d, x, o, (lo, hi, q_step, act) in zip(descs, xc, outs, specs):
+            d.n, d.x, d.out, d.v_out, d.v_x = x.numel(), B.ptr(x), B.ptr(o), None, None
+            d.lo, d.hi, d.q_step, d.activation, d.philox_offset = _f32(lo), _f32(hi), _f32(q_step), act, off
+            off += int(B.query("gs_quantize_philox_advance", x.numel(), cap))
+        gen.set_offset(off)
+        with _device_of(xc[0]):
+            B.call("gs_quantize_noise_multi_fwd", len(xc), ctypes.addressof(descs), seed, cap, _stream(xc[0]))
+        ctx.specs = [(_f32(lo), _f32(hi), act) for lo, hi, _, act in specs]
+        ctx.save_for_backward(*xc, *[o if sp[3] else None for o, sp in zip(outs, specs)])
+        ctx.set_materialize_grads(False)
+        return tuple(o.view(x.shape) for o, x in zip(outs, xs))
+
+    @staticmethod
+    def backward(ctx, *v_outs):
+        k = len(ctx.specs)
+        xc, outs = ctx.saved_tensors[:k], ctx.saved_tensors[k:]
+        descs = (_QuantDesc * k)()
+        grads: List[Optional[Tensor]] = []
+        live = []
+        for i, (x, o, v, (lo, hi, act)) in enumerate(zip(xc, outs, v_outs, ctx.specs)):
+            if v is None or not ctx.needs_input_grad[1 + i]:
+                grads.append(None)
+                descs[i].n = 0
+                continue
+            g = v.contiguous()
+            vx = torch.empty_like(x)
+            live.append(g)
+            d = descs[i]
+            d.n, d.x, d.out, d.v_out, d.v_x = x.numel(), B.ptr(x), B.ptr(o), B.ptr(g), B.ptr(vx)
+            d.lo, d.hi, d.q_step, d.activation, d.philox_offset = lo, hi, 0.0, act, 0
+            grads.append(vx.view(v.shape))
+        if live:
+            with _device_of(xc[0]):
+                B.call("gs_quantize_noise_multi_bwd", k, ctypes.addressof(descs), _stream(xc[0]))
+        return (None, *grads)
+
+
+def fake_quantize_noise_multi(inputs: Sequence[Tensor], bounds: Sequence[Tuple[float, float]], bitwidths: Sequence[int],
+                              activations: Optional[Sequence[Optional[str]]] = None) -> List[Dict[str, object]]:
+    """``[fake_quantize_ste(x, lo, hi, bits, "noise", activation) for ...]`` -- same outputs, same RNG stream -- in one launch
+    (up to QUANT_MULTI_MAX tensors; not in the reference, whose hooks run tensor by tensor: simulation.py:206-324)."""
+    assert 1 <= len(inputs) <= QUANT_MULTI_MAX and len(inputs) == len(bounds) == len(bitwidths)
+    acts = list(activations) if activations is not None else [None] * len(inputs)
+    q_steps = [(hi - lo) / (2**b - 1) for (lo, hi), b in zip(bounds, bitwidths)]
+    specs = [(lo, hi, q, _ACTS[a]) for (lo, hi), q, a in zip(bounds, q_steps, acts)]
+    outs = _NoiseQuantMulti.apply(specs, *inputs)
+    return [{"output_value": o, "q_step": q} for o, q in zip(outs, q_steps)]
 
 
 def fake_quantize_ste(input: Tensor, lower_bd: float, upper_bd: float, bitwidth: int = 8,

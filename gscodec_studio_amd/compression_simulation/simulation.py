@@ -15,6 +15,7 @@ examples/simple_trainer.py:619-632, 906-907, 991-1007, 1046-1050, 1070-1074, 109
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -24,7 +25,7 @@ from typing_extensions import Literal
 from .ada_mask import AnnealingMask
 from .ada_mask import shN_gradient_threshold as _shN_gradient_threshold
 from .entropy_model import Entropy_factorized_optimized_refactor
-from .ops import fake_quantize_ste
+from .ops import QUANT_MULTI_MAX, fake_quantize_noise_multi, fake_quantize_ste
 
 
 class _SimulationBase:
@@ -97,7 +98,10 @@ class _SimulationBase:
                     and step > self.entropy_steps[name] and self.entropy_models.get(name) is not None)
         act = self.ACTIVATIONS.get(name) if self._activate else None
         fused = act if not estimate else None  # (the bits estimator needs the quantized value itself: activate afterwards)
-        if self.q_type is None:
+        pre = self._pre.pop(name, None)
+        if pre is not None and pre[0] is param and pre[1] == fused:
+            out = pre[2]  # quantized together with the step's other hooked attributes (one launch, see _simulate)
+        elif self.q_type is None:
             out = fake_quantize_ste(param, lo, hi, bits, activation=fused)  # default q_type="noise"
         else:
             out = fake_quantize_ste(param, lo, hi, bits, self.q_type, activation=fused)
@@ -123,8 +127,41 @@ class _SimulationBase:
         finally:
             self._activate = False
 
+    _pre: Dict[str, tuple] = {}
+    _MULTI = os.environ.get("GS_QUANT_MULTI", "1") != "0"
+
+    def _prequantize(self, splats: Dict[str, Tensor], step: int) -> None:
+        """All noise-quantized attributes of the step in ONE launch (ops.fake_quantize_noise_multi): the noise is drawn in the
+        kernel exactly as the per-attribute ``uniform_`` calls of the reference would have drawn it, in the same order, so the
+        values and the RNG stream are those of the tensor-by-tensor hooks.  Only the class's own hook functions take part (a
+        subclass that overrides one keeps its behaviour)."""
+        self._pre = {}
+        if not self._MULTI or self.q_type not in (None, "noise"):
+            return
+        names = []
+        for name, p in splats.items():
+            if not self.simulation_option.get(name, False) or self.bds.get(name) is None:
+                continue
+            fn = getattr(type(self), f"simulate_compression_{name}", None)
+            if fn is None or getattr(fn, "__qualname__", "").split(".")[0] not in ("CompressionSimulation", "STGCompressionSimulation"):
+                return
+            if not (isinstance(p, Tensor) and p.is_cuda and p.dtype == torch.float32):
+                return
+            names.append(name)
+        if not 2 <= len(names) <= QUANT_MULTI_MAX or len({splats[n].device for n in names}) != 1:
+            return
+        acts = []
+        for n in names:
+            estimate = (self.entropy_model_enable and self.entropy_model_option.get(n, False)
+                        and step > self.entropy_steps[n] and self.entropy_models.get(n) is not None)
+            acts.append(self.ACTIVATIONS.get(n) if (self._activate and not estimate) else None)
+        outs = fake_quantize_noise_multi([splats[n] for n in names], [tuple(self.bds[n]) for n in names],
+                                         [self.q_bitwidth[n] for n in names], acts)
+        self._pre = {n: (splats[n], a, o) for n, a, o in zip(names, acts, outs)}
+
     def _simulate(self, splats: Dict[str, Tensor], step: int):
         new_splats, esti_bits = {}, {}
+        self._prequantize(splats, step)
         for name in splats.keys():
             if self.simulation_option[name]:
                 fn = getattr(self, f"simulate_compression_{name}", None)

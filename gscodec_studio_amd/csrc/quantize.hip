@@ -219,6 +219,146 @@ extern "C" int32_t gs_quantize_noise_bwd(
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Multi-tensor "noise" quantizer with the noise generated IN the kernel (BASELINE config 3: the hooks of four attributes in
+// front of every render).  The reference draws the noise of every attribute with torch.empty_like(x).uniform_(-0.5, 0.5) from
+// the device's default generator; torch's kernel for it is a Philox4x32-10 counter scheme
+// (ATen/native/cuda/DistributionTemplates.h: distribution_elementwise_grid_stride_kernel): a grid of G = min(ceil(n / 256),
+// CUs * (max threads per CU / 256)) workgroups of 256 threads, thread idx owns the Philox subsequence idx of (seed, offset) and
+// its k-th draw of four 32-bit values serves the elements idx + (4 k + j) * 256 G, j = 0..3; u = 2^-32 v + 2^-32 in fp32,
+// noise = u * (to - from) + from with the value `to` mapped back to `from`; the generator's offset then advances by
+// 4 * (floor((n - 1) / (1024 G)) + 1).  The same draws are evaluated here, per (tensor, idx, k) -- four elements a stride apart
+// per thread, coalesced across threads -- so the outputs are bit-identical to uniform_ + gs_quantize_noise_fwd while the
+// noise never exists in memory (12 -> 8 bytes per quantized float, 8 launches -> 1 for four attributes) and the RNG stream of
+// the process stays exactly the reference's (the caller advances the generator by the same amounts).
+// ---------------------------------------------------------------------------
+struct QuantMultiArgs {
+    gs_quant_desc d[GS_QUANT_MULTI_MAX];
+    uint64_t item_end[GS_QUANT_MULTI_MAX]; // inclusive prefix sum of the tensors' work items ((idx, k) pairs)
+    uint32_t stride[GS_QUANT_MULTI_MAX];   // 256 * G of the tensor
+    uint32_t n;
+    uint32_t seed_lo, seed_hi;
+};
+
+GS_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+GS_DEV float philox_noise(uint32_t v) { // torch's uniform_(-0.5, 0.5) of one 32-bit draw
+    const float u = __fadd_rn(__fmul_rn((float)v, 2.3283064e-10f), 2.3283064e-10f); // (0, 1]
+    const float val = __fadd_rn(__fmul_rn(u, 1.0f), -0.5f);
+    return val == 0.5f ? -0.5f : val;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(GS_BLOCK) quant_noise_multi_kernel(QuantMultiArgs a) {
+    const uint64_t total = a.item_end[a.n - 1];
+    const uint64_t gstride = (uint64_t)gridDim.x * GS_BLOCK;
+    for (uint64_t it = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x; it < total; it += gstride) {
+        uint32_t t = 0;
+        while (it >= a.item_end[t]) ++t; // (<= 8 tensors)
+        const gs_quant_desc d = a.d[t];
+        const uint64_t local = it - (t ? a.item_end[t - 1] : 0);
+        const uint32_t stride = a.stride[t];
+        const uint32_t idx = (uint32_t)(local % stride);
+        const uint64_t k = local / stride;
+        const uint64_t e0 = (uint64_t)idx + 4ull * k * stride;
+        if (e0 >= d.n) continue;
+        if (!BWD) {
+            const uint64_t ctr = d.philox_offset / 4 + k;
+            uint32_t r[4];
+            philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), idx, 0u, a.seed_lo, a.seed_hi, r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t e = e0 + (uint64_t)j * stride;
+                if (e < d.n) {
+                    const float q = q_noise(d.x[e], philox_noise(r[j]), d.lo, d.hi, d.q_step);
+                    d.out[e] = d.activation == GS_ACT_EXP ? q_act<GS_ACT_EXP>(q) : d.activation == GS_ACT_SIGMOID ? q_act<GS_ACT_SIGMOID>(q) : q;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t e = e0 + (uint64_t)j * stride;
+                if (e < d.n) {
+                    float g = d.v_out[e];
+                    if (d.activation == GS_ACT_EXP) g = q_act_grad<GS_ACT_EXP>(d.out[e], g);
+                    else if (d.activation == GS_ACT_SIGMOID) g = q_act_grad<GS_ACT_SIGMOID>(d.out[e], g);
+                    d.v_x[e] = q_mask(d.x[e], g, d.lo, d.hi);
+                }
+            }
+        }
+    }
+}
+
+static int32_t quant_multi_launch(uint32_t n_tensors, const gs_quant_desc *descs, uint64_t seed, uint32_t grid_cap, bool bwd,
+                                  hipStream_t st, const char *who) {
+    QuantMultiArgs a;
+    uint64_t items = 0;
+    a.n = 0;
+    for (uint32_t t = 0; t < n_tensors; ++t) {
+        const gs_quant_desc &d = descs[t];
+        if (d.n == 0) continue;
+        if (!d.x || (bwd ? (!d.v_out || !d.v_x) : !d.out) || d.activation < GS_ACT_NONE || d.activation > GS_ACT_SIGMOID ||
+            (bwd && d.activation != GS_ACT_NONE && !d.out) || d.philox_offset % 4 != 0) {
+            gs_set_error("%s: bad descriptor %u (null pointer, unknown activation or an offset that is not a multiple of 4)", who, t);
+            return 1;
+        }
+        const uint64_t blocks = (d.n + GS_BLOCK - 1) / GS_BLOCK;
+        const uint32_t G = (uint32_t)(blocks < grid_cap ? blocks : grid_cap);
+        a.stride[a.n] = GS_BLOCK * G;
+        const uint64_t calls = (d.n - 1) / ((uint64_t)a.stride[a.n] * 4) + 1;
+        items += (uint64_t)a.stride[a.n] * calls;
+        a.item_end[a.n] = items;
+        a.d[a.n] = d;
+        ++a.n;
+    }
+    if (a.n == 0) return 0;
+    a.seed_lo = (uint32_t)seed;
+    a.seed_hi = (uint32_t)(seed >> 32);
+    uint64_t blocks = (items + GS_BLOCK - 1) / GS_BLOCK;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (bwd) hipLaunchKernelGGL(quant_noise_multi_kernel<true>, dim3((uint32_t)blocks), dim3(GS_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL(quant_noise_multi_kernel<false>, dim3((uint32_t)blocks), dim3(GS_BLOCK), 0, st, a);
+    return 0;
+}
+
+extern "C" uint64_t gs_quantize_philox_advance(uint64_t n, uint32_t grid_cap) {
+    if (n == 0 || grid_cap == 0) return 0;
+    const uint64_t blocks = (n + GS_BLOCK - 1) / GS_BLOCK;
+    const uint64_t G = blocks < grid_cap ? blocks : grid_cap;
+    return ((n - 1) / (GS_BLOCK * G * 4) + 1) * 4;
+}
+
+extern "C" int32_t gs_quantize_noise_multi_fwd(uint32_t n_tensors, const gs_quant_desc *descs, uint64_t philox_seed, uint32_t grid_cap,
+                                               gs_stream_t stream) {
+    GS_CHECK_ARG(n_tensors <= GS_QUANT_MULTI_MAX && (n_tensors == 0 || descs != nullptr), "up to GS_QUANT_MULTI_MAX descriptors");
+    GS_CHECK_ARG(grid_cap > 0, "grid_cap (CUs * max threads per CU / 256 of the device, what torch sizes uniform_'s grid by) must be > 0");
+    const int32_t rc = quant_multi_launch(n_tensors, descs, philox_seed, grid_cap, false, (hipStream_t)stream, "gs_quantize_noise_multi_fwd");
+    if (rc) return rc;
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_quantize_noise_multi_bwd(uint32_t n_tensors, const gs_quant_desc *descs, gs_stream_t stream) {
+    GS_CHECK_ARG(n_tensors <= GS_QUANT_MULTI_MAX && (n_tensors == 0 || descs != nullptr), "up to GS_QUANT_MULTI_MAX descriptors");
+    const int32_t rc = quant_multi_launch(n_tensors, descs, 0, 1u << 20, true, (hipStream_t)stream, "gs_quantize_noise_multi_bwd");
+    if (rc) return rc;
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int32_t gs_quantize_round_fwd(
     uint64_t n, float *x_inplace, float lo, float hi, float range, float q_step_norm, int32_t activation, float *out,
     gs_stream_t stream) {

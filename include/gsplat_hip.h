@@ -586,6 +586,29 @@ int32_t gs_quantize_round_fwd(
 int32_t gs_quantize_round_bwd(
     uint64_t n, const float *v_out, int32_t activation, const float *out, float *v_x, gs_stream_t stream);
 
+/* Multi-tensor "noise" quantizer with the noise generated in the kernel (the hooks of BASELINE config 3 in ONE launch each way;
+ * the noise never exists in memory).  Bit-identical to  noise = torch.empty_like(x).uniform_(-0.5, 0.5)  followed by
+ * gs_quantize_noise_fwd, tensor after tensor: the kernel evaluates the Philox4x32-10 draws torch's uniform_ kernel would have
+ * made for (philox_seed, philox_offset) -- see csrc/quantize.hip for the counter scheme.  The caller reads seed and offset from
+ * the device's default generator and advances it by gs_quantize_philox_advance(n, grid_cap) per tensor, so the process's RNG
+ * stream is exactly the reference's.  grid_cap = CUs * (max threads per CU / 256) of the device (what torch caps uniform_'s grid
+ * at).  descs: HOST array (copied into the kernel arguments). */
+#define GS_QUANT_MULTI_MAX 8
+typedef struct gs_quant_desc {
+    uint64_t n;             /* floats in the tensor (0: skipped) */
+    const float *x;         /* input */
+    float *out;             /* fwd: output; bwd: the forward's output (only read with an activation) */
+    const float *v_out;     /* bwd: upstream gradient */
+    float *v_x;             /* bwd: gradient out */
+    float lo, hi, q_step;
+    int32_t activation;     /* GS_ACT_* fused behind the quantizer */
+    uint64_t philox_offset; /* fwd: the generator's offset when this tensor's uniform_ call would have run (multiple of 4) */
+} gs_quant_desc;
+uint64_t gs_quantize_philox_advance(uint64_t n, uint32_t grid_cap);
+int32_t gs_quantize_noise_multi_fwd(
+    uint32_t n_tensors, const gs_quant_desc *descs, uint64_t philox_seed, uint32_t grid_cap, gs_stream_t stream);
+int32_t gs_quantize_noise_multi_bwd(uint32_t n_tensors, const gs_quant_desc *descs, gs_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Q3  learnable per-splat mask on the higher SH bands ("shN adaptive mask") of the compression-simulation hooks
  * replaces the torch ops of AnnealingMask (gsplat/compression_simulation/ada_mask.py:6-62), applied by

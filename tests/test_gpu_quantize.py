@@ -143,3 +143,72 @@ def test_fused_activation_matches_hook_then_torch_activation(q_type, act):
         assert int(out_of_range.sum()) > 0 and float(gb[out_of_range].abs().max()) == 0.0
     else:  # the parameter was clamped in place in both forms
         assert torch.equal(xa.detach(), xb.detach()) and float(xb.min()) >= lo and float(xb.max()) <= hi
+
+
+@pytest.mark.parametrize("sizes", [(1,), (5, 1000), (4099, 3, 777, 100_003), (3_018_195, 4_024_260, 1_006_065, 3_018_195), (2**22 + 17, 12)])
+def test_multi_tensor_noise_quantizer_replays_torch_rng(sizes):
+    """gs_quantize_noise_multi_fwd generates its noise IN the kernel from the default generator's (seed, offset), draw for draw
+    what ``torch.empty_like(x).uniform_(-0.5, 0.5)`` would have produced tensor after tensor (Philox4x32-10, torch's grid and
+    counter scheme): outputs BIT-IDENTICAL to the tensor-by-tensor hooks, the generator left at the same offset, gradients equal."""
+    from gscodec_studio_amd.compression_simulation import fake_quantize_ste
+    from gscodec_studio_amd.compression_simulation.ops import fake_quantize_noise_multi
+
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    bounds = [(-10, 2), (-1, 1), (-15, 15), (-2, 4)]
+    acts = [None, None, "sigmoid", "exp"]
+    xs0 = [torch.randn(n, device="cuda:0", generator=g) * 3 for n in sizes]
+    b = [bounds[i % 4] for i in range(len(sizes))]
+    a = [acts[i % 4] for i in range(len(sizes))]
+    gen = torch.cuda.default_generators[0]
+    torch.manual_seed(4242)
+    torch.rand(7, device="cuda:0")  # (a non-zero starting offset)
+    xs1 = [x.clone().requires_grad_(True) for x in xs0]
+    one = [fake_quantize_ste(x, lo, hi, 8, "noise", activation=ac)["output_value"] for x, (lo, hi), ac in zip(xs1, b, a)]
+    off_one = gen.get_offset()
+    after_one = torch.rand(5, device="cuda:0")
+    torch.manual_seed(4242)
+    torch.rand(7, device="cuda:0")
+    xs2 = [x.clone().requires_grad_(True) for x in xs0]
+    multi = fake_quantize_noise_multi(xs2, b, [8] * len(sizes), a)
+    assert gen.get_offset() == off_one
+    assert torch.equal(torch.rand(5, device="cuda:0"), after_one)  # the stream continues identically
+    for o, m, (lo, hi) in zip(one, multi, b):
+        assert bits_equal(N(m["output_value"]), N(o)) and m["q_step"] == (hi - lo) / 255
+    vs = [torch.randn_like(x) for x in xs0]
+    g1 = torch.autograd.grad(sum((o * v).sum() for o, v in zip(one, vs)), xs1)
+    g2 = torch.autograd.grad(sum((m["output_value"] * v).sum() for m, v in zip(multi, vs)), xs2)
+    for p, q in zip(g1, g2):
+        assert torch.equal(p, q)
+
+
+def test_hooks_in_one_launch_equal_hooks_one_by_one():
+    """CompressionSimulation.simulate_compression quantizes all hooked attributes in one launch (ops.fake_quantize_noise_multi);
+    with GS_QUANT_MULTI off it runs them one by one like the reference: identical values, identical RNG stream, and a
+    subset of gradients requested."""
+    from gscodec_studio_amd.compression_simulation import CompressionSimulation
+
+    n = 20_011
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    raw = {"means": torch.randn(n, 3, device="cuda:0", generator=g), "scales": torch.randn(n, 3, device="cuda:0", generator=g) * 3 - 4,
+           "quats": torch.randn(n, 4, device="cuda:0", generator=g), "opacities": torch.randn(n, device="cuda:0", generator=g) * 5,
+           "sh0": torch.randn(n, 1, 3, device="cuda:0", generator=g), "shN": torch.randn(n, 15, 3, device="cuda:0", generator=g)}
+    res = {}
+    for multi in (True, False):
+        for activate in (False, True):
+            sim = CompressionSimulation(entropy_model_enable=False, entropy_steps={k: -1 for k in raw})
+            sim._MULTI = multi
+            splats = {k: v.clone().requires_grad_(k != "quats") for k, v in raw.items()}
+            torch.manual_seed(77)
+            new, _ = sim.simulate_compression(splats, step=5, activate=activate)
+            tail = torch.rand(3, device="cuda:0")
+            loss = sum((new[k] * (i + 1)).sum() for i, k in enumerate(("scales", "quats", "opacities", "sh0")))
+            loss.backward()
+            res[(multi, activate)] = ({k: new[k].detach() for k in new}, tail, {k: p.grad for k, p in splats.items() if p.grad is not None})
+    for activate in (False, True):
+        (a, ta, ga), (b, tb, gb) = res[(True, activate)], res[(False, activate)]
+        assert torch.equal(ta, tb)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (k, activate)
+        assert set(ga) == set(gb) == {"scales", "opacities", "sh0"}
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), (k, activate)

@@ -5,9 +5,23 @@
 bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB, and FETCH_SIZE reports half of the
 fetched bytes on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
 import csv
+import hashlib
 import json
+import os
 import sys
 from collections import defaultdict
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gscodec_studio_amd", "csrc")
+
+
+def source_hashes():
+    """SHA-256 prefix of every kernel source: bench.py reports the counters only while the sources they were taken from are
+    unchanged (a kernel edited after the profile makes its traffic figure stale)."""
+    out = {}
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".h")):
+            out[name] = hashlib.sha256(open(os.path.join(CSRC, name), "rb").read()).hexdigest()[:16]
+    return out
 
 
 def load(path, counter):
@@ -34,6 +48,7 @@ def main():
         "workload_key": "grid3_1920x1080_sh3",
         "command": "tools/pmc.sh: cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras ; same with --pmc WRITE_SIZE and --pmc SQ_INSTS_VALU (separate passes)",
         "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: KB units; FETCH_SIZE reports 1/2 of the fetched bytes on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated",
+        "source_hashes": source_hashes(),
         "kernels": kernels,
     }, open(out, "w"), indent=1)
     for k, v in list(kernels.items())[:8]:
