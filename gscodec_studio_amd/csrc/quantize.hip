@@ -227,8 +227,8 @@ extern "C" int32_t gs_quantize_noise_bwd(
 // CUs * (max threads per CU / 256)) workgroups of 256 threads, thread idx owns the Philox subsequence idx of (seed, offset) and
 // its k-th draw of four 32-bit values serves the elements idx + (4 k + j) * 256 G, j = 0..3; u = 2^-32 v + 2^-32 in fp32,
 // noise = u * (to - from) + from with the value `to` mapped back to `from`; the generator's offset then advances by
-// 4 * (floor((n - 1) / (1024 G)) + 1).  The same draws are evaluated here, per (tensor, idx, k) -- four elements a stride apart
-// per thread, coalesced across threads -- so the outputs are bit-identical to uniform_ + gs_quantize_noise_fwd while the
+// 4 * (floor((n - 1) / (1024 G)) + 1).  The same draws are evaluated here, per (tensor, four consecutive idx, k) -- sixteen
+// elements as four 16-byte accesses a stride apart -- so the outputs are bit-identical to uniform_ + gs_quantize_noise_fwd while the
 // noise never exists in memory (12 -> 8 bytes per quantized float, 8 launches -> 1 for four attributes) and the RNG stream of
 // the process stays exactly the reference's (the caller advances the generator by the same amounts).
 // ---------------------------------------------------------------------------
@@ -236,6 +236,7 @@ struct QuantMultiArgs {
     gs_quant_desc d[GS_QUANT_MULTI_MAX];
     uint64_t item_end[GS_QUANT_MULTI_MAX]; // inclusive prefix sum of the tensors' work items ((idx, k) pairs)
     uint32_t stride[GS_QUANT_MULTI_MAX];   // 256 * G of the tensor
+    uint32_t vec[GS_QUANT_MULTI_MAX];      // 16-byte accesses allowed
     uint32_t n;
     uint32_t seed_lo, seed_hi;
 };
@@ -261,8 +262,16 @@ GS_DEV float philox_noise(uint32_t v) { // torch's uniform_(-0.5, 0.5) of one 32
     return val == 0.5f ? -0.5f : val;
 }
 
-template <bool BWD>
-__global__ void __launch_bounds__(GS_BLOCK) quant_noise_multi_kernel(QuantMultiArgs a) {
+template <int ACT_DYN>
+GS_DEV float q_act_dyn(float q, int act) { return act == GS_ACT_EXP ? q_act<GS_ACT_EXP>(q) : act == GS_ACT_SIGMOID ? q_act<GS_ACT_SIGMOID>(q) : q; }
+GS_DEV float q_act_grad_dyn(float o, float g, int act) {
+    return act == GS_ACT_EXP ? q_act_grad<GS_ACT_EXP>(o, g) : act == GS_ACT_SIGMOID ? q_act_grad<GS_ACT_SIGMOID>(o, g) : g;
+}
+
+// Forward work item: (tensor, idx4, k) = the four Philox subsequences 4 idx4 .. 4 idx4 + 3 at draw k -> 16 elements, as four
+// 16-byte accesses a stride apart (element 4 idx4 + i + (4 k + j) stride uses value j of subsequence 4 idx4 + i).
+// item_end counts these items (stride / 4 per draw).  vec[t] = 0: the tensor's pointers are not 16-byte aligned -> 4-byte accesses.
+__global__ void __launch_bounds__(GS_BLOCK) quant_noise_multi_fwd_kernel(QuantMultiArgs a) {
     const uint64_t total = a.item_end[a.n - 1];
     const uint64_t gstride = (uint64_t)gridDim.x * GS_BLOCK;
     for (uint64_t it = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x; it < total; it += gstride) {
@@ -270,33 +279,62 @@ __global__ void __launch_bounds__(GS_BLOCK) quant_noise_multi_kernel(QuantMultiA
         while (it >= a.item_end[t]) ++t; // (<= 8 tensors)
         const gs_quant_desc d = a.d[t];
         const uint64_t local = it - (t ? a.item_end[t - 1] : 0);
-        const uint32_t stride = a.stride[t];
-        const uint32_t idx = (uint32_t)(local % stride);
-        const uint64_t k = local / stride;
-        const uint64_t e0 = (uint64_t)idx + 4ull * k * stride;
+        const uint32_t stride = a.stride[t], q4 = stride / 4;
+        const uint32_t idx0 = 4u * (uint32_t)(local % q4);
+        const uint64_t k = local / q4;
+        const uint64_t e0 = (uint64_t)idx0 + 4ull * k * stride;
         if (e0 >= d.n) continue;
-        if (!BWD) {
-            const uint64_t ctr = d.philox_offset / 4 + k;
-            uint32_t r[4];
-            philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), idx, 0u, a.seed_lo, a.seed_hi, r);
+        const uint64_t ctr = d.philox_offset / 4 + k;
+        uint32_t r[4][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint64_t e = e0 + (uint64_t)j * stride;
-                if (e < d.n) {
-                    const float q = q_noise(d.x[e], philox_noise(r[j]), d.lo, d.hi, d.q_step);
-                    d.out[e] = d.activation == GS_ACT_EXP ? q_act<GS_ACT_EXP>(q) : d.activation == GS_ACT_SIGMOID ? q_act<GS_ACT_SIGMOID>(q) : q;
-                }
+        for (int i = 0; i < 4; ++i) philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), idx0 + (uint32_t)i, 0u, a.seed_lo, a.seed_hi, r[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t e = e0 + (uint64_t)j * stride;
+            if (e >= d.n) break;
+            if (a.vec[t] && e + 4 <= d.n) {
+                const float4 x = *reinterpret_cast<const float4 *>(d.x + e);
+                float4 o;
+                o.x = q_act_dyn<0>(q_noise(x.x, philox_noise(r[0][j]), d.lo, d.hi, d.q_step), d.activation);
+                o.y = q_act_dyn<0>(q_noise(x.y, philox_noise(r[1][j]), d.lo, d.hi, d.q_step), d.activation);
+                o.z = q_act_dyn<0>(q_noise(x.z, philox_noise(r[2][j]), d.lo, d.hi, d.q_step), d.activation);
+                o.w = q_act_dyn<0>(q_noise(x.w, philox_noise(r[3][j]), d.lo, d.hi, d.q_step), d.activation);
+                *reinterpret_cast<float4 *>(d.out + e) = o;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (e + i < d.n) d.out[e + i] = q_act_dyn<0>(q_noise(d.x[e + i], philox_noise(r[i][j]), d.lo, d.hi, d.q_step), d.activation);
             }
+        }
+    }
+}
+
+// Backward work item: four consecutive elements of a tensor (no noise involved: plain streaming).
+__global__ void __launch_bounds__(GS_BLOCK) quant_noise_multi_bwd_kernel(QuantMultiArgs a) {
+    const uint64_t total = a.item_end[a.n - 1];
+    const uint64_t gstride = (uint64_t)gridDim.x * GS_BLOCK;
+    for (uint64_t it = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x; it < total; it += gstride) {
+        uint32_t t = 0;
+        while (it >= a.item_end[t]) ++t;
+        const gs_quant_desc d = a.d[t];
+        const uint64_t e = 4ull * (it - (t ? a.item_end[t - 1] : 0));
+        if (a.vec[t] && e + 4 <= d.n) {
+            const float4 x = *reinterpret_cast<const float4 *>(d.x + e);
+            float4 g = *reinterpret_cast<const float4 *>(d.v_out + e);
+            if (d.activation != GS_ACT_NONE) {
+                const float4 o = *reinterpret_cast<const float4 *>(d.out + e);
+                g.x = q_act_grad_dyn(o.x, g.x, d.activation); g.y = q_act_grad_dyn(o.y, g.y, d.activation);
+                g.z = q_act_grad_dyn(o.z, g.z, d.activation); g.w = q_act_grad_dyn(o.w, g.w, d.activation);
+            }
+            float4 r;
+            r.x = q_mask(x.x, g.x, d.lo, d.hi); r.y = q_mask(x.y, g.y, d.lo, d.hi);
+            r.z = q_mask(x.z, g.z, d.lo, d.hi); r.w = q_mask(x.w, g.w, d.lo, d.hi);
+            *reinterpret_cast<float4 *>(d.v_x + e) = r;
         } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint64_t e = e0 + (uint64_t)j * stride;
-                if (e < d.n) {
-                    float g = d.v_out[e];
-                    if (d.activation == GS_ACT_EXP) g = q_act_grad<GS_ACT_EXP>(d.out[e], g);
-                    else if (d.activation == GS_ACT_SIGMOID) g = q_act_grad<GS_ACT_SIGMOID>(d.out[e], g);
-                    d.v_x[e] = q_mask(d.x[e], g, d.lo, d.hi);
-                }
+            for (uint64_t i = e; i < e + 4 && i < d.n; ++i) {
+                float g = d.v_out[i];
+                if (d.activation != GS_ACT_NONE) g = q_act_grad_dyn(d.out[i], g, d.activation);
+                d.v_x[i] = q_mask(d.x[i], g, d.lo, d.hi);
             }
         }
     }
@@ -318,8 +356,14 @@ static int32_t quant_multi_launch(uint32_t n_tensors, const gs_quant_desc *descs
         const uint64_t blocks = (d.n + GS_BLOCK - 1) / GS_BLOCK;
         const uint32_t G = (uint32_t)(blocks < grid_cap ? blocks : grid_cap);
         a.stride[a.n] = GS_BLOCK * G;
-        const uint64_t calls = (d.n - 1) / ((uint64_t)a.stride[a.n] * 4) + 1;
-        items += (uint64_t)a.stride[a.n] * calls;
+        if (bwd) {
+            items += (d.n + 3) / 4;
+            a.vec[a.n] = ((uintptr_t)d.x % 16 == 0 && (uintptr_t)d.v_out % 16 == 0 && (uintptr_t)d.v_x % 16 == 0 && (uintptr_t)d.out % 16 == 0) ? 1u : 0u;
+        } else {
+            const uint64_t calls = (d.n - 1) / ((uint64_t)a.stride[a.n] * 4) + 1;
+            items += (uint64_t)(a.stride[a.n] / 4) * calls;
+            a.vec[a.n] = ((uintptr_t)d.x % 16 == 0 && (uintptr_t)d.out % 16 == 0) ? 1u : 0u;
+        }
         a.item_end[a.n] = items;
         a.d[a.n] = d;
         ++a.n;
@@ -328,9 +372,9 @@ static int32_t quant_multi_launch(uint32_t n_tensors, const gs_quant_desc *descs
     a.seed_lo = (uint32_t)seed;
     a.seed_hi = (uint32_t)(seed >> 32);
     uint64_t blocks = (items + GS_BLOCK - 1) / GS_BLOCK;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    if (bwd) hipLaunchKernelGGL(quant_noise_multi_kernel<true>, dim3((uint32_t)blocks), dim3(GS_BLOCK), 0, st, a);
-    else hipLaunchKernelGGL(quant_noise_multi_kernel<false>, dim3((uint32_t)blocks), dim3(GS_BLOCK), 0, st, a);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (bwd) hipLaunchKernelGGL(quant_noise_multi_bwd_kernel, dim3((uint32_t)blocks), dim3(GS_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL(quant_noise_multi_fwd_kernel, dim3((uint32_t)blocks), dim3(GS_BLOCK), 0, st, a);
     return 0;
 }
 
