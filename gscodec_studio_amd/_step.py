@@ -1,0 +1,262 @@
+"""Fast path of ``rasterization()`` over the native step driver (``gs_step_fwd_begin`` / ``gs_step_fwd_finish``, csrc/step.hip).
+
+The common training call -- unpacked batch, shared SH coefficients (contiguous, or the trainer's ``(sh0, shN)`` pair) or
+``[N, 3]`` colours, three render channels, fixed camera poses -- runs the reference's pipeline
+(gsplat/rendering.py:279-582: projection, tile binning, compositing) as TWO native calls around the one host read-back
+instead of seven operator calls with their Python glue: ~0.6 ms of host work per forward + backward becomes ~0.3 ms
+(tools/cpu_overhead.py), with the same launches, i.e. identical results (tests/test_gpu_step.py).
+
+Autograd sees the same two nodes as on the operator path, so that ``meta["means2d"]`` stays an autograd intermediate
+(``retain_grad()`` / ``.absgrad`` of the reference's densification strategies, strategy/default.py:150, 221-226):
+
+* ``_StepProject``   forward: the WHOLE forward (both native calls); backward: ``_ProjectRows.backward`` (projection + SH);
+* ``_StepComposite`` forward: hands out the images node 1 rendered; backward: ``_RasterizeToPixels.backward``.
+
+The backward bodies are the operator path's own (same saved tensors, same context attributes), so every property tested
+there -- prefilled gradients, repeated backward, partial requires_grad, expanded image gradients -- carries over.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _backend as B
+from . import _wrapper as W
+
+ENABLED = os.environ.get("GS_STEP_DRIVER", "1") != "0"
+
+
+class _Plan(ctypes.Structure):  # gs_raster_plan
+    _fields_ = [("magic", ctypes.c_uint32), ("n_tiles_all", ctypes.c_uint32), ("n_isects", ctypes.c_uint32), ("channels", ctypes.c_uint32),
+                ("seg", ctypes.c_int32), ("solo_min", ctypes.c_int32), ("xcd_fwd", ctypes.c_uint32), ("xcd_bwd", ctypes.c_uint32),
+                ("scratch_bytes", ctypes.c_uint64), ("reserved", ctypes.c_uint32 * 6)]
+
+
+_P, _U32, _I32, _U64, _I64, _F = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_int64, ctypes.c_float
+
+
+class _Step(ctypes.Structure):  # gs_step of include/gsplat_hip.h (field for field)
+    _fields_ = [
+        ("C", _U32), ("N", _U32),
+        ("means", _P), ("covars", _P), ("quats", _P), ("scales", _P), ("viewmats", _P), ("Ks", _P), ("opacities", _P), ("colors", _P),
+        ("sh_coeffs", _P), ("sh_rest", _P),
+        ("sh_K", _U32), ("sh_degree", _U32), ("width", _I32), ("height", _I32),
+        ("eps2d", _F), ("near_plane", _F), ("far_plane", _F), ("radius_clip", _F),
+        ("camera_model", _I32), ("antialiased", _I32), ("tile_size", _U32), ("tile_width", _U32), ("tile_height", _U32),
+        ("bucketed", _I32), ("lds_capacity", _U32), ("reserved0", _U32),
+        ("backgrounds", _P),
+        ("radii", _P), ("depths", _P), ("rows", _P), ("tiles_per_gauss", _P), ("depth_keys", _P), ("depth_vals", _P),
+        ("sort_temp", _P), ("sort_temp_bytes", _U64), ("splitters", _P), ("sorted_keys", _P), ("perm", _P), ("n_kept", _P),
+        ("group_sums", _P), ("group_prefix", _P), ("cumsum_scratch", _P), ("cumsum_scratch_bytes", _U64), ("block_sums", _P),
+        ("n_isects", _U64), ("isect_ids", _P), ("flatten_ids", _P), ("offsets", _P), ("work", _P), ("work_bytes", _U64),
+        ("render_colors", _P), ("render_alphas", _P), ("last_ids", _P), ("plan", _Plan), ("scratch", _P), ("zero_fill", _P),
+        ("zero_fill_bytes", _U64),
+        ("v_render_colors", _P), ("v_render_alphas", _P), ("vrc_pixel_stride", _I64), ("vrc_channel_stride", _I64),
+        ("grad_rows", _P), ("v_depths", _P), ("v_means", _P), ("v_covars", _P), ("v_quats", _P), ("v_scales", _P),
+        ("v_opacities", _P), ("v_colors", _P), ("v_sh", _P), ("v_sh_rest", _P),
+        ("absgrad", _I32), ("outputs_prefilled", _I32), ("skip_projection_bwd", _I32), ("reserved1", _I32),
+    ]
+
+
+_ROW_STRIDES = (ctypes.c_uint32 * 4)(W.ROW, W.ROW, W.ROW, W.ROW)
+
+
+class _Handover:
+    """What node 1's forward leaves for node 2 (the rendered images and everything its backward saves)."""
+
+    __slots__ = ("render_colors", "render_alphas", "last_ids", "scratch", "plan", "grad_rows", "offsets", "flatten_ids")
+
+
+def applicable(means: Tensor, viewmats: Tensor, colors, sh_degree, packed: bool, distributed: bool, render_mode: str,
+               channel_chunk: int, deterministic: bool, fuse_sh: bool, row_colors) -> bool:
+    return (ENABLED and not packed and not distributed and not deterministic and render_mode == "RGB" and channel_chunk >= 3
+            and means.is_cuda and viewmats.is_cuda and not viewmats.requires_grad and means.shape[0] > 0 and viewmats.shape[0] > 0
+            and (fuse_sh or row_colors is not None))
+
+
+def _c(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32 tensor, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _StepProject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, sh_rest, backgrounds, cfg, hand):
+        (width, height, eps2d, near_plane, far_plane, radius_clip, antialiased, camera_model, sh_degree, tile_size, tile_width,
+         tile_height, needs_bwd) = cfg
+        means, covars, quats, scales = _c(means), _c(covars), _c(quats), _c(scales)
+        viewmats, Ks, opacities, colors = _c(viewmats), _c(Ks), _c(opacities), _c(colors)
+        sh_coeffs, sh_rest, backgrounds = _c(sh_coeffs), _c(sh_rest), _c(backgrounds)
+        C, N = viewmats.shape[0], means.shape[0]
+        n_elems = C * N
+        dev = means.device
+        i32, i64, f32, u8 = torch.int32, torch.int64, torch.float32, torch.uint8
+        empty = torch.empty
+        s = _Step()
+        s.C, s.N = C, N
+        ptr = B.ptr
+        s.means, s.covars, s.quats, s.scales, s.viewmats, s.Ks = ptr(means), ptr(covars), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks)
+        s.opacities, s.colors, s.sh_coeffs, s.sh_rest, s.backgrounds = ptr(opacities), ptr(colors), ptr(sh_coeffs), ptr(sh_rest), ptr(backgrounds)
+        s.sh_K = (sh_coeffs.shape[1] + (sh_rest.shape[1] if sh_rest is not None else 0)) if sh_coeffs is not None else 0
+        s.sh_degree = int(sh_degree or 0)
+        s.width, s.height, s.eps2d, s.near_plane, s.far_plane, s.radius_clip = width, height, eps2d, near_plane, far_plane, radius_clip
+        cm = W._CAMERA_MODELS[camera_model]
+        s.camera_model, s.antialiased = cm, int(antialiased)
+        s.tile_size, s.tile_width, s.tile_height = tile_size, tile_width, tile_height
+        # ---- phase 1: everything whose size follows from C * N
+        radii = empty((C, N), dtype=i32, device=dev)
+        depths = empty((C, N), dtype=f32, device=dev)
+        rows = empty((C, N, W.ROW), dtype=f32, device=dev)
+        tiles_per_gauss = empty((C, N), dtype=i32, device=dev)
+        dkeys = empty(n_elems, dtype=i64, device=dev)
+        dvals = empty(n_elems, dtype=i32, device=dev)
+        perm = empty(n_elems, dtype=i32, device=dev)
+        n_kept = empty(1, dtype=i32, device=dev)
+        gshift = _GSHIFT[0] or _init_consts()
+        n_groups = (n_elems + (1 << gshift) - 1) >> gshift
+        gsums = empty(n_groups, dtype=i32, device=dev)
+        bucketed = W._PRESORT["on"] and bool(B.query("gs_presort_applicable", n_elems))
+        tb = B.query("gs_presort_temp_bytes" if bucketed else "gs_sort_temp_bytes", n_elems)
+        temp = empty(tb, dtype=u8, device=dev)
+        split = empty(256, dtype=i64, device=dev) if bucketed else None
+        ko = None if bucketed else empty(n_elems, dtype=i64, device=dev)
+        gpre = scratch1 = None
+        if n_groups > 8192:
+            gpre = empty(n_groups, dtype=i64, device=dev)
+            sb1 = B.query("gs_cumsum_scratch_bytes", n_groups)
+            scratch1 = empty(sb1, dtype=u8, device=dev)
+            s.cumsum_scratch, s.cumsum_scratch_bytes = ptr(scratch1), sb1
+        n_sums = B.query("gs_isect_count_blocks", n_elems)
+        direct = n_sums <= W._PINNED_DIRECT_MAX
+        if not direct:
+            raise RuntimeError("_step: the native step driver serves up to 2 M elements per call")  # (checked by the caller)
+        pinned = W._pinned_take(n_sums)
+        s.radii, s.depths, s.rows, s.tiles_per_gauss = ptr(radii), ptr(depths), ptr(rows), ptr(tiles_per_gauss)
+        s.depth_keys, s.depth_vals, s.sort_temp, s.sort_temp_bytes = ptr(dkeys), ptr(dvals), ptr(temp), tb
+        s.splitters, s.sorted_keys, s.perm, s.n_kept, s.group_sums, s.group_prefix = ptr(split), ptr(ko), ptr(perm), ptr(n_kept), ptr(gsums), ptr(gpre)
+        s.block_sums = pinned.data_ptr()
+        s.bucketed, s.lds_capacity = int(bucketed), W._PRESORT["lds_capacity"]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        sp = ctypes.addressof(s)
+        with torch.cuda.device(dev):
+            B.call("gs_step_fwd_begin", sp, stream)
+            # ---- buffers that do not depend on the intersection count are made while the GPU works
+            offsets = empty((C, tile_height, tile_width), dtype=i32, device=dev)
+            render_colors = empty((C, height, width, 3), dtype=f32, device=dev)
+            render_alphas = empty((C, height, width, 1), dtype=f32, device=dev)
+            last_ids = empty((C, height, width), dtype=i32, device=dev)
+            fill = None
+            prefill = None
+            need = ctx.needs_input_grad
+            if needs_bwd:
+                # the per-gaussian gradients the backward returns live behind the gradient rows in ONE zero-filled buffer
+                # (_wrapper.GradPrefill: the compositing forward zero-fills it as a side job)
+                prefill = W.GradPrefill()
+                req = []
+                for key, t, flag in (("means", means, need[0]), ("covars", covars, need[1]), ("quats", quats, need[2]),
+                                     ("scales", scales, need[3]), ("opacities", opacities, need[6]), ("colors", colors, need[7]),
+                                     ("sh", sh_coeffs, need[8]), ("sh_rest", sh_rest, need[9])):
+                    if t is not None and flag:
+                        req.append((key, tuple(t.shape)))
+                prefill.request = req
+                extra = prefill.floats()
+                if extra:
+                    extra += 64
+                fill = empty(n_elems * 16 + extra, dtype=f32, device=dev)
+                if extra:
+                    prefill.carve(fill, n_elems * 16)
+                else:
+                    prefill = None
+            # ---- the one host sync: the count kernel's block sums land in pinned memory (-1 -> >= 0)
+            W._wait_event(W._SentinelEvent(pinned))
+            n_isects = int(pinned.sum(dtype=torch.int64))
+            W._PINNED_FREE.setdefault(n_sums, []).append(pinned)
+            isect_ids = empty(n_isects, dtype=i64, device=dev)
+            flatten_ids = empty(n_isects, dtype=i32, device=dev)
+            wb = B.query("gs_isect_finish_work_bytes", n_isects)
+            work = empty(wb, dtype=u8, device=dev)
+            plan, sbytes = W._raster_plan(C * tile_height * tile_width, n_isects, 3, forward_only=not needs_bwd)
+            ctypes.memmove(ctypes.addressof(s.plan), plan, 64)
+            scratch = empty(sbytes, dtype=u8, device=dev)
+            s.n_isects, s.isect_ids, s.flatten_ids, s.offsets, s.work, s.work_bytes = n_isects, ptr(isect_ids), ptr(flatten_ids), ptr(offsets), ptr(work), wb
+            s.render_colors, s.render_alphas, s.last_ids, s.scratch = ptr(render_colors), ptr(render_alphas), ptr(last_ids), ptr(scratch)
+            if fill is not None:
+                s.zero_fill, s.zero_fill_bytes = ptr(fill), fill.numel() * 4
+            B.call("gs_step_fwd_finish", sp, stream)
+        # ---- node 2's share
+        hand.render_colors, hand.render_alphas, hand.last_ids, hand.scratch, hand.plan = render_colors, render_alphas, last_ids, scratch, plan
+        hand.grad_rows = fill[:n_elems * 16].view(C, N, 16) if fill is not None else None
+        hand.offsets, hand.flatten_ids = offsets, flatten_ids
+        # ---- this node's backward is _ProjectRows.backward: same saved tensors, same attributes
+        ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, opacities, radii, rows, sh_coeffs, sh_rest)
+        ctx.width, ctx.height, ctx.eps2d, ctx.cm, ctx.antialiased = width, height, eps2d, cm, bool(antialiased)
+        ctx.has_colors, ctx.sh_degree = colors is not None, (int(sh_degree) if sh_coeffs is not None else None)
+        ctx.prefill = prefill
+        ctx.mark_non_differentiable(radii, rows, tiles_per_gauss, isect_ids, flatten_ids, offsets)
+        ctx.set_materialize_grads(False)
+        R = W
+        return (radii, rows[..., R.ROW_MEAN2D:R.ROW_MEAN2D + 2], depths, rows[..., R.ROW_CONIC:R.ROW_CONIC + 3], rows[..., R.ROW_OPACITY],
+                rows[..., R.ROW_COLOR:R.ROW_COLOR + 3], rows, tiles_per_gauss, isect_ids, flatten_ids, offsets)
+
+    @staticmethod
+    def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_opac, v_colors, v_rows, *_ints):
+        g = W._ProjectRows.backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_opac, v_colors, v_rows)
+        # _ProjectRows' inputs: means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, sh_rest, ...
+        return (g[0], g[1], g[2], g[3], g[4], None, g[6], g[7], g[8], g[9], None, None, None)
+
+
+class _StepComposite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, cfg, hand):
+        width, height, tile_size, absgrad = cfg
+        ctx.grad_rows = hand.grad_rows
+        ctx.plan, ctx.strides = hand.plan, _ROW_STRIDES
+        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, None, hand.offsets, hand.flatten_ids, hand.render_alphas,
+                              hand.last_ids, hand.scratch, hand.render_colors)
+        ctx.width, ctx.height, ctx.tile_size, ctx.absgrad, ctx.deterministic = width, height, tile_size, absgrad, False
+        ctx.set_materialize_grads(False)
+        return hand.render_colors, hand.render_alphas
+
+    @staticmethod
+    def backward(ctx, v_render_colors, v_render_alphas):
+        g = W._RasterizeToPixels.backward(ctx, v_render_colors, v_render_alphas)
+        return (g[0], g[1], g[2], g[3], g[4], None, None)
+
+
+_GSHIFT = [0]
+
+
+def _init_consts() -> int:
+    _GSHIFT[0] = int(B.query("gs_isect_emit_group_shift"))
+    return _GSHIFT[0]
+
+
+def rasterize_step(means, covars, quats, scales, opacities, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
+                   antialiased, camera_model, row_colors, sh_coeffs, sh_rest, sh_degree, tile_size, backgrounds, absgrad):
+    """The fast path's forward; returns ``(render_colors, render_alphas, meta)`` with the reference's meta keys."""
+    C, N = viewmats.shape[0], means.shape[0]
+    tile_width, tile_height = math.ceil(width / float(tile_size)), math.ceil(height / float(tile_size))
+    needs_bwd = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (means, covars, quats, scales, opacities, row_colors, sh_coeffs, sh_rest, backgrounds))
+    hand = _Handover()
+    cfg = (int(width), int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip), bool(antialiased), camera_model,
+           sh_degree, int(tile_size), tile_width, tile_height, needs_bwd)
+    (radii, means2d, depths, conics, opac_cn, colors_cn, rows, tiles_per_gauss, isect_ids, flatten_ids, offsets) = _StepProject.apply(
+        means, covars, quats, scales, viewmats, Ks, opacities, row_colors, sh_coeffs, sh_rest, backgrounds, cfg, hand)
+    render_colors, render_alphas = _StepComposite.apply(means2d, conics, colors_cn, opac_cn, backgrounds,
+                                                        (int(width), int(height), int(tile_size), bool(absgrad)), hand)
+    meta = {
+        "camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
+        "opacities": opac_cn, "tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
+        "isect_ids": isect_ids, "flatten_ids": flatten_ids, "isect_offsets": offsets, "width": width, "height": height,
+        "tile_size": tile_size, "n_cameras": C,
+    }
+    return render_colors, render_alphas, meta

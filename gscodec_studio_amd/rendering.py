@@ -23,6 +23,7 @@ import torch
 from torch import Tensor
 from typing_extensions import Literal
 
+from . import _step
 from ._wrapper import (
     fully_fused_projection,
     project_rows,
@@ -67,6 +68,12 @@ def _camera_centers(viewmats: Tensor) -> Tensor:
     det = (c0 * r0).sum(-1, keepdim=True)
     inv_t = torch.stack([(r0 * t).sum(-1), (r1 * t).sum(-1), (r2 * t).sum(-1)], dim=-1) / det
     return -inv_t
+
+
+def _step_max_elems() -> int:
+    from ._wrapper import _PINNED_DIRECT_MAX
+
+    return _PINNED_DIRECT_MAX * 1024  # (the count kernel's block sums go straight into pinned memory up to this size)
 
 
 def rasterization(
@@ -211,6 +218,13 @@ def rasterization(
     prefill = None
     if use_rows:
         row_colors = colors if (sh_degree is None and colors.dim() == 2 and colors.shape[-1] == 3) else None
+        if _step.applicable(means, viewmats, colors, sh_degree, packed, distributed, render_mode, channel_chunk, deterministic,
+                            fuse_sh, row_colors) and C * N <= _step_max_elems():
+            # the common training call: the whole forward as two native calls around the one host read-back (_step.py)
+            return _step.rasterize_step(
+                means, covars, quats, scales, opacities, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
+                rasterize_mode == "antialiased", camera_model, row_colors, colors if fuse_sh else None, sh_rest,
+                sh_degree if fuse_sh else None, tile_size, backgrounds, absgrad)
         # the dense per-gaussian gradients of the projection node are allocated and zero-filled by the compositing
         # forward's side job; its backward then writes the visible gaussians' rows only (_wrapper.GradPrefill)
         prefill = GradPrefill() if torch.is_grad_enabled() else None

@@ -893,6 +893,77 @@ int32_t gs_dp_reduce_rows(uint64_t n_recv, uint32_t width, uint32_t world, const
                           const int32_t *map, int32_t map_offset, uint64_t umax, uint32_t n_valid, const int32_t *uidx, float scale,
                           int32_t *inv, float *acc, gs_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Native step driver (round 4): the launches of one rasterization() forward + backward of the common training case --
+ * unpacked batch, quats + scales or covars, shared SH coefficients (contiguous or split) or [N,3] colours, three render
+ * channels, fixed camera poses -- issued from ONE descriptor in three calls instead of nine operator calls from the host
+ * language.  Every launch goes through the operator entry points above: identical results; the operators stay the drop-in
+ * boundary, this is the executor around them (the counterpart of gsplat/rendering.py:28-582's orchestration).
+ *   gs_step_fwd_begin   gs_projection_rows_fwd -> [gs_presort_split] -> gs_isect_count_keys -> gs_presort_buckets |
+ *                       gs_sort_pairs_u64_i32_drop [-> gs_cumsum_i32 when group_prefix is given]
+ *   (the caller waits until every entry of block_sums -- pinned host memory it pre-set to -1 -- is >= 0, sets n_isects to
+ *    their sum, sizes the phase-2 buffers with gs_isect_finish_work_bytes / gs_rasterize_plan and allocates them)
+ *   gs_step_fwd_finish  gs_isect_finish_presorted -> gs_rasterize_fwd (zero-filling zero_fill as its side job)
+ *   gs_step_bwd         gs_rasterize_bwd (packed gradient rows) -> gs_projection_rows_bwd
+ * All pointers are device pointers except block_sums (pinned host).  Buffers: radii i32 [C,N], depths [C,N], rows [C,N,16]
+ * (64-byte aligned), tiles_per_gauss i32 [C,N], depth_keys i64 [C N], depth_vals i32 [C N], sort_temp
+ * (gs_presort_temp_bytes / gs_sort_temp_bytes of C N), splitters i64 [256] (bucketed), sorted_keys i64 [C N] (radix), perm
+ * i32 [C N], n_kept u32 [1], group_sums u32 [ceil(C N / 2^gs_isect_emit_group_shift())], group_prefix i64 of the same length
+ * + cumsum_scratch (both or neither), block_sums i32 [gs_isect_count_blocks(C N)]; isect_ids i64 / flatten_ids i32
+ * [n_isects], offsets i32 [C, tile_height, tile_width], work (gs_isect_finish_work_bytes), render_colors [C,H,W,3],
+ * render_alphas [C,H,W,1], last_ids i32 [C,H,W], scratch (plan.scratch_bytes; NULL: no checkpoints), zero_fill: the gradient rows
+ * [C N,16] (+ whatever else the caller wants zeroed behind them); backward: grad_rows = that zero-filled buffer, v_* outputs as
+ * in gs_projection_rows_bwd (NULL: not wanted). */
+typedef struct gs_step {
+    uint32_t C, N;
+    const float *means, *covars, *quats, *scales, *viewmats, *Ks, *opacities, *colors, *sh_coeffs, *sh_rest;
+    uint32_t sh_K, sh_degree;
+    int32_t width, height;
+    float eps2d, near_plane, far_plane, radius_clip;
+    int32_t camera_model, antialiased;
+    uint32_t tile_size, tile_width, tile_height;
+    int32_t bucketed; /* != 0: the bucketed depth pre-sort where gs_presort_applicable(C N) */
+    uint32_t lds_capacity;
+    uint32_t reserved0;
+    const float *backgrounds; /* [C,3] or NULL */
+    /* phase 1 */
+    int32_t *radii;
+    float *depths, *rows;
+    int32_t *tiles_per_gauss;
+    int64_t *depth_keys;
+    int32_t *depth_vals;
+    void *sort_temp;
+    uint64_t sort_temp_bytes;
+    int64_t *splitters, *sorted_keys;
+    int32_t *perm;
+    uint32_t *n_kept, *group_sums;
+    int64_t *group_prefix;
+    void *cumsum_scratch;
+    uint64_t cumsum_scratch_bytes;
+    int32_t *block_sums;
+    /* phase 2 */
+    uint64_t n_isects;
+    int64_t *isect_ids;
+    int32_t *flatten_ids, *offsets;
+    void *work;
+    uint64_t work_bytes;
+    float *render_colors, *render_alphas;
+    int32_t *last_ids;
+    gs_raster_plan plan;
+    void *scratch, *zero_fill;
+    uint64_t zero_fill_bytes;
+    /* backward */
+    const float *v_render_colors, *v_render_alphas;
+    int64_t vrc_pixel_stride, vrc_channel_stride;
+    float *grad_rows;
+    const float *v_depths;
+    float *v_means, *v_covars, *v_quats, *v_scales, *v_opacities, *v_colors, *v_sh, *v_sh_rest;
+    int32_t absgrad, outputs_prefilled, skip_projection_bwd, reserved1;
+} gs_step;
+int32_t gs_step_fwd_begin(gs_step *step, gs_stream_t stream);
+int32_t gs_step_fwd_finish(gs_step *step, gs_stream_t stream);
+int32_t gs_step_bwd(gs_step *step, gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
