@@ -59,7 +59,7 @@ class _Step(ctypes.Structure):  # gs_step of include/gsplat_hip.h (field for fie
         ("v_render_colors", _P), ("v_render_alphas", _P), ("vrc_pixel_stride", _I64), ("vrc_channel_stride", _I64),
         ("grad_rows", _P), ("v_depths", _P), ("v_means", _P), ("v_covars", _P), ("v_quats", _P), ("v_scales", _P),
         ("v_opacities", _P), ("v_colors", _P), ("v_sh", _P), ("v_sh_rest", _P),
-        ("absgrad", _I32), ("outputs_prefilled", _I32), ("skip_projection_bwd", _I32), ("reserved1", _I32),
+        ("absgrad", _I32), ("outputs_prefilled", _I32), ("skip_projection_bwd", _I32), ("finish_phase", _I32),
     ]
 
 
@@ -148,8 +148,21 @@ class _StepProject(torch.autograd.Function):
         sp = ctypes.addressof(s)
         with torch.cuda.device(dev):
             B.call("gs_step_fwd_begin", sp, stream)
-            # ---- buffers that do not depend on the intersection count are made while the GPU works
+            # ---- the one host sync: the count kernel's block sums land in pinned memory (-1 -> >= 0)
+            W._wait_event(W._SentinelEvent(pinned))
+            n_isects = int(pinned.sum(dtype=torch.int64))
+            W._PINNED_FREE.setdefault(n_sums, []).append(pinned)
             offsets = empty((C, tile_height, tile_width), dtype=i32, device=dev)
+            isect_ids = empty(n_isects, dtype=i64, device=dev)
+            flatten_ids = empty(n_isects, dtype=i32, device=dev)
+            wb = B.query("gs_isect_finish_work_bytes", n_isects)
+            work = empty(wb, dtype=u8, device=dev)
+            s.n_isects, s.isect_ids, s.flatten_ids, s.offsets, s.work, s.work_bytes = n_isects, ptr(isect_ids), ptr(flatten_ids), ptr(offsets), ptr(work), wb
+            # the binning half goes out at once (the GPU has been waiting for this call since the pre-sort ended); the
+            # compositing scratch is sized and allocated while it runs
+            s.finish_phase = 1
+            B.call("gs_step_fwd_finish", sp, stream)
+            # ---- the compositing buffers (made while the GPU is busy with the binning)
             render_colors = empty((C, height, width, 3), dtype=f32, device=dev)
             render_alphas = empty((C, height, width, 1), dtype=f32, device=dev)
             last_ids = empty((C, height, width), dtype=i32, device=dev)
@@ -175,21 +188,14 @@ class _StepProject(torch.autograd.Function):
                     prefill.carve(fill, n_elems * 16)
                 else:
                     prefill = None
-            # ---- the one host sync: the count kernel's block sums land in pinned memory (-1 -> >= 0)
-            W._wait_event(W._SentinelEvent(pinned))
-            n_isects = int(pinned.sum(dtype=torch.int64))
-            W._PINNED_FREE.setdefault(n_sums, []).append(pinned)
-            isect_ids = empty(n_isects, dtype=i64, device=dev)
-            flatten_ids = empty(n_isects, dtype=i32, device=dev)
-            wb = B.query("gs_isect_finish_work_bytes", n_isects)
-            work = empty(wb, dtype=u8, device=dev)
+            s.render_colors, s.render_alphas, s.last_ids = ptr(render_colors), ptr(render_alphas), ptr(last_ids)
+            if fill is not None:
+                s.zero_fill, s.zero_fill_bytes = ptr(fill), fill.numel() * 4
             plan, sbytes = W._raster_plan(C * tile_height * tile_width, n_isects, 3, forward_only=not needs_bwd)
             ctypes.memmove(ctypes.addressof(s.plan), plan, 64)
             scratch = empty(sbytes, dtype=u8, device=dev)
-            s.n_isects, s.isect_ids, s.flatten_ids, s.offsets, s.work, s.work_bytes = n_isects, ptr(isect_ids), ptr(flatten_ids), ptr(offsets), ptr(work), wb
-            s.render_colors, s.render_alphas, s.last_ids, s.scratch = ptr(render_colors), ptr(render_alphas), ptr(last_ids), ptr(scratch)
-            if fill is not None:
-                s.zero_fill, s.zero_fill_bytes = ptr(fill), fill.numel() * 4
+            s.scratch = ptr(scratch)
+            s.finish_phase = 2
             B.call("gs_step_fwd_finish", sp, stream)
         # ---- node 2's share
         hand.render_colors, hand.render_alphas, hand.last_ids, hand.scratch, hand.plan = render_colors, render_alphas, last_ids, scratch, plan

@@ -65,14 +65,18 @@ extern "C" int32_t gs_step_fwd_begin(gs_step *s, gs_stream_t stream) {
 
 extern "C" int32_t gs_step_fwd_finish(gs_step *s, gs_stream_t stream) {
     GS_CHECK_ARG(s != nullptr, "null descriptor");
-    GS_CHECK_ARG(s->offsets && s->render_colors && s->render_alphas && s->last_ids, "a phase-2 buffer is missing");
+    GS_CHECK_ARG(s->offsets && (s->finish_phase == 1 || (s->render_colors && s->render_alphas && s->last_ids)), "a phase-2 buffer is missing");
     GS_CHECK_ARG(s->n_isects == 0 || (s->isect_ids && s->flatten_ids && s->work), "a phase-2 buffer is missing");
     const uint32_t n_elems = s->C * s->N;
     const uint32_t n_tiles = s->tile_width * s->tile_height;
+    // finish_phase 1 / 2: the binning half and the compositing half as separate calls (the caller sizes the compositing
+    // scratch from n_isects while the GPU is busy with the binning); 0: both
+    if (s->finish_phase != 2)
     GS_STEP_TRY(gs_isect_finish_presorted(n_elems, s->N, s->n_isects, s->perm, s->n_kept, nullptr, s->rows, GS_ROW_FLOATS, s->radii, s->depths,
                                           s->tiles_per_gauss, s->group_sums, s->group_prefix, s->tile_size, s->tile_width, s->tile_height,
                                           floor_log2_plus1(n_tiles), floor_log2_plus1(s->C), s->C, s->isect_ids, s->flatten_ids, s->offsets,
                                           s->work, (size_t)s->work_bytes, stream));
+    if (s->finish_phase == 1) return 0;
     const uint32_t strides[4] = {GS_ROW_FLOATS, GS_ROW_FLOATS, GS_ROW_FLOATS, GS_ROW_FLOATS};
     GS_STEP_TRY(gs_rasterize_fwd(s->C, n_elems, (uint32_t)s->n_isects, 3, s->rows + GS_ROW_MEAN2D, s->rows + GS_ROW_CONIC, s->rows + GS_ROW_COLOR,
                                  s->rows + GS_ROW_OPACITY, strides, s->backgrounds, nullptr, (uint32_t)s->width, (uint32_t)s->height, s->tile_size,

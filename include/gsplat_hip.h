@@ -958,7 +958,8 @@ typedef struct gs_step {
     float *grad_rows;
     const float *v_depths;
     float *v_means, *v_covars, *v_quats, *v_scales, *v_opacities, *v_colors, *v_sh, *v_sh_rest;
-    int32_t absgrad, outputs_prefilled, skip_projection_bwd, reserved1;
+    int32_t absgrad, outputs_prefilled, skip_projection_bwd;
+    int32_t finish_phase; /* gs_step_fwd_finish: 0 = binning + compositing, 1 = binning only, 2 = compositing only */
 } gs_step;
 int32_t gs_step_fwd_begin(gs_step *step, gs_stream_t stream);
 int32_t gs_step_fwd_finish(gs_step *step, gs_stream_t stream);
