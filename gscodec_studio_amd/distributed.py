@@ -1036,7 +1036,7 @@ def _one_span(plist: List[Tensor], length: int) -> Optional[Tensor]:
     if any(g.untyped_storage().data_ptr() != st.data_ptr() for g in grads[1:]):
         return None
     lo = min(g.storage_offset() for g in grads)
-    if lo % 64 or any((g.storage_offset() - lo) % 64 for g in grads):
+    if any((g.storage_offset() - lo) % 64 for g in grads):  # (the carving pads every piece to 64 floats from the first one on)
         return None
     ends = sorted((g.storage_offset(), g.storage_offset() + g.numel()) for g in grads)
     pos = lo

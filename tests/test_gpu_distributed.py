@@ -193,7 +193,7 @@ def _span_reduce(rank, world, port, backend):
 
         def carve(value):
             buf = torch.zeros(length + 4096, device=dev)
-            off = 1024  # (something else -- the compositing gradient rows -- lies in front)
+            off = 1040  # (something else -- the compositing gradient rows, n_elems * 16 floats: NOT a multiple of 64 -- lies in front)
             buf[:off] = -7.0
             for p in params.values():
                 p.grad = buf[off:off + p.numel()].view(p.shape)
@@ -215,7 +215,7 @@ def _span_reduce(rank, world, port, backend):
                 want = 1.0
             assert torch.equal(p.grad, torch.full(shapes[k], want, device=dev)), (k, p.grad.flatten()[:3])
         if rank == 0:
-            assert bool((buf[:1024] == -7.0).all())
+            assert bool((buf[:1040] == -7.0).all())
         # subset, averaged -- then the pieces in between, summed
         if rank == 0:
             buf = carve(1.0)
