@@ -112,6 +112,9 @@ def parse():
     ap.add_argument("--quantize-reference-calls", action="store_true",
                     help="with --quantize: the reference trainer's exact call pattern (torch.exp / torch.sigmoid / torch.cat after the "
                          "hooks, simple_trainer.py:779-786) instead of the opt-in fused form (activate=True, colors=(sh0, shN))")
+    ap.add_argument("--ada-mask", action="store_true",
+                    help="with --quantize: the learnable shN mask of the reference's compression benchmark (--shN_ada_mask_opt, "
+                         "examples/benchmarks/compression/mcmc_tt_sim.sh:31-33) active in the hooks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scene-grid", type=int, default=0,
                     help="scene_grid of the cpu_baseline sample (0 = the bench scene itself: ~3 s per pass on 128 threads)")
@@ -332,7 +335,8 @@ def main():
     if args.quantize:
         from gscodec_studio_amd.compression_simulation import CompressionSimulation
 
-        sim = CompressionSimulation(entropy_model_enable=False, entropy_steps={})
+        sim = CompressionSimulation(entropy_model_enable=False, entropy_steps={}, device=dev, ada_mask_opt=args.ada_mask, ada_mask_step=0,
+                                    cap_max=N)
 
     last_meta = {}
     dense_grad = [None]  # set to a dense tensor of ones for the dense-image-gradient variant
@@ -363,12 +367,12 @@ def main():
             for p in params.values():
                 p.grad = None
             if sim is not None and args.quantize_reference_calls:
-                q, _ = sim.simulate_compression({k: params[k] for k in ("scales", "quats", "opacities", "sh0", "shN")}, step=0)
+                q, _ = sim.simulate_compression({k: params[k] for k in ("scales", "quats", "opacities", "sh0", "shN")}, step=1)
                 quats, scales, opac = q["quats"], torch.exp(q["scales"]), torch.sigmoid(q["opacities"])
                 sh = torch.cat([q["sh0"], q["shN"]], dim=1)
             elif sim is not None:
                 # the opt-in fused form: activations inside the quantizer kernels, sh0 / shN handed over as they are
-                q, _ = sim.simulate_compression({k: params[k] for k in ("scales", "quats", "opacities", "sh0", "shN")}, step=0,
+                q, _ = sim.simulate_compression({k: params[k] for k in ("scales", "quats", "opacities", "sh0", "shN")}, step=1,
                                                 activate=True)
                 quats, scales, opac, sh = q["quats"], q["scales"], q["opacities"], (q["sh0"], q["shN"])
             else:
@@ -539,7 +543,7 @@ def main():
             "config": {
                 "workload": f"BASELINE config 2: load_test_data(scene_grid={args.scene_grid}) -> {N} gaussians, "
                             f"SH degree {args.sh_degree}, {world}x1 camera {w['width']}x{w['height']}, packed=False, "
-                            f"tile 16, fwd + bwd of sum(render)" + ((", quantize hooks on" + (" (reference call pattern)" if args.quantize_reference_calls else " (fused activations, split SH)")) if args.quantize else ""),
+                            f"tile 16, fwd + bwd of sum(render)" + ((", quantize hooks on" + (" + learnable shN mask" if args.ada_mask else "") + (" (reference call pattern)" if args.quantize_reference_calls else " (fused activations, split SH" + (", mask applied by the renderer" if args.ada_mask else "") + ")")) if args.quantize else ""),
                 "visible": stats["V"], "n_isects": stats["I"], "native_step_driver": bool(step_driver_on), "parallelism": (f"camera-sharded dp{world}" + ((", RCCL sum of splat gradients" + (" (visible rows only)" if mode == "camera_sparse" else "")) if world > 1 else "")) if mode.startswith("camera")
                 else f"gaussian-sharded x{world}, 1 camera per rank, all-to-all of projected splats + dual for gradients"
                      + (" (visible rows only)" if mode == "gaussian" else " (all rows)"),

@@ -48,7 +48,8 @@ class _Step(ctypes.Structure):  # gs_step of include/gsplat_hip.h (field for fie
         ("sh_K", _U32), ("sh_degree", _U32), ("width", _I32), ("height", _I32),
         ("eps2d", _F), ("near_plane", _F), ("far_plane", _F), ("radius_clip", _F),
         ("camera_model", _I32), ("antialiased", _I32), ("tile_size", _U32), ("tile_width", _U32), ("tile_height", _U32),
-        ("bucketed", _I32), ("lds_capacity", _U32), ("reserved0", _U32),
+        ("bucketed", _I32), ("lds_capacity", _U32), ("sh_mask_binary", _I32),
+        ("sh_mask_logits", _P), ("v_sh_mask_logits", _P), ("sh_mask_temperature", _F), ("reserved0", _U32),
         ("backgrounds", _P),
         ("radii", _P), ("depths", _P), ("rows", _P), ("tiles_per_gauss", _P), ("depth_keys", _P), ("depth_vals", _P),
         ("sort_temp", _P), ("sort_temp_bytes", _U64), ("splitters", _P), ("sorted_keys", _P), ("perm", _P), ("n_kept", _P),
@@ -89,9 +90,10 @@ def _c(t: Optional[Tensor]) -> Optional[Tensor]:
 
 class _StepProject(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, sh_rest, backgrounds, cfg, hand):
+    def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, sh_rest, mask_logits, backgrounds, cfg, hand):
         (width, height, eps2d, near_plane, far_plane, radius_clip, antialiased, camera_model, sh_degree, tile_size, tile_width,
-         tile_height, needs_bwd) = cfg
+         tile_height, needs_bwd, mask_cfg) = cfg
+        mask_logits = _c(mask_logits)
         means, covars, quats, scales = _c(means), _c(covars), _c(quats), _c(scales)
         viewmats, Ks, opacities, colors = _c(viewmats), _c(Ks), _c(opacities), _c(colors)
         sh_coeffs, sh_rest, backgrounds = _c(sh_coeffs), _c(sh_rest), _c(backgrounds)
@@ -107,6 +109,8 @@ class _StepProject(torch.autograd.Function):
         s.opacities, s.colors, s.sh_coeffs, s.sh_rest, s.backgrounds = ptr(opacities), ptr(colors), ptr(sh_coeffs), ptr(sh_rest), ptr(backgrounds)
         s.sh_K = (sh_coeffs.shape[1] + (sh_rest.shape[1] if sh_rest is not None else 0)) if sh_coeffs is not None else 0
         s.sh_degree = int(sh_degree or 0)
+        if mask_logits is not None:
+            s.sh_mask_logits, s.sh_mask_temperature, s.sh_mask_binary = ptr(mask_logits), mask_cfg[0], int(mask_cfg[1])
         s.width, s.height, s.eps2d, s.near_plane, s.far_plane, s.radius_clip = width, height, eps2d, near_plane, far_plane, radius_clip
         cm = W._CAMERA_MODELS[camera_model]
         s.camera_model, s.antialiased = cm, int(antialiased)
@@ -206,6 +210,7 @@ class _StepProject(torch.autograd.Function):
         ctx.width, ctx.height, ctx.eps2d, ctx.cm, ctx.antialiased = width, height, eps2d, cm, bool(antialiased)
         ctx.has_colors, ctx.sh_degree = colors is not None, (int(sh_degree) if sh_coeffs is not None else None)
         ctx.prefill = prefill
+        ctx.mask = (mask_logits, float(mask_cfg[0]), bool(mask_cfg[1])) if mask_logits is not None else None
         ctx.mark_non_differentiable(radii, rows, tiles_per_gauss, isect_ids, flatten_ids, offsets)
         ctx.set_materialize_grads(False)
         R = W
@@ -216,7 +221,7 @@ class _StepProject(torch.autograd.Function):
     def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_opac, v_colors, v_rows, *_ints):
         g = W._ProjectRows.backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_opac, v_colors, v_rows)
         # _ProjectRows' inputs: means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, sh_rest, ...
-        return (g[0], g[1], g[2], g[3], g[4], None, g[6], g[7], g[8], g[9], None, None, None)
+        return (g[0], g[1], g[2], g[3], g[4], None, g[6], g[7], g[8], g[9], g[10], None, None, None)
 
 
 class _StepComposite(torch.autograd.Function):
@@ -246,17 +251,20 @@ def _init_consts() -> int:
 
 
 def rasterize_step(means, covars, quats, scales, opacities, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
-                   antialiased, camera_model, row_colors, sh_coeffs, sh_rest, sh_degree, tile_size, backgrounds, absgrad):
+                   antialiased, camera_model, row_colors, sh_coeffs, sh_rest, sh_degree, tile_size, backgrounds, absgrad, sh_mask=None):
     """The fast path's forward; returns ``(render_colors, render_alphas, meta)`` with the reference's meta keys."""
     C, N = viewmats.shape[0], means.shape[0]
     tile_width, tile_height = math.ceil(width / float(tile_size)), math.ceil(height / float(tile_size))
+    mask_logits = sh_mask[0] if sh_mask is not None else None
     needs_bwd = torch.is_grad_enabled() and any(
-        t is not None and t.requires_grad for t in (means, covars, quats, scales, opacities, row_colors, sh_coeffs, sh_rest, backgrounds))
+        t is not None and t.requires_grad for t in (means, covars, quats, scales, opacities, row_colors, sh_coeffs, sh_rest, backgrounds,
+                                                    mask_logits))
     hand = _Handover()
     cfg = (int(width), int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip), bool(antialiased), camera_model,
-           sh_degree, int(tile_size), tile_width, tile_height, needs_bwd)
+           sh_degree, int(tile_size), tile_width, tile_height, needs_bwd,
+           (float(sh_mask[1]), bool(sh_mask[2])) if sh_mask is not None else None)
     (radii, means2d, depths, conics, opac_cn, colors_cn, rows, tiles_per_gauss, isect_ids, flatten_ids, offsets) = _StepProject.apply(
-        means, covars, quats, scales, viewmats, Ks, opacities, row_colors, sh_coeffs, sh_rest, backgrounds, cfg, hand)
+        means, covars, quats, scales, viewmats, Ks, opacities, row_colors, sh_coeffs, sh_rest, mask_logits, backgrounds, cfg, hand)
     render_colors, render_alphas = _StepComposite.apply(means2d, conics, colors_cn, opac_cn, backgrounds,
                                                         (int(width), int(height), int(tile_size), bool(absgrad)), hand)
     meta = {

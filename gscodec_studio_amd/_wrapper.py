@@ -850,6 +850,7 @@ def project_rows(
     sh_degree: Optional[int] = None,
     sh_rest: Optional[Tensor] = None,  # SPLIT coefficients: ``sh_coeffs`` is the DC band [N, 1, 3], this [N, K-1, 3]
     prefill: Optional[GradPrefill] = None,  # see GradPrefill; hand the same object to ``rasterize_to_pixels``
+    sh_mask=None,  # (mask_logits with N elements, temperature, binary): the shN mask applied on the fly (split rows only)
 ):
     """``fully_fused_projection`` in ROW form, what ``rasterization`` uses for unpacked batches: the same projection, but
     every (camera, gaussian) pair gets one 64-byte splat row (include/gsplat_hip.h) that the compositing kernels fetch
@@ -890,9 +891,14 @@ def project_rows(
     else:
         assert sh_rest is None
     assert camera_model in _CAMERA_MODELS, camera_model
+    mask_logits, mask_cfg = None, None
+    if sh_mask is not None:
+        assert sh_rest is not None, "the shN mask needs split coefficients (sh_rest)"
+        mask_logits, mask_cfg = sh_mask[0], (float(sh_mask[1]), bool(sh_mask[2]))
+        assert mask_logits.numel() == N, (mask_logits.shape, N)
     return _ProjectRows.apply(means.contiguous(), covars, quats, scales, viewmats.contiguous(), Ks.contiguous(),
-                              opacities.contiguous(), colors, sh_coeffs, sh_rest, width, height, eps2d, near_plane, far_plane,
-                              radius_clip, antialiased, camera_model, sh_degree, prefill)
+                              opacities.contiguous(), colors, sh_coeffs, sh_rest, mask_logits, width, height, eps2d, near_plane, far_plane,
+                              radius_clip, antialiased, camera_model, sh_degree, prefill, mask_cfg)
 
 
 def _grad_rows_of(parts, shape, device):
@@ -942,12 +948,14 @@ def _grad_rows_of(parts, shape, device):
 
 class _ProjectRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, sh_rest, width, height, eps2d,
-                near_plane, far_plane, radius_clip, antialiased, camera_model="pinhole", sh_degree=None, prefill=None):
+    def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, sh_rest, mask_logits, width, height,
+                eps2d, near_plane, far_plane, radius_clip, antialiased, camera_model="pinhole", sh_degree=None, prefill=None,
+                mask_cfg=None):
         _require_gpu(means, "project_rows")
         means, covars, quats, scales = _f32c(means), _f32c(covars), _f32c(quats), _f32c(scales)
         viewmats, Ks, opacities, colors = _f32c(viewmats), _f32c(Ks), _f32c(opacities), _f32c(colors)
-        sh_coeffs, sh_rest = _f32c(sh_coeffs), _f32c(sh_rest)
+        sh_coeffs, sh_rest, mask_logits = _f32c(sh_coeffs), _f32c(sh_rest), _f32c(mask_logits)
+        m_temp, m_bin = mask_cfg if mask_logits is not None else (1.0, False)
         sh_K = (sh_coeffs.shape[1] + (sh_rest.shape[1] if sh_rest is not None else 0)) if sh_coeffs is not None else 0
         C, N = viewmats.shape[0], means.shape[0]
         dev = means.device
@@ -959,9 +967,10 @@ class _ProjectRows(torch.autograd.Function):
             B.call("gs_projection_rows_fwd", C, N, B.ptr(means), B.ptr(covars), B.ptr(quats), B.ptr(scales),
                    B.ptr(viewmats), B.ptr(Ks), int(width), int(height), float(eps2d), float(near_plane),
                    float(far_plane), float(radius_clip), cm, B.ptr(opacities), B.ptr(colors), int(bool(antialiased)),
-                   B.ptr(sh_coeffs), B.ptr(sh_rest), sh_K, int(sh_degree or 0),
+                   B.ptr(sh_coeffs), B.ptr(sh_rest), sh_K, int(sh_degree or 0), B.ptr(mask_logits), float(m_temp), int(m_bin),
                    B.ptr(radii), B.ptr(depths), B.ptr(rows), _stream(means))
         ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, opacities, radii, rows, sh_coeffs, sh_rest)
+        ctx.mask = (mask_logits, float(m_temp), bool(m_bin)) if mask_logits is not None else None
         ctx.width, ctx.height, ctx.eps2d, ctx.cm, ctx.antialiased = width, height, eps2d, cm, bool(antialiased)
         ctx.has_colors, ctx.sh_degree = colors is not None, (int(sh_degree) if sh_coeffs is not None else None)
         ctx.prefill = None
@@ -1005,7 +1014,9 @@ class _ProjectRows(torch.autograd.Function):
         def out(key, like):
             return pre[key] if prefilled else torch.empty_like(like)
 
-        v_sh = v_rest = v_means_add = None
+        v_sh = v_rest = v_means_add = v_mask = None
+        mask = getattr(ctx, "mask", None)
+        mask_args = (None, 1.0, 0, None)
         sh_args = (None, None, 0, 0, None, None)
         if sh_coeffs is not None:
             # the colour columns of the gradient rows go back through the SH evaluation (clamp gate from the colours in the
@@ -1017,6 +1028,12 @@ class _ProjectRows(torch.autograd.Function):
             v_rest = out("sh_rest", sh_rest) if sh_rest is not None else None
             fused = (_FUSE_SH_BWD and (3 * K) % 4 == 0 and not need[4] and v_sh.data_ptr() % 16 == 0 and (v_rest is None or v_rest.data_ptr() % 16 == 0)
                      and (sh_rest is not None or sh_coeffs.data_ptr() % 16 == 0))
+            if mask is not None:
+                if not fused:
+                    raise RuntimeError("project_rows: the fused shN mask needs the fused SH backward (3 K % 4 == 0, aligned rows, fixed poses)")
+                if need[10] and not mask[2]:
+                    v_mask = torch.empty_like(mask[0])
+                mask_args = (B.ptr(mask[0]), mask[1], int(mask[2]), B.ptr(v_mask))
             if fused:
                 sh_args = (B.ptr(sh_coeffs), B.ptr(sh_rest), K, ctx.sh_degree, B.ptr(v_sh), B.ptr(v_rest))
             else:
@@ -1039,14 +1056,15 @@ class _ProjectRows(torch.autograd.Function):
                    B.ptr(viewmats), B.ptr(Ks), int(ctx.width), int(ctx.height), float(ctx.eps2d), ctx.cm,
                    B.ptr(radii), B.ptr(rows), g_ptr, B.ptr(v_depths), B.ptr(opacities), int(ctx.antialiased),
                    B.ptr(v_means), B.ptr(v_covars), B.ptr(v_quats), B.ptr(v_scales), B.ptr(v_viewmats), B.ptr(v_opac),
-                   B.ptr(v_colors), B.ptr(v_means_add) if v_means is not None else None, *sh_args, int(prefilled), _stream(means))
+                   B.ptr(v_colors), B.ptr(v_means_add) if v_means is not None else None, *sh_args, *mask_args, int(prefilled),
+                   _stream(means))
         if sh_coeffs is not None:
             if not need[8]:
                 v_sh = None
             if not need[9]:
                 v_rest = None
         del g_keep
-        return (v_means, v_covars, v_quats, v_scales, v_viewmats, None, v_opac, v_colors, v_sh, v_rest) + (None,) * 10
+        return (v_means, v_covars, v_quats, v_scales, v_viewmats, None, v_opac, v_colors, v_sh, v_rest, v_mask) + (None,) * 11
 
 
 class _FullyFusedProjectionPacked(torch.autograd.Function):

@@ -104,6 +104,26 @@ class _MaskMean(torch.autograd.Function):
         return v_l.view(logits.shape), None
 
 
+class MaskedShN:
+    """``shN`` together with the mask that is to multiply it -- what ``AnnealingMask.fused`` (and ``simulate_compression(...,
+    activate=True)``) hand to ``rasterization(colors=(sh0, MaskedShN))`` instead of the masked tensor: the projection pass then
+    multiplies the coefficients as it loads them and its backward returns both gradients, so the 180 bytes per splat of masked
+    coefficients (and of their gradient) are never written or read (opt-in, not in the reference; same values).  Any consumer
+    that needs the tensor calls ``materialize()``."""
+
+    __slots__ = ("shN", "mask_logits", "temperature", "binary")
+
+    def __init__(self, shN: Tensor, mask_logits: Tensor, temperature: float, binary: bool):
+        self.shN, self.mask_logits, self.temperature, self.binary = shN, mask_logits, float(temperature), bool(binary)
+
+    @property
+    def shape(self):
+        return self.shN.shape
+
+    def materialize(self) -> Tensor:
+        return _ShNMask.apply(self.shN, self.mask_logits, self.temperature, self.binary)
+
+
 class AnnealingMask(nn.Module):
     """reference ada_mask.py:6-62"""
 
@@ -130,6 +150,13 @@ class AnnealingMask(nn.Module):
             self.current_iter = current_step
             return _ShNMask.apply(x, self.mask_logits, self.get_temperature(current_step), False)
         return _ShNMask.apply(x, self.mask_logits, 1.0, True)
+
+    def fused(self, x, current_step) -> MaskedShN:
+        """``forward`` without the multiplication: (x, logits, temperature, binary) for the renderer to apply (``MaskedShN``)."""
+        if self.training:
+            self.current_iter = current_step
+            return MaskedShN(x, self.mask_logits, self.get_temperature(current_step), False)
+        return MaskedShN(x, self.mask_logits, 1.0, True)
 
     @torch.no_grad()
     def get_binary_mask(self):

@@ -119,8 +119,9 @@ class _SimulationBase:
 
         ``activate=True`` (opt-in, not in the reference): ``new_splats["scales"]`` / ``["opacities"]`` come back ALREADY
         activated (exp / sigmoid, what the trainer applies next), evaluated inside the quantizer kernels -- two elementwise
-        passes and their backward passes less per step; together with ``rasterization(colors=(sh0, shN))`` this is the
-        fused form of the reference's ``simple_trainer.py:779-800``."""
+        passes and their backward passes less per step -- and, when the learnable shN mask applies, ``new_splats["shN"]`` is a
+        ``MaskedShN`` (the parameter + the mask) for ``rasterization(colors=(sh0, shN))`` to apply on the fly; together this is
+        the fused form of the reference's ``simple_trainer.py:779-800``."""
         self._activate = bool(activate)
         try:
             return self._simulate(splats, step)
@@ -214,7 +215,8 @@ class CompressionSimulation(_SimulationBase):
     def simulate_compression_shN(self, param, step, *_):
         """reference simulation.py:319-324: past ``ada_mask_step`` the learnable mask multiplies the higher bands."""
         if self.shN_ada_mask_opt and self.shN_ada_mask_strategy == "learnable" and step > self.shN_ada_mask_step:
-            param = self.shN_ada_mask(param, step)
+            # (activate=True, opt-in: the mask rides to the renderer, which applies it while it loads the coefficients)
+            param = self.shN_ada_mask.fused(param, step) if self._activate else self.shN_ada_mask(param, step)
         return param, None
 
     def shN_gradient_threshold(self, param: torch.nn.Parameter, step: int) -> None:

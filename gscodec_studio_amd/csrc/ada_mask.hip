@@ -24,12 +24,8 @@ namespace {
 
 constexpr int AM_SPLATS = 256; // splats per workgroup
 
-GS_DEV float am_sigmoid(float v) { return __fdiv_rn(1.f, __fadd_rn(1.f, expf(-v))); }
-
-GS_DEV float am_mask(float logit, float temperature, int binary) {
-    if (binary) return am_sigmoid(logit) >= 0.5f ? 1.f : 0.f; // ada_mask.py:39, 44
-    return am_sigmoid(__fdiv_rn(logit, temperature));         // ada_mask.py:37
-}
+GS_DEV float am_sigmoid(float v) { return gs_mask_sigmoid(v); }
+GS_DEV float am_mask(float logit, float temperature, int binary) { return gs_mask_value(logit, temperature, binary); } // ada_mask.py:37, 39, 44
 
 // e / row for e < 2^26, row < 2^6 .. 2^10: floor(e * ceil(2^32 / row) / 2^32) is exact while e * row < 2^32
 GS_DEV uint32_t am_div(uint32_t e, uint32_t magic) { return __umulhi(e, magic); }

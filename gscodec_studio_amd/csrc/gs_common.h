@@ -53,6 +53,16 @@ __device__ __forceinline__ uint32_t gs_bucket_of(const uint64_t *s_split, uint64
 }
 #endif
 
+// The shN mask of the compression-simulation hooks (ada_mask.hip; fused into the SH evaluation by projection.hip / sh.hip):
+// sigmoid(logit / T) in training mode, sigmoid(logit) >= 0.5 in eval mode -- IEEE operations in torch's order.
+#ifdef __HIPCC__
+__device__ __forceinline__ float gs_mask_sigmoid(float v) { return __fdiv_rn(1.f, __fadd_rn(1.f, expf(-v))); }
+__device__ __forceinline__ float gs_mask_value(float logit, float temperature, int binary) {
+    if (binary) return gs_mask_sigmoid(logit) >= 0.5f ? 1.f : 0.f;
+    return gs_mask_sigmoid(__fdiv_rn(logit, temperature));
+}
+#endif
+
 // radix_sort.hip: slot of the first pass's [256][n_blocks] digit histogram inside a sort's temp buffer (nullptr: not applicable)
 uint32_t *sort_first_hist_slot(uint64_t n, void *temp, size_t temp_bytes, uint32_t *n_blocks);
 

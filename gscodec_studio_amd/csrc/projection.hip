@@ -133,6 +133,11 @@ struct RowExtras {
     const float *sh_rest;   // split rows (sh_eval.h): sh_coeffs is [N,1,3], this [N,K-1,3]
     uint32_t sh_K, sh_degree;
     int sh_vec;             // coefficient rows are 16-byte aligned (dwordx4 loads)
+    // the shN mask of the compression-simulation hooks applied on the fly (split rows only): coefficients of the bands >= 1
+    // times gs_mask_value(logit[n]) -- the masked coefficients are never materialised
+    const float *sh_mask_logits; // [N] or NULL
+    float sh_mask_temp;
+    int sh_mask_binary;
 };
 
 // SHMODE: -1 = no SH colours; else 3 * degree + kind, kind 0 = coefficient rows read with scalar loads, 1 = 16-byte aligned
@@ -176,7 +181,13 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_fwd_kernel(
                 const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
                 const float *crow = rx.sh_coeffs + (size_t)n * (rx.sh_rest != nullptr ? 3u : rx.sh_K * 3);
                 const float *rest = rx.sh_rest != nullptr ? rx.sh_rest + (size_t)n * (rx.sh_K - 1) * 3 : nullptr;
-                if constexpr (SHMODE >= 0) sh_view_color<SHMODE / 3, (SHMODE % 3) == 1, (SHMODE % 3) == 2 ? 1 : 0>(dx, dy, dz, crow, rest, true, c0, c1, c2);
+                float bm = 1.f;
+                const float *bmp = nullptr;
+                if ((SHMODE % 3) == 2 && rx.sh_mask_logits != nullptr) { // (uniform)
+                    bm = gs_mask_value(rx.sh_mask_logits[n], rx.sh_mask_temp, rx.sh_mask_binary);
+                    bmp = &bm;
+                }
+                if constexpr (SHMODE >= 0) sh_view_color<SHMODE / 3, (SHMODE % 3) == 1, (SHMODE % 3) == 2 ? 1 : 0>(dx, dy, dz, crow, rest, true, c0, c1, c2, bmp);
                 else c0 = c1 = c2 = 0.f;
             } else {
                 const float *cp = rx.colors + 3 * (size_t)n;
@@ -370,6 +381,10 @@ struct RowGrads {
     uint32_t sh_K;
     float *v_sh;            // gradient of sh_coeffs
     float *v_sh_rest;       // gradient of sh_rest
+    const float *sh_mask_logits; // the forward's shN mask (split rows), or NULL
+    float sh_mask_temp;
+    int sh_mask_binary;
+    float *v_sh_mask_logits;     // [N] gradient of the logits (every entry written), or NULL
 };
 
 // SHDEG >= 0 (row form, shared coefficients, fixed poses): the SH backward of the colours the forward evaluated runs FIRST in
@@ -397,7 +412,8 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
     float shx = 0.f, shy = 0.f, shz = 0.f; // d/d means through the SH view directions
     if (SHDEG >= 0) {
         const ShView view = {means, viewmats, radii, 1, 1, nullptr, nullptr, nullptr, 0u, nullptr, rg.sh_rest, rg.v_sh_rest,
-                             (uint32_t)GS_ROW_FLOATS, rg.prefilled};
+                             (uint32_t)GS_ROW_FLOATS, rg.prefilled, rg.sh_mask_logits, rg.sh_mask_temp, rg.sh_mask_binary,
+                             rg.v_sh_mask_logits};
         bool any_sh;
         sh_bwd_lane<(SHDEG >= 0 ? SHDEG : 0), true, true>(C, N, rg.sh_K, n, in_range, nullptr, rg.sh_coeffs, nullptr, rg.grad_rows + GS_ROW_COLOR,
                                                           rg.v_sh, nullptr, view, rg.rows + GS_ROW_COLOR, (uint32_t)GS_ROW_FLOATS,
@@ -697,7 +713,8 @@ extern "C" int32_t gs_projection_rows_fwd(
     const float *scales, const float *viewmats, const float *Ks, int32_t image_width,
     int32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
     int32_t camera_model, const float *opacities, const float *colors, int32_t antialiased, const float *sh_coeffs, const float *sh_coeffs_rest,
-    uint32_t sh_K, uint32_t sh_degree, int32_t *radii, float *depths, float *rows, gs_stream_t stream) {
+    uint32_t sh_K, uint32_t sh_degree, const float *sh_mask_logits, float sh_mask_temperature, int32_t sh_mask_binary,
+    int32_t *radii, float *depths, float *rows, gs_stream_t stream) {
     if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && viewmats && Ks && radii && depths && rows, "null pointer");
     GS_CHECK_ARG((uintptr_t)rows % 64 == 0, "the row buffer must be 64-byte aligned");
@@ -710,7 +727,10 @@ extern "C" int32_t gs_projection_rows_fwd(
     dim3 grid(gs_div_up(N, GS_BLOCK), C);
     GS_CHECK_ARG(sh_coeffs_rest == nullptr || (sh_coeffs != nullptr && sh_K >= 2), "sh_coeffs_rest needs sh_coeffs and K >= 2");
     const int sh_vec = sh_coeffs != nullptr && (sh_coeffs_rest != nullptr || (uintptr_t)sh_coeffs % 16 == 0) && ((sh_K * 3u) % 4u == 0);
-    const RowExtras rx = {opacities, colors, antialiased, sh_coeffs, sh_coeffs_rest, sh_K, sh_degree, sh_vec};
+    GS_CHECK_ARG(sh_mask_logits == nullptr || sh_coeffs_rest != nullptr, "the shN mask needs split coefficient rows (sh_coeffs_rest)");
+    GS_CHECK_ARG(sh_mask_logits == nullptr || sh_mask_binary || sh_mask_temperature > 0.f, "the mask temperature must be positive");
+    const RowExtras rx = {opacities, colors, antialiased, sh_coeffs, sh_coeffs_rest, sh_K, sh_degree, sh_vec, sh_mask_logits, sh_mask_temperature,
+                          sh_mask_binary};
     const int shmode = sh_coeffs == nullptr ? -1 : (int)sh_degree * 3 + (sh_coeffs_rest != nullptr ? 2 : (sh_vec ? 1 : 0));
 #define GS_ROWS_LAUNCH(M)                                                                                                        \
     case M:                                                                                                                      \
@@ -735,7 +755,8 @@ extern "C" int32_t gs_projection_rows_bwd(
     const float *grad_rows, const float *v_depths, const float *opacities, int32_t antialiased, float *v_means,
     float *v_covars, float *v_quats, float *v_scales, float *v_viewmats, float *v_opacities, float *v_colors,
     const float *v_means_add, const float *sh_coeffs, const float *sh_coeffs_rest, uint32_t sh_K, uint32_t sh_degree,
-    float *v_sh_coeffs, float *v_sh_coeffs_rest, int32_t outputs_prefilled, gs_stream_t stream) {
+    float *v_sh_coeffs, float *v_sh_coeffs_rest, const float *sh_mask_logits, float sh_mask_temperature, int32_t sh_mask_binary,
+    float *v_sh_mask_logits, int32_t outputs_prefilled, gs_stream_t stream) {
     if (N == 0) return 0;
     GS_CHECK_ARG(means && viewmats && Ks && radii && rows && grad_rows, "null pointer");
     GS_CHECK_ARG((uintptr_t)rows % 16 == 0 && (uintptr_t)grad_rows % 16 == 0, "row buffers must be 16-byte aligned");
@@ -743,7 +764,10 @@ extern "C" int32_t gs_projection_rows_bwd(
                  "exactly one of covars / (quats, scales) must be given");
     GS_CHECK_ARG(!antialiased || opacities != nullptr, "antialiased needs the opacities");
     dim3 grid(gs_div_up(N, GS_BLOCK));
-    RowGrads rg = {rows, grad_rows, opacities, v_opacities, v_colors, antialiased, outputs_prefilled != 0, nullptr, nullptr, 0u, nullptr, nullptr};
+    RowGrads rg = {rows, grad_rows, opacities, v_opacities, v_colors, antialiased, outputs_prefilled != 0, nullptr, nullptr, 0u, nullptr, nullptr,
+                   nullptr, 1.f, 0, nullptr};
+    GS_CHECK_ARG(sh_mask_logits == nullptr || (sh_coeffs != nullptr && sh_coeffs_rest != nullptr), "the shN mask needs the fused SH backward with split rows");
+    GS_CHECK_ARG(v_sh_mask_logits == nullptr || (sh_mask_logits != nullptr && !sh_mask_binary), "v_sh_mask_logits needs the (training-mode) mask");
     const float *nul = nullptr;
     if (sh_coeffs != nullptr) {
         // the SH backward in the same pass: the vectorised row form only (what gs_sh_view_bwd stages through LDS), fixed poses
@@ -754,6 +778,8 @@ extern "C" int32_t gs_projection_rows_bwd(
                          (sh_coeffs_rest != nullptr ? sh_K >= 2 : (uintptr_t)sh_coeffs % 16 == 0),
                      "fused SH backward needs 3 K % 4 == 0 and 16-byte aligned rows (gs_projection_rows_bwd_sh_ok); call gs_sh_view_bwd instead");
         rg.sh_coeffs = sh_coeffs; rg.sh_rest = sh_coeffs_rest; rg.sh_K = sh_K; rg.v_sh = v_sh_coeffs; rg.v_sh_rest = v_sh_coeffs_rest;
+        rg.sh_mask_logits = sh_mask_logits; rg.sh_mask_temp = sh_mask_temperature; rg.sh_mask_binary = sh_mask_binary;
+        rg.v_sh_mask_logits = v_sh_mask_logits;
 #define GS_ROWS_BWD_SH(D)                                                                                                        \
     case D:                                                                                                                      \
         hipLaunchKernelGGL((projection_bwd_kernel<false, D>), grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N, means, covars,  \
@@ -794,7 +820,7 @@ extern "C" int32_t gs_projection_bwd(
     GS_CHECK_ARG((v_compensations == nullptr) || (compensations != nullptr),
                  "v_compensations given without compensations");
     dim3 grid(gs_div_up(N, GS_BLOCK));
-    const RowGrads rg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0u, nullptr, nullptr};
+    const RowGrads rg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 1.f, 0, nullptr};
     if (v_viewmats != nullptr) {
         hipLaunchKernelGGL(projection_bwd_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, C, N,
                            means, covars, quats, scales, viewmats, Ks, image_width, image_height, eps2d,

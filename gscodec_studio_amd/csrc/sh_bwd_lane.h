@@ -105,6 +105,13 @@ struct ShView {
                              // they are columns of the splat rows (include/gsplat_hip.h)
     int prefilled;           // bwd, shared coefficients: v_coeffs (/ v_coeffs_rest) hold zeros already -- rows of gaussians no
                              // camera sees are not stored, v_means is only written for the others
+    // the shN mask applied by the forward (split rows): effective coefficients of the bands >= 1 = raw * mask.  bwd: the
+    // gradient of the raw coefficients is v_effective * mask, the logit's (v_effective . raw) * mask (1 - mask) / T, reduced
+    // in the lane (over cameras and coefficients) in the order of the stand-alone mask kernel
+    const float *mask_logits; // [N] or NULL
+    float mask_temp;
+    int mask_binary;
+    float *v_mask_logits;     // [N] (every entry written) or NULL
 };
 
 GS_DEV bool sh_active(const uint8_t *masks, const ShView &v, size_t e) {
@@ -159,6 +166,8 @@ GS_DEV void sh_bwd_lane(
     float cf[NB * 3];
     bool have_cf = false;
     any_on = false;
+    const bool masked = SHARED && split && view.mask_logits != nullptr; // (uniform)
+    const float band_mask = (masked && in_range) ? gs_mask_value(view.mask_logits[n], view.mask_temp, view.mask_binary) : 1.f;
     for (uint32_t c = 0; c < C; ++c) {
         size_t e = (size_t)c * N + n;
         bool on = in_range && sh_active(masks, view, e);
@@ -214,8 +223,15 @@ GS_DEV void sh_bwd_lane(
                     have_cf = true;
                 }
                 float w[NB];
+                if (masked) { // (cf holds the RAW coefficients: the effective ones are rounded products, as the forward used them)
+                    w[0] = cf[0] * vr + cf[1] * vg + cf[2] * vb;
+#pragma unroll
+                    for (int k = 1; k < NB; ++k)
+                        w[k] = __fmul_rn(cf[3 * k], band_mask) * vr + __fmul_rn(cf[3 * k + 1], band_mask) * vg + __fmul_rn(cf[3 * k + 2], band_mask) * vb;
+                } else {
 #pragma unroll
                 for (int k = 0; k < NB; ++k) w[k] = cf[3 * k] * vr + cf[3 * k + 1] * vg + cf[3 * k + 2] * vb;
+                }
                 float vx, vy, vz;
                 sh_basis_grad_contract<DEG>(x, y, z, w, vx, vy, vz);
                 float dot = vx * x + vy * y + vz * z;
@@ -228,6 +244,22 @@ GS_DEV void sh_bwd_lane(
             }
             vmx += gx; vmy += gy; vmz += gz;
         }
+    }
+    if (masked) {
+        // acc holds d/d (effective coefficients), summed over the cameras
+        if (view.v_mask_logits != nullptr && in_range) {
+            float v_logit = 0.f;
+            if (any_on) {
+                if (!have_cf) load_coeff_row<NB * 3, VEC>(coeffs + 3 * (size_t)n, view.coeffs_rest + (size_t)n * (K - 1) * 3, cf);
+                float dot = 0.f;
+#pragma unroll
+                for (int i = 3; i < NB * 3; ++i) dot = __fadd_rn(dot, __fmul_rn(acc[i], cf[i]));
+                v_logit = __fdiv_rn(__fmul_rn(__fmul_rn(dot, __fsub_rn(1.f, band_mask)), band_mask), view.mask_temp);
+            }
+            view.v_mask_logits[n] = v_logit;
+        }
+#pragma unroll
+        for (int i = 3; i < NB * 3; ++i) acc[i] = __fmul_rn(acc[i], band_mask);
     }
     if (SHARED) {
         // Every lane holds one 4*NV-float gradient row; rows of neighbouring lanes are row_len floats apart, so

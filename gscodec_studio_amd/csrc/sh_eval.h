@@ -124,9 +124,11 @@ GS_DEV void load_coeff_row(const float *__restrict__ row, const float *__restric
 // ([K,3], the first (DEG+1)^2 bands are used): the arithmetic of sh_fwd_kernel's view mode, shared so that the projection's
 // fused colour is bit-identical to gs_sh_view_fwd's.
 // LAYOUT: 0 = one row (VEC: 16-byte aligned), 1 = split rows, -1 = decided at run time by `rest`
+// band_mask (optional): the coefficients of the bands >= 1 are multiplied by *band_mask first (the shN mask of the
+// compression-simulation hooks, one rounding per coefficient: what the stand-alone mask kernel would have stored).
 template <int DEG, bool VEC, int LAYOUT = -1>
 GS_DEV void sh_view_color(float dx, float dy, float dz, const float *__restrict__ row, const float *__restrict__ rest, bool clamp_half,
-                          float &r, float &g, float &b) {
+                          float &r, float &g, float &b, const float *band_mask = nullptr) {
     constexpr int NB = ShDim<DEG>::NB;
     float Y[NB];
     if (DEG >= 1) {
@@ -139,6 +141,11 @@ GS_DEV void sh_view_color(float dx, float dy, float dz, const float *__restrict_
     if (LAYOUT == 0) load_floats<NB * 3, VEC>(row, cf);
     else if (LAYOUT == 1) load_coeff_row_split<NB * 3>(row, rest, cf);
     else load_coeff_row<NB * 3, VEC>(row, rest, cf);
+    if (band_mask != nullptr) {
+        const float m = *band_mask;
+#pragma unroll
+        for (int i = 3; i < NB * 3; ++i) cf[i] = __fmul_rn(cf[i], m);
+    }
     r = g = b = 0.f;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {

@@ -39,7 +39,8 @@ extern "C" int32_t gs_step_fwd_begin(gs_step *s, gs_stream_t stream) {
     const uint32_t n_elems = s->C * s->N;
     GS_STEP_TRY(gs_projection_rows_fwd(s->C, s->N, s->means, s->covars, s->quats, s->scales, s->viewmats, s->Ks, s->width, s->height, s->eps2d,
                                        s->near_plane, s->far_plane, s->radius_clip, s->camera_model, s->opacities, s->colors, s->antialiased,
-                                       s->sh_coeffs, s->sh_rest, s->sh_K, s->sh_degree, s->radii, s->depths, s->rows, stream));
+                                       s->sh_coeffs, s->sh_rest, s->sh_K, s->sh_degree, s->sh_mask_logits, s->sh_mask_temperature, s->sh_mask_binary,
+                                       s->radii, s->depths, s->rows, stream));
     const int32_t hist_ready = gs_sort_first_hist_applicable(n_elems);
     const bool bucketed = s->bucketed && gs_presort_applicable(n_elems);
     GS_CHECK_ARG(!bucketed || s->splitters != nullptr, "the bucketed pre-sort needs the splitter table");
@@ -100,6 +101,7 @@ extern "C" int32_t gs_step_bwd(gs_step *s, gs_stream_t stream) {
         GS_STEP_TRY(gs_projection_rows_bwd(s->C, s->N, s->means, s->covars, s->quats, s->scales, s->viewmats, s->Ks, s->width, s->height, s->eps2d,
                                            s->camera_model, s->radii, s->rows, s->grad_rows, s->v_depths, s->opacities, s->antialiased, s->v_means,
                                            s->v_covars, s->v_quats, s->v_scales, nullptr, s->v_opacities, s->v_colors, nullptr, s->sh_coeffs,
-                                           s->sh_rest, s->sh_K, s->sh_degree, s->v_sh, s->v_sh_rest, s->outputs_prefilled, stream));
+                                           s->sh_rest, s->sh_K, s->sh_degree, s->v_sh, s->v_sh_rest, s->sh_mask_logits, s->sh_mask_temperature,
+                                           s->sh_mask_binary, s->v_sh_mask_logits, s->outputs_prefilled, stream));
     return 0;
 }

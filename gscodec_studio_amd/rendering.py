@@ -24,6 +24,7 @@ from torch import Tensor
 from typing_extensions import Literal
 
 from . import _step
+from .compression_simulation.ada_mask import MaskedShN
 from ._wrapper import (
     fully_fused_projection,
     project_rows,
@@ -147,14 +148,25 @@ def rasterization(
     # (reference examples/simple_trainer.py:779-786 concatenates them before every render: 193 MB each way at 1 M splats, and
     # autograd splits the gradient again).  The fused route takes the two tensors as they are; every other route gets the cat.
     sh_rest = None
+    sh_mask = None
     if isinstance(colors, (tuple, list)):
         assert sh_degree is not None and len(colors) == 2, "a (sh0, shN) pair needs sh_degree"
         sh0, shN = colors
+        masked = shN if isinstance(shN, MaskedShN) else None  # shN + the mask to apply to it (compression_simulation.ada_mask)
+        if masked is not None:
+            shN = masked.shN
         assert sh0.shape == (N, 1, 3) and shN.dim() == 3 and shN.shape[0] == N and shN.shape[2] == 3, (sh0.shape, shN.shape)
         split_ok = ((not packed) and (not distributed) and means.is_cuda and viewmats.is_cuda and not viewmats.requires_grad
                     and shN.shape[1] >= 1)
+        # the fused mask rides on the fused SH backward: vectorisable rows (3 K % 4 == 0), which covers degrees 1 and 3
+        mask_ok = masked is None or (split_ok and (3 * (1 + shN.shape[1])) % 4 == 0 and shN.is_contiguous()
+                                     and masked.mask_logits.numel() == N)
+        if masked is not None and not mask_ok:
+            shN, masked = masked.materialize(), None
         if split_ok:
             colors, sh_rest = sh0, shN
+            if masked is not None:
+                sh_mask = (masked.mask_logits, masked.temperature, masked.binary)
         else:
             colors = torch.cat([sh0, shN], dim=1)
     # the compositing kernels map a tile onto wave64 quadrants of 8x8 pixels: tiles up to 16x16 (the reference launches
@@ -224,7 +236,7 @@ def rasterization(
             return _step.rasterize_step(
                 means, covars, quats, scales, opacities, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
                 rasterize_mode == "antialiased", camera_model, row_colors, colors if fuse_sh else None, sh_rest,
-                sh_degree if fuse_sh else None, tile_size, backgrounds, absgrad)
+                sh_degree if fuse_sh else None, tile_size, backgrounds, absgrad, sh_mask=sh_mask)
         # the dense per-gaussian gradients of the projection node are allocated and zero-filled by the compositing
         # forward's side job; its backward then writes the visible gaussians' rows only (_wrapper.GradPrefill)
         prefill = GradPrefill() if torch.is_grad_enabled() else None
@@ -234,7 +246,7 @@ def rasterization(
             antialiased=(rasterize_mode == "antialiased"), camera_model=camera_model,
             # shared SH coefficients and fixed poses: the colours are evaluated by the projection pass itself
             sh_coeffs=colors if fuse_sh else None, sh_degree=sh_degree if fuse_sh else None, sh_rest=sh_rest,
-            prefill=prefill,
+            prefill=prefill, sh_mask=sh_mask,
         )
         camera_ids, gaussian_ids = None, None
         opacity_rider = False

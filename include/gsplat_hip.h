@@ -158,6 +158,11 @@ int32_t gs_projection_rows_fwd(
     const float *opacities, const float *colors, int32_t antialiased,
     const float *sh_coeffs, const float *sh_coeffs_rest /* NULL or split rows, as in gs_sh_view_fwd */, uint32_t sh_K,
     uint32_t sh_degree,
+    const float *sh_mask_logits /* NULL, or [N] (split rows only): the shN mask of the compression-simulation hooks
+                                   (gs_shn_mask_fwd) applied on the fly -- the coefficients of the bands >= 1 are
+                                   multiplied by sigmoid(logit / temperature) (binary: sigmoid(logit) >= 0.5) as they are
+                                   loaded, the masked coefficients are never materialised; bit-identical to masking first */,
+    float sh_mask_temperature, int32_t sh_mask_binary,
     int32_t *radii, /* [C,N] */
     float *depths,  /* [C,N] */
     float *rows,    /* [C,N,16] */
@@ -186,6 +191,8 @@ int32_t gs_projection_rows_bwd(
     const float *v_means_add, /* [N,3] or NULL, as in gs_projection_bwd */
     const float *sh_coeffs, const float *sh_coeffs_rest, uint32_t sh_K, uint32_t sh_degree,
     float *v_sh_coeffs, float *v_sh_coeffs_rest,
+    const float *sh_mask_logits, float sh_mask_temperature, int32_t sh_mask_binary, /* the forward's mask (or NULL, 0, 0) */
+    float *v_sh_mask_logits /* [N] or NULL: gradient of the logits, every entry written (training-mode mask only) */,
     int32_t outputs_prefilled,
     gs_stream_t stream);
 
@@ -924,6 +931,10 @@ typedef struct gs_step {
     uint32_t tile_size, tile_width, tile_height;
     int32_t bucketed; /* != 0: the bucketed depth pre-sort where gs_presort_applicable(C N) */
     uint32_t lds_capacity;
+    int32_t sh_mask_binary;
+    const float *sh_mask_logits; /* the shN mask fused into the SH evaluation (split rows), or NULL */
+    float *v_sh_mask_logits;     /* backward: [N] or NULL */
+    float sh_mask_temperature;
     uint32_t reserved0;
     const float *backgrounds; /* [C,3] or NULL */
     /* phase 1 */

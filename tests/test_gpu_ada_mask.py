@@ -263,3 +263,75 @@ def test_full_size_properties():
     changed = (g != g0).any(-1).any(-1)
     assert torch.equal(changed | edge, kill | edge)
     assert bool((g[kill & ~edge] == 0).all()) and torch.equal(g[~kill & ~edge], g0[~kill & ~edge])
+
+
+@pytest.mark.parametrize("step_driver", [True, False])
+@pytest.mark.parametrize("training", [True, False])
+def test_mask_fused_into_the_renderer_equals_masking_first(step_driver, training):
+    """``rasterization(colors=(sh0, MaskedShN))`` -- the mask applied by the projection pass while it loads the coefficients,
+    both gradients from its backward -- against masking first (``AnnealingMask.forward``) and rendering the masked tensor: the
+    same roundings in the same order, so the image is identical and the gradients agree to the order of the compositing
+    backward's float atomics."""
+    from gscodec_studio_amd import _step, rasterization
+    from gscodec_studio_amd.compression_simulation import AnnealingMask
+
+    g = garden(2500, scale_mult=4.0)
+    n = len(g["means"])
+    sh = garden_sh(g["rgb"])
+    gen = torch.Generator(device=dev()).manual_seed(5)
+    m = AnnealingMask(input_shape=[n, 1, 1], device=dev(), annealing_start_iter=10)
+    with torch.no_grad():
+        m.mask_logits.copy_(torch.randn(n, 1, 1, device=dev(), generator=gen) * 2)
+    m.train(training)
+    vm, Ks = T(g["viewmats"][:2]), T(g["Ks"][:2])
+    target = torch.rand(2, g["height"], g["width"], 3, device=dev(), generator=gen)
+    res = {}
+    prev = _step.ENABLED
+    _step.ENABLED = step_driver
+    try:
+        for fused in (True, False):
+            P = {k: T(v).requires_grad_(True) for k, v in dict(means=g["means"], quats=g["quats"], scales=g["scales"], opacities=g["opacities"],
+                                                              sh0=sh[:, :1], shN=sh[:, 1:]).items()}
+            m.mask_logits.grad = None
+            shN = m.fused(P["shN"], 25) if fused else m(P["shN"], 25)
+            rc, ra, meta = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], (P["sh0"], shN), vm, Ks, g["width"], g["height"],
+                                         sh_degree=3, packed=False)
+            ((rc - target) ** 2).sum().backward()
+            res[fused] = (rc.detach(), {k: p.grad for k, p in P.items()}, None if m.mask_logits.grad is None else m.mask_logits.grad.clone())
+    finally:
+        _step.ENABLED = prev
+    (rc_f, g_f, l_f), (rc_u, g_u, l_u) = res[True], res[False]
+    assert torch.equal(rc_f, rc_u)
+    for k in g_f:
+        den = float(g_u[k].norm()) + 1e-30
+        assert float((g_f[k] - g_u[k]).norm()) <= 3e-4 * den, (k, float((g_f[k] - g_u[k]).norm()) / den)
+    if training:
+        assert l_f is not None and l_u is not None and l_f.shape == m.mask_logits.shape
+        assert float((l_f - l_u).norm()) <= 3e-4 * float(l_u.norm()), float((l_f - l_u).norm()) / float(l_u.norm())
+        assert float(l_u.abs().max()) > 0
+    else:
+        assert l_f is None and l_u is None
+
+
+def test_simulation_activate_hands_the_mask_to_the_renderer():
+    """simulate_compression(activate=True) past ada_mask_step: new_splats["shN"] is a MaskedShN that rasterization() takes in
+    the (sh0, shN) pair; degree-2 coefficients (27 floats per splat: not vectorisable) fall back to materialising the mask."""
+    from gscodec_studio_amd import rasterization
+    from gscodec_studio_amd.compression_simulation import CompressionSimulation
+    from gscodec_studio_amd.compression_simulation.ada_mask import MaskedShN
+
+    g = garden(1200, scale_mult=4.0)
+    n = len(g["means"])
+    for K, deg in ((16, 3), (9, 2)):
+        sh = garden_sh(g["rgb"], K=K)
+        sim = CompressionSimulation(False, "factorized_model", ENTROPY_STEPS, dev(), True, 2, "learnable", cap_max=n)
+        splats = {"means": T(g["means"]), "scales": T(np.log(g["scales"])), "quats": T(g["quats"]),
+                  "opacities": torch.logit(T(g["opacities"]).clamp(0.01, 0.99)), "sh0": T(sh[:, :1]), "shN": T(sh[:, 1:])}
+        splats = {k: v.requires_grad_(True) for k, v in splats.items()}
+        new, _ = sim.simulate_compression(splats, step=7, activate=True)
+        assert isinstance(new["shN"], MaskedShN) and new["shN"].shN is splats["shN"]
+        rc, _, _ = rasterization(new["means"], new["quats"], new["scales"], new["opacities"], (new["sh0"], new["shN"]), T(g["viewmats"][:1]),
+                                 T(g["Ks"][:1]), g["width"], g["height"], sh_degree=deg, packed=False)
+        (rc.sum() + sim.shN_ada_mask.get_sparsity_loss()).backward()
+        assert splats["shN"].grad is not None and sim.shN_ada_mask.mask_logits.grad is not None
+        assert float(sim.shN_ada_mask.mask_logits.grad.abs().sum()) > 0 and bool(torch.isfinite(splats["shN"].grad).all())
