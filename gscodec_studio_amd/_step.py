@@ -133,7 +133,7 @@ class _StepProject(torch.autograd.Function):
         split = empty(256, dtype=i64, device=dev) if bucketed else None
         ko = None if bucketed else empty(n_elems, dtype=i64, device=dev)
         gpre = scratch1 = None
-        if n_groups > 8192:
+        if n_groups > _PREFIX_FROM[0]:
             gpre = empty(n_groups, dtype=i64, device=dev)
             sb1 = B.query("gs_cumsum_scratch_bytes", n_groups)
             scratch1 = empty(sb1, dtype=u8, device=dev)
@@ -178,7 +178,7 @@ class _StepProject(torch.autograd.Function):
                 # (_wrapper.GradPrefill: the compositing forward zero-fills it as a side job)
                 prefill = W.GradPrefill()
                 req = []
-                for key, t, flag in (("means", means, need[0]), ("covars", covars, need[1]), ("quats", quats, need[2]),
+                for key, t, flag in () if not W.PREFILL_ENABLED else (("means", means, need[0]), ("covars", covars, need[1]), ("quats", quats, need[2]),
                                      ("scales", scales, need[3]), ("opacities", opacities, need[6]), ("colors", colors, need[7]),
                                      ("sh", sh_coeffs, need[8]), ("sh_rest", sh_rest, need[9])):
                     if t is not None and flag:
@@ -242,11 +242,12 @@ class _StepComposite(torch.autograd.Function):
         return (g[0], g[1], g[2], g[3], g[4], None, None)
 
 
-_GSHIFT = [0]
+_GSHIFT, _PREFIX_FROM = [0], [8192]
 
 
 def _init_consts() -> int:
     _GSHIFT[0] = int(B.query("gs_isect_emit_group_shift"))
+    _PREFIX_FROM[0] = int(B.query("gs_isect_emit_prefix_from_groups"))
     return _GSHIFT[0]
 
 

@@ -791,6 +791,12 @@ class _FullyFusedProjection(torch.autograd.Function):
 _FUSE_SH_BWD = os.environ.get("GS_FUSE_SH_BWD", "1") == "1"  # (A/B switch: 0 = gs_sh_view_bwd + gs_projection_rows_bwd as two launches)
 
 
+# GS_GRAD_PREFILL=0: the per-gaussian gradients are allocated by the projection backward itself instead of behind the
+# compositing gradient rows (they then do not keep the C * N * 64-byte row buffer alive while they are held as .grad, and a
+# forward under grad mode that never runs backward does not zero-fill ~236 B per gaussian for nothing; ~3 % slower per step)
+PREFILL_ENABLED = os.environ.get("GS_GRAD_PREFILL", "1") != "0"
+
+
 class GradPrefill:
     """Hand-over between the two autograd nodes of ONE ``rasterization()`` call (not in the reference).
 
@@ -1332,7 +1338,7 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                     B.call("gs_sort_pairs_u64_i32_drop", n_elems, B.ptr(dkeys), B.ptr(dvals), B.ptr(ko), B.ptr(perm), 32, 64,
                            0x7FFFFFFF, B.ptr(n_kept), B.ptr(temp), tb, hist_ready, B.ptr(tiles_per_gauss), B.ptr(gsums), gshift, st)
                 gpre = None
-                if gsums.numel() > 8192:  # many groups: one prefix sum over them instead of a quadratic number of loads
+                if gsums.numel() > int(B.query("gs_isect_emit_prefix_from_groups")):  # many groups: one prefix sum over them
                     gpre = torch.empty(gsums.numel(), dtype=torch.int64, device=dev)
                     sb = B.query("gs_cumsum_scratch_bytes", gsums.numel())
                     scratch = torch.empty(sb, dtype=torch.uint8, device=dev)

@@ -600,6 +600,9 @@ extern "C" int32_t gs_isect_emit_compact(
 }
 
 extern "C" uint32_t gs_isect_emit_group_shift(void) { return EMIT_SCAN_SHIFT; }
+// Above this many groups the emission wants the groups' prefix sum (group_prefix): without it every workgroup adds up its
+// predecessors' sums itself, a number of loads quadratic in the number of groups (fine for a 1 M-element frame: 7.9 K groups).
+extern "C" uint32_t gs_isect_emit_prefix_from_groups(void) { return 8192u; }
 
 extern "C" int32_t gs_isect_emit_presorted(
     uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids, const float *means2d,

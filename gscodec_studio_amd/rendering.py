@@ -71,6 +71,12 @@ def _camera_centers(viewmats: Tensor) -> Tensor:
     return -inv_t
 
 
+def _prefill_enabled() -> bool:
+    from . import _wrapper
+
+    return _wrapper.PREFILL_ENABLED
+
+
 def _step_max_elems() -> int:
     from ._wrapper import _PINNED_DIRECT_MAX
 
@@ -239,7 +245,7 @@ def rasterization(
                 sh_degree if fuse_sh else None, tile_size, backgrounds, absgrad, sh_mask=sh_mask)
         # the dense per-gaussian gradients of the projection node are allocated and zero-filled by the compositing
         # forward's side job; its backward then writes the visible gaussians' rows only (_wrapper.GradPrefill)
-        prefill = GradPrefill() if torch.is_grad_enabled() else None
+        prefill = GradPrefill() if (torch.is_grad_enabled() and _prefill_enabled()) else None
         radii, means2d, depths, conics, opacities, colors_rows, rows = project_rows(
             means, covars, quats, scales, viewmats, Ks, width, height, opacities, row_colors,
             eps2d=eps2d, near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip,

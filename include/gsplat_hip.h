@@ -395,6 +395,7 @@ int32_t gs_isect_emit_compact(
  * positions [g << s, (g + 1) << s), s = gs_isect_emit_group_shift() -- what that sort's last pass leaves behind in its
  * side_sums (side_vals = tiles_per_gauss, side_shift = s).  compact != 0: keys32 as gs_isect_emit_compact; else isect_ids. */
 uint32_t gs_isect_emit_group_shift(void);
+uint32_t gs_isect_emit_prefix_from_groups(void); /* more groups than this: hand group_prefix (gs_cumsum_i32 of group_sums) */
 int32_t gs_isect_emit_presorted(
     uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids,
     const float *means2d, uint32_t means2d_stride, const int32_t *radii, const float *depths,
