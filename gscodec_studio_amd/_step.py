@@ -138,10 +138,7 @@ class _StepProject(torch.autograd.Function):
             sb1 = B.query("gs_cumsum_scratch_bytes", n_groups)
             scratch1 = empty(sb1, dtype=u8, device=dev)
             s.cumsum_scratch, s.cumsum_scratch_bytes = ptr(scratch1), sb1
-        n_sums = B.query("gs_isect_count_blocks", n_elems)
-        direct = n_sums <= W._PINNED_DIRECT_MAX
-        if not direct:
-            raise RuntimeError("_step: the native step driver serves up to 2 M elements per call")  # (checked by the caller)
+        n_sums = C * ((N + 255) // 256)  # gs_projection_rows_blocks(N) per camera: the projection counts the tiles itself
         pinned = W._pinned_take(n_sums)
         s.radii, s.depths, s.rows, s.tiles_per_gauss = ptr(radii), ptr(depths), ptr(rows), ptr(tiles_per_gauss)
         s.depth_keys, s.depth_vals, s.sort_temp, s.sort_temp_bytes = ptr(dkeys), ptr(dvals), ptr(temp), tb
@@ -152,20 +149,23 @@ class _StepProject(torch.autograd.Function):
         sp = ctypes.addressof(s)
         with torch.cuda.device(dev):
             B.call("gs_step_fwd_begin", sp, stream)
-            # ---- the one host sync: the count kernel's block sums land in pinned memory (-1 -> >= 0)
-            W._wait_event(W._SentinelEvent(pinned))
-            n_isects = int(pinned.sum(dtype=torch.int64))
-            W._PINNED_FREE.setdefault(n_sums, []).append(pinned)
             offsets = empty((C, tile_height, tile_width), dtype=i32, device=dev)
+            s.offsets = ptr(offsets)
+            sentinel = W._SentinelEvent(pinned)
+            # ---- the one host sync: the count kernel's block sums land in pinned memory (-1 -> >= 0).  From here to the
+            # binning launches the GPU has ~40 us of pre-sort left: nothing that can be done earlier or later sits in between
+            W._wait_event(sentinel)
+            n_isects = int(sentinel.np.sum(dtype="int64"))
             isect_ids = empty(n_isects, dtype=i64, device=dev)
             flatten_ids = empty(n_isects, dtype=i32, device=dev)
             wb = B.query("gs_isect_finish_work_bytes", n_isects)
             work = empty(wb, dtype=u8, device=dev)
-            s.n_isects, s.isect_ids, s.flatten_ids, s.offsets, s.work, s.work_bytes = n_isects, ptr(isect_ids), ptr(flatten_ids), ptr(offsets), ptr(work), wb
+            s.n_isects, s.isect_ids, s.flatten_ids, s.work, s.work_bytes = n_isects, ptr(isect_ids), ptr(flatten_ids), ptr(work), wb
             # the binning half goes out at once (the GPU has been waiting for this call since the pre-sort ended); the
             # compositing scratch is sized and allocated while it runs
             s.finish_phase = 1
             B.call("gs_step_fwd_finish", sp, stream)
+            W._PINNED_FREE.setdefault(n_sums, []).append(pinned)
             # ---- the compositing buffers (made while the GPU is busy with the binning)
             render_colors = empty((C, height, width, 3), dtype=f32, device=dev)
             render_alphas = empty((C, height, width, 1), dtype=f32, device=dev)

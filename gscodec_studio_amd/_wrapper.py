@@ -974,7 +974,7 @@ class _ProjectRows(torch.autograd.Function):
                    B.ptr(viewmats), B.ptr(Ks), int(width), int(height), float(eps2d), float(near_plane),
                    float(far_plane), float(radius_clip), cm, B.ptr(opacities), B.ptr(colors), int(bool(antialiased)),
                    B.ptr(sh_coeffs), B.ptr(sh_rest), sh_K, int(sh_degree or 0), B.ptr(mask_logits), float(m_temp), int(m_bin),
-                   B.ptr(radii), B.ptr(depths), B.ptr(rows), _stream(means))
+                   0, 0, 0, None, None, B.ptr(radii), B.ptr(depths), B.ptr(rows), _stream(means))
         ctx.save_for_backward(means, covars, quats, scales, viewmats, Ks, opacities, radii, rows, sh_coeffs, sh_rest)
         ctx.mask = (mask_logits, float(m_temp), bool(m_bin)) if mask_logits is not None else None
         ctx.width, ctx.height, ctx.eps2d, ctx.cm, ctx.antialiased = width, height, eps2d, cm, bool(antialiased)

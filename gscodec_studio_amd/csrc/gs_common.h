@@ -63,6 +63,26 @@ __device__ __forceinline__ float gs_mask_value(float logit, float temperature, i
 }
 #endif
 
+// Tile rectangle of a projected splat (isect_tiles.cu:56-69; the reference casts a possibly negative float to uint32 and
+// relies on the saturating conversion, here the clamp is explicit).  Explicitly rounded operations: the same values in every
+// translation unit, whatever its contraction setting (isect.hip counts and emits with it, projection.hip counts with it).
+#ifdef __HIPCC__
+struct TileBox {
+    int32_t x0, y0, x1, y1; // min inclusive, max exclusive
+};
+__device__ __forceinline__ TileBox tile_box(float mx, float my, int32_t radius, float tile_size, int32_t tw, int32_t th) {
+    const float tr = __fdiv_rn((float)radius, tile_size);
+    const float tx = __fdiv_rn(mx, tile_size);
+    const float ty = __fdiv_rn(my, tile_size);
+    TileBox b;
+    b.x0 = min(max(0, (int32_t)floorf(__fsub_rn(tx, tr))), tw);
+    b.y0 = min(max(0, (int32_t)floorf(__fsub_rn(ty, tr))), th);
+    b.x1 = min(max(0, (int32_t)ceilf(__fadd_rn(tx, tr))), tw);
+    b.y1 = min(max(0, (int32_t)ceilf(__fadd_rn(ty, tr))), th);
+    return b;
+}
+#endif
+
 // radix_sort.hip: slot of the first pass's [256][n_blocks] digit histogram inside a sort's temp buffer (nullptr: not applicable)
 uint32_t *sort_first_hist_slot(uint64_t n, void *temp, size_t temp_bytes, uint32_t *n_blocks);
 

@@ -11,24 +11,6 @@
 
 namespace {
 
-struct TileBox {
-    int32_t x0, y0, x1, y1; // min inclusive, max exclusive
-};
-
-// isect_tiles.cu:56-69.  The reference casts a possibly negative float to uint32 and
-// relies on the saturating conversion; here the clamp is explicit.
-GS_DEV TileBox tile_box(float mx, float my, int32_t radius, float tile_size, int32_t tw, int32_t th) {
-    float tr = (float)radius / tile_size;
-    float tx = mx / tile_size;
-    float ty = my / tile_size;
-    TileBox b;
-    b.x0 = min(max(0, (int32_t)floorf(tx - tr)), tw);
-    b.y0 = min(max(0, (int32_t)floorf(ty - tr)), th);
-    b.x1 = min(max(0, (int32_t)ceilf(tx + tr)), tw);
-    b.y1 = min(max(0, (int32_t)ceilf(ty + tr)), th);
-    return b;
-}
-
 __global__ void __launch_bounds__(GS_BLOCK) isect_count_kernel(
     uint32_t n_elems, const float *__restrict__ means2d, uint32_t s_m2, const int32_t *__restrict__ radii,
     float tile_size, int32_t tw, int32_t th, int32_t *__restrict__ tiles_per_gauss) {
@@ -84,12 +66,14 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_count_keys_kernel(
         uint32_t d = 0x7fffffffu;
         int32_t cnt = 0;
         if (r > 0) {
-            float2 m = *reinterpret_cast<const float2 *>(means2d + (size_t)i * s_m2);
-            TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
-            cnt = (b.y1 - b.y0) * (b.x1 - b.x0);
+            if (means2d != nullptr) { // (uniform; NULL: tiles_per_gauss holds the counts already -- gs_projection_rows_fwd made them)
+                float2 m = *reinterpret_cast<const float2 *>(means2d + (size_t)i * s_m2);
+                TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
+                cnt = (b.y1 - b.y0) * (b.x1 - b.x0);
+            }
             d = (uint32_t)__float_as_int(depths[i]) & 0x7fffffffu;
         }
-        tiles_per_gauss[i] = cnt;
+        if (means2d != nullptr) tiles_per_gauss[i] = cnt;
         const uint64_t key = ((uint64_t)d << 32) | (uint64_t)i;
         keys[i] = (int64_t)key;
         vals[i] = (int32_t)i;
@@ -527,7 +511,8 @@ extern "C" int32_t gs_isect_count_keys(
     uint32_t tile_width, uint32_t tile_height, int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals, int32_t *block_sums,
     void *sort_temp, size_t sort_temp_bytes, const int64_t *bucket_splitters, gs_stream_t stream) {
     if (n_elems == 0) return 0;
-    GS_CHECK_ARG(means2d && radii && depths && tiles_per_gauss && keys && vals, "null pointer");
+    GS_CHECK_ARG(radii && depths && tiles_per_gauss && keys && vals, "null pointer");
+    GS_CHECK_ARG(means2d != nullptr || block_sums == nullptr, "means2d NULL (tiles_per_gauss given): the block sums were made with the counts");
     GS_CHECK_ARG(bucket_splitters == nullptr || sort_temp != nullptr, "bucket_splitters come with sort_temp (the histogram's place)");
     GS_CHECK_ARG(tile_size > 0, "tile_size must be > 0");
     GS_CHECK_ARG(means2d_stride >= 2 && means2d_stride % 2 == 0, "means2d_stride must be even and >= 2");

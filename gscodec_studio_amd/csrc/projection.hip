@@ -138,6 +138,12 @@ struct RowExtras {
     const float *sh_mask_logits; // [N] or NULL
     float sh_mask_temp;
     int sh_mask_binary;
+    // the binning's intersection count in the same pass (what gs_isect_count_keys would compute from the rows afterwards): the
+    // host learns n_isects one kernel after the step starts, with the whole depth pre-sort still queued behind it
+    int32_t *tiles_per_gauss; // [C,N] or NULL
+    int32_t *block_sums;      // [C * gridDim.x] (pinned host memory) or NULL
+    float tile_size;
+    int32_t tile_width, tile_height;
 };
 
 // SHMODE: -1 = no SH colours; else 3 * degree + kind, kind 0 = coefficient rows read with scalar loads, 1 = 16-byte aligned
@@ -157,11 +163,31 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_fwd_kernel(
     // grid = (ceil(N/256), C): the camera index is block-uniform => camera constants in SGPRs
     uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
     uint32_t c = blockIdx.y;
-    if (n >= N) return;
+    if (!(ROWS && rx.tiles_per_gauss != nullptr) && n >= N) return;
+    const bool in = n < N;
     Camera cam = load_camera(viewmats, Ks, c);
-    Splat2D s = project_one<false>(cam, means, covars, quats, scales, n, W, H, eps2d, near_plane,
-                                   far_plane, radius_clip, camera_model);
+    Splat2D s;
+    s.radius = 0;
+    if (in) s = project_one<false>(cam, means, covars, quats, scales, n, W, H, eps2d, near_plane, far_plane, radius_clip, camera_model);
     size_t idx = (size_t)c * N + n;
+    if (ROWS && rx.tiles_per_gauss != nullptr) { // (uniform) every thread of the workgroup takes part in the sum
+        int32_t cnt = 0;
+        if (s.radius > 0) {
+            const TileBox b = tile_box(s.mx, s.my, s.radius, rx.tile_size, rx.tile_width, rx.tile_height);
+            cnt = (b.y1 - b.y0) * (b.x1 - b.x0);
+        }
+        if (in) rx.tiles_per_gauss[idx] = cnt;
+        if (rx.block_sums != nullptr) {
+            __shared__ int32_t s_cnt[GS_BLOCK / GS_WAVE];
+            int32_t v = cnt;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if ((threadIdx.x & 63u) == 0u) s_cnt[threadIdx.x >> 6] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) rx.block_sums[blockIdx.y * gridDim.x + blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        }
+        if (!in) return;
+    }
     radii[idx] = s.radius;
     if (s.radius <= 0) return;
     if (ROWS) {
@@ -708,12 +734,15 @@ extern "C" int32_t gs_projection_fwd(
     return 0;
 }
 
+extern "C" uint32_t gs_projection_rows_blocks(uint32_t N) { return gs_div_up(N, GS_BLOCK); }
+
 extern "C" int32_t gs_projection_rows_fwd(
     uint32_t C, uint32_t N, const float *means, const float *covars, const float *quats,
     const float *scales, const float *viewmats, const float *Ks, int32_t image_width,
     int32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip,
     int32_t camera_model, const float *opacities, const float *colors, int32_t antialiased, const float *sh_coeffs, const float *sh_coeffs_rest,
     uint32_t sh_K, uint32_t sh_degree, const float *sh_mask_logits, float sh_mask_temperature, int32_t sh_mask_binary,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, int32_t *tiles_per_gauss, int32_t *block_sums,
     int32_t *radii, float *depths, float *rows, gs_stream_t stream) {
     if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && viewmats && Ks && radii && depths && rows, "null pointer");
@@ -729,8 +758,10 @@ extern "C" int32_t gs_projection_rows_fwd(
     const int sh_vec = sh_coeffs != nullptr && (sh_coeffs_rest != nullptr || (uintptr_t)sh_coeffs % 16 == 0) && ((sh_K * 3u) % 4u == 0);
     GS_CHECK_ARG(sh_mask_logits == nullptr || sh_coeffs_rest != nullptr, "the shN mask needs split coefficient rows (sh_coeffs_rest)");
     GS_CHECK_ARG(sh_mask_logits == nullptr || sh_mask_binary || sh_mask_temperature > 0.f, "the mask temperature must be positive");
+    GS_CHECK_ARG(tiles_per_gauss != nullptr || block_sums == nullptr, "block_sums come with tiles_per_gauss");
+    GS_CHECK_ARG(tiles_per_gauss == nullptr || tile_size > 0, "tile_size must be > 0");
     const RowExtras rx = {opacities, colors, antialiased, sh_coeffs, sh_coeffs_rest, sh_K, sh_degree, sh_vec, sh_mask_logits, sh_mask_temperature,
-                          sh_mask_binary};
+                          sh_mask_binary, tiles_per_gauss, block_sums, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height};
     const int shmode = sh_coeffs == nullptr ? -1 : (int)sh_degree * 3 + (sh_coeffs_rest != nullptr ? 2 : (sh_vec ? 1 : 0));
 #define GS_ROWS_LAUNCH(M)                                                                                                        \
     case M:                                                                                                                      \

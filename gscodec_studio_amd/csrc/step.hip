@@ -40,13 +40,15 @@ extern "C" int32_t gs_step_fwd_begin(gs_step *s, gs_stream_t stream) {
     GS_STEP_TRY(gs_projection_rows_fwd(s->C, s->N, s->means, s->covars, s->quats, s->scales, s->viewmats, s->Ks, s->width, s->height, s->eps2d,
                                        s->near_plane, s->far_plane, s->radius_clip, s->camera_model, s->opacities, s->colors, s->antialiased,
                                        s->sh_coeffs, s->sh_rest, s->sh_K, s->sh_degree, s->sh_mask_logits, s->sh_mask_temperature, s->sh_mask_binary,
-                                       s->radii, s->depths, s->rows, stream));
+                                       s->tile_size, s->tile_width, s->tile_height, s->tiles_per_gauss, s->block_sums, s->radii, s->depths,
+                                       s->rows, stream));
     const int32_t hist_ready = gs_sort_first_hist_applicable(n_elems);
     const bool bucketed = s->bucketed && gs_presort_applicable(n_elems);
     GS_CHECK_ARG(!bucketed || s->splitters != nullptr, "the bucketed pre-sort needs the splitter table");
     if (bucketed) GS_STEP_TRY(gs_presort_split(n_elems, s->radii, s->depths, s->splitters, stream));
-    GS_STEP_TRY(gs_isect_count_keys(n_elems, s->rows, GS_ROW_FLOATS, s->radii, s->depths, s->tile_size, s->tile_width, s->tile_height,
-                                    s->tiles_per_gauss, s->depth_keys, s->depth_vals, s->block_sums, hist_ready ? s->sort_temp : nullptr,
+    // (the projection counted the tiles and left the block sums: the count kernel only makes the depth keys and their histogram)
+    GS_STEP_TRY(gs_isect_count_keys(n_elems, nullptr, GS_ROW_FLOATS, s->radii, s->depths, s->tile_size, s->tile_width, s->tile_height,
+                                    s->tiles_per_gauss, s->depth_keys, s->depth_vals, nullptr, hist_ready ? s->sort_temp : nullptr,
                                     hist_ready ? (size_t)s->sort_temp_bytes : 0, bucketed ? s->splitters : nullptr, stream));
     const uint32_t gshift = gs_isect_emit_group_shift();
     if (bucketed) {

@@ -163,10 +163,17 @@ int32_t gs_projection_rows_fwd(
                                    multiplied by sigmoid(logit / temperature) (binary: sigmoid(logit) >= 0.5) as they are
                                    loaded, the masked coefficients are never materialised; bit-identical to masking first */,
     float sh_mask_temperature, int32_t sh_mask_binary,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+    int32_t *tiles_per_gauss /* NULL, or [C,N]: the binning's tile count of every pair (gs_isect_count), in the same pass */,
+    int32_t *block_sums /* NULL, or [C * gs_projection_rows_blocks(N)] (may be pinned host memory): the counts' sums per
+                           workgroup -- their total is n_isects, known to the host one kernel into the step (the read-back of
+                           isect_tiles.cu:200) while the whole depth pre-sort is still queued; gs_isect_count_keys then takes
+                           means2d = NULL, block_sums = NULL (tiles_per_gauss is an input there) */,
     int32_t *radii, /* [C,N] */
     float *depths,  /* [C,N] */
     float *rows,    /* [C,N,16] */
     gs_stream_t stream);
+uint32_t gs_projection_rows_blocks(uint32_t N);
 /* Its backward: grad_rows [C,N,16] holds d/d(mean2d, conic, opacity, colour) in the splat-row columns (what gs_rasterize_bwd
  * accumulates with packed16), v_depths [C,N] or NULL.  Besides the outputs of gs_projection_bwd (all OVERWRITTEN),
  * v_opacities [N] = sum over cameras of column 5 (x compensation when antialiased, whose own gradient then enters the
@@ -347,7 +354,7 @@ int32_t gs_gather_i32(uint32_t n, const int32_t *src, const int32_t *idx, int32_
 /* the same in fewer launches: gs_isect_count + gs_isect_depth_keys in one kernel, and the inclusive prefix sum
  * of in[idx[i]] (= gs_gather_i32 followed by gs_cumsum_i32) without the intermediate array */
 int32_t gs_isect_count_keys(
-    uint32_t n_elems, const float *means2d, uint32_t means2d_stride, const int32_t *radii, const float *depths,
+    uint32_t n_elems, const float *means2d /* NULL: tiles_per_gauss is an INPUT (gs_projection_rows_fwd counted) */, uint32_t means2d_stride, const int32_t *radii, const float *depths,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
     int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals,
     int32_t *block_sums /* [gs_isect_count_blocks(n_elems)] or NULL: intersections per block; their sum is n_isects,
