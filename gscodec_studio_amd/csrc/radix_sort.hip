@@ -616,7 +616,8 @@ constexpr uint32_t PS_CAP = 4096;                   // LDS capacity of a local s
 
 #ifdef PS_PROFILE
 __device__ unsigned long long ps_stamps[64];
-#define PS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == PS_PROFILE_BLOCK) ps_stamps[k] = wall_clock64(); } while (0)
+__device__ unsigned int ps_profile_block;
+#define PS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == ps_profile_block) ps_stamps[k] = wall_clock64(); } while (0)
 #else
 #define PS_STAMP(k) do { } while (0)
 #endif
@@ -720,8 +721,8 @@ GS_DEV uint2 *lds_stable_sort(const LdsSort &L, uint32_t m, uint32_t max_bits = 
     for (uint32_t p = 0; p < passes; ++p) {
         const uint32_t shift = drop + p * wbits;
         PS_STAMP(17 + 4 * p);
-        __syncthreads(); // (L.red / the previous pass's counters are still being read)
-        for (uint32_t c = tid; c < PS_WAVES * RADIX; c += PS_THREADS) (&L.cnt[0][0])[c] = 0;
+        // (five workgroup barriers per pass: with 16 waves each costs a few hundred cycles)
+        for (uint32_t c = tid; c < PS_WAVES * RADIX; c += PS_THREADS) (&L.cnt[0][0])[c] = 0; // (the previous pass ended on a barrier)
         __syncthreads();
 #pragma unroll 1
         for (uint32_t r = 0; r < rounds; ++r) {
@@ -746,20 +747,31 @@ GS_DEV uint2 *lds_stable_sort(const LdsSort &L, uint32_t m, uint32_t max_bits = 
         }
         PS_STAMP(18 + 4 * p);
         __syncthreads();
-        {
-            uint32_t run = 0;
-            if (tid < RADIX) { // (all 16 counts requested at once: as a read-modify-write chain this was 1.2 us per pass)
-                uint32_t c[PS_WAVES];
+        uint32_t run = 0, inc = 0;
+        if (tid < RADIX) { // digit tid: prefix over the waves (all 16 counts requested at once), then a wave-level scan of the totals
+            uint32_t c[PS_WAVES];
 #pragma unroll
-                for (int w = 0; w < PS_WAVES; ++w) c[w] = L.cnt[w][tid];
+            for (int w = 0; w < PS_WAVES; ++w) c[w] = L.cnt[w][tid];
 #pragma unroll
-                for (int w = 0; w < PS_WAVES; ++w) {
-                    L.cnt[w][tid] = run;
-                    run += c[w];
-                }
+            for (int w = 0; w < PS_WAVES; ++w) {
+                L.cnt[w][tid] = run;
+                run += c[w];
             }
-            const uint32_t lb = ps_scan256(run, L.red, nullptr);
-            if (tid < RADIX) L.lbase[tid] = lb;
+            inc = run;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off, 64);
+                if (lane >= (uint32_t)off) inc += o;
+            }
+            if (lane == GS_WAVE - 1) L.red[wave] = inc;
+        }
+        __syncthreads();
+        if (tid < RADIX) {
+            uint32_t wbase = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                if ((uint32_t)w < wave) wbase += L.red[w];
+            L.lbase[tid] = wbase + inc - run;
         }
         __syncthreads();
         PS_STAMP(19 + 4 * p);
@@ -781,16 +793,23 @@ GS_DEV uint2 *lds_stable_sort(const LdsSort &L, uint32_t m, uint32_t max_bits = 
 }
 
 // 1. splitters.  radii / depths: the projection's dense outputs; split [256]: 255 ascending keys (depth bits << 32), padded with
-// UINT64_MAX.  Candidates: 1024 runs of 16 consecutive elements at regular positions (16 K elements in 2 K cache lines, read by
-// consecutive lanes: one workgroup has to fetch them); the visible ones, thinned evenly to at most PS_SPLIT_CAP, are the
+// UINT64_MAX.  Candidates: 512 runs of 16 consecutive elements at regular positions (8 K elements in 1 K cache lines, read by
+// consecutive lanes: ONE workgroup has to fetch them, and their latency is most of this kernel); the visible ones are the
 // samples (every visible element has the same chance: the balance of the buckets does not depend on how visibility is
-// distributed over the array).
-constexpr uint32_t PS_RUN = 16, PS_RUNS = 1024, PS_ROUNDS = PS_RUN * PS_RUNS / PS_THREADS, PS_SPLIT_CAP = 2048;
+// distributed over the array; ~9 samples per bucket at 29 % visibility).
+constexpr uint32_t PS_RUN = 16, PS_RUNS = 512, PS_ROUNDS = PS_RUN * PS_RUNS / PS_THREADS, PS_SPLIT_CAP = 8192;
 
 __global__ void __launch_bounds__(PS_THREADS) presort_split_kernel(uint32_t n_elems, const int32_t *__restrict__ radii,
                                                                    const float *__restrict__ depths, uint64_t *__restrict__ split) {
     extern __shared__ __align__(16) unsigned char ps_lds[];
-    const LdsSort L = lds_sort_carve(ps_lds, PS_SPLIT_CAP);
+    struct {
+        uint2 *a;      // [PS_SPLIT_CAP] samples (depth bits, element)
+        uint2 *b;      // histogram cells (4096 x u32) live here
+        uint32_t *red; // [2 * PS_WAVES + 8]
+    } L;
+    L.a = reinterpret_cast<uint2 *>(ps_lds);
+    L.b = L.a + PS_SPLIT_CAP;
+    L.red = reinterpret_cast<uint32_t *>(ps_lds + PS_SPLIT_CAP * sizeof(uint2) + 4096 * sizeof(uint32_t));
     const uint32_t tid = threadIdx.x, lane = tid % GS_WAVE, wave = tid / GS_WAVE;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     PS_STAMP(0);
@@ -814,75 +833,102 @@ __global__ void __launch_bounds__(PS_THREADS) presort_split_kernel(uint32_t n_el
             if (rr[r] > 0) vis |= 1u << r;
     }
     PS_STAMP(1);
-    // number of visible candidates -> thinning step (every keep-th visible candidate of a thread, phase tid % keep)
-    uint32_t cnt = (uint32_t)__popc(vis);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-    if (lane == 0) L.red[wave] = cnt;
+    // the visible candidates become the samples, in any order (a histogram follows): per round one ballot and one LDS atomic
+    // of the wave's first visible lane reserve the slots; beyond PS_SPLIT_CAP samples the later rounds' candidates are dropped
+    // (round r holds candidates 1024 r ..: every round is a regular subset of the array)
+    uint32_t *s_count = L.red + 2 * PS_WAVES;
+    if (tid == 0) *s_count = 0u;
     __syncthreads();
-    uint32_t nv = 0;
-#pragma unroll
-    for (int w = 0; w < PS_WAVES; ++w) nv += L.red[w];
-    const uint32_t keep = nv ? (nv + (PS_SPLIT_CAP - PS_THREADS) - 1) / (PS_SPLIT_CAP - PS_THREADS) : 1u;
-    uint32_t kept = 0u;
-    {
-        uint32_t phase = tid % keep;
-#pragma unroll
-        for (uint32_t r = 0; r < PS_ROUNDS; ++r)
-            if ((vis >> r) & 1u) {
-                if (phase == 0u) kept |= 1u << r;
-                if (++phase == keep) phase = 0u;
-            }
-    }
-    // slots: waves in order, rounds in order, lanes in order (any order would do; this one needs no atomics)
-    uint32_t wave_kept = 0;
-#pragma unroll
-    for (uint32_t r = 0; r < PS_ROUNDS; ++r) wave_kept += (uint32_t)__popcll(__ballot((kept >> r) & 1u));
-    __syncthreads();
-    if (lane == 0) L.red[wave] = wave_kept;
-    __syncthreads();
-    uint32_t slot = 0, m = 0;
-#pragma unroll
-    for (int w = 0; w < PS_WAVES; ++w) {
-        if ((uint32_t)w < wave) slot += L.red[w];
-        m += L.red[w];
-    }
 #pragma unroll
     for (uint32_t r = 0; r < PS_ROUNDS; ++r) {
-        const bool k = (kept >> r) & 1u;
+        const bool k = (vis >> r) & 1u;
         const unsigned long long bl = __ballot(k);
-        if (k) L.a[slot + (uint32_t)__popcll(bl & lt_mask)] = make_uint2((uint32_t)__float_as_int(dd[r]) & 0x7fffffffu, el[r]);
-        slot += (uint32_t)__popcll(bl);
+        if (bl != 0ull) { // (wave-uniform)
+            const uint32_t first = (uint32_t)__builtin_ctzll(bl);
+            uint32_t base = 0;
+            if (lane == first) base = atomicAdd(s_count, (uint32_t)__popcll(bl));
+            base = __shfl(base, (int)first, 64);
+            const uint32_t slot = base + (uint32_t)__popcll(bl & lt_mask);
+            if (k && slot < PS_SPLIT_CAP) L.a[slot] = make_uint2((uint32_t)__float_as_int(dd[r]) & 0x7fffffffu, el[r]);
+        }
     }
     __syncthreads();
-    PS_STAMP(2);
-    // The samples are sorted on the top 16 of their differing depth bits only (two LDS passes instead of four: this is one
-    // workgroup, every pass is serial latency) and a splitter is its sample's depth with the unsorted low bits cleared and element
-    // 0: the table is ascending whatever the order of the samples inside a 16-bit cell, which is all the bucket function needs
-    // (splitters that coincide just leave buckets empty; it takes thousands of keys within 2^-16 of the depth range to overfill one).
-    uint32_t low_mask = 0u;
-    uint32_t smin = 0xffffffffu; // (the sort's own minimum: recomputed here to truncate relative to it)
-    for (uint32_t j = tid; j < m; j += PS_THREADS) smin = min(smin, L.a[j].x);
-    const uint2 *sorted = lds_stable_sort(L, m, 16, &low_mask);
-    PS_STAMP(3);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) smin = min(smin, (uint32_t)__shfl_xor(smin, off, 64));
+    const uint32_t m = min(*s_count, PS_SPLIT_CAP);
     __syncthreads();
-    if (lane == 0) L.red[wave] = smin;
+    PS_STAMP(2);
+    // Splitters = equal-frequency quantiles of the samples, read off a 4096-cell histogram over the samples' depth range (no
+    // sort: this is ONE workgroup, every sorting pass is serial latency -- 9.6 us for 2.4 K samples against ~2 us here).
+    // A splitter is the lower edge of the cell holding the sample of rank (j + 1) m / 256, element 0: the table is ascending,
+    // which is all the bucket function needs (splitters that coincide just leave buckets empty; it takes thousands of keys
+    // within 2^-12 of the depth range to overfill one bucket, and then the local sort's global-memory route takes it).
+    constexpr uint32_t CELLS = 4096, CPT = CELLS / PS_THREADS; // 4 cells per thread
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(L.b);      // [CELLS] counts, then inclusive prefix
+    uint32_t smin = 0xffffffffu, smax = 0u;
+    for (uint32_t j = tid; j < m; j += PS_THREADS) {
+        const uint32_t k = L.a[j].x;
+        smin = min(smin, k);
+        smax = max(smax, k);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        smin = min(smin, (uint32_t)__shfl_xor(smin, off, 64));
+        smax = max(smax, (uint32_t)__shfl_xor(smax, off, 64));
+    }
+    if (lane == 0) {
+        L.red[wave] = smin;
+        L.red[PS_WAVES + wave] = smax;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < CPT; ++i) s_hist[tid * CPT + i] = 0u;
     __syncthreads();
     smin = 0xffffffffu;
+    smax = 0u;
 #pragma unroll
-    for (int w = 0; w < PS_WAVES; ++w) smin = min(smin, L.red[w]);
+    for (int w = 0; w < PS_WAVES; ++w) {
+        smin = min(smin, L.red[w]);
+        smax = max(smax, L.red[PS_WAVES + w]);
+    }
+    const uint32_t span = smax >= smin ? smax - smin : 0u;
+    const uint32_t nb = span == 0u ? 0u : 32u - (uint32_t)__builtin_clz(span);
+    const uint32_t shift = nb > 12u ? nb - 12u : 0u;
+    for (uint32_t j = tid; j < m; j += PS_THREADS) atomicAdd(&s_hist[(L.a[j].x - smin) >> shift], 1u);
+    __syncthreads();
+    // inclusive prefix over the cells: 4 consecutive cells per thread, wave scans of the thread totals, 16 wave totals
+    uint32_t c4[CPT], tsum = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < CPT; ++i) {
+        tsum += s_hist[tid * CPT + i];
+        c4[i] = tsum;
+    }
+    uint32_t inc = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= (uint32_t)off) inc += o;
+    }
+    __syncthreads();
+    if (lane == GS_WAVE - 1) L.red[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+#pragma unroll
+    for (int w = 0; w < PS_WAVES; ++w)
+        if ((uint32_t)w < wave) wbase += L.red[w];
+    const uint32_t excl = wbase + inc - tsum;
+#pragma unroll
+    for (uint32_t i = 0; i < CPT; ++i) s_hist[tid * CPT + i] = excl + c4[i];
+    __syncthreads();
+    PS_STAMP(3);
     if (tid < GS_PRESORT_BUCKETS) {
         uint64_t out = ~0ull;
         if (tid < GS_PRESORT_BUCKETS - 1 && m > 0) {
-            uint32_t pick = 0xffffffffu;
-            if (m <= GS_PRESORT_BUCKETS - 1) {
-                if (tid < m) pick = tid;
-            } else {
-                pick = (uint32_t)(((uint64_t)(tid + 1) * m) / GS_PRESORT_BUCKETS);
+            const uint32_t rank = (uint32_t)(((uint64_t)(tid + 1) * m) / GS_PRESORT_BUCKETS); // sample rank of this splitter (< m)
+            uint32_t lo = 0, hi = CELLS - 1; // smallest cell whose inclusive prefix exceeds the rank
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_hist[mid] > rank) hi = mid;
+                else lo = mid + 1;
             }
-            if (pick != 0xffffffffu) out = (uint64_t)(smin + ((sorted[pick].x - smin) & ~low_mask)) << 32;
+            out = (uint64_t)(smin + (lo << shift)) << 32;
         }
         split[tid] = out;
     }
@@ -1049,7 +1095,7 @@ __global__ void __launch_bounds__(PS_THREADS) presort_local_kernel(const uint32_
 }
 
 constexpr size_t PS_LOCAL_LDS = lds_sort_bytes(PS_CAP) + (GS_PRESORT_BUCKETS + 1) * 4 + 60;
-constexpr size_t PS_SPLIT_LDS = lds_sort_bytes(PS_SPLIT_CAP);
+constexpr size_t PS_SPLIT_LDS = PS_SPLIT_CAP * sizeof(uint2) + 4096 * sizeof(uint32_t) + (2 * PS_WAVES + 8) * sizeof(uint32_t) + 64;
 
 } // namespace
 

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
+#include <numeric>
 #include <cmath>
 #include <cstring>
 void gs_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
@@ -55,13 +56,32 @@ int main() {
         hipEventElapsedTime(&t_split, e[0], e[1]); hipEventElapsedTime(&t_count, e[1], e[2]); hipEventElapsedTime(&t_bucket, e[2], e[3]);
     }
     printf("events (ms): split %.4f  count %.4f  scan+scatter+local %.4f\n", t_split, t_count, t_bucket);
+    // the slowest local-sort workgroup: the largest bucket
+    {
+        const SortLayout L = sort_layout(n);
+        std::vector<uint32_t> tot(256);
+        hipMemcpy(tot.data(), (char *)temp + L.off_totals, 256 * 4, hipMemcpyDeviceToHost);
+        unsigned int arg = (unsigned int)(std::max_element(tot.begin(), tot.end()) - tot.begin());
+        printf("largest bucket: #%u with %u keys (mean %.0f)\n", arg, tot[arg], 0.0 + std::accumulate(tot.begin(), tot.end(), 0.0) / 256);
+        hipMemcpyToSymbol(HIP_SYMBOL(ps_profile_block), &arg, 4);
+        gs_presort_split(n, d_r, d_d, d_split, nullptr);
+        gs_isect_count_keys(n, d_m2, 2, d_r, d_d, 16, 120, 68, d_tpg, d_keys, d_vals, d_bs, temp, tb, d_split, nullptr);
+        gs_presort_buckets(n, d_keys, d_vals, d_split, d_perm, d_nk, temp, tb, d_tpg, d_gs, 7, 0, nullptr);
+        hipDeviceSynchronize();
+        unsigned long long s2[64];
+        hipMemcpyFromSymbol(s2, HIP_SYMBOL(ps_stamps), sizeof(s2));
+        auto us2 = [&](int a, int b) { return (double)(s2[b] - s2[a]) / 100.0; };
+        printf("local kernel, largest bucket (us): prelude %.1f  load %.1f  sort %.1f  output %.1f  total %.1f\n", us2(8, 9), us2(9, 10), us2(10, 11), us2(11, 12), us2(8, 12));
+        unsigned int zero = 0;
+        hipMemcpyToSymbol(HIP_SYMBOL(ps_profile_block), &zero, 4);
+    }
     unsigned long long st[64];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(ps_stamps), sizeof(st));
     auto us = [&](int a, int b) { return (double)(st[b] - st[a]) / 100.0; };
-    printf("split kernel (us): gather %.1f  scan+compaction %.1f  sort %.1f  splitters %.1f  total %.1f\n", us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(0, 4));
+    printf("split kernel (us): gather %.1f  scan+compaction %.1f  histogram+prefix %.1f  splitters %.1f  total %.1f\n", us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(0, 4));
     printf("  sort detail: setup %.1f", us(2, 16));
     for (int p = 0; p < 2; ++p) printf(" | pass %d: zero %.1f rank %.1f scan %.1f", p, us(17 + 4 * p, 17 + 4 * p) , us(17 + 4 * p, 18 + 4 * p), us(18 + 4 * p, 19 + 4 * p));
     printf("\n");
-    printf("local kernel, block %d (us): prelude %.1f  load %.1f  sort %.1f  output %.1f  total %.1f\n", PS_PROFILE_BLOCK, us(8, 9), us(9, 10), us(10, 11), us(11, 12), us(8, 12));
+    printf("local kernel, block %d (us): prelude %.1f  load %.1f  sort %.1f  output %.1f  total %.1f\n", 0, us(8, 9), us(9, 10), us(10, 11), us(11, 12), us(8, 12));
     return 0;
 }
