@@ -1,0 +1,37 @@
+#!/bin/bash
+# Everything profiles/rNN_* is made from, on the GPU box:  tools/final_profiles.sh r04
+set -u
+tag=${1:-r04}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/final
+mkdir -p "$out"
+cd "$root"
+python bench.py > "$out/${tag}_bench.json" 2> "$out/bench.err" < /dev/null
+python bench.py --gpus 1 --steps 20 --warmup 5 > "$out/${tag}_bench_driver_cmd.json" 2>> "$out/bench.err" < /dev/null
+{
+  for f in "--quantize" "--quantize --quantize-reference-calls" "--quantize --ada-mask" "--quantize --ada-mask --quantize-reference-calls"; do
+    python bench.py --no-cpu-baseline --no-extras --no-dp-projection $f 2>/dev/null < /dev/null | tail -1
+  done
+} > "$out/${tag}_bench_quantize.jsonl"
+bash tools/prof.sh $tag > "$out/prof.log" 2>&1
+cp gpurun_out/prof_${tag}_kernel_stats.csv "$out/${tag}_kernel_stats.csv"
+cp gpurun_out/prof_${tag}_last_step.txt "$out/${tag}_last_step_timeline.txt"
+bash tools/prof.sh ${tag}q --quantize --ada-mask > "$out/profq.log" 2>&1
+cp gpurun_out/prof_${tag}q_kernel_stats.csv "$out/${tag}_quantize_kernel_stats.csv"
+cp gpurun_out/prof_${tag}q_last_step.txt "$out/${tag}_quantize_last_step_timeline.txt"
+bash tools/pmc.sh "$out/${tag}_pmc_traffic.json" > "$out/pmc.log" 2>&1
+{
+  python tools/bench_multicam.py 2>/dev/null
+  python tools/bench_inference.py 2>/dev/null
+  python tools/cpu_overhead.py 2>/dev/null | head -1
+  GS_STEP_DRIVER=0 python tools/cpu_overhead.py 2>/dev/null | head -1 | sed 's/^/operator path: /'
+  for cfg in "1 1" "0 1" "1 0" "0 0"; do set -- $cfg
+    GS_PRESORT=$1 GS_STEP_DRIVER=$2 python bench.py --steps 100 --min-timed-s 2 --no-cpu-baseline --no-extras --no-dp-projection 2>/dev/null < /dev/null | tail -1 | \
+      python -c "import json,sys; d=json.loads(sys.stdin.read()); print('A/B bucketed pre-sort', sys.argv[1], 'step driver', sys.argv[2], ': ms/step', round(d['ms_per_step'],4))" $1 $2
+  done
+} > "$out/${tag}_secondary.txt" 2>&1
+python tools/bench_profile_protocol.py 5 > "$out/${tag}_profile_protocol.txt" 2>&1
+python -m pytest tests/test_gpu_fullsize_parity.py -q -s 2>&1 | grep -E "full size|config 4|passed|failed" > "$out/${tag}_fullsize_parity.txt"
+./build_abl/mfma_reduce_ab > "$out/${tag}_mfma_reduce_ab.txt" 2>&1
+./build_abl/presort_bench > "$out/${tag}_presort_breakdown.txt" 2>&1
+echo done
