@@ -49,7 +49,7 @@ class _Step(ctypes.Structure):  # gs_step of include/gsplat_hip.h (field for fie
         ("eps2d", _F), ("near_plane", _F), ("far_plane", _F), ("radius_clip", _F),
         ("camera_model", _I32), ("antialiased", _I32), ("tile_size", _U32), ("tile_width", _U32), ("tile_height", _U32),
         ("bucketed", _I32), ("lds_capacity", _U32), ("sh_mask_binary", _I32),
-        ("sh_mask_logits", _P), ("v_sh_mask_logits", _P), ("sh_mask_temperature", _F), ("reserved0", _U32),
+        ("sh_mask_logits", _P), ("v_sh_mask_logits", _P), ("sh_mask_temperature", _F), ("rows_ready", _U32),
         ("backgrounds", _P),
         ("radii", _P), ("depths", _P), ("rows", _P), ("tiles_per_gauss", _P), ("depth_keys", _P), ("depth_vals", _P),
         ("sort_temp", _P), ("sort_temp_bytes", _U64), ("splitters", _P), ("sorted_keys", _P), ("perm", _P), ("n_kept", _P),
@@ -88,6 +88,102 @@ def _c(t: Optional[Tensor]) -> Optional[Tensor]:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _phase1(s: "_Step", C: int, N: int, dev, n_sums: int, given=None) -> dict:
+    """Everything whose size follows from C * N: allocates the phase-1 buffers of ``gs_step`` and enters them into ``s``.
+    ``given`` = (radii, depths, rows) when they are inputs (rows_ready)."""
+    n_elems = C * N
+    i32, i64, f32, u8 = torch.int32, torch.int64, torch.float32, torch.uint8
+    empty = torch.empty
+    ptr = B.ptr
+    if given is None:
+        radii = empty((C, N), dtype=i32, device=dev)
+        depths = empty((C, N), dtype=f32, device=dev)
+        rows = empty((C, N, W.ROW), dtype=f32, device=dev)
+    else:
+        radii, depths, rows = given
+    tiles_per_gauss = empty((C, N), dtype=i32, device=dev)
+    dkeys = empty(n_elems, dtype=i64, device=dev)
+    dvals = empty(n_elems, dtype=i32, device=dev)
+    perm = empty(n_elems, dtype=i32, device=dev)
+    n_kept = empty(1, dtype=i32, device=dev)
+    gshift = _GSHIFT[0] or _init_consts()
+    n_groups = (n_elems + (1 << gshift) - 1) >> gshift
+    gsums = empty(n_groups, dtype=i32, device=dev)
+    bucketed = W._PRESORT["on"] and bool(B.query("gs_presort_applicable", n_elems))
+    tb = B.query("gs_presort_temp_bytes" if bucketed else "gs_sort_temp_bytes", n_elems)
+    temp = empty(tb, dtype=u8, device=dev)
+    split = empty(256, dtype=i64, device=dev) if bucketed else None
+    ko = None if bucketed else empty(n_elems, dtype=i64, device=dev)
+    gpre = scratch1 = None
+    if n_groups > _PREFIX_FROM[0]:
+        gpre = empty(n_groups, dtype=i64, device=dev)
+        sb1 = B.query("gs_cumsum_scratch_bytes", n_groups)
+        scratch1 = empty(sb1, dtype=u8, device=dev)
+        s.cumsum_scratch, s.cumsum_scratch_bytes = ptr(scratch1), sb1
+    pinned = W._pinned_take(n_sums)
+    s.radii, s.depths, s.rows, s.tiles_per_gauss = ptr(radii), ptr(depths), ptr(rows), ptr(tiles_per_gauss)
+    s.depth_keys, s.depth_vals, s.sort_temp, s.sort_temp_bytes = ptr(dkeys), ptr(dvals), ptr(temp), tb
+    s.splitters, s.sorted_keys, s.perm, s.n_kept, s.group_sums, s.group_prefix = ptr(split), ptr(ko), ptr(perm), ptr(n_kept), ptr(gsums), ptr(gpre)
+    s.block_sums = pinned.data_ptr()
+    s.bucketed, s.lds_capacity = int(bucketed), W._PRESORT["lds_capacity"]
+    # (the dict keeps every buffer alive until the forward's launches are queued)
+    return {"radii": radii, "depths": depths, "rows": rows, "tiles_per_gauss": tiles_per_gauss, "pinned": pinned,
+            "keep": (dkeys, dvals, perm, n_kept, gsums, temp, split, ko, gpre, scratch1)}
+
+
+def _finish(s, sp, stream, bufs, n_sums, C, N, height, width, tile_height, tile_width, dev, needs_bwd, prefill):
+    """From behind ``gs_step_fwd_begin`` to the compositing launch: the one host sync and both ``gs_step_fwd_finish`` phases."""
+    i32, i64, f32, u8 = torch.int32, torch.int64, torch.float32, torch.uint8
+    empty = torch.empty
+    ptr = B.ptr
+    n_elems = C * N
+    pinned = bufs["pinned"]
+    offsets = empty((C, tile_height, tile_width), dtype=i32, device=dev)
+    s.offsets = ptr(offsets)
+    sentinel = W._SentinelEvent(pinned)
+    # ---- the one host sync: the count kernel's block sums land in pinned memory (-1 -> >= 0).  From here to the
+    # binning launches the GPU has ~40 us of pre-sort left: nothing that can be done earlier or later sits in between
+    W._wait_event(sentinel)
+    n_isects = int(sentinel.np.sum(dtype="int64"))
+    isect_ids = empty(n_isects, dtype=i64, device=dev)
+    flatten_ids = empty(n_isects, dtype=i32, device=dev)
+    wb = B.query("gs_isect_finish_work_bytes", n_isects)
+    work = empty(wb, dtype=u8, device=dev)
+    s.n_isects, s.isect_ids, s.flatten_ids, s.work, s.work_bytes = n_isects, ptr(isect_ids), ptr(flatten_ids), ptr(work), wb
+    # the binning half goes out at once (the GPU has been waiting for this call since the pre-sort ended); the
+    # compositing scratch is sized and allocated while it runs
+    s.finish_phase = 1
+    B.call("gs_step_fwd_finish", sp, stream)
+    W._PINNED_FREE.setdefault(n_sums, []).append(pinned)
+    bufs["pinned"] = None
+    # ---- the compositing buffers (made while the GPU is busy with the binning)
+    render_colors = empty((C, height, width, 3), dtype=f32, device=dev)
+    render_alphas = empty((C, height, width, 1), dtype=f32, device=dev)
+    last_ids = empty((C, height, width), dtype=i32, device=dev)
+    fill = None
+    if needs_bwd:
+        extra = prefill.floats() if prefill is not None else 0
+        if extra:
+            extra += 64  # slack behind the last piece (a multi-GPU reduction rounds the span of all pieces up into it)
+        fill = empty(n_elems * 16 + extra, dtype=f32, device=dev)
+        if extra:
+            prefill.carve(fill, n_elems * 16)
+        else:
+            prefill = None
+    else:
+        prefill = None
+    s.render_colors, s.render_alphas, s.last_ids = ptr(render_colors), ptr(render_alphas), ptr(last_ids)
+    if fill is not None:
+        s.zero_fill, s.zero_fill_bytes = ptr(fill), fill.numel() * 4
+    plan, sbytes = W._raster_plan(C * tile_height * tile_width, n_isects, 3, forward_only=not needs_bwd)
+    ctypes.memmove(ctypes.addressof(s.plan), plan, 64)
+    scratch = empty(sbytes, dtype=u8, device=dev)
+    s.scratch = ptr(scratch)
+    s.finish_phase = 2
+    B.call("gs_step_fwd_finish", sp, stream)
+    return offsets, isect_ids, flatten_ids, render_colors, render_alphas, last_ids, fill, prefill, scratch, plan
+
+
 class _StepProject(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, sh_rest, mask_logits, backgrounds, cfg, hand):
@@ -115,92 +211,26 @@ class _StepProject(torch.autograd.Function):
         cm = W._CAMERA_MODELS[camera_model]
         s.camera_model, s.antialiased = cm, int(antialiased)
         s.tile_size, s.tile_width, s.tile_height = tile_size, tile_width, tile_height
-        # ---- phase 1: everything whose size follows from C * N
-        radii = empty((C, N), dtype=i32, device=dev)
-        depths = empty((C, N), dtype=f32, device=dev)
-        rows = empty((C, N, W.ROW), dtype=f32, device=dev)
-        tiles_per_gauss = empty((C, N), dtype=i32, device=dev)
-        dkeys = empty(n_elems, dtype=i64, device=dev)
-        dvals = empty(n_elems, dtype=i32, device=dev)
-        perm = empty(n_elems, dtype=i32, device=dev)
-        n_kept = empty(1, dtype=i32, device=dev)
-        gshift = _GSHIFT[0] or _init_consts()
-        n_groups = (n_elems + (1 << gshift) - 1) >> gshift
-        gsums = empty(n_groups, dtype=i32, device=dev)
-        bucketed = W._PRESORT["on"] and bool(B.query("gs_presort_applicable", n_elems))
-        tb = B.query("gs_presort_temp_bytes" if bucketed else "gs_sort_temp_bytes", n_elems)
-        temp = empty(tb, dtype=u8, device=dev)
-        split = empty(256, dtype=i64, device=dev) if bucketed else None
-        ko = None if bucketed else empty(n_elems, dtype=i64, device=dev)
-        gpre = scratch1 = None
-        if n_groups > _PREFIX_FROM[0]:
-            gpre = empty(n_groups, dtype=i64, device=dev)
-            sb1 = B.query("gs_cumsum_scratch_bytes", n_groups)
-            scratch1 = empty(sb1, dtype=u8, device=dev)
-            s.cumsum_scratch, s.cumsum_scratch_bytes = ptr(scratch1), sb1
         n_sums = C * ((N + 255) // 256)  # gs_projection_rows_blocks(N) per camera: the projection counts the tiles itself
-        pinned = W._pinned_take(n_sums)
-        s.radii, s.depths, s.rows, s.tiles_per_gauss = ptr(radii), ptr(depths), ptr(rows), ptr(tiles_per_gauss)
-        s.depth_keys, s.depth_vals, s.sort_temp, s.sort_temp_bytes = ptr(dkeys), ptr(dvals), ptr(temp), tb
-        s.splitters, s.sorted_keys, s.perm, s.n_kept, s.group_sums, s.group_prefix = ptr(split), ptr(ko), ptr(perm), ptr(n_kept), ptr(gsums), ptr(gpre)
-        s.block_sums = pinned.data_ptr()
-        s.bucketed, s.lds_capacity = int(bucketed), W._PRESORT["lds_capacity"]
+        bufs = _phase1(s, C, N, dev, n_sums)
+        radii, depths, rows, tiles_per_gauss = bufs["radii"], bufs["depths"], bufs["rows"], bufs["tiles_per_gauss"]
         stream = torch.cuda.current_stream(dev).cuda_stream
         sp = ctypes.addressof(s)
+        prefill = None
+        if needs_bwd and W.PREFILL_ENABLED:
+            # the per-gaussian gradients the backward returns live behind the gradient rows in ONE zero-filled buffer
+            # (_wrapper.GradPrefill: the compositing forward zero-fills it as a side job)
+            need = ctx.needs_input_grad
+            prefill = W.GradPrefill()
+            prefill.request = [(key, tuple(t.shape)) for key, t, flag in (
+                ("means", means, need[0]), ("covars", covars, need[1]), ("quats", quats, need[2]), ("scales", scales, need[3]),
+                ("opacities", opacities, need[6]), ("colors", colors, need[7]), ("sh", sh_coeffs, need[8]), ("sh_rest", sh_rest, need[9]))
+                if t is not None and flag]
         with torch.cuda.device(dev):
             B.call("gs_step_fwd_begin", sp, stream)
-            offsets = empty((C, tile_height, tile_width), dtype=i32, device=dev)
-            s.offsets = ptr(offsets)
-            sentinel = W._SentinelEvent(pinned)
-            # ---- the one host sync: the count kernel's block sums land in pinned memory (-1 -> >= 0).  From here to the
-            # binning launches the GPU has ~40 us of pre-sort left: nothing that can be done earlier or later sits in between
-            W._wait_event(sentinel)
-            n_isects = int(sentinel.np.sum(dtype="int64"))
-            isect_ids = empty(n_isects, dtype=i64, device=dev)
-            flatten_ids = empty(n_isects, dtype=i32, device=dev)
-            wb = B.query("gs_isect_finish_work_bytes", n_isects)
-            work = empty(wb, dtype=u8, device=dev)
-            s.n_isects, s.isect_ids, s.flatten_ids, s.work, s.work_bytes = n_isects, ptr(isect_ids), ptr(flatten_ids), ptr(work), wb
-            # the binning half goes out at once (the GPU has been waiting for this call since the pre-sort ended); the
-            # compositing scratch is sized and allocated while it runs
-            s.finish_phase = 1
-            B.call("gs_step_fwd_finish", sp, stream)
-            W._PINNED_FREE.setdefault(n_sums, []).append(pinned)
-            # ---- the compositing buffers (made while the GPU is busy with the binning)
-            render_colors = empty((C, height, width, 3), dtype=f32, device=dev)
-            render_alphas = empty((C, height, width, 1), dtype=f32, device=dev)
-            last_ids = empty((C, height, width), dtype=i32, device=dev)
-            fill = None
-            prefill = None
-            need = ctx.needs_input_grad
-            if needs_bwd:
-                # the per-gaussian gradients the backward returns live behind the gradient rows in ONE zero-filled buffer
-                # (_wrapper.GradPrefill: the compositing forward zero-fills it as a side job)
-                prefill = W.GradPrefill()
-                req = []
-                for key, t, flag in () if not W.PREFILL_ENABLED else (("means", means, need[0]), ("covars", covars, need[1]), ("quats", quats, need[2]),
-                                     ("scales", scales, need[3]), ("opacities", opacities, need[6]), ("colors", colors, need[7]),
-                                     ("sh", sh_coeffs, need[8]), ("sh_rest", sh_rest, need[9])):
-                    if t is not None and flag:
-                        req.append((key, tuple(t.shape)))
-                prefill.request = req
-                extra = prefill.floats()
-                if extra:
-                    extra += 64
-                fill = empty(n_elems * 16 + extra, dtype=f32, device=dev)
-                if extra:
-                    prefill.carve(fill, n_elems * 16)
-                else:
-                    prefill = None
-            s.render_colors, s.render_alphas, s.last_ids = ptr(render_colors), ptr(render_alphas), ptr(last_ids)
-            if fill is not None:
-                s.zero_fill, s.zero_fill_bytes = ptr(fill), fill.numel() * 4
-            plan, sbytes = W._raster_plan(C * tile_height * tile_width, n_isects, 3, forward_only=not needs_bwd)
-            ctypes.memmove(ctypes.addressof(s.plan), plan, 64)
-            scratch = empty(sbytes, dtype=u8, device=dev)
-            s.scratch = ptr(scratch)
-            s.finish_phase = 2
-            B.call("gs_step_fwd_finish", sp, stream)
+            (offsets, isect_ids, flatten_ids, render_colors, render_alphas, last_ids, fill, prefill, scratch, plan) = _finish(
+                s, sp, stream, bufs, n_sums, C, N, height, width, tile_height, tile_width, dev, needs_bwd, prefill)
+        n_isects = isect_ids.shape[0]
         # ---- node 2's share
         hand.render_colors, hand.render_alphas, hand.last_ids, hand.scratch, hand.plan = render_colors, render_alphas, last_ids, scratch, plan
         hand.grad_rows = fill[:n_elems * 16].view(C, N, 16) if fill is not None else None
@@ -240,6 +270,87 @@ class _StepComposite(torch.autograd.Function):
     def backward(ctx, v_render_colors, v_render_alphas):
         g = W._RasterizeToPixels.backward(ctx, v_render_colors, v_render_alphas)
         return (g[0], g[1], g[2], g[3], g[4], None, None)
+
+
+class _RowsState:
+    """Binning in flight over splat rows some other producer wrote (``rows_begin`` ... ``rows_composite`` | ``rows_abandon``)."""
+
+    __slots__ = ("s", "bufs", "n_sums", "C", "N", "dev", "tile")
+
+
+def rows_applicable(rows: Optional[Tensor], colors: Optional[Tensor], packed: bool, render_mode: str, channel_chunk: int,
+                    deterministic: bool, absgrad: bool) -> bool:
+    """The gaussian-sharded mode's receiver side: [C_local, N_total, 16] splat rows with RGB colours in them."""
+    return (ENABLED and rows is not None and rows.is_cuda and not packed and not deterministic and render_mode == "RGB"
+            and channel_chunk >= 3 and colors is not None and colors.shape[-1] == 3 and rows.shape[0] * rows.shape[1] > 0)
+
+
+def rows_begin(radii: Tensor, depths: Tensor, rows: Tensor, tile_size: int, tile_width: int, tile_height: int) -> _RowsState:
+    """Queue the binning of ``rows`` up to its host read-back (``gs_step_fwd_begin`` with ``rows_ready``): count + depth keys
+    -> depth pre-sort.  Nothing differentiable happens here (the reference's ``isect_tiles`` is not differentiable either)."""
+    C, N = radii.shape
+    dev = rows.device
+    assert rows.is_contiguous() and radii.is_contiguous() and depths.is_contiguous() and rows.shape == (C, N, W.ROW)
+    st = _RowsState()
+    s = _Step()
+    s.C, s.N, s.rows_ready = C, N, 1
+    s.tile_size, s.tile_width, s.tile_height = tile_size, tile_width, tile_height
+    n_sums = int(B.query("gs_isect_count_blocks", C * N))
+    st.s, st.n_sums, st.C, st.N, st.dev, st.tile = s, n_sums, C, N, dev, (tile_size, tile_width, tile_height)
+    st.bufs = _phase1(s, C, N, dev, n_sums, given=(radii, depths, rows))
+    with torch.cuda.device(dev):
+        B.call("gs_step_fwd_begin", ctypes.addressof(s), torch.cuda.current_stream(dev).cuda_stream)
+    return st
+
+
+def rows_abandon(st: Optional[_RowsState]) -> None:
+    """Drop a ``rows_begin`` without finishing it (the sparse exchange's overflow retry).  The count kernel stores its block
+    sums straight into the pinned buffer: it goes back to the free list only once the kernel has run."""
+    if st is None or st.bufs.get("pinned") is None:
+        return
+    pinned = st.bufs["pinned"]
+    W._wait_event(W._SentinelEvent(pinned))
+    W._PINNED_FREE.setdefault(st.n_sums, []).append(pinned)
+    st.bufs["pinned"] = None
+
+
+class _StepRowsComposite(torch.autograd.Function):
+    """Second half over rows: host sync -> emit + pair sort + offsets -> compositing forward; backward =
+    ``_RasterizeToPixels.backward`` (the gradient rows feed the exchange's backward)."""
+
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, cfg, st, prefill):
+        width, height, absgrad = cfg
+        s, C, N, dev = st.s, st.C, st.N, st.dev
+        tile_size, tile_width, tile_height = st.tile
+        backgrounds = _c(backgrounds)
+        s.backgrounds = B.ptr(backgrounds)
+        s.width, s.height = width, height
+        needs_bwd = any(ctx.needs_input_grad[:5])
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            (offsets, isect_ids, flatten_ids, render_colors, render_alphas, last_ids, fill, prefill, scratch, plan) = _finish(
+                s, ctypes.addressof(s), stream, st.bufs, st.n_sums, C, N, height, width, tile_height, tile_width, dev, needs_bwd, prefill)
+        ctx.grad_rows = fill[:C * N * 16].view(C, N, 16) if fill is not None else None
+        ctx.plan, ctx.strides = plan, _ROW_STRIDES
+        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, None, offsets, flatten_ids, render_alphas, last_ids, scratch,
+                              render_colors)
+        ctx.width, ctx.height, ctx.tile_size, ctx.absgrad, ctx.deterministic = width, height, tile_size, absgrad, False
+        tiles_per_gauss = st.bufs["tiles_per_gauss"]
+        ctx.mark_non_differentiable(tiles_per_gauss, isect_ids, flatten_ids, offsets)
+        ctx.set_materialize_grads(False)
+        st.bufs = None
+        return render_colors, render_alphas, tiles_per_gauss, isect_ids, flatten_ids, offsets
+
+    @staticmethod
+    def backward(ctx, v_render_colors, v_render_alphas, *_ints):
+        g = W._RasterizeToPixels.backward(ctx, v_render_colors, v_render_alphas)
+        return (g[0], g[1], g[2], g[3], g[4], None, None, None)
+
+
+def rows_composite(st: _RowsState, means2d, conics, colors, opacities, backgrounds, width, height, absgrad, prefill):
+    """-> (render_colors, render_alphas, tiles_per_gauss, isect_ids, flatten_ids, isect_offsets)"""
+    return _StepRowsComposite.apply(means2d, conics, colors, opacities, backgrounds, (int(width), int(height), bool(absgrad)), st, prefill)
 
 
 _GSHIFT, _PREFIX_FROM = [0], [8192]

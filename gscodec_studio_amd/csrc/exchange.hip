@@ -218,9 +218,12 @@ __global__ void exchange_header_kernel(uint32_t world, uint32_t cap, const uint3
 
 // pre-fill of the compaction's outputs in ONE launch (four separate memsets cost a launch and a ~6 us gap each on the
 // host-bound exchange path): src_index = -1, hdr = (-1, -1), counters = 0, stats = 0
+// (+ optionally the RECEIVER's radii, zero before the scatter of the received rows fills in the visible ones: the same
+// process allocates them before the all-to-all, and this launch has the GPU to itself -- a memset behind the collective
+// was two more launches on the critical path)
 __global__ void __launch_bounds__(GS_BLOCK) exchange_init_kernel(size_t rows, uint32_t world, int32_t *__restrict__ src_index,
                                                                  int2 *__restrict__ hdr, uint32_t *__restrict__ counters,
-                                                                 uint32_t *__restrict__ stats) {
+                                                                 uint32_t *__restrict__ stats, int32_t *__restrict__ zero, size_t n_zero) {
     const size_t i = (size_t)blockIdx.x * GS_BLOCK + threadIdx.x;
     if (i < rows) {
         src_index[i] = -1;
@@ -228,6 +231,8 @@ __global__ void __launch_bounds__(GS_BLOCK) exchange_init_kernel(size_t rows, ui
     }
     if (i < world) counters[i] = 0u;
     if (i < 2) stats[i] = 0u;
+    const size_t stride = (size_t)gridDim.x * GS_BLOCK;
+    for (size_t j = i; j < n_zero; j += stride) zero[j] = 0;
 }
 
 // After the all-to-all: the overflow flags of ALL senders (bit 30 of the count in the header row of every received chunk)
@@ -319,16 +324,16 @@ extern "C" int32_t gs_exchange_flags(uint32_t world, const int32_t *recv, uint32
     return 0;
 }
 
-extern "C" int32_t gs_exchange_compact(uint32_t C_total, uint32_t N, uint32_t C_local, uint32_t world, uint32_t cap, uint32_t N_total,
-                                       uint32_t N_off, const int32_t *radii, int32_t *src_index, int32_t *hdr, uint32_t *counters,
-                                       uint32_t *stats, gs_stream_t stream) {
+static int32_t exchange_compact_impl(uint32_t C_total, uint32_t N, uint32_t C_local, uint32_t world, uint32_t cap, uint32_t N_total,
+                                     uint32_t N_off, const int32_t *radii, int32_t *src_index, int32_t *hdr, uint32_t *counters,
+                                     uint32_t *stats, int32_t *zero, size_t n_zero, gs_stream_t stream) {
     GS_CHECK_ARG(C_local >= 1 && world >= 1 && C_total == C_local * world && world <= 1024, "C_total = C_local * world, world <= 1024");
     GS_CHECK_ARG(src_index && hdr && counters && stats, "null pointer");
     GS_CHECK_ARG((uint64_t)C_total * N < (1ull << 31) && (uint64_t)C_local * N_total < (1ull << 31), "row indices must fit 31 bits");
     hipStream_t st = (hipStream_t)stream;
     const size_t rows = (size_t)world * (cap + 1);
     hipLaunchKernelGGL(exchange_init_kernel, dim3(gs_div_up(std::max(rows, (size_t)world), GS_BLOCK)), dim3(GS_BLOCK), 0, st, rows, world,
-                       src_index, (int2 *)hdr, counters, stats);
+                       src_index, (int2 *)hdr, counters, stats, zero, zero ? n_zero : (size_t)0);
     if (N > 0) {
         GS_CHECK_ARG(radii != nullptr, "null pointer");
         hipLaunchKernelGGL(exchange_compact_kernel, dim3(gs_div_up(N, COMPACT_BLOCK), C_total), dim3(COMPACT_BLOCK), 0, st, N, C_local, cap, N_total,
@@ -338,6 +343,12 @@ extern "C" int32_t gs_exchange_compact(uint32_t C_total, uint32_t N, uint32_t C_
     hipLaunchKernelGGL(exchange_header_kernel, dim3(1), dim3(1024), 0, st, world, cap, counters, (int2 *)hdr, stats);
     GS_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int32_t gs_exchange_compact(uint32_t C_total, uint32_t N, uint32_t C_local, uint32_t world, uint32_t cap, uint32_t N_total,
+                                       uint32_t N_off, const int32_t *radii, int32_t *src_index, int32_t *hdr, uint32_t *counters,
+                                       uint32_t *stats, gs_stream_t stream) {
+    return exchange_compact_impl(C_total, N, C_local, world, cap, N_total, N_off, radii, src_index, hdr, counters, stats, nullptr, 0, stream);
 }
 
 extern "C" int32_t gs_rows_pack(uint64_t n_rows, int32_t n_parts, const void *const *parts, const int32_t *widths,
@@ -648,16 +659,19 @@ extern "C" int32_t gs_scatter_add_rows_f32(uint64_t n_rows, uint32_t width, cons
 
 extern "C" int32_t gs_exchange_rows_send(uint32_t C_total, uint32_t N, uint32_t C_local, uint32_t world, uint32_t cap, uint32_t N_total,
                                          uint32_t N_off, const int32_t *radii, const float *rows, int32_t *src_index, int32_t *hdr,
-                                         uint32_t *counters, uint32_t *stats, float *send_rows, gs_stream_t stream) {
-    if (int32_t rc = gs_exchange_compact(C_total, N, C_local, world, cap, N_total, N_off, radii, src_index, hdr, counters, stats, stream)) return rc;
+                                         uint32_t *counters, uint32_t *stats, float *send_rows, int32_t *zero_radii, uint64_t n_zero,
+                                         gs_stream_t stream) {
+    if (int32_t rc = exchange_compact_impl(C_total, N, C_local, world, cap, N_total, N_off, radii, src_index, hdr, counters, stats, zero_radii,
+                                           (size_t)n_zero, stream))
+        return rc;
     return gs_rows16_gather((uint64_t)world * (cap + 1), src_index, 1, rows, hdr, send_rows, stream);
 }
 
 extern "C" int32_t gs_exchange_rows_recv(uint64_t n_recv, const float *recv_rows, uint64_t n_dst, float *dst_rows, int32_t *radii,
                                          float *depths, uint32_t world, const int64_t *hdr_rows, const uint32_t *stats, int32_t *out3,
-                                         gs_stream_t stream) {
+                                         int32_t radii_zeroed, gs_stream_t stream) {
     GS_CHECK_ARG(recv_rows != nullptr || n_recv == 0, "null pointer");
-    if (n_dst > 0) {
+    if (n_dst > 0 && !radii_zeroed) {
         GS_CHECK_ARG(radii != nullptr, "null pointer");
         if (hipMemsetAsync(radii, 0, n_dst * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) { gs_set_error("gs_exchange_rows_recv: memset failed"); return 1; }
     }

@@ -37,6 +37,9 @@ extern "C" int32_t gs_step_fwd_begin(gs_step *s, gs_stream_t stream) {
                      s->perm && s->n_kept && s->group_sums && s->block_sums,
                  "a phase-1 buffer is missing");
     const uint32_t n_elems = s->C * s->N;
+    // rows_ready: the splat rows, radii and depths are already there (they arrived through the multi-GPU exchange of the
+    // gaussian-sharded mode, C = the local cameras, N = all ranks' splats): binning only, the count kernel counts the tiles
+    if (!s->rows_ready)
     GS_STEP_TRY(gs_projection_rows_fwd(s->C, s->N, s->means, s->covars, s->quats, s->scales, s->viewmats, s->Ks, s->width, s->height, s->eps2d,
                                        s->near_plane, s->far_plane, s->radius_clip, s->camera_model, s->opacities, s->colors, s->antialiased,
                                        s->sh_coeffs, s->sh_rest, s->sh_K, s->sh_degree, s->sh_mask_logits, s->sh_mask_temperature, s->sh_mask_binary,
@@ -47,8 +50,9 @@ extern "C" int32_t gs_step_fwd_begin(gs_step *s, gs_stream_t stream) {
     GS_CHECK_ARG(!bucketed || s->splitters != nullptr, "the bucketed pre-sort needs the splitter table");
     if (bucketed) GS_STEP_TRY(gs_presort_split(n_elems, s->radii, s->depths, s->splitters, stream));
     // (the projection counted the tiles and left the block sums: the count kernel only makes the depth keys and their histogram)
-    GS_STEP_TRY(gs_isect_count_keys(n_elems, nullptr, GS_ROW_FLOATS, s->radii, s->depths, s->tile_size, s->tile_width, s->tile_height,
-                                    s->tiles_per_gauss, s->depth_keys, s->depth_vals, nullptr, hist_ready ? s->sort_temp : nullptr,
+    GS_STEP_TRY(gs_isect_count_keys(n_elems, s->rows_ready ? s->rows + GS_ROW_MEAN2D : nullptr, GS_ROW_FLOATS, s->radii, s->depths, s->tile_size,
+                                    s->tile_width, s->tile_height, s->tiles_per_gauss, s->depth_keys, s->depth_vals,
+                                    s->rows_ready ? s->block_sums : nullptr, hist_ready ? s->sort_temp : nullptr,
                                     hist_ready ? (size_t)s->sort_temp_bytes : 0, bucketed ? s->splitters : nullptr, stream));
     const uint32_t gshift = gs_isect_emit_group_shift();
     if (bucketed) {

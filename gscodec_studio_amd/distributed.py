@@ -39,8 +39,16 @@ from torch import Tensor
 # ---------------------------------------------------------------------------
 # low-level helpers
 # ---------------------------------------------------------------------------
+_BACKEND: dict = {"pg": None, "name": ""}
+
+
 def _backend_name() -> str:
-    return str(dist.get_backend()).lower()
+    # (cached per default process group -- the object itself is held, so a re-created group can never alias it: three
+    # look-ups per step at ~3 us each on a path that is bound by host work)
+    pg = dist.group.WORLD
+    if _BACKEND["pg"] is not pg:
+        _BACKEND["pg"], _BACKEND["name"] = pg, str(dist.get_backend()).lower()
+    return _BACKEND["name"]
 
 
 # bytes this rank puts on the wire (payload leaving the GPU, computed from the collective's shape: all-to-all = everything
@@ -586,15 +594,15 @@ class _ExchangeRows(torch.autograd.Function):
         hdr, counters, stats = aux[:n_send * 2], aux[n_send * 2:n_send * 2 + world], aux[n_send * 2 + world:]
         send = torch.empty((n_send, ROW), dtype=torch.float32, device=dev)
         radii = radii.contiguous()
+        radii_l = torch.empty((C_local, N_total), dtype=torch.int32, device=dev)  # (zero-filled by the call's first launch)
         with torch.cuda.device(dev):
             B.call("gs_exchange_rows_send", C_total, N, C_local, world, cap, N_total, N_off, B.ptr(radii), B.ptr(rows), B.ptr(src_index),
-                   B.ptr(hdr), B.ptr(counters), B.ptr(stats), B.ptr(send), st)
+                   B.ptr(hdr), B.ptr(counters), B.ptr(stats), B.ptr(send), B.ptr(radii_l), C_local * N_total, st)
         send_splits = [cap + 1] * world
         recv_splits = [int(c) + 1 for c in cap_world]
         n_recv = sum(recv_splits)
         recv = send.new_empty((n_recv, ROW))
         _all_to_all_single(recv, send, recv_splits, send_splits)
-        radii_l = torch.empty((C_local, N_total), dtype=torch.int32, device=dev)  # (zero-filled by the call below)
         depths_l = torch.empty((C_local, N_total), dtype=torch.float32, device=dev)
         rows_l = torch.empty((C_local, N_total, ROW), dtype=torch.float32, device=dev)
         key = (tuple(recv_splits), dev)
@@ -603,9 +611,9 @@ class _ExchangeRows(torch.autograd.Function):
         if _SPARSE.get("pinned") is None:
             _SPARSE["pinned"] = torch.empty(3, dtype=torch.int32).pin_memory()
         p3 = _SPARSE["pinned"]
-        with torch.cuda.device(dev):  # zero radii, scatter the rows to their places, collect the overflow flags: one call
+        with torch.cuda.device(dev):  # scatter the rows to their places, collect the overflow flags: one call
             B.call("gs_exchange_rows_recv", n_recv, B.ptr(recv), C_local * N_total, B.ptr(rows_l), B.ptr(radii_l), B.ptr(depths_l), world,
-                   B.ptr(_HDR_ROWS[key]), B.ptr(stats), B.ptr(p3), st)
+                   B.ptr(_HDR_ROWS[key]), B.ptr(stats), B.ptr(p3), 1, st)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         _SPARSE["overflow"], _SPARSE["stats"] = (p3, ev), (p3, ev, C_local * N)

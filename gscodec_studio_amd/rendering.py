@@ -366,15 +366,29 @@ def rasterization(
                 )
             # binning up to its read-back; the depth pre-sort queued behind the count keeps the GPU busy while the host
             # looks at the overflow flags (stored to pinned memory before the count) and comes back for the rest
-            isect_state = isect_tiles_start(
-                means2d, radii, depths, tile_size, tile_width, tile_height,
-                packed=packed, n_cameras=C, camera_ids=camera_ids, gaussian_ids=gaussian_ids,
-            )
+            rows_state = None
+            if use_rows and _step.rows_applicable(rows, colors, packed, render_mode, channel_chunk, deterministic, absgrad):
+                # (received rows: binning + compositing as native calls around the read-back, like the one-GPU fast path)
+                rows_state = _step.rows_begin(radii, depths, rows, tile_size, tile_width, tile_height)
+            else:
+                isect_state = isect_tiles_start(
+                    means2d, radii, depths, tile_size, tile_width, tile_height,
+                    packed=packed, n_cameras=C, camera_ids=camera_ids, gaussian_ids=gaussian_ids,
+                )
             if cap_world is None or not D.exchange_overflowed():
                 break
-            isect_tiles_abandon(isect_state)  # (its pinned block-sum buffer is still being written by the count kernel)
-            isect_state = None
+            # (the pinned block-sum buffer is still being written by the count kernel)
+            _step.rows_abandon(rows_state)
+            isect_tiles_abandon(isect_state)
+            isect_state = rows_state = None
             cap_world = [C_world[r] * N_world[r] for r in range(world_size)]
+        if rows_state is not None:
+            render_colors, render_alphas, tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = _step.rows_composite(
+                rows_state, means2d, conics, colors, opacities, backgrounds, width, height, absgrad, prefill)
+            meta.update({"tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids,
+                         "flatten_ids": flatten_ids, "isect_offsets": isect_offsets, "width": width, "height": height,
+                         "tile_size": tile_size, "n_cameras": C})
+            return render_colors, render_alphas, meta
 
     if render_mode in ["RGB+D", "RGB+ED"]:
         colors = torch.cat((colors, depths[..., None]), dim=-1)

@@ -864,14 +864,16 @@ int32_t gs_rows16_scatter(
  * by the host's launch work, every native call less counts):
  * gs_exchange_rows_send = gs_exchange_compact + gs_rows16_gather(src_index, hdr) into send_rows [world * (cap + 1), 16];
  *   src_index is kept for the backward, hdr / counters are scratch of the call.
+ *   zero_radii (optional, [n_zero] int32): zero-filled by the call's first launch -- the RECEIVER-side radii of the same
+ *   process, allocated before the all-to-all; gs_exchange_rows_recv(radii_zeroed = 1) then skips its own fill.
  * gs_exchange_rows_recv = zero-fill of radii [n_dst] + gs_rows16_scatter(index = column 12 of recv_rows) + gs_exchange_flags. */
 int32_t gs_exchange_rows_send(
     uint32_t C_total, uint32_t N, uint32_t C_local, uint32_t world, uint32_t cap, uint32_t N_total, uint32_t N_off,
     const int32_t *radii, const float *rows, int32_t *src_index, int32_t *hdr, uint32_t *counters, uint32_t *stats,
-    float *send_rows, gs_stream_t stream);
+    float *send_rows, int32_t *zero_radii, uint64_t n_zero, gs_stream_t stream);
 int32_t gs_exchange_rows_recv(
     uint64_t n_recv, const float *recv_rows, uint64_t n_dst, float *dst_rows, int32_t *radii, float *depths,
-    uint32_t world, const int64_t *hdr_rows, const uint32_t *stats, int32_t *out3, gs_stream_t stream);
+    uint32_t world, const int64_t *hdr_rows, const uint32_t *stats, int32_t *out3, int32_t radii_zeroed, gs_stream_t stream);
 /* After the all-to-all of those chunks: out3 = (some sender overflowed (bit 30 of the count in the header row hdr_rows[d] of
  * every received chunk; recv rows are row_width ints wide), stats[0], stats[1]).  out3 may be pinned HOST memory: the flags
  * then reach the host with the renderer's own tile-count read-back, without a copy command or a sync of their own. */
@@ -920,11 +922,12 @@ int32_t gs_dp_reduce_rows(uint64_t n_recv, uint32_t width, uint32_t world, const
  *    their sum, sizes the phase-2 buffers with gs_isect_finish_work_bytes / gs_rasterize_plan and allocates them)
  *   gs_step_fwd_finish  gs_isect_finish_presorted -> gs_rasterize_fwd (zero-filling zero_fill as its side job)
  *   gs_step_bwd         gs_rasterize_bwd (packed gradient rows) -> gs_projection_rows_bwd
+ * With rows_ready the first call starts at gs_isect_count_keys (binning + compositing of rows some other producer wrote).
  * All pointers are device pointers except block_sums (pinned host).  Buffers: radii i32 [C,N], depths [C,N], rows [C,N,16]
  * (64-byte aligned), tiles_per_gauss i32 [C,N], depth_keys i64 [C N], depth_vals i32 [C N], sort_temp
  * (gs_presort_temp_bytes / gs_sort_temp_bytes of C N), splitters i64 [256] (bucketed), sorted_keys i64 [C N] (radix), perm
  * i32 [C N], n_kept u32 [1], group_sums u32 [ceil(C N / 2^gs_isect_emit_group_shift())], group_prefix i64 of the same length
- * + cumsum_scratch (both or neither), block_sums i32 [gs_isect_count_blocks(C N)]; isect_ids i64 / flatten_ids i32
+ * + cumsum_scratch (both or neither), block_sums i32 [C * gs_projection_rows_blocks(N)] ([gs_isect_count_blocks(C N)] with rows_ready); isect_ids i64 / flatten_ids i32
  * [n_isects], offsets i32 [C, tile_height, tile_width], work (gs_isect_finish_work_bytes), render_colors [C,H,W,3],
  * render_alphas [C,H,W,1], last_ids i32 [C,H,W], scratch (plan.scratch_bytes; NULL: no checkpoints), zero_fill: the gradient rows
  * [C N,16] (+ whatever else the caller wants zeroed behind them); backward: grad_rows = that zero-filled buffer, v_* outputs as
@@ -943,7 +946,8 @@ typedef struct gs_step {
     const float *sh_mask_logits; /* the shN mask fused into the SH evaluation (split rows), or NULL */
     float *v_sh_mask_logits;     /* backward: [N] or NULL */
     float sh_mask_temperature;
-    uint32_t reserved0;
+    uint32_t rows_ready; /* != 0: rows / radii / depths are inputs (e.g. received through the gaussian-sharded exchange): no projection,
+                          * gs_isect_count_keys counts the tiles; block_sums then has gs_isect_count_blocks(C N) entries */
     const float *backgrounds; /* [C,3] or NULL */
     /* phase 1 */
     int32_t *radii;
