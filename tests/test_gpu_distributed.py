@@ -235,6 +235,58 @@ def _span_reduce(rank, world, port, backend):
         dist.destroy_process_group()
 
 
+def _dynamic_round_robin(rank, world, port, backend, frames):
+    """BASELINE config 5's multi-GPU half at fixture size: ``frames`` timestamps of ONE dynamic scene handed out round-robin
+    (frame f -> rank f % world, reference examples/simple_trainer_dyngs.py: one (camera, timestamp) sample per rank and step),
+    per frame round-quantize hooks -> temporal slice -> render -> backward, gradients accumulated over a rank's frames and
+    summed over the ranks: equals the single-process sum over all frames."""
+    dev = _setup(rank, world, port, backend)
+    try:
+        import numpy as np
+
+        from gscodec_studio_amd import distributed as D
+        from gscodec_studio_amd.compression_simulation import STGCompressionSimulation
+        from test_gpu_configs import _dyn_params, _dyn_step
+        from util import garden
+
+        fx = garden(3000, scale_mult=5.0)
+        raw = _dyn_params(fx["means"], fx["scales"], fx["quats"], fx["opacities"], fx["rgb"], seed=5)
+        W, H = fx["width"], fx["height"]
+        t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)  # noqa: E731
+        cams = [(t(fx["viewmats"][f % 3])[None], t(fx["Ks"][f % 3])[None], f / max(frames - 1, 1)) for f in range(frames)]
+
+        def run(P, frame_ids):
+            sim = STGCompressionSimulation(quantization_sim_type="round", entropy_steps={})
+            imgs = {}
+            for f in frame_ids:
+                vm, Ks, ts = cams[f]
+                _, rc, _, _ = _dyn_step(P, sim, vm, Ks, W, H, ts)
+                rc.sum().backward()
+                imgs[f] = rc.detach()
+            return imgs
+
+        P = {k: torch.nn.Parameter(t(v)) for k, v in raw.items()}
+        mine = run(P, range(rank, frames, world))
+        D.all_reduce_splat_grads(P, average=False)
+        R = {k: torch.nn.Parameter(t(v)) for k, v in raw.items()}
+        ref = run(R, range(frames))
+        for f, img in mine.items():
+            assert torch.allclose(img, ref[f], rtol=1e-5, atol=1e-6), f
+        seen = 0
+        for k in P:
+            if R[k].grad is None:
+                assert P[k].grad is None or float(P[k].grad.abs().max()) == 0.0, k
+                continue
+            seen += 1
+            assert _rel(P[k].grad, R[k].grad) < 5e-4, (k, _rel(P[k].grad, R[k].grad))
+        assert seen >= 9
+        for k in ("scales", "quats", "opacities", "colors"):  # the in-place clamp of the round hooks is the same on every rank
+            assert torch.equal(P[k].detach(), R[k].detach()), k
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
 def _spawn(fn, args, nprocs, deadline_s=150):
     """mp.spawn with a deadline: a rank stuck in a collective (its peer died) must not hang the suite."""
     import time
@@ -313,6 +365,11 @@ def test_camera_sharded_sparse_gradients_world8():
 @pytest.mark.parametrize("sparse", [True, False])
 def test_gaussian_sharded_world8(sparse):
     _spawn(_gaussian_sharded, (8, _free_port(), _backend_for(8), False, sparse, 1), 8, deadline_s=600)
+
+
+@pytest.mark.parametrize("world,frames", [(8, 8), (8, 19), (2, 5)])
+def test_config5_dynamic_frames_round_robin(world, frames):
+    _spawn(_dynamic_round_robin, (world, _free_port(), _backend_for(world), frames), world, deadline_s=240)
 
 
 def test_camera_sharded_rccl_world1():
