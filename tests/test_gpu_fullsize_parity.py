@@ -177,7 +177,9 @@ def test_config4_eight_cameras_full_size_vs_oracle():
     fixture cameras and their rolled copies -- eight distinct views with 2x different visible counts).  Unpacked: the full
     recipe above for all 8 cameras at once (binning bit-exact for every camera, image 1e-4, the five parameter gradients --
     sums over the 8 cameras -- within 1e-4 of the float64 oracle chain).  Packed: the same batch through the COO pipeline:
-    identical intersection keys, the same image, gradients within 1e-5 relative L2 of the unpacked ones."""
+    its own binning bit-exact against the oracle on ITS projection outputs, the visible set equal to the unpacked one up to
+    <= 1e-5 of the pairs (the two projection kernels contract their arithmetic differently: a radius at the clip threshold may
+    fall on either side), the same image and gradients up to those pairs."""
     from gscodec_studio_amd import rasterization
     from gscodec_studio_amd._helper import sh_workload
 
