@@ -1,3 +1,5 @@
+# Gaussian-sharded step at world 1 with the collectives forced through RCCL: tests, bench (plain / gaussian / operator path),
+# kernel timeline, host-bound step.  Run on the GPU box: bash tools/dist_profile.sh
 mkdir -p gpurun_out/dist
 python -m pytest tests/test_gpu_step.py tests/test_gpu_distributed.py -x -q 2>&1 | tail -5
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-dp-projection 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('plain', d['ms_per_step'])"
