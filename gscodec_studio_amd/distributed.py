@@ -188,16 +188,17 @@ def _host_group():
     """A gloo group next to the RCCL one, for exchanging HOST integers (shard sizes) without touching the GPU queue:
     a device-side gather + read-back would make the host wait for the whole previous step before it can queue the
     next one.  None when it cannot be created (then the device path is used)."""
-    key = id(dist.group.WORLD)
-    if key not in _HOST_GROUP:
+    world = dist.group.WORLD
+    hit = _HOST_GROUP.get("world")
+    if hit is None or hit[0] is not world:  # (the world object itself is held: a re-created default group can never alias it)
         g = None
         if "nccl" in _backend_name() and os.environ.get("GS_DIST_HOST_GROUP", "1") == "1":
             try:
                 g = dist.new_group(backend="gloo")
             except Exception:  # noqa: BLE001 -- same outcome on every rank (same environment)
                 g = None
-        _HOST_GROUP[key] = g
-    return _HOST_GROUP[key]
+        hit = _HOST_GROUP["world"] = (world, g)
+    return hit[1]
 
 
 def gather_shard_meta(world_size: int, N: int, viewmats: Tensor, Ks: Tensor, cap: int = 0):

@@ -6,6 +6,9 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/final
 mkdir -p "$out"
 cd "$root"
+# (the counter passes first: bench.py reads roofline.traffic / roofline.valu from the file they produce)
+bash tools/pmc.sh "$out/${tag}_pmc_traffic.json" > "$out/pmc.log" 2>&1
+cp "$out/${tag}_pmc_traffic.json" profiles/${tag}_pmc_traffic.json
 python bench.py > "$out/${tag}_bench.json" 2> "$out/bench.err" < /dev/null
 python bench.py --gpus 1 --steps 20 --warmup 5 > "$out/${tag}_bench_driver_cmd.json" 2>> "$out/bench.err" < /dev/null
 {
@@ -19,7 +22,6 @@ cp gpurun_out/prof_${tag}_last_step.txt "$out/${tag}_last_step_timeline.txt"
 bash tools/prof.sh ${tag}q --quantize --ada-mask > "$out/profq.log" 2>&1
 cp gpurun_out/prof_${tag}q_kernel_stats.csv "$out/${tag}_quantize_kernel_stats.csv"
 cp gpurun_out/prof_${tag}q_last_step.txt "$out/${tag}_quantize_last_step_timeline.txt"
-bash tools/pmc.sh "$out/${tag}_pmc_traffic.json" > "$out/pmc.log" 2>&1
 {
   python tools/bench_multicam.py 2>/dev/null
   python tools/bench_inference.py 2>/dev/null
@@ -34,4 +36,17 @@ python tools/bench_profile_protocol.py 5 > "$out/${tag}_profile_protocol.txt" 2>
 python -m pytest tests/test_gpu_fullsize_parity.py -q -s 2>&1 | grep -E "full size|config 4|passed|failed" > "$out/${tag}_fullsize_parity.txt"
 ./build_abl/mfma_reduce_ab > "$out/${tag}_mfma_reduce_ab.txt" 2>&1
 ./build_abl/presort_bench > "$out/${tag}_presort_breakdown.txt" 2>&1
+{
+  python tools/host_phases.py 2>&1 | grep " us"
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-dp-projection 2>/dev/null < /dev/null | tail -1 | python -c "import sys,json; print('plain ms/step', round(json.loads(sys.stdin.read())['ms_per_step'], 4))"
+  for i in 1 2 3; do
+    GS_BENCH_PG=1 GS_DIST_FORCE_COLLECTIVES=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=2965$i python bench.py --gpus 1 --dp-mode gaussian --steps 20 --warmup 5 --min-timed-s 0.3 --no-cpu-baseline --no-extras --no-dp-projection 2>/dev/null < /dev/null | tail -1 | python -c "import sys,json; print('gaussian-sharded, world 1, forced collectives: ms/step', round(json.loads(sys.stdin.read())['ms_per_step'], 4))"
+  done
+} > "$out/${tag}_gaussian_mode.txt" 2>&1
+# extended fuzz sessions on the final kernels (shifted seeds; every kernel route)
+{
+  for k in 4100 4200 4300 4400 4500 4600 4700 4800 4900 5000 5100 5200 5300 5400 5500 5600 5700 5800 5900 6000; do
+    echo "GS_FUZZ_SEED_OFFSET=$k: $(GS_FUZZ_SEED_OFFSET=$k python -m pytest tests/test_gpu_fuzz.py -q 2>&1 | tail -1)"
+  done
+} > "$out/${tag}_fuzz_extended.txt" 2>&1
 echo done
