@@ -64,6 +64,20 @@ class _Step(ctypes.Structure):  # gs_step of include/gsplat_hip.h (field for fie
     ]
 
 
+_LAYOUT_FIELDS = ("C", "sh_K", "eps2d", "tile_size", "sh_mask_logits", "rows_ready", "backgrounds", "radii", "sort_temp_bytes", "block_sums",
+                  "n_isects", "work_bytes", "plan", "scratch", "zero_fill_bytes", "v_render_colors", "vrc_pixel_stride", "grad_rows",
+                  "v_sh_rest", "absgrad", "finish_phase")
+
+
+def check_layout() -> None:
+    """The ctypes mirror above against the library's own ``sizeof`` / ``offsetof`` of ``gs_step`` (``gs_step_layout``)."""
+    want = (ctypes.c_uint64 * 64)()
+    m = int(B.query("gs_step_layout", want, 64))
+    mine = [ctypes.sizeof(_Step)] + [getattr(_Step, f).offset for f in _LAYOUT_FIELDS]
+    if m != len(mine) or list(want[:m]) != mine:
+        raise ImportError(f"gs_step: the ctypes mirror in _step.py does not match the library's struct layout ({list(want[:m])} vs {mine})")
+
+
 _ROW_STRIDES = (ctypes.c_uint32 * 4)(W.ROW, W.ROW, W.ROW, W.ROW)
 
 
@@ -129,6 +143,28 @@ def _phase1(s: "_Step", C: int, N: int, dev, n_sums: int, given=None) -> dict:
     # (the dict keeps every buffer alive until the forward's launches are queued)
     return {"radii": radii, "depths": depths, "rows": rows, "tiles_per_gauss": tiles_per_gauss, "pinned": pinned,
             "keep": (dkeys, dvals, perm, n_kept, gsums, temp, split, ko, gpre, scratch1)}
+
+
+_LEAKED: list = []  # pinned buffers a kernel may still write to (never handed back: see _drop_pinned)
+
+
+def _drop_pinned(bufs: Optional[dict], n_sums: int) -> None:
+    """Give the pinned block-sum buffer of an abandoned forward back.  The count kernel stores into it from the GPU and torch's
+    pinned allocator does not see kernel stores: the buffer may only be reused once every sum has landed -- bounded wait, and
+    if the kernel never gets there (a failed launch in front of it) the buffer is kept alive for good instead."""
+    if not bufs or bufs.get("pinned") is None:
+        return
+    import time
+
+    pinned, bufs["pinned"] = bufs["pinned"], None
+    ev = W._SentinelEvent(pinned)
+    deadline = time.perf_counter() + 1.0
+    while not ev.query():
+        if time.perf_counter() > deadline:
+            _LEAKED.append(pinned)
+            return
+        time.sleep(0)
+    W._PINNED_FREE.setdefault(n_sums, []).append(pinned)
 
 
 def _finish(s, sp, stream, bufs, n_sums, C, N, height, width, tile_height, tile_width, dev, needs_bwd, prefill):
@@ -226,11 +262,14 @@ class _StepProject(torch.autograd.Function):
                 ("means", means, need[0]), ("covars", covars, need[1]), ("quats", quats, need[2]), ("scales", scales, need[3]),
                 ("opacities", opacities, need[6]), ("colors", colors, need[7]), ("sh", sh_coeffs, need[8]), ("sh_rest", sh_rest, need[9]))
                 if t is not None and flag]
-        with torch.cuda.device(dev):
-            B.call("gs_step_fwd_begin", sp, stream)
-            (offsets, isect_ids, flatten_ids, render_colors, render_alphas, last_ids, fill, prefill, scratch, plan) = _finish(
-                s, sp, stream, bufs, n_sums, C, N, height, width, tile_height, tile_width, dev, needs_bwd, prefill)
-        n_isects = isect_ids.shape[0]
+        try:
+            with torch.cuda.device(dev):
+                B.call("gs_step_fwd_begin", sp, stream)
+                (offsets, isect_ids, flatten_ids, render_colors, render_alphas, last_ids, fill, prefill, scratch, plan) = _finish(
+                    s, sp, stream, bufs, n_sums, C, N, height, width, tile_height, tile_width, dev, needs_bwd, prefill)
+        except BaseException:
+            _drop_pinned(bufs, n_sums)  # (an error between the two calls: the count kernel may still be storing into it)
+            raise
         # ---- node 2's share
         hand.render_colors, hand.render_alphas, hand.last_ids, hand.scratch, hand.plan = render_colors, render_alphas, last_ids, scratch, plan
         hand.grad_rows = fill[:n_elems * 16].view(C, N, 16) if fill is not None else None
@@ -277,6 +316,12 @@ class _RowsState:
 
     __slots__ = ("s", "bufs", "n_sums", "C", "N", "dev", "tile")
 
+    def __del__(self):  # dropped without finish or abandon (an exception in between): same care for the pinned buffer
+        try:
+            _drop_pinned(getattr(self, "bufs", None), getattr(self, "n_sums", 0))
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
 
 def rows_applicable(rows: Optional[Tensor], colors: Optional[Tensor], packed: bool, render_mode: str, channel_chunk: int,
                     deterministic: bool, absgrad: bool) -> bool:
@@ -297,6 +342,7 @@ def rows_begin(radii: Tensor, depths: Tensor, rows: Tensor, tile_size: int, tile
     s.tile_size, s.tile_width, s.tile_height = tile_size, tile_width, tile_height
     n_sums = int(B.query("gs_isect_count_blocks", C * N))
     st.s, st.n_sums, st.C, st.N, st.dev, st.tile = s, n_sums, C, N, dev, (tile_size, tile_width, tile_height)
+    st.bufs = None
     st.bufs = _phase1(s, C, N, dev, n_sums, given=(radii, depths, rows))
     with torch.cuda.device(dev):
         B.call("gs_step_fwd_begin", ctypes.addressof(s), torch.cuda.current_stream(dev).cuda_stream)
@@ -306,12 +352,8 @@ def rows_begin(radii: Tensor, depths: Tensor, rows: Tensor, tile_size: int, tile
 def rows_abandon(st: Optional[_RowsState]) -> None:
     """Drop a ``rows_begin`` without finishing it (the sparse exchange's overflow retry).  The count kernel stores its block
     sums straight into the pinned buffer: it goes back to the free list only once the kernel has run."""
-    if st is None or st.bufs.get("pinned") is None:
-        return
-    pinned = st.bufs["pinned"]
-    W._wait_event(W._SentinelEvent(pinned))
-    W._PINNED_FREE.setdefault(st.n_sums, []).append(pinned)
-    st.bufs["pinned"] = None
+    if st is not None:
+        _drop_pinned(st.bufs, st.n_sums)
 
 
 class _StepRowsComposite(torch.autograd.Function):
@@ -339,7 +381,7 @@ class _StepRowsComposite(torch.autograd.Function):
         tiles_per_gauss = st.bufs["tiles_per_gauss"]
         ctx.mark_non_differentiable(tiles_per_gauss, isect_ids, flatten_ids, offsets)
         ctx.set_materialize_grads(False)
-        st.bufs = None
+        st.bufs = None  # (its pinned buffer went back to the free list inside _finish)
         return render_colors, render_alphas, tiles_per_gauss, isect_ids, flatten_ids, offsets
 
     @staticmethod
@@ -357,6 +399,7 @@ _GSHIFT, _PREFIX_FROM = [0], [8192]
 
 
 def _init_consts() -> int:
+    check_layout()  # (once per process, before the first descriptor is handed to the library)
     _GSHIFT[0] = int(B.query("gs_isect_emit_group_shift"))
     _PREFIX_FROM[0] = int(B.query("gs_isect_emit_prefix_from_groups"))
     return _GSHIFT[0]

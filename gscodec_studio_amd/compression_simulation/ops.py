@@ -104,6 +104,18 @@ class _QuantDesc(ctypes.Structure):  # gs_quant_desc of include/gsplat_hip.h
 
 
 QUANT_MULTI_MAX = 8
+_DESC_CHECKED = [False]
+
+
+def check_desc_layout() -> None:
+    """``_QuantDesc`` against the library's ``sizeof`` / ``offsetof`` of ``gs_quant_desc``."""
+    want = (ctypes.c_uint64 * 16)()
+    m = int(B.query("gs_quant_desc_layout", want, 16))
+    mine = [ctypes.sizeof(_QuantDesc)] + [getattr(_QuantDesc, f).offset for f in ("n", "x", "out", "v_out", "v_x", "lo", "q_step", "activation",
+                                                                                  "philox_offset")]
+    if m != len(mine) or list(want[:m]) != mine:
+        raise ImportError(f"gs_quant_desc: the ctypes mirror in ops.py does not match the library's struct layout ({list(want[:m])} vs {mine})")
+    _DESC_CHECKED[0] = True
 _GRID_CAP: Dict[int, int] = {}
 
 
@@ -124,6 +136,8 @@ class _NoiseQuantMulti(torch.autograd.Function):
     @staticmethod
     def forward(ctx, specs: Sequence[Tuple[float, float, float, int]], *xs: Tensor):
         dev = xs[0].device
+        if not _DESC_CHECKED[0]:
+            check_desc_layout()
         for x in xs:
             _require_gpu(x, "fake_quantize_ste")
             if x.dtype != torch.float32 or x.device != dev:

@@ -30,6 +30,30 @@ static uint32_t floor_log2_plus1(uint32_t x) { // floor(log2(x)) + 1, as the ref
     return b ? b : 1;
 }
 
+#include <cstddef>
+
+extern "C" uint32_t gs_step_layout(uint64_t *out, uint32_t n) {
+    const uint64_t v[] = {sizeof(gs_step), offsetof(gs_step, C), offsetof(gs_step, sh_K), offsetof(gs_step, eps2d), offsetof(gs_step, tile_size),
+                          offsetof(gs_step, sh_mask_logits), offsetof(gs_step, rows_ready), offsetof(gs_step, backgrounds),
+                          offsetof(gs_step, radii), offsetof(gs_step, sort_temp_bytes), offsetof(gs_step, block_sums),
+                          offsetof(gs_step, n_isects), offsetof(gs_step, work_bytes), offsetof(gs_step, plan), offsetof(gs_step, scratch),
+                          offsetof(gs_step, zero_fill_bytes), offsetof(gs_step, v_render_colors), offsetof(gs_step, vrc_pixel_stride),
+                          offsetof(gs_step, grad_rows), offsetof(gs_step, v_sh_rest), offsetof(gs_step, absgrad),
+                          offsetof(gs_step, finish_phase)};
+    const uint32_t m = (uint32_t)(sizeof(v) / sizeof(v[0]));
+    for (uint32_t i = 0; out != nullptr && i < n && i < m; ++i) out[i] = v[i];
+    return m;
+}
+
+extern "C" uint32_t gs_quant_desc_layout(uint64_t *out, uint32_t n) {
+    const uint64_t v[] = {sizeof(gs_quant_desc), offsetof(gs_quant_desc, n), offsetof(gs_quant_desc, x), offsetof(gs_quant_desc, out),
+                          offsetof(gs_quant_desc, v_out), offsetof(gs_quant_desc, v_x), offsetof(gs_quant_desc, lo),
+                          offsetof(gs_quant_desc, q_step), offsetof(gs_quant_desc, activation), offsetof(gs_quant_desc, philox_offset)};
+    const uint32_t m = (uint32_t)(sizeof(v) / sizeof(v[0]));
+    for (uint32_t i = 0; out != nullptr && i < n && i < m; ++i) out[i] = v[i];
+    return m;
+}
+
 extern "C" int32_t gs_step_fwd_begin(gs_step *s, gs_stream_t stream) {
     GS_CHECK_ARG(s != nullptr, "null descriptor");
     GS_CHECK_ARG(s->C > 0 && s->N > 0, "C and N must be > 0");

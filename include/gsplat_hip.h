@@ -984,6 +984,14 @@ typedef struct gs_step {
     int32_t absgrad, outputs_prefilled, skip_projection_bwd;
     int32_t finish_phase; /* gs_step_fwd_finish: 0 = binning + compositing, 1 = binning only, 2 = compositing only */
 } gs_step;
+/* Layout guard for bindings that mirror the host structs by hand (ctypes, cgo, JNA ...): writes up to n entries --
+ * sizeof(struct), then offsetof of the listed fields in this order -- and returns how many the list has.
+ *   gs_step:       C, sh_K, eps2d, tile_size, sh_mask_logits, rows_ready, backgrounds, radii, sort_temp_bytes, block_sums, n_isects,
+ *                  work_bytes, plan, scratch, zero_fill_bytes, v_render_colors, vrc_pixel_stride, grad_rows, v_sh_rest, absgrad,
+ *                  finish_phase
+ *   gs_quant_desc: n, x, out, v_out, v_x, lo, q_step, activation, philox_offset */
+uint32_t gs_step_layout(uint64_t *out, uint32_t n);
+uint32_t gs_quant_desc_layout(uint64_t *out, uint32_t n);
 int32_t gs_step_fwd_begin(gs_step *step, gs_stream_t stream);
 int32_t gs_step_fwd_finish(gs_step *step, gs_stream_t stream);
 int32_t gs_step_bwd(gs_step *step, gs_stream_t stream);

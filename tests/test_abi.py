@@ -110,6 +110,31 @@ def test_cpu_tensors_are_rejected_not_emulated():
         fake_quantize_ste(torch.randn(10), -1, 1, 8, "round")
 
 
+def test_host_struct_mirrors_match_the_library_layout():
+    """The two host structs that cross the boundary by pointer (gs_step, gs_quant_desc) are mirrored by hand in ctypes: the
+    library reports its own sizeof / offsetof (gs_step_layout, gs_quant_desc_layout) and the mirrors must agree; a mirror that
+    drifts is refused before a descriptor is ever handed over."""
+    import ctypes
+
+    from gscodec_studio_amd import _step
+    from gscodec_studio_amd.compression_simulation import ops
+
+    _step.check_layout()
+    ops.check_desc_layout()
+    assert int(_step.B.query("gs_step_layout", None, 0)) == 1 + len(_step._LAYOUT_FIELDS)
+
+    class Drift(ctypes.Structure):  # a field too many in the middle: everything behind it moves
+        _fields_ = _step._Step._fields_[:5] + [("extra", ctypes.c_uint64)] + _step._Step._fields_[5:]
+
+    real = _step._Step
+    _step._Step = Drift
+    try:
+        with pytest.raises(ImportError, match="struct layout"):
+            _step.check_layout()
+    finally:
+        _step._Step = real
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under gscodec_studio_amd/ may reference it."""
     pkg = os.path.join(ROOT, "gscodec_studio_amd")
