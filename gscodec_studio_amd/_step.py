@@ -54,7 +54,7 @@ class _Step(ctypes.Structure):  # gs_step of include/gsplat_hip.h (field for fie
         ("radii", _P), ("depths", _P), ("rows", _P), ("tiles_per_gauss", _P), ("depth_keys", _P), ("depth_vals", _P),
         ("sort_temp", _P), ("sort_temp_bytes", _U64), ("splitters", _P), ("sorted_keys", _P), ("perm", _P), ("n_kept", _P),
         ("group_sums", _P), ("group_prefix", _P), ("cumsum_scratch", _P), ("cumsum_scratch_bytes", _U64), ("block_sums", _P),
-        ("n_isects", _U64), ("isect_ids", _P), ("flatten_ids", _P), ("offsets", _P), ("work", _P), ("work_bytes", _U64),
+        ("n_isects", _U64), ("n_kept_host", _U32), ("reserved1", _U32), ("isect_ids", _P), ("flatten_ids", _P), ("offsets", _P), ("work", _P), ("work_bytes", _U64),
         ("render_colors", _P), ("render_alphas", _P), ("last_ids", _P), ("plan", _Plan), ("scratch", _P), ("zero_fill", _P),
         ("zero_fill_bytes", _U64),
         ("v_render_colors", _P), ("v_render_alphas", _P), ("vrc_pixel_stride", _I64), ("vrc_channel_stride", _I64),
@@ -65,7 +65,7 @@ class _Step(ctypes.Structure):  # gs_step of include/gsplat_hip.h (field for fie
 
 
 _LAYOUT_FIELDS = ("C", "sh_K", "eps2d", "tile_size", "sh_mask_logits", "rows_ready", "backgrounds", "radii", "sort_temp_bytes", "block_sums",
-                  "n_isects", "work_bytes", "plan", "scratch", "zero_fill_bytes", "v_render_colors", "vrc_pixel_stride", "grad_rows",
+                  "n_isects", "n_kept_host", "work_bytes", "plan", "scratch", "zero_fill_bytes", "v_render_colors", "vrc_pixel_stride", "grad_rows",
                   "v_sh_rest", "absgrad", "finish_phase")
 
 
@@ -134,7 +134,7 @@ def _phase1(s: "_Step", C: int, N: int, dev, n_sums: int, given=None) -> dict:
         sb1 = B.query("gs_cumsum_scratch_bytes", n_groups)
         scratch1 = empty(sb1, dtype=u8, device=dev)
         s.cumsum_scratch, s.cumsum_scratch_bytes = ptr(scratch1), sb1
-    pinned = W._pinned_take(n_sums)
+    pinned = W._pinned_take(2 * n_sums)  # [n_sums][2]: (intersections, visible elements) per block
     s.radii, s.depths, s.rows, s.tiles_per_gauss = ptr(radii), ptr(depths), ptr(rows), ptr(tiles_per_gauss)
     s.depth_keys, s.depth_vals, s.sort_temp, s.sort_temp_bytes = ptr(dkeys), ptr(dvals), ptr(temp), tb
     s.splitters, s.sorted_keys, s.perm, s.n_kept, s.group_sums, s.group_prefix = ptr(split), ptr(ko), ptr(perm), ptr(n_kept), ptr(gsums), ptr(gpre)
@@ -164,7 +164,7 @@ def _drop_pinned(bufs: Optional[dict], n_sums: int) -> None:
             _LEAKED.append(pinned)
             return
         time.sleep(0)
-    W._PINNED_FREE.setdefault(n_sums, []).append(pinned)
+    W._PINNED_FREE.setdefault(2 * n_sums, []).append(pinned)
 
 
 def _finish(s, sp, stream, bufs, n_sums, C, N, height, width, tile_height, tile_width, dev, needs_bwd, prefill):
@@ -180,7 +180,9 @@ def _finish(s, sp, stream, bufs, n_sums, C, N, height, width, tile_height, tile_
     # ---- the one host sync: the count kernel's block sums land in pinned memory (-1 -> >= 0).  From here to the
     # binning launches the GPU has ~40 us of pre-sort left: nothing that can be done earlier or later sits in between
     W._wait_event(sentinel)
-    n_isects = int(sentinel.np.sum(dtype="int64"))
+    totals = sentinel.np.reshape(-1, 2).sum(0, dtype="int64")
+    n_isects = int(totals[0])
+    s.n_kept_host = int(totals[1]) if W._PACKED_PAIRS else 0
     isect_ids = empty(n_isects, dtype=i64, device=dev)
     flatten_ids = empty(n_isects, dtype=i32, device=dev)
     wb = B.query("gs_isect_finish_work_bytes", n_isects)
@@ -190,7 +192,7 @@ def _finish(s, sp, stream, bufs, n_sums, C, N, height, width, tile_height, tile_
     # compositing scratch is sized and allocated while it runs
     s.finish_phase = 1
     B.call("gs_step_fwd_finish", sp, stream)
-    W._PINNED_FREE.setdefault(n_sums, []).append(pinned)
+    W._PINNED_FREE.setdefault(2 * n_sums, []).append(pinned)
     bufs["pinned"] = None
     # ---- the compositing buffers (made while the GPU is busy with the binning)
     render_colors = empty((C, height, width, 3), dtype=f32, device=dev)

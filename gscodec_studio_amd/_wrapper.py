@@ -1235,6 +1235,11 @@ def _pinned_take(n: int) -> Tensor:
     return buf
 
 
+# (camera, tile) key + depth rank as ONE 32-bit word through emission and pair sort when they fit (gs_isect_finish_presorted's
+# n_kept_host): GS_PACKED_PAIRS=0 keeps the (key, flatten id) pairs
+_PACKED_PAIRS = os.environ.get("GS_PACKED_PAIRS", "1") != "0"
+
+
 class _SentinelEvent:
     """``query`` / ``synchronize`` of an event over a pinned buffer whose entries go from -1 to >= 0 as the kernel stores them
     (posted 4-byte writes of independent workgroups into host-coherent memory: each becomes visible on its own)."""
@@ -1300,9 +1305,10 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                 # (a few thousand blocks -- 983 at 1 M splats -- store straight into pinned memory; beyond that the sums are
                 # added up on the device and 8 bytes are copied, as in round 1: with 48 K block sums per step at 49 M splats,
                 # stored directly OR copied as one 192 KB block, every third or fourth forward stalled the GPU for ~85 ms)
+                # every block reports (intersections, visible elements) as one 8-byte store: [n_sums][2]
                 direct = n_sums <= _PINNED_DIRECT_MAX
-                pinned = _pinned_take(n_sums) if direct else torch.empty(1, dtype=torch.int64, pin_memory=True)
-                bsums = pinned if direct else torch.empty(n_sums, dtype=torch.int32, device=dev)
+                pinned = _pinned_take(2 * n_sums) if direct else torch.empty(2, dtype=torch.int64, pin_memory=True)
+                bsums = pinned if direct else torch.empty(2 * n_sums, dtype=torch.int32, device=dev)
                 # the depth pre-sort: up to 2 M elements the BUCKETED form (sampled splitters -> one partition pass -> local
                 # sorts in LDS: 4 launches), above that the plain LSD radix sort (4 passes, bandwidth-bound there); the count
                 # kernel counts the digits of the first (only) partition pass into the sort's temp buffer either way
@@ -1320,7 +1326,7 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                 if direct:
                     ev = _SentinelEvent(pinned)
                 else:
-                    pinned.copy_(bsums.sum(dtype=torch.int64).reshape(1), non_blocking=True)
+                    pinned.copy_(bsums.view(-1, 2).sum(0, dtype=torch.int64), non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream(dev))
                 # culled elements carry the maximal key: the sort drops them in its first pass
@@ -1344,6 +1350,7 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                     scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
                     B.call("gs_cumsum_i32", gsums.numel(), B.ptr(gsums), B.ptr(gpre), B.ptr(scratch), sb, st)
                 st_["perm"], st_["n_kept"], st_["gsums"], st_["gpre"] = perm, n_kept, gsums, gpre
+                st_["sorted_keys"] = dkeys if bucketed else ko  # (depth bits << 32 | element) in perm's order
                 cum = None
             else:
                 cum = torch.empty(n_elems, dtype=torch.int64, device=dev)
@@ -1398,10 +1405,14 @@ def isect_tiles_finish(st_, offsets_for: Optional[int] = None):
     offsets = None
     if offsets_for is not None:  # (allocated before the wait: its size does not depend on the count)
         offsets = torch.empty((offsets_for, st_["tile_height"], st_["tile_width"]), dtype=torch.int32, device=dev)
-    n_isects = 0
+    n_isects = n_kept = 0
     if st_["event"] is not None:
         _wait_event(st_["event"])  # the one host sync (isect_tiles.cu:200)
-        n_isects = int(st_["pinned"].sum(dtype=torch.int64))
+        if st_["pinned"].numel() == 1:  # (the unsorted path: cum[-1])
+            n_isects = int(st_["pinned"][0])
+        else:  # [blocks][2] (or their two totals): intersections, elements the depth pre-sort keeps
+            pairs = st_["pinned"].numpy().reshape(-1, 2).sum(0, dtype="int64")
+            n_isects, n_kept = int(pairs[0]), int(pairs[1])
         if st_["pinned"].dtype == torch.int32:
             _PINNED_FREE.setdefault(st_["pinned"].numel(), []).append(st_["pinned"])
             st_["pinned"] = None
@@ -1414,7 +1425,8 @@ def isect_tiles_finish(st_, offsets_for: Optional[int] = None):
             B.call("gs_isect_finish_presorted", st_["n_elems"], max(st_["N"], 1), n_isects, B.ptr(st_["perm"]), B.ptr(st_["n_kept"]),
                    B.ptr(st_["camera_ids"]), B.ptr(means2d), st_["s_m2"], B.ptr(radii), B.ptr(depths), B.ptr(st_["tiles_per_gauss"]),
                    B.ptr(st_["gsums"]), B.ptr(st_["gpre"]), st_["tile_size"], st_["tile_width"], st_["tile_height"], st_["tile_n_bits"],
-                   st_["cam_n_bits"], offsets_for, B.ptr(isect_ids), B.ptr(flatten_ids), B.ptr(offsets), B.ptr(work), wb, st)
+                   st_["cam_n_bits"], offsets_for, B.ptr(isect_ids), B.ptr(flatten_ids), B.ptr(offsets), B.ptr(work), wb,
+                   n_kept if _PACKED_PAIRS else 0, B.ptr(st_.get("sorted_keys")), st)
             return st_["tiles_per_gauss"], isect_ids, flatten_ids, offsets
         if n_isects > 0 and st_["sort"]:
             # compact form: (32-bit camera|tile key, flatten id) pairs = 8 B instead of 12 through the sort; its last pass

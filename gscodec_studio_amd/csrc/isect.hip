@@ -51,13 +51,13 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_count_keys_kernel(
     const float *__restrict__ depths, float tile_size, int32_t tw, int32_t th,
     int32_t *__restrict__ tiles_per_gauss, int64_t *__restrict__ keys, int32_t *__restrict__ vals, int32_t *__restrict__ block_sums,
     uint32_t *__restrict__ hist, uint32_t n_blocks, const uint64_t *__restrict__ split) {
-    __shared__ int32_t s_sum[GS_BLOCK / GS_WAVE];
+    __shared__ int32_t s_sum[GS_BLOCK / GS_WAVE], s_vis[GS_BLOCK / GS_WAVE];
     __shared__ uint32_t s_hist[256];
     __shared__ uint64_t s_split[GS_PRESORT_BUCKETS];
     if (hist != nullptr) s_hist[threadIdx.x] = 0u;
     if (split != nullptr) s_split[threadIdx.x] = split[threadIdx.x]; // bucketed pre-sort: digit = bucket of the whole key
     __syncthreads();
-    int32_t cnt_sum = 0;
+    int32_t cnt_sum = 0, vis_sum = 0;
 #pragma unroll
     for (int k = 0; k < COUNT_ITEMS; ++k) {
         const uint32_t i = (blockIdx.x * COUNT_ITEMS + k) * GS_BLOCK + threadIdx.x;
@@ -78,15 +78,23 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_count_keys_kernel(
         keys[i] = (int64_t)key;
         vals[i] = (int32_t)i;
         cnt_sum += cnt;
+        vis_sum += r > 0 ? 1 : 0;
         if (hist != nullptr && d != 0x7fffffffu) atomicAdd(&s_hist[split != nullptr ? gs_bucket_of(s_split, key) : (d & 0xffu)], 1u);
     }
     if (block_sums != nullptr) { // (block-uniform)
-        int32_t v = cnt_sum;
+        int32_t v = cnt_sum, u = vis_sum;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if ((threadIdx.x & 63u) == 0u) s_sum[threadIdx.x >> 6] = v;
+        for (int off = 32; off > 0; off >>= 1) {
+            v += __shfl_xor(v, off, 64);
+            u += __shfl_xor(u, off, 64);
+        }
+        if ((threadIdx.x & 63u) == 0u) {
+            s_sum[threadIdx.x >> 6] = v;
+            s_vis[threadIdx.x >> 6] = u;
+        }
         __syncthreads();
-        if (threadIdx.x == 0) block_sums[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        if (threadIdx.x == 0) // (intersections, visible elements) as ONE 8-byte store: they reach the host together
+            reinterpret_cast<int2 *>(block_sums)[blockIdx.x] = make_int2(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3], s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3]);
     }
     if (hist != nullptr) {
         __syncthreads();
@@ -202,13 +210,16 @@ constexpr uint32_t EMIT_SCAN_SHIFT = 7; // 128 positions per workgroup: two grou
 constexpr uint32_t EMIT_SCAN_TILE = 1u << EMIT_SCAN_SHIFT;
 static_assert(EMIT_SCAN_TILE <= GS_BLOCK && EMIT_SCAN_TILE % EMIT_SPW == 0, "one position per thread");
 
-template <bool COMPACT>
+// MODE 0: 64-bit ids + flatten ids; 1 (compact): 32-bit (camera, tile) key + flatten id; 2 (packed): ONE 32-bit word per pair,
+// key << pos_bits | emission position -- the position is the splat's depth rank, nothing else has to ride through the sort
+template <int MODE>
 __global__ void __launch_bounds__(GS_BLOCK) isect_emit_scan_kernel(
     uint32_t n_elems, uint32_t N, const int32_t *__restrict__ perm, const uint32_t *__restrict__ n_valid,
     const int64_t *__restrict__ camera_ids, const float *__restrict__ means2d, uint32_t s_m2, const int32_t *__restrict__ radii,
     const float *__restrict__ depths, const int32_t *__restrict__ tiles_per_gauss, const uint32_t *__restrict__ group_sums,
     const int64_t *__restrict__ group_prefix, float tile_size, int32_t tw, int32_t th, uint32_t tile_n_bits,
-    int64_t *__restrict__ isect_ids, uint32_t *__restrict__ keys32, int32_t *__restrict__ flatten_ids) {
+    int64_t *__restrict__ isect_ids, uint32_t *__restrict__ keys32, int32_t *__restrict__ flatten_ids, uint32_t pos_bits) {
+    constexpr bool COMPACT = MODE != 0;
     __shared__ int32_t s_cum[EMIT_SCAN_TILE + 1]; // s_cum[j] = tiles of the block's positions [0, j)
     __shared__ int32_t s_elem[EMIT_SCAN_TILE];    // the element at every position (-1: none)
     __shared__ int64_t s_red[GS_BLOCK / GS_WAVE];
@@ -270,7 +281,7 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_scan_kernel(
                 const TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
                 const int64_t cid = camera_ids != nullptr ? camera_ids[i] : (int64_t)((uint32_t)i / N);
                 rec.key_base = COMPACT ? (cid << tile_n_bits) : ((cid << (32 + tile_n_bits)) | (int64_t)__float_as_int(depths[i]));
-                rec.id = i;
+                rec.id = MODE == 2 ? (int32_t)(block_first + j0 + lane) : i; // (packed: the emission position)
                 rec.x0 = b.x0;
                 rec.y0 = b.y0;
                 rec.w = max(b.x1 - b.x0, 1);
@@ -291,9 +302,10 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_scan_kernel(
             const int32_t k = t - wstart[sidx];
             const int32_t dy = k / o.w, dx = k - dy * o.w;
             const int64_t tile_id = (int64_t)(o.y0 + dy) * tw + (o.x0 + dx);
-            if (COMPACT) keys32[out0 + t] = (uint32_t)(o.key_base | tile_id);
+            if (MODE == 2) keys32[out0 + t] = ((uint32_t)(o.key_base | tile_id) << pos_bits) | (uint32_t)o.id;
+            else if (MODE == 1) keys32[out0 + t] = (uint32_t)(o.key_base | tile_id);
             else isect_ids[out0 + t] = o.key_base | (tile_id << 32);
-            flatten_ids[out0 + t] = o.id;
+            if (MODE != 2) flatten_ids[out0 + t] = o.id;
         }
         __builtin_amdgcn_wave_barrier(); // the next group reuses wrec / wstart
     }
@@ -589,29 +601,57 @@ extern "C" uint32_t gs_isect_emit_group_shift(void) { return EMIT_SCAN_SHIFT; }
 // predecessors' sums itself, a number of loads quadratic in the number of groups (fine for a 1 M-element frame: 7.9 K groups).
 extern "C" uint32_t gs_isect_emit_prefix_from_groups(void) { return 8192u; }
 
-extern "C" int32_t gs_isect_emit_presorted(
-    uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids, const float *means2d,
-    uint32_t means2d_stride, const int32_t *radii, const float *depths, const int32_t *tiles_per_gauss, const uint32_t *group_sums,
-    const int64_t *group_prefix, uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits, int32_t compact,
-    int64_t *isect_ids, uint32_t *keys32, int32_t *flatten_ids, gs_stream_t stream) {
+// mode 0 / 1 / 2: see isect_emit_scan_kernel
+static int32_t emit_presorted_launch(
+    int mode, uint32_t pos_bits, uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids,
+    const float *means2d, uint32_t means2d_stride, const int32_t *radii, const float *depths, const int32_t *tiles_per_gauss,
+    const uint32_t *group_sums, const int64_t *group_prefix, uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+    uint32_t tile_n_bits, int64_t *isect_ids, uint32_t *keys32, int32_t *flatten_ids, gs_stream_t stream) {
+    const int32_t compact = mode != 0;
     if (n_elems == 0) return 0;
-    GS_CHECK_ARG(means2d && radii && depths && tiles_per_gauss && (group_sums || group_prefix) && flatten_ids, "null pointer");
+    GS_CHECK_ARG(means2d && radii && depths && tiles_per_gauss && (group_sums || group_prefix) && (flatten_ids || mode == 2), "null pointer");
     GS_CHECK_ARG(compact ? keys32 != nullptr : isect_ids != nullptr, "null output");
     GS_CHECK_ARG(camera_ids != nullptr || N > 0, "N must be > 0 when camera_ids is NULL");
     GS_CHECK_ARG(tile_n_bits < 32, "tile_n_bits must be < 32");
     GS_CHECK_ARG(means2d_stride >= 2 && means2d_stride % 2 == 0, "means2d_stride must be even and >= 2");
     GS_CHECK_ARG(n_elems < (1u << 31), "n_elems must be < 2^31");
     const dim3 grid(gs_div_up(n_elems, EMIT_SCAN_TILE));
-    if (compact)
-        hipLaunchKernelGGL(isect_emit_scan_kernel<true>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids,
+    if (mode == 2)
+        hipLaunchKernelGGL(isect_emit_scan_kernel<2>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids,
                            means2d, means2d_stride, radii, depths, tiles_per_gauss, group_sums, group_prefix, (float)tile_size, (int32_t)tile_width,
-                           (int32_t)tile_height, tile_n_bits, (int64_t *)nullptr, keys32, flatten_ids);
+                           (int32_t)tile_height, tile_n_bits, (int64_t *)nullptr, keys32, (int32_t *)nullptr, pos_bits);
+    else if (compact)
+        hipLaunchKernelGGL(isect_emit_scan_kernel<1>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids,
+                           means2d, means2d_stride, radii, depths, tiles_per_gauss, group_sums, group_prefix, (float)tile_size, (int32_t)tile_width,
+                           (int32_t)tile_height, tile_n_bits, (int64_t *)nullptr, keys32, flatten_ids, 0u);
     else
-        hipLaunchKernelGGL(isect_emit_scan_kernel<false>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids,
+        hipLaunchKernelGGL(isect_emit_scan_kernel<0>, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, n_elems, N, perm, n_valid, camera_ids,
                            means2d, means2d_stride, radii, depths, tiles_per_gauss, group_sums, group_prefix, (float)tile_size, (int32_t)tile_width,
-                           (int32_t)tile_height, tile_n_bits, isect_ids, (uint32_t *)nullptr, flatten_ids);
+                           (int32_t)tile_height, tile_n_bits, isect_ids, (uint32_t *)nullptr, flatten_ids, 0u);
     GS_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int32_t gs_isect_emit_presorted(
+    uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids, const float *means2d,
+    uint32_t means2d_stride, const int32_t *radii, const float *depths, const int32_t *tiles_per_gauss, const uint32_t *group_sums,
+    const int64_t *group_prefix, uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits, int32_t compact,
+    int64_t *isect_ids, uint32_t *keys32, int32_t *flatten_ids, gs_stream_t stream) {
+    return emit_presorted_launch(compact ? 1 : 0, 0u, n_elems, N, perm, n_valid, camera_ids, means2d, means2d_stride, radii, depths,
+                                 tiles_per_gauss, group_sums, group_prefix, tile_size, tile_width, tile_height, tile_n_bits, isect_ids, keys32,
+                                 flatten_ids, stream);
+}
+
+// Packed emission: words[i] = (camera << tile_n_bits | tile) << pos_bits | emission position of the splat (its index in perm:
+// the depth rank).  Needs key bits + pos_bits <= 32; see gs_sort_isect_packed.
+extern "C" int32_t gs_isect_emit_packed(
+    uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids, const float *means2d,
+    uint32_t means2d_stride, const int32_t *radii, const float *depths, const int32_t *tiles_per_gauss, const uint32_t *group_sums,
+    const int64_t *group_prefix, uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits, uint32_t pos_bits,
+    uint32_t *words, gs_stream_t stream) {
+    GS_CHECK_ARG(pos_bits + tile_n_bits <= 32, "tile bits + position bits must fit 32 bits");
+    return emit_presorted_launch(2, pos_bits, n_elems, N, perm, n_valid, camera_ids, means2d, means2d_stride, radii, depths, tiles_per_gauss,
+                                 group_sums, group_prefix, tile_size, tile_width, tile_height, tile_n_bits, nullptr, words, nullptr, stream);
 }
 
 extern "C" int32_t gs_isect_offset_encode(
@@ -647,7 +687,7 @@ extern "C" int32_t gs_isect_finish_presorted(
     const float *means2d, uint32_t means2d_stride, const int32_t *radii, const float *depths, const int32_t *tiles_per_gauss,
     const uint32_t *group_sums, const int64_t *group_prefix, uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
     uint32_t tile_n_bits, uint32_t cam_n_bits, uint32_t C, int64_t *isect_ids, int32_t *flatten_ids, int32_t *offsets, void *work,
-    size_t work_bytes, gs_stream_t stream) {
+    size_t work_bytes, uint32_t n_kept_host, const int64_t *sorted_keys, gs_stream_t stream) {
     GS_CHECK_ARG(offsets != nullptr, "null pointer");
     if (n_isects > 0) {
         GS_CHECK_ARG(work != nullptr && (uintptr_t)work % 16 == 0 && work_bytes >= gs_isect_finish_work_bytes(n_isects),
@@ -656,6 +696,23 @@ extern "C" int32_t gs_isect_finish_presorted(
         uint32_t *keys32 = (uint32_t *)work;
         int32_t *vals = (int32_t *)((char *)work + pb);
         void *temp = (char *)work + 2 * pb;
+        // PACKED route: the caller knows how many splats the pre-sort kept (n_kept_host, e.g. from the projection's block sums)
+        // and (camera, tile) key + emission position fit ONE 32-bit word -- 4 bytes per pair through emission and sort instead
+        // of 8, no value array.  The key bits that can be set: the tile bits + the bits of the largest camera index.
+        uint32_t pos_bits = 0, cam_bits = 0;
+        while (n_kept_host > 0 && ((uint64_t)1 << pos_bits) < (uint64_t)n_kept_host) ++pos_bits;
+        while (((uint32_t)1 << cam_bits) < C) ++cam_bits;
+        const uint32_t key_bits_eff = tile_n_bits + cam_bits;
+        if (n_kept_host > 0 && perm != nullptr && camera_ids == nullptr && key_bits_eff >= 1 && key_bits_eff + pos_bits <= 32 &&
+            key_bits_eff <= 31) {
+            int32_t rc = gs_isect_emit_packed(n_elems, N, perm, n_valid, camera_ids, means2d, means2d_stride, radii, depths, tiles_per_gauss,
+                                              group_sums, group_prefix, tile_size, tile_width, tile_height, tile_n_bits, pos_bits, keys32, stream);
+            if (rc != 0) return rc;
+            rc = gs_sort_isect_packed(n_isects, keys32, perm, sorted_keys, depths, (int32_t)key_bits_eff, pos_bits, isect_ids, flatten_ids,
+                                      temp, work_bytes - 2 * pb, stream);
+            if (rc != 0) return rc;
+            return gs_isect_offset_encode((uint32_t)n_isects, isect_ids, C, tile_width * tile_height, tile_n_bits, offsets, stream);
+        }
         int32_t rc = gs_isect_emit_presorted(n_elems, N, perm, n_valid, camera_ids, means2d, means2d_stride, radii, depths, tiles_per_gauss,
                                              group_sums, group_prefix, tile_size, tile_width, tile_height, tile_n_bits, 1, nullptr,
                                              keys32, vals, stream);

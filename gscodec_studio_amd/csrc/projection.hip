@@ -141,7 +141,7 @@ struct RowExtras {
     // the binning's intersection count in the same pass (what gs_isect_count_keys would compute from the rows afterwards): the
     // host learns n_isects one kernel after the step starts, with the whole depth pre-sort still queued behind it
     int32_t *tiles_per_gauss; // [C,N] or NULL
-    int32_t *block_sums;      // [C * gridDim.x] (pinned host memory) or NULL
+    int32_t *block_sums;      // [C * gridDim.x][2] (pinned host memory) or NULL: (intersections, visible pairs) per workgroup
     float tile_size;
     int32_t tile_width, tile_height;
 };
@@ -178,13 +178,19 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_fwd_kernel(
         }
         if (in) rx.tiles_per_gauss[idx] = cnt;
         if (rx.block_sums != nullptr) {
-            __shared__ int32_t s_cnt[GS_BLOCK / GS_WAVE];
+            __shared__ int32_t s_cnt[GS_BLOCK / GS_WAVE], s_vis[GS_BLOCK / GS_WAVE];
             int32_t v = cnt;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            if ((threadIdx.x & 63u) == 0u) s_cnt[threadIdx.x >> 6] = v;
+            const int32_t nvis = (int32_t)__popcll(__ballot(s.radius > 0));
+            if ((threadIdx.x & 63u) == 0u) {
+                s_cnt[threadIdx.x >> 6] = v;
+                s_vis[threadIdx.x >> 6] = nvis;
+            }
             __syncthreads();
-            if (threadIdx.x == 0) rx.block_sums[blockIdx.y * gridDim.x + blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            if (threadIdx.x == 0) // (intersections, visible pairs) of the block as ONE 8-byte store: they reach the host together
+                reinterpret_cast<int2 *>(rx.block_sums)[blockIdx.y * gridDim.x + blockIdx.x] =
+                    make_int2(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3], s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3]);
         }
         if (!in) return;
     }

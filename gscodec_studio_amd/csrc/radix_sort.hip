@@ -60,6 +60,11 @@ struct IsectEpilogue {
     const float *depths; // indexed by the flatten id
     int64_t *isect_ids;
     int32_t *flatten_ids;
+    // PACKED pairs (KEYS_ONLY kernels): a pair is ONE word  key << pos_bits | emission position; the flatten id is perm[position]
+    const int32_t *perm;
+    uint32_t pos_bits;
+    const uint64_t *sorted_keys; // or NULL: the pre-sort's sorted (depth bits << 32 | element) keys by position -- flatten id AND
+                                 // depth bits in ONE 8-byte gather instead of the dependent pair perm[position] -> depths[id]
 };
 
 // What a scatter launch produces ON THE SIDE while it places its keys:
@@ -161,7 +166,9 @@ GS_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :::
 
 // BUCKET: the one partition pass of the bucketed depth pre-sort -- the digit of a (64-bit) key is its bucket among 255
 // sampled splitters (table in LDS, 8 reads per lookup) instead of 8 key bits; everything else is the same stable scatter.
-template <typename KeyT, int SORT_ROUNDS, bool FINAL_ISECT, bool BUCKET = false>
+// KEYS_ONLY: no value array rides along (the binning's packed pairs: the low bits of the word ARE the value) -- the second
+// LDS trip and half of the global traffic of a pass are gone.
+template <typename KeyT, int SORT_ROUNDS, bool FINAL_ISECT, bool BUCKET = false, bool KEYS_ONLY = false>
 __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
     uint64_t n, const uint32_t *__restrict__ n_dev, const KeyT *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
     KeyT *__restrict__ keys_out, int32_t *__restrict__ vals_out, DigitSpec d,
@@ -300,10 +307,27 @@ __global__ void __launch_bounds__(GS_BLOCK) sort_scatter_kernel(
         if (j < block_count) {
             const KeyT kk = s_keys[j];
             pos[k] = s_gofs[digit(kk)] + j;
-            if (FINAL_ISECT) kept_key[FINAL_ISECT ? k : 0] = kk;
+            if (FINAL_ISECT && KEYS_ONLY) {
+                // the word's low bits are the emission position = the depth rank: flatten id and depth through perm
+                const uint32_t w32 = (uint32_t)kk;
+                const uint32_t at = w32 & ((1u << ep.pos_bits) - 1u);
+                int32_t v;
+                int64_t db;
+                if (ep.sorted_keys != nullptr) { // (uniform) depths of visible splats are positive: their bits ARE the key's high half
+                    const uint64_t sk = ep.sorted_keys[at];
+                    v = (int32_t)(uint32_t)sk;
+                    db = (int64_t)(sk >> 32);
+                } else {
+                    v = ep.perm[at];
+                    db = (int64_t)__float_as_int(ep.depths[v]);
+                }
+                ep.isect_ids[pos[k]] = (int64_t)((uint64_t)(w32 >> ep.pos_bits) << 32) | db;
+                ep.flatten_ids[pos[k]] = v;
+            } else if (FINAL_ISECT) kept_key[FINAL_ISECT ? k : 0] = kk;
             else keys_out[pos[k]] = kk;
         }
     }
+    if (KEYS_ONLY) return; // (block-uniform)
     lds_barrier();
     int32_t *s_vals = reinterpret_cast<int32_t *>(s_keys); // the same LDS, second trip for the values
 #pragma unroll
@@ -541,9 +565,67 @@ void launch_pass32(uint64_t n, const uint32_t *src_k, const int32_t *src_v, uint
                            dst_k, dst_v, d, L.n_blocks, hist, totals, (uint32_t *)nullptr, ep, none);
 }
 
+template <int ROUNDS>
+void launch_pass32_keys(uint64_t n, const uint32_t *src_k, uint32_t *dst_k, DigitSpec d, const Sort32Layout &L, uint32_t *hist,
+                        uint32_t *totals, bool final, const IsectEpilogue &ep, hipStream_t st) {
+    hipLaunchKernelGGL((sort_hist_kernel<uint32_t, ROUNDS>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, (const uint32_t *)nullptr, src_k, d, L.n_blocks, hist);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, hist, totals, (uint32_t *)nullptr, 0u);
+    const ScatterSide none = {nullptr, nullptr, 0u};
+    if (final)
+        hipLaunchKernelGGL((sort_scatter_kernel<uint32_t, ROUNDS, true, false, true>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, (const uint32_t *)nullptr,
+                           src_k, (const int32_t *)nullptr, dst_k, (int32_t *)nullptr, d, L.n_blocks, hist, totals, (uint32_t *)nullptr, ep, none);
+    else
+        hipLaunchKernelGGL((sort_scatter_kernel<uint32_t, ROUNDS, false, false, true>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n, (const uint32_t *)nullptr,
+                           src_k, (const int32_t *)nullptr, dst_k, (int32_t *)nullptr, d, L.n_blocks, hist, totals, (uint32_t *)nullptr, ep, none);
+}
+
 } // namespace
 
 extern "C" size_t gs_sort_isect_temp_bytes(uint64_t n) { return sort32_layout(n).total; }
+
+// Packed pairs: one 32-bit word per pair, key << pos_bits | emission position.  The positions are the depth ranks, so a stable
+// sort on the key bits [pos_bits, pos_bits + key_bits) is all it takes, and nothing but the words moves; the last pass writes
+// the reference's outputs through perm.  temp: gs_sort_isect_temp_bytes(n) (the value half stays unused).
+extern "C" int32_t gs_sort_isect_packed(uint64_t n, uint32_t *words, const int32_t *perm, const int64_t *sorted_keys, const float *depths,
+                                        int32_t key_bits, uint32_t pos_bits, int64_t *isect_ids, int32_t *flatten_ids, void *temp,
+                                        size_t temp_bytes, gs_stream_t stream) {
+    if (n == 0) return 0;
+    GS_CHECK_ARG(words && ((perm && depths) || sorted_keys) && isect_ids && flatten_ids, "null pointer");
+    GS_CHECK_ARG(key_bits >= 1 && key_bits <= 31 && (uint32_t)key_bits + pos_bits <= 32, "key_bits (<= 31) + pos_bits must fit 32 bits");
+    GS_CHECK_ARG(n < (1ull << 32), "n must be < 2^32");
+    const Sort32Layout L = sort32_layout(n);
+    if (temp == nullptr || temp_bytes < L.total) {
+        gs_set_error("gs_sort_isect_packed: temp too small (%zu < %zu)", temp_bytes, L.total);
+        return 1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char *tp = (char *)temp;
+    uint32_t *tkeys = (uint32_t *)(tp + L.off_keys);
+    uint32_t *hist = (uint32_t *)(tp + L.off_hist), *totals = (uint32_t *)(tp + L.off_totals);
+    const int passes = (key_bits + RADIX_BITS - 1) / RADIX_BITS;
+    const int first_bits = key_bits - (passes - 1) * RADIX_BITS;
+    const IsectEpilogue ep = {depths, isect_ids, flatten_ids, perm, pos_bits, (const uint64_t *)sorted_keys};
+    const bool small = sort_rounds_for(n) == SORT_ROUNDS_SMALL;
+    const uint32_t *src_k = words;
+    int shift = (int)pos_bits;
+    for (int p = 0; p < passes; ++p) {
+        DigitSpec d;
+        const bool final = p == passes - 1;
+        const int bits = (p == 0) ? first_bits : RADIX_BITS;
+        d.shift = (uint32_t)shift;
+        shift += bits;
+        d.mask = (1u << bits) - 1u;
+        d.drop = d.drop_hi = 0u;
+        d.split = nullptr;
+        d.flip = 0u; // (key_bits < 32 here: the id's sign bit is never set)
+        uint32_t *dst_k = (p % 2 == 0) ? tkeys : words;
+        if (small) launch_pass32_keys<SORT_ROUNDS_SMALL>(n, src_k, dst_k, d, L, hist, totals, final, ep, st);
+        else launch_pass32_keys<SORT_ROUNDS_BIG>(n, src_k, dst_k, d, L, hist, totals, final, ep, st);
+        src_k = dst_k;
+    }
+    GS_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int32_t gs_sort_isect_pairs(uint64_t n, uint32_t *keys32, int32_t *vals, const float *depths, int32_t key_bits,
                                        int64_t *isect_ids, int32_t *flatten_ids, void *temp, size_t temp_bytes, gs_stream_t stream) {
@@ -565,7 +647,7 @@ extern "C" int32_t gs_sort_isect_pairs(uint64_t n, uint32_t *keys32, int32_t *va
     // the first pass takes the remainder (14 bits -> 6 + 8).  (Remainder LAST, for longer store runs in the pass that
     // writes 12 bytes per pair, measured 34.6 + 28.8 us against 36.0 + 25.0 us: no.)
     const int first_bits = key_bits - (passes - 1) * RADIX_BITS;
-    const IsectEpilogue ep = {depths, isect_ids, flatten_ids};
+    const IsectEpilogue ep = {depths, isect_ids, flatten_ids, nullptr, 0u, nullptr};
     const bool small = sort_rounds_for(n) == SORT_ROUNDS_SMALL;
     const uint32_t *src_k = keys32;
     const int32_t *src_v = vals;
@@ -958,7 +1040,8 @@ GS_DEV void ps_side_add(uint32_t *side_sums, bool on, uint32_t grp, uint32_t inc
 // for a range that does not fit LDS.  perm [*n_kept] out; side_sums[p >> side_shift] += side_vals[perm[p]].
 __global__ void __launch_bounds__(PS_THREADS) presort_local_kernel(const uint32_t *__restrict__ n_kept_p, const uint32_t *__restrict__ totals,
                                                                    uint64_t *__restrict__ keys, uint64_t *__restrict__ alt,
-                                                                   int32_t *__restrict__ perm, const int32_t *__restrict__ side_vals,
+                                                                   int32_t *__restrict__ perm, uint64_t *__restrict__ sorted_out,
+                                                                   const int32_t *__restrict__ side_vals,
                                                                    uint32_t *__restrict__ side_sums, uint32_t side_shift, uint32_t cap) {
     extern __shared__ __align__(16) unsigned char ps_lds[];
     const LdsSort L = lds_sort_carve(ps_lds, PS_CAP);
@@ -993,6 +1076,7 @@ __global__ void __launch_bounds__(PS_THREADS) presort_local_kernel(const uint32_
             const bool on = j < m;
             const uint32_t e = on ? sorted[j].y : 0u;
             if (on) perm[lo + j] = (int32_t)e;
+            if (on && sorted_out != nullptr) sorted_out[lo + j] = ((uint64_t)sorted[j].x << 32) | (uint64_t)e;
             if (side_sums != nullptr) ps_side_add(side_sums, on, (lo + j) >> side_shift, on ? (uint32_t)side_vals[e] : 0u);
         }
         PS_STAMP(12);
@@ -1088,8 +1172,10 @@ __global__ void __launch_bounds__(PS_THREADS) presort_local_kernel(const uint32_
     for (uint32_t j0 = 0; j0 < m; j0 += PS_THREADS) {
         const uint32_t j = j0 + tid;
         const bool on = j < m;
-        const uint32_t e = on ? (uint32_t)src[lo + j] : 0u;
+        const uint64_t sk = on ? src[lo + j] : 0ull;
+        const uint32_t e = (uint32_t)sk;
         if (on) perm[lo + j] = (int32_t)e;
+        if (on && sorted_out != nullptr) sorted_out[lo + j] = sk;
         if (side_sums != nullptr) ps_side_add(side_sums, on, (lo + j) >> side_shift, on ? (uint32_t)side_vals[e] : 0u);
     }
 }
@@ -1116,7 +1202,7 @@ extern "C" int32_t gs_presort_split(uint32_t n_elems, const int32_t *radii, cons
     return 0;
 }
 
-extern "C" int32_t gs_presort_buckets(uint64_t n, const int64_t *keys_in, const int32_t *vals_in, const int64_t *splitters,
+extern "C" int32_t gs_presort_buckets(uint64_t n, int64_t *keys_in, const int32_t *vals_in, const int64_t *splitters,
                                       int32_t *perm, uint32_t *n_kept, void *temp, size_t temp_bytes, const int32_t *side_vals,
                                       uint32_t *side_sums, uint32_t side_shift, uint32_t lds_capacity, gs_stream_t stream) {
     if (n == 0) return 0;
@@ -1146,7 +1232,7 @@ extern "C" int32_t gs_presort_buckets(uint64_t n, const int64_t *keys_in, const 
                                        (int)PS_LOCAL_LDS);
     GS_CHECK_ARG(e == hipSuccess, "cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL(presort_local_kernel, dim3(GS_PRESORT_BUCKETS), dim3(PS_THREADS), PS_LOCAL_LDS, st, n_kept, totals, tkeys, alt, perm,
-                       side_vals, side_sums, side_shift, lds_capacity ? lds_capacity : PS_CAP);
+                       (uint64_t *)keys_in /* dead after the partition pass: receives the sorted keys */, side_vals, side_sums, side_shift, lds_capacity ? lds_capacity : PS_CAP);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -36,7 +36,7 @@ extern "C" uint32_t gs_step_layout(uint64_t *out, uint32_t n) {
     const uint64_t v[] = {sizeof(gs_step), offsetof(gs_step, C), offsetof(gs_step, sh_K), offsetof(gs_step, eps2d), offsetof(gs_step, tile_size),
                           offsetof(gs_step, sh_mask_logits), offsetof(gs_step, rows_ready), offsetof(gs_step, backgrounds),
                           offsetof(gs_step, radii), offsetof(gs_step, sort_temp_bytes), offsetof(gs_step, block_sums),
-                          offsetof(gs_step, n_isects), offsetof(gs_step, work_bytes), offsetof(gs_step, plan), offsetof(gs_step, scratch),
+                          offsetof(gs_step, n_isects), offsetof(gs_step, n_kept_host), offsetof(gs_step, work_bytes), offsetof(gs_step, plan), offsetof(gs_step, scratch),
                           offsetof(gs_step, zero_fill_bytes), offsetof(gs_step, v_render_colors), offsetof(gs_step, vrc_pixel_stride),
                           offsetof(gs_step, grad_rows), offsetof(gs_step, v_sh_rest), offsetof(gs_step, absgrad),
                           offsetof(gs_step, finish_phase)};
@@ -106,7 +106,8 @@ extern "C" int32_t gs_step_fwd_finish(gs_step *s, gs_stream_t stream) {
     GS_STEP_TRY(gs_isect_finish_presorted(n_elems, s->N, s->n_isects, s->perm, s->n_kept, nullptr, s->rows, GS_ROW_FLOATS, s->radii, s->depths,
                                           s->tiles_per_gauss, s->group_sums, s->group_prefix, s->tile_size, s->tile_width, s->tile_height,
                                           floor_log2_plus1(n_tiles), floor_log2_plus1(s->C), s->C, s->isect_ids, s->flatten_ids, s->offsets,
-                                          s->work, (size_t)s->work_bytes, stream));
+                                          s->work, (size_t)s->work_bytes, s->n_kept_host,
+                                          (s->bucketed && gs_presort_applicable(n_elems)) ? s->depth_keys : s->sorted_keys, stream));
     if (s->finish_phase == 1) return 0;
     const uint32_t strides[4] = {GS_ROW_FLOATS, GS_ROW_FLOATS, GS_ROW_FLOATS, GS_ROW_FLOATS};
     GS_STEP_TRY(gs_rasterize_fwd(s->C, n_elems, (uint32_t)s->n_isects, 3, s->rows + GS_ROW_MEAN2D, s->rows + GS_ROW_CONIC, s->rows + GS_ROW_COLOR,

@@ -165,10 +165,11 @@ int32_t gs_projection_rows_fwd(
     float sh_mask_temperature, int32_t sh_mask_binary,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
     int32_t *tiles_per_gauss /* NULL, or [C,N]: the binning's tile count of every pair (gs_isect_count), in the same pass */,
-    int32_t *block_sums /* NULL, or [C * gs_projection_rows_blocks(N)] (may be pinned host memory): the counts' sums per
-                           workgroup -- their total is n_isects, known to the host one kernel into the step (the read-back of
-                           isect_tiles.cu:200) while the whole depth pre-sort is still queued; gs_isect_count_keys then takes
-                           means2d = NULL, block_sums = NULL (tiles_per_gauss is an input there) */,
+    int32_t *block_sums /* NULL, or [C * gs_projection_rows_blocks(N)][2] (8-byte aligned; may be pinned host memory): per
+                           workgroup (sum of the counts, number of visible pairs), written as ONE 8-byte store -- the totals
+                           are n_isects and the number of elements the depth pre-sort keeps, known to the host one kernel into
+                           the step (the read-back of isect_tiles.cu:200) while the whole depth pre-sort is still queued;
+                           gs_isect_count_keys then takes means2d = NULL, block_sums = NULL (tiles_per_gauss is an input there) */,
     int32_t *radii, /* [C,N] */
     float *depths,  /* [C,N] */
     float *rows,    /* [C,N,16] */
@@ -357,9 +358,10 @@ int32_t gs_isect_count_keys(
     uint32_t n_elems, const float *means2d /* NULL: tiles_per_gauss is an INPUT (gs_projection_rows_fwd counted) */, uint32_t means2d_stride, const int32_t *radii, const float *depths,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
     int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals,
-    int32_t *block_sums /* [gs_isect_count_blocks(n_elems)] or NULL: intersections per block; their sum is n_isects,
-                           known here -- before the depth pre-sort and the prefix sum -- so the host read-back of
-                           isect_tiles.cu:200 can overlap them */,
+    int32_t *block_sums /* [gs_isect_count_blocks(n_elems)][2] (8-byte aligned) or NULL: per block (intersections, visible
+                           elements), ONE 8-byte store; the totals are n_isects -- known here, before the depth pre-sort and the
+                           prefix sum, so the host read-back of isect_tiles.cu:200 can overlap them -- and the number of
+                           elements the pre-sort keeps (gs_isect_finish_presorted's n_kept_host) */,
     void *sort_temp, size_t sort_temp_bytes /* NULL, 0 -- or the temp buffer the keys will be sorted with
                            (gs_sort_pairs_u64_i32_drop over bits [32, 64)), when gs_sort_first_hist_applicable(n_elems): this
                            kernel then also counts the digits of that sort's first pass (pass first_hist_ready = 1 there) */,
@@ -422,7 +424,31 @@ int32_t gs_isect_finish_presorted(
     const int32_t *tiles_per_gauss, const uint32_t *group_sums, const int64_t *group_prefix,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits, uint32_t cam_n_bits, uint32_t C,
     int64_t *isect_ids /* [n_isects] */, int32_t *flatten_ids /* [n_isects] */, int32_t *offsets /* [C, tile_height, tile_width] */,
-    void *work, size_t work_bytes, gs_stream_t stream);
+    void *work, size_t work_bytes,
+    uint32_t n_kept_host /* 0, or the number of elements in perm (*n_valid) when the host knows it (the block sums of
+                            gs_projection_rows_fwd / gs_isect_count_keys): when (camera, tile) key and emission position fit 32
+                            bits together the pairs then travel PACKED -- gs_isect_emit_packed + gs_sort_isect_packed, 4 bytes
+                            per pair instead of 8 through emission and sort; same outputs */,
+    const int64_t *sorted_keys /* NULL, or the pre-sort's sorted keys (depth bits << 32 | element, in perm's order: keys_out of
+                            gs_sort_pairs_u64_i32_drop, keys_in of gs_presort_buckets after the call): the packed route's last pass
+                            then fetches flatten id and depth bits with one gather */,
+    gs_stream_t stream);
+/* Packed pairs.  A pair is ONE 32-bit word  (camera << tile_n_bits | tile) << pos_bits | emission position, the position being
+ * the splat's index in perm = its depth rank: the words of one tile are in depth order when the array is sorted stably on the
+ * key bits, so no value array rides along, and the last pass writes the reference's outputs through perm:
+ * flatten_ids = perm[position], isect_ids = key << 32 | float_bits(depths[flatten id]).  Needs key_bits (the bits a key can
+ * have set, <= 31) + pos_bits (2^pos_bits >= number of elements in perm) <= 32.  words: scratch, destroyed.
+ * temp: gs_sort_isect_temp_bytes(n). */
+int32_t gs_isect_emit_packed(
+    uint32_t n_elems, uint32_t N, const int32_t *perm, const uint32_t *n_valid, const int64_t *camera_ids,
+    const float *means2d, uint32_t means2d_stride, const int32_t *radii, const float *depths,
+    const int32_t *tiles_per_gauss, const uint32_t *group_sums, const int64_t *group_prefix,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, uint32_t tile_n_bits, uint32_t pos_bits,
+    uint32_t *words /* [n_isects] */, gs_stream_t stream);
+int32_t gs_sort_isect_packed(
+    uint64_t n, uint32_t *words, const int32_t *perm, const int64_t *sorted_keys /* NULL, or (depth bits << 32 | element) by
+    position: replaces perm + depths */, const float *depths /* indexed by the flatten id */, int32_t key_bits,
+    uint32_t pos_bits, int64_t *isect_ids, int32_t *flatten_ids, void *temp, size_t temp_bytes, gs_stream_t stream);
 size_t gs_sort_isect_temp_bytes(uint64_t n);
 int32_t gs_sort_isect_pairs(
     uint64_t n, uint32_t *keys32, int32_t *vals, const float *depths /* indexed by the flatten id */, int32_t key_bits,
@@ -473,7 +499,8 @@ size_t gs_presort_temp_bytes(uint64_t n);
 int32_t gs_presort_split(
     uint32_t n_elems, const int32_t *radii, const float *depths, int64_t *splitters /* [256] */, gs_stream_t stream);
 int32_t gs_presort_buckets(
-    uint64_t n, const int64_t *keys_in, const int32_t *vals_in, const int64_t *splitters,
+    uint64_t n, int64_t *keys_in /* DESTROYED: on return [0, *n_kept) holds the sorted keys (depth bits << 32 | element), what
+    gs_isect_finish_presorted takes as sorted_keys */, const int32_t *vals_in, const int64_t *splitters,
     int32_t *perm /* [n]; [0, *n_kept) written */, uint32_t *n_kept /* device scalar, written */,
     void *temp, size_t temp_bytes, const int32_t *side_vals, uint32_t *side_sums, uint32_t side_shift,
     uint32_t lds_capacity, gs_stream_t stream);
@@ -918,8 +945,9 @@ int32_t gs_dp_reduce_rows(uint64_t n_recv, uint32_t width, uint32_t world, const
  * boundary, this is the executor around them (the counterpart of gsplat/rendering.py:28-582's orchestration).
  *   gs_step_fwd_begin   gs_projection_rows_fwd -> [gs_presort_split] -> gs_isect_count_keys -> gs_presort_buckets |
  *                       gs_sort_pairs_u64_i32_drop [-> gs_cumsum_i32 when group_prefix is given]
- *   (the caller waits until every entry of block_sums -- pinned host memory it pre-set to -1 -- is >= 0, sets n_isects to
- *    their sum, sizes the phase-2 buffers with gs_isect_finish_work_bytes / gs_rasterize_plan and allocates them)
+ *   (the caller waits until every entry of block_sums -- pinned host memory it pre-set to -1 -- is >= 0, sets n_isects /
+ *    n_kept_host to the sums of its even / odd entries, sizes the phase-2 buffers with gs_isect_finish_work_bytes /
+ *    gs_rasterize_plan and allocates them)
  *   gs_step_fwd_finish  gs_isect_finish_presorted -> gs_rasterize_fwd (zero-filling zero_fill as its side job)
  *   gs_step_bwd         gs_rasterize_bwd (packed gradient rows) -> gs_projection_rows_bwd
  * With rows_ready the first call starts at gs_isect_count_keys (binning + compositing of rows some other producer wrote).
@@ -927,7 +955,7 @@ int32_t gs_dp_reduce_rows(uint64_t n_recv, uint32_t width, uint32_t world, const
  * (64-byte aligned), tiles_per_gauss i32 [C,N], depth_keys i64 [C N], depth_vals i32 [C N], sort_temp
  * (gs_presort_temp_bytes / gs_sort_temp_bytes of C N), splitters i64 [256] (bucketed), sorted_keys i64 [C N] (radix), perm
  * i32 [C N], n_kept u32 [1], group_sums u32 [ceil(C N / 2^gs_isect_emit_group_shift())], group_prefix i64 of the same length
- * + cumsum_scratch (both or neither), block_sums i32 [C * gs_projection_rows_blocks(N)] ([gs_isect_count_blocks(C N)] with rows_ready); isect_ids i64 / flatten_ids i32
+ * + cumsum_scratch (both or neither), block_sums i32 [C * gs_projection_rows_blocks(N)][2] ([gs_isect_count_blocks(C N)][2] with rows_ready); isect_ids i64 / flatten_ids i32
  * [n_isects], offsets i32 [C, tile_height, tile_width], work (gs_isect_finish_work_bytes), render_colors [C,H,W,3],
  * render_alphas [C,H,W,1], last_ids i32 [C,H,W], scratch (plan.scratch_bytes; NULL: no checkpoints), zero_fill: the gradient rows
  * [C N,16] (+ whatever else the caller wants zeroed behind them); backward: grad_rows = that zero-filled buffer, v_* outputs as
@@ -966,6 +994,8 @@ typedef struct gs_step {
     int32_t *block_sums;
     /* phase 2 */
     uint64_t n_isects;
+    uint32_t n_kept_host; /* elements the pre-sort kept (sum of the odd entries of block_sums); 0: unknown (no packed pairs) */
+    uint32_t reserved1;
     int64_t *isect_ids;
     int32_t *flatten_ids, *offsets;
     void *work;
@@ -987,7 +1017,7 @@ typedef struct gs_step {
 /* Layout guard for bindings that mirror the host structs by hand (ctypes, cgo, JNA ...): writes up to n entries --
  * sizeof(struct), then offsetof of the listed fields in this order -- and returns how many the list has.
  *   gs_step:       C, sh_K, eps2d, tile_size, sh_mask_logits, rows_ready, backgrounds, radii, sort_temp_bytes, block_sums, n_isects,
- *                  work_bytes, plan, scratch, zero_fill_bytes, v_render_colors, vrc_pixel_stride, grad_rows, v_sh_rest, absgrad,
+ *                  n_kept_host, work_bytes, plan, scratch, zero_fill_bytes, v_render_colors, vrc_pixel_stride, grad_rows, v_sh_rest, absgrad,
  *                  finish_phase
  *   gs_quant_desc: n, x, out, v_out, v_x, lo, q_step, activation, philox_offset */
 uint32_t gs_step_layout(uint64_t *out, uint32_t n);

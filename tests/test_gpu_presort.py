@@ -89,3 +89,74 @@ def test_bucketed_presort_multi_camera_and_full_pipeline():
             W._PRESORT.update(prev)
     for x, y in zip(outs[True], outs[False]):
         assert torch.equal(x, y)
+
+
+def _finish(means2d, radii, depths, tw, th, packed_pairs):
+    from gscodec_studio_amd import _wrapper as W
+
+    prev = W._PACKED_PAIRS
+    W._PACKED_PAIRS = packed_pairs
+    try:
+        C, n = radii.shape
+        st = W.isect_tiles_begin(means2d, radii, depths, 16, tw, th, True, C, n, C * n, None)
+        return W.isect_tiles_finish(st, offsets_for=C)
+    finally:
+        W._PACKED_PAIRS = prev
+
+
+@pytest.mark.parametrize("n,C,vis,tw,th,kind", [
+    (200_000, 1, 0.4, 120, 68, "clustered"),   # 17 position bits + 13 key bits: packed
+    (1_006_065, 1, 0.29, 120, 68, "uniform"),  # BASELINE config 2's shape: 19 + 13 = 32 bits exactly
+    (50_000, 2, 0.9, 40, 30, "equal"),         # two cameras (1 camera bit), every depth equal: ties resolved by position
+    (3000, 3, 1.0, 8, 8, "uniform"),
+    (1, 1, 1.0, 120, 68, "uniform"),           # one visible element: 0 position bits
+    (700_000, 1, 1.0, 120, 68, "uniform"),     # 20 position bits + 13: does not fit, the call falls back to (key, id) pairs
+])
+def test_packed_pairs_equal_key_value_pairs(n, C, vis, tw, th, kind):
+    """gs_isect_finish_presorted with n_kept_host (pairs as ONE 32-bit word, key << pos_bits | depth rank) against the same call
+    without it ((key, flatten id) pairs): identical tiles_per_gauss, isect_ids, flatten_ids and offsets."""
+    m2, radii, d = _case(n, kind, seed=n % 97, vis=vis, C=C)
+    m2[..., 0] *= tw * 16 / 1920.0
+    m2[..., 1] *= th * 16 / 1080.0
+    args = (T(m2), T(radii), T(d))
+    a = _finish(*args, tw, th, True)
+    b = _finish(*args, tw, th, False)
+    assert a[1].numel() > 0
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    ids = N(a[1])
+    assert np.all(ids[1:] >= ids[:-1])
+
+
+def test_packed_kernels_directly_with_spare_position_bits():
+    """gs_isect_emit_packed + gs_sort_isect_packed with MORE position bits than needed (and the minimum): same outputs as the
+    (key, id) route of gs_isect_emit_presorted + gs_sort_isect_pairs."""
+    from gscodec_studio_amd import _backend as B
+    from gscodec_studio_amd import _wrapper as W
+
+    m2, radii, d = _case(60_000, "clustered", seed=3, vis=0.5, C=2)
+    tw, th = 30, 20
+    m2[..., 0] *= tw * 16 / 1920.0
+    m2[..., 1] *= th * 16 / 1080.0
+    m2t, rt, dt = T(m2), T(radii), T(d)
+    C, n = radii.shape
+    st = W.isect_tiles_begin(m2t, rt, dt, 16, tw, th, True, C, n, C * n, None)
+    want = W.isect_tiles_finish(dict(st), offsets_for=None)  # (key, id) pairs through the separate entry points
+    n_isects, n_kept = want[1].numel(), int(st["n_kept"])
+    stream = torch.cuda.current_stream().cuda_stream
+    key_bits = st["tile_n_bits"] + 1  # 10 tile bits + 1 bit for camera index 1
+    need = max(n_kept - 1, 1).bit_length()
+    for pos_bits, sk in ((need, None), (need + 3, B.ptr(st["sorted_keys"])), (32 - key_bits, None), (need, B.ptr(st["sorted_keys"]))):
+        words = torch.empty(n_isects, dtype=torch.int32, device=dev())
+        ids = torch.empty(n_isects, dtype=torch.int64, device=dev())
+        flat = torch.empty(n_isects, dtype=torch.int32, device=dev())
+        tb = B.query("gs_sort_isect_temp_bytes", n_isects)
+        temp = torch.empty(tb, dtype=torch.uint8, device=dev())
+        B.call("gs_isect_emit_packed", C * n, n, B.ptr(st["perm"]), B.ptr(st["n_kept"]), None, B.ptr(m2t), 2, B.ptr(rt), B.ptr(dt),
+               B.ptr(st["tiles_per_gauss"]), B.ptr(st["gsums"]), B.ptr(st["gpre"]), 16, tw, th, st["tile_n_bits"], pos_bits, B.ptr(words), stream)
+        B.call("gs_sort_isect_packed", n_isects, B.ptr(words), B.ptr(st["perm"]), sk, B.ptr(dt), key_bits, pos_bits, B.ptr(ids), B.ptr(flat),
+               B.ptr(temp), tb, stream)
+        assert torch.equal(ids, want[1]) and torch.equal(flat, want[2]), pos_bits
+    with pytest.raises(RuntimeError, match="32 bits"):
+        B.call("gs_sort_isect_packed", n_isects, B.ptr(words), B.ptr(st["perm"]), None, B.ptr(dt), key_bits, 33 - key_bits, B.ptr(ids), B.ptr(flat),
+               B.ptr(temp), tb, stream)
