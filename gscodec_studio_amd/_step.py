@@ -117,13 +117,13 @@ def _phase1(s: "_Step", C: int, N: int, dev, n_sums: int, given=None) -> dict:
         radii, depths, rows = given
     tiles_per_gauss = empty((C, N), dtype=i32, device=dev)
     dkeys = empty(n_elems, dtype=i64, device=dev)
-    dvals = empty(n_elems, dtype=i32, device=dev)
     perm = empty(n_elems, dtype=i32, device=dev)
     n_kept = empty(1, dtype=i32, device=dev)
     gshift = _GSHIFT[0] or _init_consts()
     n_groups = (n_elems + (1 << gshift) - 1) >> gshift
     gsums = empty(n_groups, dtype=i32, device=dev)
     bucketed = W._PRESORT["on"] and bool(B.query("gs_presort_applicable", n_elems))
+    dvals = None if bucketed else empty(n_elems, dtype=i32, device=dev)  # (bucketed: the element rides in the key's low half)
     tb = B.query("gs_presort_temp_bytes" if bucketed else "gs_sort_temp_bytes", n_elems)
     temp = empty(tb, dtype=u8, device=dev)
     split = empty(256, dtype=i64, device=dev) if bucketed else None

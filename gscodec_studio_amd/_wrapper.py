@@ -1296,7 +1296,6 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
             if sort:
                 # splat-level depth pre-sort: afterwards only the (camera, tile) bits need sorting
                 dkeys = torch.empty(n_elems, dtype=torch.int64, device=dev)
-                dvals = torch.empty(n_elems, dtype=torch.int32, device=dev)
                 # n_isects = the sum of the per-block counts, known to the host ~100 us of GPU work (pre-sort, prefix sum,
                 # SH colours) before the pipeline needs it
                 # sum there.  The kernel stores them STRAIGHT into pinned host memory (device-visible under HIP's unified
@@ -1316,6 +1315,7 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                 tb = B.query("gs_presort_temp_bytes" if bucketed else "gs_sort_temp_bytes", n_elems)
                 temp = torch.empty(tb, dtype=torch.uint8, device=dev)
                 hist_ready = int(B.query("gs_sort_first_hist_applicable", n_elems))
+                dvals = None if bucketed else torch.empty(n_elems, dtype=torch.int32, device=dev)  # (bucketed: keys only)
                 split = None
                 if bucketed:
                     split = torch.empty(256, dtype=torch.int64, device=dev)
@@ -1330,7 +1330,7 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream(dev))
                 # culled elements carry the maximal key: the sort drops them in its first pass
-                perm = torch.empty_like(dvals)
+                perm = torch.empty(n_elems, dtype=torch.int32, device=dev)
                 n_kept = torch.empty(1, dtype=torch.int32, device=dev)
                 # the sort's last launch also leaves the tile counts per group of 2^gshift emission positions behind (the block
                 # sums of the emission's prefix scan, which gs_isect_emit_presorted then finishes itself: no cumsum launches)

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_count_keys_kernel(
         if (means2d != nullptr) tiles_per_gauss[i] = cnt;
         const uint64_t key = ((uint64_t)d << 32) | (uint64_t)i;
         keys[i] = (int64_t)key;
-        vals[i] = (int32_t)i;
+        if (vals != nullptr) vals[i] = (int32_t)i; // (NULL: the bucketed pre-sort reads the element off the key's low half)
         cnt_sum += cnt;
         vis_sum += r > 0 ? 1 : 0;
         if (hist != nullptr && d != 0x7fffffffu) atomicAdd(&s_hist[split != nullptr ? gs_bucket_of(s_split, key) : (d & 0xffu)], 1u);
@@ -221,10 +221,9 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_scan_kernel(
     int64_t *__restrict__ isect_ids, uint32_t *__restrict__ keys32, int32_t *__restrict__ flatten_ids, uint32_t pos_bits) {
     constexpr bool COMPACT = MODE != 0;
     __shared__ int32_t s_cum[EMIT_SCAN_TILE + 1]; // s_cum[j] = tiles of the block's positions [0, j)
-    __shared__ int32_t s_elem[EMIT_SCAN_TILE];    // the element at every position (-1: none)
     __shared__ int64_t s_red[GS_BLOCK / GS_WAVE];
     __shared__ int32_t s_wsum[GS_BLOCK / GS_WAVE];
-    __shared__ EmitRec s_rec[EMIT_WAVES * EMIT_SPW];
+    __shared__ EmitRec s_rec[EMIT_SCAN_TILE]; // the record of EVERY position of the block, gathered in one phase
     __shared__ int32_t s_start[EMIT_WAVES * (EMIT_SPW + 1)];
     const uint32_t tid = threadIdx.x, lane = tid % GS_WAVE, wave = tid / GS_WAVE;
     const uint32_t nv = n_valid != nullptr ? min(n_elems, *n_valid) : n_elems;
@@ -245,8 +244,26 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_scan_kernel(
     if (tid < EMIT_SCAN_TILE) {
         const uint32_t pos = block_first + tid;
         e = pos < nv ? (perm != nullptr ? perm[pos] : (int32_t)pos) : -1;
-        c = e >= 0 ? tiles_per_gauss[e] : 0;
-        s_elem[tid] = e;
+        // the three gathers that hang off the element index go out together (they used to be two dependent phases: the tile
+        // count here, radius and mean inside the per-group loop below -- once per group and wave)
+        int32_t r = 0;
+        float2 m = make_float2(0.f, 0.f);
+        if (e >= 0) {
+            c = tiles_per_gauss[e];
+            r = radii[e];
+            m = *reinterpret_cast<const float2 *>(means2d + (size_t)e * s_m2);
+        }
+        EmitRec rec = {0, 0, 0, 0, 1};
+        if (r > 0) {
+            const TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
+            const int64_t cid = camera_ids != nullptr ? camera_ids[e] : (int64_t)((uint32_t)e / N);
+            rec.key_base = COMPACT ? (cid << tile_n_bits) : ((cid << (32 + tile_n_bits)) | (int64_t)__float_as_int(depths[e]));
+            rec.id = MODE == 2 ? (int32_t)pos : e; // (packed: the emission position)
+            rec.x0 = b.x0;
+            rec.y0 = b.y0;
+            rec.w = max(b.x1 - b.x0, 1);
+        }
+        s_rec[tid] = rec;
     }
     int32_t inc = c;
 #pragma unroll
@@ -265,30 +282,14 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_scan_kernel(
     const int64_t block_out0 = s_red[0] + s_red[1] + s_red[2] + s_red[3];
     __syncthreads();
 
-    EmitRec *wrec = s_rec + wave * EMIT_SPW;
     int32_t *wstart = s_start + wave * (EMIT_SPW + 1);
     for (uint32_t grp = wave; grp < EMIT_SCAN_TILE / EMIT_SPW; grp += EMIT_WAVES) { // groups of EMIT_SPW positions, one wave each
         const uint32_t j0 = grp * EMIT_SPW;
         if (block_first + j0 >= nv) break; // (wave-uniform)
         const int32_t g0 = s_cum[j0], g1 = s_cum[j0 + EMIT_SPW];
         if (g1 == g0) continue;
-        if (lane < EMIT_SPW) {
-            EmitRec rec = {0, 0, 0, 0, 1};
-            const int32_t i = s_elem[j0 + lane];
-            const int32_t r = i >= 0 ? radii[i] : 0;
-            if (r > 0) {
-                const float2 m = *reinterpret_cast<const float2 *>(means2d + (size_t)i * s_m2);
-                const TileBox b = tile_box(m.x, m.y, r, tile_size, tw, th);
-                const int64_t cid = camera_ids != nullptr ? camera_ids[i] : (int64_t)((uint32_t)i / N);
-                rec.key_base = COMPACT ? (cid << tile_n_bits) : ((cid << (32 + tile_n_bits)) | (int64_t)__float_as_int(depths[i]));
-                rec.id = MODE == 2 ? (int32_t)(block_first + j0 + lane) : i; // (packed: the emission position)
-                rec.x0 = b.x0;
-                rec.y0 = b.y0;
-                rec.w = max(b.x1 - b.x0, 1);
-            }
-            wrec[lane] = rec;
-            wstart[lane] = s_cum[j0 + lane] - g0;
-        }
+        const EmitRec *wrec = s_rec + j0;
+        if (lane < EMIT_SPW) wstart[lane] = s_cum[j0 + lane] - g0;
         if (lane == 0) wstart[EMIT_SPW] = g1 - g0;
         __builtin_amdgcn_wave_barrier();
         const int32_t total = g1 - g0;
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_scan_kernel(
             else isect_ids[out0 + t] = o.key_base | (tile_id << 32);
             if (MODE != 2) flatten_ids[out0 + t] = o.id;
         }
-        __builtin_amdgcn_wave_barrier(); // the next group reuses wrec / wstart
+        __builtin_amdgcn_wave_barrier(); // the next group reuses wstart
     }
 }
 
@@ -523,7 +524,7 @@ extern "C" int32_t gs_isect_count_keys(
     uint32_t tile_width, uint32_t tile_height, int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals, int32_t *block_sums,
     void *sort_temp, size_t sort_temp_bytes, const int64_t *bucket_splitters, gs_stream_t stream) {
     if (n_elems == 0) return 0;
-    GS_CHECK_ARG(radii && depths && tiles_per_gauss && keys && vals, "null pointer");
+    GS_CHECK_ARG(radii && depths && tiles_per_gauss && keys && (vals || bucket_splitters), "null pointer (vals may be NULL with bucket_splitters only)");
     GS_CHECK_ARG(means2d != nullptr || block_sums == nullptr, "means2d NULL (tiles_per_gauss given): the block sums were made with the counts");
     GS_CHECK_ARG(bucket_splitters == nullptr || sort_temp != nullptr, "bucket_splitters come with sort_temp (the histogram's place)");
     GS_CHECK_ARG(tile_size > 0, "tile_size must be > 0");

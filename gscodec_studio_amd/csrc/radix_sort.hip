@@ -1206,7 +1206,8 @@ extern "C" int32_t gs_presort_buckets(uint64_t n, int64_t *keys_in, const int32_
                                       int32_t *perm, uint32_t *n_kept, void *temp, size_t temp_bytes, const int32_t *side_vals,
                                       uint32_t *side_sums, uint32_t side_shift, uint32_t lds_capacity, gs_stream_t stream) {
     if (n == 0) return 0;
-    GS_CHECK_ARG(keys_in && vals_in && splitters && perm && n_kept, "null pointer");
+    (void)vals_in; // (the element index is the low half of the key: nothing rides along with the keys)
+    GS_CHECK_ARG(keys_in && splitters && perm && n_kept, "null pointer");
     GS_CHECK_ARG(gs_presort_applicable(n), "gs_presort_applicable(n) is 0: use gs_sort_pairs_u64_i32_drop");
     GS_CHECK_ARG((side_vals == nullptr) == (side_sums == nullptr) && side_shift < 32, "side_vals and side_sums go together");
     GS_CHECK_ARG(lds_capacity <= PS_CAP, "lds_capacity exceeds gs_presort_capacity()");
@@ -1217,7 +1218,6 @@ extern "C" int32_t gs_presort_buckets(uint64_t n, int64_t *keys_in, const int32_
     hipStream_t st = (hipStream_t)stream;
     char *tp = (char *)temp;
     uint64_t *tkeys = (uint64_t *)(tp + L.off_keys);
-    int32_t *tvals = (int32_t *)(tp + L.off_vals);
     uint32_t *hist = (uint32_t *)(tp + L.off_hist), *totals = (uint32_t *)(tp + L.off_totals);
     uint64_t *alt = (uint64_t *)(tp + alt_off);
     const uint32_t n_side = side_sums != nullptr ? (uint32_t)((n + (1ull << side_shift) - 1) >> side_shift) : 0u;
@@ -1225,9 +1225,9 @@ extern "C" int32_t gs_presort_buckets(uint64_t n, int64_t *keys_in, const int32_
     d.shift = 32; d.mask = 0xffu; d.flip = 0u; d.drop = 1u; d.drop_hi = 0x7fffffffu;
     d.split = (const uint64_t *)splitters;
     hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, st, L.n_blocks, hist, totals, side_sums, n_side);
-    hipLaunchKernelGGL((sort_scatter_kernel<uint64_t, SORT_ROUNDS_SMALL, false, true>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n,
-                       (const uint32_t *)nullptr, (const uint64_t *)keys_in, vals_in, tkeys, tvals, d, L.n_blocks, hist, totals, n_kept,
-                       IsectEpilogue{}, ScatterSide{nullptr, nullptr, 0u});
+    hipLaunchKernelGGL((sort_scatter_kernel<uint64_t, SORT_ROUNDS_SMALL, false, true, true>), dim3(L.n_blocks), dim3(GS_BLOCK), 0, st, n,
+                       (const uint32_t *)nullptr, (const uint64_t *)keys_in, (const int32_t *)nullptr, tkeys, (int32_t *)nullptr, d, L.n_blocks, hist,
+                       totals, n_kept, IsectEpilogue{}, ScatterSide{nullptr, nullptr, 0u});
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(presort_local_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)PS_LOCAL_LDS);
     GS_CHECK_ARG(e == hipSuccess, "cannot raise the dynamic LDS limit");

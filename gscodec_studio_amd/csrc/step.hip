@@ -57,7 +57,7 @@ extern "C" uint32_t gs_quant_desc_layout(uint64_t *out, uint32_t n) {
 extern "C" int32_t gs_step_fwd_begin(gs_step *s, gs_stream_t stream) {
     GS_CHECK_ARG(s != nullptr, "null descriptor");
     GS_CHECK_ARG(s->C > 0 && s->N > 0, "C and N must be > 0");
-    GS_CHECK_ARG(s->radii && s->depths && s->rows && s->tiles_per_gauss && s->depth_keys && s->depth_vals && s->sort_temp &&
+    GS_CHECK_ARG(s->radii && s->depths && s->rows && s->tiles_per_gauss && s->depth_keys && s->sort_temp &&
                      s->perm && s->n_kept && s->group_sums && s->block_sums,
                  "a phase-1 buffer is missing");
     const uint32_t n_elems = s->C * s->N;
@@ -72,6 +72,7 @@ extern "C" int32_t gs_step_fwd_begin(gs_step *s, gs_stream_t stream) {
     const int32_t hist_ready = gs_sort_first_hist_applicable(n_elems);
     const bool bucketed = s->bucketed && gs_presort_applicable(n_elems);
     GS_CHECK_ARG(!bucketed || s->splitters != nullptr, "the bucketed pre-sort needs the splitter table");
+    GS_CHECK_ARG(bucketed || s->depth_vals != nullptr, "the radix pre-sort needs depth_vals");
     if (bucketed) GS_STEP_TRY(gs_presort_split(n_elems, s->radii, s->depths, s->splitters, stream));
     // (the projection counted the tiles and left the block sums: the count kernel only makes the depth keys and their histogram)
     GS_STEP_TRY(gs_isect_count_keys(n_elems, s->rows_ready ? s->rows + GS_ROW_MEAN2D : nullptr, GS_ROW_FLOATS, s->radii, s->depths, s->tile_size,

@@ -357,7 +357,8 @@ int32_t gs_gather_i32(uint32_t n, const int32_t *src, const int32_t *idx, int32_
 int32_t gs_isect_count_keys(
     uint32_t n_elems, const float *means2d /* NULL: tiles_per_gauss is an INPUT (gs_projection_rows_fwd counted) */, uint32_t means2d_stride, const int32_t *radii, const float *depths,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
-    int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals,
+    int32_t *tiles_per_gauss, int64_t *keys, int32_t *vals /* element indices; may be NULL with bucket_splitters (the bucketed
+                           pre-sort takes the element from the key's low half) */,
     int32_t *block_sums /* [gs_isect_count_blocks(n_elems)][2] (8-byte aligned) or NULL: per block (intersections, visible
                            elements), ONE 8-byte store; the totals are n_isects -- known here, before the depth pre-sort and the
                            prefix sum, so the host read-back of isect_tiles.cu:200 can overlap them -- and the number of
@@ -500,7 +501,7 @@ int32_t gs_presort_split(
     uint32_t n_elems, const int32_t *radii, const float *depths, int64_t *splitters /* [256] */, gs_stream_t stream);
 int32_t gs_presort_buckets(
     uint64_t n, int64_t *keys_in /* DESTROYED: on return [0, *n_kept) holds the sorted keys (depth bits << 32 | element), what
-    gs_isect_finish_presorted takes as sorted_keys */, const int32_t *vals_in, const int64_t *splitters,
+    gs_isect_finish_presorted takes as sorted_keys */, const int32_t *vals_in /* unused (may be NULL) */, const int64_t *splitters,
     int32_t *perm /* [n]; [0, *n_kept) written */, uint32_t *n_kept /* device scalar, written */,
     void *temp, size_t temp_bytes, const int32_t *side_vals, uint32_t *side_sums, uint32_t side_shift,
     uint32_t lds_capacity, gs_stream_t stream);
@@ -952,7 +953,7 @@ int32_t gs_dp_reduce_rows(uint64_t n_recv, uint32_t width, uint32_t world, const
  *   gs_step_bwd         gs_rasterize_bwd (packed gradient rows) -> gs_projection_rows_bwd
  * With rows_ready the first call starts at gs_isect_count_keys (binning + compositing of rows some other producer wrote).
  * All pointers are device pointers except block_sums (pinned host).  Buffers: radii i32 [C,N], depths [C,N], rows [C,N,16]
- * (64-byte aligned), tiles_per_gauss i32 [C,N], depth_keys i64 [C N], depth_vals i32 [C N], sort_temp
+ * (64-byte aligned), tiles_per_gauss i32 [C,N], depth_keys i64 [C N], depth_vals i32 [C N] (radix pre-sort only), sort_temp
  * (gs_presort_temp_bytes / gs_sort_temp_bytes of C N), splitters i64 [256] (bucketed), sorted_keys i64 [C N] (radix), perm
  * i32 [C N], n_kept u32 [1], group_sums u32 [ceil(C N / 2^gs_isect_emit_group_shift())], group_prefix i64 of the same length
  * + cumsum_scratch (both or neither), block_sums i32 [C * gs_projection_rows_blocks(N)][2] ([gs_isect_count_blocks(C N)][2] with rows_ready); isect_ids i64 / flatten_ids i32
