@@ -301,7 +301,12 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_scan_kernel(
                 if (wstart[sidx + step] <= t) sidx += step;
             const EmitRec o = wrec[sidx];
             const int32_t k = t - wstart[sidx];
-            const int32_t dy = k / o.w, dx = k - dy * o.w;
+            // k / w without the ~30-instruction integer division: float quotient, then one exact correction step (the float
+            // result is off by at most one for any k < 2^24)
+            int32_t dy = (int32_t)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)o.w));
+            int32_t dx = k - dy * o.w;
+            if (dx < 0) { dy -= 1; dx += o.w; }
+            else if (dx >= o.w) { dy += 1; dx -= o.w; }
             const int64_t tile_id = (int64_t)(o.y0 + dy) * tw + (o.x0 + dx);
             if (MODE == 2) keys32[out0 + t] = ((uint32_t)(o.key_base | tile_id) << pos_bits) | (uint32_t)o.id;
             else if (MODE == 1) keys32[out0 + t] = (uint32_t)(o.key_base | tile_id);
