@@ -611,6 +611,8 @@ extern "C" int32_t gs_sort_isect_packed(uint64_t n, uint32_t *words, const int32
     for (int p = 0; p < passes; ++p) {
         DigitSpec d;
         const bool final = p == passes - 1;
+        // (remainder bits FIRST, as for the pairs; remainder last -- longer store runs in the pass that writes 12 bytes per pair --
+        // was measured again for the packed words: 0.7274 / 0.7475 / 0.7414 against 0.7276 / 0.7207 / 0.7207 ms/step: no)
         const int bits = (p == 0) ? first_bits : RADIX_BITS;
         d.shift = (uint32_t)shift;
         shift += bits;
