@@ -317,26 +317,43 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_scan_kernel(
     }
 }
 
-// isect_tiles.cu:308-354
+// isect_tiles.cu:308-354.  Four consecutive ids per thread (two 16-byte loads + the 8 bytes in front): the kernel streams the
+// 8 I bytes of sorted ids once, and the tile arithmetic only runs at the ~T boundaries.
+constexpr uint32_t OFFSET_ITEMS = 4;
 __global__ void __launch_bounds__(GS_BLOCK) isect_offset_encode_kernel(
     uint32_t n_isects, const int64_t *__restrict__ isect_ids, uint32_t C, uint32_t n_tiles,
     uint32_t tile_n_bits, int32_t *__restrict__ offsets) {
-    uint32_t idx = blockIdx.x * GS_BLOCK + threadIdx.x;
-    if (idx >= n_isects) return;
+    const uint32_t base = (blockIdx.x * GS_BLOCK + threadIdx.x) * OFFSET_ITEMS;
+    if (base >= n_isects) return;
     const int64_t tmask = ((int64_t)1 << tile_n_bits) - 1;
-    int64_t cur = isect_ids[idx] >> 32;
-    int64_t id_cur = (cur >> tile_n_bits) * n_tiles + (cur & tmask);
-    if (idx == 0) {
-        for (int64_t i = 0; i <= id_cur; ++i) offsets[i] = 0;
+    auto tile_index = [&](int64_t key) { return (key >> tile_n_bits) * (int64_t)n_tiles + (key & tmask); };
+    int64_t k[OFFSET_ITEMS];
+    if (base + OFFSET_ITEMS <= n_isects && (reinterpret_cast<uintptr_t>(isect_ids) & 15u) == 0u) { // (uniform but for the last thread)
+        typedef long long v2ll __attribute__((ext_vector_type(2)));
+        const v2ll a = *reinterpret_cast<const v2ll *>(isect_ids + base), b = *reinterpret_cast<const v2ll *>(isect_ids + base + 2);
+        k[0] = a.x >> 32; k[1] = a.y >> 32; k[2] = b.x >> 32; k[3] = b.y >> 32;
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < OFFSET_ITEMS; ++j) k[j] = base + j < n_isects ? (isect_ids[base + j] >> 32) : 0;
     }
-    if (idx == n_isects - 1) {
-        for (int64_t i = id_cur + 1; i < (int64_t)C * n_tiles; ++i) offsets[i] = (int32_t)n_isects;
-    }
-    if (idx > 0) {
-        int64_t prev = isect_ids[idx - 1] >> 32;
-        if (prev == cur) return;
-        int64_t id_prev = (prev >> tile_n_bits) * n_tiles + (prev & tmask);
-        for (int64_t i = id_prev + 1; i <= id_cur; ++i) offsets[i] = (int32_t)idx;
+    int64_t prev = base > 0 ? (isect_ids[base - 1] >> 32) : 0;
+#pragma unroll
+    for (uint32_t j = 0; j < OFFSET_ITEMS; ++j) {
+        const uint32_t idx = base + j;
+        if (idx >= n_isects) break;
+        const int64_t cur = k[j];
+        if (idx == 0) {
+            const int64_t id_cur = tile_index(cur);
+            for (int64_t i = 0; i <= id_cur; ++i) offsets[i] = 0;
+        } else if (prev != cur) {
+            const int64_t id_prev = tile_index(prev), id_cur = tile_index(cur);
+            for (int64_t i = id_prev + 1; i <= id_cur; ++i) offsets[i] = (int32_t)idx;
+        }
+        if (idx == n_isects - 1) {
+            const int64_t id_cur = tile_index(cur);
+            for (int64_t i = id_cur + 1; i < (int64_t)C * n_tiles; ++i) offsets[i] = (int32_t)n_isects;
+        }
+        prev = cur;
     }
 }
 
@@ -675,7 +692,7 @@ extern "C" int32_t gs_isect_offset_encode(
         return 0;
     }
     GS_CHECK_ARG(isect_ids_sorted != nullptr, "null pointer");
-    hipLaunchKernelGGL(isect_offset_encode_kernel, dim3(gs_div_up(n_isects, GS_BLOCK)), dim3(GS_BLOCK), 0,
+    hipLaunchKernelGGL(isect_offset_encode_kernel, dim3(gs_div_up(n_isects, GS_BLOCK * OFFSET_ITEMS)), dim3(GS_BLOCK), 0,
                        (hipStream_t)stream, n_isects, isect_ids_sorted, C, n_tiles, tile_n_bits, offsets);
     GS_CHECK_LAUNCH();
     return 0;

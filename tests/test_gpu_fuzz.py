@@ -76,11 +76,17 @@ def _compositing_fuzz(seed):
     rc, ra = ops.rasterize_to_pixels(m2, cn, col, op, c["W"], c["H"], c["ts"], T(offs), T(flat), backgrounds=bg_t,
                                      masks=T(c["masks"]) if c["masks"] is not None else None)
     ok = bl == 0
+    kept = 1.0  # fraction of the pixels the tile masks leave to compare
     if c["masks"] is not None:  # skipped tiles: colours = background (or 0), alphas are left unwritten by the reference
         pm = np.repeat(np.repeat(c["masks"], c["ts"], 1), c["ts"], 2)[:, :c["H"], :c["W"]]
         ok = ok & pm
+        kept = float(pm.mean())
     tag = f"seed {seed}: C={c['C']} {c['W']}x{c['H']} tile {c['ts']} n={c['n']} D={c['D']} bg={c['bg'] is not None} masks={c['masks'] is not None}"
-    assert ok.mean() > 0.5, tag
+    # (most of the comparable pixels must not be borderline; a random mask over a 2 x 7 tile image may itself keep less than half
+    # of them -- seed offset 4600, case 12: 48.9 % -- which says nothing about the kernels)
+    if kept == 0.0:
+        return  # every tile masked out: nothing to compare
+    assert ok.mean() > 0.5 * kept, tag
     assert_close(N(rc)[ok], o_rc[ok], 1e-4, 2e-5, "render_colors " + tag, max_bad_frac=1e-4)
     assert_close(N(ra)[ok], o_ra[ok], 1e-4, 2e-5, "render_alphas " + tag, max_bad_frac=1e-4)
 
