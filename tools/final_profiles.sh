@@ -25,8 +25,8 @@ cp gpurun_out/prof_${tag}q_last_step.txt "$out/${tag}_quantize_last_step_timelin
 {
   python tools/bench_multicam.py 2>/dev/null
   python tools/bench_inference.py 2>/dev/null
-  python tools/cpu_overhead.py 2>/dev/null | head -1
-  GS_STEP_DRIVER=0 python tools/cpu_overhead.py 2>/dev/null | head -1 | sed 's/^/operator path: /'
+  AB=1 python tools/cpu_overhead.py 2>/dev/null | head -2
+  AB=1 python tools/cpu_overhead.py 2>/dev/null | head -2
   for cfg in "1 1" "0 1" "1 0" "0 0"; do set -- $cfg
     GS_PRESORT=$1 GS_STEP_DRIVER=$2 python bench.py --steps 100 --min-timed-s 2 --no-cpu-baseline --no-extras --no-dp-projection 2>/dev/null < /dev/null | tail -1 | \
       python -c "import json,sys; d=json.loads(sys.stdin.read()); print('A/B bucketed pre-sort', sys.argv[1], 'step driver', sys.argv[2], ': ms/step', round(d['ms_per_step'],4))" $1 $2
