@@ -160,3 +160,22 @@ def test_packed_kernels_directly_with_spare_position_bits():
     with pytest.raises(RuntimeError, match="32 bits"):
         B.call("gs_sort_isect_packed", n_isects, B.ptr(words), B.ptr(st["perm"]), None, B.ptr(dt), key_bits, 33 - key_bits, B.ptr(ids), B.ptr(flat),
                B.ptr(temp), tb, stream)
+
+
+def test_block_sums_summed_on_the_device_route():
+    """Scenes with more count blocks than _PINNED_DIRECT_MAX add the (intersections, visible) block pairs up on the device and
+    copy the two totals (the route of 49 M-splat scenes): forced here with a tiny threshold, same outputs -- packed pairs included."""
+    from gscodec_studio_amd import _wrapper as W
+
+    m2, radii, d = _case(150_000, "uniform", seed=11, vis=0.5, C=1)
+    args = (T(m2), T(radii), T(d))
+    a = _finish(*args, 120, 68, True)
+    prev = W._PINNED_DIRECT_MAX
+    W._PINNED_DIRECT_MAX = 4
+    try:
+        b = _finish(*args, 120, 68, True)
+        c = _finish(*args, 120, 68, False)
+    finally:
+        W._PINNED_DIRECT_MAX = prev
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y) and torch.equal(x, z)
