@@ -20,8 +20,17 @@ from ._wrapper import (
 from .rendering import rasterization
 from .version import __version__
 
+
+def __getattr__(name):  # (lazy: the codec module is not on the training path)
+    if name == "PngCompression":  # reference: gsplat/__init__.py:3
+        from .compression import PngCompression
+
+        return PngCompression
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
 __all__ = [
     "rasterization", "fully_fused_projection", "spherical_harmonics", "spherical_harmonics_shared",
     "isect_tiles", "isect_offset_encode", "rasterize_to_pixels", "quat_scale_to_covar_preci", "proj", "persp_proj",
-    "world_to_cam", "rasterize_to_indices_in_range", "__version__",
+    "world_to_cam", "rasterize_to_indices_in_range", "PngCompression", "__version__",
 ]
