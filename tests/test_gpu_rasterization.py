@@ -510,8 +510,11 @@ def test_prefilled_gradients_equal_full_writes(mode):
     through the same graph (retain_graph) finds the hand-over consumed and takes the path that allocates and writes every
     row itself: with ``deterministic=True`` both must give bit-identical gradients for every parameter, and a gaussian no
     camera sees must get exact zeros from both."""
+    from gscodec_studio_amd import _wrapper as W
     from gscodec_studio_amd import rasterization
 
+    if not W.PREFILL_ENABLED:
+        pytest.skip("GS_GRAD_PREFILL=0: the prefilled hand-over this test is about is switched off")
     sh_degree = None if mode == "colors" else 3
     d = _inputs(n=5000, cams=2, sh_degree=sh_degree, scale_mult=6.0)
     d["means"] = d["means"].copy()
