@@ -199,10 +199,11 @@ __global__ void __launch_bounds__(GS_BLOCK) isect_emit_kernel(
 }
 
 // Emission for the PRE-SORTED path with the prefix scan folded in (round 3: the two launches of gs_cumsum_gather_i32 and the
-// cum_tiles array are gone).  A workgroup owns EMIT_SCAN_TILE = 512 consecutive positions of the emission order:
-//   * its output offset = the sum of its predecessors' group sums (group_sums[g] = tiles of positions [512 g, 512 (g+1)),
-//     left behind by the LAST pass of the depth pre-sort, gs_sort_pairs_u64_i32_drop: side_sums);
-//   * the inclusive scan of its own 512 tile counts (gathered through perm) lives in LDS;
+// cum_tiles array are gone).  A workgroup owns EMIT_SCAN_TILE (= 128) consecutive positions of the emission order:
+//   * its output offset = the sum of its predecessors' group sums (group_sums[g] = tiles of positions [128 g, 128 (g+1)),
+//     left behind by the LAST pass of the depth pre-sort -- gs_presort_buckets / gs_sort_pairs_u64_i32_drop: side_sums);
+//   * tile count, radius and mean of its positions are gathered through perm in ONE phase; the inclusive scan of the
+//     counts and the emission records of all 128 positions live in LDS;
 //   * its four waves then emit groups of EMIT_SPW positions exactly like isect_emit_kernel.
 constexpr uint32_t EMIT_SCAN_SHIFT = 7; // 128 positions per workgroup: two groups of EMIT_SPW per wave (512: 58 us for 572
                                         // workgroups of eight sequential groups per wave -- too few waves in flight; the
