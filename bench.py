@@ -97,6 +97,9 @@ def measured_traffic(entry, workload_key):
 
 # fp32 vector peak 157.3 TFLOP/s = 256 CU x 4 SIMD x 2.4 GHz x one wave64 instruction per 2 cycles (MI355X_MICROARCH.md)
 VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2
+# what the vector pipes were MEASURED to issue on this part: 64 independent v_fma_f32 x 2048 iterations x 5 waves per SIMD on every
+# SIMD in 0.812 ... 0.817 ms (tools/mfma_reduce_ab.hip, profiles/r04_mfma_reduce_ab.txt) -- reported next to the nominal peak
+VALU_MEASURED_WAVE_INSTR_PER_S = 256 * 4 * 5 * 64 * 2048 / 0.815e-3
 
 
 def parse():
@@ -558,7 +561,9 @@ def main():
                 # (committed PMC pass) over the live kernel time, against one wave64 VALU instruction per 2 cycles per SIMD
                 "valu": (lambda vi: None if vi is None else {
                     "wave_instr_per_launch": vi, "achieved": vi / (dom_ms * 1e-3), "peak": VALU_PEAK_WAVE_INSTR_PER_S,
-                    "unit": "wave64 VALU instr/s", "frac": vi / (dom_ms * 1e-3) / VALU_PEAK_WAVE_INSTR_PER_S})(
+                    "unit": "wave64 VALU instr/s", "frac": vi / (dom_ms * 1e-3) / VALU_PEAK_WAVE_INSTR_PER_S,
+                    "measured_issue_rate": VALU_MEASURED_WAVE_INSTR_PER_S,
+                    "frac_of_measured_issue_rate": vi / (dom_ms * 1e-3) / VALU_MEASURED_WAVE_INSTR_PER_S})(
                     measured_pmc(dominant, f"grid{args.scene_grid}_{w['width']}x{w['height']}_sh{args.sh_degree}",
                                  "valu_wave_instr_per_launch")),
                 "algorithmic_bytes": alg.get(dominant, 0),
