@@ -296,10 +296,68 @@ def psnr_vs_oracle(dev):
             "config": f"config 1: garden crop {means.shape[0]} gaussians, camera 0, {W}x{H}, RGB, GPU render vs CPU oracle render"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): start the N ranks
+    here, one process per GPU, with the environment torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT) -- the reference's harness launches itself the same way (profiling/main.py:370 ->
+    gsplat/distributed.py:304-360).  Rank 0 inherits this process's stdout, so its JSON line is the last line of stdout; the
+    other ranks' stdout goes to stderr.  Any rank dying takes the others down and the exit code is non-zero.  Fewer visible
+    GPUs than ranks is refused unless GS_BENCH_SHARE_GPU=1 (all ranks on cuda:0 over gloo: control flow only, not a speed)."""
+    import signal
+    import subprocess
+
+    from gscodec_studio_amd.distributed import _find_free_port
+
+    n = args.gpus
+    share = os.environ.get("GS_BENCH_SHARE_GPU") == "1"
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < n and not share:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, found {n_dev} (set GS_BENCH_SHARE_GPU=1 to run all ranks on one "
+              f"GPU over gloo: control flow only)", file=sys.stderr)
+        return 2
+    port = os.environ.get("MASTER_PORT") or str(_find_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, GS_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr, start_new_session=True))
+    rc = 0
+    try:
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                c = procs[r].poll()
+                if c is None:
+                    continue
+                live.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 128 - c
+                    print(f"bench.py: rank {r} exited with {c}; stopping the other ranks", file=sys.stderr)
+                    for q in live:  # (exactly the process groups started above)
+                        try:
+                            os.killpg(procs[q].pid, signal.SIGTERM)
+                        except ProcessLookupError:
+                            pass
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for q in procs:
+            if q.poll() is None:
+                os.killpg(q.pid, signal.SIGTERM)
+        rc = 130
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("GS_BENCH_TEST_KILL_RANK") == str(rank) and world > 1:  # (tests/test_gpu_bench_launch.py: a rank that dies)
+        sys.exit(17)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # GS_BENCH_PG=1 / a forced mode: one GPU still goes through the process group and RCCL (debugging aid)
     use_pg = world > 1 or args.dp_mode.startswith("gaussian") or os.environ.get("GS_BENCH_PG") == "1"

@@ -948,6 +948,8 @@ def all_reduce_splat_grads(
     if world_size is None:
         world_size = dist.get_world_size() if dist.is_initialized() else 1
     plist = list(params.values()) if isinstance(params, dict) else list(params)
+    keys = list(params.keys()) if isinstance(params, dict) else [None] * len(plist)
+    keys = [k for k, p in zip(keys, plist) if p.requires_grad]
     plist = [p for p in plist if p.requires_grad]
     if _single(world_size) or not plist:
         return
@@ -966,10 +968,15 @@ def all_reduce_splat_grads(
         used = sum(numels)
         if used * 4 >= _DIRECT_RS_AG_MIN_BYTES and all(p.dtype == torch.float32 for p in plist):
             length = _span_length(numels, world_size)
-            span = _one_span(plist, length)
+            # ONE layout of the span on every rank, whichever way a rank gets there: the pieces in _canonical_order (a
+            # function of the dict keys / the list order only).  A rank reduces in place only when its gradients lie in
+            # exactly that order; any other arrangement is staged into it (round-4 advisor finding: in-place ranks used
+            # the carving order, staging ranks the dict order -- quats [N,4] and scales [N,3] swapped places between them)
+            canon = [plist[i] for i in _canonical_order(keys)]
+            span = _one_span(canon, length)
             staged = span is None
             if staged:
-                span = _stage_span(plist, length)
+                span = _stage_span(canon, length)
             if "nccl" not in _backend_name():  # (gloo: no reduce_scatter_tensor; the tests' route)
                 _all_reduce_sum(span)
                 if average:
@@ -985,7 +992,7 @@ def all_reduce_splat_grads(
                     shard.mul_(scale)
                 dist.all_gather_into_tensor(span, shard)
             if staged:
-                _unstage_span(plist, span)
+                _unstage_span(canon, span)
             return
         for p in plist:
             if p.grad is None:
@@ -1033,26 +1040,37 @@ def _span_length(numels: List[int], world_size: int) -> int:
     return n + (-n) % world_size
 
 
+# the order in which rasterization() carves the per-gaussian gradients out of its one buffer (_wrapper.GradPrefill.request:
+# means, covars, quats, scales, opacities, colours | SH (DC band), SH rest), by the names trainers give those parameters
+_CARVE_RANK = {"means": 0, "covars": 1, "quats": 2, "scales": 3, "opacities": 4, "colors": 5, "sh": 5, "sh0": 5, "sh_coeffs": 5,
+               "shN": 6, "sh_rest": 6}
+
+
+def _canonical_order(keys: List[Optional[str]]) -> List[int]:
+    """Rank-invariant order of the span's pieces: parameters with a known name in the carving order of rasterization()
+    (so a trainer's dict -- means, scales, quats, ... in the reference's -- maps onto the buffer its gradients already lie in),
+    everything else behind them in the order given.  Depends on the keys / positions only, never on where a rank's gradients
+    happen to live."""
+    return sorted(range(len(keys)), key=lambda i: (_CARVE_RANK.get(keys[i], len(_CARVE_RANK) + 1), i))
+
+
 def _one_span(plist: List[Tensor], length: int) -> Optional[Tensor]:
     """The flat fp32 tensor of ``length`` floats covering every ``p.grad`` IN PLACE, when they are all dense contiguous
-    pieces of ONE storage and the gaps between them are nothing but the 256-byte alignment padding of GradPrefill's
-    carving (``hi - lo == sum of the padded sizes``: no foreign data -- e.g. the gradient of a parameter that is not in
-    ``plist`` -- can sit inside the span, so reducing the span touches only what was asked for); None otherwise."""
+    pieces of ONE storage lying **in the order of ``plist``**, every piece starting where the 256-byte padding of the
+    previous one ends (GradPrefill's carving: no foreign data -- e.g. the gradient of a parameter that is not in ``plist``
+    -- can sit inside the span, so reducing the span touches only what was asked for, and the layout equals what
+    ``_stage_span`` builds from the same list on a rank that has to stage); None otherwise."""
     grads = [p.grad for p in plist]
-    if any(g is None or g.is_sparse or g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda for g in grads):
+    if any(g is None or g.is_sparse or g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
         return None
     st = grads[0].untyped_storage()
     if any(g.untyped_storage().data_ptr() != st.data_ptr() for g in grads[1:]):
         return None
-    lo = min(g.storage_offset() for g in grads)
-    if any((g.storage_offset() - lo) % 64 for g in grads):  # (the carving pads every piece to 64 floats from the first one on)
-        return None
-    ends = sorted((g.storage_offset(), g.storage_offset() + g.numel()) for g in grads)
-    pos = lo
-    for a, b in ends:  # back to back at 64-float granularity: every piece starts where the previous one's padding ends
-        if a != pos:
+    lo = pos = grads[0].storage_offset()
+    for g in grads:
+        if g.storage_offset() != pos:
             return None
-        pos = a + (b - a + 63) // 64 * 64
+        pos += (g.numel() + 63) // 64 * 64
     # (the world-size rounding reaches into the slack rasterization() leaves behind the last piece -- never downwards: the
     # compositing gradient rows, which meta["means2d"].grad / .absgrad may still view, lie in front of the first piece)
     if lo + length > st.nbytes() // 4:

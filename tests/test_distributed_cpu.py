@@ -195,6 +195,55 @@ def test_splat_grad_reduction_one_span_world2():
     _run("_grad_reduce_span")
 
 
+def _grad_reduce_span_trainer_order(rank, world):
+    """Round-4 advisor finding: the reference trainer's dict order (means, scales, quats, ...: examples/simple_trainer.py) is
+    NOT the order rasterization() carves the gradients in (means, quats, scales, ...).  Rank 0 reduces IN PLACE on the carved
+    buffer, rank 1 stages (separately allocated gradients): both must use one layout, or quats [N,4] and scales [N,3] are added
+    at each other's offsets.  Random values, so any mix-up shows."""
+    os.environ["GS_DP_RS_AG_MIN_BYTES"] = "64"
+    from gscodec_studio_amd import distributed as D
+
+    N = 37
+    shapes = {"means": (N, 3), "scales": (N, 3), "quats": (N, 4), "opacities": (N,), "sh0": (N, 1, 3), "shN": (N, 15, 3)}
+    carve_order = ["means", "quats", "scales", "opacities", "sh0", "shN"]
+    assert [list(shapes)[i] for i in D._canonical_order(list(shapes))] == carve_order
+    assert D._canonical_order([None, None, None]) == [0, 1, 2]
+    assert [["x", "shN", "means"][i] for i in D._canonical_order(["x", "shN", "means"])] == ["means", "shN", "x"]
+    g = torch.Generator().manual_seed(5)
+    vals = {k: torch.randn(world, *shp, generator=g) for k, shp in shapes.items()}
+    params = {k: torch.nn.Parameter(torch.zeros(shp)) for k, shp in shapes.items()}
+    length = D._span_length([params[k].numel() for k in carve_order], world)
+    if rank == 0:
+        buf = torch.full((length + 200,), -7.0)
+        off = 72  # (the compositing gradient rows lie in front)
+        for k in carve_order:
+            p = params[k]
+            p.grad = buf[off:off + p.numel()].view(p.shape)
+            p.grad.copy_(vals[k][rank])
+            off += (p.numel() + 63) // 64 * 64
+        assert D._one_span([params[k] for k in carve_order], length) is not None     # taken in place ...
+        assert D._one_span(list(params.values()), length) is None                    # ... but never in the dict's order
+    else:
+        for k, p in params.items():
+            p.grad = vals[k][rank].clone()
+    D.all_reduce_splat_grads(params, average=False, algorithm="direct")
+    for k, p in params.items():
+        assert torch.allclose(p.grad, vals[k].sum(0), atol=1e-6), k
+    if rank == 0:
+        assert bool((buf[:72] == -7.0).all())
+        assert params["quats"].grad.untyped_storage().data_ptr() == buf.untyped_storage().data_ptr()  # (still in place)
+    # as a LIST in the dict's order (no names: the list order is the layout), rank 0's carved buffer no longer matches -> staged
+    for k, p in params.items():
+        p.grad.copy_(vals[k][rank])
+    D.all_reduce_splat_grads(list(params.values()), average=True, algorithm="direct")
+    for k, p in params.items():
+        assert torch.allclose(p.grad, vals[k].mean(0), atol=1e-6), k
+
+
+def test_splat_grad_reduction_trainer_dict_order_world2():
+    _run("_grad_reduce_span_trainer_order")
+
+
 # --------------------------------------------------------------------------- sparse gradient reduction (camera-sharded)
 def _sparse_grad_reduce(rank, world):
     """plan_sparse_grad_exchange + all_reduce_splat_grads(plan=...) equals the dense sum: ragged N (not a multiple of the
