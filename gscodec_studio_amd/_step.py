@@ -329,7 +329,10 @@ def rows_applicable(rows: Optional[Tensor], colors: Optional[Tensor], packed: bo
                     deterministic: bool, absgrad: bool) -> bool:
     """The gaussian-sharded mode's receiver side: [C_local, N_total, 16] splat rows with RGB colours in them."""
     return (ENABLED and rows is not None and rows.is_cuda and not packed and not deterministic and render_mode == "RGB"
-            and channel_chunk >= 3 and colors is not None and colors.shape[-1] == 3 and rows.shape[0] * rows.shape[1] > 0)
+            and channel_chunk >= 3 and colors is not None and colors.shape[-1] == 3
+            # (the block sums go straight into pinned memory: same size gate as the one-GPU fast path / isect_tiles_begin --
+            # tens of thousands of direct PCIe stores stalled the GPU for ~85 ms on some forwards)
+            and 0 < rows.shape[0] * rows.shape[1] <= W._PINNED_DIRECT_MAX * 1024)
 
 
 def rows_begin(radii: Tensor, depths: Tensor, rows: Tensor, tile_size: int, tile_width: int, tile_height: int) -> _RowsState:

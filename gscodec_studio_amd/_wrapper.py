@@ -1240,25 +1240,60 @@ def _pinned_take(n: int) -> Tensor:
 _PACKED_PAIRS = os.environ.get("GS_PACKED_PAIRS", "1") != "0"
 
 
+_WAIT_TIMEOUT_S = float(os.environ.get("GS_WAIT_TIMEOUT_S", "30"))  # hard limit of any host wait on the GPU
+
+
 class _SentinelEvent:
     """``query`` / ``synchronize`` of an event over a pinned buffer whose entries go from -1 to >= 0 as the kernel stores them
-    (posted 4-byte writes of independent workgroups into host-coherent memory: each becomes visible on its own)."""
+    (posted 4-byte writes of independent workgroups into host-coherent memory: each becomes visible on its own -- the
+    mechanism needs fine-grained coherent pinned memory, HIP's default for ``hipHostMalloc``; with HIP_HOST_COHERENT=0 the
+    stores only show at a synchronisation point, which the stream check below turns into a late but correct result).
 
-    __slots__ = ("buf", "np")
+    The wait is BOUNDED and notices a dead GPU: a yielding spin for the first millisecond, then 50 us naps; every ~2 ms the launch stream is queried -- a
+    device fault raises there, and a stream that has drained while the sentinel is still unset means the kernel never stored
+    (failed launch, lost write): RuntimeError instead of a core spinning for good; ``GS_WAIT_TIMEOUT_S`` (30) ends any wait."""
 
-    def __init__(self, buf: Tensor):
+    __slots__ = ("buf", "np", "stream", "what")
+
+    def __init__(self, buf: Tensor, stream=None, what: str = "the count kernel's block sums (isect_count_keys_kernel / projection_fwd_kernel)"):
         self.buf = buf
         self.np = buf.numpy()  # (a view of the pinned memory: numpy's min over ~1 K ints is a microsecond, torch's op is ~5)
+        self.stream = stream  # the stream the storing kernel was launched on (None: the current one at wait time)
+        self.what = what
 
     def query(self) -> bool:
         a = self.np
         return a[-1] >= 0 and a[0] >= 0 and int(a.min()) >= 0  # (two cache lines while the kernel is far from done)
 
-    def synchronize(self) -> None:
+    def synchronize(self, timeout_s: Optional[float] = None) -> None:
         import time
 
+        if self.query():
+            return
+        t0 = time.perf_counter()
+        limit = _WAIT_TIMEOUT_S if timeout_s is None else timeout_s
+        next_check = t0 + 2e-3
         while not self.query():
-            time.sleep(0)
+            now = time.perf_counter()
+            if now - t0 < 1e-3:
+                time.sleep(0)  # (yielding spin: the usual wait is a few tens of microseconds, and a nap's wake-up is ~100 us late)
+                continue
+            if now >= next_check:
+                next_check = now + 2e-3
+                st = self.stream if self.stream is not None else torch.cuda.current_stream()
+                try:
+                    drained = st.query()  # raises on a device fault / an earlier HIP error on the stream
+                except Exception as e:
+                    raise RuntimeError(f"GPU error while waiting for {self.what}: {e}") from e
+                if drained:
+                    # everything queued has run: stores of a finished kernel are visible now or never
+                    if self.query():
+                        return
+                    raise RuntimeError(f"the stream drained but {self.what} never arrived in pinned memory "
+                                       f"(kernel not launched, faulted, or its stores were lost)")
+                if now - t0 > limit:
+                    raise RuntimeError(f"timed out after {limit:.1f} s (GS_WAIT_TIMEOUT_S) waiting for {self.what}")
+            time.sleep(50e-6)
 
 
 @torch.no_grad()
@@ -1370,9 +1405,14 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
 def _wait_event(ev) -> None:
     """Wait for a CUDA event by POLLING it.  ``Event.synchronize()`` spins only briefly and then sleeps; when the GPU needs a
     few milliseconds to get there (49 M splats: 3 ms per forward) the wake-up came ~17 ms late on the bench host -- the
-    forward ran at 42 FPS instead of 300.  A few milliseconds of host polling cost nothing here."""
+    forward ran at 42 FPS instead of 300.  A few milliseconds of host polling cost nothing here.  Past 0.25 s the wait is
+    handed to the event's own ``synchronize`` (a real event sleeps and raises HIP errors; a ``_SentinelEvent`` naps, watches
+    the stream for faults and gives up after ``GS_WAIT_TIMEOUT_S``): never an unbounded spin."""
     import time
 
+    if isinstance(ev, _SentinelEvent):
+        ev.synchronize()
+        return
     deadline = time.perf_counter() + 0.25
     while not ev.query():
         if time.perf_counter() > deadline:  # something long is queued in front: stop burning the core

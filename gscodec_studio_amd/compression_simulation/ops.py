@@ -185,6 +185,49 @@ class _NoiseQuantMulti(torch.autograd.Function):
         return (None, *grads)
 
 
+_SELFCHECK: Dict[int, bool] = {}
+
+
+def multi_selfcheck(device: torch.device) -> bool:
+    """Once per device: does the in-kernel noise of ``_NoiseQuantMulti`` still equal torch's ``uniform_`` stream?  The kernel
+    restates torch internals by hand (grid cap CUs x max-threads / 256, unroll 4, the Philox offset advance, rocrand's
+    ``v 2^-32 + 2^-32`` conversion): a torch or ROCm change would silently break the bit-identity with the tensor-by-tensor hooks.
+    Two tensors (one spanning several grid strides, one ragged) are quantized both ways from the same generator state; the
+    values AND the generator offset afterwards must agree.  The caller's RNG state is restored.  False (+ a warning) disables
+    the one-launch path for the process -- the per-tensor calls are the reference's own sequence."""
+    i = device.index if device.index is not None else torch.cuda.current_device()
+    if i in _SELFCHECK:
+        return _SELFCHECK[i]
+    gen = torch.cuda.default_generators[i]
+    state = gen.get_state()
+    ok = False
+    try:
+        with torch.no_grad():
+            xs = [torch.linspace(-3.0, 3.0, 300_007, device=device), torch.linspace(-1.0, 1.0, 1_001, device=device)]
+            bounds, bits = [(-2.0, 2.0), (-1.0, 1.0)], [8, 8]
+            gen.manual_seed(0x5EED)
+            multi = fake_quantize_noise_multi(xs, bounds, bits)
+            off_multi = gen.get_offset()
+            gen.manual_seed(0x5EED)
+            single = [fake_quantize_ste(x, lo, hi, b, "noise") for x, (lo, hi), b in zip(xs, bounds, bits)]
+            off_single = gen.get_offset()
+            ok = off_multi == off_single and all(torch.equal(m["output_value"], s_["output_value"]) for m, s_ in zip(multi, single))
+    except Exception as e:  # (a missing symbol, an unexpected generator API: the per-tensor path stays)
+        ok = False
+        import warnings
+
+        warnings.warn(f"gscodec_studio_amd: multi-tensor quantizer self-check failed to run ({type(e).__name__}: {e})")
+    finally:
+        gen.set_state(state)
+    if not ok:
+        import warnings
+
+        warnings.warn("gscodec_studio_amd: the in-kernel noise of the multi-tensor quantizer no longer reproduces torch's uniform_ "
+                      "stream on this torch / ROCm build; falling back to the per-tensor hooks (GS_QUANT_MULTI=0 behaviour)")
+    _SELFCHECK[i] = ok
+    return ok
+
+
 def fake_quantize_noise_multi(inputs: Sequence[Tensor], bounds: Sequence[Tuple[float, float]], bitwidths: Sequence[int],
                               activations: Optional[Sequence[Optional[str]]] = None) -> List[Dict[str, object]]:
     """``[fake_quantize_ste(x, lo, hi, bits, "noise", activation) for ...]`` -- same outputs, same RNG stream -- in one launch

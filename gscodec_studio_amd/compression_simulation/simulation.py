@@ -25,7 +25,7 @@ from typing_extensions import Literal
 from .ada_mask import AnnealingMask
 from .ada_mask import shN_gradient_threshold as _shN_gradient_threshold
 from .entropy_model import Entropy_factorized_optimized_refactor
-from .ops import QUANT_MULTI_MAX, fake_quantize_noise_multi, fake_quantize_ste
+from .ops import QUANT_MULTI_MAX, fake_quantize_noise_multi, fake_quantize_ste, multi_selfcheck
 
 
 class _SimulationBase:
@@ -151,6 +151,9 @@ class _SimulationBase:
             names.append(name)
         if not 2 <= len(names) <= QUANT_MULTI_MAX or len({splats[n].device for n in names}) != 1:
             return
+        if not multi_selfcheck(splats[names[0]].device):  # (first use per device; a torch / ROCm change of the RNG kernel shows here)
+            type(self)._MULTI = False
+            return
         acts = []
         for n in names:
             estimate = (self.entropy_model_enable and self.entropy_model_option.get(n, False)
@@ -162,7 +165,13 @@ class _SimulationBase:
 
     def _simulate(self, splats: Dict[str, Tensor], step: int):
         new_splats, esti_bits = {}, {}
-        self._prequantize(splats, step)
+        try:
+            self._prequantize(splats, step)
+            return self._run_hooks(splats, step, new_splats, esti_bits)
+        finally:
+            self._pre = {}  # (nothing pre-quantized outlives its call: an exception in a hook must not leave stale values behind)
+
+    def _run_hooks(self, splats, step, new_splats, esti_bits):
         for name in splats.keys():
             if self.simulation_option[name]:
                 fn = getattr(self, f"simulate_compression_{name}", None)

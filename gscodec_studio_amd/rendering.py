@@ -165,8 +165,11 @@ def rasterization(
         split_ok = ((not packed) and (not distributed) and means.is_cuda and viewmats.is_cuda and not viewmats.requires_grad
                     and shN.shape[1] >= 1)
         # the fused mask rides on the fused SH backward: vectorisable rows (3 K % 4 == 0), which covers degrees 1 and 3
-        mask_ok = masked is None or (split_ok and (3 * (1 + shN.shape[1])) % 4 == 0 and shN.is_contiguous()
-                                     and masked.mask_logits.numel() == N)
+        # -- and everything else the backward's fused route checks must be known to hold HERE, or the forward would succeed and
+        # training die in loss.backward() (GS_FUSE_SH_BWD=0, a misaligned shN view): such masks are materialised up front
+        from ._wrapper import _FUSE_SH_BWD
+        mask_ok = masked is None or (split_ok and _FUSE_SH_BWD and (3 * (1 + shN.shape[1])) % 4 == 0 and shN.is_contiguous()
+                                     and shN.data_ptr() % 16 == 0 and masked.mask_logits.numel() == N)
         if masked is not None and not mask_ok:
             shN, masked = masked.materialize(), None
         if split_ok:

@@ -176,6 +176,7 @@ def test_config3_full_size_properties():
         err = (q[k].detach() - before[k].clamp(lo, hi)).abs().max()
         assert float(err) <= (hi - lo) / 255 / 2 * 1.0001, k
         assert torch.equal(P[k].detach(), before[k])
+    ra = ra.detach()
     assert bool(torch.isfinite(rc).all()) and float(ra.min()) >= 0 and float(ra.max()) <= 1
     vis = meta["radii"][0] > 0
     n_isects = meta["flatten_ids"].numel()
@@ -245,7 +246,7 @@ def test_config5_slice_quantize_render_vs_oracle_chain():
         clamped[k], o_q[k] = O.quant_round_fwd(raw[k], lo, hi, 8)
         assert np.array_equal(N(q[k]), o_q[k]), k
         assert np.array_equal(N(P[k]), clamped[k]), k  # clamped in place (reference ops.py:63)
-    assert float(P["colors"][:9, 1].max()) == 7.5
+    assert float(P["colors"][:9, 1].detach().max()) == 7.5
     o_scales = np.exp(o_q["scales"]).astype(np.float32)
     o_opac = (1.0 / (1.0 + np.exp(-o_q["opacities"].astype(np.float64)))).astype(np.float32)
     o_ts = np.exp(raw["trbf_scale"]).astype(np.float32)
@@ -305,7 +306,7 @@ def test_config5_full_size_properties():
     # parameters clamped in place; quantized values on the 255-level grid
     assert float(P["scales"][:11, 2].max()) == 2.0
     for k, (lo, hi) in BDS5.items():
-        assert float(P[k].min()) >= lo and float(P[k].max()) <= hi, k
+        assert float(P[k].detach().min()) >= lo and float(P[k].detach().max()) <= hi, k
         lv = (q[k].detach() - lo) / ((hi - lo) / 255)
         assert float((lv - lv.round()).abs().max()) < 2e-3, k
     vis = meta["radii"][0] > 0

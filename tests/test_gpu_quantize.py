@@ -94,7 +94,7 @@ def test_compression_simulation_hooks():
     assert new["shN"] is splats["shN"]
     for k, (lo, hi) in dict(scales=(-10, 2), quats=(-1, 1), opacities=(-15, 15), sh0=(-2, 4)).items():
         q = (hi - lo) / 255
-        err = (new[k] - before[k].clamp(lo, hi)).abs().max()
+        err = (new[k].detach() - before[k].clamp(lo, hi)).abs().max()
         assert float(err) <= q / 2 * 1.0001, k  # uniform noise of +- q/2 around the clamped value
         assert torch.equal(splats[k].detach(), before[k])  # noise mode leaves the parameter alone
     # dynamic variant, round mode: parameters ARE clamped in place
