@@ -797,6 +797,9 @@ _FUSE_SH_BWD = os.environ.get("GS_FUSE_SH_BWD", "1") == "1"  # (A/B switch: 0 = 
 PREFILL_ENABLED = os.environ.get("GS_GRAD_PREFILL", "1") != "0"
 
 
+_FAST_MAX_CHANNELS = 32  # channel counts the tile forward / segmented backward cover (csrc/rasterize.hip: FAST_MAX_CHANNELS)
+
+
 class GradPrefill:
     """Hand-over between the two autograd nodes of ONE ``rasterization()`` call (not in the reference).
 
@@ -1643,15 +1646,21 @@ class _RasterizeToPixels(torch.autograd.Function):
             # the packed gradient rows of the backward ([n_elems,16], accumulated with atomics) are zero-filled by THIS
             # launch, as a side job of the tile workgroups: no fill pass in the backward
             grad_rows = fill = None
-            if needs_bwd and channels <= 4 and n_elems > 0:
+            ctx.grad_colors = None
+            if needs_bwd and channels <= _FAST_MAX_CHANNELS and n_elems > 0:
                 # (+ the per-gaussian gradient tensors the projection node asked for, GradPrefill: one buffer, one fill)
                 extra = prefill.floats() if prefill is not None else 0
                 if extra:
                     extra += 64  # slack behind the last piece (a multi-GPU reduction rounds the span of all pieces up into it)
-                fill = torch.empty(n_elems * 16 + extra, dtype=torch.float32, device=dev)
+                # 5..32 channels: the geometry gradients keep their 16-float rows (the projection backward reads them in
+                # place), the colour gradients get a dense [n_elems, channels] array behind them -- same buffer, same fill
+                wide = _pad64(n_elems * channels) if channels > 4 else 0
+                fill = torch.empty(n_elems * 16 + wide + extra, dtype=torch.float32, device=dev)
                 grad_rows = fill[:n_elems * 16].view(opacities.shape + (16,))
+                if wide:
+                    ctx.grad_colors = fill[n_elems * 16:n_elems * 16 + n_elems * channels].view(opacities.shape + (channels,))
                 if extra:
-                    prefill.carve(fill, n_elems * 16)
+                    prefill.carve(fill, n_elems * 16 + wide)
             B.call("gs_rasterize_fwd", C, n_elems, n_isects, channels, B.ptr(means2d), B.ptr(conics), B.ptr(colors),
                    B.ptr(opacities), ctypes.addressof(strides) if strides is not None else None, B.ptr(backgrounds), B.ptr(m8),
                    width, height, tile_size, tile_width,
@@ -1692,7 +1701,7 @@ class _RasterizeToPixels(torch.autograd.Function):
         # accumulated with atomics -> zero-filled.  Up to 4 channels: ONE packed [n_elems,16] buffer
         # (64-byte row per splat: vx vy | ca cb cc | o | c0..c3 | ax ay) so that a splat's whole
         # gradient is one L2 request; the tensors handed to autograd are views of it.
-        packed = channels <= 4
+        packed = channels <= _FAST_MAX_CHANNELS
         # deterministic mode: fixed-point sums in an int64 buffer of their own; the float rows are then WRITTEN by a second kernel
         det = torch.zeros((n_elems, 2, 12), dtype=torch.int64, device=means2d.device) if (ctx.deterministic and n_elems > 0) else None
         if packed:
@@ -1703,9 +1712,15 @@ class _RasterizeToPixels(torch.autograd.Function):
                 P = (torch.empty if (det is not None and n_isects > 0) else torch.zeros)(
                     opacities.shape + (16,), dtype=torch.float32, device=means2d.device)
             v_means2d, v_conics, v_opacities = P[..., 0:2], P[..., 2:5], P[..., 5]
-            v_colors = P[..., 6:6 + channels]
             v_means2d_abs = P[..., 10:12] if ctx.absgrad else None
-            out_ptrs = (B.ptr(P) if ctx.absgrad else None, B.ptr(P), None, None, None)
+            if channels <= 4:
+                v_colors = P[..., 6:6 + channels]
+                out_ptrs = (B.ptr(P) if ctx.absgrad else None, B.ptr(P), None, None, None)
+            else:  # geometry rows + the colour gradients in their own dense array (packed16 = 2)
+                v_colors, ctx.grad_colors = ctx.grad_colors, None
+                if v_colors is None:
+                    v_colors = torch.zeros(opacities.shape + (channels,), dtype=torch.float32, device=means2d.device)
+                out_ptrs = (B.ptr(P) if ctx.absgrad else None, B.ptr(P), None, B.ptr(v_colors), None)
         else:
             v_means2d = torch.zeros_like(means2d)
             v_conics = torch.zeros_like(conics)
@@ -1721,7 +1736,7 @@ class _RasterizeToPixels(torch.autograd.Function):
                    ctx.width, ctx.height, ctx.tile_size,
                    tile_width, tile_height, B.ptr(isect_offsets), B.ptr(flatten_ids), B.ptr(render_colors),
                    B.ptr(render_alphas), B.ptr(last_ids), B.ptr(v_render_colors), B.ptr(v_render_alphas), vrc_pix, vrc_ch, *out_ptrs,
-                   int(packed), B.ptr(det), ctypes.addressof(plan) if plan is not None else None,
+                   (1 if channels <= 4 else 2) if packed else 0, B.ptr(det), ctypes.addressof(plan) if plan is not None else None,
                    B.ptr(scratch) if plan is not None else None, _stream(means2d))
         if ctx.absgrad:
             means2d.absgrad = v_means2d_abs

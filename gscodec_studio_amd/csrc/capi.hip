@@ -61,6 +61,10 @@ static int32_t set_splat_layout(RasterArgs &a, const uint32_t *strides) {
         a.row16 = (a.channels <= 4u && a.s_xy == 16u && a.s_conic == 16u && a.s_color == 16u && a.s_opac == 16u && a.means2d != nullptr &&
                    ((uintptr_t)a.means2d % 64u) == 0u && a.conics == a.means2d + GS_ROW_CONIC && a.opacities == a.means2d + GS_ROW_OPACITY &&
                    a.colors == a.means2d + GS_ROW_COLOR) ? 1u : 0u;
+        // more than 4 channels: the geometry alone from the row (two 16-byte loads of one line), colours from their own array
+        if (a.channels > 4u && a.s_xy == 16u && a.s_conic == 16u && a.s_opac == 16u && a.means2d != nullptr && ((uintptr_t)a.means2d % 64u) == 0u &&
+            a.conics == a.means2d + GS_ROW_CONIC && a.opacities == a.means2d + GS_ROW_OPACITY)
+            a.row16 = 2u;
     }
     return 0;
 }
@@ -111,7 +115,10 @@ extern "C" int32_t gs_rasterize_bwd(
     GS_CHECK_ARG(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids && v_means2d),
                  "null pointer");
     GS_CHECK_ARG(n_isects == 0 || packed16 || (v_conics && v_colors && v_opacities), "null pointer");
-    GS_CHECK_ARG(!packed16 || channels <= 4, "packed16 gradients need channels <= 4");
+    GS_CHECK_ARG(packed16 >= 0 && packed16 <= 2, "packed16 must be 0, 1 or 2");
+    GS_CHECK_ARG(packed16 != 1 || channels <= 4, "packed16 = 1 (every gradient in the rows) needs channels <= 4");
+    GS_CHECK_ARG(packed16 != 2 || channels > 4, "packed16 = 2 (geometry rows + separate colour gradients) is the form for more than 4 channels");
+    GS_CHECK_ARG(packed16 != 2 || n_isects == 0 || v_colors != nullptr, "packed16 = 2 takes the colour gradients in v_colors");
     GS_CHECK_ARG((plan == nullptr) == (scratch == nullptr), "plan and scratch go together (both or neither)");
     RasterArgs a = {C, n_elems, n_isects, channels, means2d, conics, colors, opacities, backgrounds, masks,
                     image_width, image_height, tile_size, tile_width, tile_height, tile_offsets, flatten_ids,
@@ -124,9 +131,12 @@ extern "C" int32_t gs_rasterize_bwd(
         ga.v_means2d = P;
         ga.v_conics = P + 2;
         ga.v_opacities = P + 5;
-        ga.v_colors = P + 6;
         ga.v_means2d_abs = v_means2d_abs != nullptr ? P + 10 : nullptr;
-        ga.s_abs = ga.s_xy = ga.s_conic = ga.s_color = ga.s_opac = 16u;
+        ga.s_abs = ga.s_xy = ga.s_conic = ga.s_opac = 16u;
+        if (packed16 == 1) {
+            ga.v_colors = P + 6;
+            ga.s_color = 16u;
+        }
         ga.packed = 1u;
     }
     if (int32_t rc = check_raster_args(a)) return rc;

@@ -53,186 +53,9 @@
 #include <cstring>
 #include <type_traits>
 
+#include "rasterize_dev.h"
+
 namespace {
-
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
-constexpr float ALPHA_MIN = 1.f / 255.f;
-constexpr float LOG2_255 = 7.994353436858858f;
-constexpr int HEAVY_TILE = 1024; // list length from which a wave raises its priority
-// cost classes of the backward's work items: a segment of `seg` entries costs at most 4 * seg record evaluations
-constexpr int COST_CLASSES = 32;
-GS_DEV uint32_t cost_class(uint32_t c, int32_t seg) { return min(c * 8u / (uint32_t)seg, (uint32_t)COST_CLASSES - 1u); }
-
-struct SplatRaw {
-    int32_t g;
-    float mx, my, ca, cb, cc, opac;
-};
-
-// One splat of the sorted list.  Row form (a.row16, include/gsplat_hip.h "splat rows"): the whole splat is ONE 64-byte line,
-// fetched with two (three with the colours) 16-byte loads; otherwise the reference's four arrays through their row strides.
-template <int CDIM>
-GS_DEV void fetch_splat(const RasterArgs &a, int32_t g, SplatRaw &s, float *col) {
-    s.g = g;
-    if (a.row16) {
-        const float4 *r = reinterpret_cast<const float4 *>(a.means2d + (size_t)g * 16u);
-        const float4 r0 = r[0], r1 = r[1];
-        s.mx = r0.x; s.my = r0.y; s.ca = r0.z; s.cb = r0.w;
-        s.cc = r1.x; s.opac = r1.y;
-        if (CDIM > 0) col[0] = r1.z;
-        if (CDIM > 1) col[CDIM > 1 ? 1 : 0] = r1.w;
-        if (CDIM == 3) col[CDIM > 2 ? 2 : 0] = reinterpret_cast<const float *>(r + 2)[0];
-        if (CDIM > 3) {
-            const float2 v = reinterpret_cast<const float2 *>(r + 2)[0];
-            col[CDIM > 2 ? 2 : 0] = v.x;
-            col[CDIM > 3 ? 3 : 0] = v.y;
-        }
-    } else {
-        const float2 xy = *reinterpret_cast<const float2 *>(a.means2d + (size_t)g * a.s_xy);
-        const float *cn = a.conics + (size_t)g * a.s_conic;
-        s.mx = xy.x; s.my = xy.y;
-        s.ca = cn[0]; s.cb = cn[1]; s.cc = cn[2];
-        s.opac = a.opacities[(size_t)g * a.s_opac];
-#pragma unroll
-        for (int k = 0; k < CDIM; ++k) col[k] = a.colors[(size_t)g * a.s_color + k];
-    }
-}
-
-GS_DEV SplatRaw gather_splat(const RasterArgs &a, int32_t idx, bool in_range) {
-    SplatRaw s;
-    s.g = 0;
-    s.mx = s.my = s.ca = s.cb = s.cc = 0.f;
-    s.opac = 0.f;
-    if (in_range) {
-        float none[1];
-        fetch_splat<0>(a, a.flatten_ids[idx], s, none);
-    }
-    return s;
-}
-
-// Exact culling of a splat against a rectangle of pixel centres: the splat can reach
-// alpha >= 1/255 somewhere in the rectangle iff min over the rectangle of
-// sigma(d) = a/2 dx^2 + b dx dy + c/2 dy^2 is <= ln(255 o).  sigma is convex, so its minimum
-// over the box is at the centre (inside: 0) or on one of the (at most two) edges FACING the
-// centre -- from the true minimiser the segment towards the centre must leave the box at once --
-// and along an edge it is a clamped 1-D parabola.  About 25 VALU per (splat, rectangle), evaluated
-// once by the staging lane; the 3-sigma bounding boxes of the tile lists pass ~4x more
-// (splat, quadrant) pairs than this test and the axis-aligned extent test ~1.35x more (measured).
-struct CullSplat {
-    float ha, hc, nbc, nba, t; // a/2, c/2, -b/c, -b/a, threshold with safety margin
-    bool pd;                   // positive-definite conic (otherwise: never cull)
-};
-
-// false when the splat cannot contribute anywhere (opacity below 1/255, zero, negative or NaN)
-GS_DEV bool cull_prepare(const SplatRaw &s, CullSplat &c) {
-    c.ha = 0.5f * s.ca;
-    c.hc = 0.5f * s.cc;
-    c.nbc = c.nba = 0.f;
-    c.t = 0.f;
-    c.pd = false;
-    if (!(s.opac > 0.f)) return false;
-    float t = (__log2f(s.opac) + LOG2_255) * LN2; // ln(255 o): alpha >= 1/255 <=> sigma <= t
-    if (!(t > -1e-3f)) return false;
-    c.t = t * 1.001f + 2e-3f;
-    const float det = s.ca * s.cc - s.cb * s.cb;
-    c.pd = det > 0.f && s.ca > 0.f && s.cc > 0.f;
-    if (c.pd) {
-        c.nbc = -s.cb * __builtin_amdgcn_rcpf(s.cc);
-        c.nba = -s.cb * __builtin_amdgcn_rcpf(s.ca);
-    }
-    return true;
-}
-
-GS_DEV bool rect_touch(const SplatRaw &s, const CullSplat &c, float x0, float x1, float y0, float y1) {
-    const float X0 = x0 - s.mx, X1 = x1 - s.mx, Y0 = y0 - s.my, Y1 = y1 - s.my;
-    const float xe = __builtin_amdgcn_fmed3f(0.f, X0, X1), ye = __builtin_amdgcn_fmed3f(0.f, Y0, Y1); // nearest point
-    const float dyA = __builtin_amdgcn_fmed3f(c.nbc * xe, Y0, Y1); // best point of the line x = xe
-    const float sA = xe * (c.ha * xe + s.cb * dyA) + c.hc * dyA * dyA;
-    const float dxB = __builtin_amdgcn_fmed3f(c.nba * ye, X0, X1); // best point of the line y = ye
-    const float sB = dxB * (c.ha * dxB + s.cb * ye) + c.hc * ye * ye;
-    // margin: the products above cancel for strongly elongated splats; scale the slack with them
-    const float slack = 1e-5f * (fabsf(c.ha * xe * xe) + fabsf(c.hc * ye * ye));
-    return !c.pd || (fminf(sA, sB) <= c.t + slack);
-}
-
-// XCD-aware work-item remap (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroup b runs on
-// XCD b % 8).  Consecutive virtual items (neighbouring tiles, which share most of their splats)
-// are given to the SAME XCD, so their gathers hit that XCD's L2 instead of re-fetching the
-// splat from the fabric on all 8.  Bijective for any M.  Placement only affects speed.
-// `group` > 0: XCD x owns every 8th group of `group` consecutive virtual items (locality inside a
-// group, load spread over the whole image: the heavy tiles are spatially clustered, so giving one
-// XCD a contiguous 1/8 of the image costs more in imbalance than it saves in traffic -- measured).
-GS_DEV uint32_t xcd_remap(uint32_t b, uint32_t M, uint32_t group) {
-    group &= 0x7fffffffu;
-    if (group == 0u) return b;
-    const uint32_t full = (M / (8u * group)) * (8u * group); // items covered by complete rounds
-    if (b >= full) return b;                                  // ragged tail: identity
-    const uint32_t x = b & 7u, i = b >> 3;                    // i-th item of XCD x
-    return ((i / group) * 8u + x) * group + (i % group);
-}
-
-// Bounding rectangle (pixel centres) of the lanes set in `m` inside an 8x8 quadrant whose first pixel centre is
-// (X0, Y0); lane = ly * 8 + lx.  Wave-uniform (scalar bit operations).  m != 0.
-struct LiveRect {
-    float x0, x1, y0, y1;
-};
-GS_DEV LiveRect live_rect(unsigned long long m, float X0, float Y0) {
-    const uint32_t ylo = (uint32_t)__builtin_ctzll(m) >> 3, yhi = (63u - (uint32_t)__builtin_clzll(m)) >> 3;
-    uint32_t c = (uint32_t)m | (uint32_t)(m >> 32);
-    c |= c >> 16;
-    c |= c >> 8;
-    c &= 0xffu; // columns in use
-    const uint32_t xlo = (uint32_t)__builtin_ctz(c), xhi = 31u - (uint32_t)__builtin_clz(c);
-    LiveRect r;
-    r.x0 = X0 + (float)xlo;
-    r.x1 = X0 + (float)xhi;
-    r.y0 = Y0 + (float)ylo;
-    r.y1 = Y0 + (float)yhi;
-    return r;
-}
-
-struct TileGeom {
-    uint32_t lin, cam, tile_id;
-    int32_t range_start, range_end;
-    uint32_t px0, py0;
-};
-
-GS_DEV TileGeom tile_geom(const RasterArgs &a, uint32_t slot) {
-    TileGeom g;
-    const uint32_t tiles = a.tile_width * a.tile_height;
-    g.lin = slot;
-    g.cam = g.lin / tiles;
-    g.tile_id = g.lin % tiles;
-    g.range_start = a.tile_offsets[g.lin];
-    g.range_end = (g.lin + 1 == a.C * tiles) ? (int32_t)a.n_isects : a.tile_offsets[g.lin + 1];
-    g.px0 = (g.tile_id % a.tile_width) * a.tile_size;
-    g.py0 = (g.tile_id / a.tile_width) * a.tile_size;
-    return g;
-}
-
-// Pixel rectangle (centres) covered by this wave: the tile (NQ == 4) or one quadrant,
-// clipped to the tile size and the image.  Wave-uniform.
-struct Rect {
-    float x0, x1, y0, y1;
-    bool empty;
-};
-
-template <int NQ>
-GS_DEV Rect wave_rect(const RasterArgs &a, const TileGeom &tg, uint32_t q_first) {
-    uint32_t ox0 = (NQ == 4) ? 0u : 8u * (q_first & 1u), oy0 = (NQ == 4) ? 0u : 8u * (q_first >> 1);
-    uint32_t ox1 = (NQ == 4) ? 16u : ox0 + 8u, oy1 = (NQ == 4) ? 16u : oy0 + 8u;
-    ox1 = min(ox1, a.tile_size);
-    oy1 = min(oy1, a.tile_size);
-    uint32_t X0 = tg.px0 + ox0, Y0 = tg.py0 + oy0;
-    uint32_t X1 = min(tg.px0 + ox1, a.image_width), Y1 = min(tg.py0 + oy1, a.image_height);
-    Rect r;
-    r.empty = (ox0 >= ox1) || (oy0 >= oy1) || X0 >= X1 || Y0 >= Y1;
-    r.x0 = (float)X0 + 0.5f;
-    r.y0 = (float)Y0 + 0.5f;
-    r.x1 = (float)X1 - 0.5f;
-    r.y1 = (float)Y1 - 0.5f;
-    return r;
-}
 
 // ---------------------------------------------------------------------------
 // forward
@@ -460,13 +283,21 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
 // Sub-batches are aligned to multiples of 64 of the GLOBAL list index, so a checkpoint boundary
 // (multiple of seg) always coincides with a sub-batch start.
 // ---------------------------------------------------------------------------
+// WIDE (5 <= CDIM <= 16, round 5): the same kernel for feature rendering -- the record grows by the colours
+// (REC = 2 + ceil((CDIM - 2) / 4) float4: 64 B at 9 channels, 96 B at 16), the walk takes two records per iteration instead of
+// four (the colour FMAs are independent work already, and four records of 6 float4 would not fit the registers), the launch
+// covers channels [ch_off, ch_off + cnt) of a.channels (cnt <= CDIM; 17..32 channels = two launches over halves: render_alphas /
+// last_ids / costs / the T plane of the checkpoints are written by the first), checkpoints are [k][1 + a.channels][256].
 template <int CDIM, bool CKPT>
 __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, float *__restrict__ ckpt, int32_t seg, int32_t solo_min,
                                                               uint32_t *__restrict__ cost_head, uint32_t *__restrict__ cost_body,
                                                               uint32_t *__restrict__ body_tile, uint32_t *__restrict__ class_count,
-                                                              ZeroFill zf) {
-    constexpr int REC = 3;
+                                                              ZeroFill zf, uint32_t ch_off, uint32_t cnt) {
+    constexpr bool WIDE = CDIM > 4;
+    constexpr int NCW = WIDE ? (CDIM - 2 + 3) / 4 : 0; // float4s of colours 2.. behind R0, R1
+    constexpr int REC = WIDE ? 2 + NCW : 3;
     constexpr int BATCH = 256;
+    static_assert((2 * BATCH * REC + REC) * 16 < 65536, "record offsets are 16-bit");
     // records of both buffers in ONE array + a null record (alpha = 0) that pads every list to a multiple of four
     __shared__ float4 s_rec[2 * BATCH * REC + REC];
     constexpr uint32_t NULL_REC_OFF = 2u * BATCH * REC * 16u; // byte offset of the null record
@@ -482,7 +313,8 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
     // the class counters of the backward's work list (seg_items_build_kernel runs after this kernel, in the same call)
     if (CKPT && blockIdx.x == 0 && tid < (uint32_t)COST_CLASSES) class_count[tid] = 0u;
     const TileGeom tg = tile_geom(a, a.tile_order != nullptr ? a.tile_order[blockIdx.x] : xcd_remap(blockIdx.x, gridDim.x, a.xcd_group));
-    const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels : nullptr;
+    const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels + (WIDE ? ch_off : 0u) : nullptr;
+    const uint32_t CH = WIDE ? a.channels : (uint32_t)CDIM; // channels of the output image / checkpoint planes
 
     const uint32_t ox = lx + 8u * (w & 1u), oy = ly + 8u * (w >> 1);
     const uint32_t x = tg.px0 + ox, y = tg.py0 + oy;
@@ -507,7 +339,8 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
     if (a.masks != nullptr && !a.masks[tg.lin]) {
         if (inside) {
 #pragma unroll
-            for (int k = 0; k < CDIM; ++k) a.render_colors[pix * CDIM + k] = bg ? bg[k] : 0.f;
+            for (int k = 0; k < CDIM; ++k)
+                if (!WIDE || (uint32_t)k < cnt) a.render_colors[pix * CH + (WIDE ? ch_off : 0u) + k] = bg ? bg[k] : 0.f;
         }
         zero_fill_slice();
         return;
@@ -546,7 +379,20 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
         o.s.mx = o.s.my = o.s.ca = o.s.cb = o.s.cc = o.s.opac = 0.f;
 #pragma unroll
         for (int k = 0; k < CDIM; ++k) o.col[k] = 0.f;
-        if (g >= 0) fetch_splat<CDIM>(a, g, o.s, o.col);
+        if (g >= 0) {
+            if constexpr (WIDE) fetch_splat_wide<CDIM>(a, g, o.s, o.col, ch_off, cnt);
+            else fetch_splat<CDIM>(a, g, o.s, o.col);
+        }
+    };
+    // the record of one staged entry (R0, R1 and the colour float4s behind them)
+    auto write_rec = [&](float4 *r, const Staged &st) {
+        r[0] = make_float4(st.s.mx, st.s.my, -0.5f * LOG2E * st.s.ca, -LOG2E * st.s.cb);
+        r[1] = make_float4(-0.5f * LOG2E * st.s.cc, __log2f(st.s.opac), st.col[0], st.col[CDIM > 1 ? 1 : 0]);
+#pragma unroll
+        for (int j = 0; j < NCW; ++j) {
+            auto c = [&](int k) { return k < CDIM ? st.col[k < CDIM ? k : 0] : 0.f; };
+            r[2 + j] = make_float4(c(2 + 4 * j), c(3 + 4 * j), c(4 + 4 * j), c(5 + 4 * j));
+        }
     };
     int32_t id_cur = load_id(base0 + (int32_t)tid);
     int32_t id_nxt = load_id(base0 + BATCH + (int32_t)tid);
@@ -574,16 +420,20 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
         first_seg = false;
     };
     auto store_ckpt = [&]() {
-        float *base = ckpt + (size_t)next_k * (CDIM + 1) * 256;
+        float *base = ckpt + (size_t)next_k * (CH + 1) * 256;
         const uint32_t p = w * 64u + lane;
-        base[p] = T;
+        if (!WIDE || ch_off == 0u) base[p] = T;
 #pragma unroll
-        for (int k = 0; k < CDIM; ++k) base[(k + 1) * 256 + p] = out[k];
+        for (int k = 0; k < CDIM; ++k)
+            if (!WIDE || (uint32_t)k < cnt) base[((WIDE ? ch_off : 0u) + k + 1) * 256 + p] = out[k];
         store_cost();
     };
 
     // ---- the record walk of one (sub-batch, quadrant) list, shared by the cooperative and the solo path
-    constexpr int GW = 4; // records per iteration of the bulk loop
+#ifndef GS_WIDE_GW9
+#define GS_WIDE_GW9 2
+#endif
+    constexpr int GW = WIDE ? (CDIM <= 9 ? GS_WIDE_GW9 : 2) : 4; // records per iteration of the bulk loop
     struct alignas(sizeof(list_t) * GW) Pack { list_t v[GW]; };
     // G records in one basic block (G = 4: the bulk of a list; G = 1: its last 1-3 records -- the lists used to be walked as
     // whole groups of four with their null-record padding, ~1.5 wasted evaluations per (sub-batch, quadrant) list = 9 % of
@@ -592,6 +442,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
         constexpr int G = decltype(gtag)::value;
                 float4 c0[G], c1[G];
                 float c2x[G], c2y[G]; // colours 2, 3 (only what CDIM needs is read)
+                float4 cw[G][WIDE ? NCW : 1]; // WIDE: colours 2 .. CDIM - 1
                 uint32_t off[G];
                 {
 #pragma unroll
@@ -602,8 +453,12 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
                         c0[g] = r[0];
                         c1[g] = r[1];
                         c2x[g] = c2y[g] = 0.f;
+                        if constexpr (WIDE) {
+#pragma unroll
+                            for (int j = 0; j < NCW; ++j) cw[g][j] = r[2 + j];
+                        }
                         if (CDIM == 3) c2x[g] = reinterpret_cast<const float *>(r + 2)[0];
-                        if (CDIM > 3) {
+                        if (CDIM == 4) {
                             const float2 v = reinterpret_cast<const float2 *>(r + 2)[0];
                             c2x[g] = v.x;
                             c2y[g] = v.y;
@@ -641,8 +496,17 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
                     const float vis = a_use * Tj;
                     out[0] += c1[g].z * vis;
                     if (CDIM > 1) out[CDIM > 1 ? 1 : 0] += c1[g].w * vis;
+                    if constexpr (WIDE) {
+#pragma unroll
+                        for (int k = 2; k < CDIM; ++k) {
+                            const float4 v = cw[g][(k - 2) / 4];
+                            const int e = (k - 2) % 4;
+                            out[k] += (e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w) * vis;
+                        }
+                    } else {
                     if (CDIM > 2) out[CDIM > 2 ? 2 : 0] += c2x[g] * vis;
                     if (CDIM > 3) out[CDIM > 3 ? 3 : 0] += c2y[g] * vis;
+                    }
                     cur_off = use ? off[g] : cur_off;
                     T = __builtin_fmaf(-Tj, a_use, Tj);
                 }
@@ -701,14 +565,17 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
                 }
                 m = __ballot(touch);
                 if (touch) {
+                    float4 *r = &s_rec[slot * REC];
+                    if constexpr (WIDE) write_rec(r, st);
+                    else {
                     float c0 = st.col[0], c1 = 0.f, c2 = 0.f, c3 = 0.f;
                     if (CDIM > 1) c1 = st.col[CDIM > 1 ? 1 : 0];
                     if (CDIM > 2) c2 = st.col[CDIM > 2 ? 2 : 0];
                     if (CDIM > 3) c3 = st.col[CDIM > 3 ? 3 : 0];
-                    float4 *r = &s_rec[slot * REC];
                     r[0] = make_float4(st.s.mx, st.s.my, -0.5f * LOG2E * st.s.ca, -LOG2E * st.s.cb);
                     r[1] = make_float4(-0.5f * LOG2E * st.s.cc, __log2f(st.s.opac), c0, c1);
                     if (CDIM > 2) r[2] = make_float4(c2, c3, 0.f, 0.f);
+                    }
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                     s_list[buf][w][w][below] = (list_t)(slot * REC * 16u);
                 }
@@ -728,7 +595,8 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
             uint32_t cur_off = 0xffffffffu;
             if (CKPT) evals += (uint32_t)__popcll(m);
             walk(&s_list[buf][w][w][0], (uint32_t)__popcll(m), cur_off);
-            if (cur_off != 0xffffffffu) cur = sb_start + (int32_t)(((((cur_off >> 4) * 43691u) >> 17)) & 63u);
+            if (cur_off != 0xffffffffu)
+                cur = sb_start + (int32_t)((WIDE ? (cur_off >> 4) / (uint32_t)REC : (((cur_off >> 4) * 43691u) >> 17)) & 63u);
             if (__all(done)) break;
         }
     } else
@@ -752,14 +620,17 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
                 m[q] = __ballot(touch);
             }
             if (any_touch) {
+                float4 *r = &s_rec[(buf * BATCH + tid) * REC];
+                if constexpr (WIDE) write_rec(r, st);
+                else {
                 float c0 = st.col[0], c1 = 0.f, c2 = 0.f, c3 = 0.f;
                 if (CDIM > 1) c1 = st.col[CDIM > 1 ? 1 : 0];
                 if (CDIM > 2) c2 = st.col[CDIM > 2 ? 2 : 0];
                 if (CDIM > 3) c3 = st.col[CDIM > 3 ? 3 : 0];
-                float4 *r = &s_rec[(buf * BATCH + tid) * REC];
                 r[0] = make_float4(st.s.mx, st.s.my, -0.5f * LOG2E * st.s.ca, -LOG2E * st.s.cb);
                 r[1] = make_float4(-0.5f * LOG2E * st.s.cc, __log2f(st.s.opac), c0, c1);
                 if (CDIM > 2) r[2] = make_float4(c2, c3, 0.f, 0.f);
+                }
             }
             {
                 // compacted lists: a lone wave issues one instruction per ~5 cycles WHATEVER its kind, so the consumer
@@ -811,7 +682,8 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
             if (__all(done)) break;
         }
         if (cur_off != 0xffffffffu) // offset -> list index: (offset / 16 - buffer base) / 3, exact for these small multiples of 3
-            cur = batch_start + (int32_t)((((cur_off >> 4) - buf * (uint32_t)(BATCH * REC)) * 43691u) >> 17);
+            cur = batch_start + (int32_t)(WIDE ? ((cur_off >> 4) - buf * (uint32_t)(BATCH * REC)) / (uint32_t)REC
+                                               : ((((cur_off >> 4) - buf * (uint32_t)(BATCH * REC)) * 43691u) >> 17));
     }
 
     if (CKPT && n > 0) {
@@ -825,10 +697,11 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
     }
     if (inside) {
         const float Tf = T;
-        a.render_alphas[pix] = 1.f - Tf;
+        if (!WIDE || ch_off == 0u) a.render_alphas[pix] = 1.f - Tf;
 #pragma unroll
-        for (int k = 0; k < CDIM; ++k) a.render_colors[pix * CDIM + k] = bg ? out[k] + Tf * bg[k] : out[k];
-        a.last_ids[pix] = cur;
+        for (int k = 0; k < CDIM; ++k)
+            if (!WIDE || (uint32_t)k < cnt) a.render_colors[pix * CH + (WIDE ? ch_off : 0u) + k] = bg ? out[k] + Tf * bg[k] : out[k];
+        if (!WIDE || ch_off == 0u) a.last_ids[pix] = cur;
     }
     zero_fill_slice();
 }
@@ -895,12 +768,12 @@ __global__ void __launch_bounds__(ORDER_THREADS) tile_order_kernel(uint32_t n_ti
 
 template <int CDIM>
 void launch_tile_fwd(const RasterArgs &a, float *ckpt, int32_t seg, int32_t solo_min, uint32_t *cost_head, uint32_t *cost_body,
-                     uint32_t *body_tile, uint32_t *class_count, ZeroFill zf, hipStream_t st) {
+                     uint32_t *body_tile, uint32_t *class_count, ZeroFill zf, hipStream_t st, uint32_t ch_off = 0u, uint32_t cnt = (uint32_t)CDIM) {
     dim3 grid(a.C * a.tile_width * a.tile_height);
     if (ckpt != nullptr)
-        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true>), grid, dim3(256), 0, st, a, ckpt, seg, solo_min, cost_head, cost_body, body_tile, class_count, zf);
+        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, true>), grid, dim3(256), 0, st, a, ckpt, seg, solo_min, cost_head, cost_body, body_tile, class_count, zf, ch_off, cnt);
     else
-        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, false>), grid, dim3(256), 0, st, a, ckpt, seg, solo_min, cost_head, cost_body, body_tile, class_count, zf);
+        hipLaunchKernelGGL((raster_tile_fwd_kernel<CDIM, false>), grid, dim3(256), 0, st, a, ckpt, seg, solo_min, cost_head, cost_body, body_tile, class_count, zf, ch_off, cnt);
 }
 
 // ---------------------------------------------------------------------------
@@ -913,14 +786,6 @@ void launch_tile_fwd(const RasterArgs &a, float *ckpt, int32_t seg, int32_t solo
 // SEG: blockIdx.x indexes a work item (tile, k): the list entries [k*seg, (k+1)*seg) of that
 // tile.  The state at the item's far end comes from the forward's checkpoint k+1
 // (T, accumulated colour) and the final render: B = v_out . (colour_final - colour_ckpt).
-struct SegArgs {
-    const uint2 *items;          // [COST_CLASSES][max_items] (tile, k), one region per cost class
-    const uint32_t *class_count; // [COST_CLASSES] items per class
-    uint32_t max_items;          // region length
-    const float *ckpt;           // [k][CDIM+1][256]
-    const float *render_colors;
-    int32_t seg;
-};
 
 template <int NQ, int CDIM, int CMODE, bool ABS>
 __global__ void __launch_bounds__(GS_WAVE) raster_wave_bwd_kernel(RasterArgs a, RasterGradArgs ga, uint32_t cnt, uint32_t ch_off, int use_v_alpha) {
@@ -1599,6 +1464,10 @@ struct ScratchLayout {
     uint32_t max_items, n_bounds;
 };
 
+// channel counts the tile forward / segmented backward cover: 1..4 in one launch, 5..16 in one launch of the wide instances,
+// 17..32 as two launches over halves (rasterize_wide.hip)
+constexpr uint32_t FAST_MAX_CHANNELS = 32;
+
 ScratchLayout scratch_layout(uint32_t n_tiles_all, uint32_t n_isects, uint32_t channels, int32_t seg) {
     ScratchLayout L;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -1606,17 +1475,17 @@ ScratchLayout scratch_layout(uint32_t n_tiles_all, uint32_t n_isects, uint32_t c
     L.n_bounds = (seg > 0 ? n_isects / (uint32_t)seg : 0) + 2; // list boundaries k * seg, k < n_bounds
     L.max_items = n_tiles_all + L.n_bounds;
     L.off_items = o;
-    if (seg > 0 && channels <= 4) o += up((size_t)COST_CLASSES * L.max_items * sizeof(uint2));
+    if (seg > 0 && channels <= FAST_MAX_CHANNELS) o += up((size_t)COST_CLASSES * L.max_items * sizeof(uint2));
     L.off_cost_head = o; // per (tile, quadrant wave): cost of the tile's first backward segment
     o += up((size_t)n_tiles_all * 4 * sizeof(uint32_t));
     L.off_cost_body = o; // per (segment boundary, quadrant wave): cost of the later segments
-    if (seg > 0 && channels <= 4) o += up((size_t)L.n_bounds * 4 * sizeof(uint32_t));
+    if (seg > 0 && channels <= FAST_MAX_CHANNELS) o += up((size_t)L.n_bounds * 4 * sizeof(uint32_t));
     L.off_body_tile = o; // per segment boundary: the tile that owns it
-    if (seg > 0 && channels <= 4) o += up((size_t)L.n_bounds * sizeof(uint32_t));
+    if (seg > 0 && channels <= FAST_MAX_CHANNELS) o += up((size_t)L.n_bounds * sizeof(uint32_t));
     L.off_ckpt = o;
-    if (seg > 0 && channels <= 4) o += up(((size_t)n_isects / seg + 2) * (channels + 1) * 256 * sizeof(float));
+    if (seg > 0 && channels <= FAST_MAX_CHANNELS) o += up(((size_t)n_isects / seg + 2) * (channels + 1) * 256 * sizeof(float));
     L.off_order = o; // the forward's tile order, heaviest lists first (tile_order_kernel)
-    if (channels <= 4) o += up((size_t)n_tiles_all * sizeof(uint32_t));
+    if (channels <= FAST_MAX_CHANNELS) o += up((size_t)n_tiles_all * sizeof(uint32_t));
     L.total = o;
     return L;
 }
@@ -1635,8 +1504,9 @@ int32_t raster_make_plan(uint32_t n_tiles_all, uint32_t n_isects, uint32_t chann
         if (tuning[3] >= 0) xb = tuning[3];
         if (tuning[4] >= 0) order = tuning[4] != 0;
     }
-    // the segment length is doubled until the checkpoint array stays below 65536 boundaries (256 MB for RGB)
-    while (seg > 0 && (uint64_t)n_isects / (uint32_t)seg > 65536u) seg *= 2;
+    // the segment length is doubled until the checkpoint array stays below 65536 boundaries (256 MB for RGB; the same
+    // byte bound for more planes: 5..32 channels)
+    while (seg > 0 && (uint64_t)n_isects / (uint32_t)seg * (channels > 4u ? channels + 1u : 4u) > 65536u * 4u) seg *= 2;
     plan->magic = PLAN_MAGIC;
     plan->n_tiles_all = n_tiles_all;
     plan->n_isects = n_isects;
@@ -1667,7 +1537,7 @@ int32_t raster_wave_fwd(const RasterArgs &a_in, const gs_raster_plan *plan, void
     }
     const gs_raster_plan &P = plan ? *plan : dflt;
     const int32_t seg = P.seg;
-    const bool ckpt_on = a.channels <= 4 && seg > 0 && scratch != nullptr;
+    const bool ckpt_on = a.channels <= FAST_MAX_CHANNELS && seg > 0 && scratch != nullptr;
     // the side job: spread over the tile workgroups when each gets at most 256 KB of it, a plain fill otherwise
     ZeroFill zf = {nullptr, 0, 0u};
     if (zero_fill != nullptr && zero_fill_bytes > 0) {
@@ -1704,7 +1574,36 @@ int32_t raster_wave_fwd(const RasterArgs &a_in, const gs_raster_plan *plan, void
                                a.tile_offsets, a.masks, seg, L.n_bounds, ch, cb, bt, cc, (uint2 *)((char *)scratch + L.off_items), L.max_items);
         return 0;
     }
-    // more than 4 channels: one quadrant per wave, exact chunks of 32 channels
+    if (a.channels <= FAST_MAX_CHANNELS && plan != nullptr) {
+        // 5..32 channels (round 5): the tile kernel with the colours in the LDS record; 17..32 as two launches over halves
+        const ScratchLayout L = scratch_layout(P);
+        float *ckpt = ckpt_on ? (float *)((char *)scratch + L.off_ckpt) : nullptr;
+        a.xcd_group = P.xcd_fwd;
+        a.tile_order = nullptr;
+        if (scratch != nullptr && P.reserved[0] != 0u && n_tiles_all > 0) {
+            uint32_t *order = (uint32_t *)((char *)scratch + L.off_order);
+            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, st, n_tiles_all, a.tile_offsets, a.n_isects, order);
+            a.tile_order = order;
+        }
+        uint32_t *ch = ckpt ? (uint32_t *)((char *)scratch + L.off_cost_head) : nullptr;
+        uint32_t *cb = ckpt ? (uint32_t *)((char *)scratch + L.off_cost_body) : nullptr;
+        uint32_t *bt = ckpt ? (uint32_t *)((char *)scratch + L.off_body_tile) : nullptr;
+        uint32_t *cc = ckpt ? (uint32_t *)scratch : nullptr;
+        const uint32_t n_chunks = a.channels > 16u ? 2u : 1u, first = (a.channels + n_chunks - 1u) / n_chunks;
+        for (uint32_t off = 0; off < a.channels; off += first) {
+            const uint32_t cnt = min(first, a.channels - off);
+            const ZeroFill z = off == 0u ? zf : ZeroFill{nullptr, 0, 0u};
+            if (cnt <= 8u) launch_tile_fwd<8>(a, ckpt, seg, P.solo_min, ch, cb, bt, cc, z, st, off, cnt);
+            else if (cnt == 9u) launch_tile_fwd<9>(a, ckpt, seg, P.solo_min, ch, cb, bt, cc, z, st, off, cnt);
+            else if (cnt <= 12u) launch_tile_fwd<12>(a, ckpt, seg, P.solo_min, ch, cb, bt, cc, z, st, off, cnt);
+            else launch_tile_fwd<16>(a, ckpt, seg, P.solo_min, ch, cb, bt, cc, z, st, off, cnt);
+        }
+        if (ckpt != nullptr)
+            hipLaunchKernelGGL(seg_items_build_kernel, dim3(gs_div_up(L.max_items, GS_BLOCK)), dim3(GS_BLOCK), 0, st, n_tiles_all, a.n_isects,
+                               a.tile_offsets, a.masks, seg, L.n_bounds, ch, cb, bt, cc, (uint2 *)((char *)scratch + L.off_items), L.max_items);
+        return 0;
+    }
+    // (no plan, or more than 32 channels) one quadrant per wave, exact chunks of 32 channels
     a.xcd_group = P.xcd_fwd * 4u;
     for (uint32_t off = 0; off < a.channels; off += 32) {
         uint32_t cnt = min(32u, a.channels - off);
@@ -1745,7 +1644,18 @@ int32_t raster_wave_bwd(const RasterArgs &a_in, const RasterGradArgs &ga, const 
             hipLaunchKernelGGL(raster_det_finalize_kernel, dim3(gs_div_up(a.n_elems, GS_BLOCK)), dim3(GS_BLOCK), 0, st, a.n_elems, c, ga.det, ga);
         return 0;
     }
-    // no checkpoints (forward ran without scratch, or segments are switched off) or more than 4 channels:
+    // 5..32 channels: the wide segmented kernel (rasterize_wide.hip); absgrad is not linear in the image gradient, so with it
+    // only what fits ONE launch (<= 16 channels) goes this way
+    if (seg > 0 && c > 4 && c <= FAST_MAX_CHANNELS && scratch != nullptr && render_colors != nullptr && ga.det == nullptr &&
+        (c <= 16 || ga.v_means2d_abs == nullptr)) {
+        const ScratchLayout L = scratch_layout(P);
+        const uint32_t n_chunks = c > 16u ? 2u : 1u, first = (c + n_chunks - 1u) / n_chunks;
+        for (uint32_t off = 0; off < c; off += first)
+            raster_seg_bwd_wide(a, ga, L.max_items, (use_va && off == 0u) ? 1 : 0, (const char *)scratch + L.off_items, (const uint32_t *)scratch,
+                                (const float *)((char *)scratch + L.off_ckpt), render_colors, seg, off, min(first, c - off), st);
+        return 0;
+    }
+    // no checkpoints (forward ran without scratch, or segments are switched off) or more than 32 channels:
     // one quadrant per wave walking the whole list back to front
     a.xcd_group = P.xcd_bwd * 4u;
     if (c <= 4) {

@@ -99,3 +99,7 @@ int32_t raster_wave_fwd(const RasterArgs &a, const gs_raster_plan *plan, void *s
                         hipStream_t st);
 int32_t raster_wave_bwd(const RasterArgs &a, const RasterGradArgs &ga, const float *render_colors, const gs_raster_plan *plan,
                         void *scratch, hipStream_t st);
+// rasterize_wide.hip: one launch of the segmented backward over channels [ch_off, ch_off + cnt), 5 <= cnt <= 16
+void raster_seg_bwd_wide(const RasterArgs &a, const RasterGradArgs &ga, uint32_t max_items, int use_va, const void *items,
+                         const uint32_t *class_count, const float *ckpt, const float *render_colors, int32_t seg, uint32_t ch_off,
+                         uint32_t cnt, hipStream_t st);

@@ -520,6 +520,9 @@ int32_t gs_isect_offset_encode(
  * channels is a runtime value (1..513); no padding is required from the caller.
  * n_elems = C*N (unpacked) or nnz (packed): size of the per-splat arrays.
  * bwd outputs are ACCUMULATED with atomics: caller zero-fills them.
+ * Channel counts: 1..4 and 5..16 run as one launch each way (tile forward + depth-segmented backward, colours in the LDS
+ * records), 17..32 as two launches over halves of the channels (the gradients are linear in v_render_colors; with absgrad,
+ * which is not, the backward of more than 16 channels takes the generic one-pass kernel), more than 32 the generic kernels.
  * scratch (optional, gs_raster_plan.scratch_bytes bytes): the forward stores per-pixel checkpoints (transmittance, accumulated colour) at fixed
  * list-index boundaries in it; when the SAME buffer (contents preserved) and the forward's
  * render_colors are handed to gs_rasterize_bwd, the backward runs depth-segmented (one wave per
@@ -552,7 +555,9 @@ int32_t gs_rasterize_fwd(
     const uint32_t *splat_strides, /* NULL: the reference's dense arrays (rows of 2 / 3 / channels / 1 floats); else 4 HOST
                                       ints: row strides in floats of means2d, conics, colors, opacities.  When all four
                                       are GS_ROW_FLOATS and the pointers are columns 0 / 2 / 6 / 5 of one 64-byte-aligned
-                                      row buffer (channels <= 4), the kernels fetch whole splat rows */
+                                      row buffer (channels <= 4), the kernels fetch whole splat rows; with more than 4
+                                      channels the same holds for the geometry alone (means2d / conics / opacities at
+                                      columns 0 / 2 / 5 with stride GS_ROW_FLOATS, colours in their own array) */
     const float *backgrounds, /* [C,channels] or NULL */
     const uint8_t *masks,     /* [C,tile_h,tile_w] or NULL */
     uint32_t image_width, uint32_t image_height, uint32_t tile_size,
@@ -590,7 +595,11 @@ int32_t gs_rasterize_bwd(
     int32_t packed16,     /* != 0: v_means2d is ONE zero-filled [n_elems,16] buffer receiving every gradient (the splat-row
                              columns, see above); v_conics / v_colors / v_opacities are ignored, v_means2d_abs only
                              selects absgrad (non-NULL).  One 64-byte row per splat lets the kernels add a whole splat's
-                             gradient with a single L2 request.  Requires channels <= 4. */
+                             gradient with a single L2 request.  1 requires channels <= 4.
+                             2 (more than 4 channels): the GEOMETRY rows only -- v_means2d is the zero-filled [n_elems,16]
+                             buffer (columns 0..5 and, with absgrad, 10 / 11), the colour gradients go to v_colors
+                             [n_elems,channels] (zero-filled by the caller): the form the 5..32-channel kernels want,
+                             and gs_projection_rows_bwd reads the rows in place */
     int64_t *det_accum,   /* NULL, or DETERMINISTIC mode (channels <= 4): a zero-filled int64 [n_elems,2,12] buffer.  The per-splat
                              sums are then accumulated in fixed point with integer atomics (the order in which the work
                              items reach a splat no longer matters; two accumulators per value: units of 2^-38 for

@@ -1,5 +1,5 @@
 """Randomised differential test of the compositing kernels against the CPU oracle: image sizes that are not multiples of
-the tile, tile sizes 4..16, 1..9 channels, 1..3 cameras, backgrounds / tile masks on and off, dense and sparse scenes,
+the tile, tile sizes 4..16, 1..32 channels, 1..3 cameras, backgrounds / tile masks on and off, dense and sparse scenes,
 saturating opacities (early termination) and depth ties -- configurations the hand-written cases do not enumerate."""
 import math
 import os
@@ -18,7 +18,7 @@ def _scene(rs):
     W, H = int(rs.randint(17, 260)), int(rs.randint(17, 200))
     ts = int(rs.choice([4, 8, 12, 16]))
     n = int(rs.choice([40, 300, 1500, 4000]))
-    D = int(rs.choice([1, 2, 3, 4, 5, 9]))
+    D = int(rs.choice([1, 2, 3, 4, 5, 9, 8, 12, 16, 17, 32]))  # (round 5: the wide instances and the two-halves route)
     means2d = (rs.rand(C, n, 2) * np.array([W + 30, H + 30]) - 15).astype(np.float32)
     # random PSD 2x2 covariances (pixels^2), conic = inverse
     s1 = np.exp(rs.uniform(np.log(0.6), np.log(rs.choice([6.0, 25.0])), size=(C, n)))

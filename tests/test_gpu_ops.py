@@ -364,9 +364,17 @@ def _raster_case(n=3000, scale_mult=6.0, cams=2, channels=3, seed=0, opac_boost=
     return dict(means2d=means2d, conics=conics, colors=colors, opacities=opac, W=W, H=H, offs=offs, flat=flat, C=C)
 
 
-@pytest.mark.parametrize("channels", [3, 1, 4, 7, 32, 40])
-def test_rasterize_fwd_bwd_vs_oracle(ops, channels):
-    c = _raster_case(n=2500 if channels > 8 else 4000, channels=channels, opac_boost=(channels == 3))
+_R4_CASES = {(3, True), (1, True), (4, True), (7, True), (32, True), (40, True)}
+
+
+# channels x absgrad: 1..4 the hot kernels; 5..16 the wide instances (8 / 9 / 12 / 16) in one launch; 17..32 two launches over
+# halves without absgrad, the generic one-pass backward with it; 40: generic (round 5: 5, 8, 9, 12, 16, 17, 24 added, 9 being the
+# reference's spacetime render, examples/simple_trainer_STG.py:531-551, and the no-absgrad halves of 32)
+@pytest.mark.parametrize("channels,absgrad", [(3, True), (1, True), (4, True), (7, True), (32, True), (40, True), (5, False), (8, True),
+                                              (9, False), (9, True), (12, False), (16, True), (16, False), (17, False), (24, False),
+                                              (32, False)])
+def test_rasterize_fwd_bwd_vs_oracle(ops, channels, absgrad):
+    c = _raster_case(n=2500 if channels > 8 else 4000, channels=channels, opac_boost=(channels in (3, 9, 32)))
     rs = np.random.RandomState(5)
     bg = rs.rand(c["C"], channels).astype(np.float32)
     o_rc, o_ra, o_li, bl = O.rasterize_fwd(c["means2d"], c["conics"], c["colors"], c["opacities"], c["W"], c["H"], 16,
@@ -374,8 +382,14 @@ def test_rasterize_fwd_bwd_vs_oracle(ops, channels):
     m2, cn, col, op = T(c["means2d"], True), T(c["conics"], True), T(c["colors"], True), T(c["opacities"], True)
     bg_t = T(bg, True)
     rc, ra = ops.rasterize_to_pixels(m2, cn, col, op, c["W"], c["H"], 16, T(c["offs"]), T(c["flat"]), backgrounds=bg_t,
-                                     absgrad=True)
+                                     absgrad=absgrad)
     ok = bl == 0  # pixels whose threshold decisions are not within a few ulp of flipping
+    r4 = (channels, absgrad) in _R4_CASES
+    if not r4:  # (round-5 cases: the float64 oracle is the gradient reference below; a pixel IT flags is borderline too)
+        with O.precision(64):
+            _, d_ra, d_li, bl64 = O.rasterize_fwd(c["means2d"], c["conics"], c["colors"], c["opacities"], c["W"], c["H"], 16,
+                                                  c["offs"], c["flat"], backgrounds=bg, return_borderline=True)
+        ok = ok & (bl64 == 0)
     assert ok.mean() > 0.995
     assert_close(N(rc)[ok], o_rc[ok], 1e-4, 2e-5, "render_colors", max_bad_frac=2e-5)
     assert_close(N(ra)[ok], o_ra[ok], 1e-4, 2e-5, "render_alphas", max_bad_frac=2e-5)
@@ -385,13 +399,16 @@ def test_rasterize_fwd_bwd_vs_oracle(ops, channels):
     loss = (rc * T(v_rc)).sum() + (ra * T(v_ra)).sum()
     g_m2, g_cn, g_col, g_op, g_bg = torch.autograd.grad(loss, (m2, cn, col, op, bg_t))
     # oracle backward from the oracle's own forward state
-    o = O.rasterize_bwd(c["means2d"], c["conics"], c["colors"], c["opacities"], c["W"], c["H"], 16, c["offs"],
-                        c["flat"], o_ra, o_li, v_rc, v_ra, backgrounds=bg, absgrad=True)
+    # (the cases added in round 5 take the FLOAT64 build of the oracle as their reference: one entry in 8000 of the fp32 oracle's
+    # own v_opacities sat 0.4 % off at 8 channels -- its error bar, not the kernels': HIP 2.8e-5, oracle 2.3e-4 in max norm)
+    with O.precision(32 if r4 else 64):
+        o = O.rasterize_bwd(c["means2d"], c["conics"], c["colors"], c["opacities"], c["W"], c["H"], 16, c["offs"],
+                            c["flat"], o_ra if r4 else d_ra, o_li if r4 else d_li, v_rc, v_ra, backgrounds=bg, absgrad=True)
     # Tolerances here are those of the fp32 ORACLE, not of the kernels: against a float64 ground truth the oracle's own
     # gradients are 4e-5 ... 2e-4 off (rel. L2) and the HIP kernels 2e-6 ... 3e-5 (tests/test_gpu_parity_f64.py, which
     # carries the 1e-4 assertions); this test pins decisions, plumbing, channel counts and absgrad.
     for name, got, ref in (("v_means2d", g_m2, o[0]), ("v_conics", g_cn, o[1]), ("v_colors", g_col, o[2]),
-                           ("v_opacities", g_op, o[3]), ("absgrad", m2.absgrad, o[4])):
+                           ("v_opacities", g_op, o[3])) + ((("absgrad", m2.absgrad, o[4]),) if absgrad else ()):
         assert rel_l2(N(got), ref) < 2e-4, (name, rel_l2(N(got), ref))
         assert_close(N(got), ref, 1e-3, 1e-4 * np.abs(ref).max(), name, max_bad_frac=1e-4)
     o_vbg = (v_rc * (1.0 - o_ra)).sum(axis=(1, 2))

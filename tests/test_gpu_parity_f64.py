@@ -59,8 +59,10 @@ def _check(name, hip, f32, f64, cond=None):
     f64 = np.asarray(f64, np.float64)
     hip, f32 = np.asarray(hip, np.float64), np.asarray(f32, np.float64)
     floor = 1e-7 * np.abs(f64).max()
-    # max norm: no entry is off by more than 1e-4 of the largest entry
-    assert np.abs(hip - f64).max() <= 1e-4 * np.abs(f64).max(), (name, "max norm", np.abs(hip - f64).max() / np.abs(f64).max())
+    # max norm: no entry is off by more than 1e-4 of the largest entry -- or, where the fp32 ORACLE itself is further off than
+    # that (32 channels: 1.35e-4 for v_opacities, the kernels 1.13e-4), by more than the oracle is
+    bound = max(1e-4, np.abs(f32 - f64).max() / np.abs(f64).max())
+    assert np.abs(hip - f64).max() <= bound * np.abs(f64).max(), (name, "max norm", np.abs(hip - f64).max() / np.abs(f64).max())
     # entrywise 1e-4 relative is reached on (at least) as many entries as the fp32 oracle reaches it on: the entries that
     # miss it are small differences of large per-pixel terms, which no fp32 evaluation resolves (see `cond` below)
     reach_o = (np.abs(f32 - f64) <= 1e-4 * np.abs(f64) + floor).mean()
@@ -72,11 +74,13 @@ def _check(name, hip, f32, f64, cond=None):
         assert bad.mean() <= 1e-5, (name, "conditioned bound", bad.mean())
 
 
-@pytest.mark.parametrize("channels", [3, 1])
-def test_compositing_gradients_vs_float64(channels):
+# (round 5: 9 and 32 channels -- the wide instances, 32 as two launches over halves -- without absgrad: with it the 32-channel
+# backward is the generic kernel, which the absgrad=True cases of tests/test_gpu_ops.py cover)
+@pytest.mark.parametrize("channels,absgrad", [(3, True), (1, True), (9, False), (9, True), (16, False), (32, False)])
+def test_compositing_gradients_vs_float64(channels, absgrad):
     from gscodec_studio_amd import _wrapper as ops
 
-    c = _case(channels=channels)
+    c = _case(channels=channels, n=4000 if channels <= 9 else 2500)
     rs = np.random.RandomState(5)
     bg = rs.rand(c["C"], channels).astype(np.float32)
     geo = (c["means2d"], c["conics"], c["colors"], c["opacities"], c["W"], c["H"], 16, c["offs"], c["flat"])
@@ -87,7 +91,7 @@ def test_compositing_gradients_vs_float64(channels):
     assert ok.mean() > 0.995
     assert np.array_equal(o_li[ok], d_li[ok])  # same decisions on every pixel that is not flagged
     m2, cn, col, op = T(c["means2d"], True), T(c["conics"], True), T(c["colors"], True), T(c["opacities"], True)
-    rc, ra = ops.rasterize_to_pixels(m2, cn, col, op, c["W"], c["H"], 16, T(c["offs"]), T(c["flat"]), backgrounds=T(bg), absgrad=True)
+    rc, ra = ops.rasterize_to_pixels(m2, cn, col, op, c["W"], c["H"], 16, T(c["offs"]), T(c["flat"]), backgrounds=T(bg), absgrad=absgrad)
     # forward against float64: 1e-4 relative (+ 1e-6 absolute: colours are O(1))
     assert_close(N(rc)[ok], d_rc[ok], 1e-4, 1e-6, "render vs f64", max_bad_frac=1e-5)
     assert_close(N(ra)[ok], d_ra[ok], 1e-4, 1e-6, "alpha vs f64", max_bad_frac=1e-5)

@@ -190,7 +190,7 @@ def test_full_size_properties():
     counts = torch.bincount(tile_of, minlength=o.numel())
     assert torch.equal(torch.cat([o[1:], o.new_tensor([n_isects])]) - o, counts)
     # image sanity: alpha in [0,1], colours finite and >= 0 (clamp_min(sh + 0.5, 0) inputs)
-    assert float(ra.min()) >= 0 and float(ra.max()) <= 1.0 and bool(torch.isfinite(rc).all()) and float(rc.min()) >= 0
+    assert float(ra.detach().min()) >= 0 and float(ra.detach().max()) <= 1.0 and bool(torch.isfinite(rc).all()) and float(rc.detach().min()) >= 0
     # linearity of compositing in the colours: render(2*sh0-shifted colours) -- use the gradient instead:
     (rc.sum()).backward()
     for k, p in P.items():
