@@ -1616,14 +1616,14 @@ def rasterize_to_pixels(
     return _RasterizeToPixels.apply(
         means2d, conics, colors, opacities, backgrounds,
         masks, image_width, image_height, tile_size, isect_offsets.contiguous(), flatten_ids.contiguous(), absgrad,
-        bool(deterministic), prefill,
+        bool(deterministic), prefill, torch.is_grad_enabled(),
     )
 
 
 class _RasterizeToPixels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size,
-                isect_offsets, flatten_ids, absgrad, deterministic=False, prefill=None):
+                isect_offsets, flatten_ids, absgrad, deterministic=False, prefill=None, grad_mode=True):
         _require_gpu(means2d, "rasterize_to_pixels")
         means2d, conics, colors, opacities, strides = _splat_layout(means2d, conics, colors, opacities)
         backgrounds = _f32c(backgrounds)
@@ -1639,7 +1639,9 @@ class _RasterizeToPixels(torch.autograd.Function):
         assert isect_offsets.dtype == torch.int32 and flatten_ids.dtype == torch.int32
         # the scratch carries the forward checkpoints of the depth-segmented backward (128 MB written at 1 M splats /
         # 1080p): only ask for them when a backward can follow
-        needs_bwd = any(ctx.needs_input_grad[:5])
+        # (ctx.needs_input_grad says True for parameters even under torch.no_grad(), where no backward can follow: the caller's
+        # grad mode comes along as an argument -- inside forward() it always reads False)
+        needs_bwd = bool(grad_mode) and any(ctx.needs_input_grad[:5])
         with _device_of(means2d):
             plan, sb = _raster_plan(C * tile_height * tile_width, n_isects, channels, forward_only=not needs_bwd)
             scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
@@ -1744,4 +1746,4 @@ class _RasterizeToPixels(torch.autograd.Function):
             v_backgrounds = (v_render_colors * (1.0 - render_alphas).float()).sum(dim=(1, 2))
         else:
             v_backgrounds = None
-        return (v_means2d, v_conics, v_colors, v_opacities, v_backgrounds) + (None,) * 9
+        return (v_means2d, v_conics, v_colors, v_opacities, v_backgrounds) + (None,) * 10

@@ -25,9 +25,10 @@
 
 namespace {
 
-// waves per SIMD the register allocation of the <= 9-channel instances is held to (0: the compiler's choice)
+// waves per SIMD the register allocation of the <= 9-channel instances is held to (0: the compiler's choice, 3 at 9 channels;
+// 4 measured 1.072 -> 1.037 ms per 9-channel step at config 2, round 5)
 #ifndef GS_WIDE_BWD_WAVES
-#define GS_WIDE_BWD_WAVES 0
+#define GS_WIDE_BWD_WAVES 4
 #endif
 template <int CDIM, bool ABS>
 __global__ void __launch_bounds__(GS_WAVE, (GS_WIDE_BWD_WAVES > 0 && CDIM <= 9) ? GS_WIDE_BWD_WAVES : 1) raster_seg_bwd_wide_kernel(RasterArgs a, RasterGradArgs ga, int use_v_alpha, SegArgs sg,
