@@ -69,12 +69,26 @@ def test_refuses_more_ranks_than_gpus():
 
 
 def test_dead_rank_fails_the_launch():
-    """A rank that dies (here: rank 1 told to exit at start-up) must end the launch with a non-zero code, not hang rank 0 in its
-    first collective."""
+    """A rank that dies (here: rank 1 told to exit at start-up, in every attempt) must end the launch with a non-zero code, not
+    hang rank 0 in its first collective."""
+    share = torch.cuda.device_count() < 2
+    env = _env(share)
+    env["GS_BENCH_TEST_KILL_RANK"] = "1"
+    env["GS_BENCH_TEST_KILL_ALWAYS"] = "1"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + FAST, cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode != 0
+    assert "rank 1 exited" in r.stderr and "retrying once with --dp-mode camera" in r.stderr
+
+
+def test_failed_auto_run_falls_back_to_camera_mode():
+    """The calibrated run dies (rank 1, first attempt only): ONE retry with --dp-mode camera delivers the line, marked as such."""
     share = torch.cuda.device_count() < 2
     env = _env(share)
     env["GS_BENCH_TEST_KILL_RANK"] = "1"
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + FAST, cwd=ROOT, env=env, capture_output=True, text=True,
-                       timeout=300)
-    assert r.returncode != 0
-    assert "rank 1 exited" in r.stderr
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = _last_json(r.stdout)
+    _check(rec, 2)
+    assert rec["config"]["dp_mode"] == "camera" and "launch_fallback" in rec["config"]

@@ -90,3 +90,17 @@ tot = time.perf_counter() - t0
 print(f"step {1e6 * tot / K:.0f} us: forward {1e6 * tf / K:.0f}, loss + backward {1e6 * tb / K:.0f}")
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
     print(f"  {k:28s} {1e6 * v / K:7.1f} us")
+if os.environ.get("PROFILE") == "1":  # Python-level profile of the same steps (which calls the host time goes to)
+    import cProfile
+    import io
+    import pstats
+
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(100):
+        step()
+    pr.disable()
+    torch.cuda.synchronize()
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(32)
+    print(s.getvalue()[:6500])
