@@ -53,11 +53,13 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # PMC traffic (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 correction applied)
 # measured for this workload and committed under profiles/; bench.py cannot run rocprof on itself.
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+HBM_COPY_GBS = 6290.0  # what a float4 copy was measured to reach on this part (MI355X_MICROARCH.md: 6.29 TB/s, 79 % of spec)
 # entry point -> (kernel name fragment, the source file the kernel lives in)
-KERNEL_OF_ENTRY = {"gs_rasterize_bwd": ("raster_seg_bwd_kernel", "rasterize.hip"), "gs_rasterize_fwd": ("raster_tile_fwd_kernel", "rasterize.hip"),
-                   "gs_sh_view_bwd": ("sh_bwd_kernel", "sh.hip"), "gs_projection_rows_bwd": ("projection_bwd_kernel<false, 3>", "projection.hip"),
-                   "gs_sort_isect_pairs": ("sort_scatter_kernel<unsigned int, 16, true", "radix_sort.hip")}
+_RASTER_SRC = ("rasterize.hip", "rasterize_dev.h", "rasterize_common.h", "dpp_reduce.h")
+KERNEL_OF_ENTRY = {"gs_rasterize_bwd": ("raster_seg_bwd_kernel", _RASTER_SRC), "gs_rasterize_fwd": ("raster_tile_fwd_kernel", _RASTER_SRC),
+                   "gs_sh_view_bwd": ("sh_bwd_kernel", ("sh.hip",)), "gs_projection_rows_bwd": ("projection_bwd_kernel<false, 3>", ("projection.hip",)),
+                   "gs_sort_isect_pairs": ("sort_scatter_kernel<unsigned int, 16, true", ("radix_sort.hip",))}
 
 
 def _source_hash(name):
@@ -75,8 +77,8 @@ def measured_pmc(entry, workload_key, field="traffic_bytes_per_launch"):
         d = json.load(open(TRAFFIC_JSON))
         if d.get("workload_key") != workload_key:
             return None
-        frag, src = KERNEL_OF_ENTRY.get(entry, (None, None))
-        if src is not None and d.get("source_hashes", {}).get(src) != _source_hash(src):
+        frag, srcs = KERNEL_OF_ENTRY.get(entry, (None, ()))
+        if any(d.get("source_hashes", {}).get(src) != _source_hash(src) for src in srcs):
             return None
         for name, v in d["kernels"].items():
             if frag and frag in name:
@@ -97,9 +99,16 @@ def measured_traffic(entry, workload_key):
 
 # fp32 vector peak 157.3 TFLOP/s = 256 CU x 4 SIMD x 2.4 GHz x one wave64 instruction per 2 cycles (MI355X_MICROARCH.md)
 VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2
-# what the vector pipes were MEASURED to issue on this part: 64 independent v_fma_f32 x 2048 iterations x 5 waves per SIMD on every
-# SIMD in 0.812 ... 0.817 ms (tools/mfma_reduce_ab.hip, profiles/r04_mfma_reduce_ab.txt) -- reported next to the nominal peak
-VALU_MEASURED_WAVE_INSTR_PER_S = 256 * 4 * 5 * 64 * 2048 / 0.815e-3
+
+
+def measured_valu_issue_rate():
+    """What the vector pipes were MEASURED to issue on this part (64 independent v_fma_f32 x 2048 iterations x 5 waves per SIMD on
+    every SIMD, tools/mfma_reduce_ab.hip), as tools/pmc.sh recorded it next to the counters of the same session -- read from the
+    committed file, None when it is not there (round 4 carried the figure as a constant in this file, which goes stale silently)."""
+    try:
+        return float(json.load(open(TRAFFIC_JSON))["valu_measured_issue_rate"]["wave_instr_per_s"])
+    except Exception:
+        return None
 
 
 def parse():
@@ -197,6 +206,10 @@ def algorithmic_bytes(stats):
         "gs_rasterize_bwd": 40 * I + 24 * P + 36 * V,
         "gs_sh_bwd": (24 + 12 * K) * V + 12 * K * N + 12 * V,
         "gs_projection_bwd": 92 * V + 40 * N + 4 * N,
+        # the compression-simulation hooks of config 3 (quats 4 + scales 3 + opacities 1 + sh0 3 floats per splat): SURVEY 8(d)'s
+        # 8 A bytes per splat forward (x read, y written), 12 A backward (v_y + x read, v_x written)
+        "gs_quantize_noise_multi_fwd": 8 * 11 * N,
+        "gs_quantize_noise_multi_bwd": 12 * 11 * N,
     }
 
 
@@ -643,8 +656,8 @@ def main():
                 "valu": (lambda vi: None if vi is None else {
                     "wave_instr_per_launch": vi, "achieved": vi / (dom_ms * 1e-3), "peak": VALU_PEAK_WAVE_INSTR_PER_S,
                     "unit": "wave64 VALU instr/s", "frac": vi / (dom_ms * 1e-3) / VALU_PEAK_WAVE_INSTR_PER_S,
-                    "measured_issue_rate": VALU_MEASURED_WAVE_INSTR_PER_S,
-                    "frac_of_measured_issue_rate": vi / (dom_ms * 1e-3) / VALU_MEASURED_WAVE_INSTR_PER_S})(
+                    "measured_issue_rate": measured_valu_issue_rate(),
+                    "frac_of_measured_issue_rate": (lambda r: None if not r else vi / (dom_ms * 1e-3) / r)(measured_valu_issue_rate())})(
                     measured_pmc(dominant, f"grid{args.scene_grid}_{w['width']}x{w['height']}_sh{args.sh_degree}",
                                  "valu_wave_instr_per_launch")),
                 "algorithmic_bytes": alg.get(dominant, 0),
@@ -653,6 +666,14 @@ def main():
                                "formula": "SURVEY 8(d): Fwd 48N+(80+12K)V+84I+4T+20P + Bwd (44+12K)N+(164+12K)V+40I+24P",
                                "algorithmic_bytes_of_called_entry_points": called_alg},
                 "per_entry_point_ms": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+                # the stages whose OWN bound is HBM streaming (projection + SH each way; the quantizer hooks with --quantize):
+                # algorithmic bytes over the entry point's event time (pass A), against the 8 TB/s spec AND against what a
+                # float4 copy reaches on this part (6.29 TB/s)
+                "streaming": {k: {"ms": round(per_step[k], 4), "algorithmic_bytes": alg[k], "achieved": alg[k] / (per_step[k] * 1e-3) / 1e9,
+                                  "unit": "GB/s", "frac": alg[k] / (per_step[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "frac_of_measured_copy_rate": alg[k] / (per_step[k] * 1e-3) / 1e9 / HBM_COPY_GBS}
+                              for k in ("gs_projection_rows_fwd", "gs_projection_rows_bwd", "gs_quantize_noise_multi_fwd",
+                                        "gs_quantize_noise_multi_bwd") if k in per_step and k in alg and per_step[k] > 0},
                 # the binning chain (count -> depth pre-sort -> emit -> pair sort -> offsets), the stage whose OWN bound is HBM:
                 # SURVEY 8(d)'s bytes of isect (32V + 4N + 12I) + sort (24I) + offsets (8I + 4T) over the sum of its entry
                 # points' event times (pass A above)

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Everything profiles/rNN_* is made from, on the GPU box:  tools/final_profiles.sh r04
+# Everything profiles/rNN_* is made from, on the GPU box:  tools/final_profiles.sh r05
 set -u
-tag=${1:-r04}
+tag=${1:-r05}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/final
 mkdir -p "$out"
@@ -43,9 +43,19 @@ python -m pytest tests/test_gpu_fullsize_parity.py -q -s 2>&1 | grep -E "full si
     GS_BENCH_PG=1 GS_DIST_FORCE_COLLECTIVES=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=2965$i python bench.py --gpus 1 --dp-mode gaussian --steps 20 --warmup 5 --min-timed-s 0.3 --no-cpu-baseline --no-extras --no-dp-projection 2>/dev/null < /dev/null | tail -1 | python -c "import sys,json; print('gaussian-sharded, world 1, forced collectives: ms/step', round(json.loads(sys.stdin.read())['ms_per_step'], 4))"
   done
 } > "$out/${tag}_gaussian_mode.txt" 2>&1
+# 5..32 colour channels (round 5): the step at config 2's size, the reference's 32-channel protocol row, kernel stats
+{
+  python tools/bench_channels.py 3 9 16 32 2>&1 | grep -v amdgpu.ids
+  python tools/bench_profile_protocol.py --channels 32 1 2>&1 | grep -v amdgpu.ids
+} > "$out/${tag}_channels.txt" 2>&1
+bash tools/prof_cmd.sh ${tag}_ch9 python "$root/tools/bench_channels.py" 9 > "$out/prof_ch9.log" 2>&1
+cp gpurun_out/prof_${tag}_ch9_kernel_stats.csv "$out/${tag}_channels9_kernel_stats.csv"
+bash tools/prof_cmd.sh ${tag}_ch32 python "$root/tools/bench_channels.py" 32 > "$out/prof_ch32.log" 2>&1
+cp gpurun_out/prof_${tag}_ch32_kernel_stats.csv "$out/${tag}_channels32_kernel_stats.csv"
+[ -x ./build_abl/grid_barrier ] && timeout 120 ./build_abl/grid_barrier > "$out/${tag}_grid_barrier_raw.txt" 2>&1
 # extended fuzz sessions on the final kernels (shifted seeds; every kernel route)
 {
-  for k in 4100 4200 4300 4400 4500 4600 4700 4800 4900 5000 5100 5200 5300 5400 5500 5600 5700 5800 5900 6000; do
+  for k in ${FUZZ_OFFSETS:-6100 6200 6300 6400 6500 6600 6700 6800}; do
     echo "GS_FUZZ_SEED_OFFSET=$k: $(GS_FUZZ_SEED_OFFSET=$k python -m pytest tests/test_gpu_fuzz.py -q 2>&1 | tail -1)"
   done
 } > "$out/${tag}_fuzz_extended.txt" 2>&1

@@ -18,7 +18,9 @@ f=$(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 w=$(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 v=$(find /tmp/pmc_SQ_INSTS_VALU -name "*counter_collection.csv" | head -1)
 if [ -n "$f" ] && [ -n "$w" ] && [ -n "$v" ]; then
-    python "$root/tools/pmc_traffic.py" "$f" "$w" "$out" "$v" < /dev/null
+    # (the measured VALU issue rate of this session rides along: bench.py's roofline.valu reads it from the JSON)
+    [ -x "$root/build_abl/mfma_reduce_ab" ] && timeout 120 "$root/build_abl/mfma_reduce_ab" > /tmp/mfma_reduce_ab.txt 2>&1
+    python "$root/tools/pmc_traffic.py" "$f" "$w" "$out" "$v" /tmp/mfma_reduce_ab.txt < /dev/null
 else
     echo "missing counter CSVs: '$f' '$w' '$v'"; tail -3 /tmp/pmc_FETCH_SIZE.log
 fi

@@ -1,6 +1,6 @@
 """Build profiles/rNN_pmc_traffic.json (driven by tools/pmc.sh) from two rocprofv3 counter-collection CSVs (separate --pmc passes).
 
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [<sq_insts_valu.csv>]
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [<sq_insts_valu.csv> [<mfma_reduce_ab.txt>]]
 
 bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB, and FETCH_SIZE reports half of the
 fetched bytes on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
@@ -44,7 +44,19 @@ def main():
         if k in valu:  # wave-level VALU instructions per launch (third pass: --pmc SQ_INSTS_VALU)
             kernels[k]["valu_wave_instr_per_launch"] = valu[k]
     kernels = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"]))
+    # the VALU issue rate measured in the SAME session (tools/mfma_reduce_ab.hip, first line: 64 independent v_fma_f32 x 2048
+    # iterations x 5 waves per SIMD on every SIMD): bench.py's roofline.valu reads it from here
+    issue = None
+    if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):
+        import re
+
+        m = re.search(r"^64 v_fma\s+([0-9.]+) ms", open(sys.argv[5]).read(), re.M)
+        if m:
+            ms = float(m.group(1))
+            issue = {"wave_instr_per_s": 256 * 4 * 5 * 64 * 2048 / (ms * 1e-3), "ms": ms,
+                     "source": "tools/mfma_reduce_ab.hip: 64 independent v_fma_f32 x 2048 iterations x 5 waves per SIMD x 1024 SIMDs"}
     json.dump({
+        "valu_measured_issue_rate": issue,
         "workload_key": "grid3_1920x1080_sh3",
         "command": "tools/pmc.sh: cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras ; same with --pmc WRITE_SIZE and --pmc SQ_INSTS_VALU (separate passes)",
         "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: KB units; FETCH_SIZE reports 1/2 of the fetched bytes on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated",
