@@ -71,8 +71,22 @@ GS_DEV void fetch_splat_wide(const RasterArgs &a, int32_t g, SplatRaw &s, float 
         s.opac = a.opacities[(size_t)g * a.s_opac];
     }
     const float *cp = a.colors + (size_t)g * a.s_color + ch_off;
+    if (cnt == (uint32_t)CDIM) {
+        // the whole instance: 16-byte loads at 4-byte alignment (global memory takes dword-aligned multi-dword accesses) -- a
+        // 9-float row is two of them and a dword instead of nine dword gathers of 64 different cache lines each (the texture
+        // path services one line per lane and instruction: at 16 channels the scalar form cost ~100 us of the forward)
+        typedef float v4a4 __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
-    for (int k = 0; k < CDIM; ++k) col[k] = (uint32_t)k < cnt ? cp[k] : 0.f;
+        for (int k = 0; k + 4 <= CDIM; k += 4) {
+            const v4a4 v = *reinterpret_cast<const v4a4 *>(cp + k);
+            col[k] = v.x; col[k + 1 < CDIM ? k + 1 : 0] = v.y; col[k + 2 < CDIM ? k + 2 : 0] = v.z; col[k + 3 < CDIM ? k + 3 : 0] = v.w;
+        }
+#pragma unroll
+        for (int k = CDIM & ~3; k < CDIM; ++k) col[k] = cp[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) col[k] = (uint32_t)k < cnt ? cp[k] : 0.f;
+    }
 }
 
 GS_DEV SplatRaw gather_splat(const RasterArgs &a, int32_t idx, bool in_range) {
