@@ -282,6 +282,71 @@ def test_config5_slice_quantize_render_vs_oracle_chain():
     assert P["features_dir"].grad is None or float(P["features_dir"].grad.abs().max()) == 0.0
 
 
+def test_spacetime_trainer_nine_channel_feature_render_vs_oracle_chain():
+    """The STG trainer's step (examples/simple_trainer_STG.py:506-551): hooks (round) -> temporal slice -> colors_precomp =
+    cat(feature_color, feature_dir, tforpoly * feature_time) -> a 9-CHANNEL render -> backward.  This is the one consumer of the
+    features_dir / features_time tensors the STG hooks quantize; the render runs on the wide compositing kernels (round 5).
+    Forward against the oracle's pipeline, every parameter gradient against the hand-chained oracle VJPs."""
+    from gscodec_studio_amd import rasterization
+    from gscodec_studio_amd.compression_simulation import STGCompressionSimulation
+    from gscodec_studio_amd.dynamic import temporal_slice
+
+    n, timestamp = 2500, 0.41
+    fx = garden(n, scale_mult=5.0)
+    W, H = fx["width"], fx["height"]
+    raw = _dyn_params(fx["means"], fx["scales"], fx["quats"], fx["opacities"], fx["rgb"], seed=4)
+    P = {k: torch.nn.Parameter(T(v)) for k, v in raw.items()}
+    sim = STGCompressionSimulation(quantization_sim_type="round", entropy_steps={})
+    vm, Ks = fx["viewmats"][:1], fx["Ks"][:1]
+    q, _ = sim.simulate_compression(P, step=0)
+    scales, opac, tscale = torch.exp(q["scales"]), torch.sigmoid(q["opacities"]), torch.exp(q["trbf_scale"])
+    means_t, quats_t, opac_t, _ = temporal_slice(q["means"], q["motion"], q["quats"], q["omega"], opac, q["trbf_center"], tscale, timestamp)
+    tforpoly = (timestamp - q["trbf_center"]).detach()                                              # STG.py:506-509, 524
+    feats = torch.cat((q["colors"], q["features_dir"], tforpoly * q["features_time"]), dim=1)       # STG.py:531
+    rc, ra, meta = rasterization(means_t, quats_t, scales, opac_t, feats, T(vm), T(Ks), W, H, packed=False)
+    assert rc.shape[-1] == 9
+
+    o_q = {k: O.quant_round_fwd(raw[k], lo, hi, 8)[1] for k, (lo, hi) in BDS5.items()}
+    for k in BDS5:
+        assert np.array_equal(N(q[k]), o_q[k]), k
+    o_scales = np.exp(o_q["scales"]).astype(np.float32)
+    o_opac = (1.0 / (1.0 + np.exp(-o_q["opacities"].astype(np.float64)))).astype(np.float32)
+    o_ts = np.exp(raw["trbf_scale"]).astype(np.float32)
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64)  # noqa: E731
+    m_t, q_t, o_t, _ = UO.temporal_slice(t64(raw["means"]), t64(raw["motion"]), t64(o_q["quats"]), t64(raw["omega"]), t64(o_opac),
+                                         t64(raw["trbf_center"]), t64(o_ts), timestamp)
+    m_t, q_t, o_t = (x.numpy().astype(np.float32) for x in (m_t, q_t, o_t))
+    tfp = (np.float32(timestamp) - raw["trbf_center"]).astype(np.float32)
+    o_feats = np.concatenate([o_q["colors"], o_q["features_dir"], tfp * o_q["features_time"]], 1).astype(np.float32)
+    assert np.allclose(N(feats), o_feats, rtol=0, atol=1e-6)
+    _, _, om = O.rasterization(m_t, q_t, o_scales, o_t.reshape(-1), o_feats, vm, Ks, W, H)
+    cols = o_feats[None]
+    o_rc, o_ra, o_li, bl = O.rasterize_fwd(om["means2d"], om["conics"], cols, om["opacities"], W, H, 16, om["isect_offsets"], om["flatten_ids"],
+                                           return_borderline=True)
+    ok = bl == 0
+    assert_close(N(rc)[ok], o_rc[ok], 1e-4, 5e-5, "9-channel feature render", max_bad_frac=3e-4)
+
+    rs = np.random.RandomState(8)
+    v_rc = rs.randn(*o_rc.shape).astype(np.float32) * ok[..., None]
+    (rc * T(v_rc)).sum().backward()
+    v_m2, v_cn, v_col, v_op, _ = O.rasterize_bwd(om["means2d"], om["conics"], cols, om["opacities"], W, H, 16, om["isect_offsets"],
+                                                 om["flatten_ids"], o_ra, o_li, v_rc, np.zeros_like(o_ra))
+    g_mt, _, g_qt, g_sc, _ = O.projection_bwd(m_t, None, q_t, o_scales, vm, Ks, W, H, 0.3, "pinhole", om["radii"], om["conics"], None, v_m2,
+                                              np.zeros_like(om["depths"]), v_cn, None, need_viewmats=False)
+    keys = ["means", "motion", "quats", "omega", "opacities", "trbf_center", "trbf_scale"]
+    ins = [raw["means"], raw["motion"], o_q["quats"], raw["omega"], o_opac, raw["trbf_center"], o_ts]
+    _, grads = UO.with_grads(lambda *a: UO.temporal_slice(*a, timestamp)[:3], ins, (g_mt, g_qt, v_op[0]))
+    gs = dict(zip(keys, grads))
+    expect = dict(
+        means=gs["means"], motion=gs["motion"], omega=gs["omega"], quats=gs["quats"],
+        opacities=gs["opacities"].reshape(-1) * o_opac * (1 - o_opac), scales=g_sc * o_scales,
+        trbf_center=gs["trbf_center"].reshape(n, 1), trbf_scale=gs["trbf_scale"].reshape(n, 1) * o_ts,
+        colors=v_col[0][:, 0:3], features_dir=v_col[0][:, 3:6], features_time=tfp * v_col[0][:, 6:9])  # round STE: identity
+    for k, ref in expect.items():
+        got = N(P[k].grad)
+        assert rel_l2(got, ref.reshape(got.shape)) < 1e-3, (k, rel_l2(got, ref.reshape(got.shape)))
+
+
 def test_config5_full_size_properties():
     """2 M dynamic splats, one 1080p camera: temporal_slice -> round-quantize (17 floats) -> rasterization([N,3]) -> backward."""
     from gscodec_studio_amd._helper import load_test_data
@@ -302,7 +367,7 @@ def test_config5_full_size_properties():
     q, rc, ra, meta = _dyn_step(P, sim, viewmats[:1].contiguous(), Ks, W, H, 0.5)
     rc.sum().backward()
     assert rc.shape == (1, H, W, 3) and bool(torch.isfinite(rc).all())
-    assert float(ra.min()) >= 0 and float(ra.max()) <= 1
+    assert float(ra.detach().min()) >= 0 and float(ra.detach().max()) <= 1
     # parameters clamped in place; quantized values on the 255-level grid
     assert float(P["scales"][:11, 2].max()) == 2.0
     for k, (lo, hi) in BDS5.items():

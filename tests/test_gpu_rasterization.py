@@ -58,6 +58,45 @@ def test_rasterization_vs_oracle(sh_degree, packed, render_mode):
     assert_close(N(rc), o_rc, 1e-4, 5e-5, "colors", max_bad_frac=2e-4)
 
 
+@pytest.mark.parametrize("channels", [9, 32])
+@pytest.mark.parametrize("packed", [False, True])
+def test_feature_render_forward_backward_vs_oracle_chain(channels, packed):
+    """The reference's spacetime trainer renders a 9-channel feature image every step -- colors = cat(feature_color,
+    feature_dir, t * feature_time), examples/simple_trainer_STG.py:531-551 -- and its profile publishes a 32-channel row
+    (docs/source/tests/profile.rst:76-93): `rasterization()` with [N, D] post-activation colours through the wide compositing
+    kernels (round 5), forward against the oracle's pipeline and the full gradient chain against the hand-chained oracle VJPs,
+    packed and unpacked, with a background."""
+    from gscodec_studio_amd import rasterization
+
+    d = _inputs(n=2500, cams=2, sh_degree=None)
+    rs = np.random.RandomState(3 + channels)
+    feats = rs.rand(d["means"].shape[0], channels).astype(np.float32)
+    bg = rs.rand(2, channels).astype(np.float32)
+    P = {k: T(d[k], True) for k in ("means", "quats", "scales", "opacities")}
+    P["colors"] = T(feats, True)
+    rc, ra, meta = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], T(d["viewmats"]), T(d["Ks"]),
+                                 d["W"], d["H"], packed=packed, backgrounds=T(bg))
+    assert rc.shape == (2, d["H"], d["W"], channels)
+    o_rc, o_ra, om = O.rasterization(d["means"], d["quats"], d["scales"], d["opacities"], feats, d["viewmats"], d["Ks"], d["W"], d["H"])
+    cols = np.ascontiguousarray(np.broadcast_to(feats[None], (2,) + feats.shape))
+    o_rc, o_ra, o_li, bl = O.rasterize_fwd(om["means2d"], om["conics"], cols, om["opacities"], d["W"], d["H"], 16, om["isect_offsets"],
+                                           om["flatten_ids"], backgrounds=bg, return_borderline=True)
+    ok = bl == 0
+    assert ok.mean() > 0.99
+    assert_close(N(ra)[ok], o_ra[ok], 1e-4, 5e-5, "alphas", max_bad_frac=2e-4)
+    assert_close(N(rc)[ok], o_rc[ok], 1e-4, 5e-5, "features", max_bad_frac=2e-4)
+    v_rc = rs.randn(*o_rc.shape).astype(np.float32) * ok[..., None]
+    v_ra = rs.randn(*o_ra.shape).astype(np.float32) * ok[..., None]
+    ((rc * T(v_rc)).sum() + (ra * T(v_ra)).sum()).backward()
+    v_m2, v_cn, v_col, v_op, _ = O.rasterize_bwd(om["means2d"], om["conics"], cols, om["opacities"], d["W"], d["H"], 16, om["isect_offsets"],
+                                                 om["flatten_ids"], o_ra, o_li, v_rc, v_ra, backgrounds=bg)
+    vm, _, vq, vs, _ = O.projection_bwd(d["means"], None, d["quats"], d["scales"], d["viewmats"], d["Ks"], d["W"], d["H"], 0.3, "pinhole",
+                                        om["radii"], om["conics"], None, v_m2, np.zeros_like(om["depths"]), v_cn, None, need_viewmats=False)
+    for name, ref in (("means", vm), ("quats", vq), ("scales", vs), ("opacities", v_op.sum(0)), ("colors", v_col.sum(0))):
+        got = N(P[name].grad)
+        assert rel_l2(got, ref) < 2e-3, (name, channels, packed, rel_l2(got, ref))
+
+
 def test_rasterization_backward_vs_oracle_chain():
     """Full chain gradient (quantizer-free): d(sum of weighted render)/d(params) on the GPU vs the
     oracle stage VJPs chained by hand."""
