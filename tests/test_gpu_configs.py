@@ -369,7 +369,7 @@ def test_config5_full_size_properties():
     assert rc.shape == (1, H, W, 3) and bool(torch.isfinite(rc).all())
     assert float(ra.detach().min()) >= 0 and float(ra.detach().max()) <= 1
     # parameters clamped in place; quantized values on the 255-level grid
-    assert float(P["scales"][:11, 2].max()) == 2.0
+    assert float(P["scales"][:11, 2].detach().max()) == 2.0
     for k, (lo, hi) in BDS5.items():
         assert float(P[k].detach().min()) >= lo and float(P[k].detach().max()) <= hi, k
         lv = (q[k].detach() - lo) / ((hi - lo) / 255)
