@@ -396,7 +396,7 @@ def main():
 
         # a collective that never completes (mismatched call sequences on real links) ends the rank after this long instead
         # of the default 10 minutes; the launcher then stops the others and falls back (self_launch)
-        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("GS_BENCH_PG_TIMEOUT_S", "180")))
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("GS_BENCH_PG_TIMEOUT_S", "300")))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

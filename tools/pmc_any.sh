@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in "$@"; do
     rm -rf /tmp/pmca_$c
     timeout -k 5 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmca_$c -o p -- \
-        python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-dp-projection --min-timed-s 0 > /tmp/pmca_$c.log 2>&1 < /dev/null
+        ${PMC_CMD:-python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-dp-projection --min-timed-s 0} > /tmp/pmca_$c.log 2>&1 < /dev/null
     echo "$c rc=$?"
 done
 cat > /tmp/pmca_sum.py <<'PY' 
