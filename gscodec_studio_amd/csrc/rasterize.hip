@@ -288,8 +288,11 @@ __global__ void __launch_bounds__(GS_WAVE) raster_wave_fwd_kernel(RasterArgs a, 
 // four (the colour FMAs are independent work already, and four records of 6 float4 would not fit the registers), the launch
 // covers channels [ch_off, ch_off + cnt) of a.channels (cnt <= CDIM; 17..32 channels = two launches over halves: render_alphas /
 // last_ids / costs / the T plane of the checkpoints are written by the first), checkpoints are [k][1 + a.channels][256].
+#ifndef GS_WIDE_FWD_WAVES
+#define GS_WIDE_FWD_WAVES 4 // waves per SIMD the 12- / 16-channel instances are held to (A/B at 16 channels: 1 = 419 us, 4 = 406, 5 = 480 with spills)
+#endif
 template <int CDIM, bool CKPT>
-__global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, float *__restrict__ ckpt, int32_t seg, int32_t solo_min,
+__global__ void __launch_bounds__(256, CDIM > 9 ? GS_WIDE_FWD_WAVES : 1) raster_tile_fwd_kernel(RasterArgs a, float *__restrict__ ckpt, int32_t seg, int32_t solo_min,
                                                               uint32_t *__restrict__ cost_head, uint32_t *__restrict__ cost_body,
                                                               uint32_t *__restrict__ body_tile, uint32_t *__restrict__ class_count,
                                                               ZeroFill zf, uint32_t ch_off, uint32_t cnt) {
@@ -297,19 +300,23 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
     constexpr int NCW = WIDE ? (CDIM - 2 + 3) / 4 : 0; // float4s of colours 2.. behind R0, R1
     constexpr int REC = WIDE ? 2 + NCW : 3;
     constexpr int BATCH = 256;
-    static_assert((2 * BATCH * REC + REC) * 16 < 65536, "record offsets are 16-bit");
+    // record buffers: 2 (staging of batch b + 1 overlaps the compositing of batch b across the four waves: one barrier per batch);
+    // the 12- and 16-channel instances take ONE (half the LDS -- 27 instead of 54 KB at 16 channels, i.e. no longer 3 workgroups
+    // per CU -- for a second barrier per batch: 537 -> 415 us at 16 channels; at 9 channels a wash, 275 vs 281)
+    constexpr int NBUF = (WIDE && CDIM > 9) ? 1 : 2;
+    static_assert((NBUF * BATCH * REC + REC) * 16 < 65536, "record offsets are 16-bit");
     // records of both buffers in ONE array + a null record (alpha = 0) that pads every list to a multiple of four
-    __shared__ float4 s_rec[2 * BATCH * REC + REC];
-    constexpr uint32_t NULL_REC_OFF = 2u * BATCH * REC * 16u; // byte offset of the null record
+    __shared__ float4 s_rec[NBUF * BATCH * REC + REC];
+    constexpr uint32_t NULL_REC_OFF = (uint32_t)NBUF * BATCH * REC * 16u; // byte offset of the null record
     // per (buffer, sub-batch, quadrant): byte offsets (into s_rec) of the records that touch the quadrant, in list order
     typedef uint16_t list_t; // 16-bit entries keep the workgroup under 32 KB of LDS (5 per CU); 32-bit ones measured 0.252 vs 0.244 ms
-    __shared__ __attribute__((aligned(16))) list_t s_list[2][4][4][72];
-    __shared__ unsigned long long s_mask[2][4][4]; // [buffer][sub-batch (= staging wave)][quadrant]
-    __shared__ uint32_t s_done[2][4];              // [buffer][quadrant]
+    __shared__ __attribute__((aligned(16))) list_t s_list[NBUF][4][4][72];
+    __shared__ unsigned long long s_mask[NBUF][4][4]; // [buffer][sub-batch (= staging wave)][quadrant]
+    __shared__ uint32_t s_done[NBUF][4];              // [buffer][quadrant]
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6); // staging sub-batch AND composited quadrant
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-    if (tid < REC) s_rec[2 * BATCH * REC + tid] = make_float4(0.f, tid == 1 ? -__builtin_inff() : 0.f, 0.f, 0.f); // log2(opacity) = -inf
+    if (tid < REC) s_rec[NBUF * BATCH * REC + tid] = make_float4(0.f, tid == 1 ? -__builtin_inff() : 0.f, 0.f, 0.f); // log2(opacity) = -inf
     // the class counters of the backward's work list (seg_items_build_kernel runs after this kernel, in the same call)
     if (CKPT && blockIdx.x == 0 && tid < (uint32_t)COST_CLASSES) class_count[tid] = 0u;
     const TileGeom tg = tile_geom(a, a.tile_order != nullptr ? a.tile_order[blockIdx.x] : xcd_remap(blockIdx.x, gridDim.x, a.xcd_group));
@@ -547,7 +554,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
         gather(sid_cur, snx);
         __syncthreads(); // the null record (written by the first lanes of wave 0) is visible to every wave
         for (int32_t sbi = 0; sbi < n_sb; ++sbi) {
-            const uint32_t buf = (uint32_t)sbi & 1u;
+            const uint32_t buf = (uint32_t)sbi & (uint32_t)(NBUF - 1);
             const int32_t sb_start = base0 + sbi * GS_WAVE;
             const uint32_t slot = buf * BATCH + w * GS_WAVE + lane; // my record slot: the wave's own quarter of the buffer
             unsigned long long m;
@@ -601,7 +608,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
         }
     } else
     for (int32_t b = 0; b < num_batches; ++b) {
-        const uint32_t buf = (uint32_t)b & 1u;
+        const uint32_t buf = (uint32_t)b & (uint32_t)(NBUF - 1);
         const int32_t batch_start = base0 + b * BATCH;
         // ---- stage: exact cull of my entry against the four quadrants
         {
@@ -684,6 +691,7 @@ __global__ void __launch_bounds__(256) raster_tile_fwd_kernel(RasterArgs a, floa
         if (cur_off != 0xffffffffu) // offset -> list index: (offset / 16 - buffer base) / 3, exact for these small multiples of 3
             cur = batch_start + (int32_t)(WIDE ? ((cur_off >> 4) - buf * (uint32_t)(BATCH * REC)) / (uint32_t)REC
                                                : ((((cur_off >> 4) - buf * (uint32_t)(BATCH * REC)) * 43691u) >> 17));
+        if (NBUF == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // nobody restages while a wave still walks this batch
     }
 
     if (CKPT && n > 0) {

@@ -54,6 +54,7 @@ if __name__ == "__main__":
     Ds = [int(a) for a in sys.argv[1:]] or [3, 9, 16, 32]
     base = None
     for D in Ds:
+        torch.cuda.empty_cache()  # (a run after several other widths once read 2.9 ms forward-only at D = 32 against 0.86 alone: allocator state)
         t = run(D)
         if D == 3:
             base = t
