@@ -30,8 +30,11 @@ namespace {
 #ifndef GS_WIDE_BWD_WAVES
 #define GS_WIDE_BWD_WAVES 4
 #endif
+#ifndef GS_WIDE_BWD_WAVES_HI // the 12- / 16-channel instances (the compiler's choice: 161 / 189 VGPRs = 3 / 2 waves)
+#define GS_WIDE_BWD_WAVES_HI 3 // (16 channels: 806 -> 723 us; 4 is out of reach: the allocation stays at 2 waves)
+#endif
 template <int CDIM, bool ABS>
-__global__ void __launch_bounds__(GS_WAVE, (GS_WIDE_BWD_WAVES > 0 && CDIM <= 9) ? GS_WIDE_BWD_WAVES : 1) raster_seg_bwd_wide_kernel(RasterArgs a, RasterGradArgs ga, int use_v_alpha, SegArgs sg,
+__global__ void __launch_bounds__(GS_WAVE, (GS_WIDE_BWD_WAVES > 0 && CDIM <= 9) ? GS_WIDE_BWD_WAVES : GS_WIDE_BWD_WAVES_HI) raster_seg_bwd_wide_kernel(RasterArgs a, RasterGradArgs ga, int use_v_alpha, SegArgs sg,
                                                                       uint32_t ch_off, uint32_t cnt) {
     static_assert(CDIM > 4 && CDIM <= 16, "5..16 channels per launch");
     constexpr int NC4 = (CDIM - 4 + 3) / 4; // float4s of colours 4..
