@@ -1557,6 +1557,32 @@ def _splat_layout(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Te
     return m2, cn, col, op, (ctypes.c_uint32 * 4)(s0, s1, s2, s3)
 
 
+@torch.no_grad()
+def _split_big_tiles(isect_offsets: Tensor, flatten_ids: Tensor, masks: Optional[Tensor]):
+    """Tiles of 2s x 2s pixels as 2 x 2 sub-tiles of s x s: -> (offsets [C, 2 th, 2 tw], flatten_ids [4 n], masks) where every
+    sub-tile owns a copy of its tile's list range (no host synchronisation: the total is 4 n)."""
+    C, th, tw = isect_offsets.shape
+    n = int(flatten_ids.shape[0])
+    dev = flatten_ids.device
+    start = isect_offsets.reshape(-1).to(torch.int64)
+    end = torch.cat([start[1:], start.new_full((1,), n)])
+
+    def rep(t):
+        return t.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+
+    vcount = rep((end - start).view(C, th, tw)).reshape(-1)
+    vstart = rep(start.view(C, th, tw)).reshape(-1)
+    voff = torch.cumsum(vcount, 0) - vcount
+    total = 4 * n
+    if total > 0:
+        tile_of = torch.repeat_interleave(torch.arange(vcount.numel(), device=dev), vcount, output_size=total)
+        src = vstart[tile_of] + (torch.arange(total, device=dev) - voff[tile_of])
+        flat = flatten_ids[src].contiguous()
+    else:
+        flat = flatten_ids.new_empty(0)
+    return voff.to(torch.int32).view(C, 2 * th, 2 * tw).contiguous(), flat, (rep(masks).contiguous() if masks is not None else None)
+
+
 def rasterize_to_pixels(
     means2d: Tensor,  # [C, N, 2] or [nnz, 2]
     conics: Tensor,  # [C, N, 3] or [nnz, 3]
@@ -1610,7 +1636,18 @@ def rasterize_to_pixels(
     tile_height, tile_width = isect_offsets.shape[1:3]
     assert tile_height * tile_size >= image_height, f"Assert Failed: {tile_height} * {tile_size} >= {image_height}"
     assert tile_width * tile_size >= image_width, f"Assert Failed: {tile_width} * {tile_size} >= {image_width}"
-    assert 1 <= tile_size <= 16, f"tile_size must be in [1, 16] on the HIP backend, got {tile_size}"
+    assert 1 <= tile_size <= 32, f"tile_size must be in [1, 32], got {tile_size}"
+    if tile_size > 16:
+        # The kernels map a tile onto four wave64 quadrants of 8x8 pixels (tiles up to 16x16); the reference launches tile_size^2
+        # threads and takes up to 32 (rasterize_to_pixels_fwd.cu:228; no caller of the reference uses more than 16).  A tile of
+        # 18, 20, ... 32 pixels is composited as 2 x 2 SUB-TILES of half the size, each walking its own copy of the tile's list
+        # (the exact per-quadrant culling drops what a sub-tile does not need): same images and gradients, 4x the list entries.
+        if tile_size % 2:
+            raise ValueError(f"tile_size {tile_size}: odd tile sizes above 16 are not supported on the HIP backend (1..16 and the even "
+                             f"sizes 18..32 are)")
+        isect_offsets, flatten_ids, masks = _split_big_tiles(isect_offsets, flatten_ids, masks)
+        tile_size //= 2
+        tile_height, tile_width = isect_offsets.shape[1:3]
 
     # (no .contiguous() on the splat arrays: column views of the splat rows are read in place, _splat_layout)
     return _RasterizeToPixels.apply(

@@ -181,7 +181,8 @@ def rasterization(
     # the compositing kernels map a tile onto wave64 quadrants of 8x8 pixels: tiles up to 16x16 (the reference launches
     # tile_size^2 threads per block, i.e. accepts up to 32; every caller in the reference uses 16).  Checked here, before
     # projection and binning run, instead of surfacing as a native error afterwards.
-    assert 1 <= tile_size <= 16, f"tile_size must be in [1, 16] on the HIP backend, got {tile_size}"
+    assert 1 <= tile_size <= 32 and (tile_size <= 16 or tile_size % 2 == 0), \
+        f"tile_size must be in [1, 16] or an even size up to 32 on the HIP backend, got {tile_size}"
 
     if sh_degree is None:
         # post-activation values [N, D] or [C, N, D]
@@ -240,7 +241,7 @@ def rasterization(
     if use_rows:
         row_colors = colors if (sh_degree is None and colors.dim() == 2 and colors.shape[-1] == 3) else None
         if _step.applicable(means, viewmats, colors, sh_degree, packed, distributed, render_mode, channel_chunk, deterministic,
-                            fuse_sh, row_colors) and C * N <= _step_max_elems():
+                            fuse_sh, row_colors) and C * N <= _step_max_elems() and tile_size <= 16:
             # the common training call: the whole forward as two native calls around the one host read-back (_step.py)
             return _step.rasterize_step(
                 means, covars, quats, scales, opacities, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
@@ -370,7 +371,7 @@ def rasterization(
             # binning up to its read-back; the depth pre-sort queued behind the count keeps the GPU busy while the host
             # looks at the overflow flags (stored to pinned memory before the count) and comes back for the rest
             rows_state = None
-            if use_rows and _step.rows_applicable(rows, colors, packed, render_mode, channel_chunk, deterministic, absgrad):
+            if use_rows and tile_size <= 16 and _step.rows_applicable(rows, colors, packed, render_mode, channel_chunk, deterministic, absgrad):
                 # (received rows: binning + compositing as native calls around the read-back, like the one-GPU fast path)
                 rows_state = _step.rows_begin(radii, depths, rows, tile_size, tile_width, tile_height)
             else:

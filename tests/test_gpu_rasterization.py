@@ -420,13 +420,58 @@ def test_inplace_edit_of_the_render_before_backward_raises():
     assert all(bool(torch.isfinite(p.grad).all()) for p in P.values())
 
 
-def test_tile_size_above_16_is_rejected_up_front():
+@pytest.mark.parametrize("tile_size", [18, 24, 32])
+def test_tile_sizes_above_16_as_sub_tiles(tile_size):
+    """The reference launches tile_size^2 threads per tile and takes up to 32 (rasterize_to_pixels_fwd.cu:228); here the even
+    sizes 18 .. 32 are composited as 2 x 2 sub-tiles of half the size (round 5): binning in the caller's tile size (meta as the
+    reference's), image and gradients against the oracle run with the SAME tile size, masks and backgrounds included."""
+    from gscodec_studio_amd import rasterization
+    from gscodec_studio_amd import _wrapper as ops
+
+    d = _inputs(n=2500, cams=2, sh_degree=None)
+    P = {k: T(d[k], True) for k in ("means", "quats", "scales", "opacities", "colors")}
+    rc, ra, meta = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], T(d["viewmats"]), T(d["Ks"]), d["W"], d["H"],
+                                 packed=False, tile_size=tile_size)
+    o_rc, o_ra, om = O.rasterization(d["means"], d["quats"], d["scales"], d["opacities"], d["colors"], d["viewmats"], d["Ks"], d["W"], d["H"],
+                                     tile_size=tile_size)
+    assert meta["tile_size"] == tile_size and tuple(meta["isect_offsets"].shape) == om["isect_offsets"].shape
+    assert np.array_equal(N(meta["isect_offsets"]), om["isect_offsets"]) or (N(meta["radii"]) != om["radii"]).any()
+    _, _, o_li, bl = O.rasterize_fwd(om["means2d"], om["conics"], om["colors"], om["opacities"], d["W"], d["H"], tile_size, om["isect_offsets"],
+                                     om["flatten_ids"], return_borderline=True)
+    ok = bl == 0
+    assert_close(N(ra)[ok], o_ra[ok], 1e-4, 5e-5, "alphas", max_bad_frac=2e-4)
+    assert_close(N(rc)[ok], o_rc[ok], 1e-4, 5e-5, "colors", max_bad_frac=2e-4)
+    rs = np.random.RandomState(tile_size)
+    v_rc = rs.randn(*o_rc.shape).astype(np.float32) * ok[..., None]
+    (rc * T(v_rc)).sum().backward()
+    v_m2, v_cn, v_col, v_op, _ = O.rasterize_bwd(om["means2d"], om["conics"], om["colors"], om["opacities"], d["W"], d["H"], tile_size,
+                                                 om["isect_offsets"], om["flatten_ids"], o_ra, o_li, v_rc, np.zeros_like(o_ra))
+    vm, _, vq, vs, _ = O.projection_bwd(d["means"], None, d["quats"], d["scales"], d["viewmats"], d["Ks"], d["W"], d["H"], 0.3, "pinhole",
+                                        om["radii"], om["conics"], None, v_m2, np.zeros_like(om["depths"]), v_cn, None, need_viewmats=False)
+    for name, ref in (("means", vm), ("quats", vq), ("scales", vs), ("opacities", v_op.sum(0)), ("colors", v_col.sum(0))):
+        assert rel_l2(N(P[name].grad), ref) < 2e-3, (name, tile_size, rel_l2(N(P[name].grad), ref))
+    # the op itself, with tile masks and a background, on the oracle's own binning
+    th, tw = om["isect_offsets"].shape[1:]
+    masks = rs.rand(2, th, tw) > 0.3
+    bg = rs.rand(2, 3).astype(np.float32)
+    m_rc, m_ra, _ = O.rasterize_fwd(om["means2d"], om["conics"], om["colors"], om["opacities"], d["W"], d["H"], tile_size, om["isect_offsets"],
+                                    om["flatten_ids"], backgrounds=bg, masks=masks)
+    g_rc, g_ra = ops.rasterize_to_pixels(T(om["means2d"]), T(om["conics"]), T(om["colors"]), T(om["opacities"]), d["W"], d["H"], tile_size,
+                                         T(om["isect_offsets"]), T(om["flatten_ids"]), backgrounds=T(bg), masks=T(masks))
+    pm = np.repeat(np.repeat(masks, tile_size, 1), tile_size, 2)[:, :d["H"], :d["W"]] & ok
+    assert_close(N(g_rc)[pm], m_rc[pm], 1e-4, 5e-5, "masked render (kept tiles)", max_bad_frac=2e-4)
+    off = ~np.repeat(np.repeat(masks, tile_size, 1), tile_size, 2)[:, :d["H"], :d["W"]]
+    assert np.allclose(N(g_rc)[off], np.broadcast_to(bg[:, None, None, :], N(g_rc).shape)[off])
+
+
+def test_odd_tile_sizes_above_16_are_rejected_up_front():
     from gscodec_studio_amd import rasterization
 
     d = _inputs(n=100, cams=1, sh_degree=None)
-    with pytest.raises(AssertionError, match="tile_size"):
-        rasterization(T(d["means"]), T(d["quats"]), T(d["scales"]), T(d["opacities"]), T(d["colors"]), T(d["viewmats"]), T(d["Ks"]),
-                      d["W"], d["H"], packed=False, tile_size=32)
+    for ts in (17, 33):
+        with pytest.raises(AssertionError, match="tile_size"):
+            rasterization(T(d["means"]), T(d["quats"]), T(d["scales"]), T(d["opacities"]), T(d["colors"]), T(d["viewmats"]), T(d["Ks"]),
+                          d["W"], d["H"], packed=False, tile_size=ts)
 
 
 def test_repeated_backward_and_means_gradient_routes():
