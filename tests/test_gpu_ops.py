@@ -415,6 +415,57 @@ def test_rasterize_fwd_bwd_vs_oracle(ops, channels, absgrad):
     assert_close(N(g_bg), o_vbg, 1e-3, 1e-3, "v_backgrounds")
 
 
+@pytest.mark.parametrize("channels,absgrad", [(9, False), (16, True), (24, False)])
+def test_wide_backward_gradient_layouts_through_the_c_abi(ops, channels, absgrad):
+    """gs_rasterize_bwd with a plan + scratch (segmented wide kernels) takes the gradients three ways: `packed16 = 2` (geometry rows
+    + dense colour array: what rasterize_to_pixels uses), `packed16 = 0` (the reference's four separate arrays: a C-ABI caller's
+    form, reachable from no Python wrapper) and, without scratch, the generic kernels.  All three must agree."""
+    import ctypes
+
+    from gscodec_studio_amd import _backend as B
+    from gscodec_studio_amd import _wrapper as W
+
+    c = _raster_case(n=2500, channels=channels, opac_boost=True)
+    C, H, Wd = c["C"], c["H"], c["W"]
+    dev = torch.device("cuda")
+    m2, cn, col, op = T(c["means2d"]), T(c["conics"]), T(c["colors"]), T(c["opacities"])
+    offs, flat = T(c["offs"]), T(c["flat"])
+    th, tw = c["offs"].shape[1:]
+    n_elems, n_isects = op.numel(), flat.shape[0]
+    rs = np.random.RandomState(channels)
+    v_rc, v_ra = T(rs.randn(C, H, Wd, channels).astype(np.float32)), T(rs.randn(C, H, Wd, 1).astype(np.float32))
+    st = torch.cuda.current_stream().cuda_stream
+    plan, sb = W._raster_plan(C * th * tw, n_isects, channels)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+    rc = torch.empty((C, H, Wd, channels), device=dev)
+    ra = torch.empty((C, H, Wd, 1), device=dev)
+    li = torch.empty((C, H, Wd), dtype=torch.int32, device=dev)
+    B.call("gs_rasterize_fwd", C, n_elems, n_isects, channels, B.ptr(m2), B.ptr(cn), B.ptr(col), B.ptr(op), None, None, None, Wd, H, 16, tw, th,
+           B.ptr(offs), B.ptr(flat), B.ptr(rc), B.ptr(ra), B.ptr(li), ctypes.addressof(plan), B.ptr(scratch), None, 0, st)
+
+    def bwd(packed16, use_plan):
+        z = lambda *shape: torch.zeros(shape, device=dev)  # noqa: E731
+        if packed16 == 2:
+            P, vcol = z(C, c["means2d"].shape[1], 16), z(*col.shape)
+            ptrs = (B.ptr(P) if absgrad else None, B.ptr(P), None, B.ptr(vcol), None)
+        else:
+            vm, vc_, vcol, vo, va = z(*m2.shape), z(*cn.shape), z(*col.shape), z(*op.shape), (z(*m2.shape) if absgrad else None)
+            ptrs = (B.ptr(va), B.ptr(vm), B.ptr(vc_), B.ptr(vcol), B.ptr(vo))
+        B.call("gs_rasterize_bwd", C, n_elems, n_isects, channels, B.ptr(m2), B.ptr(cn), B.ptr(col), B.ptr(op), None, None, None, Wd, H, 16, tw,
+               th, B.ptr(offs), B.ptr(flat), B.ptr(rc), B.ptr(ra), B.ptr(li), B.ptr(v_rc), B.ptr(v_ra), channels, 1, *ptrs, packed16, None,
+               ctypes.addressof(plan) if use_plan else None, B.ptr(scratch) if use_plan else None, st)
+        if packed16 == 2:
+            return P[..., 0:2], P[..., 2:5], vcol, P[..., 5], (P[..., 10:12] if absgrad else None)
+        return vm, vc_, vcol, vo, va
+
+    a, b, g = bwd(2, True), bwd(0, True), bwd(0, False)
+    for name, x, y, z_ in zip(("v_means2d", "v_conics", "v_colors", "v_opacities", "absgrad"), a, b, g):
+        if x is None:
+            continue
+        assert rel_l2(N(y), N(x)) < 2e-5, (name, "separate arrays vs rows", rel_l2(N(y), N(x)))
+        assert rel_l2(N(z_), N(x)) < 2e-4, (name, "generic vs segmented", rel_l2(N(z_), N(x)))
+
+
 def test_rasterize_masks_tilesize_and_last_ids(ops):
     c = _raster_case(n=2000, cams=1, channels=3)
     th, tw = c["offs"].shape[1:]
