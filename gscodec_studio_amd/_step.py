@@ -176,7 +176,7 @@ def _finish(s, sp, stream, bufs, n_sums, C, N, height, width, tile_height, tile_
     pinned = bufs["pinned"]
     offsets = empty((C, tile_height, tile_width), dtype=i32, device=dev)
     s.offsets = ptr(offsets)
-    sentinel = W._SentinelEvent(pinned)
+    sentinel = W._SentinelEvent(pinned, stream=torch.cuda.current_stream(dev))  # (the launch stream: what the wait watches for faults)
     # ---- the one host sync: the count kernel's block sums land in pinned memory (-1 -> >= 0).  From here to the
     # binning launches the GPU has ~40 us of pre-sort left: nothing that can be done earlier or later sits in between
     W._wait_event(sentinel)

@@ -1362,7 +1362,7 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                        tile_height, B.ptr(tiles_per_gauss), B.ptr(dkeys), B.ptr(dvals), B.ptr(bsums),
                        B.ptr(temp) if hist_ready else None, tb if hist_ready else 0, B.ptr(split), st)
                 if direct:
-                    ev = _SentinelEvent(pinned)
+                    ev = _SentinelEvent(pinned, stream=torch.cuda.current_stream(dev))  # (the stream the count kernel was queued on)
                 else:
                     pinned.copy_(bsums.view(-1, 2).sum(0, dtype=torch.int64), non_blocking=True)
                     ev = torch.cuda.Event()
