@@ -96,12 +96,27 @@ def _compositing_fuzz(seed):
     grads = torch.autograd.grad(loss, (m2, cn, col, op))
     o = O.rasterize_bwd(c["means2d"], c["conics"], c["colors"], c["opac"], c["W"], c["H"], c["ts"], offs, flat, o_ra, o_li,
                         v_rc, v_ra, backgrounds=c["bg"], masks=c["masks"])
-    for name, got, ref in zip(("v_means2d", "v_conics", "v_colors", "v_opacities"), grads, o[:4]):
+    d64 = None  # the float64 build of the oracle, evaluated only when the fp32 oracle and the kernels are further apart than 5e-4
+    for i, (name, got, ref) in enumerate(zip(("v_means2d", "v_conics", "v_colors", "v_opacities"), grads, o[:4])):
         scale = np.abs(ref).max()
         if scale == 0:
             assert np.abs(N(got)).max() == 0, (name, tag)
             continue
-        assert rel_l2(N(got), ref) < 5e-4, (name, tag, rel_l2(N(got), ref))
+        e32 = rel_l2(N(got), ref)
+        if e32 < 5e-4:
+            continue
+        # 5e-4 is the fp32 ORACLE's error bar, not the kernels': its back-to-front T / (1 - alpha) recurrence over the whole list
+        # reaches 7e-4 on some scenes (seed offset 7700, scene 15: v_conics oracle 6.9e-4, kernels 5.8e-5 against float64).  The
+        # float64 oracle decides: the kernels must be within the north star's 1e-4 of it, and closer to it than the fp32 oracle is
+        if d64 is None:
+            with O.precision(64):
+                _, q_ra, q_li, bl64 = O.rasterize_fwd(c["means2d"], c["conics"], c["colors"], c["opac"], c["W"], c["H"], c["ts"], offs, flat,
+                                                      backgrounds=c["bg"], masks=c["masks"], return_borderline=True)
+                assert not ((bl64 != 0) & ok).any(), ("a pixel only the float64 run flags carries upstream gradient", tag)
+                d64 = O.rasterize_bwd(c["means2d"], c["conics"], c["colors"], c["opac"], c["W"], c["H"], c["ts"], offs, flat, q_ra, q_li,
+                                      v_rc, v_ra, backgrounds=c["bg"], masks=c["masks"])
+        e_hip, e_orc = rel_l2(N(got).astype(np.float64), d64[i]), rel_l2(ref, d64[i])
+        assert e_hip < 1e-4 and e_hip < e_orc, (name, tag, "HIP vs f64", e_hip, "fp32 oracle vs f64", e_orc, "HIP vs fp32 oracle", e32)
 
 
 @pytest.mark.parametrize("seed", range(16))
