@@ -286,6 +286,17 @@ def dp_projection(args, t1_ms, stats):
             rec["local_overhead_ms"] = max(ms - t1_ms, 0.0)
             rec["implied_efficiency_world8"] = t1_ms / (t1_ms + rec["local_overhead_ms"] + rec["xgmi_floor_ms"])
             rec["implied_speedup_world8"] = 8 * rec["implied_efficiency_world8"]
+            if mode == "gaussian":
+                # this mode is bound by HOST work and follows whatever else runs on the box (0.70 ... 0.79 from run to run): two
+                # more runs, and the spread next to the first run's figure -- interference only ever slows a run down, so the
+                # fastest of the three is the least disturbed one
+                runs = [ms]
+                for _ in range(2):
+                    r2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180)
+                    runs.append(json.loads(r2.stdout.strip().splitlines()[-1])["ms_per_step"])
+                best = min(runs)
+                rec["ms_per_step_runs"] = runs
+                rec["implied_efficiency_world8_least_disturbed_run"] = t1_ms / (t1_ms + max(best - t1_ms, 0.0) + rec["xgmi_floor_ms"])
         except Exception as e:  # (a projection must never take the measurement down with it)
             rec["error"] = f"{type(e).__name__}: {e}"[:200]
         out[mode] = rec
