@@ -94,3 +94,33 @@ def test_camera_sharding():
     assert shard_cameras(8, 1, 4) == [1, 5]
     got = sorted(sum((shard_cameras(10, r, 4) for r in range(4)), []))
     assert got == list(range(10))
+
+
+def test_big_tiles_are_split_into_sub_tiles_with_their_own_list_copies():
+    """`_wrapper._split_big_tiles` (tile sizes 18..32 on the HIP backend: every 2s x 2s tile becomes 2 x 2 sub-tiles of s x s, each
+    owning a copy of the tile's list range): offsets, lists and masks against a brute-force construction, empty tiles and an
+    empty scene included."""
+    from gscodec_studio_amd._wrapper import _split_big_tiles
+
+    rs = np.random.RandomState(0)
+    C, th, tw = 2, 3, 4
+    counts = rs.randint(0, 5, size=(C, th, tw))
+    counts[0, 1, 2] = 0
+    n = int(counts.sum())
+    offsets = (np.cumsum(counts.reshape(-1)) - counts.reshape(-1)).reshape(C, th, tw).astype(np.int32)
+    flat = rs.randint(0, 1000, size=n).astype(np.int32)
+    masks = rs.rand(C, th, tw) > 0.4
+    vo, vf, vm = _split_big_tiles(torch.tensor(offsets), torch.tensor(flat), torch.tensor(masks))
+    assert vo.shape == (C, 2 * th, 2 * tw) and vo.dtype == torch.int32 and vf.shape == (4 * n,) and vm.shape == (C, 2 * th, 2 * tw)
+    vo_n, vf_n = vo.numpy().reshape(-1), vf.numpy()
+    ends = np.append(vo_n[1:], 4 * n)
+    k = 0
+    for c in range(C):
+        for vy in range(2 * th):
+            for vx in range(2 * tw):
+                a, b = offsets[c, vy // 2, vx // 2], offsets[c, vy // 2, vx // 2] + counts[c, vy // 2, vx // 2]
+                assert np.array_equal(vf_n[vo_n[k]:ends[k]], flat[a:b]), (c, vy, vx)
+                assert bool(vm[c, vy, vx]) == bool(masks[c, vy // 2, vx // 2])
+                k += 1
+    vo0, vf0, vm0 = _split_big_tiles(torch.zeros((1, 2, 2), dtype=torch.int32), torch.zeros(0, dtype=torch.int32), None)
+    assert vo0.shape == (1, 4, 4) and int(vo0.abs().sum()) == 0 and vf0.numel() == 0 and vm0 is None
