@@ -1252,7 +1252,7 @@ class _SentinelEvent:
     mechanism needs fine-grained coherent pinned memory, HIP's default for ``hipHostMalloc``; with HIP_HOST_COHERENT=0 the
     stores only show at a synchronisation point, which the stream check below turns into a late but correct result).
 
-    The wait is BOUNDED and notices a dead GPU: a yielding spin for the first millisecond, then 50 us naps; every ~2 ms the launch stream is queried -- a
+    The wait is BOUNDED and notices a dead GPU: a yielding spin for the first 20 ms (steps wait here for up to a step's length), naps after that; every ~2 ms the launch stream is queried -- a
     device fault raises there, and a stream that has drained while the sentinel is still unset means the kernel never stored
     (failed launch, lost write): RuntimeError instead of a core spinning for good; ``GS_WAIT_TIMEOUT_S`` (30) ends any wait."""
 
@@ -1278,8 +1278,11 @@ class _SentinelEvent:
         next_check = t0 + 2e-3
         while not self.query():
             now = time.perf_counter()
-            if now - t0 < 1e-3:
-                time.sleep(0)  # (yielding spin: the usual wait is a few tens of microseconds, and a nap's wake-up is ~100 us late)
+            if now - t0 < 20e-3 and now < next_check:
+                # yielding spin: the usual wait is tens to hundreds of microseconds -- up to a whole step when the host runs ahead
+                # of the GPU -- and a thread that napped comes back late (a 50 us time.sleep takes ~100 us on the test hosts, and
+                # with naps from 1 ms on a 2-camera step read 2.63 ms instead of 1.37: tools/bench_multicam.py, round 5)
+                time.sleep(0)
                 continue
             if now >= next_check:
                 next_check = now + 2e-3
@@ -1296,7 +1299,8 @@ class _SentinelEvent:
                                        f"(kernel not launched, faulted, or its stores were lost)")
                 if now - t0 > limit:
                     raise RuntimeError(f"timed out after {limit:.1f} s (GS_WAIT_TIMEOUT_S) waiting for {self.what}")
-            time.sleep(50e-6)
+            if now - t0 >= 20e-3:
+                time.sleep(200e-6)  # (a wait this long is not a step's own: stop burning the core)
 
 
 @torch.no_grad()
