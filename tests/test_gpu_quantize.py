@@ -108,7 +108,7 @@ def test_compression_simulation_hooks():
                             features_dir=(-10, 10), features_time=(-10, 10)).items():
         assert float(dyn[k].detach().min()) >= lo and float(dyn[k].detach().max()) <= hi
         lv = (new2[k] - lo) / ((hi - lo) / 255)
-        assert float((lv - lv.round()).abs().max()) < 1e-3
+        assert float((lv - lv.round()).detach().abs().max()) < 1e-3
     with pytest.raises(NotImplementedError):  # the hash-grid Gaussian model is not built (the factorized prior is: test_gpu_entropy.py)
         CompressionSimulation(entropy_model_enable=True, entropy_model_type="gaussian_model", entropy_steps={"scales": 1})
 
