@@ -139,6 +139,18 @@ def parse():
     ap.add_argument("--dp-mode", choices=["auto", "camera", "camera_sparse", "gaussian", "gaussian_dense"], default="auto",
                     help="multi-GPU exchange pattern (see the module docstring); ignored with one GPU")
     ap.add_argument("--calib-steps", type=int, default=5)
+    ap.add_argument("--dynamic", action="store_true",
+                    help="BASELINE config 5's step instead of config 2's: 2 M dynamic (spacetime) splats, round-quantize hooks over the "
+                         "17 floats -> temporal slice -> render -> backward (see main_dynamic)")
+    ap.add_argument("--dynamic-splats", type=int, default=2_000_000)
+    ap.add_argument("--dynamic-channels", type=int, choices=[3, 9], default=3,
+                    help="3: the dyngs trainer's RGB render (simple_trainer_dyngs.py:519-520); 9: the spacetime trainer's feature render "
+                         "cat(colors, features_dir, tau * features_time) (simple_trainer_STG.py:531-551)")
+    ap.add_argument("--dynamic-form", choices=["reference", "activate", "fused", "full"], default="full",
+                    help="reference: the trainer's own call pattern (hooks -> torch.exp / sigmoid -> temporal_slice -> rasterization); "
+                         "activate: simulate_compression(activate=True); fused: + rasterization(dynamic=...), the slice inside the "
+                         "projection kernels; full: dynamic.render_dynamic -- hooks, activations and slice inside the projection kernels")
+    ap.add_argument("--timestamp", type=float, default=0.5)
     ap.add_argument("--no-dp-projection", action="store_true",
                     help="(one GPU) skip the multi-GPU projection: the exchange modes re-timed on this GPU with their collectives "
                          "forced through RCCL (world 1), next to the bytes a world-8 run would put on the xGMI links")
@@ -392,10 +404,220 @@ def _launch_once(args, n, argv, extra_env):
     return rc
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(args))
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: one frame of the dynamic-splat trainer's step
+DYN_QUANT_FLOATS = 17  # scales 3 + quats 4 + opacities 1 + colors 3 + features_dir 3 + features_time 3
+
+
+def dynamic_algorithmic_bytes(N, V, I, P, T, D):
+    """Compulsory HBM bytes per launch of the entry points of config 5's step.  D = render channels."""
+    proj_f = 40 * N + 4 * N + 24 * V + 4 * D * V            # SURVEY 8(d) projection + the colour columns of the visible rows
+    proj_b = 92 * V + 40 * N + 4 * N + 4 * D * V
+    slice_f, slice_b = 128 * N, 216 * N                     # csrc/dynamic.hip: 92 B in + 36 B out | 92 + 32 B in + 92 B out
+    return {
+        "gs_quantize_round_fwd": 8 * DYN_QUANT_FLOATS * N,  # SURVEY 8(d): 8 A bytes per splat (all six hooked tensors together)
+        "gs_temporal_slice_fwd": slice_f, "gs_temporal_slice_bwd": slice_b,
+        "gs_projection_rows_fwd": proj_f, "gs_projection_rows_bwd": proj_b,
+        # fused: the slice's inputs are read by the projection itself (+ 36 B per splat of motion / omega / centre / scale rows that
+        # the means_t / quats_t / opacity_t round trip replaces), its gradients written by the projection backward for the V
+        # visible splats only (23 floats: means 3 + motion 9 + quats 4 + omega 4 + opacity, centre, scale)
+        "gs_projection_rows_dyn_fwd": proj_f + 36 * N, "gs_projection_rows_dyn_bwd": proj_b + 36 * N + 92 * V,
+        "gs_rasterize_fwd": (28 + 4 * D) * I + (4 * D + 8) * P,   # 40 I + 20 P at D = 3 (SURVEY 8d)
+        "gs_rasterize_bwd": (28 + 4 * D) * I + (4 * D + 12) * P + (24 + 4 * D) * V,
+        "gs_isect_finish_presorted": (24 * V + 12 * I) + 24 * I + (8 * I + 4 * T),
+        "gs_presort_buckets": 24 * V, "gs_isect_count_keys": 16 * N + 4 * N + 12 * N, "gs_presort_split": 0,
+    }
+
+
+def main_dynamic(args):
+    """`bench.py --dynamic`: BASELINE config 5's step on one frame -- N = 2 M dynamic splats, one 1080p camera:
+    STGCompressionSimulation("round") hooks over the 17 hooked floats (reference simulation.py:508-780) -> activations ->
+    temporal slice at a timestamp (simple_trainer_dyngs.py:506-521) -> rasterization -> backward of sum(render).
+    --gpus N: frames round-robin, rank r renders its own timestamp of the same splats; the step ends with the RCCL sum of the
+    parameter gradients (weak scaling over frames, value = N_splats x frames / step time)."""
+    world, rank, use_pg, dev = init_ranks(args)
+    from gscodec_studio_amd import _backend as B
+    from gscodec_studio_amd import rasterization
+    from gscodec_studio_amd._helper import DYNAMIC_KEYS, dynamic_workload
+    from gscodec_studio_amd.compression_simulation import STGCompressionSimulation
+    from gscodec_studio_amd.distributed import all_reduce_splat_grads
+    from gscodec_studio_amd.dynamic import render_dynamic, temporal_slice
+
+    B.lib()
+    w = dynamic_workload(args.dynamic_splats, args.width, args.height, device=dev)
+    N, W_, H_ = w["N"], w["width"], w["height"]
+    viewmats, Ks = w["viewmats"], w["Ks"]
+    params = {k: w[k].clone().requires_grad_(True) for k in DYNAMIC_KEYS}
+    sim = STGCompressionSimulation(quantization_sim_type="round", entropy_steps={}, device=dev)
+    t_frame = (args.timestamp + 0.37 * rank) % 1.0
+    D = args.dynamic_channels
+    form = args.dynamic_form
+    last_meta = {}
+
+    def features(q, tau):
+        if D == 3:
+            return q["colors"]                                                              # simple_trainer_dyngs.py:519-520
+        return torch.cat((q["colors"], q["features_dir"], tau * q["features_time"]), dim=1)  # simple_trainer_STG.py:531
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        if form == "full":
+            rc, ra, meta = render_dynamic(params, t_frame, viewmats, Ks, W_, H_, compression_sim=sim, step=1,
+                                          features="colors" if D == 3 else "stg", packed=False)
+            rc.sum().backward()
+            if use_pg:
+                all_reduce_splat_grads(params, world_size=world, average=False)
+            last_meta.update(meta)
+            return
+        if form == "reference":
+            q, _ = sim.simulate_compression(params, step=1)
+            scales, opac, tscale = torch.exp(q["scales"]), torch.sigmoid(q["opacities"]), torch.exp(q["trbf_scale"])
+        else:
+            q, _ = sim.simulate_compression(params, step=1, activate=True)
+            scales, opac, tscale = q["scales"], q["opacities"], torch.exp(q["trbf_scale"])
+        tau = (t_frame - q["trbf_center"]).detach() if D == 9 else None
+        if form == "fused":
+            rc, ra, meta = rasterization(q["means"], q["quats"], scales, opac, features(q, tau), viewmats, Ks, W_, H_, packed=False,
+                                         dynamic=(q["motion"], q["omega"], q["trbf_center"], tscale, t_frame))
+        else:
+            means_t, quats_t, opac_t, _ = temporal_slice(q["means"], q["motion"], q["quats"], q["omega"], opac, q["trbf_center"], tscale,
+                                                         t_frame)
+            rc, ra, meta = rasterization(means_t, quats_t, scales, opac_t, features(q, tau), viewmats, Ks, W_, H_, packed=False)
+        rc.sum().backward()
+        if use_pg:
+            all_reduce_splat_grads(params, world_size=world, average=False)
+        last_meta.update(meta)
+
+    def max_over_ranks(x):
+        if not use_pg:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier():
+        if use_pg:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # pass A (untimed): every C-ABI entry point with events, on the operator path (see main())
+    from gscodec_studio_amd import _step
+    step_driver_on = _step.ENABLED
+    _step.ENABLED = False
+    for _ in range(2):
+        step()
+    with CallTimer(B) as ct:
+        for _ in range(2):
+            step()
+    _step.ENABLED = step_driver_on
+    for _ in range(2):
+        step()
+    per_call = {k: float(np.mean(v)) for k, v in ct.totals_ms().items()}
+    calls_per_step = {k: len(v) / 2 for k, v in ct.events.items()}
+    per_step = {k: per_call[k] * calls_per_step[k] for k in per_call}
+    dominant = max((k for k in per_step if not k.startswith("gs_step_")), key=per_step.get)
+
+    def timed_region(n_steps, timer_only):
+        barrier()
+        with CallTimer(B, only=timer_only) as ct_:
+            t0_ = time.perf_counter()
+            for _ in range(n_steps):
+                step()
+            barrier()
+            t1_ = time.perf_counter()
+        return max_over_ranks(t1_ - t0_), ct_
+
+    gc.collect()
+    gc.disable()
+    if args.ramp_s > 0:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step()
+        barrier()
+        for _ in range(int(min(5000, args.ramp_s / max(max_over_ranks(time.perf_counter() - t0) / 5, 1e-5)))):
+            step()
+    torch.cuda.reset_peak_memory_stats(dev)
+    elapsed, ct = timed_region(args.steps, {dominant})
+    dom_all = list(ct.totals_ms().get(dominant, ())) or [per_call[dominant]]
+    peak_mem = torch.cuda.max_memory_allocated(dev)
+    regions = [elapsed]
+    for _ in range(int(min(200, max(0, np.ceil(args.min_timed_s / max(elapsed, 1e-6)) - 1)))):
+        regions.append(timed_region(args.steps, set())[0])
+    gc.enable()
+    dom_ms = float(np.mean(dom_all))
+    ms_per_step = sum(regions) / (len(regions) * args.steps) * 1e3
+
+    if rank == 0:
+        meta = last_meta
+        V, I = int((meta["radii"] > 0).sum()), int(meta["flatten_ids"].numel())
+        P, T = W_ * H_, meta["tile_width"] * meta["tile_height"]
+        alg = dynamic_algorithmic_bytes(N, V, I, P, T, D)
+        # whole step: SURVEY 8(d)'s closed form with the [N, D] colours in place of the SH rows, plus the hooks (8 A each way is the
+        # survey's figure; the round STE's backward is the identity: 0) and the slice both ways
+        total_alg = (alg["gs_quantize_round_fwd"] + alg["gs_temporal_slice_fwd"] + alg["gs_projection_rows_fwd"]
+                     + (32 * V + 4 * N + 12 * I) + 24 * I + (8 * I + 4 * T) + alg["gs_rasterize_fwd"]
+                     + alg["gs_rasterize_bwd"] + alg["gs_projection_rows_bwd"] + alg["gs_temporal_slice_bwd"])
+        achieved = alg.get(dominant, 0) / (dom_ms * 1e-3) / 1e9
+        gpu_entry_ms = sum(per_step.values())
+        out = {
+            "metric": "Msplats/s fwd+bwd @1080p (2M dynamic splats, config 5 step)",
+            "value": N * world / (ms_per_step * 1e-3) / 1e6, "unit": "Msplats/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "timed": {"regions": len(regions), "steps_per_region": args.steps, "total_s": sum(regions), "untimed_ramp_s": args.ramp_s,
+                      "ms_per_step_min_region": min(regions) / args.steps * 1e3, "ms_per_step_max_region": max(regions) / args.steps * 1e3},
+            "peak_mem_gb": peak_mem / 2**30,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE config 5, one frame per step: {N} dynamic gaussians (load_test_data grid {w['scene_grid']}, seeded shuffle, "
+                            f"synthetic motion / omega / trbf), STGCompressionSimulation('round') hooks over {DYN_QUANT_FLOATS} floats -> "
+                            f"temporal slice at t = {t_frame:.2f} -> rasterization([N, {D}]) {world}x1 camera {W_}x{H_}, packed=False, tile 16 "
+                            f"-> backward of sum(render)",
+                "form": {"reference": "the trainer's call pattern: hooks, torch.exp / sigmoid, temporal_slice(), rasterization()",
+                         "activate": "simulate_compression(activate=True), temporal_slice(), rasterization()",
+                         "fused": "simulate_compression(activate=True), rasterization(dynamic=...): the slice inside the projection kernels",
+                         "full": "dynamic.render_dynamic(raw parameters, sim): round hooks, activations and slice inside the projection kernels "
+                                 "(rasterization(dynamic=DynamicSlice(raw=..., quantize=...)))"}[form],
+                "visible": V, "n_isects": I, "channels": D, "native_step_driver": bool(step_driver_on),
+                "parallelism": f"frames round-robin over {world} rank(s)" + (", RCCL sum of the parameter gradients" if world > 1 else ""),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "kernel_ms": dom_ms, "algorithmic_bytes": alg.get(dominant, 0),
+                "whole_step": {"algorithmic_bytes": total_alg, "achieved": total_alg / (ms_per_step * 1e-3) / 1e9,
+                               "frac": total_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "formula": "hooks 8*17 N + slice (128 + 216) N + SURVEY 8(d) with [N, D] colours"},
+                "per_entry_point_ms": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+                "entry_points_ms": gpu_entry_ms,
+                # what the step spends OUTSIDE the C-ABI entry points (torch's own kernels: `p + 0.` copies of the un-hooked parameters,
+                # exp / sigmoid, cat, sum, gradient accumulation) when the GPU is the bound: step time - entry-point time
+                "outside_entry_points_ms": ms_per_step - gpu_entry_ms,
+                "streaming": {k: {"ms": round(per_step[k], 4), "calls_per_step": calls_per_step[k], "algorithmic_bytes": alg[k],
+                                  "achieved": alg[k] / (per_step[k] * 1e-3) / 1e9, "unit": "GB/s",
+                                  "frac": alg[k] / (per_step[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "frac_of_measured_copy_rate": alg[k] / (per_step[k] * 1e-3) / 1e9 / HBM_COPY_GBS}
+                              for k in ("gs_quantize_round_fwd", "gs_temporal_slice_fwd", "gs_temporal_slice_bwd", "gs_projection_rows_fwd",
+                                        "gs_projection_rows_bwd", "gs_projection_rows_dyn_fwd", "gs_projection_rows_dyn_bwd")
+                              if k in per_step and per_step[k] > 0},
+            },
+        }
+    if use_pg:
+        dist.barrier()
+        dist.destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+
+
+def init_ranks(args, force_pg=False):
+    """One process per GPU: rank / world from the launcher's environment, the process group (RCCL; gloo with GS_BENCH_SHARE_GPU=1)
+    -> (world, rank, use_pg, dev)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if (os.environ.get("GS_BENCH_TEST_KILL_RANK") == str(rank) and world > 1 and
@@ -403,7 +625,7 @@ def main():
         sys.exit(17)  # (tests/test_gpu_bench_launch.py: a rank that dies -- in the first attempt only, or in every attempt)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # GS_BENCH_PG=1 / a forced mode: one GPU still goes through the process group and RCCL (debugging aid)
-    use_pg = world > 1 or args.dp_mode.startswith("gaussian") or os.environ.get("GS_BENCH_PG") == "1"
+    use_pg = world > 1 or force_pg or os.environ.get("GS_BENCH_PG") == "1"
     if use_pg:
         import datetime
 
@@ -427,6 +649,17 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+
+    return world, rank, use_pg, dev
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.dynamic:
+        return main_dynamic(args)
+    world, rank, use_pg, dev = init_ranks(args, force_pg=args.dp_mode.startswith("gaussian"))
 
     from gscodec_studio_amd import _backend as B
     from gscodec_studio_amd import rasterization

@@ -100,3 +100,34 @@ def sh_workload(scene_grid: int = 3, width: int = 1920, height: int = 1080, n_ca
     d = {k: v.contiguous().to(device) for k, v in d.items()}
     d.update(width=width, height=height, sh_degree=sh_degree, N=N)
     return d
+
+
+DYNAMIC_KEYS = ("means", "scales", "quats", "opacities", "trbf_center", "trbf_scale", "motion", "omega", "colors", "features_dir",
+                "features_time")
+
+
+def dynamic_workload(n_splats: int = 2_000_000, width: int = 1920, height: int = 1080, device="cuda", seed: int = 42) -> Dict:
+    """BASELINE.json config 5, one frame of it: ``n_splats`` DYNAMIC (spacetime) gaussians with the trainer's raw parameter set
+    (reference examples/simple_trainer_dyngs.py:283-332: means, log-scales, quats, opacity logits, trbf_center, log trbf_scale,
+    motion [N,9], omega [N,4], colors / features_dir / features_time [N,3]) and one 1080p camera.  The static part is the
+    ``load_test_data`` scene (the smallest odd grid with at least ``n_splats`` gaussians, the first ``n_splats`` of a seeded
+    shuffle); the temporal part is drawn so that, as in a trained spacetime scene, only part of the splats is alive at a given
+    timestamp: centres ~ U(0,1), log-scale ~ U(-1.5, 0.5), motion ~ 0.02 N(0,1), omega ~ 0.1 N(0,1)."""
+    grid = 1
+    while grid * grid * 111_785 < n_splats:
+        grid += 2
+    means, quats, scales, opacities, rgb, viewmats, Ks, w0, h0 = load_test_data(device="cpu", scene_grid=grid, seed=seed)
+    g = torch.Generator().manual_seed(seed + 2)
+    sel = torch.randperm(means.shape[0], generator=g)[:n_splats]
+    n = int(sel.numel())
+    Ks = rescale_intrinsics(Ks, w0, h0, width, height)
+    op = opacities[sel].clamp(1e-4, 1 - 1e-4)
+    d = dict(
+        means=means[sel], scales=scales[sel].clamp_min(1e-6).log(), quats=quats[sel], opacities=torch.log(op / (1 - op)),
+        trbf_center=torch.rand((n, 1), generator=g), trbf_scale=torch.rand((n, 1), generator=g) * 2.0 - 1.5,
+        motion=0.02 * torch.randn((n, 9), generator=g), omega=0.1 * torch.randn((n, 4), generator=g),
+        colors=rgb[sel], features_dir=torch.randn((n, 3), generator=g), features_time=torch.randn((n, 3), generator=g),
+        viewmats=viewmats[:1], Ks=Ks[:1])
+    d = {k: v.contiguous().float().to(device) for k, v in d.items()}
+    d.update(width=width, height=height, N=n, scene_grid=grid)
+    return d

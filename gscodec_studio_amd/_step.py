@@ -61,12 +61,16 @@ class _Step(ctypes.Structure):  # gs_step of include/gsplat_hip.h (field for fie
         ("grad_rows", _P), ("v_depths", _P), ("v_means", _P), ("v_covars", _P), ("v_quats", _P), ("v_scales", _P),
         ("v_opacities", _P), ("v_colors", _P), ("v_sh", _P), ("v_sh_rest", _P),
         ("absgrad", _I32), ("outputs_prefilled", _I32), ("skip_projection_bwd", _I32), ("finish_phase", _I32),
+        ("dyn_motion", _P), ("dyn_omega", _P), ("dyn_trbf_center", _P), ("dyn_trbf_scale", _P),
+        ("dyn_timestamp", _F), ("dyn_raw_params", _U32), ("dyn_quant_mask", _U32), ("reserved2", _U32),
+        ("dyn_quant_lo", _F * 4), ("dyn_quant_hi", _F * 4), ("dyn_quant_range", _F * 4), ("dyn_quant_step_norm", _F * 4),
+        ("v_dyn_motion", _P), ("v_dyn_omega", _P), ("v_dyn_trbf_center", _P), ("v_dyn_trbf_scale", _P),
     ]
 
 
 _LAYOUT_FIELDS = ("C", "sh_K", "eps2d", "tile_size", "sh_mask_logits", "rows_ready", "backgrounds", "radii", "sort_temp_bytes", "block_sums",
                   "n_isects", "n_kept_host", "work_bytes", "plan", "scratch", "zero_fill_bytes", "v_render_colors", "vrc_pixel_stride", "grad_rows",
-                  "v_sh_rest", "absgrad", "finish_phase")
+                  "v_sh_rest", "absgrad", "finish_phase", "dyn_motion", "dyn_timestamp", "dyn_quant_lo", "v_dyn_motion")
 
 
 def check_layout() -> None:
@@ -224,7 +228,8 @@ def _finish(s, sp, stream, bufs, n_sums, C, N, height, width, tile_height, tile_
 
 class _StepProject(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, sh_rest, mask_logits, backgrounds, cfg, hand):
+    def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, sh_rest, mask_logits, backgrounds, cfg, hand,
+                dyn_motion=None, dyn_omega=None, dyn_center=None, dyn_tscale=None, dyn=None):
         (width, height, eps2d, near_plane, far_plane, radius_clip, antialiased, camera_model, sh_degree, tile_size, tile_width,
          tile_height, needs_bwd, mask_cfg) = cfg
         mask_logits = _c(mask_logits)
@@ -249,6 +254,15 @@ class _StepProject(torch.autograd.Function):
         cm = W._CAMERA_MODELS[camera_model]
         s.camera_model, s.antialiased = cm, int(antialiased)
         s.tile_size, s.tile_width, s.tile_height = tile_size, tile_width, tile_height
+        ctx.dyn, ctx.dyn_first = None, 14
+        if dyn is not None:  # dynamic splats: the slice (+ activations / round quantizer) inside the projection kernel
+            dt = dyn.bind(quats, scales, opacities, colors, dyn_motion, dyn_omega, dyn_center, dyn_tscale)
+            (s.dyn_motion, s.dyn_omega, s.dyn_trbf_center, s.dyn_trbf_scale, s.dyn_timestamp, s.dyn_raw_params, s.dyn_quant_mask,
+             lo_, hi_, rng_, qn_) = dyn.c_args(dt)
+            for dst, src in ((s.dyn_quant_lo, dyn._tables[0]), (s.dyn_quant_hi, dyn._tables[1]), (s.dyn_quant_range, dyn._tables[2]),
+                             (s.dyn_quant_step_norm, dyn._tables[3])):
+                dst[:] = src[:]
+            ctx.dyn = (dyn, dt)
         n_sums = C * ((N + 255) // 256)  # gs_projection_rows_blocks(N) per camera: the projection counts the tiles itself
         bufs = _phase1(s, C, N, dev, n_sums)
         radii, depths, rows, tiles_per_gauss = bufs["radii"], bufs["depths"], bufs["rows"], bufs["tiles_per_gauss"]
@@ -263,6 +277,7 @@ class _StepProject(torch.autograd.Function):
             prefill.request = [(key, tuple(t.shape)) for key, t, flag in (
                 ("means", means, need[0]), ("covars", covars, need[1]), ("quats", quats, need[2]), ("scales", scales, need[3]),
                 ("opacities", opacities, need[6]), ("colors", colors, need[7]), ("sh", sh_coeffs, need[8]), ("sh_rest", sh_rest, need[9]))
+                + (W.dyn_prefill_items(ctx.dyn, need, 14) if ctx.dyn is not None else ())
                 if t is not None and flag]
         try:
             with torch.cuda.device(dev):
@@ -292,7 +307,8 @@ class _StepProject(torch.autograd.Function):
     def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_opac, v_colors, v_rows, *_ints):
         g = W._ProjectRows.backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_opac, v_colors, v_rows)
         # _ProjectRows' inputs: means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, sh_rest, ...
-        return (g[0], g[1], g[2], g[3], g[4], None, g[6], g[7], g[8], g[9], g[10], None, None, None)
+        head = (g[0], g[1], g[2], g[3], g[4], None, g[6], g[7], g[8], g[9], g[10], None, None, None)
+        return head + tuple(g[22:27]) if ctx.dyn is not None else head
 
 
 class _StepComposite(torch.autograd.Function):
@@ -411,20 +427,26 @@ def _init_consts() -> int:
 
 
 def rasterize_step(means, covars, quats, scales, opacities, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
-                   antialiased, camera_model, row_colors, sh_coeffs, sh_rest, sh_degree, tile_size, backgrounds, absgrad, sh_mask=None):
+                   antialiased, camera_model, row_colors, sh_coeffs, sh_rest, sh_degree, tile_size, backgrounds, absgrad, sh_mask=None,
+                   dynamic=None):
     """The fast path's forward; returns ``(render_colors, render_alphas, meta)`` with the reference's meta keys."""
     C, N = viewmats.shape[0], means.shape[0]
     tile_width, tile_height = math.ceil(width / float(tile_size)), math.ceil(height / float(tile_size))
     mask_logits = sh_mask[0] if sh_mask is not None else None
+    dyn_in = ()
+    if dynamic is not None:
+        dynamic.check(N)
+        dyn_in = (dynamic.motion, dynamic.omega, dynamic.trbf_center, dynamic.trbf_scale)
     needs_bwd = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (means, covars, quats, scales, opacities, row_colors, sh_coeffs, sh_rest, backgrounds,
-                                                    mask_logits))
+                                                    mask_logits) + dyn_in)
     hand = _Handover()
     cfg = (int(width), int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip), bool(antialiased), camera_model,
            sh_degree, int(tile_size), tile_width, tile_height, needs_bwd,
            (float(sh_mask[1]), bool(sh_mask[2])) if sh_mask is not None else None)
     (radii, means2d, depths, conics, opac_cn, colors_cn, rows, tiles_per_gauss, isect_ids, flatten_ids, offsets) = _StepProject.apply(
-        means, covars, quats, scales, viewmats, Ks, opacities, row_colors, sh_coeffs, sh_rest, mask_logits, backgrounds, cfg, hand)
+        means, covars, quats, scales, viewmats, Ks, opacities, row_colors, sh_coeffs, sh_rest, mask_logits, backgrounds, cfg, hand,
+        *(dyn_in + (dynamic,) if dynamic is not None else ()))
     render_colors, render_alphas = _StepComposite.apply(means2d, conics, colors_cn, opac_cn, backgrounds,
                                                         (int(width), int(height), int(tile_size), bool(absgrad)), hand)
     meta = {

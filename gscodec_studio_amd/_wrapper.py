@@ -860,6 +860,7 @@ def project_rows(
     sh_rest: Optional[Tensor] = None,  # SPLIT coefficients: ``sh_coeffs`` is the DC band [N, 1, 3], this [N, K-1, 3]
     prefill: Optional[GradPrefill] = None,  # see GradPrefill; hand the same object to ``rasterize_to_pixels``
     sh_mask=None,  # (mask_logits with N elements, temperature, binary): the shN mask applied on the fly (split rows only)
+    dynamic=None,  # dynamic.DynamicSlice: the temporal slice (+ opt-in activations / round quantizer) evaluated by the projection itself
 ):
     """``fully_fused_projection`` in ROW form, what ``rasterization`` uses for unpacked batches: the same projection, but
     every (camera, gaussian) pair gets one 64-byte splat row (include/gsplat_hip.h) that the compositing kernels fetch
@@ -905,6 +906,13 @@ def project_rows(
         assert sh_rest is not None, "the shN mask needs split coefficients (sh_rest)"
         mask_logits, mask_cfg = sh_mask[0], (float(sh_mask[1]), bool(sh_mask[2]))
         assert mask_logits.numel() == N, (mask_logits.shape, N)
+    if dynamic is not None:
+        assert covars is None and sh_coeffs is None, "dynamic splats: quats + scales and [N, 3] colours (or none) only"
+        dynamic.check(N)
+        return _ProjectRows.apply(means.contiguous(), covars, quats, scales, viewmats.contiguous(), Ks.contiguous(),
+                                  opacities.contiguous(), colors, sh_coeffs, sh_rest, mask_logits, width, height, eps2d, near_plane, far_plane,
+                                  radius_clip, antialiased, camera_model, sh_degree, prefill, mask_cfg, dynamic.motion, dynamic.omega,
+                                  dynamic.trbf_center, dynamic.trbf_scale, dynamic)
     return _ProjectRows.apply(means.contiguous(), covars, quats, scales, viewmats.contiguous(), Ks.contiguous(),
                               opacities.contiguous(), colors, sh_coeffs, sh_rest, mask_logits, width, height, eps2d, near_plane, far_plane,
                               radius_clip, antialiased, camera_model, sh_degree, prefill, mask_cfg)
@@ -955,11 +963,49 @@ def _grad_rows_of(parts, shape, device):
     return G.data_ptr(), G
 
 
+def dyn_prefill_items(dyn_ctx, need, first: int):
+    """(key, tensor, wanted) of the four extra inputs of the dynamic route (motion, omega, trbf_center, trbf_scale) for GradPrefill."""
+    _, dt = dyn_ctx
+    return (("motion", dt[0], need[first]), ("omega", dt[1], need[first + 1]), ("trbf_center", dt[2], need[first + 2]),
+            ("trbf_scale", dt[3], need[first + 3]))
+
+
+def _project_rows_dyn_bwd(ctx, dyn_ctx, need, out, prefilled, g_ptr, g_keep, v_depths):
+    """``_ProjectRows.backward`` of the dynamic route: gs_projection_rows_dyn_bwd = the projection VJP + the slice / activation /
+    STE VJPs for the gaussians some camera saw; returns the gradient tuple in the order of ``_ProjectRows.forward``'s inputs."""
+    means, covars, quats, scales, viewmats, Ks, opacities, radii, rows, sh_coeffs, sh_rest = ctx.saved_tensors
+    dyn, dt = dyn_ctx
+    motion, omega, center, tscale = dt
+    C, N = viewmats.shape[0], means.shape[0]
+    f = ctx.dyn_first
+    if need[4]:
+        raise RuntimeError("rasterization(dynamic=...): camera-pose gradients are not available on the fused dynamic route")
+    v_depths = _f32c(v_depths) if v_depths is not None else None
+    v_means = out("means", means) if need[0] else None
+    v_quats = out("quats", quats) if need[2] else None
+    v_scales = out("scales", scales) if need[3] else None
+    v_opac = out("opacities", opacities) if need[6] else None
+    v_colors = (out("colors", torch.empty(0)) if prefilled else torch.empty((N, 3), dtype=torch.float32, device=means.device)) \
+        if (ctx.has_colors and need[7]) else None
+    v_motion = out("motion", motion) if need[f] else None
+    v_omega = out("omega", omega) if need[f + 1] else None
+    v_center = out("trbf_center", center) if need[f + 2] else None
+    v_tscale = out("trbf_scale", tscale) if need[f + 3] else None
+    with _device_of(means):
+        B.call("gs_projection_rows_dyn_bwd", C, N, B.ptr(means), B.ptr(quats), B.ptr(scales), *dyn.c_args(dt), B.ptr(viewmats), B.ptr(Ks),
+               int(ctx.width), int(ctx.height), float(ctx.eps2d), ctx.cm, B.ptr(radii), B.ptr(rows), g_ptr, B.ptr(v_depths), B.ptr(opacities),
+               int(ctx.antialiased), B.ptr(v_means), B.ptr(v_quats), B.ptr(v_scales), B.ptr(v_motion), B.ptr(v_omega), B.ptr(v_center),
+               B.ptr(v_tscale), B.ptr(v_opac), B.ptr(v_colors), int(prefilled), _stream(means))
+    del g_keep
+    return (v_means, None, v_quats, v_scales, None, None, v_opac, v_colors, None, None, None) + (None,) * 11 + (
+        v_motion, v_omega, v_center, v_tscale, None)
+
+
 class _ProjectRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, covars, quats, scales, viewmats, Ks, opacities, colors, sh_coeffs, sh_rest, mask_logits, width, height,
                 eps2d, near_plane, far_plane, radius_clip, antialiased, camera_model="pinhole", sh_degree=None, prefill=None,
-                mask_cfg=None):
+                mask_cfg=None, dyn_motion=None, dyn_omega=None, dyn_center=None, dyn_tscale=None, dyn=None):
         _require_gpu(means, "project_rows")
         means, covars, quats, scales = _f32c(means), _f32c(covars), _f32c(quats), _f32c(scales)
         viewmats, Ks, opacities, colors = _f32c(viewmats), _f32c(Ks), _f32c(opacities), _f32c(colors)
@@ -972,7 +1018,18 @@ class _ProjectRows(torch.autograd.Function):
         depths = torch.empty((C, N), dtype=torch.float32, device=dev)
         rows = torch.empty((C, N, ROW), dtype=torch.float32, device=dev)  # (torch's allocator aligns to 512 bytes)
         cm = _CAMERA_MODELS[camera_model]
-        with _device_of(means):
+        ctx.dyn = None
+        if dyn is not None:
+            # dynamic splats: quantizer -> activation -> temporal slice in the projection's load phase (csrc/projection_dyn.hip)
+            dtens = dyn.bind(quats, scales, opacities, colors, dyn_motion, dyn_omega, dyn_center, dyn_tscale)
+            with _device_of(means):
+                B.call("gs_projection_rows_dyn_fwd", C, N, B.ptr(means), B.ptr(quats), B.ptr(scales), *dyn.c_args(dtens), B.ptr(viewmats),
+                       B.ptr(Ks), int(width), int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip), cm,
+                       B.ptr(opacities), B.ptr(colors), int(bool(antialiased)), 0, 0, 0, None, None, B.ptr(radii), B.ptr(depths),
+                       B.ptr(rows), _stream(means))
+            ctx.dyn = (dyn, dtens)
+        else:
+          with _device_of(means):
             B.call("gs_projection_rows_fwd", C, N, B.ptr(means), B.ptr(covars), B.ptr(quats), B.ptr(scales),
                    B.ptr(viewmats), B.ptr(Ks), int(width), int(height), float(eps2d), float(near_plane),
                    float(far_plane), float(radius_clip), cm, B.ptr(opacities), B.ptr(colors), int(bool(antialiased)),
@@ -983,13 +1040,15 @@ class _ProjectRows(torch.autograd.Function):
         ctx.width, ctx.height, ctx.eps2d, ctx.cm, ctx.antialiased = width, height, eps2d, cm, bool(antialiased)
         ctx.has_colors, ctx.sh_degree = colors is not None, (int(sh_degree) if sh_coeffs is not None else None)
         ctx.prefill = None
+        ctx.dyn_first = 22  # position of dyn_motion among this Function's inputs (_StepProject overrides it)
         need = ctx.needs_input_grad
-        if prefill is not None and any(need[:10]) and not need[4] and N > 0:
+        if prefill is not None and (any(need[:10]) or (dyn is not None and any(need[22:26]))) and not need[4] and N > 0:
             # what the backward will return per gaussian, for the compositing forward to allocate and zero-fill
             req = []
             for key, t, flag in (("means", means, need[0]), ("covars", covars, need[1]), ("quats", quats, need[2]),
                                  ("scales", scales, need[3]), ("opacities", opacities, need[6]),
-                                 ("colors", colors, need[7]), ("sh", sh_coeffs, need[8]), ("sh_rest", sh_rest, need[9])):
+                                 ("colors", colors, need[7]), ("sh", sh_coeffs, need[8]), ("sh_rest", sh_rest, need[9])) + (
+                    dyn_prefill_items(ctx.dyn, need, 22) if ctx.dyn is not None else ()):
                 if t is not None and flag:
                     req.append((key, tuple(t.shape)))
             prefill.request = req
@@ -1016,12 +1075,18 @@ class _ProjectRows(torch.autograd.Function):
                                   ("scales", scales, need[3]), ("opacities", opacities, need[6]),
                                   ("colors", True if ctx.has_colors else None, need[7]), ("sh", sh_coeffs, need[8]),
                                   ("sh_rest", sh_rest, need[9])) if t is not None and f]
+        dyn = getattr(ctx, "dyn", None)
+        if dyn is not None:
+            want += [k for k, t, f in dyn_prefill_items(dyn, need, ctx.dyn_first) if f]
         prefilled = bool(pre) and all(k in pre for k in want) and (sh_coeffs is None or (need[8] and (sh_rest is None or need[9])))
         if not prefilled:
             pre = {}
 
         def out(key, like):
             return pre[key] if prefilled else torch.empty_like(like)
+
+        if dyn is not None:
+            return _project_rows_dyn_bwd(ctx, dyn, need, out, prefilled, g_ptr, g_keep, v_depths)
 
         v_sh = v_rest = v_means_add = v_mask = None
         mask = getattr(ctx, "mask", None)

@@ -9,8 +9,10 @@
 //     quats_t  = normalize(quats + tau omega)            F.normalize: x / max(|x|, 1e-12)
 // ~25 elementwise torch kernels (each a pass over N x 3..9 floats) become one streaming kernel each
 // way: forward reads 92 B and writes 36 B per splat, backward reads 128 B and writes 92 B.
-// One lane per splat; rows are 12..36 B so accesses are partially coalesced, like the projection kernel.
+// One lane per splat; rows are 12..36 B so accesses are partially coalesced, like the projection kernel.  The per-splat arithmetic lives
+// in dynamic_dev.h (shared with projection_dyn.hip, which evaluates the slice inside the projection pass instead).
 #include "gs_common.h"
+#include "dynamic_dev.h"
 
 namespace {
 
@@ -22,26 +24,25 @@ struct SliceArgs {
 
 __global__ void __launch_bounds__(GS_BLOCK) temporal_slice_fwd_kernel(SliceArgs a, float *__restrict__ means_t, float *__restrict__ quats_t,
                                                                       float *__restrict__ opacity_t, float *__restrict__ trbf_out) {
+    GS_FP_STRICT;
     const uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x;
     if (i >= a.n) return;
-    const float tau = a.t - a.trbf_center[i];
-    const float d = tau / (1.4142135623730951f * a.trbf_scale[i]);
-    const float trbf = expf(-d * d);
-    opacity_t[i] = a.opacities[i] * trbf;
-    if (trbf_out != nullptr) trbf_out[i] = trbf;
-    const float t2 = tau * tau, t3 = t2 * tau;
+    const SliceTime st = slice_time(a.t, a.trbf_center[i], a.trbf_scale[i]);
+    opacity_t[i] = (a.opacities[i] * st.trbf);
+    if (trbf_out != nullptr) trbf_out[i] = st.trbf;
+    const float tau = st.tau, t2 = (tau * tau), t3 = (t2 * tau);
     const float *m = a.motion + 9 * (size_t)i;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) means_t[3 * (size_t)i + k] = a.means[3 * (size_t)i + k] + m[k] * tau + m[3 + k] * t2 + m[6 + k] * t3;
-    float q[4], nn = 0.f;
+    for (int k = 0; k < 3; ++k) means_t[3 * (size_t)i + k] = slice_mean(a.means[3 * (size_t)i + k], m[k], m[3 + k], m[6 + k], tau, t2, t3);
+    float qin[4], om[4], x[4], q[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        q[k] = a.quats[4 * (size_t)i + k] + tau * a.omega[4 * (size_t)i + k];
-        nn += q[k] * q[k];
+        qin[k] = a.quats[4 * (size_t)i + k];
+        om[k] = a.omega[4 * (size_t)i + k];
     }
-    const float inv = 1.f / fmaxf(sqrtf(nn), 1e-12f);
+    slice_quat(qin, om, tau, x, q);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) quats_t[4 * (size_t)i + k] = q[k] * inv;
+    for (int k = 0; k < 4; ++k) quats_t[4 * (size_t)i + k] = q[k];
 }
 
 __global__ void __launch_bounds__(GS_BLOCK) temporal_slice_bwd_kernel(SliceArgs a, const float *__restrict__ v_means_t,
@@ -50,58 +51,44 @@ __global__ void __launch_bounds__(GS_BLOCK) temporal_slice_bwd_kernel(SliceArgs 
                                                                       float *__restrict__ v_motion, float *__restrict__ v_quats,
                                                                       float *__restrict__ v_omega, float *__restrict__ v_opacities,
                                                                       float *__restrict__ v_center, float *__restrict__ v_scale) {
+    GS_FP_STRICT;
     const uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x;
     if (i >= a.n) return;
-    const float tau = a.t - a.trbf_center[i];
     const float s = a.trbf_scale[i];
-    const float d = tau / (1.4142135623730951f * s);
-    const float trbf = expf(-d * d);
+    const SliceTime st = slice_time(a.t, a.trbf_center[i], s);
+    const float tau = st.tau;
     // opacity and the basis itself
     const float vo = v_opacity_t != nullptr ? v_opacity_t[i] : 0.f;
-    float g_trbf = vo * a.opacities[i];
-    if (v_trbf != nullptr) g_trbf += v_trbf[i];
-    if (v_opacities != nullptr) v_opacities[i] = vo * trbf;
-    // d trbf / d d = -2 d trbf;  d d / d center = -1 / (sqrt2 s);  d d / d s = -d / s
-    const float g_d = g_trbf * (-2.f * d * trbf);
-    if (v_center != nullptr) v_center[i] = -g_d / (1.4142135623730951f * s);
-    if (v_scale != nullptr) v_scale[i] = -g_d * d / s;
+    float g_trbf = (vo * a.opacities[i]);
+    if (v_trbf != nullptr) g_trbf = (g_trbf + v_trbf[i]);
+    if (v_opacities != nullptr) v_opacities[i] = (vo * st.trbf);
+    float vc, vs;
+    slice_time_vjp(st, s, g_trbf, vc, vs);
+    if (v_center != nullptr) v_center[i] = vc;
+    if (v_scale != nullptr) v_scale[i] = vs;
     // motion: tau is detached there
-    const float t2 = tau * tau, t3 = t2 * tau;
+    const float t2 = (tau * tau), t3 = (t2 * tau);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float g = v_means_t != nullptr ? v_means_t[3 * (size_t)i + k] : 0.f;
         if (v_means != nullptr) v_means[3 * (size_t)i + k] = g;
         if (v_motion != nullptr) {
-            v_motion[9 * (size_t)i + k] = g * tau;
-            v_motion[9 * (size_t)i + 3 + k] = g * t2;
-            v_motion[9 * (size_t)i + 6 + k] = g * t3;
+            v_motion[9 * (size_t)i + k] = (g * tau);
+            v_motion[9 * (size_t)i + 3 + k] = (g * t2);
+            v_motion[9 * (size_t)i + 6 + k] = (g * t3);
         }
     }
-    // normalize: y = x / max(|x|, eps);  v_x = (g - y (y . g)) / |x|  (eps branch: g / eps)
-    float x[4], g[4], nn = 0.f;
+    float x[4], g[4], vx[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        x[k] = a.quats[4 * (size_t)i + k] + tau * a.omega[4 * (size_t)i + k];
+        x[k] = (a.quats[4 * (size_t)i + k] + (tau * a.omega[4 * (size_t)i + k]));
         g[k] = v_quats_t != nullptr ? v_quats_t[4 * (size_t)i + k] : 0.f;
-        nn += x[k] * x[k];
     }
-    const float len = sqrtf(nn);
-    float vx[4];
-    if (len > 1e-12f) {
-        const float inv = 1.f / len;
-        float dot = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) dot += x[k] * inv * g[k];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) vx[k] = (g[k] - x[k] * inv * dot) * inv;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) vx[k] = g[k] * 1e12f;
-    }
+    slice_quat_vjp(x, g, vx);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (v_quats != nullptr) v_quats[4 * (size_t)i + k] = vx[k];
-        if (v_omega != nullptr) v_omega[4 * (size_t)i + k] = vx[k] * tau;
+        if (v_omega != nullptr) v_omega[4 * (size_t)i + k] = (vx[k] * tau);
     }
 }
 

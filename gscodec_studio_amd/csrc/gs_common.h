@@ -15,6 +15,11 @@
 #define GS_BLOCK 256
 
 #define GS_DEV __device__ __forceinline__
+// First statement of a device function whose results must not depend on the kernel it is inlined into: no fma contraction of its
+// operations (the default, -ffp-contract=fast-honor-pragmas, fuses a multiply into an add wherever the surrounding code lets it, so
+// the same source can round differently in two kernels).  The projection chain carries it: every kernel that projects a splat --
+// projection.hip, projection_dyn.hip (slice / quantizer in the load phase), unfused.hip -- produces the same bits.
+#define GS_FP_STRICT _Pragma("clang fp contract(off)")
 
 // ---------------------------------------------------------------------------
 // error plumbing
@@ -64,21 +69,22 @@ __device__ __forceinline__ float gs_mask_value(float logit, float temperature, i
 #endif
 
 // Tile rectangle of a projected splat (isect_tiles.cu:56-69; the reference casts a possibly negative float to uint32 and
-// relies on the saturating conversion, here the clamp is explicit).  Explicitly rounded operations: the same values in every
-// translation unit, whatever its contraction setting (isect.hip counts and emits with it, projection.hip counts with it).
+// relies on the saturating conversion, here the clamp is explicit).  No fma contraction inside (pragma; this toolchain's __f*_rn wrappers are
+// plain operators and would be fused): the same values in every translation unit, whatever its contraction setting (isect.hip counts and emits with it, projection.hip counts with it).
 #ifdef __HIPCC__
 struct TileBox {
     int32_t x0, y0, x1, y1; // min inclusive, max exclusive
 };
 __device__ __forceinline__ TileBox tile_box(float mx, float my, int32_t radius, float tile_size, int32_t tw, int32_t th) {
-    const float tr = __fdiv_rn((float)radius, tile_size);
-    const float tx = __fdiv_rn(mx, tile_size);
-    const float ty = __fdiv_rn(my, tile_size);
+    _Pragma("clang fp contract(off)");
+    const float tr = ((float)radius / tile_size);
+    const float tx = (mx / tile_size);
+    const float ty = (my / tile_size);
     TileBox b;
-    b.x0 = min(max(0, (int32_t)floorf(__fsub_rn(tx, tr))), tw);
-    b.y0 = min(max(0, (int32_t)floorf(__fsub_rn(ty, tr))), th);
-    b.x1 = min(max(0, (int32_t)ceilf(__fadd_rn(tx, tr))), tw);
-    b.y1 = min(max(0, (int32_t)ceilf(__fadd_rn(ty, tr))), th);
+    b.x0 = min(max(0, (int32_t)floorf((tx - tr))), tw);
+    b.y0 = min(max(0, (int32_t)floorf((ty - tr))), th);
+    b.x1 = min(max(0, (int32_t)ceilf((tx + tr))), tw);
+    b.y1 = min(max(0, (int32_t)ceilf((ty + tr))), th);
     return b;
 }
 #endif
@@ -120,6 +126,7 @@ GS_DEV Mat3 sym3_to_mat3(const Sym3 &s) {
 }
 
 GS_DEV Mat3 mat3_mul(const Mat3 &a, const Mat3 &b) {
+    GS_FP_STRICT;
     Mat3 r;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -131,6 +138,7 @@ GS_DEV Mat3 mat3_mul(const Mat3 &a, const Mat3 &b) {
 
 // a^T * b
 GS_DEV Mat3 mat3_tmul(const Mat3 &a, const Mat3 &b) {
+    GS_FP_STRICT;
     Mat3 r;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -142,6 +150,7 @@ GS_DEV Mat3 mat3_tmul(const Mat3 &a, const Mat3 &b) {
 
 // a * b^T
 GS_DEV Mat3 mat3_mult(const Mat3 &a, const Mat3 &b) {
+    GS_FP_STRICT;
     Mat3 r;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -153,6 +162,7 @@ GS_DEV Mat3 mat3_mult(const Mat3 &a, const Mat3 &b) {
 
 // W * S * W^T for symmetric S -> symmetric
 GS_DEV Sym3 sym3_congruence(const Mat3 &W, const Sym3 &S) {
+    GS_FP_STRICT;
     Mat3 Sm = sym3_to_mat3(S);
     Mat3 WS = mat3_mul(W, Sm);
     Sym3 r;
@@ -167,6 +177,7 @@ GS_DEV Sym3 sym3_congruence(const Mat3 &W, const Sym3 &S) {
 
 // W^T * G * W for symmetric G -> symmetric
 GS_DEV Sym3 sym3_congruence_t(const Mat3 &W, const Sym3 &G) {
+    GS_FP_STRICT;
     Mat3 Gm = sym3_to_mat3(G);
     Mat3 GW = mat3_mul(Gm, W); // G * W
     Sym3 r;
@@ -182,6 +193,7 @@ GS_DEV Sym3 sym3_congruence_t(const Mat3 &W, const Sym3 &G) {
 // rotation matrix of a (possibly un-normalised) quaternion (w,x,y,z).
 // reference behaviour: gsplat/cuda/include/quat.cuh:9-31
 GS_DEV Mat3 quat_to_rotmat(float w, float x, float y, float z) {
+    GS_FP_STRICT;
     float inv = rsqrtf(w * w + x * x + y * y + z * z);
     w *= inv; x *= inv; y *= inv; z *= inv;
     float xx = x * x, yy = y * y, zz = z * z;
@@ -196,6 +208,7 @@ GS_DEV Mat3 quat_to_rotmat(float w, float x, float y, float z) {
 
 // Sigma = (R S)(R S)^T   (gsplat/cuda/include/quat_scale_to_covar_preci.cuh:10-41)
 GS_DEV Sym3 covar_from_rot_scale(const Mat3 &R, float sx, float sy, float sz) {
+    GS_FP_STRICT;
     Mat3 M;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -220,6 +233,7 @@ GS_DEV Sym3 covar_from_rot_scale(const Mat3 &R, float sx, float sy, float sz) {
 GS_DEV void covar_vjp_quat_scale(
     float qw, float qx, float qy, float qz, float sx, float sy, float sz,
     const Mat3 &R, const Mat3 &vSigma, float vq[4], float vs[3]) {
+    GS_FP_STRICT;
     // M = R S ; v_M = (G + G^T) M
     Mat3 Gs;
 #pragma unroll

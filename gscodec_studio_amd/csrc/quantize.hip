@@ -8,42 +8,14 @@
 // Arithmetic is IEEE fp32, no contraction, in the reference's operation order, so the
 // outputs are bit-identical to the torch ops (file compiled with -ffp-contract=off).
 #include "gs_common.h"
+#include "quant_dev.h"
 
 namespace {
 
 constexpr int Q_VEC = 4;
 
-GS_DEV float q_clamp(float x, float lo, float hi) {
-    // torch.clamp: NaN propagates; min(max(x, lo), hi)
-    float y = x < lo ? lo : x;
-    y = y > hi ? hi : y;
-    return y; // NaN compares false twice -> stays NaN
-}
-
 GS_DEV float q_noise(float x, float nz, float lo, float hi, float q_step) {
     return __fadd_rn(q_clamp(x, lo, hi), __fmul_rn(nz, q_step));
-}
-
-// Opt-in fusion: the activation the trainer applies right after the hook -- torch.exp for the log-scales,
-// torch.sigmoid for the opacity logits (reference examples/simple_trainer.py:779-786) -- evaluated in the quantizer's own
-// pass; the backward multiplies by its derivative, read off the activated output.  ACT 0 = none (bit-exact reference path).
-template <int ACT>
-GS_DEV float q_act(float v) {
-    if (ACT == GS_ACT_EXP) return expf(v);
-    if (ACT == GS_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
-    return v;
-}
-template <int ACT>
-GS_DEV float q_act_grad(float out, float v) { // d act / d pre-activation, from the activated value
-    if (ACT == GS_ACT_EXP) return v * out;
-    if (ACT == GS_ACT_SIGMOID) return v * out * (1.f - out);
-    return v;
-}
-
-GS_DEV float q_round(float xc, float lo, float range, float qn) {
-    float norm = __fdiv_rn(__fsub_rn(xc, lo), range);
-    float lvl = rintf(__fdiv_rn(norm, qn)); // round half to even, as torch.round
-    return __fadd_rn(__fmul_rn(__fmul_rn(lvl, qn), range), lo);
 }
 
 template <int ACT>

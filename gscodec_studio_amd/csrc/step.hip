@@ -39,7 +39,8 @@ extern "C" uint32_t gs_step_layout(uint64_t *out, uint32_t n) {
                           offsetof(gs_step, n_isects), offsetof(gs_step, n_kept_host), offsetof(gs_step, work_bytes), offsetof(gs_step, plan), offsetof(gs_step, scratch),
                           offsetof(gs_step, zero_fill_bytes), offsetof(gs_step, v_render_colors), offsetof(gs_step, vrc_pixel_stride),
                           offsetof(gs_step, grad_rows), offsetof(gs_step, v_sh_rest), offsetof(gs_step, absgrad),
-                          offsetof(gs_step, finish_phase)};
+                          offsetof(gs_step, finish_phase), offsetof(gs_step, dyn_motion), offsetof(gs_step, dyn_timestamp),
+                          offsetof(gs_step, dyn_quant_lo), offsetof(gs_step, v_dyn_motion)};
     const uint32_t m = (uint32_t)(sizeof(v) / sizeof(v[0]));
     for (uint32_t i = 0; out != nullptr && i < n && i < m; ++i) out[i] = v[i];
     return m;
@@ -63,7 +64,16 @@ extern "C" int32_t gs_step_fwd_begin(gs_step *s, gs_stream_t stream) {
     const uint32_t n_elems = s->C * s->N;
     // rows_ready: the splat rows, radii and depths are already there (they arrived through the multi-GPU exchange of the
     // gaussian-sharded mode, C = the local cameras, N = all ranks' splats): binning only, the count kernel counts the tiles
-    if (!s->rows_ready)
+    if (!s->rows_ready && s->dyn_motion != nullptr) {
+        GS_CHECK_ARG(s->covars == nullptr && s->sh_coeffs == nullptr, "dynamic splats: quats + scales and [N,3] colours only (no covars, no SH)");
+        GS_STEP_TRY(gs_projection_rows_dyn_fwd(s->C, s->N, s->means, const_cast<float *>(s->quats), const_cast<float *>(s->scales), s->dyn_motion,
+                                               s->dyn_omega, s->dyn_trbf_center, s->dyn_trbf_scale, s->dyn_timestamp, s->dyn_raw_params,
+                                               s->dyn_quant_mask, s->dyn_quant_lo, s->dyn_quant_hi, s->dyn_quant_range, s->dyn_quant_step_norm,
+                                               s->viewmats, s->Ks, s->width, s->height, s->eps2d, s->near_plane, s->far_plane, s->radius_clip,
+                                               s->camera_model, const_cast<float *>(s->opacities), const_cast<float *>(s->colors), s->antialiased,
+                                               s->tile_size, s->tile_width, s->tile_height, s->tiles_per_gauss, s->block_sums, s->radii, s->depths,
+                                               s->rows, stream));
+    } else if (!s->rows_ready)
     GS_STEP_TRY(gs_projection_rows_fwd(s->C, s->N, s->means, s->covars, s->quats, s->scales, s->viewmats, s->Ks, s->width, s->height, s->eps2d,
                                        s->near_plane, s->far_plane, s->radius_clip, s->camera_model, s->opacities, s->colors, s->antialiased,
                                        s->sh_coeffs, s->sh_rest, s->sh_K, s->sh_degree, s->sh_mask_logits, s->sh_mask_temperature, s->sh_mask_binary,
@@ -129,7 +139,14 @@ extern "C" int32_t gs_step_bwd(gs_step *s, gs_stream_t stream) {
                                  s->v_render_colors, s->v_render_alphas, s->vrc_pixel_stride, s->vrc_channel_stride,
                                  s->absgrad ? s->grad_rows : nullptr, s->grad_rows, nullptr, nullptr, nullptr, 1, nullptr,
                                  s->scratch ? &s->plan : nullptr, s->scratch, stream));
-    if (!s->skip_projection_bwd)
+    if (!s->skip_projection_bwd && s->dyn_motion != nullptr)
+        GS_STEP_TRY(gs_projection_rows_dyn_bwd(s->C, s->N, s->means, s->quats, s->scales, s->dyn_motion, s->dyn_omega, s->dyn_trbf_center,
+                                               s->dyn_trbf_scale, s->dyn_timestamp, s->dyn_raw_params, s->dyn_quant_mask, s->dyn_quant_lo,
+                                               s->dyn_quant_hi, s->dyn_quant_range, s->dyn_quant_step_norm, s->viewmats, s->Ks, s->width, s->height,
+                                               s->eps2d, s->camera_model, s->radii, s->rows, s->grad_rows, s->v_depths, s->opacities, s->antialiased,
+                                               s->v_means, s->v_quats, s->v_scales, s->v_dyn_motion, s->v_dyn_omega, s->v_dyn_trbf_center,
+                                               s->v_dyn_trbf_scale, s->v_opacities, s->v_colors, s->outputs_prefilled, stream));
+    else if (!s->skip_projection_bwd)
         GS_STEP_TRY(gs_projection_rows_bwd(s->C, s->N, s->means, s->covars, s->quats, s->scales, s->viewmats, s->Ks, s->width, s->height, s->eps2d,
                                            s->camera_model, s->radii, s->rows, s->grad_rows, s->v_depths, s->opacities, s->antialiased, s->v_means,
                                            s->v_covars, s->v_quats, s->v_scales, nullptr, s->v_opacities, s->v_colors, nullptr, s->sh_coeffs,

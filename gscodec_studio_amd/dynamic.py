@@ -1,14 +1,20 @@
-"""Dynamic (spacetime) gaussians: temporal slicing at one timestamp, fused.
+"""Dynamic (spacetime) gaussians: temporal slicing at one timestamp.
 
 ``temporal_slice`` is the elementwise chain that the reference's dynamic-scene trainer runs in front of
 ``rasterization()`` (examples/simple_trainer_dyngs.py:506-536; the viewer's copy:
 examples/simple_viewer_dyn.py:84-101), as ONE HIP kernel each way (csrc/dynamic.hip) instead of ~25 torch
 kernels.  Same inputs as the trainer's local variables: ``opacities`` and ``trbf_scale`` are the
 ACTIVATED values (sigmoid / exp are applied by the caller, as in the trainer).  No torch fallback.
+
+``DynamicSlice`` (round 6) hands the same slice to ``rasterization(dynamic=...)``, whose projection kernels then evaluate it in
+their load phase (csrc/projection_dyn.hip) -- bit-identical to ``temporal_slice`` followed by ``rasterization``, without the
+round trip of means_t / quats_t / opacity_t through HBM; opt-in on top, the trainer's activations (``raw``) and the round
+quantizer hooks (``quantize``) ride in the same pass.  ``render_dynamic`` is the dynamic trainer's ``rasterize_splats`` in that form.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+import ctypes
+from typing import Dict, Optional, Sequence, Tuple, Union
 
 import torch
 from torch import Tensor
@@ -75,3 +81,155 @@ def temporal_slice(
                                                              trbf_scale.reshape(N), float(timestamp))
     mask = (trbf.detach() > TEMPORAL_VISIBILITY_THRESHOLD) if temp_vis_mask else None
     return means_t, quats_t, opacity_t, mask
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+_RAW_BITS = {"scales": 1, "opacities": 2, "trbf_scale": 4}  # GS_DYN_RAW_* of include/gsplat_hip.h
+_QUANT_SLOTS = ("scales", "quats", "opacities", "colors")   # bit k of quant_mask
+_F4 = ctypes.c_float * 4
+
+
+def _f32(v: float) -> float:
+    return float(torch.tensor(v, dtype=torch.float32))
+
+
+class DynamicSlice:
+    """The temporal part of a set of dynamic gaussians, for ``rasterization(..., dynamic=DynamicSlice(...))``.
+
+    ``rasterization(means, quats, scales, opacities, colors, ..., dynamic=ds)`` equals
+    ``rasterization(*temporal_slice(means, ds.motion, quats, ds.omega, opacities, ds.trbf_center, ds.trbf_scale, ds.timestamp)...)``
+    (reference examples/simple_trainer_dyngs.py:506-554) with the slice evaluated inside the projection kernels.
+
+    raw       names among ("scales", "opacities", "trbf_scale") (or True for all three) whose tensors are the trainer's RAW
+              parameters -- log-scales, opacity logits, log trbf_scale: the exp / sigmoid / exp of dyngs.py:493-505 then runs in the
+              kernel too.
+    quantize  {"scales" | "quats" | "opacities" | "colors": (lower, upper, bits)}: the attribute goes through the reference's
+              round-to-grid STE first (gsplat/compression_simulation/ops.py:57-75): the tensor handed to ``rasterization`` is
+              CLAMPED IN PLACE like ``STE.apply``'s input (hand over the parameter itself), quantized values are never
+              materialised, the gradient is the identity.  (A quantized attribute that also has an activation must be "raw".)
+    A plain tuple ``(motion, omega, trbf_center, trbf_scale, timestamp)`` is accepted wherever a DynamicSlice is."""
+
+    def __init__(self, motion: Tensor, omega: Tensor, trbf_center: Tensor, trbf_scale: Tensor, timestamp: float,
+                 raw: Union[bool, Sequence[str]] = (), quantize: Optional[Dict[str, Tuple[float, float, int]]] = None):
+        self.motion, self.omega, self.trbf_center, self.trbf_scale = motion, omega, trbf_center, trbf_scale
+        self.timestamp = float(timestamp)
+        names = tuple(_RAW_BITS) if raw is True else tuple(raw or ())
+        assert all(n in _RAW_BITS for n in names), f"raw: names among {tuple(_RAW_BITS)}, got {names}"
+        self.raw = names
+        self.raw_mask = sum(_RAW_BITS[n] for n in set(names))
+        self.quantize = dict(quantize or {})
+        assert all(k in _QUANT_SLOTS for k in self.quantize), f"quantize: keys among {_QUANT_SLOTS}, got {tuple(self.quantize)}"
+        for k in ("scales", "opacities"):
+            assert not (k in self.quantize and k not in names), \
+                f"quantize[{k!r}] works on the raw parameter (log-scales / logits): add {k!r} to raw"
+        self.quant_mask = sum(1 << _QUANT_SLOTS.index(k) for k in self.quantize)
+        lo, hi, rng, qn = [0.0] * 4, [0.0] * 4, [1.0] * 4, [1.0] * 4
+        for k, (l_, h_, bits) in self.quantize.items():
+            i = _QUANT_SLOTS.index(k)
+            # python arithmetic first, then fp32, as torch does with the reference's python-float bounds (ops.py:65-70)
+            lo[i], hi[i], rng[i], qn[i] = _f32(l_), _f32(h_), _f32(h_ - l_), _f32(1 / (2 ** bits - 1))
+        self._tables = (_F4(*lo), _F4(*hi), _F4(*rng), _F4(*qn))
+
+    @staticmethod
+    def of(d) -> "DynamicSlice":
+        return d if isinstance(d, DynamicSlice) else DynamicSlice(*d)
+
+    def check(self, N: int) -> None:
+        assert self.motion.shape == (N, 9) and self.omega.shape == (N, 4), (self.motion.shape, self.omega.shape)
+        assert self.trbf_center.numel() == N and self.trbf_scale.numel() == N, (self.trbf_center.shape, self.trbf_scale.shape)
+
+    def bind(self, quats, scales, opacities, colors, motion, omega, center, tscale):
+        """Contiguous fp32 views of the four temporal tensors; refuses a quantized attribute that is not writable in place."""
+        for name, t in (("quats", quats), ("scales", scales), ("opacities", opacities), ("colors", colors)):
+            if name in self.quantize and t is None:
+                raise RuntimeError(f"DynamicSlice: quantize[{name!r}] but no {name} reach the projection "
+                                   "(more than three colour channels are quantized by the caller)")
+        out = []
+        for t in (motion, omega, center, tscale):
+            if t.dtype != torch.float32:
+                raise RuntimeError(f"DynamicSlice: expected float32 tensors, got {t.dtype}")
+            out.append(t if t.is_contiguous() else t.contiguous())
+        return tuple(out)
+
+    def c_args(self, dt):
+        """The (motion ... quant_step_norm) run of arguments of gs_projection_rows_dyn_fwd / _bwd."""
+        lo, hi, rng, qn = self._tables
+        return (B.ptr(dt[0]), B.ptr(dt[1]), B.ptr(dt[2]), B.ptr(dt[3]), self.timestamp, self.raw_mask, self.quant_mask,
+                ctypes.addressof(lo), ctypes.addressof(hi), ctypes.addressof(rng), ctypes.addressof(qn))
+
+    # -- the same chain through the stand-alone operators: every route the fused kernels do not cover (packed, distributed, SH colours,
+    # covars, camera-pose gradients) and the reference the fused route is tested against
+    def apply_unfused(self, means, quats, scales, opacities, colors):
+        """-> (means_t, quats_t, scales, opacity_t, colors) for a plain ``rasterization`` call: STE hooks (in-place clamp), activations,
+        ``temporal_slice``."""
+        from .compression_simulation.ops import STE
+
+        def q(name, t, act):
+            if name in self.quantize:
+                lo, hi, bits = self.quantize[name]
+                return STE.apply(t, bits, lo, hi, act)
+            if act == 1:
+                return torch.exp(t)
+            if act == 2:
+                return torch.sigmoid(t)
+            return t
+
+        quats = q("quats", quats, 0)
+        scales = q("scales", scales, 1 if "scales" in self.raw else 0)
+        opacities = q("opacities", opacities, 2 if "opacities" in self.raw else 0)
+        if colors is not None and "colors" in self.quantize:
+            colors = q("colors", colors, 0)
+        tscale = torch.exp(self.trbf_scale) if "trbf_scale" in self.raw else self.trbf_scale
+        means_t, quats_t, opacity_t, _ = temporal_slice(means, self.motion, quats, self.omega, opacities, self.trbf_center, tscale,
+                                                        self.timestamp)
+        return means_t, quats_t, scales, opacity_t, colors
+
+
+def render_dynamic(splats: Dict[str, Tensor], timestamp: float, viewmats: Tensor, Ks: Tensor, width: int, height: int,
+                   compression_sim=None, step: int = 0, features: str = "colors", **kwargs):
+    """The dynamic trainer's ``rasterize_splats`` (reference examples/simple_trainer_dyngs.py:463-577, compression_sim on or off) on
+    the fused route: ``splats`` is the trainer's RAW parameter dict (means, scales (log), quats, opacities (logits), trbf_center,
+    trbf_scale (log), motion, omega, colors [, features_dir, features_time]); returns ``(render_colors, render_alphas, info)``.
+
+    With ``compression_sim`` (an ``STGCompressionSimulation`` in "round" mode) the hooks of scales / quats / opacities / colors run
+    inside the projection kernel (parameters clamped in place, as the hooks do) unless the step needs their quantized values for the
+    bits estimator (``step > entropy_steps[name]``) -- those attributes, and every other mode of the simulation, go through
+    ``simulate_compression`` as usual and only the activations + slice are fused.  ``features="stg"`` renders the spacetime trainer's
+    nine channels cat(colors, features_dir, tau * features_time) (examples/simple_trainer_STG.py:506-551).
+    -> also returns ``esti_bits`` of the hooks that ran outside as ``info["esti_bits"]``."""
+    from .rendering import rasterization
+
+    P = dict(splats)
+    esti_bits = {}
+    quantize = {}
+    raw = ["scales", "opacities", "trbf_scale"]
+    sim = compression_sim
+    if sim is not None:
+        in_kernel = []
+        if getattr(sim, "q_type", None) == "round":
+            for name in _QUANT_SLOTS:
+                if name == "colors" and features != "colors":
+                    continue
+                needs_bits = (sim.entropy_model_enable and sim.entropy_model_option.get(name, False)
+                              and step > sim.entropy_steps.get(name, -1) and sim.entropy_models.get(name) is not None)
+                if sim.simulation_option.get(name, False) and sim.bds.get(name) is not None and not needs_bits and name in P:
+                    in_kernel.append(name)
+        rest = {k: v for k, v in P.items() if k not in in_kernel and sim.simulation_option.get(k, False)}
+        if rest:
+            new, bits = sim.simulate_compression(rest, step)
+            P.update(new)
+            esti_bits.update(bits)
+        for name in in_kernel:
+            lo, hi = sim.bds[name]
+            quantize[name] = (lo, hi, sim.q_bitwidth[name])
+    tau = None
+    if features == "stg":
+        tau = (float(timestamp) - P["trbf_center"]).detach()
+        colors = torch.cat((P["colors"], P["features_dir"], tau * P["features_time"]), dim=1)
+    else:
+        colors = P["colors"]
+    ds = DynamicSlice(P["motion"], P["omega"], P["trbf_center"], P["trbf_scale"], timestamp, raw=raw, quantize=quantize)
+    rc, ra, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], colors, viewmats, Ks, width, height,
+                                 dynamic=ds, **kwargs)
+    info["esti_bits"] = esti_bits
+    return rc, ra, info

@@ -110,6 +110,7 @@ def rasterization(
     camera_model: Literal["pinhole", "ortho", "fisheye"] = "pinhole",
     covars: Optional[Tensor] = None,
     deterministic: bool = False,
+    dynamic=None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize a set of 3D Gaussians (N) to a batch of image planes (C).
 
@@ -128,6 +129,12 @@ def rasterization(
         parallel wrapper is ``distributed.rasterization_camera_sharded``).
         deterministic (opt-in, beyond the reference's signature): bit-reproducible gradients -- the compositing
         backward accumulates in fixed point instead of with float atomics (up to 4 render channels).
+        dynamic (opt-in, beyond the reference's signature): a ``dynamic.DynamicSlice`` or the tuple ``(motion [N,9], omega [N,4],
+        trbf_center [N,1], trbf_scale [N,1], timestamp)`` -- the splats are DYNAMIC (spacetime) gaussians and ``means`` / ``quats`` /
+        ``opacities`` their time-independent parameters: the temporal slice of the reference's dynamic trainer
+        (examples/simple_trainer_dyngs.py:506-521) is evaluated inside the projection kernels, bit-identical to
+        ``dynamic.temporal_slice`` followed by this call (csrc/projection_dyn.hip; routes the fused kernels do not cover take
+        exactly that detour).
 
     Returns:
         render_colors [C,H,W,X], render_alphas [C,H,W,1], meta dict.
@@ -137,6 +144,20 @@ def rasterization(
     N = means.shape[0]
     C = viewmats.shape[0]
     device = means.device
+    if dynamic is not None:
+        from .dynamic import DynamicSlice
+
+        dynamic = DynamicSlice.of(dynamic)
+        dynamic.check(N)
+        dyn_fused = (not packed and not distributed and covars is None and sh_degree is None and means.is_cuda and viewmats.is_cuda
+                     and not viewmats.requires_grad and torch.is_tensor(colors) and colors.dim() == 2)
+        if "colors" in dynamic.quantize and not (dyn_fused and colors.shape[-1] == 3):
+            dyn_fused = False
+        if not dyn_fused:  # every other route: the same chain through the stand-alone operators, then the plain call
+            means, quats, scales, opacities, c_ = dynamic.apply_unfused(means, quats, scales, opacities,
+                                                                         colors if torch.is_tensor(colors) else None)
+            colors = c_ if c_ is not None else colors
+            dynamic = None
     assert means.shape == (N, 3), means.shape
     if covars is None:
         assert quats.shape == (N, 4), quats.shape
@@ -246,7 +267,7 @@ def rasterization(
             return _step.rasterize_step(
                 means, covars, quats, scales, opacities, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
                 rasterize_mode == "antialiased", camera_model, row_colors, colors if fuse_sh else None, sh_rest,
-                sh_degree if fuse_sh else None, tile_size, backgrounds, absgrad, sh_mask=sh_mask)
+                sh_degree if fuse_sh else None, tile_size, backgrounds, absgrad, sh_mask=sh_mask, dynamic=dynamic)
         # the dense per-gaussian gradients of the projection node are allocated and zero-filled by the compositing
         # forward's side job; its backward then writes the visible gaussians' rows only (_wrapper.GradPrefill)
         prefill = GradPrefill() if (torch.is_grad_enabled() and _prefill_enabled()) else None
@@ -256,7 +277,7 @@ def rasterization(
             antialiased=(rasterize_mode == "antialiased"), camera_model=camera_model,
             # shared SH coefficients and fixed poses: the colours are evaluated by the projection pass itself
             sh_coeffs=colors if fuse_sh else None, sh_degree=sh_degree if fuse_sh else None, sh_rest=sh_rest,
-            prefill=prefill, sh_mask=sh_mask,
+            prefill=prefill, sh_mask=sh_mask, dynamic=dynamic,
         )
         camera_ids, gaussian_ids = None, None
         opacity_rider = False

@@ -35,11 +35,11 @@ extern "C" {
 
 /* Bumped whenever an exported signature or the meaning of an argument changes (1: round 1; 2: the round-2 additions to
  * gs_rasterize_fwd, gs_isect_count_keys, gs_sort_pairs_u64_i32_drop, gs_projection_bwd; 3: round 3 -- the splat-row layout,
- * gs_raster_plan, gs_kmeans_decode's bounds; 4: round 4 -- the shN mask entry points, gs_isect_count_keys' bucket_splitters, the bucketed pre-sort).  A binding must refuse a library whose gs_version() differs from the
+ * gs_raster_plan, gs_kmeans_decode's bounds; 4: round 4 -- the shN mask entry points, gs_isect_count_keys' bucket_splitters, the bucketed pre-sort; 5: round 6 -- gs_projection_rows_dyn_*, the dyn_* fields of gs_step, gs_accumulate_*).  A binding must refuse a library whose gs_version() differs from the
  * GS_ABI_VERSION of the header it was generated from, and SHOULD also compare gs_header_hash() (the first 8 bytes of the
  * SHA-256 of the header file the library was compiled against, big-endian) with the hash of its own copy: ctypes / cgo call
  * through shifted argument lists silently otherwise. */
-#define GS_ABI_VERSION 4
+#define GS_ABI_VERSION 5
 
 /* reference: gsplat/cuda/include/bindings.h:34-38 (enum CameraModelType) */
 #define GS_CAMERA_PINHOLE 0
@@ -850,6 +850,42 @@ int32_t gs_temporal_slice_bwd(
     float *v_means, float *v_motion, float *v_quats, float *v_omega, float *v_opacities,
     float *v_trbf_center, float *v_trbf_scale, gs_stream_t stream);
 
+/* The same slice evaluated INSIDE the row-form projection (round 6; SURVEY 8f rank 2: "folded into the projection kernel's load
+ * phase"): gs_projection_rows_dyn_fwd == gs_temporal_slice_fwd followed by gs_projection_rows_fwd (colours [N,3] or none, no SH),
+ * bit for bit -- the per-splat arithmetic is one shared definition (csrc/dynamic_dev.h, projection_dev.h) -- without the round trip of
+ * means_t / quats_t / opacity_t through HBM; gs_projection_rows_dyn_bwd == gs_projection_rows_bwd followed by
+ * gs_temporal_slice_bwd, writing the gradients of means, quats, scales, motion, omega, trbf_center, trbf_scale, opacities (and colors)
+ * for the gaussians some camera saw (outputs_prefilled != 0: the other rows hold zeros already and are not stored; 0: every row is
+ * written).  Opt-in on top, so that the trainer's RAW parameters can be handed over as they are (simple_trainer_dyngs.py:493-505):
+ *   raw_params   GS_DYN_RAW_* bits: scales are log-scales (exp), opacities logits (sigmoid), trbf_scale a log-scale (exp) -- the
+ *                activation runs in the kernel, its derivative in the backward;
+ *   quant_mask   bit 0 scales, 1 quats, 2 opacities, 3 colors: the attribute goes through the STE round quantizer first
+ *                (gsplat/compression_simulation/ops.py:57-75, the arithmetic of gs_quantize_round_fwd bit for bit): clamp to
+ *                [quant_lo[k], quant_hi[k]] -- stored back into the PARAMETER when it changes a value, as the reference's in-place
+ *                clamp does, which is why quats / scales / opacities / colors are not const in the forward --, round to the grid
+ *                (quant_range[k] = hi - lo, quant_step_norm[k] = 1 / (2^bits - 1), both computed as the reference does: python
+ *                double, then float), identity gradient.  The four tables are HOST arrays of 4 floats (NULL with quant_mask 0).
+ * colors NULL: the colour columns of the rows are left to the caller (more than three render channels). */
+#define GS_DYN_RAW_SCALES 1u
+#define GS_DYN_RAW_OPACITIES 2u
+#define GS_DYN_RAW_TRBF_SCALE 4u
+int32_t gs_projection_rows_dyn_fwd(
+    uint32_t C, uint32_t N, const float *means, float *quats, float *scales, const float *motion, const float *omega,
+    const float *trbf_center, const float *trbf_scale, float timestamp, uint32_t raw_params, uint32_t quant_mask, const float *quant_lo,
+    const float *quant_hi, const float *quant_range, const float *quant_step_norm, const float *viewmats, const float *Ks,
+    int32_t image_width, int32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip, int32_t camera_model,
+    float *opacities /* [N] or NULL */, float *colors /* [N,3] or NULL */, int32_t antialiased,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, int32_t *tiles_per_gauss /* or NULL */, int32_t *block_sums /* or NULL */,
+    int32_t *radii, float *depths, float *rows, gs_stream_t stream);
+int32_t gs_projection_rows_dyn_bwd(
+    uint32_t C, uint32_t N, const float *means, const float *quats, const float *scales, const float *motion, const float *omega,
+    const float *trbf_center, const float *trbf_scale, float timestamp, uint32_t raw_params, uint32_t quant_mask, const float *quant_lo,
+    const float *quant_hi, const float *quant_range, const float *quant_step_norm, const float *viewmats, const float *Ks,
+    int32_t image_width, int32_t image_height, float eps2d, int32_t camera_model, const int32_t *radii, const float *rows,
+    const float *grad_rows, const float *v_depths /* or NULL */, const float *opacities, int32_t antialiased,
+    float *v_means, float *v_quats, float *v_scales, float *v_motion, float *v_omega, float *v_trbf_center, float *v_trbf_scale,
+    float *v_opacities, float *v_colors /* each or NULL */, int32_t outputs_prefilled, gs_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Row packing around the multi-GPU exchange of projected splats.  The gaussian-sharded mode of the reference
  * (gsplat/rendering.py:397-478, gsplat/distributed.py:170-257) concatenates radii | means2d | depths | conics |
@@ -953,7 +989,7 @@ int32_t gs_dp_reduce_rows(uint64_t n_recv, uint32_t width, uint32_t world, const
  * channels, fixed camera poses -- issued from ONE descriptor in three calls instead of nine operator calls from the host
  * language.  Every launch goes through the operator entry points above: identical results; the operators stay the drop-in
  * boundary, this is the executor around them (the counterpart of gsplat/rendering.py:28-582's orchestration).
- *   gs_step_fwd_begin   gs_projection_rows_fwd -> [gs_presort_split] -> gs_isect_count_keys -> gs_presort_buckets |
+ *   gs_step_fwd_begin   gs_projection_rows_fwd (gs_projection_rows_dyn_fwd with dyn_motion) -> [gs_presort_split] -> gs_isect_count_keys -> gs_presort_buckets |
  *                       gs_sort_pairs_u64_i32_drop [-> gs_cumsum_i32 when group_prefix is given]
  *   (the caller waits until every entry of block_sums -- pinned host memory it pre-set to -1 -- is >= 0, sets n_isects /
  *    n_kept_host to the sums of its even / odd entries, sizes the phase-2 buffers with gs_isect_finish_work_bytes /
@@ -1023,12 +1059,19 @@ typedef struct gs_step {
     float *v_means, *v_covars, *v_quats, *v_scales, *v_opacities, *v_colors, *v_sh, *v_sh_rest;
     int32_t absgrad, outputs_prefilled, skip_projection_bwd;
     int32_t finish_phase; /* gs_step_fwd_finish: 0 = binning + compositing, 1 = binning only, 2 = compositing only */
+    /* dynamic splats (round 6): dyn_motion != NULL routes the projection through gs_projection_rows_dyn_fwd / _bwd (no SH, no covars;
+     * quats / scales / opacities / colors are then written when dyn_quant_mask clamps a parameter) */
+    const float *dyn_motion, *dyn_omega, *dyn_trbf_center, *dyn_trbf_scale;
+    float dyn_timestamp;
+    uint32_t dyn_raw_params, dyn_quant_mask, reserved2;
+    float dyn_quant_lo[4], dyn_quant_hi[4], dyn_quant_range[4], dyn_quant_step_norm[4];
+    float *v_dyn_motion, *v_dyn_omega, *v_dyn_trbf_center, *v_dyn_trbf_scale;
 } gs_step;
 /* Layout guard for bindings that mirror the host structs by hand (ctypes, cgo, JNA ...): writes up to n entries --
  * sizeof(struct), then offsetof of the listed fields in this order -- and returns how many the list has.
  *   gs_step:       C, sh_K, eps2d, tile_size, sh_mask_logits, rows_ready, backgrounds, radii, sort_temp_bytes, block_sums, n_isects,
  *                  n_kept_host, work_bytes, plan, scratch, zero_fill_bytes, v_render_colors, vrc_pixel_stride, grad_rows, v_sh_rest, absgrad,
- *                  finish_phase
+ *                  finish_phase, dyn_motion, dyn_timestamp, dyn_quant_lo, v_dyn_motion
  *   gs_quant_desc: n, x, out, v_out, v_x, lo, q_step, activation, philox_offset */
 uint32_t gs_step_layout(uint64_t *out, uint32_t n);
 uint32_t gs_quant_desc_layout(uint64_t *out, uint32_t n);

@@ -31,7 +31,7 @@ def test_version_and_error_string():
     from gscodec_studio_amd import _backend as B
 
     L = B.lib()
-    assert L.gs_version() == B.header_abi_version() == 4
+    assert L.gs_version() == B.header_abi_version() == 5
     assert L.gs_header_hash() == B.header_hash()  # the library was compiled against THIS header
     assert isinstance(L.gs_last_error(), bytes)
     assert B.query("gs_sort_temp_bytes", 1000) >= 1000 * 12
