@@ -5,6 +5,7 @@ Public surface (mirrors the reference's ``gsplat`` package for this path only):
   ``compression_simulation.{CompressionSimulation, STGCompressionSimulation, fake_quantize_ste, STE}``.
 """
 from ._wrapper import (
+    accumulate,
     fully_fused_projection,
     isect_offset_encode,
     isect_tiles,
@@ -32,5 +33,5 @@ def __getattr__(name):  # (lazy: the codec module is not on the training path)
 __all__ = [
     "rasterization", "fully_fused_projection", "spherical_harmonics", "spherical_harmonics_shared",
     "isect_tiles", "isect_offset_encode", "rasterize_to_pixels", "quat_scale_to_covar_preci", "proj", "persp_proj",
-    "world_to_cam", "rasterize_to_indices_in_range", "PngCompression", "__version__",
+    "world_to_cam", "rasterize_to_indices_in_range", "accumulate", "PngCompression", "__version__",
 ]

@@ -611,6 +611,68 @@ def rasterize_to_indices_in_range(
     return gaussian_ids, out_pixel_ids, out_camera_ids
 
 
+def accumulate(
+    means2d: Tensor,  # [C, N, 2]
+    conics: Tensor,  # [C, N, 3]
+    opacities: Tensor,  # [C, N]
+    colors: Tensor,  # [C, N, channels]
+    gaussian_ids: Tensor,  # [M]
+    pixel_ids: Tensor,  # [M]
+    camera_ids: Tensor,  # [M]
+    image_width: int,
+    image_height: int,
+) -> Tuple[Tensor, Tensor]:
+    """Alpha compositing over an explicit list of (gaussian, pixel, camera) intersections -- the reference's ``gsplat.accumulate``
+    (gsplat/cuda/_torch_impl.py:432-519, torch ops + nerfacc there; here ``gs_accumulate_fwd`` / ``_bwd``, csrc/unfused.hip).  The
+    intersections come from ``rasterize_to_indices_in_range`` (grouped by ray, front to back).  Differentiable in means2d, conics,
+    opacities and colors.  Returns ``(renders [C, image_height, image_width, channels], alphas [C, image_height, image_width, 1])``."""
+    C, N = means2d.shape[:2]
+    assert means2d.shape == (C, N, 2) and conics.shape == (C, N, 3) and opacities.shape == (C, N), (means2d.shape, conics.shape, opacities.shape)
+    assert colors.dim() == 3 and colors.shape[:2] == (C, N), colors.shape
+    M = gaussian_ids.shape[0]
+    assert gaussian_ids.shape == pixel_ids.shape == camera_ids.shape == (M,), (gaussian_ids.shape, pixel_ids.shape, camera_ids.shape)
+    return _Accumulate.apply(means2d, conics, opacities, colors, gaussian_ids, pixel_ids, camera_ids, int(image_width), int(image_height))
+
+
+class _Accumulate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, conics, opacities, colors, gaussian_ids, pixel_ids, camera_ids, width, height):
+        _require_gpu(means2d, "accumulate")
+        means2d, conics, opacities, colors = _f32c(means2d), _f32c(conics), _f32c(opacities), _f32c(colors)
+        gids, pids, cids = (t.contiguous().to(torch.int64) for t in (gaussian_ids, pixel_ids, camera_ids))
+        C, N, channels = colors.shape
+        M = gids.shape[0]
+        dev = means2d.device
+        renders = torch.zeros((C, height, width, channels), dtype=torch.float32, device=dev)
+        alphas = torch.zeros((C, height, width, 1), dtype=torch.float32, device=dev)
+        alpha_buf = torch.empty((M,), dtype=torch.float32, device=dev)
+        weights = torch.empty((M,), dtype=torch.float32, device=dev)
+        with _device_of(means2d):
+            B.call("gs_accumulate_fwd", M, C, N, channels, B.ptr(means2d), B.ptr(conics), B.ptr(opacities), B.ptr(colors), B.ptr(gids),
+                   B.ptr(pids), B.ptr(cids), width, height, B.ptr(alpha_buf), B.ptr(weights), B.ptr(renders), B.ptr(alphas), _stream(means2d))
+        ctx.save_for_backward(means2d, conics, opacities, colors, gids, pids, cids, alpha_buf, weights)
+        ctx.size = (width, height)
+        ctx.set_materialize_grads(False)
+        return renders, alphas
+
+    @staticmethod
+    def backward(ctx, v_renders, v_alphas):
+        means2d, conics, opacities, colors, gids, pids, cids, alpha_buf, weights = ctx.saved_tensors
+        C, N, channels = colors.shape
+        M = gids.shape[0]
+        need = ctx.needs_input_grad
+        v_renders = _f32c(v_renders) if v_renders is not None else None
+        v_alphas = _f32c(v_alphas) if v_alphas is not None else None
+        outs = [torch.zeros_like(t) if need[i] else None for i, t in enumerate((means2d, conics, opacities, colors))]
+        if M and (v_renders is not None or v_alphas is not None):
+            scratch = torch.empty((M,), dtype=torch.float32, device=means2d.device)
+            with _device_of(means2d):
+                B.call("gs_accumulate_bwd", M, C, N, channels, B.ptr(means2d), B.ptr(conics), B.ptr(opacities), B.ptr(colors), B.ptr(gids),
+                       B.ptr(pids), B.ptr(cids), ctx.size[0], ctx.size[1], B.ptr(alpha_buf), B.ptr(weights), B.ptr(v_renders), B.ptr(v_alphas),
+                       B.ptr(scratch), *[B.ptr(o) for o in outs], _stream(means2d))
+        return (*outs, None, None, None, None, None)
+
+
 # ---------------------------------------------------------------------------
 # quat/scale -> covar/preci  (reference _wrapper.py:76-115, 646-706)
 # ---------------------------------------------------------------------------

@@ -16,9 +16,14 @@
 
 #define GS_DEV __device__ __forceinline__
 // First statement of a device function whose results must not depend on the kernel it is inlined into: no fma contraction of its
-// operations (the default, -ffp-contract=fast-honor-pragmas, fuses a multiply into an add wherever the surrounding code lets it, so
-// the same source can round differently in two kernels).  The projection chain carries it: every kernel that projects a splat --
-// projection.hip, projection_dyn.hip (slice / quantizer in the load phase), unfused.hip -- produces the same bits.
+// operations.  The default, -ffp-contract=fast-honor-pragmas, fuses a multiply into an add wherever the surrounding code lets it, so
+// the same source can round differently in two kernels -- and the __fmul_rn / __fadd_rn wrappers of this toolchain are plain
+// operators (__clang_hip_math.h) that do NOT prevent it.  Carried by the arithmetic that has an exact counterpart elsewhere: the
+// quantizers (quant_dev.h: bit-exact against torch's op-by-op arithmetic), the temporal slice (dynamic_dev.h: the stand-alone slice
+// kernels and the projection kernels that evaluate it in their load phase) and tile_box below.  The projection chain itself stays
+// contractible on purpose: with fused multiply-adds its gradients are measurably closer to float64 (round 6 tried it contraction-free:
+// the quaternion gradient of tests/test_gpu_ops.py::test_projection_vs_golden_and_oracle went from 3.7e-5 to 1.0e-4 of float64,
+// written with explicit fmas its worst entry was still 5x further off than the contracted code's).
 #define GS_FP_STRICT _Pragma("clang fp contract(off)")
 
 // ---------------------------------------------------------------------------
@@ -126,7 +131,6 @@ GS_DEV Mat3 sym3_to_mat3(const Sym3 &s) {
 }
 
 GS_DEV Mat3 mat3_mul(const Mat3 &a, const Mat3 &b) {
-    GS_FP_STRICT;
     Mat3 r;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -138,7 +142,6 @@ GS_DEV Mat3 mat3_mul(const Mat3 &a, const Mat3 &b) {
 
 // a^T * b
 GS_DEV Mat3 mat3_tmul(const Mat3 &a, const Mat3 &b) {
-    GS_FP_STRICT;
     Mat3 r;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -150,7 +153,6 @@ GS_DEV Mat3 mat3_tmul(const Mat3 &a, const Mat3 &b) {
 
 // a * b^T
 GS_DEV Mat3 mat3_mult(const Mat3 &a, const Mat3 &b) {
-    GS_FP_STRICT;
     Mat3 r;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -162,7 +164,6 @@ GS_DEV Mat3 mat3_mult(const Mat3 &a, const Mat3 &b) {
 
 // W * S * W^T for symmetric S -> symmetric
 GS_DEV Sym3 sym3_congruence(const Mat3 &W, const Sym3 &S) {
-    GS_FP_STRICT;
     Mat3 Sm = sym3_to_mat3(S);
     Mat3 WS = mat3_mul(W, Sm);
     Sym3 r;
@@ -177,7 +178,6 @@ GS_DEV Sym3 sym3_congruence(const Mat3 &W, const Sym3 &S) {
 
 // W^T * G * W for symmetric G -> symmetric
 GS_DEV Sym3 sym3_congruence_t(const Mat3 &W, const Sym3 &G) {
-    GS_FP_STRICT;
     Mat3 Gm = sym3_to_mat3(G);
     Mat3 GW = mat3_mul(Gm, W); // G * W
     Sym3 r;
@@ -193,7 +193,6 @@ GS_DEV Sym3 sym3_congruence_t(const Mat3 &W, const Sym3 &G) {
 // rotation matrix of a (possibly un-normalised) quaternion (w,x,y,z).
 // reference behaviour: gsplat/cuda/include/quat.cuh:9-31
 GS_DEV Mat3 quat_to_rotmat(float w, float x, float y, float z) {
-    GS_FP_STRICT;
     float inv = rsqrtf(w * w + x * x + y * y + z * z);
     w *= inv; x *= inv; y *= inv; z *= inv;
     float xx = x * x, yy = y * y, zz = z * z;
@@ -208,7 +207,6 @@ GS_DEV Mat3 quat_to_rotmat(float w, float x, float y, float z) {
 
 // Sigma = (R S)(R S)^T   (gsplat/cuda/include/quat_scale_to_covar_preci.cuh:10-41)
 GS_DEV Sym3 covar_from_rot_scale(const Mat3 &R, float sx, float sy, float sz) {
-    GS_FP_STRICT;
     Mat3 M;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -233,7 +231,6 @@ GS_DEV Sym3 covar_from_rot_scale(const Mat3 &R, float sx, float sy, float sz) {
 GS_DEV void covar_vjp_quat_scale(
     float qw, float qx, float qy, float qz, float sx, float sy, float sz,
     const Mat3 &R, const Mat3 &vSigma, float vq[4], float vs[3]) {
-    GS_FP_STRICT;
     // M = R S ; v_M = (G + G^T) M
     Mat3 Gs;
 #pragma unroll

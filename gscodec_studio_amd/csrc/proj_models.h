@@ -33,7 +33,6 @@ struct Jac {
 // pinhole: gsplat/cuda/include/proj.cuh:80-119 (the x/z, y/z clamp only affects J)
 GS_DEV void pinhole_jac(const Camera &cam, float x, float y, float z, int W, int H,
                         Jac &J, float &mx, float &my, float &txc, float &tyc) {
-    GS_FP_STRICT;
     float tan_fovx = 0.5f * W / cam.fx;
     float tan_fovy = 0.5f * H / cam.fy;
     float lim_x_pos = (W - cam.cx) / cam.fx + 0.3f * tan_fovx;
@@ -52,7 +51,6 @@ GS_DEV void pinhole_jac(const Camera &cam, float x, float y, float z, int W, int
 
 // orthographic: proj.cuh:9-37
 GS_DEV void ortho_jac(const Camera &cam, float x, float y, Jac &J, float &mx, float &my) {
-    GS_FP_STRICT;
     J.j00 = cam.fx; J.j01 = 0.f; J.j02 = 0.f;
     J.j10 = 0.f; J.j11 = cam.fy; J.j12 = 0.f;
     mx = cam.fx * x + cam.cx;
@@ -65,7 +63,6 @@ struct FisheyeTerms {
 };
 
 GS_DEV FisheyeTerms fisheye_terms(float x, float y, float z) {
-    GS_FP_STRICT;
     const float eps = 0.0000001f;
     FisheyeTerms t;
     t.x2 = x * x + eps;
@@ -82,7 +79,6 @@ GS_DEV FisheyeTerms fisheye_terms(float x, float y, float z) {
 }
 
 GS_DEV void fisheye_jac(const Camera &cam, float x, float y, float z, Jac &J, float &mx, float &my) {
-    GS_FP_STRICT;
     const float eps = 0.0000001f;
     FisheyeTerms t = fisheye_terms(x, y, z);
     float theta_m = atan2f(t.len, z + eps);
@@ -102,7 +98,6 @@ GS_DEV void fisheye_jac(const Camera &cam, float x, float y, float z, Jac &J, fl
 GS_DEV void proj_mean_vjp(const Camera &cam, int camera_model, float x, float y, float z, int W, int H,
                           float v_mx, float v_my, float vj00, float vj01, float vj02, float vj10, float vj11, float vj12,
                           float &vx, float &vy, float &vz) {
-    GS_FP_STRICT;
     float txc = 0.f, tyc = 0.f;
     FisheyeTerms ft = {};
     Jac J = {};

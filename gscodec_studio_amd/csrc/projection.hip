@@ -217,7 +217,6 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_bwd_kernel(
     float *__restrict__ v_means, float *__restrict__ v_covars, float *__restrict__ v_quats,
     float *__restrict__ v_scales, float *__restrict__ v_viewmats, uint32_t s_m2, uint32_t s_cn,
     const float *__restrict__ v_means_add, RowGrads rg) {
-    GS_FP_STRICT; // (the per-camera sums below: the same bits as projection_dyn.hip's backward)
     __shared__ float s_view[GS_BLOCK / GS_WAVE][12];
     float v_op = 0.f, v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f;
     uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;

@@ -24,7 +24,6 @@ GS_DEV Sym3 load_covar(
 
 // cov2d = J Sigma J^T
 GS_DEV Sym2 project_covar(const Jac &J, const Sym3 &S) {
-    GS_FP_STRICT;
     float a0 = J.j00 * S.xx + J.j01 * S.xy + J.j02 * S.xz;
     float a1 = J.j00 * S.xy + J.j01 * S.yy + J.j02 * S.yz;
     float a2 = J.j00 * S.xz + J.j01 * S.yz + J.j02 * S.zz;
@@ -52,7 +51,6 @@ GS_DEV Splat2D project_point(
     const Camera &cam, float px, float py, float pz, CovarFn covar,
     int W, int H, float eps2d, float near_plane, float far_plane, float radius_clip,
     int camera_model) {
-    GS_FP_STRICT;
     Splat2D out;
     out.radius = 0;
     float x = cam.W.m[0][0] * px + cam.W.m[0][1] * py + cam.W.m[0][2] * pz + cam.tx;
@@ -165,7 +163,6 @@ GS_DEV void project_one_vjp(
     float comp, float v_comp, bool has_comp,   // compensation
     float v_mx, float v_my, float v_depth, float v_ca, float v_cb, float v_cc,
     ProjGrad &g) {
-    GS_FP_STRICT;
     // conic = inverse(cov2d_blur): v_cov = -P G P, G = [[v_ca, v_cb/2],[v_cb/2, v_cc]]
     float g01 = 0.5f * v_cb;
     float t00 = ca * v_ca + cb * g01, t01 = ca * g01 + cb * v_cc;

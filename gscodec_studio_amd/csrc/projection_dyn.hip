@@ -73,20 +73,23 @@ GS_DEV void dyn_mean(const DynArgs &d, const float *__restrict__ means, uint32_t
     o.mz = slice_mean(p[2], m[2], m[5], m[8], tau, t2, t3);
 }
 
+// quats / scales of gaussian n as the slice takes them: through the round quantizer when hooked (raw[0..3] quaternion, raw[4..6] scales)
 template <bool QUANT>
-GS_DEV void dyn_shape(const DynArgs &d, float *__restrict__ quats, float *__restrict__ scales, uint32_t n, bool write, DynSplat &o) {
-    float qin[4], om[4];
+GS_DEV void dyn_shape_load(const DynArgs &d, float *__restrict__ quats, float *__restrict__ scales, uint32_t n, bool write, float raw[7]) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        qin[k] = dyn_q<QUANT>(d, QA_QUATS, quats + 4 * (size_t)n + k, quats[4 * (size_t)n + k], write);
-        om[k] = d.omega[4 * (size_t)n + k];
-    }
-    slice_quat(qin, om, o.st.tau, o.x, o.q);
+    for (int k = 0; k < 4; ++k) raw[k] = dyn_q<QUANT>(d, QA_QUATS, quats + 4 * (size_t)n + k, quats[4 * (size_t)n + k], write);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float v = dyn_q<QUANT>(d, QA_SCALES, scales + 3 * (size_t)n + k, scales[3 * (size_t)n + k], write);
-        o.s[k] = (d.raw & GS_DYN_RAW_SCALES) ? expf(v) : v;
-    }
+    for (int k = 0; k < 3; ++k) raw[4 + k] = dyn_q<QUANT>(d, QA_SCALES, scales + 3 * (size_t)n + k, scales[3 * (size_t)n + k], write);
+}
+
+// ... and their slice + activation (ONE body for every instance: the quantized and the plain kernels round the same way)
+GS_DEV void dyn_shape_eval(const DynArgs &d, const float raw[7], uint32_t n, DynSplat &o) {
+    float om[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) om[k] = d.omega[4 * (size_t)n + k];
+    slice_quat(raw, om, o.st.tau, o.x, o.q);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o.s[k] = (d.raw & GS_DYN_RAW_SCALES) ? expf(raw[4 + k]) : raw[4 + k];
 }
 
 template <bool QUANT>
@@ -127,10 +130,11 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_dyn_fwd_kernel(
     if (in) {
         dyn_time(dyn, n, o);
         dyn_mean(dyn, means, n, o);
+        float raw[7];
         if (QUANT) {
             // the quantizer clamps the PARAMETERS of every gaussian, seen or not: all hooked rows are read (and the rare
             // out-of-range value stored back) before anything is culled
-            dyn_shape<true>(dyn, quats, scales, n, write, o);
+            dyn_shape_load<true>(dyn, quats, scales, n, write, raw);
             if (rx.opacities != nullptr) dyn_opacity<true>(dyn, rx.opacities, n, write, o);
             if (rx.colors != nullptr) {
 #pragma unroll
@@ -138,7 +142,8 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_dyn_fwd_kernel(
             }
         }
         s = project_point<false>(cam, o.mx, o.my, o.mz, [&]() {
-            if (!QUANT) dyn_shape<false>(dyn, quats, scales, n, false, o);
+            if (!QUANT) dyn_shape_load<false>(dyn, quats, scales, n, false, raw);
+            dyn_shape_eval(dyn, raw, n, o);
             return covar_from_rot_scale(quat_to_rotmat(o.q[0], o.q[1], o.q[2], o.q[3]), o.s[0], o.s[1], o.s[2]); },
             W, H, eps2d, near_plane, far_plane, radius_clip, camera_model);
     }
@@ -183,7 +188,6 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_dyn_bwd_kernel(
     const float *__restrict__ opacities, const float *__restrict__ viewmats, const float *__restrict__ Ks, int W, int H, float eps2d,
     int camera_model, const int32_t *__restrict__ radii, const float *__restrict__ rows, const float *__restrict__ grad_rows,
     const float *__restrict__ v_depths, int antialiased, DynArgs dyn, DynGradOut out) {
-    GS_FP_STRICT;
     const uint32_t n = blockIdx.x * GS_BLOCK + threadIdx.x;
     if (n >= N) return;
     DynSplat o;
@@ -200,7 +204,9 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_dyn_bwd_kernel(
             // here is the identity, nothing is stored)
             dyn_time(dyn, n, o);
             dyn_mean(dyn, means, n, o);
-            dyn_shape<QUANT>(dyn, const_cast<float *>(quats), const_cast<float *>(scales), n, false, o);
+            float raw[7];
+            dyn_shape_load<QUANT>(dyn, const_cast<float *>(quats), const_cast<float *>(scales), n, false, raw);
+            dyn_shape_eval(dyn, raw, n, o);
             o.op_act = o.op_t = 0.f;
             if (opacities != nullptr) dyn_opacity<QUANT>(dyn, const_cast<float *>(opacities), n, false, o);
             S = covar_from_rot_scale(quat_to_rotmat(o.q[0], o.q[1], o.q[2], o.q[3]), o.s[0], o.s[1], o.s[2]);

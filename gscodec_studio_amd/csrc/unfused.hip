@@ -402,3 +402,184 @@ extern "C" int32_t gs_rasterize_indices_fill(uint32_t range_start, uint32_t rang
     GS_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------- accumulate
+// The reference's `accumulate` (gsplat/cuda/_torch_impl.py:432-519): alpha compositing over an explicit list of M (gaussian, pixel,
+// camera) intersections -- what rasterize_to_indices_in_range emits: grouped by ray (camera, pixel), front to back inside a ray.  The
+// reference evaluates it with torch ops + nerfacc (absent from the tree and unpinned: examples/requirements.txt:9-10 names the
+// git head; its two functions are restated from their published definitions):
+//     alpha_m   = min(opacity exp(-sigma_m), 0.999)                                   (_torch_impl.py:490-501)
+//     weight_m  = alpha_m prod_{k < m, same ray} (1 - alpha_k)                          nerfacc.render_weight_from_alpha
+//     renders[ray] = sum_m weight_m colors_m ;  alphas[ray] = sum_m weight_m           nerfacc.accumulate_along_rays (index_add)
+// A ray = a maximal run of consecutive entries with the same (camera, pixel) (nerfacc's packed_info over sorted ray_indices).
+// One lane per intersection; the lane that starts a run walks it (runs are a few hundred entries at most; this is the reference's
+// "playground" op, not the hot path).  Forward: grid.y = 1 + ceil(channels / 4): slice 0 writes weights and the alpha image, slice
+// 1 + k four colour channels.  Backward: the run heads walk back to front (T_m = T_{m+1} / (1 - alpha_m)), leaving d L / d alpha_m;
+// a second launch, one lane per (intersection, channel slice), scatters the parameter gradients with float atomics.
+namespace {
+
+struct AccArgs {
+    uint64_t M;
+    uint32_t C, N, channels;
+    int32_t W, H;
+    const float *means2d, *conics, *opacities, *colors; // [C,N,2] [C,N,3] [C,N] [C,N,channels]
+    const int64_t *gids, *pids, *cids;                  // [M]
+};
+
+GS_DEV int64_t acc_ray(const AccArgs &a, uint64_t m) { return a.cids[m] * (int64_t)a.H * a.W + a.pids[m]; }
+
+// alpha of entry m (and the pieces its gradient needs)
+struct AccAlpha {
+    float alpha, raw, dx, dy, e; // clamped | opacity exp(-sigma) | pixel - mean | exp(-sigma)
+    size_t elem;                 // camera * N + gaussian
+};
+GS_DEV AccAlpha acc_alpha(const AccArgs &a, uint64_t m) {
+    AccAlpha r;
+    r.elem = (size_t)a.cids[m] * a.N + (size_t)a.gids[m];
+    const int64_t p = a.pids[m];
+    const float px = (float)(p % a.W) + 0.5f, py = (float)(p / a.W) + 0.5f;
+    r.dx = px - a.means2d[2 * r.elem];
+    r.dy = py - a.means2d[2 * r.elem + 1];
+    const float ca = a.conics[3 * r.elem], cb = a.conics[3 * r.elem + 1], cc = a.conics[3 * r.elem + 2];
+    const float sigma = 0.5f * (ca * r.dx * r.dx + cc * r.dy * r.dy) + cb * r.dx * r.dy;
+    r.e = expf(-sigma);
+    r.raw = a.opacities[r.elem] * r.e;
+    r.alpha = fminf(r.raw, 0.999f);
+    return r;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) accumulate_fwd_kernel(AccArgs a, float *__restrict__ alpha_buf, float *__restrict__ weights,
+                                                                  float *__restrict__ renders, float *__restrict__ alphas) {
+    const uint64_t m = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (m >= a.M) return;
+    const int64_t ray = acc_ray(a, m);
+    const uint32_t slice = blockIdx.y;
+    if (slice == 0) alpha_buf[m] = acc_alpha(a, m).alpha; // (every lane: the backward and the other slices read it back)
+    if (m > 0 && acc_ray(a, m - 1) == ray) return;          // not the head of its run
+    float T = 1.f;
+    if (slice == 0) {
+        float acc = 0.f;
+        for (uint64_t j = m; j < a.M && acc_ray(a, j) == ray; ++j) {
+            const float al = acc_alpha(a, j).alpha;
+            const float w = al * T;
+            weights[j] = w;
+            acc += w;
+            T *= 1.f - al;
+        }
+        atomicAdd(alphas + ray, acc); // (index_add semantics: a ray split into several runs -- unsorted input -- sums its runs)
+        return;
+    }
+    const uint32_t c0 = (slice - 1u) * 4u;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (uint64_t j = m; j < a.M && acc_ray(a, j) == ray; ++j) {
+        const AccAlpha r = acc_alpha(a, j);
+        const float w = r.alpha * T;
+        const float *col = a.colors + r.elem * a.channels;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            if (c0 + k < a.channels) s[k] += w * col[c0 + k];
+        T *= 1.f - r.alpha;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k)
+        if (c0 + k < a.channels) atomicAdd(renders + ray * a.channels + c0 + k, s[k]);
+}
+
+// d L / d alpha_m for every entry (run heads walk their run back to front)
+__global__ void __launch_bounds__(GS_BLOCK) accumulate_bwd_alpha_kernel(AccArgs a, const float *__restrict__ alpha_buf,
+                                                                        const float *__restrict__ v_renders, const float *__restrict__ v_alphas,
+                                                                        float *__restrict__ v_alpha_pair) {
+    const uint64_t m = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (m >= a.M) return;
+    const int64_t ray = acc_ray(a, m);
+    if (m > 0 && acc_ray(a, m - 1) == ray) return;
+    uint64_t end = m;
+    float T = 1.f;
+    for (; end < a.M && acc_ray(a, end) == ray; ++end) T *= 1.f - alpha_buf[end];
+    const float va = v_alphas != nullptr ? v_alphas[ray] : 0.f;
+    const float *vr = v_renders != nullptr ? v_renders + ray * a.channels : nullptr;
+    float S = 0.f; // sum over the entries behind j of g_k w_k
+    for (uint64_t j = end; j-- > m;) {
+        const float al = alpha_buf[j];
+        const float ra = 1.f / (1.f - al); // alpha <= 0.999
+        T *= ra;                           // transmittance in front of j
+        float g = va;                      // d L / d weight_j
+        if (vr != nullptr) {
+            const float *col = a.colors + ((size_t)a.cids[j] * a.N + (size_t)a.gids[j]) * a.channels;
+            for (uint32_t k = 0; k < a.channels; ++k) g += vr[k] * col[k];
+        }
+        v_alpha_pair[j] = T * g - S * ra;
+        S += g * al * T;
+    }
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) accumulate_bwd_scatter_kernel(AccArgs a, const float *__restrict__ weights,
+                                                                          const float *__restrict__ v_alpha_pair, const float *__restrict__ v_renders,
+                                                                          float *__restrict__ v_means2d, float *__restrict__ v_conics,
+                                                                          float *__restrict__ v_opacities, float *__restrict__ v_colors) {
+    const uint64_t m = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (m >= a.M) return;
+    const uint32_t slice = blockIdx.y;
+    if (slice > 0) { // colours: v_colors[elem, ch] += weight v_renders[ray, ch]
+        if (v_colors == nullptr || v_renders == nullptr) return;
+        const size_t elem = (size_t)a.cids[m] * a.N + (size_t)a.gids[m];
+        const float w = weights[m];
+        const float *vr = v_renders + acc_ray(a, m) * a.channels;
+        const uint32_t c0 = (slice - 1u) * 4u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            if (c0 + k < a.channels) atomicAdd(v_colors + elem * a.channels + c0 + k, w * vr[c0 + k]);
+        return;
+    }
+    const AccAlpha r = acc_alpha(a, m);
+    const float va = v_alpha_pair[m];
+    if (!(r.raw <= 0.999f)) return; // clamp_max: no gradient above the cap (torch passes it at equality)
+    if (v_opacities != nullptr) atomicAdd(v_opacities + r.elem, va * r.e);
+    const float vs = -va * r.raw; // d / d sigma
+    if (v_conics != nullptr) {
+        atomicAdd(v_conics + 3 * r.elem, 0.5f * r.dx * r.dx * vs);
+        atomicAdd(v_conics + 3 * r.elem + 1, r.dx * r.dy * vs);
+        atomicAdd(v_conics + 3 * r.elem + 2, 0.5f * r.dy * r.dy * vs);
+    }
+    if (v_means2d != nullptr) { // delta = pixel - mean
+        const float ca = a.conics[3 * r.elem], cb = a.conics[3 * r.elem + 1], cc = a.conics[3 * r.elem + 2];
+        atomicAdd(v_means2d + 2 * r.elem, -(ca * r.dx + cb * r.dy) * vs);
+        atomicAdd(v_means2d + 2 * r.elem + 1, -(cc * r.dy + cb * r.dx) * vs);
+    }
+}
+
+} // namespace
+
+extern "C" int32_t gs_accumulate_fwd(uint64_t M, uint32_t C, uint32_t N, uint32_t channels, const float *means2d, const float *conics,
+                                     const float *opacities, const float *colors, const int64_t *gaussian_ids, const int64_t *pixel_ids,
+                                     const int64_t *camera_ids, int32_t image_width, int32_t image_height, float *alpha_buf, float *weights,
+                                     float *renders, float *alphas, gs_stream_t stream) {
+    if (M == 0) return 0;
+    GS_CHECK_ARG(means2d && conics && opacities && colors && gaussian_ids && pixel_ids && camera_ids && alpha_buf && weights && renders && alphas,
+                 "null pointer");
+    GS_CHECK_ARG(channels > 0 && image_width > 0 && image_height > 0, "channels, image_width and image_height must be > 0");
+    GS_CHECK_ARG(M <= 0x7FFFFFFFull * GS_BLOCK, "too many intersections");
+    const AccArgs a = {M, C, N, channels, image_width, image_height, means2d, conics, opacities, colors, gaussian_ids, pixel_ids, camera_ids};
+    hipLaunchKernelGGL(accumulate_fwd_kernel, dim3(gs_div_up(M, GS_BLOCK), 1 + gs_div_up(channels, 4)), dim3(GS_BLOCK), 0, (hipStream_t)stream, a,
+                       alpha_buf, weights, renders, alphas);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_accumulate_bwd(uint64_t M, uint32_t C, uint32_t N, uint32_t channels, const float *means2d, const float *conics,
+                                     const float *opacities, const float *colors, const int64_t *gaussian_ids, const int64_t *pixel_ids,
+                                     const int64_t *camera_ids, int32_t image_width, int32_t image_height, const float *alpha_buf,
+                                     const float *weights, const float *v_renders, const float *v_alphas, float *v_alpha_pair,
+                                     float *v_means2d, float *v_conics, float *v_opacities, float *v_colors, gs_stream_t stream) {
+    if (M == 0) return 0;
+    GS_CHECK_ARG(means2d && conics && opacities && colors && gaussian_ids && pixel_ids && camera_ids && alpha_buf && weights && v_alpha_pair,
+                 "null pointer");
+    GS_CHECK_ARG(channels > 0 && image_width > 0 && image_height > 0, "channels, image_width and image_height must be > 0");
+    const AccArgs a = {M, C, N, channels, image_width, image_height, means2d, conics, opacities, colors, gaussian_ids, pixel_ids, camera_ids};
+    hipLaunchKernelGGL(accumulate_bwd_alpha_kernel, dim3(gs_div_up(M, GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream, a, alpha_buf, v_renders,
+                       v_alphas, v_alpha_pair);
+    hipLaunchKernelGGL(accumulate_bwd_scatter_kernel, dim3(gs_div_up(M, GS_BLOCK), 1 + gs_div_up(channels, 4)), dim3(GS_BLOCK), 0,
+                       (hipStream_t)stream, a, weights, v_alpha_pair, v_renders, v_means2d, v_conics, v_opacities, v_colors);
+    GS_CHECK_LAUNCH();
+    return 0;
+}

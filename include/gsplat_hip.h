@@ -832,6 +832,25 @@ int32_t gs_png_unfilter(const uint8_t *data, uint32_t h, uint32_t stride, uint32
 
 
 /* ------------------------------------------------------------------------
+ * accumulate (reference gsplat/cuda/_torch_impl.py:432-519, exported as gsplat.accumulate): alpha compositing over an explicit list
+ * of M (gaussian, pixel, camera) intersections -- the output of the rasterize_indices pair above: grouped by ray (camera, pixel),
+ * front to back inside a ray.  alpha = min(opacity exp(-sigma), 0.999); weight = alpha x the product of (1 - alpha) over the
+ * entries in front of it in its run (nerfacc.render_weight_from_alpha); renders[camera, pixel] += sum weight colour,
+ * alphas[camera, pixel] += sum weight (nerfacc.accumulate_along_rays).  A run = consecutive entries with the same (camera, pixel).
+ * renders [C,H,W,channels] / alphas [C,H,W] are ADDED to (the caller zero-fills them); alpha_buf / weights [M] are written and
+ * handed back to gs_accumulate_bwd, which ADDS into v_means2d [C,N,2], v_conics [C,N,3], v_opacities [C,N], v_colors
+ * [C,N,channels] (float atomics; each may be NULL) and uses v_alpha_pair [M] as scratch.  v_renders / v_alphas may be NULL. */
+int32_t gs_accumulate_fwd(uint64_t M, uint32_t C, uint32_t N, uint32_t channels, const float *means2d, const float *conics,
+                          const float *opacities, const float *colors, const int64_t *gaussian_ids, const int64_t *pixel_ids,
+                          const int64_t *camera_ids, int32_t image_width, int32_t image_height, float *alpha_buf, float *weights,
+                          float *renders, float *alphas, gs_stream_t stream);
+int32_t gs_accumulate_bwd(uint64_t M, uint32_t C, uint32_t N, uint32_t channels, const float *means2d, const float *conics,
+                          const float *opacities, const float *colors, const int64_t *gaussian_ids, const int64_t *pixel_ids,
+                          const int64_t *camera_ids, int32_t image_width, int32_t image_height, const float *alpha_buf,
+                          const float *weights, const float *v_renders, const float *v_alphas, float *v_alpha_pair,
+                          float *v_means2d, float *v_conics, float *v_opacities, float *v_colors, gs_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Temporal slicing of dynamic (spacetime) gaussians at one timestamp: the elementwise
  * chain in front of rasterization() in examples/simple_trainer_dyngs.py:506-521 -- trbf opacity decay
  * exp(-((t - center) / (sqrt2 scale))^2), cubic motion of the means (motion [N,9] = linear | quadratic |

@@ -129,3 +129,40 @@ def temporal_slice(means, motion, quats, omega, opacities, trbf_center, trbf_sca
     x = quats + tp * omega
     quats_t = x / torch.clamp(x.norm(dim=-1, keepdim=True), min=1e-12)
     return means_t, quats_t, opacity, trbf
+
+
+def accumulate(means2d, conics, opacities, colors, gaussian_ids, pixel_ids, camera_ids, image_width, image_height):
+    """gsplat/cuda/_torch_impl.py:432-519 restated in torch (any dtype; differentiable): the reference's own statements for the alphas
+    (490-501) and its two nerfacc calls (503-517) from nerfacc's published definitions -- ``render_weight_from_alpha``: weight = alpha x
+    the exclusive product of (1 - alpha) along each ray; ``accumulate_along_rays``: ``index_add`` of weight (x value) into the rays.
+    nerfacc is absent here and unpinned by the reference (examples/requirements.txt:9-10: the git head), so this restatement is PARITY
+    UNPINNED by executable reference code; tests pin it against a per-ray python loop (tests/test_unfused_cpu.py) and, composed with
+    rasterize_to_indices_in_range as in ``_rasterize_to_pixels`` (522-617), against the compositing oracle.
+    A ray = a maximal run of consecutive entries with equal (camera, pixel), as nerfacc's packed scans see sorted ray_indices."""
+    C, N = means2d.shape[:2]
+    channels = colors.shape[-1]
+    g, p, c = (torch.as_tensor(np.asarray(t), dtype=torch.int64) for t in (gaussian_ids, pixel_ids, camera_ids))
+    px = (p % image_width).to(means2d.dtype) + 0.5
+    py = (p // image_width).to(means2d.dtype) + 0.5
+    deltas = torch.stack([px, py], -1) - means2d[c, g]
+    cn = conics[c, g]
+    sigmas = 0.5 * (cn[:, 0] * deltas[:, 0] ** 2 + cn[:, 2] * deltas[:, 1] ** 2) + cn[:, 1] * deltas[:, 0] * deltas[:, 1]
+    alphas = torch.clamp_max(opacities[c, g] * torch.exp(-sigmas), 0.999)
+    rays = c * image_height * image_width + p
+    M = rays.shape[0]
+    total = C * image_height * image_width
+    if M == 0:
+        return means2d.new_zeros((C, image_height, image_width, channels)), means2d.new_zeros((C, image_height, image_width, 1))
+    head = torch.ones(M, dtype=torch.bool)
+    head[1:] = rays[1:] != rays[:-1]
+    run = torch.cumsum(head.to(torch.int64), 0) - 1                      # run index of every entry
+    start = torch.nonzero(head).reshape(-1)
+    pos = torch.arange(M) - start[run]                                     # position inside the run
+    L = int(pos.max()) + 1
+    one_minus = alphas.new_ones((start.numel(), L + 1))
+    one_minus = one_minus.index_put((run, pos + 1), 1.0 - alphas)          # column 0 = 1: exclusive product
+    trans = torch.cumprod(one_minus, dim=1)[run, pos]
+    weights = alphas * trans
+    renders = means2d.new_zeros((total, channels)).index_add(0, rays, weights[:, None] * colors[c, g])
+    acc = means2d.new_zeros((total,)).index_add(0, rays, weights)
+    return renders.reshape(C, image_height, image_width, channels), acc.reshape(C, image_height, image_width, 1)

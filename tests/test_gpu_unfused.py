@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import N, T, assert_close, garden, golden
+from util import N, T, assert_close, garden, golden, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -134,3 +134,99 @@ def test_indices_in_range_empty_and_asserts():
         rasterize_to_indices_in_range(0, 5, torch.ones(C, H, W, device="cuda"), z(C, n, 2, device="cuda"), z(C, n, 3, device="cuda"),
                                       z(C, n, device="cuda"), W, H, 8, z(C, 2, 2, dtype=torch.int32, device="cuda"),
                                       z(4, dtype=torch.int32, device="cuda"))
+
+
+# ------------------------------------------------------------------------------------------------------------ accumulate
+def _torch_style_rasterize_to_pixels(means2d, conics, colors, opacities, W, H, tile_size, isect_offsets, flatten_ids, backgrounds=None,
+                                     batch_per_iter=100):
+    """The reference's ``_rasterize_to_pixels`` recipe (gsplat/cuda/_torch_impl.py:522-617) over this package's operators: batches of
+    ``rasterize_to_indices_in_range`` + ``accumulate``, the transmittance carried from batch to batch."""
+    from gscodec_studio_amd import accumulate, rasterize_to_indices_in_range
+
+    C = means2d.shape[0]
+    n_isects = len(flatten_ids)
+    dev = means2d.device
+    render_colors = torch.zeros((C, H, W, colors.shape[-1]), device=dev)
+    render_alphas = torch.zeros((C, H, W, 1), device=dev)
+    block = tile_size * tile_size
+    fl = torch.cat([isect_offsets.flatten(), torch.tensor([n_isects], device=dev, dtype=isect_offsets.dtype)])
+    max_range = int((fl[1:] - fl[:-1]).max().item())
+    num_batches = (max_range + block - 1) // block
+    for step in range(0, num_batches, batch_per_iter):
+        trans = 1.0 - render_alphas[..., 0]
+        gs, px, cam = rasterize_to_indices_in_range(step, step + batch_per_iter, trans, means2d, conics, opacities, W, H, tile_size,
+                                                    isect_offsets, flatten_ids)
+        if len(gs) == 0:
+            break
+        r_, a_ = accumulate(means2d, conics, opacities, colors, gs, px, cam, W, H)
+        render_colors = render_colors + r_ * trans[..., None]
+        render_alphas = render_alphas + a_ * trans[..., None]
+    if backgrounds is not None:
+        render_colors = render_colors + backgrounds[:, None, None, :] * (1.0 - render_alphas)
+    return render_colors, render_alphas
+
+
+@pytest.mark.parametrize("channels,batch_per_iter", [(3, 100), (3, 1), (32, 100), (7, 2)])
+def test_accumulate_recipe_vs_rasterize_to_pixels(channels, batch_per_iter):
+    """The reference's own test of its compositing kernels (tests/test_basic.py:475-576): ``rasterize_to_pixels`` forward and backward
+    against the torch-style recipe, same tolerances -- here both sides are HIP (the fused compositing kernels against
+    rasterize_to_indices_in_range + accumulate), so the test ties the two independent implementations together."""
+    from gscodec_studio_amd import rasterize_to_pixels
+
+    rc, ra, meta, W, H, C, n, d = _scene(n=600)
+    ts = meta["tile_size"]
+    g = torch.Generator(device="cuda").manual_seed(42)
+    means2d = meta["means2d"].detach().clone().contiguous().requires_grad_(True)
+    conics = meta["conics"].detach().clone().contiguous().requires_grad_(True)
+    opac = meta["opacities"].detach().clone().contiguous().requires_grad_(True)
+    colors = torch.randn((C, n, channels), device="cuda", generator=g).requires_grad_(True)
+    bg = torch.rand((C, channels), device="cuda", generator=g).requires_grad_(True)
+    offs, flat = meta["isect_offsets"], meta["flatten_ids"]
+    r1, a1 = rasterize_to_pixels(means2d, conics, colors, opac, W, H, ts, offs, flat, backgrounds=bg)
+    r2, a2 = _torch_style_rasterize_to_pixels(means2d, conics, colors, opac, W, H, ts, offs, flat, backgrounds=bg,
+                                              batch_per_iter=batch_per_iter)
+    torch.testing.assert_close(r1, r2, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(a1, a2, rtol=1e-4, atol=1e-4)
+    v_r = torch.randn(r1.shape, device="cuda", generator=g)
+    v_a = torch.randn(a1.shape, device="cuda", generator=g)
+    ins = (means2d, conics, colors, opac, bg)
+    g1 = torch.autograd.grad((r1 * v_r).sum() + (a1 * v_a).sum(), ins)
+    g2 = torch.autograd.grad((r2 * v_r).sum() + (a2 * v_a).sum(), ins)
+    for (x, y, tol, name) in zip(g1, g2, (5e-3, 1e-3, 1e-3, 2e-3, 1e-3), ("means2d", "conics", "colors", "opacities", "backgrounds")):
+        if batch_per_iter >= 100:  # (one batch: the reference's tolerances, tests/test_basic.py:571-575)
+            torch.testing.assert_close(x, y, rtol=tol, atol=tol, msg=lambda m: f"{name}: {m}")
+        else:  # (many batches: the transmittance carried between batches is not differentiated through the index op's threshold tests)
+            assert rel_ok(N(x), N(y), 1e-3) < 5e-3, name
+
+
+def test_accumulate_vs_oracle_and_edge_cases():
+    from gscodec_studio_amd import accumulate, rasterize_to_indices_in_range
+
+    rc, ra, meta, W, H, C, n, d = _scene(n=300)
+    ts = meta["tile_size"]
+    g, p, c = rasterize_to_indices_in_range(0, 10**10, torch.ones((C, H, W), device="cuda"), meta["means2d"], meta["conics"], meta["opacities"],
+                                            W, H, ts, meta["isect_offsets"], meta["flatten_ids"])
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    ins = [meta["means2d"].detach().clone().contiguous(), meta["conics"].detach().clone().contiguous(),
+           (meta["opacities"].detach() * 1.3).contiguous(),   # some above the 0.999 cap
+           torch.randn((C, n, 5), device="cuda", generator=gen)]
+    ins = [t.requires_grad_(True) for t in ins]
+    r, a = accumulate(*ins, g, p, c, W, H)
+    v_r, v_a = torch.randn(r.shape, device="cuda", generator=gen), torch.randn(a.shape, device="cuda", generator=gen)
+    grads = torch.autograd.grad((r * v_r).sum() + (a * v_a).sum(), ins)
+    (o_r, o_a), o_g = UO.with_grads(lambda *t: UO.accumulate(*t, N(g), N(p), N(c), W, H), [N(t) for t in ins], (N(v_r), N(v_a)))
+    assert_close(N(r), o_r, 1e-4, 1e-5, "accumulate renders")
+    assert_close(N(a), o_a, 1e-4, 1e-5, "accumulate alphas")
+    for x, y, name in zip(grads, o_g, ("means2d", "conics", "opacities", "colors")):
+        assert rel_l2(N(x), y) < 2e-5, (name, rel_l2(N(x), y))
+    # the forward image of the fused kernels, from the listed pairs (colours = the splat colours of _scene)
+    r3, a3 = accumulate(meta["means2d"], meta["conics"], meta["opacities"], d["colors"][None].expand(C, -1, -1).contiguous(), g, p, c, W, H)
+    assert_close(N(r3), N(rc), 1e-4, 1e-5, "accumulate vs the compositing forward", max_bad_frac=1e-3)
+    # no intersections: zero images, zero gradients
+    e = torch.empty((0,), dtype=torch.int64, device="cuda")
+    r0, a0 = accumulate(*ins, e, e, e, W, H)
+    assert float(r0.abs().max()) == 0.0 and r0.shape == (C, H, W, 5) and a0.shape == (C, H, W, 1)
+    g0 = torch.autograd.grad(r0.sum() + a0.sum(), ins, allow_unused=True)
+    assert all(x is None or float(x.abs().max()) == 0.0 for x in g0)
+    with pytest.raises(AssertionError):
+        accumulate(ins[0], ins[1], ins[2], ins[3], g, p[:-1], c, W, H)

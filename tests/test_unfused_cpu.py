@@ -117,3 +117,54 @@ def test_temporal_slice_oracle_vs_reference_statements():
     tr = UO.temporal_slice(*[torch.tensor(gd[k], dtype=torch.float64) for k in keys], 0.3125)[3].numpy()
     sure = np.abs(tr - 0.05) > 1e-6
     assert np.array_equal((tr > 0.05)[sure], gd["vis_mask"][sure]) and int(gd["vis_count"]) == int(gd["vis_mask"].sum())
+
+
+def test_accumulate_oracle_vs_per_ray_loop():
+    """``UO.accumulate`` (vectorised restatement of _torch_impl.py:432-519 + nerfacc's two published definitions) against the definition
+    itself, one python loop per ray: weight = alpha x prod(1 - alpha) over the entries in front, renders = sum weight colour."""
+    rng = np.random.default_rng(7)
+    C, N, W, H, ch = 2, 30, 6, 5, 5
+    means2d = torch.tensor(rng.uniform([0, 0], [W, H], size=(C, N, 2)))
+    conics = torch.tensor(np.tile(np.array([0.9, 0.1, 0.7]), (C, N, 1)) * rng.uniform(0.5, 1.5, size=(C, N, 1)))
+    opac = torch.tensor(rng.uniform(0.2, 1.5, size=(C, N)))   # > 1: the 0.999 cap is exercised
+    colors = torch.tensor(rng.normal(size=(C, N, ch)))
+    g, p, c = [], [], []
+    for cam in range(C):
+        for pix in rng.permutation(W * H)[: W * H - 4]:      # some rays stay empty
+            k = int(rng.integers(1, 7))
+            g += list(rng.choice(N, size=k, replace=False))
+            p += [int(pix)] * k
+            c += [cam] * k
+    order = np.lexsort((np.arange(len(g)), np.array(p), np.array(c)))  # rays sorted, list order kept inside a ray
+    g, p, c = (np.array(x)[order] for x in (g, p, c))
+    ins = [t.clone().requires_grad_(True) for t in (means2d, conics, opac, colors)]
+    r, a = UO.accumulate(*ins, g, p, c, W, H)
+    vr, va = torch.tensor(rng.normal(size=r.shape)), torch.tensor(rng.normal(size=a.shape))
+    grads = torch.autograd.grad((r * vr).sum() + (a * va).sum(), ins)
+
+    ins2 = [t.clone().requires_grad_(True) for t in (means2d, conics, opac, colors)]
+    m2, cn, op, col = ins2
+    r2 = torch.zeros((C, H, W, ch), dtype=torch.float64)
+    a2 = torch.zeros((C, H, W, 1), dtype=torch.float64)
+    i = 0
+    while i < len(g):
+        j = i
+        T = torch.tensor(1.0, dtype=torch.float64)
+        cam, pix = int(c[i]), int(p[i])
+        rr, aa = 0.0, 0.0
+        while j < len(g) and c[j] == cam and p[j] == pix:
+            dx = (pix % W) + 0.5 - m2[cam, g[j], 0]
+            dy = (pix // W) + 0.5 - m2[cam, g[j], 1]
+            sigma = 0.5 * (cn[cam, g[j], 0] * dx * dx + cn[cam, g[j], 2] * dy * dy) + cn[cam, g[j], 1] * dx * dy
+            alpha = torch.clamp_max(op[cam, g[j]] * torch.exp(-sigma), 0.999)
+            rr = rr + alpha * T * col[cam, g[j]]
+            aa = aa + alpha * T
+            T = T * (1 - alpha)
+            j += 1
+        r2[cam, pix // W, pix % W] = rr
+        a2[cam, pix // W, pix % W, 0] = aa
+        i = j
+    grads2 = torch.autograd.grad((r2 * vr).sum() + (a2 * va).sum(), ins2)
+    assert torch.allclose(r, r2, rtol=1e-12, atol=1e-13) and torch.allclose(a, a2, rtol=1e-12, atol=1e-13)
+    for x, y in zip(grads, grads2):
+        assert torch.allclose(x, y, rtol=1e-10, atol=1e-12)
