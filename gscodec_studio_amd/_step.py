@@ -274,11 +274,10 @@ class _StepProject(torch.autograd.Function):
             # (_wrapper.GradPrefill: the compositing forward zero-fills it as a side job)
             need = ctx.needs_input_grad
             prefill = W.GradPrefill()
-            prefill.request = [(key, tuple(t.shape)) for key, t, flag in (
+            prefill.request = W.prefill_request((
                 ("means", means, need[0]), ("covars", covars, need[1]), ("quats", quats, need[2]), ("scales", scales, need[3]),
                 ("opacities", opacities, need[6]), ("colors", colors, need[7]), ("sh", sh_coeffs, need[8]), ("sh_rest", sh_rest, need[9]))
-                + (W.dyn_prefill_items(ctx.dyn, need, 14) if ctx.dyn is not None else ())
-                if t is not None and flag]
+                + (W.dyn_prefill_items(ctx.dyn, need, 14) if ctx.dyn is not None else ()))
         try:
             with torch.cuda.device(dev):
                 B.call("gs_step_fwd_begin", sp, stream)

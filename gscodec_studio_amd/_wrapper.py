@@ -862,6 +862,18 @@ PREFILL_ENABLED = os.environ.get("GS_GRAD_PREFILL", "1") != "0"
 _FAST_MAX_CHANNELS = 32  # channel counts the tile forward / segmented backward cover (csrc/rasterize.hip: FAST_MAX_CHANNELS)
 
 
+# The order in which the per-gaussian gradients of ONE rasterization() call are carved out of their common buffer (GradPrefill.carve).
+# distributed.all_reduce_splat_grads reduces that buffer in place when a rank's gradients lie in exactly this order
+# (distributed._CARVE_RANK is derived from it), so both autograd nodes that build a request go through prefill_request().
+PREFILL_ORDER = ("means", "covars", "quats", "scales", "opacities", "colors", "sh", "sh_rest", "motion", "omega", "trbf_center", "trbf_scale")
+
+
+def prefill_request(items) -> list:
+    """[(key, shape)] of the wanted tensors among ``items`` = [(key, tensor or None, wanted)], in PREFILL_ORDER."""
+    req = [(key, tuple(t.shape)) for key, t, flag in items if t is not None and flag]
+    return sorted(req, key=lambda kv: PREFILL_ORDER.index(kv[0]))
+
+
 class GradPrefill:
     """Hand-over between the two autograd nodes of ONE ``rasterization()`` call (not in the reference).
 
@@ -1106,13 +1118,10 @@ class _ProjectRows(torch.autograd.Function):
         need = ctx.needs_input_grad
         if prefill is not None and (any(need[:10]) or (dyn is not None and any(need[22:26]))) and not need[4] and N > 0:
             # what the backward will return per gaussian, for the compositing forward to allocate and zero-fill
-            req = []
-            for key, t, flag in (("means", means, need[0]), ("covars", covars, need[1]), ("quats", quats, need[2]),
-                                 ("scales", scales, need[3]), ("opacities", opacities, need[6]),
-                                 ("colors", colors, need[7]), ("sh", sh_coeffs, need[8]), ("sh_rest", sh_rest, need[9])) + (
-                    dyn_prefill_items(ctx.dyn, need, 22) if ctx.dyn is not None else ()):
-                if t is not None and flag:
-                    req.append((key, tuple(t.shape)))
+            req = prefill_request((("means", means, need[0]), ("covars", covars, need[1]), ("quats", quats, need[2]),
+                                   ("scales", scales, need[3]), ("opacities", opacities, need[6]), ("colors", colors, need[7]),
+                                   ("sh", sh_coeffs, need[8]), ("sh_rest", sh_rest, need[9]))
+                                  + (dyn_prefill_items(ctx.dyn, need, 22) if ctx.dyn is not None else ()))
             prefill.request = req
             ctx.prefill = prefill
         ctx.mark_non_differentiable(radii, rows)
@@ -1370,7 +1379,8 @@ def _pinned_take(n: int) -> Tensor:
 _PACKED_PAIRS = os.environ.get("GS_PACKED_PAIRS", "1") != "0"
 
 
-_WAIT_TIMEOUT_S = float(os.environ.get("GS_WAIT_TIMEOUT_S", "30"))  # hard limit of any host wait on the GPU
+_WAIT_TIMEOUT_S = float(os.environ.get("GS_WAIT_TIMEOUT_S", "600"))  # backstop of any host wait on a BUSY stream (<= 0: none)
+_WAIT_WARNED = [False]
 
 
 class _SentinelEvent:
@@ -1381,7 +1391,8 @@ class _SentinelEvent:
 
     The wait is BOUNDED and notices a dead GPU: round 4's query / yield loop for the first few hundred polls, then a yielding spin up to 20 ms, naps after that; every ~2 ms the launch stream is queried -- a
     device fault raises there, and a stream that has drained while the sentinel is still unset means the kernel never stored
-    (failed launch, lost write): RuntimeError instead of a core spinning for good; ``GS_WAIT_TIMEOUT_S`` (30) ends any wait."""
+    (failed launch, lost write): RuntimeError instead of a core spinning for good.  A stream that is still busy is waited for (one
+    warning after 30 s); ``GS_WAIT_TIMEOUT_S`` (600; <= 0: none) is only the backstop behind that."""
 
     __slots__ = ("buf", "np", "stream", "what")
 
@@ -1424,7 +1435,15 @@ class _SentinelEvent:
                         return
                     raise RuntimeError(f"the stream drained but {self.what} never arrived in pinned memory "
                                        f"(kernel not launched, faulted, or its stores were lost)")
-                if now - t0 > limit:
+                # a stream that is still BUSY is not an error: a long evaluation queued ahead, a shared GPU or a profiler serialising
+                # kernels can legitimately put many seconds of work in front of the count kernel.  Warn once and keep waiting; the
+                # bound (GS_WAIT_TIMEOUT_S, default 600 s; <= 0: none) is a backstop for a hung device whose stream query still answers
+                if now - t0 > 30.0 and not _WAIT_WARNED[0]:
+                    _WAIT_WARNED[0] = True
+                    import warnings
+
+                    warnings.warn(f"gscodec_studio_amd: waited {now - t0:.0f} s for {self.what}; the launch stream is still busy -- waiting on")
+                if limit > 0 and now - t0 > limit:
                     raise RuntimeError(f"timed out after {limit:.1f} s (GS_WAIT_TIMEOUT_S) waiting for {self.what}")
             # yielding spin for 20 ms (a thread that napped comes back late: a 50 us time.sleep takes ~100 us on the test hosts, and
             # with naps from 1 ms on a 2-camera step read 2.63 ms instead of 1.37, tools/bench_multicam.py), naps after that: a wait
@@ -1693,11 +1712,18 @@ def _splat_layout(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Te
 @torch.no_grad()
 def _split_big_tiles(isect_offsets: Tensor, flatten_ids: Tensor, masks: Optional[Tensor]):
     """Tiles of 2s x 2s pixels as 2 x 2 sub-tiles of s x s: -> (offsets [C, 2 th, 2 tw], flatten_ids [4 n], masks) where every
-    sub-tile owns a copy of its tile's list range (no host synchronisation: the total is 4 n)."""
+    sub-tile owns a copy of its tile's list range (no host synchronisation: the total is 4 n).
+
+    Cost of this detour (tile sizes 18..32 serve no caller in the reference; every trainer uses 16): the list is materialised FOUR
+    times (16 n bytes) plus two int32 temporaries of 4 n entries; offsets are int32 like the reference's, so 4 n must stay below 2^31."""
     C, th, tw = isect_offsets.shape
     n = int(flatten_ids.shape[0])
+    total = 4 * n
+    if total >= 2 ** 31:
+        raise RuntimeError(f"tile_size > 16: {n} intersections x 4 sub-tile copies overflow the int32 tile offsets; use tile_size <= 16")
     dev = flatten_ids.device
-    start = isect_offsets.reshape(-1).to(torch.int64)
+    i32 = torch.int32
+    start = isect_offsets.reshape(-1).to(i32)
     end = torch.cat([start[1:], start.new_full((1,), n)])
 
     def rep(t):
@@ -1705,15 +1731,17 @@ def _split_big_tiles(isect_offsets: Tensor, flatten_ids: Tensor, masks: Optional
 
     vcount = rep((end - start).view(C, th, tw)).reshape(-1)
     vstart = rep(start.view(C, th, tw)).reshape(-1)
-    voff = torch.cumsum(vcount, 0) - vcount
-    total = 4 * n
+    vend = torch.cumsum(vcount, 0, dtype=i32)  # (< 2^31: checked above)
+    voff = vend - vcount
     if total > 0:
-        tile_of = torch.repeat_interleave(torch.arange(vcount.numel(), device=dev), vcount, output_size=total)
-        src = vstart[tile_of] + (torch.arange(total, device=dev) - voff[tile_of])
-        flat = flatten_ids[src].contiguous()
+        # sub-tile of every output slot by binary search over the running ends (no repeat_interleave + gather temporaries in int64)
+        slot = torch.arange(total, device=dev, dtype=i32)
+        tile_of = torch.searchsorted(vend, slot, right=True)
+        src = (vstart - voff)[tile_of] + slot
+        flat = flatten_ids.index_select(0, src)
     else:
         flat = flatten_ids.new_empty(0)
-    return voff.to(torch.int32).view(C, 2 * th, 2 * tw).contiguous(), flat, (rep(masks).contiguous() if masks is not None else None)
+    return voff.view(C, 2 * th, 2 * tw).contiguous(), flat, (rep(masks).contiguous() if masks is not None else None)
 
 
 def rasterize_to_pixels(

@@ -318,7 +318,10 @@ __global__ void __launch_bounds__(256, CDIM > 9 ? GS_WIDE_FWD_WAVES : 1) raster_
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     if (tid < REC) s_rec[NBUF * BATCH * REC + tid] = make_float4(0.f, tid == 1 ? -__builtin_inff() : 0.f, 0.f, 0.f); // log2(opacity) = -inf
     // the class counters of the backward's work list (seg_items_build_kernel runs after this kernel, in the same call)
-    if (CKPT && blockIdx.x == 0 && tid < (uint32_t)COST_CLASSES) class_count[tid] = 0u;
+    // (a chunked forward -- 17..32 channels as two launches -- writes the counters and the costs in its FIRST launch only: culling does
+    // not depend on the channel, and the second launch would only repeat the same stores)
+    const bool cost_owner = !WIDE || ch_off == 0u;
+    if (CKPT && cost_owner && blockIdx.x == 0 && tid < (uint32_t)COST_CLASSES) class_count[tid] = 0u;
     const TileGeom tg = tile_geom(a, a.tile_order != nullptr ? a.tile_order[blockIdx.x] : xcd_remap(blockIdx.x, gridDim.x, a.xcd_group));
     const float *bg = a.backgrounds ? a.backgrounds + (size_t)tg.cam * a.channels + (WIDE ? ch_off : 0u) : nullptr;
     const uint32_t CH = WIDE ? a.channels : (uint32_t)CDIM; // channels of the output image / checkpoint planes
@@ -416,7 +419,7 @@ __global__ void __launch_bounds__(256, CDIM > 9 ? GS_WIDE_FWD_WAVES : 1) raster_
     uint32_t evals = 0;
     bool first_seg = true;
     auto store_cost = [&]() { // the segment in front of boundary next_k has ended
-        if (lane == 0) {
+        if (lane == 0 && cost_owner) {
             if (first_seg) cost_head[tg.lin * 4u + w] = evals;
             else {
                 cost_body[(size_t)(next_k - 1) * 4u + w] = evals;

@@ -976,6 +976,14 @@ def all_reduce_splat_grads(
             span = _one_span(canon, length)
             staged = span is None
             if staged:
+                if not _STAGING_LOGGED[0] and os.environ.get("GS_DP_QUIET") != "1" and any(p.is_cuda for p in plist):
+                    _STAGING_LOGGED[0] = True
+                    import warnings
+
+                    warnings.warn("all_reduce_splat_grads: the gradients of this rank do not lie in rasterization()'s one buffer in the "
+                                  f"canonical order (parameter names {keys}; known names: {sorted(_CARVE_RANK)}): staging them through a "
+                                  "scratch span every step (correct, one extra copy each way).  Pass the parameters as a dict with the "
+                                  "trainer's names to reduce in place.")
                 span = _stage_span(canon, length)
             if "nccl" not in _backend_name():  # (gloo: no reduce_scatter_tensor; the tests' route)
                 _all_reduce_sum(span)
@@ -1040,10 +1048,21 @@ def _span_length(numels: List[int], world_size: int) -> int:
     return n + (-n) % world_size
 
 
-# the order in which rasterization() carves the per-gaussian gradients out of its one buffer (_wrapper.GradPrefill.request:
-# means, covars, quats, scales, opacities, colours | SH (DC band), SH rest), by the names trainers give those parameters
-_CARVE_RANK = {"means": 0, "covars": 1, "quats": 2, "scales": 3, "opacities": 4, "colors": 5, "sh": 5, "sh0": 5, "sh_coeffs": 5,
-               "shN": 6, "sh_rest": 6}
+# the order in which rasterization() carves the per-gaussian gradients out of its one buffer (_wrapper.PREFILL_ORDER, the one list both
+# autograd nodes build their request from), by the names trainers give those parameters (the reference's trainers: means, scales,
+# quats, opacities, sh0, shN | colors; the dynamic trainer adds motion, omega, trbf_center, trbf_scale)
+def _carve_rank() -> dict:
+    from ._wrapper import PREFILL_ORDER
+
+    rank = {k: i for i, k in enumerate(PREFILL_ORDER)}
+    rank["sh"] = rank["colors"]  # (colours and SH coefficients never ride in the same call: one slot)
+    for alias, k in (("sh0", "sh"), ("sh_coeffs", "sh"), ("features_dc", "sh"), ("shN", "sh_rest"), ("features_rest", "sh_rest")):
+        rank[alias] = rank[k]
+    return rank
+
+
+_CARVE_RANK = _carve_rank()
+_STAGING_LOGGED = [False]
 
 
 def _canonical_order(keys: List[Optional[str]]) -> List[int]:

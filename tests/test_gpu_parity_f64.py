@@ -61,8 +61,12 @@ def _check(name, hip, f32, f64, cond=None):
     floor = 1e-7 * np.abs(f64).max()
     # max norm: no entry is off by more than 1e-4 of the largest entry -- or, where the fp32 ORACLE itself is further off than
     # that (32 channels: 1.35e-4 for v_opacities, the kernels 1.13e-4), by more than the oracle is
-    bound = max(1e-4, np.abs(f32 - f64).max() / np.abs(f64).max())
-    assert np.abs(hip - f64).max() <= bound * np.abs(f64).max(), (name, "max norm", np.abs(hip - f64).max() / np.abs(f64).max())
+    # (round-5 advisor: the adaptive bound is CAPPED at 2e-4, so that a regression of the kernels cannot hide behind a bad day of the fp32
+    # oracle, and the observed error is printed per case so that drift stays visible when the bound moves)
+    bound = min(2e-4, max(1e-4, np.abs(f32 - f64).max() / np.abs(f64).max()))
+    e_max = np.abs(hip - f64).max() / np.abs(f64).max()
+    print(f"                   {name:12s} max norm: HIP {e_max:.2e}  bound {bound:.2e}")
+    assert e_max <= bound, (name, "max norm", e_max, bound)
     # entrywise 1e-4 relative is reached on (at least) as many entries as the fp32 oracle reaches it on: the entries that
     # miss it are small differences of large per-pixel terms, which no fp32 evaluation resolves (see `cond` below)
     reach_o = (np.abs(f32 - f64) <= 1e-4 * np.abs(f64) + floor).mean()

@@ -124,3 +124,25 @@ def test_big_tiles_are_split_into_sub_tiles_with_their_own_list_copies():
                 k += 1
     vo0, vf0, vm0 = _split_big_tiles(torch.zeros((1, 2, 2), dtype=torch.int32), torch.zeros(0, dtype=torch.int32), None)
     assert vo0.shape == (1, 4, 4) and int(vo0.abs().sum()) == 0 and vf0.numel() == 0 and vm0 is None
+
+
+def test_carve_order_has_one_source():
+    """distributed._CARVE_RANK (which parameter name maps onto which piece of rasterization()'s one gradient buffer) is derived from
+    _wrapper.PREFILL_ORDER, the list both autograd nodes build their GradPrefill request from (round-5 advisor: the two used to be kept
+    in sync by hand)."""
+    from gscodec_studio_amd import _wrapper as W
+    from gscodec_studio_amd import distributed as D
+
+    for k in W.PREFILL_ORDER:
+        assert k in D._CARVE_RANK, k
+    order = [k for k in W.PREFILL_ORDER if k != "sh"]  # ("sh" shares the colours' slot)
+    assert [D._CARVE_RANK[k] for k in order] == sorted(D._CARVE_RANK[k] for k in order)
+    # a trainer's dict in ITS order comes out in the carving order
+    keys = ["means", "scales", "quats", "opacities", "sh0", "shN", "motion", "trbf_scale", "omega", "trbf_center", "something_else"]
+    got = [keys[i] for i in D._canonical_order(keys)]
+    assert got == ["means", "quats", "scales", "opacities", "sh0", "shN", "motion", "omega", "trbf_center", "trbf_scale", "something_else"]
+    # requests are sorted into that order whatever order the items are listed in
+    import torch
+    t = torch.zeros(3, 2)
+    req = W.prefill_request((("omega", t, True), ("means", t, True), ("scales", None, True), ("quats", t, False), ("opacities", t, True)))
+    assert [k for k, _ in req] == ["means", "opacities", "omega"]

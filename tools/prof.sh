@@ -31,7 +31,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
 # one step = from one projection_fwd_kernel to the next
-idx = [i for i, n in enumerate(names) if 'projection_fwd_kernel' in n]
+idx = [i for i, n in enumerate(names) if 'projection_fwd_kernel' in n or 'projection_dyn_fwd_kernel' in n]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]['Start_Timestamp'])
 with open(sys.argv[2], 'w') as f:

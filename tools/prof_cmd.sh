@@ -19,7 +19,7 @@ t=$(find "$out" -name "*kernel_trace.csv" 2>/dev/null | head -1)
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'projection_fwd_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'projection_fwd_kernel' in r['Kernel_Name'] or 'projection_dyn_fwd_kernel' in r['Kernel_Name']]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]['Start_Timestamp'])
 with open(sys.argv[2], 'w') as f:
