@@ -53,13 +53,19 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # PMC traffic (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 correction applied)
 # measured for this workload and committed under profiles/; bench.py cannot run rocprof on itself.
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
+TRAFFIC_JSON_DYNAMIC = os.path.join(ROOT, "profiles", "r06_pmc_traffic_dynamic.json")  # (bench.py --dynamic, tools/pmc.sh with PMC_BENCH_ARGS)
 HBM_COPY_GBS = 6290.0  # what a float4 copy was measured to reach on this part (MI355X_MICROARCH.md: 6.29 TB/s, 79 % of spec)
 # entry point -> (kernel name fragment, the source file the kernel lives in)
 _RASTER_SRC = ("rasterize.hip", "rasterize_dev.h", "rasterize_common.h", "dpp_reduce.h")
 KERNEL_OF_ENTRY = {"gs_rasterize_bwd": ("raster_seg_bwd_kernel", _RASTER_SRC), "gs_rasterize_fwd": ("raster_tile_fwd_kernel", _RASTER_SRC),
                    "gs_sh_view_bwd": ("sh_bwd_kernel", ("sh.hip",)), "gs_projection_rows_bwd": ("projection_bwd_kernel<false, 3>", ("projection.hip",)),
-                   "gs_sort_isect_pairs": ("sort_scatter_kernel<unsigned int, 16, true", ("radix_sort.hip",))}
+                   "gs_sort_isect_pairs": ("sort_scatter_kernel<unsigned int, 16, true", ("radix_sort.hip",)),
+                   "gs_projection_rows_fwd": ("projection_fwd_kernel<true", ("projection.hip", "projection_dev.h")),
+                   "gs_projection_rows_dyn_fwd": ("projection_dyn_fwd_kernel", ("projection_dyn.hip", "projection_dev.h", "dynamic_dev.h", "quant_dev.h")),
+                   "gs_projection_rows_dyn_bwd": ("projection_dyn_bwd_kernel", ("projection_dyn.hip", "projection_dev.h", "dynamic_dev.h", "quant_dev.h")),
+                   "gs_temporal_slice_fwd": ("temporal_slice_fwd_kernel", ("dynamic.hip", "dynamic_dev.h")),
+                   "gs_temporal_slice_bwd": ("temporal_slice_bwd_kernel", ("dynamic.hip", "dynamic_dev.h"))}
 
 
 def _source_hash(name):
@@ -69,15 +75,17 @@ def _source_hash(name):
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-def measured_pmc(entry, workload_key, field="traffic_bytes_per_launch"):
+def measured_pmc(entry, workload_key, field="traffic_bytes_per_launch", path=None, wide=False):
     """A per-launch PMC figure of the kernel behind `entry` from the committed summary (HBM bytes by default), or None --
     also None when the kernel's source file has changed since the counters were collected (the JSON carries the hashes of
     the sources it was taken from: a stale figure is not reported)."""
     try:
-        d = json.load(open(TRAFFIC_JSON))
+        d = json.load(open(path or TRAFFIC_JSON))
         if d.get("workload_key") != workload_key:
             return None
         frag, srcs = KERNEL_OF_ENTRY.get(entry, (None, ()))
+        if wide and entry == "gs_rasterize_bwd":  # 5..32 channels: the wide instance of the segmented backward
+            frag, srcs = "raster_seg_bwd_wide_kernel", ("rasterize_wide.hip", "rasterize_dev.h", "rasterize_common.h", "dpp_reduce.h")
         if any(d.get("source_hashes", {}).get(src) != _source_hash(src) for src in srcs):
             return None
         for name, v in d["kernels"].items():
@@ -409,13 +417,14 @@ def _launch_once(args, n, argv, extra_env):
 DYN_QUANT_FLOATS = 17  # scales 3 + quats 4 + opacities 1 + colors 3 + features_dir 3 + features_time 3
 
 
-def dynamic_algorithmic_bytes(N, V, I, P, T, D):
+def dynamic_algorithmic_bytes(N, V, I, P, T, D, A_hooks=DYN_QUANT_FLOATS):
     """Compulsory HBM bytes per launch of the entry points of config 5's step.  D = render channels."""
     proj_f = 40 * N + 4 * N + 24 * V + 4 * D * V            # SURVEY 8(d) projection + the colour columns of the visible rows
     proj_b = 92 * V + 40 * N + 4 * N + 4 * D * V
     slice_f, slice_b = 128 * N, 216 * N                     # csrc/dynamic.hip: 92 B in + 36 B out | 92 + 32 B in + 92 B out
     return {
         "gs_quantize_round_fwd": 8 * DYN_QUANT_FLOATS * N,  # SURVEY 8(d): 8 A bytes per splat (all six hooked tensors together)
+        "gs_quantize_round_multi_fwd": 8 * A_hooks * N,     # (the hooks that run OUTSIDE the projection kernel, one launch)
         "gs_temporal_slice_fwd": slice_f, "gs_temporal_slice_bwd": slice_b,
         "gs_projection_rows_fwd": proj_f, "gs_projection_rows_bwd": proj_b,
         # fused: the slice's inputs are read by the projection itself (+ 36 B per splat of motion / omega / centre / scale rows that
@@ -556,7 +565,10 @@ def main_dynamic(args):
         meta = last_meta
         V, I = int((meta["radii"] > 0).sum()), int(meta["flatten_ids"].numel())
         P, T = W_ * H_, meta["tile_width"] * meta["tile_height"]
-        alg = dynamic_algorithmic_bytes(N, V, I, P, T, D)
+        # floats per splat the hooks quantize outside the projection kernel: all 17, or -- form "full" -- what the kernel does not take
+        A_hooks = DYN_QUANT_FLOATS if form != "full" else (6 if D == 3 else 9)
+        alg = dynamic_algorithmic_bytes(N, V, I, P, T, D, A_hooks)
+        dyn_key = f"dynamic_{N}_{W_}x{H_}_ch{D}_{form}"
         # whole step: SURVEY 8(d)'s closed form with the [N, D] colours in place of the SH rows, plus the hooks (8 A each way is the
         # survey's figure; the round STE's backward is the identity: 0) and the slice both ways
         total_alg = (alg["gs_quantize_round_fwd"] + alg["gs_temporal_slice_fwd"] + alg["gs_projection_rows_fwd"]
@@ -587,7 +599,9 @@ def main_dynamic(args):
             },
             "roofline": {
                 "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel_ms": dom_ms, "algorithmic_bytes": alg.get(dominant, 0),
+                "traffic": measured_pmc(dominant, dyn_key, path=TRAFFIC_JSON_DYNAMIC, wide=D > 4), "kernel_ms": dom_ms,
+                "algorithmic_bytes": alg.get(dominant, 0),
+                "own_bound": "valu" if dominant in ("gs_rasterize_bwd", "gs_rasterize_fwd") else "hbm",
                 "whole_step": {"algorithmic_bytes": total_alg, "achieved": total_alg / (ms_per_step * 1e-3) / 1e9,
                                "frac": total_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "formula": "hooks 8*17 N + slice (128 + 216) N + SURVEY 8(d) with [N, D] colours"},
@@ -599,8 +613,10 @@ def main_dynamic(args):
                 "streaming": {k: {"ms": round(per_step[k], 4), "calls_per_step": calls_per_step[k], "algorithmic_bytes": alg[k],
                                   "achieved": alg[k] / (per_step[k] * 1e-3) / 1e9, "unit": "GB/s",
                                   "frac": alg[k] / (per_step[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "frac_of_measured_copy_rate": alg[k] / (per_step[k] * 1e-3) / 1e9 / HBM_COPY_GBS}
-                              for k in ("gs_quantize_round_fwd", "gs_temporal_slice_fwd", "gs_temporal_slice_bwd", "gs_projection_rows_fwd",
+                                  "frac_of_measured_copy_rate": alg[k] / (per_step[k] * 1e-3) / 1e9 / HBM_COPY_GBS,
+                                  # HBM bytes per launch from the committed counter passes (None: not collected / sources changed)
+                                  "traffic": measured_pmc(k, dyn_key, path=TRAFFIC_JSON_DYNAMIC)}
+                              for k in ("gs_quantize_round_fwd", "gs_quantize_round_multi_fwd", "gs_temporal_slice_fwd", "gs_temporal_slice_bwd", "gs_projection_rows_fwd",
                                         "gs_projection_rows_bwd", "gs_projection_rows_dyn_fwd", "gs_projection_rows_dyn_bwd")
                               if k in per_step and per_step[k] > 0},
             },

@@ -240,6 +240,73 @@ def fake_quantize_noise_multi(inputs: Sequence[Tensor], bounds: Sequence[Tuple[f
     return [{"output_value": o, "q_step": q} for o, q in zip(outs, q_steps)]
 
 
+class _RoundQuantMulti(torch.autograd.Function):
+    """``STE.apply(x_i, bits_i, lo_i, hi_i[, act_i])`` for several tensors in ONE launch (``gs_quantize_round_multi_fwd``): every ``x_i`` is
+    clamped IN PLACE like ``STE``'s input, the outputs are the grid values (activated where asked); backward = identity, times the
+    activation's derivative where one was fused (one launch for those)."""
+
+    @staticmethod
+    def forward(ctx, specs: Sequence[Tuple[float, float, int, int]], *xs: Tensor):
+        dev = xs[0].device
+        if not _DESC_CHECKED[0]:
+            check_desc_layout()
+        for x in xs:
+            _require_gpu(x, "STE")
+            if x.dtype != torch.float32 or x.device != dev or not x.is_contiguous():
+                raise RuntimeError("STE (multi): contiguous float32 tensors on one device (they are clamped in place)")
+        outs = [torch.empty_like(x) for x in xs]
+        k = len(xs)
+        descs = (_QuantDesc * k)()
+        ranges, qns = (ctypes.c_float * k)(), (ctypes.c_float * k)()
+        for i, (d, x, o, (lo, hi, bits, act)) in enumerate(zip(descs, xs, outs, specs)):
+            d.n, d.x, d.out, d.v_out, d.v_x = x.numel(), B.ptr(x), B.ptr(o), None, B.ptr(x)
+            d.lo, d.hi, d.q_step, d.activation, d.philox_offset = _f32(lo), _f32(hi), 0.0, act, 0
+            ranges[i], qns[i] = _f32(hi - lo), _f32(1 / (2**bits - 1))  # python arithmetic first, then fp32, as torch does
+        with _device_of(xs[0]):
+            B.call("gs_quantize_round_multi_fwd", k, ctypes.addressof(descs), ctypes.addressof(ranges), ctypes.addressof(qns), _stream(xs[0]))
+        ctx.acts = [sp[3] for sp in specs]
+        ctx.save_for_backward(*[o if a else None for o, a in zip(outs, ctx.acts)])
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *v_outs):
+        outs = ctx.saved_tensors
+        k = len(ctx.acts)
+        grads: List[Optional[Tensor]] = [None] * k
+        descs = (_QuantDesc * k)()
+        live = []
+        for i, (o, v, act) in enumerate(zip(outs, v_outs, ctx.acts)):
+            descs[i].n = 0
+            if v is None or not ctx.needs_input_grad[1 + i]:
+                continue
+            if not act:
+                grads[i] = v  # identity, everywhere (ops.py:73-75)
+                continue
+            g = v.contiguous()
+            vx = torch.empty_like(o)
+            live.append(g)
+            d = descs[i]
+            d.n, d.x, d.out, d.v_out, d.v_x = o.numel(), B.ptr(o), B.ptr(o), B.ptr(g), B.ptr(vx)
+            d.lo, d.hi, d.q_step, d.activation, d.philox_offset = 0.0, 0.0, 0.0, act, 0
+            grads[i] = vx
+        if live:
+            with _device_of(live[0]):
+                B.call("gs_quantize_round_multi_bwd", k, ctypes.addressof(descs), _stream(live[0]))
+        return (None, *grads)
+
+
+def fake_quantize_round_multi(inputs: Sequence[Tensor], bounds: Sequence[Tuple[float, float]], bitwidths: Sequence[int],
+                              activations: Optional[Sequence[Optional[str]]] = None) -> List[Dict[str, object]]:
+    """``[fake_quantize_ste(x, lo, hi, bits, "round", activation) for ...]`` -- same outputs, same in-place clamp of every input -- in
+    one launch (up to QUANT_MULTI_MAX contiguous float32 tensors; not in the reference, whose hooks run tensor by tensor)."""
+    assert 1 <= len(inputs) <= QUANT_MULTI_MAX and len(inputs) == len(bounds) == len(bitwidths)
+    acts = list(activations) if activations is not None else [None] * len(inputs)
+    specs = [(lo, hi, b, _ACTS[a]) for (lo, hi), b, a in zip(bounds, bitwidths, acts)]
+    outs = _RoundQuantMulti.apply(specs, *inputs)
+    return [{"output_value": o, "q_step": (hi - lo) / (2**b - 1)} for o, (lo, hi), b in zip(outs, bounds, bitwidths)]
+
+
 def fake_quantize_ste(input: Tensor, lower_bd: float, upper_bd: float, bitwidth: int = 8,
                       q_type: str = "noise", activation: str = None) -> Dict[str, object]:
     """``activation`` (opt-in, not in the reference): "exp" / "sigmoid" -- the activation the trainer applies to the hooked

@@ -25,7 +25,7 @@ from typing_extensions import Literal
 from .ada_mask import AnnealingMask
 from .ada_mask import shN_gradient_threshold as _shN_gradient_threshold
 from .entropy_model import Entropy_factorized_optimized_refactor
-from .ops import QUANT_MULTI_MAX, fake_quantize_noise_multi, fake_quantize_ste, multi_selfcheck
+from .ops import QUANT_MULTI_MAX, fake_quantize_noise_multi, fake_quantize_round_multi, fake_quantize_ste, multi_selfcheck
 
 
 class _SimulationBase:
@@ -132,13 +132,15 @@ class _SimulationBase:
     _MULTI = os.environ.get("GS_QUANT_MULTI", "1") != "0"
 
     def _prequantize(self, splats: Dict[str, Tensor], step: int) -> None:
-        """All noise-quantized attributes of the step in ONE launch (ops.fake_quantize_noise_multi): the noise is drawn in the
+        """All quantized attributes of the step in ONE launch.  Noise mode (ops.fake_quantize_noise_multi): the noise is drawn in the
         kernel exactly as the per-attribute ``uniform_`` calls of the reference would have drawn it, in the same order, so the
-        values and the RNG stream are those of the tensor-by-tensor hooks.  Only the class's own hook functions take part (a
+        values and the RNG stream are those of the tensor-by-tensor hooks.  Round mode (ops.fake_quantize_round_multi, round 6): the
+        same arithmetic and the same in-place clamp of every parameter as the per-tensor ``STE`` calls.  Only the class's own hook functions take part (a
         subclass that overrides one keeps its behaviour)."""
         self._pre = {}
-        if not self._MULTI or self.q_type not in (None, "noise"):
+        if not self._MULTI or self.q_type not in (None, "noise", "round"):
             return
+        rnd = self.q_type == "round"
         names = []
         for name, p in splats.items():
             if not self.simulation_option.get(name, False) or self.bds.get(name) is None:
@@ -148,10 +150,12 @@ class _SimulationBase:
                 return
             if not (isinstance(p, Tensor) and p.is_cuda and p.dtype == torch.float32):
                 return
+            if rnd and not p.is_contiguous():  # (the round hook clamps its input in place: only the tensor itself will do)
+                return
             names.append(name)
         if not 2 <= len(names) <= QUANT_MULTI_MAX or len({splats[n].device for n in names}) != 1:
             return
-        if not multi_selfcheck(splats[names[0]].device):  # (first use per device; a torch / ROCm change of the RNG kernel shows here)
+        if not rnd and not multi_selfcheck(splats[names[0]].device):  # (first use per device; a torch / ROCm change of the RNG kernel shows here)
             type(self)._MULTI = False
             return
         acts = []
@@ -159,8 +163,8 @@ class _SimulationBase:
             estimate = (self.entropy_model_enable and self.entropy_model_option.get(n, False)
                         and step > self.entropy_steps[n] and self.entropy_models.get(n) is not None)
             acts.append(self.ACTIVATIONS.get(n) if (self._activate and not estimate) else None)
-        outs = fake_quantize_noise_multi([splats[n] for n in names], [tuple(self.bds[n]) for n in names],
-                                         [self.q_bitwidth[n] for n in names], acts)
+        outs = (fake_quantize_round_multi if rnd else fake_quantize_noise_multi)(
+            [splats[n] for n in names], [tuple(self.bds[n]) for n in names], [self.q_bitwidth[n] for n in names], acts)
         self._pre = {n: (splats[n], a, o) for n, a, o in zip(names, acts, outs)}
 
     def _simulate(self, splats: Dict[str, Tensor], step: int):

@@ -211,6 +211,8 @@ struct QuantMultiArgs {
     uint32_t vec[GS_QUANT_MULTI_MAX];      // 16-byte accesses allowed
     uint32_t n;
     uint32_t seed_lo, seed_hi;
+    uint32_t no_mask;                      // backward: gradients pass everywhere (the round mode, ops.py:73-75)
+    float range[GS_QUANT_MULTI_MAX], q_norm[GS_QUANT_MULTI_MAX]; // round mode: hi - lo and 1 / (2^bits - 1) as torch rounds them
 };
 
 GS_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -298,28 +300,67 @@ __global__ void __launch_bounds__(GS_BLOCK) quant_noise_multi_bwd_kernel(QuantMu
                 g.x = q_act_grad_dyn(o.x, g.x, d.activation); g.y = q_act_grad_dyn(o.y, g.y, d.activation);
                 g.z = q_act_grad_dyn(o.z, g.z, d.activation); g.w = q_act_grad_dyn(o.w, g.w, d.activation);
             }
-            float4 r;
-            r.x = q_mask(x.x, g.x, d.lo, d.hi); r.y = q_mask(x.y, g.y, d.lo, d.hi);
-            r.z = q_mask(x.z, g.z, d.lo, d.hi); r.w = q_mask(x.w, g.w, d.lo, d.hi);
+            float4 r = g;
+            if (!a.no_mask) {
+                r.x = q_mask(x.x, g.x, d.lo, d.hi); r.y = q_mask(x.y, g.y, d.lo, d.hi);
+                r.z = q_mask(x.z, g.z, d.lo, d.hi); r.w = q_mask(x.w, g.w, d.lo, d.hi);
+            }
             *reinterpret_cast<float4 *>(d.v_x + e) = r;
         } else {
             for (uint64_t i = e; i < e + 4 && i < d.n; ++i) {
                 float g = d.v_out[i];
                 if (d.activation != GS_ACT_NONE) g = q_act_grad_dyn(d.out[i], g, d.activation);
-                d.v_x[i] = q_mask(d.x[i], g, d.lo, d.hi);
+                d.v_x[i] = a.no_mask ? g : q_mask(d.x[i], g, d.lo, d.hi);
+            }
+        }
+    }
+}
+
+// Round mode, all hooked tensors of a step in one launch (work item: four consecutive elements of a tensor): the arithmetic of
+// quant_round_fwd_kernel -- the parameter (d.v_x, the writable alias of d.x) is clamped IN PLACE (ops.py:63), out = the grid value.
+__global__ void __launch_bounds__(GS_BLOCK) quant_round_multi_fwd_kernel(QuantMultiArgs a) {
+    const uint64_t total = a.item_end[a.n - 1];
+    const uint64_t gstride = (uint64_t)gridDim.x * GS_BLOCK;
+    for (uint64_t it = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x; it < total; it += gstride) {
+        uint32_t t = 0;
+        while (it >= a.item_end[t]) ++t;
+        const gs_quant_desc d = a.d[t];
+        const float range = a.range[t], qn = a.q_norm[t];
+        const uint64_t e = 4ull * (it - (t ? a.item_end[t - 1] : 0));
+        if (a.vec[t] && e + 4 <= d.n) {
+            float4 x = *reinterpret_cast<const float4 *>(d.x + e);
+            x.x = q_clamp(x.x, d.lo, d.hi); x.y = q_clamp(x.y, d.lo, d.hi);
+            x.z = q_clamp(x.z, d.lo, d.hi); x.w = q_clamp(x.w, d.lo, d.hi);
+            *reinterpret_cast<float4 *>(d.v_x + e) = x;
+            float4 o;
+            o.x = q_act_dyn<0>(q_round(x.x, d.lo, range, qn), d.activation); o.y = q_act_dyn<0>(q_round(x.y, d.lo, range, qn), d.activation);
+            o.z = q_act_dyn<0>(q_round(x.z, d.lo, range, qn), d.activation); o.w = q_act_dyn<0>(q_round(x.w, d.lo, range, qn), d.activation);
+            *reinterpret_cast<float4 *>(d.out + e) = o;
+        } else {
+            for (uint64_t i = e; i < e + 4 && i < d.n; ++i) {
+                const float c = q_clamp(d.x[i], d.lo, d.hi);
+                d.v_x[i] = c;
+                d.out[i] = q_act_dyn<0>(q_round(c, d.lo, range, qn), d.activation);
             }
         }
     }
 }
 
 static int32_t quant_multi_launch(uint32_t n_tensors, const gs_quant_desc *descs, uint64_t seed, uint32_t grid_cap, bool bwd,
-                                  hipStream_t st, const char *who) {
+                                  hipStream_t st, const char *who, const float *round_range = nullptr, const float *round_q_norm = nullptr,
+                                  bool no_mask = false) {
     QuantMultiArgs a;
     uint64_t items = 0;
     a.n = 0;
+    a.no_mask = no_mask ? 1u : 0u;
+    const bool round_fwd = round_range != nullptr;
     for (uint32_t t = 0; t < n_tensors; ++t) {
         const gs_quant_desc &d = descs[t];
         if (d.n == 0) continue;
+        if (round_fwd && (d.v_x == nullptr || (const float *)d.v_x != d.x)) {
+            gs_set_error("%s: descriptor %u: v_x must be the writable alias of x (the parameter is clamped in place)", who, t);
+            return 1;
+        }
         if (!d.x || (bwd ? (!d.v_out || !d.v_x) : !d.out) || d.activation < GS_ACT_NONE || d.activation > GS_ACT_SIGMOID ||
             (bwd && d.activation != GS_ACT_NONE && !d.out) || d.philox_offset % 4 != 0) {
             gs_set_error("%s: bad descriptor %u (null pointer, unknown activation or an offset that is not a multiple of 4)", who, t);
@@ -328,7 +369,12 @@ static int32_t quant_multi_launch(uint32_t n_tensors, const gs_quant_desc *descs
         const uint64_t blocks = (d.n + GS_BLOCK - 1) / GS_BLOCK;
         const uint32_t G = (uint32_t)(blocks < grid_cap ? blocks : grid_cap);
         a.stride[a.n] = GS_BLOCK * G;
-        if (bwd) {
+        if (round_fwd) {
+            items += (d.n + 3) / 4;
+            a.vec[a.n] = ((uintptr_t)d.x % 16 == 0 && (uintptr_t)d.out % 16 == 0) ? 1u : 0u;
+            a.range[a.n] = round_range[t];
+            a.q_norm[a.n] = round_q_norm[t];
+        } else if (bwd) {
             items += (d.n + 3) / 4;
             a.vec[a.n] = ((uintptr_t)d.x % 16 == 0 && (uintptr_t)d.v_out % 16 == 0 && (uintptr_t)d.v_x % 16 == 0 && (uintptr_t)d.out % 16 == 0) ? 1u : 0u;
         } else {
@@ -345,7 +391,8 @@ static int32_t quant_multi_launch(uint32_t n_tensors, const gs_quant_desc *descs
     a.seed_hi = (uint32_t)(seed >> 32);
     uint64_t blocks = (items + GS_BLOCK - 1) / GS_BLOCK;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    if (bwd) hipLaunchKernelGGL(quant_noise_multi_bwd_kernel, dim3((uint32_t)blocks), dim3(GS_BLOCK), 0, st, a);
+    if (round_fwd) hipLaunchKernelGGL(quant_round_multi_fwd_kernel, dim3((uint32_t)blocks), dim3(GS_BLOCK), 0, st, a);
+    else if (bwd) hipLaunchKernelGGL(quant_noise_multi_bwd_kernel, dim3((uint32_t)blocks), dim3(GS_BLOCK), 0, st, a);
     else hipLaunchKernelGGL(quant_noise_multi_fwd_kernel, dim3((uint32_t)blocks), dim3(GS_BLOCK), 0, st, a);
     return 0;
 }
@@ -370,6 +417,25 @@ extern "C" int32_t gs_quantize_noise_multi_fwd(uint32_t n_tensors, const gs_quan
 extern "C" int32_t gs_quantize_noise_multi_bwd(uint32_t n_tensors, const gs_quant_desc *descs, gs_stream_t stream) {
     GS_CHECK_ARG(n_tensors <= GS_QUANT_MULTI_MAX && (n_tensors == 0 || descs != nullptr), "up to GS_QUANT_MULTI_MAX descriptors");
     const int32_t rc = quant_multi_launch(n_tensors, descs, 0, 1u << 20, true, (hipStream_t)stream, "gs_quantize_noise_multi_bwd");
+    if (rc) return rc;
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_quantize_round_multi_fwd(uint32_t n_tensors, const gs_quant_desc *descs, const float *ranges, const float *q_step_norms,
+                                               gs_stream_t stream) {
+    GS_CHECK_ARG(n_tensors <= GS_QUANT_MULTI_MAX && (n_tensors == 0 || (descs != nullptr && ranges != nullptr && q_step_norms != nullptr)),
+                 "up to GS_QUANT_MULTI_MAX descriptors with their range / step tables");
+    const int32_t rc = quant_multi_launch(n_tensors, descs, 0, 1u << 20, false, (hipStream_t)stream, "gs_quantize_round_multi_fwd", ranges, q_step_norms);
+    if (rc) return rc;
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+// (the round mode's backward is the identity; with activations fused in: v_x = v_out x the activation's derivative, no clamp mask)
+extern "C" int32_t gs_quantize_round_multi_bwd(uint32_t n_tensors, const gs_quant_desc *descs, gs_stream_t stream) {
+    GS_CHECK_ARG(n_tensors <= GS_QUANT_MULTI_MAX && (n_tensors == 0 || descs != nullptr), "up to GS_QUANT_MULTI_MAX descriptors");
+    const int32_t rc = quant_multi_launch(n_tensors, descs, 0, 1u << 20, true, (hipStream_t)stream, "gs_quantize_round_multi_bwd", nullptr, nullptr, true);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;

@@ -660,6 +660,15 @@ uint64_t gs_quantize_philox_advance(uint64_t n, uint32_t grid_cap);
 int32_t gs_quantize_noise_multi_fwd(
     uint32_t n_tensors, const gs_quant_desc *descs, uint64_t philox_seed, uint32_t grid_cap, gs_stream_t stream);
 int32_t gs_quantize_noise_multi_bwd(uint32_t n_tensors, const gs_quant_desc *descs, gs_stream_t stream);
+/* The round mode for several tensors in one launch each way (round 6): gs_quantize_round_fwd's arithmetic per element.  descs[t].x is
+ * the parameter and descs[t].v_x its WRITABLE alias (the same pointer: the parameter is clamped in place, ops.py:63), out the grid
+ * value (activated when descs[t].activation is set); ranges[t] = hi - lo and q_step_norms[t] = 1 / (2^bits - 1), both computed as the
+ * reference does (python double, then float); HOST arrays.  The backward is the identity (no call needed) except behind a fused
+ * activation: gs_quantize_round_multi_bwd writes v_x = v_out x d act (out), no clamp mask, for the descriptors with n > 0. */
+int32_t gs_quantize_round_multi_fwd(uint32_t n_tensors, const gs_quant_desc *descs, const float *ranges, const float *q_step_norms,
+                                    gs_stream_t stream);
+int32_t gs_quantize_round_multi_bwd(uint32_t n_tensors, const gs_quant_desc *descs, gs_stream_t stream);
+
 
 /* ------------------------------------------------------------------------
  * Q3  learnable per-splat mask on the higher SH bands ("shN adaptive mask") of the compression-simulation hooks

@@ -212,3 +212,45 @@ def test_hooks_in_one_launch_equal_hooks_one_by_one():
         assert set(ga) == set(gb) == {"scales", "opacities", "sh0"}
         for k in ga:
             assert torch.equal(ga[k], gb[k]), (k, activate)
+
+
+def test_round_hooks_in_one_launch_equal_hooks_one_by_one():
+    """STGCompressionSimulation("round"): all hooked attributes through ONE launch (ops.fake_quantize_round_multi, round 6) against the
+    tensor-by-tensor STE calls of the reference (GS_QUANT_MULTI off): identical quantized values, identical in-place clamps of the
+    parameters, identical gradients -- with and without the fused activations -- and a ragged / unaligned tensor in the set."""
+    from gscodec_studio_amd.compression_simulation import STGCompressionSimulation
+
+    n = 20_011
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    R = lambda *s: torch.randn(*s, device="cuda:0", generator=g)  # noqa: E731
+    raw = {"means": R(n, 3), "scales": R(n, 3) * 4 - 4, "quats": R(n, 4) * 0.8, "opacities": R(n) * 6, "trbf_center": R(n, 1),
+           "trbf_scale": R(n, 1), "motion": R(n, 9), "omega": R(n, 4), "colors": R(n, 3) * 5, "features_dir": R(n, 3) * 7,
+           "features_time": R(n, 3) * 7}
+    res = {}
+    for multi in (True, False):
+        for activate in (False, True):
+            sim = STGCompressionSimulation(quantization_sim_type="round", entropy_steps={})
+            sim._MULTI = multi
+            splats = {k: v.clone().requires_grad_(k != "quats") for k, v in raw.items()}
+            new, _ = sim.simulate_compression(splats, step=5, activate=activate)
+            loss = sum((new[k] * (i + 1)).sum() for i, k in enumerate(("scales", "quats", "opacities", "colors", "features_time", "motion")))
+            loss.backward()
+            res[(multi, activate)] = ({k: new[k].detach() for k in new}, {k: p.detach().clone() for k, p in splats.items()},
+                                      {k: p.grad for k, p in splats.items() if p.grad is not None})
+    for activate in (False, True):
+        (a, pa, ga), (b, pb, gb) = res[(True, activate)], res[(False, activate)]
+        for k in a:
+            assert torch.equal(a[k], b[k]), (k, activate)
+        for k in pa:  # the parameters after the hooks: clamped in place where hooked, untouched elsewhere
+            assert torch.equal(pa[k], pb[k]), (k, activate)
+        assert float(pa["scales"].max()) <= 2.0 and float(pa["features_dir"].min()) >= -10.0 and torch.equal(pa["motion"], raw["motion"])
+        assert not torch.equal(pa["scales"], raw["scales"])  # (something was out of range)
+        assert set(ga) == set(gb)
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), (k, activate)
+    # a non-contiguous hooked tensor keeps the per-tensor route (STE refuses it, as before)
+    sim = STGCompressionSimulation(quantization_sim_type="round", entropy_steps={})
+    bad = {k: v.clone() for k, v in raw.items()}
+    bad["colors"] = torch.randn(3, n, device="cuda:0").t()
+    with pytest.raises(RuntimeError):
+        sim.simulate_compression(bad, step=0)

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Everything profiles/rNN_* is made from, on the GPU box:  tools/final_profiles.sh r05
+# Everything profiles/rNN_* is made from, on the GPU box:  tools/final_profiles.sh r06
 set -u
-tag=${1:-r05}
+tag=${1:-r06}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/final
 mkdir -p "$out"
@@ -59,4 +59,23 @@ cp gpurun_out/prof_${tag}_ch32_kernel_stats.csv "$out/${tag}_channels32_kernel_s
     echo "GS_FUZZ_SEED_OFFSET=$k: $(GS_FUZZ_SEED_OFFSET=$k python -m pytest tests/test_gpu_fuzz.py -q 2>&1 | tail -1)"
   done
 } > "$out/${tag}_fuzz_extended.txt" 2>&1
+# ---- round 6: BASELINE config 5's step (bench.py --dynamic): counters, bench lines per form, kernel tables, timelines
+PMC_BENCH_ARGS="--dynamic" PMC_WORKLOAD_KEY=dynamic_2000000_1920x1080_ch3_full bash tools/pmc.sh "$out/${tag}_pmc_traffic_dynamic.json" > "$out/pmc_dyn.log" 2>&1
+cp "$out/${tag}_pmc_traffic_dynamic.json" profiles/${tag}_pmc_traffic_dynamic.json
+{
+  for f in reference activate fused full; do for d in 3 9; do
+    python bench.py --dynamic --dynamic-form $f --dynamic-channels $d 2>/dev/null < /dev/null | tail -1
+  done; done
+} > "$out/${tag}_bench_dynamic.jsonl"
+for f in reference full; do
+  bash tools/prof.sh ${tag}dyn_$f --dynamic --dynamic-form $f > "$out/prof_dyn_$f.log" 2>&1
+  cp gpurun_out/prof_${tag}dyn_${f}_kernel_stats.csv "$out/${tag}_dynamic_${f}_kernel_stats.csv"
+  cp gpurun_out/prof_${tag}dyn_${f}_last_step.txt "$out/${tag}_dynamic_${f}_last_step_timeline.txt"
+done
+bash tools/prof.sh ${tag}dyn_full9 --dynamic --dynamic-form full --dynamic-channels 9 > "$out/prof_dyn_full9.log" 2>&1
+cp gpurun_out/prof_${tag}dyn_full9_kernel_stats.csv "$out/${tag}_dynamic_full_ch9_kernel_stats.csv"
+# counters of one wide instance (9 channels): HBM traffic + VALU instructions per launch of the tile forward / wide backward
+PMC_CMD="python $root/tools/bench_channels.py 9" bash tools/pmc_any.sh ${tag}_ch9 FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU > "$out/pmc_ch9.log" 2>&1
+cp gpurun_out/pmc_${tag}_ch9.txt "$out/${tag}_channels9_pmc.txt"
+timeout 300 python tools/probe_two_streams.py > "$out/${tag}_probe_two_streams.txt" 2>&1
 echo done

@@ -1,5 +1,6 @@
 #!/bin/bash
 # HBM traffic + VALU instruction counters of bench.py's kernels on the GPU box:  tools/pmc.sh <out.json>
+# (PMC_BENCH_ARGS="--dynamic ..." PMC_WORKLOAD_KEY=... for another workload of bench.py)
 # Three SEPARATE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU), as MI355X_MICROARCH.md prescribes; the JSON
 # (per-launch bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 and wave-level VALU instructions) is built by tools/pmc_traffic.py.
 set -u
@@ -11,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
     rm -rf /tmp/pmc_$c
     timeout -k 5 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- \
-        python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-dp-projection --min-timed-s 0 > /tmp/pmc_$c.log 2>&1 < /dev/null
+        python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-dp-projection --min-timed-s 0 --ramp-s 0 ${PMC_BENCH_ARGS:-} > /tmp/pmc_$c.log 2>&1 < /dev/null
     echo "$c rc=$?"
 done
 f=$(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)

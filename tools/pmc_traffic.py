@@ -57,7 +57,8 @@ def main():
                      "source": "tools/mfma_reduce_ab.hip: 64 independent v_fma_f32 x 2048 iterations x 5 waves per SIMD x 1024 SIMDs"}
     json.dump({
         "valu_measured_issue_rate": issue,
-        "workload_key": "grid3_1920x1080_sh3",
+        "workload_key": os.environ.get("PMC_WORKLOAD_KEY", "grid3_1920x1080_sh3"),
+        "bench_args": os.environ.get("PMC_BENCH_ARGS", ""),
         "command": "tools/pmc.sh: cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras ; same with --pmc WRITE_SIZE and --pmc SQ_INSTS_VALU (separate passes)",
         "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: KB units; FETCH_SIZE reports 1/2 of the fetched bytes on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated",
         "source_hashes": source_hashes(),
