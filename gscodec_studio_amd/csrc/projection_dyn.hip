@@ -47,13 +47,33 @@ struct DynSplat {
     SliceTime st;
 };
 
+// The round quantizer on one value: c = the clamped parameter (what ops.py:63 leaves in the tensor), returns the grid value.
 template <bool QUANT>
-GS_DEV float dyn_q(const DynArgs &d, int a, float *p, float v, bool write) {
+GS_DEV float dyn_q(const DynArgs &d, int a, float v, float &c) {
     GS_FP_STRICT;
+    c = v;
     if (!QUANT || !((d.quant >> a) & 1u)) return v;
-    const float c = q_clamp(v, d.q_lo[a], d.q_hi[a]);
-    if (write && !(c == v)) *p = c; // the parameter itself is clamped (rare: only out-of-range values are stored; NaN stays)
+    c = q_clamp(v, d.q_lo[a], d.q_hi[a]);
     return q_round(c, d.q_lo[a], d.q_rng[a], d.q_n[a]);
+}
+
+// A row of K parameters through the quantizer: ALL loads first (one vector load), the clamped row stored back only when the clamp
+// changed something (rare: the parameter itself is clamped in place, as the hooks do; NaN stays NaN)
+template <bool QUANT, int K>
+GS_DEV void dyn_q_row(const DynArgs &d, int a, float *__restrict__ p, bool write, float *out) {
+    float v[K], c[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = p[k];
+    bool changed = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        out[k] = dyn_q<QUANT>(d, a, v[k], c[k]);
+        changed |= !(c[k] == v[k]);
+    }
+    if (QUANT && write && changed) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) p[k] = c[k];
+    }
 }
 
 GS_DEV void dyn_time(const DynArgs &d, uint32_t n, DynSplat &o) {
@@ -76,10 +96,8 @@ GS_DEV void dyn_mean(const DynArgs &d, const float *__restrict__ means, uint32_t
 // quats / scales of gaussian n as the slice takes them: through the round quantizer when hooked (raw[0..3] quaternion, raw[4..6] scales)
 template <bool QUANT>
 GS_DEV void dyn_shape_load(const DynArgs &d, float *__restrict__ quats, float *__restrict__ scales, uint32_t n, bool write, float raw[7]) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) raw[k] = dyn_q<QUANT>(d, QA_QUATS, quats + 4 * (size_t)n + k, quats[4 * (size_t)n + k], write);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) raw[4 + k] = dyn_q<QUANT>(d, QA_SCALES, scales + 3 * (size_t)n + k, scales[3 * (size_t)n + k], write);
+    dyn_q_row<QUANT, 4>(d, QA_QUATS, quats + 4 * (size_t)n, write, raw);
+    dyn_q_row<QUANT, 3>(d, QA_SCALES, scales + 3 * (size_t)n, write, raw + 4);
 }
 
 // ... and their slice + activation (ONE body for every instance: the quantized and the plain kernels round the same way)
@@ -95,7 +113,8 @@ GS_DEV void dyn_shape_eval(const DynArgs &d, const float raw[7], uint32_t n, Dyn
 template <bool QUANT>
 GS_DEV void dyn_opacity(const DynArgs &d, float *__restrict__ opacities, uint32_t n, bool write, DynSplat &o) {
     GS_FP_STRICT;
-    float v = dyn_q<QUANT>(d, QA_OPACITIES, opacities + n, opacities[n], write);
+    float v;
+    dyn_q_row<QUANT, 1>(d, QA_OPACITIES, opacities + n, write, &v);
     if (d.raw & GS_DYN_RAW_OPACITIES) v = q_act<GS_ACT_SIGMOID>(v);
     o.op_act = v;
     o.op_t = (v * o.st.trbf);
@@ -136,10 +155,7 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_dyn_fwd_kernel(
             // out-of-range value stored back) before anything is culled
             dyn_shape_load<true>(dyn, quats, scales, n, write, raw);
             if (rx.opacities != nullptr) dyn_opacity<true>(dyn, rx.opacities, n, write, o);
-            if (rx.colors != nullptr) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) col[k] = dyn_q<true>(dyn, QA_COLORS, rx.colors + 3 * (size_t)n + k, rx.colors[3 * (size_t)n + k], write);
-            }
+            if (rx.colors != nullptr) dyn_q_row<true, 3>(dyn, QA_COLORS, rx.colors + 3 * (size_t)n, write, col);
         }
         s = project_point<false>(cam, o.mx, o.my, o.mz, [&]() {
             if (!QUANT) dyn_shape_load<false>(dyn, quats, scales, n, false, raw);

@@ -83,18 +83,20 @@ __global__ void __launch_bounds__(GS_BLOCK) quant_round_fwd_kernel(
     uint64_t t = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
     uint64_t nv = vec_ok ? n / Q_VEC : 0;
     for (uint64_t i = t; i < nv; i += stride) {
-        float4 a = reinterpret_cast<const float4 *>(x)[i];
-        a.x = q_clamp(a.x, lo, hi); a.y = q_clamp(a.y, lo, hi);
-        a.z = q_clamp(a.z, lo, hi); a.w = q_clamp(a.w, lo, hi);
-        reinterpret_cast<float4 *>(x)[i] = a; // in-place clamp of the parameter (ops.py:63)
+        const float4 a0 = reinterpret_cast<const float4 *>(x)[i];
+        float4 a;
+        a.x = q_clamp(a0.x, lo, hi); a.y = q_clamp(a0.y, lo, hi);
+        a.z = q_clamp(a0.z, lo, hi); a.w = q_clamp(a0.w, lo, hi);
+        // in-place clamp of the parameter (ops.py:63) -- stored only where it changes a value (a third of the kernel's traffic otherwise)
+        if (a.x != a0.x || a.y != a0.y || a.z != a0.z || a.w != a0.w) reinterpret_cast<float4 *>(x)[i] = a;
         float4 r;
         r.x = q_act<ACT>(q_round(a.x, lo, range, qn)); r.y = q_act<ACT>(q_round(a.y, lo, range, qn));
         r.z = q_act<ACT>(q_round(a.z, lo, range, qn)); r.w = q_act<ACT>(q_round(a.w, lo, range, qn));
         reinterpret_cast<float4 *>(out)[i] = r;
     }
     for (uint64_t i = nv * Q_VEC + t; i < n; i += stride) {
-        float a = q_clamp(x[i], lo, hi);
-        x[i] = a;
+        const float a0 = x[i], a = q_clamp(a0, lo, hi);
+        if (a != a0) x[i] = a;
         out[i] = q_act<ACT>(q_round(a, lo, range, qn));
     }
 }
@@ -328,18 +330,19 @@ __global__ void __launch_bounds__(GS_BLOCK) quant_round_multi_fwd_kernel(QuantMu
         const float range = a.range[t], qn = a.q_norm[t];
         const uint64_t e = 4ull * (it - (t ? a.item_end[t - 1] : 0));
         if (a.vec[t] && e + 4 <= d.n) {
-            float4 x = *reinterpret_cast<const float4 *>(d.x + e);
-            x.x = q_clamp(x.x, d.lo, d.hi); x.y = q_clamp(x.y, d.lo, d.hi);
-            x.z = q_clamp(x.z, d.lo, d.hi); x.w = q_clamp(x.w, d.lo, d.hi);
-            *reinterpret_cast<float4 *>(d.v_x + e) = x;
+            const float4 x0 = *reinterpret_cast<const float4 *>(d.x + e);
+            float4 x;
+            x.x = q_clamp(x0.x, d.lo, d.hi); x.y = q_clamp(x0.y, d.lo, d.hi);
+            x.z = q_clamp(x0.z, d.lo, d.hi); x.w = q_clamp(x0.w, d.lo, d.hi);
+            if (x.x != x0.x || x.y != x0.y || x.z != x0.z || x.w != x0.w) *reinterpret_cast<float4 *>(d.v_x + e) = x; // (only where it clamps)
             float4 o;
             o.x = q_act_dyn<0>(q_round(x.x, d.lo, range, qn), d.activation); o.y = q_act_dyn<0>(q_round(x.y, d.lo, range, qn), d.activation);
             o.z = q_act_dyn<0>(q_round(x.z, d.lo, range, qn), d.activation); o.w = q_act_dyn<0>(q_round(x.w, d.lo, range, qn), d.activation);
             *reinterpret_cast<float4 *>(d.out + e) = o;
         } else {
             for (uint64_t i = e; i < e + 4 && i < d.n; ++i) {
-                const float c = q_clamp(d.x[i], d.lo, d.hi);
-                d.v_x[i] = c;
+                const float c0 = d.x[i], c = q_clamp(c0, d.lo, d.hi);
+                if (c != c0) d.v_x[i] = c;
                 d.out[i] = q_act_dyn<0>(q_round(c, d.lo, range, qn), d.activation);
             }
         }
