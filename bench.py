@@ -427,10 +427,12 @@ def dynamic_algorithmic_bytes(N, V, I, P, T, D, A_hooks=DYN_QUANT_FLOATS):
         "gs_quantize_round_multi_fwd": 8 * A_hooks * N,     # (the hooks that run OUTSIDE the projection kernel, one launch)
         "gs_temporal_slice_fwd": slice_f, "gs_temporal_slice_bwd": slice_b,
         "gs_projection_rows_fwd": proj_f, "gs_projection_rows_bwd": proj_b,
-        # fused: the slice's inputs are read by the projection itself (+ 36 B per splat of motion / omega / centre / scale rows that
-        # the means_t / quats_t / opacity_t round trip replaces), its gradients written by the projection backward for the V
-        # visible splats only (23 floats: means 3 + motion 9 + quats 4 + omega 4 + opacity, centre, scale)
-        "gs_projection_rows_dyn_fwd": proj_f + 36 * N, "gs_projection_rows_dyn_bwd": proj_b + 36 * N + 92 * V,
+        # fused: the projection reads the RAW rows itself -- means 12 + motion 36 + quats 16 + omega 16 + scales 12 + opacity 4 + trbf
+        # centre / scale 8 (+ colours 4 D when they ride in the rows) per splat -- and writes radii + tile counts (8 N) and the visible
+        # rows (64 + 4 V); its backward reads radii (4 N) and, for the V visible gaussians, the same inputs, the splat and gradient rows
+        # (128) and writes the 23 (+ D) gradient floats
+        "gs_projection_rows_dyn_fwd": (104 + (4 * D if D == 3 else 0)) * N + 8 * N + 68 * V,
+        "gs_projection_rows_dyn_bwd": 4 * N + (104 + 128 + 92 + (8 * D if D == 3 else 0)) * V,
         "gs_rasterize_fwd": (28 + 4 * D) * I + (4 * D + 8) * P,   # 40 I + 20 P at D = 3
         "gs_rasterize_bwd": (28 + 4 * D) * I + (4 * D + 12) * P + (24 + 4 * D) * V,
         "gs_isect_finish_presorted": (24 * V + 12 * I) + 24 * I + (8 * I + 4 * T),

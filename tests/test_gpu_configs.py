@@ -387,3 +387,69 @@ def test_config5_full_size_properties():
         p.grad = None
     q2, rc2, _, meta2 = _dyn_step(P, sim, viewmats[:1].contiguous(), Ks, W, H, 0.5)
     assert torch.equal(meta2["flatten_ids"], meta["flatten_ids"]) and torch.equal(rc2, rc)
+
+
+def test_config5_full_size_fused_forms_match_the_chain():
+    """BASELINE config 5 at its full size (2 M dynamic splats, one 1080p camera): the three fused forms of the frame render against the
+    trainer's own sequence (hooks -> exp / sigmoid -> temporal_slice -> rasterization, simple_trainer_dyngs.py:463-554):
+    * ``rasterization(dynamic=...)`` on hook outputs: binning and image BIT-IDENTICAL, gradients within the compositing atomics' noise;
+    * ``render_dynamic`` (round hooks + activations + slice inside the projection kernels, raw parameters in): the parameters end up
+      clamped exactly as the hooks clamp them; image within 1e-4 (torch's exp / sigmoid vs the kernel's), gradients within 2e-3."""
+    from gscodec_studio_amd import rasterization
+    from gscodec_studio_amd._helper import DYNAMIC_KEYS, dynamic_workload
+    from gscodec_studio_amd.compression_simulation import STGCompressionSimulation
+    from gscodec_studio_amd.dynamic import render_dynamic, temporal_slice
+
+    w = dynamic_workload(2_000_000, 1920, 1080, device="cuda:0")
+    W, H, vm, Ks, t = w["width"], w["height"], w["viewmats"], w["Ks"], 0.5
+    w["scales"][:13, 1] = 2.75  # outside [-10, 2]: clamped in the parameter by every form
+
+    def params():
+        return {k: w[k].clone().requires_grad_(True) for k in DYNAMIC_KEYS}
+
+    def chain(P, fused_slice):
+        sim = STGCompressionSimulation(quantization_sim_type="round", entropy_steps={})
+        q, _ = sim.simulate_compression(P, step=1)
+        scales, opac, tscale = torch.exp(q["scales"]), torch.sigmoid(q["opacities"]), torch.exp(q["trbf_scale"])
+        if fused_slice:
+            return rasterization(q["means"], q["quats"], scales, opac, q["colors"], vm, Ks, W, H, packed=False,
+                                 dynamic=(q["motion"], q["omega"], q["trbf_center"], tscale, t))
+        m_t, q_t, o_t, _ = temporal_slice(q["means"], q["motion"], q["quats"], q["omega"], opac, q["trbf_center"], tscale, t)
+        return rasterization(m_t, q_t, scales, o_t, q["colors"], vm, Ks, W, H, packed=False)
+
+    res = {}
+    for name in ("chain", "slice", "full"):
+        P = params()
+        if name == "full":
+            sim = STGCompressionSimulation(quantization_sim_type="round", entropy_steps={})
+            rc, ra, meta = render_dynamic(P, t, vm, Ks, W, H, compression_sim=sim, step=1, packed=False)
+        else:
+            rc, ra, meta = chain(P, name == "slice")
+        rc.sum().backward()
+        res[name] = (rc.detach(), meta, {k: p.grad for k, p in P.items() if p.grad is not None}, {k: p.detach() for k, p in P.items()})
+    rc0, m0, g0, p0 = res["chain"]
+    vis = m0["radii"] > 0
+    assert 100_000 < int(vis.sum()) < 2_000_000
+    # ---- the slice inside the projection: identical
+    rc1, m1, g1, p1 = res["slice"]
+    for k in ("radii", "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets"):
+        assert torch.equal(m0[k], m1[k]), k
+    for k in ("means2d", "conics", "depths", "opacities"):
+        assert torch.equal(m0[k][vis], m1[k][vis]), k
+    assert torch.equal(rc0, rc1)
+    for k in g0:
+        assert rel_l2(N(g1[k]), N(g0[k])) < 1e-4, (k, rel_l2(N(g1[k]), N(g0[k])))
+    # ---- everything inside the projection
+    rc2, m2, g2, p2 = res["full"]
+    for k in DYNAMIC_KEYS:
+        assert torch.equal(p2[k], p0[k]), k            # same in-place clamps, nothing else touched
+    assert float(p2["scales"][:13, 1].max()) == 2.0
+    same = (m2["radii"] == m0["radii"]).float().mean()
+    assert float(same) > 0.9999, float(same)
+    assert_close(N(rc2), N(rc0), 1e-4, 1e-5, "render_dynamic vs the trainer's sequence", max_bad_frac=1e-4)
+    for k in g0:
+        if k in ("features_dir", "features_time"):
+            continue
+        assert rel_l2(N(g2[k]), N(g0[k])) < 2e-3, (k, rel_l2(N(g2[k]), N(g0[k])))
+    print(f"[config 5, full size] V = {int(vis.sum())}  I = {m0['flatten_ids'].numel()}  radii equal {float(same) * 100:.4f} %  "
+          + "  ".join(f"d/d {k} {rel_l2(N(g2[k]), N(g0[k])):.1e}" for k in ("means", "scales", "quats", "motion", "omega", "trbf_center")))
