@@ -402,7 +402,8 @@ def test_config5_full_size_fused_forms_match_the_chain():
 
     w = dynamic_workload(2_000_000, 1920, 1080, device="cuda:0")
     W, H, vm, Ks, t = w["width"], w["height"], w["viewmats"], w["Ks"], 0.5
-    w["scales"][:13, 1] = 2.75  # outside [-10, 2]: clamped in the parameter by every form
+    w["scales"][:13, 1] = -11.5  # outside [-10, 2]: clamped in the parameter by every form (the low side: a screen-filling splat at the
+    #                              upper bound sums millions of cancelling atomics and drowns the comparison in its own noise)
 
     def params():
         return {k: w[k].clone().requires_grad_(True) for k in DYNAMIC_KEYS}
@@ -443,7 +444,7 @@ def test_config5_full_size_fused_forms_match_the_chain():
     rc2, m2, g2, p2 = res["full"]
     for k in DYNAMIC_KEYS:
         assert torch.equal(p2[k], p0[k]), k            # same in-place clamps, nothing else touched
-    assert float(p2["scales"][:13, 1].max()) == 2.0
+    assert float(p2["scales"][:13, 1].min()) == -10.0 and float(p2["scales"][:13, 1].max()) == -10.0
     same = (m2["radii"] == m0["radii"]).float().mean()
     assert float(same) > 0.9999, float(same)
     assert_close(N(rc2), N(rc0), 1e-4, 1e-5, "render_dynamic vs the trainer's sequence", max_bad_frac=1e-4)
