@@ -62,9 +62,9 @@ class _Step(ctypes.Structure):  # gs_step of include/gsplat_hip.h (field for fie
         ("v_opacities", _P), ("v_colors", _P), ("v_sh", _P), ("v_sh_rest", _P),
         ("absgrad", _I32), ("outputs_prefilled", _I32), ("skip_projection_bwd", _I32), ("finish_phase", _I32),
         ("dyn_motion", _P), ("dyn_omega", _P), ("dyn_trbf_center", _P), ("dyn_trbf_scale", _P),
-        ("dyn_timestamp", _F), ("dyn_raw_params", _U32), ("dyn_quant_mask", _U32), ("reserved2", _U32),
+        ("dyn_timestamp", _F), ("dyn_raw_params", _U32), ("dyn_quant_mask", _U32), ("dyn_min_trbf", _F),
         ("dyn_quant_lo", _F * 4), ("dyn_quant_hi", _F * 4), ("dyn_quant_range", _F * 4), ("dyn_quant_step_norm", _F * 4),
-        ("v_dyn_motion", _P), ("v_dyn_omega", _P), ("v_dyn_trbf_center", _P), ("v_dyn_trbf_scale", _P),
+        ("v_dyn_motion", _P), ("v_dyn_omega", _P), ("v_dyn_trbf_center", _P), ("v_dyn_trbf_scale", _P), ("dyn_trbf_alive", _P),
     ]
 
 
@@ -259,6 +259,7 @@ class _StepProject(torch.autograd.Function):
             dt = dyn.bind(quats, scales, opacities, colors, dyn_motion, dyn_omega, dyn_center, dyn_tscale)
             (s.dyn_motion, s.dyn_omega, s.dyn_trbf_center, s.dyn_trbf_scale, s.dyn_timestamp, s.dyn_raw_params, s.dyn_quant_mask,
              lo_, hi_, rng_, qn_) = dyn.c_args(dt)
+            s.dyn_min_trbf, s.dyn_trbf_alive = dyn.min_trbf_arg(), ptr(dyn.alive_buffer(N, dev))
             for dst, src in ((s.dyn_quant_lo, dyn._tables[0]), (s.dyn_quant_hi, dyn._tables[1]), (s.dyn_quant_range, dyn._tables[2]),
                              (s.dyn_quant_step_norm, dyn._tables[3])):
                 dst[:] = src[:]

@@ -1097,7 +1097,7 @@ class _ProjectRows(torch.autograd.Function):
             # dynamic splats: quantizer -> activation -> temporal slice in the projection's load phase (csrc/projection_dyn.hip)
             dtens = dyn.bind(quats, scales, opacities, colors, dyn_motion, dyn_omega, dyn_center, dyn_tscale)
             with _device_of(means):
-                B.call("gs_projection_rows_dyn_fwd", C, N, B.ptr(means), B.ptr(quats), B.ptr(scales), *dyn.c_args(dtens), B.ptr(viewmats),
+                B.call("gs_projection_rows_dyn_fwd", C, N, B.ptr(means), B.ptr(quats), B.ptr(scales), *dyn.c_args(dtens, fwd_on=dev, N=N), B.ptr(viewmats),
                        B.ptr(Ks), int(width), int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip), cm,
                        B.ptr(opacities), B.ptr(colors), int(bool(antialiased)), 0, 0, 0, None, None, B.ptr(radii), B.ptr(depths),
                        B.ptr(rows), _stream(means))

@@ -35,6 +35,8 @@ struct DynArgs {
     uint32_t raw;   // GS_DYN_RAW_* bits: scales are log-scales / opacities logits / trbf_scale a log-scale -- exp / sigmoid / exp in the kernel
     uint32_t quant; // bit k: attribute k goes through the STE round quantizer (clamped IN PLACE, ops.py:63) first
     float q_lo[4], q_hi[4], q_rng[4], q_n[4];
+    float min_trbf;      // forward: gaussians whose temporal basis is <= this are culled at this timestamp (-1: none)
+    uint8_t *alive_out;  // forward: [N] or NULL, 1 where trbf > min_trbf (the trainer's t_vis_mask)
 };
 
 // One gaussian's parameters after quantizer -> activation -> slice: what the projection consumes, and what the backward needs again.
@@ -148,6 +150,9 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_dyn_fwd_kernel(
     float col[3] = {0.f, 0.f, 0.f};
     if (in) {
         dyn_time(dyn, n, o);
+        // temporal visibility (simple_trainer_dyngs.py:526-535 filters these splats out before rasterization): culled here instead
+        const bool alive = o.st.trbf > dyn.min_trbf;
+        if (dyn.alive_out != nullptr && write) dyn.alive_out[n] = alive ? 1 : 0;
         dyn_mean(dyn, means, n, o);
         float raw[7];
         if (QUANT) {
@@ -162,6 +167,9 @@ __global__ void __launch_bounds__(GS_BLOCK) projection_dyn_fwd_kernel(
             dyn_shape_eval(dyn, raw, n, o);
             return covar_from_rot_scale(quat_to_rotmat(o.q[0], o.q[1], o.q[2], o.q[3]), o.s[0], o.s[1], o.s[2]); },
             W, H, eps2d, near_plane, far_plane, radius_clip, camera_model);
+        // (culled AFTER the projection, not around it: the projection chain is contractible code shared with projection.hip, and it is
+        // the unchanged shape of this call that keeps the two kernels' rows bit-identical -- tests/test_gpu_dynamic_fused.py watches it)
+        if (!alive) s.radius = 0;
     }
     const size_t idx = (size_t)c * N + n;
     if (rx.tiles_per_gauss != nullptr) { // (uniform)
@@ -299,6 +307,7 @@ int dyn_args(DynArgs &d, const float *motion, const float *omega, const float *t
              const float *quant_step_norm) {
     d.motion = motion; d.omega = omega; d.center = trbf_center; d.tscale = trbf_scale;
     d.t = timestamp; d.raw = (uint32_t)raw_params & 7u; d.quant = quant_mask & 15u;
+    d.min_trbf = -1.f; d.alive_out = nullptr;
     for (int k = 0; k < 4; ++k) {
         const bool on = (d.quant >> k) & 1u;
         if (on && !(quant_lo && quant_hi && quant_range && quant_step_norm)) return 1;
@@ -312,11 +321,11 @@ int dyn_args(DynArgs &d, const float *motion, const float *omega, const float *t
 
 extern "C" int32_t gs_projection_rows_dyn_fwd(
     uint32_t C, uint32_t N, const float *means, float *quats, float *scales, const float *motion, const float *omega,
-    const float *trbf_center, const float *trbf_scale, float timestamp, uint32_t raw_params, uint32_t quant_mask, const float *quant_lo,
-    const float *quant_hi, const float *quant_range, const float *quant_step_norm, const float *viewmats, const float *Ks,
-    int32_t image_width, int32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip, int32_t camera_model,
-    float *opacities, float *colors, int32_t antialiased, uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
-    int32_t *tiles_per_gauss, int32_t *block_sums, int32_t *radii, float *depths, float *rows, gs_stream_t stream) {
+    const float *trbf_center, const float *trbf_scale, float timestamp, float min_trbf, uint8_t *trbf_alive, uint32_t raw_params,
+    uint32_t quant_mask, const float *quant_lo, const float *quant_hi, const float *quant_range, const float *quant_step_norm,
+    const float *viewmats, const float *Ks, int32_t image_width, int32_t image_height, float eps2d, float near_plane, float far_plane,
+    float radius_clip, int32_t camera_model, float *opacities, float *colors, int32_t antialiased, uint32_t tile_size, uint32_t tile_width,
+    uint32_t tile_height, int32_t *tiles_per_gauss, int32_t *block_sums, int32_t *radii, float *depths, float *rows, gs_stream_t stream) {
     if (C == 0 || N == 0) return 0;
     GS_CHECK_ARG(means && quats && scales && motion && omega && trbf_center && trbf_scale && viewmats && Ks && radii && depths && rows,
                  "null pointer");
@@ -330,6 +339,8 @@ extern "C" int32_t gs_projection_rows_dyn_fwd(
     DynArgs d;
     GS_CHECK_ARG(dyn_args(d, motion, omega, trbf_center, trbf_scale, timestamp, raw_params, quant_mask, quant_lo, quant_hi, quant_range,
                           quant_step_norm) == 0, "quant_mask set without the quantizer tables (4 floats each: scales, quats, opacities, colors)");
+    d.min_trbf = min_trbf;
+    d.alive_out = trbf_alive;
     const DynRowArgs rx = {opacities, colors, antialiased, tiles_per_gauss, block_sums, (float)tile_size, (int32_t)tile_width, (int32_t)tile_height};
     const dim3 grid(gs_div_up(N, GS_BLOCK), C);
     if (d.quant)

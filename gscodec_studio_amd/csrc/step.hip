@@ -67,9 +67,10 @@ extern "C" int32_t gs_step_fwd_begin(gs_step *s, gs_stream_t stream) {
     if (!s->rows_ready && s->dyn_motion != nullptr) {
         GS_CHECK_ARG(s->covars == nullptr && s->sh_coeffs == nullptr, "dynamic splats: quats + scales and [N,3] colours only (no covars, no SH)");
         GS_STEP_TRY(gs_projection_rows_dyn_fwd(s->C, s->N, s->means, const_cast<float *>(s->quats), const_cast<float *>(s->scales), s->dyn_motion,
-                                               s->dyn_omega, s->dyn_trbf_center, s->dyn_trbf_scale, s->dyn_timestamp, s->dyn_raw_params,
-                                               s->dyn_quant_mask, s->dyn_quant_lo, s->dyn_quant_hi, s->dyn_quant_range, s->dyn_quant_step_norm,
-                                               s->viewmats, s->Ks, s->width, s->height, s->eps2d, s->near_plane, s->far_plane, s->radius_clip,
+                                               s->dyn_omega, s->dyn_trbf_center, s->dyn_trbf_scale, s->dyn_timestamp, s->dyn_min_trbf, s->dyn_trbf_alive,
+                                               s->dyn_raw_params, s->dyn_quant_mask, s->dyn_quant_lo, s->dyn_quant_hi, s->dyn_quant_range,
+                                               s->dyn_quant_step_norm, s->viewmats, s->Ks, s->width, s->height, s->eps2d, s->near_plane,
+                                               s->far_plane, s->radius_clip,
                                                s->camera_model, const_cast<float *>(s->opacities), const_cast<float *>(s->colors), s->antialiased,
                                                s->tile_size, s->tile_width, s->tile_height, s->tiles_per_gauss, s->block_sums, s->radii, s->depths,
                                                s->rows, stream));

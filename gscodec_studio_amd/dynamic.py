@@ -107,12 +107,20 @@ class DynamicSlice:
               round-to-grid STE first (gsplat/compression_simulation/ops.py:57-75): the tensor handed to ``rasterization`` is
               CLAMPED IN PLACE like ``STE.apply``'s input (hand over the parameter itself), quantized values are never
               materialised, the gradient is the identity.  (A quantized attribute that also has an activation must be "raw".)
+    min_trbf  the trainer's temporal visibility filter (``temp_vis_mask``, simple_trainer_dyngs.py:526-535: splats whose temporal basis
+              ``trbf`` is not above 0.05 are dropped before rasterization): such splats are CULLED by the projection (radius 0, no tiles,
+              no gradient) instead of being filtered out of the arrays -- same image, and every ``meta`` tensor keeps its full [C, N]
+              shape (the reference re-expands radii / depths / conics / opacities to it afterwards, :557-571).  ``t_vis_mask`` (bool [N])
+              holds the mask after the call.
     A plain tuple ``(motion, omega, trbf_center, trbf_scale, timestamp)`` is accepted wherever a DynamicSlice is."""
 
     def __init__(self, motion: Tensor, omega: Tensor, trbf_center: Tensor, trbf_scale: Tensor, timestamp: float,
-                 raw: Union[bool, Sequence[str]] = (), quantize: Optional[Dict[str, Tuple[float, float, int]]] = None):
+                 raw: Union[bool, Sequence[str]] = (), quantize: Optional[Dict[str, Tuple[float, float, int]]] = None,
+                 min_trbf: Optional[float] = None):
         self.motion, self.omega, self.trbf_center, self.trbf_scale = motion, omega, trbf_center, trbf_scale
         self.timestamp = float(timestamp)
+        self.min_trbf = None if min_trbf is None else float(min_trbf)
+        self._alive: Optional[Tensor] = None
         names = tuple(_RAW_BITS) if raw is True else tuple(raw or ())
         assert all(n in _RAW_BITS for n in names), f"raw: names among {tuple(_RAW_BITS)}, got {names}"
         self.raw = names
@@ -151,11 +159,28 @@ class DynamicSlice:
             out.append(t if t.is_contiguous() else t.contiguous())
         return tuple(out)
 
-    def c_args(self, dt):
-        """The (motion ... quant_step_norm) run of arguments of gs_projection_rows_dyn_fwd / _bwd."""
+    def c_args(self, dt, fwd_on: Optional[torch.device] = None, N: int = 0):
+        """The (motion ... quant_step_norm) run of arguments of gs_projection_rows_dyn_bwd; with ``fwd_on`` (a device) that of
+        gs_projection_rows_dyn_fwd, which also takes the temporal visibility threshold and the mask buffer."""
         lo, hi, rng, qn = self._tables
-        return (B.ptr(dt[0]), B.ptr(dt[1]), B.ptr(dt[2]), B.ptr(dt[3]), self.timestamp, self.raw_mask, self.quant_mask,
-                ctypes.addressof(lo), ctypes.addressof(hi), ctypes.addressof(rng), ctypes.addressof(qn))
+        head = (B.ptr(dt[0]), B.ptr(dt[1]), B.ptr(dt[2]), B.ptr(dt[3]), self.timestamp)
+        if fwd_on is not None:
+            head += (self.min_trbf_arg(), B.ptr(self.alive_buffer(N, fwd_on)))
+        return head + (self.raw_mask, self.quant_mask, ctypes.addressof(lo), ctypes.addressof(hi), ctypes.addressof(rng), ctypes.addressof(qn))
+
+    def min_trbf_arg(self) -> float:
+        return -1.0 if self.min_trbf is None else self.min_trbf
+
+    def alive_buffer(self, N: int, device) -> Optional[Tensor]:
+        """The uint8 [N] buffer the forward writes the temporal visibility into (None without ``min_trbf``)."""
+        if self.min_trbf is None:
+            return None
+        self._alive = torch.empty((N,), dtype=torch.uint8, device=device)
+        return self._alive
+
+    @property
+    def t_vis_mask(self) -> Optional[Tensor]:
+        return None if self._alive is None else self._alive.bool()
 
     # -- the same chain through the stand-alone operators: every route the fused kernels do not cover (packed, distributed, SH colours,
     # covars, camera-pose gradients) and the reference the fused route is tested against
@@ -180,13 +205,18 @@ class DynamicSlice:
         if colors is not None and "colors" in self.quantize:
             colors = q("colors", colors, 0)
         tscale = torch.exp(self.trbf_scale) if "trbf_scale" in self.raw else self.trbf_scale
-        means_t, quats_t, opacity_t, _ = temporal_slice(means, self.motion, quats, self.omega, opacities, self.trbf_center, tscale,
-                                                        self.timestamp)
+        means_t, quats_t, opacity_t, trbf = _TemporalSlice.apply(means, self.motion, quats, self.omega, opacities,
+                                                                 self.trbf_center.reshape(-1), tscale.reshape(-1), self.timestamp)
+        if self.min_trbf is not None:
+            # (the stand-alone route cannot drop the splats -- meta keeps its [C, N] shape -- so they are made invisible instead: an
+            # opacity of zero composites nothing and receives no gradient, like the trainer's filter)
+            self._alive = (trbf.detach() > self.min_trbf).to(torch.uint8)
+            opacity_t = opacity_t * self._alive.to(opacity_t.dtype)
         return means_t, quats_t, scales, opacity_t, colors
 
 
 def render_dynamic(splats: Dict[str, Tensor], timestamp: float, viewmats: Tensor, Ks: Tensor, width: int, height: int,
-                   compression_sim=None, step: int = 0, features: str = "colors", **kwargs):
+                   compression_sim=None, step: int = 0, features: str = "colors", temp_vis_mask: bool = False, **kwargs):
     """The dynamic trainer's ``rasterize_splats`` (reference examples/simple_trainer_dyngs.py:463-577, compression_sim on or off) on
     the fused route: ``splats`` is the trainer's RAW parameter dict (means, scales (log), quats, opacities (logits), trbf_center,
     trbf_scale (log), motion, omega, colors [, features_dir, features_time]); returns ``(render_colors, render_alphas, info)``.
@@ -196,6 +226,9 @@ def render_dynamic(splats: Dict[str, Tensor], timestamp: float, viewmats: Tensor
     bits estimator (``step > entropy_steps[name]``) -- those attributes, and every other mode of the simulation, go through
     ``simulate_compression`` as usual and only the activations + slice are fused.  ``features="stg"`` renders the spacetime trainer's
     nine channels cat(colors, features_dir, tau * features_time) (examples/simple_trainer_STG.py:506-551).
+    ``temp_vis_mask`` (the trainer's option, dyngs.py:137, 526-571): splats whose temporal basis is <= 0.05 at this timestamp are culled
+    by the projection; ``info["t_vis_mask"]`` is the mask and the per-gaussian ``info`` tensors are full-size, as the reference leaves them
+    (its ``info["means2d"]`` alone stays compacted to the masked subset: here it is [C, N, 2] like the rest).
     -> also returns ``esti_bits`` of the hooks that ran outside as ``info["esti_bits"]``."""
     from .rendering import rasterization
 
@@ -228,8 +261,11 @@ def render_dynamic(splats: Dict[str, Tensor], timestamp: float, viewmats: Tensor
         colors = torch.cat((P["colors"], P["features_dir"], tau * P["features_time"]), dim=1)
     else:
         colors = P["colors"]
-    ds = DynamicSlice(P["motion"], P["omega"], P["trbf_center"], P["trbf_scale"], timestamp, raw=raw, quantize=quantize)
+    ds = DynamicSlice(P["motion"], P["omega"], P["trbf_center"], P["trbf_scale"], timestamp, raw=raw, quantize=quantize,
+                      min_trbf=TEMPORAL_VISIBILITY_THRESHOLD if temp_vis_mask else None)
     rc, ra, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], colors, viewmats, Ks, width, height,
                                  dynamic=ds, **kwargs)
     info["esti_bits"] = esti_bits
+    if temp_vis_mask:
+        info["t_vis_mask"] = ds.t_vis_mask
     return rc, ra, info

@@ -899,7 +899,10 @@ int32_t gs_temporal_slice_bwd(
 #define GS_DYN_RAW_TRBF_SCALE 4u
 int32_t gs_projection_rows_dyn_fwd(
     uint32_t C, uint32_t N, const float *means, float *quats, float *scales, const float *motion, const float *omega,
-    const float *trbf_center, const float *trbf_scale, float timestamp, uint32_t raw_params, uint32_t quant_mask, const float *quant_lo,
+    const float *trbf_center, const float *trbf_scale, float timestamp,
+    float min_trbf /* gaussians whose temporal basis is <= this are culled at this timestamp (the trainer's temp_vis_mask, 0.05); < 0: none */,
+    uint8_t *trbf_alive /* [N] or NULL: 1 where trbf > min_trbf (the trainer's t_vis_mask) */,
+    uint32_t raw_params, uint32_t quant_mask, const float *quant_lo,
     const float *quant_hi, const float *quant_range, const float *quant_step_norm, const float *viewmats, const float *Ks,
     int32_t image_width, int32_t image_height, float eps2d, float near_plane, float far_plane, float radius_clip, int32_t camera_model,
     float *opacities /* [N] or NULL */, float *colors /* [N,3] or NULL */, int32_t antialiased,
@@ -1091,9 +1094,11 @@ typedef struct gs_step {
      * quats / scales / opacities / colors are then written when dyn_quant_mask clamps a parameter) */
     const float *dyn_motion, *dyn_omega, *dyn_trbf_center, *dyn_trbf_scale;
     float dyn_timestamp;
-    uint32_t dyn_raw_params, dyn_quant_mask, reserved2;
+    uint32_t dyn_raw_params, dyn_quant_mask;
+    float dyn_min_trbf; /* < 0: no temporal culling */
     float dyn_quant_lo[4], dyn_quant_hi[4], dyn_quant_range[4], dyn_quant_step_norm[4];
     float *v_dyn_motion, *v_dyn_omega, *v_dyn_trbf_center, *v_dyn_trbf_scale;
+    uint8_t *dyn_trbf_alive; /* [N] or NULL */
 } gs_step;
 /* Layout guard for bindings that mirror the host structs by hand (ctypes, cgo, JNA ...): writes up to n entries --
  * sizeof(struct), then offsetof of the listed fields in this order -- and returns how many the list has.

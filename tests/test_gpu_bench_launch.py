@@ -92,3 +92,24 @@ def test_failed_auto_run_falls_back_to_camera_mode():
     rec = _last_json(r.stdout)
     _check(rec, 2)
     assert rec["config"]["dp_mode"] == "camera" and "launch_fallback" in rec["config"]
+
+
+@pytest.mark.parametrize("form", ["reference", "full"])
+def test_dynamic_bench_one_and_two_ranks(form):
+    """``bench.py --dynamic`` (BASELINE config 5's frame step): the one-GPU line carries roofline + streaming rows, and the driver's
+    ``--gpus 2`` form shards frames round-robin (each rank its own timestamp) and sums the parameter gradients."""
+    args = ["--dynamic", "--dynamic-form", form, "--dynamic-splats", "150000", "--steps", "2", "--warmup", "1", "--min-timed-s", "0",
+            "--ramp-s", "0"]
+    r = subprocess.run([sys.executable, "bench.py"] + args, cwd=ROOT, env=_env(False), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = _last_json(r.stdout)
+    assert rec["n_gpus"] == 1 and rec["unit"] == "Msplats/s" and rec["value"] > 0 and "config 5" in rec["config"]["workload"]
+    assert rec["roofline"]["frac"] > 0 and rec["roofline"]["whole_step"]["frac"] > 0
+    want = "gs_projection_rows_dyn_fwd" if form == "full" else "gs_temporal_slice_fwd"
+    assert want in rec["roofline"]["streaming"], sorted(rec["roofline"]["streaming"])
+    share = torch.cuda.device_count() < 2
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + args, cwd=ROOT, env=_env(share), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec2 = _last_json(r.stdout)
+    assert rec2["n_gpus"] == 2 and rec2["value"] > 0 and "frames round-robin over 2" in rec2["config"]["parallelism"]

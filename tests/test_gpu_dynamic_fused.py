@@ -284,3 +284,55 @@ def test_render_dynamic_matches_the_trainer_call_pattern():
             # (float atomics in the compositing backward + torch's exp / sigmoid in the chain: the ill-conditioned log-scale gradient of
             # this fixture moves by a few 1e-4 from run to run; bit-identity is the business of the tests above)
             assert rel_l2(N(P[k].grad), N(P2[k].grad)) < 2e-3, (feats, k, rel_l2(N(P[k].grad), N(P2[k].grad)))
+
+
+@pytest.mark.parametrize("raw_mode", [False, True])
+def test_temporal_visibility_mask_culls_like_the_trainer_filter(raw_mode):
+    """``temp_vis_mask`` of the dynamic trainer (simple_trainer_dyngs.py:526-571): the reference FILTERS the splats whose temporal basis is
+    <= 0.05 out of every array before rasterization and re-expands the per-gaussian info afterwards; the fused route culls them in the
+    projection.  Same image bit for bit (the same splats reach the same lists in the same order), same gradients (exact zeros for the
+    masked splats), full-size info with the reference's t_vis_mask."""
+    from gscodec_studio_amd import rasterization
+    from gscodec_studio_amd.dynamic import DynamicSlice, render_dynamic, temporal_slice
+
+    fx, raw = _params(6000, seed=21, activated=not raw_mode)
+    raw["trbf_scale"] = raw["trbf_scale"] * (0.35 if not raw_mode else 1.0) - (1.0 if raw_mode else 0.0)  # narrow lifetimes: many splats are off at t
+    t = 0.3
+    vm, Ks, W, H = T(fx["viewmats"][:2]), T(fx["Ks"][:2]), fx["width"], fx["height"]
+    # ---- the trainer's way: slice, mask, filter, render, scatter the info back
+    P = _P(raw)
+    scales, opac, tscale = (torch.exp(P["scales"]), torch.sigmoid(P["opacities"]), torch.exp(P["trbf_scale"])) if raw_mode else \
+        (P["scales"], P["opacities"], P["trbf_scale"])
+    m_t, q_t, o_t, mask = temporal_slice(P["means"], P["motion"], P["quats"], P["omega"], opac, P["trbf_center"], tscale, t, temp_vis_mask=True)
+    assert 0.05 < float(mask.float().mean()) < 0.95, float(mask.float().mean())
+    rc0, ra0, info0 = rasterization(m_t[mask], q_t[mask], scales[mask], o_t[mask], P["colors"][mask], vm, Ks, W, H, packed=False)
+    rc0.sum().backward()
+    # ---- fused
+    P2 = _P(raw)
+    if raw_mode:
+        rc1, ra1, info1 = render_dynamic(P2, t, vm, Ks, W, H, temp_vis_mask=True, packed=False)
+        tmask = info1["t_vis_mask"]
+    else:
+        ds = DynamicSlice(P2["motion"], P2["omega"], P2["trbf_center"], P2["trbf_scale"], t, min_trbf=0.05)
+        rc1, ra1, info1 = rasterization(P2["means"], P2["quats"], P2["scales"], P2["opacities"], P2["colors"], vm, Ks, W, H, packed=False, dynamic=ds)
+        tmask = ds.t_vis_mask
+    rc1.sum().backward()
+    if not raw_mode:
+        assert torch.equal(tmask, mask)
+        assert torch.equal(rc1, rc0) and torch.equal(ra1, ra0)
+        assert torch.equal(info1["radii"][:, mask], info0["radii"])
+    else:  # (torch's exp / sigmoid in the chain: a basis value on the threshold may fall the other way)
+        assert float((tmask != mask).float().mean()) < 1e-3
+        assert_close(N(rc1), N(rc0), 1e-4, 1e-5, "temp_vis_mask render", max_bad_frac=3e-4)
+    assert int((info1["radii"][:, ~tmask] != 0).sum()) == 0 and info1["radii"].shape == (2, raw["means"].shape[0])
+    assert info1["flatten_ids"].numel() == info0["flatten_ids"].numel() or raw_mode
+    for k in KEYS:
+        g0, g1 = P[k].grad, P2[k].grad
+        assert float(g1[~tmask].abs().max()) == 0.0, k       # masked at this timestamp: no gradient at all
+        assert rel_l2(N(g1), N(g0)) < (1e-4 if not raw_mode else 5e-3), (k, rel_l2(N(g1), N(g0)))
+    # the stand-alone route (packed): masked splats composite nothing
+    P3 = _P(raw)
+    if not raw_mode:
+        ds3 = DynamicSlice(P3["motion"], P3["omega"], P3["trbf_center"], P3["trbf_scale"], t, min_trbf=0.05)
+        rc3, _, _ = rasterization(P3["means"], P3["quats"], P3["scales"], P3["opacities"], P3["colors"], vm, Ks, W, H, packed=True, dynamic=ds3)
+        assert torch.equal(rc3, rc0) and torch.equal(ds3.t_vis_mask, mask)
