@@ -146,3 +146,37 @@ def test_carve_order_has_one_source():
     t = torch.zeros(3, 2)
     req = W.prefill_request((("omega", t, True), ("means", t, True), ("scales", None, True), ("quats", t, False), ("opacities", t, True)))
     assert [k for k, _ in req] == ["means", "opacities", "omega"]
+
+
+def test_dynamic_slice_descriptor_logic():
+    """``dynamic.DynamicSlice`` (host logic only: no kernel runs): raw / quantize bookkeeping, the bit masks and float tables the C ABI
+    takes (GS_DYN_RAW_*, quant slots scales / quats / opacities / colors), the argument runs of the two entry points, refusals."""
+    import ctypes
+
+    import torch
+
+    from gscodec_studio_amd.dynamic import DynamicSlice
+
+    n = 5
+    mo, om, c, s = torch.zeros(n, 9), torch.zeros(n, 4), torch.zeros(n, 1), torch.zeros(n, 1)
+    ds = DynamicSlice.of((mo, om, c, s, 0.25))
+    assert isinstance(ds, DynamicSlice) and ds.raw_mask == 0 and ds.quant_mask == 0 and ds.min_trbf is None and ds.min_trbf_arg() == -1.0
+    ds.check(n)
+    with pytest.raises(AssertionError):
+        ds.check(n + 1)
+    ds = DynamicSlice(mo, om, c, s, 0.5, raw=True, quantize={"scales": (-10, 2, 8), "colors": (-7.5, 7.5, 8)}, min_trbf=0.05)
+    assert ds.raw_mask == 7 and ds.quant_mask == 0b1001 and ds.min_trbf_arg() == 0.05
+    lo, hi, rng, qn = ds._tables
+    assert (lo[0], hi[0], rng[0]) == (-10.0, 2.0, 12.0) and abs(qn[0] - 1 / 255) < 1e-9 and (lo[3], hi[3], rng[3]) == (-7.5, 7.5, 15.0)
+    assert (lo[1], hi[1], rng[1], qn[1]) == (0.0, 0.0, 1.0, 1.0)  # unhooked slot: neutral
+    bwd = ds.c_args((mo, om, c.reshape(-1), s.reshape(-1)))
+    fwd = ds.c_args((mo, om, c.reshape(-1), s.reshape(-1)), fwd_on=torch.device("cpu"), N=n)
+    assert len(bwd) == 11 and len(fwd) == 13 and fwd[4] == 0.5 and fwd[5] == 0.05 and bwd[5] == 7 and bwd[6] == 0b1001
+    assert ds.t_vis_mask is not None and ds.t_vis_mask.shape == (n,) and ds.t_vis_mask.dtype == torch.bool
+    with pytest.raises(AssertionError):  # a quantized attribute with an activation works on the raw parameter
+        DynamicSlice(mo, om, c, s, 0.5, raw=("trbf_scale",), quantize={"opacities": (-7, 7, 8)})
+    with pytest.raises(AssertionError):
+        DynamicSlice(mo, om, c, s, 0.5, quantize={"means": (-1, 1, 8)})
+    with pytest.raises(RuntimeError):  # quantized colours that do not reach the projection (more than three channels)
+        DynamicSlice(mo, om, c, s, 0.5, quantize={"colors": (-7.5, 7.5, 8)}).bind(torch.zeros(n, 4), torch.zeros(n, 3), torch.zeros(n), None,
+                                                                                    mo, om, c, s)
