@@ -982,6 +982,7 @@ def project_rows(
         assert mask_logits.numel() == N, (mask_logits.shape, N)
     if dynamic is not None:
         assert covars is None and sh_coeffs is None, "dynamic splats: quats + scales and [N, 3] colours (or none) only"
+        assert not viewmats.requires_grad, "project_rows(dynamic=...): no camera-pose gradients on the fused route (rasterization() falls back)"
         dynamic.check(N)
         return _ProjectRows.apply(means.contiguous(), covars, quats, scales, viewmats.contiguous(), Ks.contiguous(),
                                   opacities.contiguous(), colors, sh_coeffs, sh_rest, mask_logits, width, height, eps2d, near_plane, far_plane,

@@ -149,6 +149,7 @@ def rasterization(
 
         dynamic = DynamicSlice.of(dynamic)
         dynamic.check(N)
+        assert covars is None, "dynamic splats rotate their quaternions in time: pass quats + scales, not covars"
         dyn_fused = (not packed and not distributed and covars is None and sh_degree is None and means.is_cuda and viewmats.is_cuda
                      and not viewmats.requires_grad and torch.is_tensor(colors) and colors.dim() == 2)
         if "colors" in dynamic.quantize and not (dyn_fused and colors.shape[-1] == 3):
