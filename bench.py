@@ -159,6 +159,8 @@ def parse():
                          "activate: simulate_compression(activate=True); fused: + rasterization(dynamic=...), the slice inside the "
                          "projection kernels; full: dynamic.render_dynamic -- hooks, activations and slice inside the projection kernels")
     ap.add_argument("--timestamp", type=float, default=0.5)
+    ap.add_argument("--dynamic-order", choices=["shuffle", "morton"], default="shuffle",
+                    help="memory order of the dynamic splats: a seeded shuffle (default, what a trained scene looks like) or a Z-order curve")
     ap.add_argument("--no-dp-projection", action="store_true",
                     help="(one GPU) skip the multi-GPU projection: the exchange modes re-timed on this GPU with their collectives "
                          "forced through RCCL (world 1), next to the bytes a world-8 run would put on the xGMI links")
@@ -455,7 +457,7 @@ def main_dynamic(args):
     from gscodec_studio_amd.dynamic import render_dynamic, temporal_slice
 
     B.lib()
-    w = dynamic_workload(args.dynamic_splats, args.width, args.height, device=dev)
+    w = dynamic_workload(args.dynamic_splats, args.width, args.height, device=dev, order=args.dynamic_order)
     N, W_, H_ = w["N"], w["width"], w["height"]
     viewmats, Ks = w["viewmats"], w["Ks"]
     params = {k: w[k].clone().requires_grad_(True) for k in DYNAMIC_KEYS}
@@ -596,7 +598,7 @@ def main_dynamic(args):
                          "fused": "simulate_compression(activate=True), rasterization(dynamic=...): the slice inside the projection kernels",
                          "full": "dynamic.render_dynamic(raw parameters, sim): round hooks, activations and slice inside the projection kernels "
                                  "(rasterization(dynamic=DynamicSlice(raw=..., quantize=...)))"}[form],
-                "visible": V, "n_isects": I, "channels": D, "native_step_driver": bool(step_driver_on),
+                "visible": V, "n_isects": I, "channels": D, "native_step_driver": bool(step_driver_on), "splat_order": w["order"],
                 "parallelism": f"frames round-robin over {world} rank(s)" + (", RCCL sum of the parameter gradients" if world > 1 else ""),
             },
             "roofline": {

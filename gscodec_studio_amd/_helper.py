@@ -106,13 +106,16 @@ DYNAMIC_KEYS = ("means", "scales", "quats", "opacities", "trbf_center", "trbf_sc
                 "features_time")
 
 
-def dynamic_workload(n_splats: int = 2_000_000, width: int = 1920, height: int = 1080, device="cuda", seed: int = 42) -> Dict:
+def dynamic_workload(n_splats: int = 2_000_000, width: int = 1920, height: int = 1080, device="cuda", seed: int = 42,
+                     order: str = "shuffle") -> Dict:
     """BASELINE.json config 5, one frame of it: ``n_splats`` DYNAMIC (spacetime) gaussians with the trainer's raw parameter set
     (reference examples/simple_trainer_dyngs.py:283-332: means, log-scales, quats, opacity logits, trbf_center, log trbf_scale,
     motion [N,9], omega [N,4], colors / features_dir / features_time [N,3]) and one 1080p camera.  The static part is the
     ``load_test_data`` scene (the smallest odd grid with at least ``n_splats`` gaussians, the first ``n_splats`` of a seeded
     shuffle); the temporal part is drawn so that, as in a trained spacetime scene, only part of the splats is alive at a given
-    timestamp: centres ~ U(0,1), log-scale ~ U(-1.5, 0.5), motion ~ 0.02 N(0,1), omega ~ 0.1 N(0,1)."""
+    timestamp: centres ~ U(0,1), log-scale ~ U(-1.5, 0.5), motion ~ 0.02 N(0,1), omega ~ 0.1 N(0,1).
+    ``order``: "shuffle" (default: the arbitrary order a trained scene's splats are in) or "morton" (the same splats sorted along a
+    Z-order curve of their positions: neighbours in space are neighbours in memory -- what a trainer could do at densification time)."""
     grid = 1
     while grid * grid * 111_785 < n_splats:
         grid += 2
@@ -128,6 +131,18 @@ def dynamic_workload(n_splats: int = 2_000_000, width: int = 1920, height: int =
         motion=0.02 * torch.randn((n, 9), generator=g), omega=0.1 * torch.randn((n, 4), generator=g),
         colors=rgb[sel], features_dir=torch.randn((n, 3), generator=g), features_time=torch.randn((n, 3), generator=g),
         viewmats=viewmats[:1], Ks=Ks[:1])
+    if order == "morton":
+        m = d["means"]
+        q = ((m - m.min(0).values) / (m.max(0).values - m.min(0).values).clamp_min(1e-9) * 1023).long().clamp(0, 1023)
+        code = torch.zeros(n, dtype=torch.long)
+        for b in range(10):
+            for a in range(3):
+                code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+        perm = torch.argsort(code)
+        for k in DYNAMIC_KEYS:
+            d[k] = d[k][perm]
+    else:
+        assert order == "shuffle", order
     d = {k: v.contiguous().float().to(device) for k, v in d.items()}
-    d.update(width=width, height=height, N=n, scene_grid=grid)
+    d.update(width=width, height=height, N=n, scene_grid=grid, order=order)
     return d

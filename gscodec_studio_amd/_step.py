@@ -130,7 +130,7 @@ def _phase1(s: "_Step", C: int, N: int, dev, n_sums: int, given=None) -> dict:
     dvals = None if bucketed else empty(n_elems, dtype=i32, device=dev)  # (bucketed: the element rides in the key's low half)
     tb = B.query("gs_presort_temp_bytes" if bucketed else "gs_sort_temp_bytes", n_elems)
     temp = empty(tb, dtype=u8, device=dev)
-    split = empty(256, dtype=i64, device=dev) if bucketed else None
+    split = W.presort_split_buffer(dev) if bucketed else None
     ko = None if bucketed else empty(n_elems, dtype=i64, device=dev)
     gpre = scratch1 = None
     if n_groups > _PREFIX_FROM[0]:

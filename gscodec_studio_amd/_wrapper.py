@@ -1365,6 +1365,19 @@ _PINNED_DIRECT_MAX = 2048  # block sums a kernel may store straight into pinned 
 _PRESORT = {"on": os.environ.get("GS_PRESORT", "1") != "0", "lds_capacity": 0}
 
 
+def presort_split_buffer(dev: torch.device) -> Tensor:
+    """The int64 buffer ``gs_presort_split`` works in: the 256 splitters in front, its candidate slots behind them."""
+    return torch.empty(_SPLIT_ELEMS[0] or _split_elems(), dtype=torch.int64, device=dev)
+
+
+_SPLIT_ELEMS = [0]
+
+
+def _split_elems() -> int:
+    _SPLIT_ELEMS[0] = int(B.query("gs_presort_split_elems"))
+    return _SPLIT_ELEMS[0]
+
+
 def _pinned_take(n: int) -> Tensor:
     """A pinned int32 buffer the count kernel stores its block sums into, PRE-SET to -1: every sum is >= 0, so the host sees
     the kernel's progress in the buffer itself (``_SentinelEvent``) and no event has to be recorded behind the kernel -- a
@@ -1509,7 +1522,7 @@ def isect_tiles_begin(means2d, radii, depths, tile_size, tile_width, tile_height
                 dvals = None if bucketed else torch.empty(n_elems, dtype=torch.int32, device=dev)  # (bucketed: keys only)
                 split = None
                 if bucketed:
-                    split = torch.empty(256, dtype=torch.int64, device=dev)
+                    split = presort_split_buffer(dev)
                     B.call("gs_presort_split", n_elems, B.ptr(radii), B.ptr(depths), B.ptr(split), st)
                 B.call("gs_isect_count_keys", n_elems, B.ptr(means2d), s_m2, B.ptr(radii), B.ptr(depths), tile_size, tile_width,
                        tile_height, B.ptr(tiles_per_gauss), B.ptr(dkeys), B.ptr(dvals), B.ptr(bsums),

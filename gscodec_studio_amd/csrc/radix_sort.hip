@@ -682,8 +682,8 @@ extern "C" int32_t gs_sort_isect_pairs(uint64_t n, uint32_t *keys32, int32_t *va
 // Bucketed depth pre-sort (round 4).  The splat-level depth pre-sort of the binning orders the ~0.3 M visible (depth, element)
 // keys of a 1 M-splat frame.  As four 8-bit LSD passes that is 11 launches, each sitting at its ~5-10 us latency floor
 // (76 us at BASELINE config 2, whatever the number of live keys).  Here it is ONE partition pass plus ONE launch of local sorts:
-//   1. presort_split_kernel (1 workgroup): up to 4096 keys sampled at a regular stride are sorted in LDS and 255 of them, at
-//      equal ranks, become SPLITTERS -- whatever the depth distribution, every bucket then holds ~n_kept / 256 keys (the gap
+//   1. presort_sample_kernel + presort_split_kernel: 8192 elements sampled at a regular stride (32 workgroups fetch them);
+//      the visible ones are histogrammed in LDS by one workgroup and 255 of them, at equal ranks, become SPLITTERS -- whatever the depth distribution, every bucket then holds ~n_kept / 256 keys (the gap
 //      between splitters is a sum of ~15 sample gaps: more than 2.6x the mean happens about once in 10^6 buckets);
 //   2. gs_isect_count_keys counts the keys of every 1024-element block per BUCKET (digit = number of splitters <= key);
 //      sort_scan_kernel + sort_scatter_kernel<BUCKET> place them: a stable partition, the culled keys dropped;
@@ -876,15 +876,36 @@ GS_DEV uint2 *lds_stable_sort(const LdsSort &L, uint32_t m, uint32_t max_bits = 
     return src;
 }
 
-// 1. splitters.  radii / depths: the projection's dense outputs; split [256]: 255 ascending keys (depth bits << 32), padded with
-// UINT64_MAX.  Candidates: 512 runs of 16 consecutive elements at regular positions (8 K elements in 1 K cache lines, read by
-// consecutive lanes: ONE workgroup has to fetch them, and their latency is most of this kernel); the visible ones are the
-// samples (every visible element has the same chance: the balance of the buckets does not depend on how visibility is
-// distributed over the array; ~9 samples per bucket at 29 % visibility).
-constexpr uint32_t PS_RUN = 16, PS_RUNS = 512, PS_ROUNDS = PS_RUN * PS_RUNS / PS_THREADS, PS_SPLIT_CAP = 8192;
+// 1. splitters.  radii / depths: the projection's dense outputs; split: 255 ascending keys (depth bits << 32) padded with UINT64_MAX in
+// [0, 256), behind it the candidate slots (gs_presort_split_elems() int64 in all).
+// Candidates: 8192 elements at a regular stride; the visible ones are the samples (every visible element has the same chance: the
+// balance of the buckets does not depend on how visibility is distributed over the array; ~9 samples per bucket at 29 %
+// visibility).  Until round 6 the candidates were 512 runs of 16 CONSECUTIVE elements fetched by the splitter workgroup itself
+// (1 K cache lines): fine for an arbitrary splat order, but in a spatially sorted array (Morton / PLAS order, what a codec leaves
+// behind) a run's 16 depths are nearly equal and visibility comes in runs too -- ~120 effective samples for 255 splitters, buckets
+// overflowing LDS: the pre-sort of 2 M Morton-ordered splats took 175 us instead of 55.  8 K individual elements are 16 K
+// distinct cache lines, which ONE workgroup needs 34-42 us to fetch (its CU's miss rate) and which several workgroups cannot
+// hand to one of them inside a launch for less than ~10 us (agent-scope fence + ticket across 8 XCDs: measured 19-20 us for the
+// kernel): so presort_sample_kernel (32 workgroups x 256 candidates, ~2 us) writes candidate slot c = (depth bits | invalid,
+// element) and the splitter workgroup of the NEXT launch reads the 64 KB of slots as one coalesced stream.
+constexpr uint32_t PS_CAND = 8192, PS_SAMPLE_BLOCKS = 32, PS_SPLIT_CAP = 8192, PS_ROUNDS = PS_CAND / PS_THREADS;
+constexpr uint32_t PS_SPLIT_ELEMS = GS_PRESORT_BUCKETS + PS_CAND; // int64: table | candidate slots
+constexpr uint32_t PS_INVALID = 0xffffffffu;
 
-__global__ void __launch_bounds__(PS_THREADS) presort_split_kernel(uint32_t n_elems, const int32_t *__restrict__ radii,
-                                                                   const float *__restrict__ depths, uint64_t *__restrict__ split) {
+__global__ void __launch_bounds__(GS_BLOCK) presort_sample_kernel(uint32_t n_elems, const int32_t *__restrict__ radii,
+                                                                  const float *__restrict__ depths, uint64_t *__restrict__ split) {
+    const uint32_t c = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (c >= PS_CAND) return;
+    const uint32_t i = (uint32_t)(((uint64_t)c * n_elems) / PS_CAND);
+    const bool fresh = c == 0u || i != (uint32_t)(((uint64_t)(c - 1u) * n_elems) / PS_CAND); // (fewer elements than candidates)
+    const uint32_t ic = i < n_elems ? i : 0u;
+    const int32_t r = radii[ic];
+    const float d = depths[ic]; // (both loads in flight together; undefined where culled: never used there)
+    const bool k = fresh && i < n_elems && r > 0;
+    reinterpret_cast<uint2 *>(split + GS_PRESORT_BUCKETS)[c] = make_uint2(k ? ((uint32_t)__float_as_int(d) & 0x7fffffffu) : PS_INVALID, i);
+}
+
+__global__ void __launch_bounds__(PS_THREADS) presort_split_kernel(uint64_t *__restrict__ split) {
     extern __shared__ __align__(16) unsigned char ps_lds[];
     struct {
         uint2 *a;      // [PS_SPLIT_CAP] samples (depth bits, element)
@@ -896,36 +917,20 @@ __global__ void __launch_bounds__(PS_THREADS) presort_split_kernel(uint32_t n_el
     L.red = reinterpret_cast<uint32_t *>(ps_lds + PS_SPLIT_CAP * sizeof(uint2) + 4096 * sizeof(uint32_t));
     const uint32_t tid = threadIdx.x, lane = tid % GS_WAVE, wave = tid / GS_WAVE;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint2 *g_samp = reinterpret_cast<const uint2 *>(split + GS_PRESORT_BUCKETS);
     PS_STAMP(0);
-    uint32_t vis = 0u;
-    float dd[PS_ROUNDS];
-    uint32_t el[PS_ROUNDS];
-    {
-        int32_t rr[PS_ROUNDS];
+    uint2 cand[PS_ROUNDS];
 #pragma unroll
-        for (uint32_t r = 0; r < PS_ROUNDS; ++r) { // candidate c = 1024 r + tid: run c / 16, element c % 16 of it
-            const uint32_t c = r * PS_THREADS + tid;
-            const uint32_t i = (uint32_t)(((uint64_t)(c / PS_RUN) * n_elems) / PS_RUNS) + c % PS_RUN;
-            const uint32_t ic = i < n_elems ? i : 0u;
-            el[r] = i;
-            rr[r] = radii[ic];
-            dd[r] = depths[ic]; // (undefined where culled: never used there)
-            if (i >= n_elems) rr[r] = 0;
-        }
-#pragma unroll
-        for (uint32_t r = 0; r < PS_ROUNDS; ++r)
-            if (rr[r] > 0) vis |= 1u << r;
-    }
+    for (uint32_t r = 0; r < PS_ROUNDS; ++r) cand[r] = g_samp[r * PS_THREADS + tid]; // (64 KB, coalesced)
     PS_STAMP(1);
-    // the visible candidates become the samples, in any order (a histogram follows): per round one ballot and one LDS atomic
-    // of the wave's first visible lane reserve the slots; beyond PS_SPLIT_CAP samples the later rounds' candidates are dropped
-    // (round r holds candidates 1024 r ..: every round is a regular subset of the array)
+    // the valid candidates become the samples, in any order (a histogram follows): per round one ballot and one LDS atomic of the
+    // wave's first valid lane reserve the slots
     uint32_t *s_count = L.red + 2 * PS_WAVES;
     if (tid == 0) *s_count = 0u;
     __syncthreads();
 #pragma unroll
     for (uint32_t r = 0; r < PS_ROUNDS; ++r) {
-        const bool k = (vis >> r) & 1u;
+        const bool k = cand[r].x != PS_INVALID;
         const unsigned long long bl = __ballot(k);
         if (bl != 0ull) { // (wave-uniform)
             const uint32_t first = (uint32_t)__builtin_ctzll(bl);
@@ -933,7 +938,7 @@ __global__ void __launch_bounds__(PS_THREADS) presort_split_kernel(uint32_t n_el
             if (lane == first) base = atomicAdd(s_count, (uint32_t)__popcll(bl));
             base = __shfl(base, (int)first, 64);
             const uint32_t slot = base + (uint32_t)__popcll(bl & lt_mask);
-            if (k && slot < PS_SPLIT_CAP) L.a[slot] = make_uint2((uint32_t)__float_as_int(dd[r]) & 0x7fffffffu, el[r]);
+            if (k && slot < PS_SPLIT_CAP) L.a[slot] = cand[r];
         }
     }
     __syncthreads();
@@ -1192,14 +1197,18 @@ constexpr size_t PS_SPLIT_LDS = PS_SPLIT_CAP * sizeof(uint2) + 4096 * sizeof(uin
 extern "C" int32_t gs_presort_applicable(uint64_t n) { return (n > 0 && sort_rounds_for(n) == SORT_ROUNDS_SMALL) ? 1 : 0; }
 extern "C" uint32_t gs_presort_capacity(void) { return PS_CAP; }
 
+extern "C" uint32_t gs_presort_split_elems(void) { return PS_SPLIT_ELEMS; }
+
 extern "C" int32_t gs_presort_split(uint32_t n_elems, const int32_t *radii, const float *depths, int64_t *splitters, gs_stream_t stream) {
     GS_CHECK_ARG(radii && depths && splitters, "null pointer");
     GS_CHECK_ARG(n_elems > 0, "n_elems must be > 0");
+    GS_CHECK_ARG((uintptr_t)splitters % 8 == 0, "splitters must be 8-byte aligned");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(presort_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)PS_SPLIT_LDS);
     GS_CHECK_ARG(e == hipSuccess, "cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL(presort_split_kernel, dim3(1), dim3(PS_THREADS), PS_SPLIT_LDS, (hipStream_t)stream, n_elems, radii, depths,
+    hipLaunchKernelGGL(presort_sample_kernel, dim3(PS_SAMPLE_BLOCKS), dim3(GS_BLOCK), 0, (hipStream_t)stream, n_elems, radii, depths,
                        (uint64_t *)splitters);
+    hipLaunchKernelGGL(presort_split_kernel, dim3(1), dim3(PS_THREADS), PS_SPLIT_LDS, (hipStream_t)stream, (uint64_t *)splitters);
     GS_CHECK_LAUNCH();
     return 0;
 }

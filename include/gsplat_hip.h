@@ -35,7 +35,7 @@ extern "C" {
 
 /* Bumped whenever an exported signature or the meaning of an argument changes (1: round 1; 2: the round-2 additions to
  * gs_rasterize_fwd, gs_isect_count_keys, gs_sort_pairs_u64_i32_drop, gs_projection_bwd; 3: round 3 -- the splat-row layout,
- * gs_raster_plan, gs_kmeans_decode's bounds; 4: round 4 -- the shN mask entry points, gs_isect_count_keys' bucket_splitters, the bucketed pre-sort; 5: round 6 -- gs_projection_rows_dyn_*, the dyn_* fields of gs_step, gs_accumulate_*).  A binding must refuse a library whose gs_version() differs from the
+ * gs_raster_plan, gs_kmeans_decode's bounds; 4: round 4 -- the shN mask entry points, gs_isect_count_keys' bucket_splitters, the bucketed pre-sort; 5: round 6 -- gs_projection_rows_dyn_*, the dyn_* fields of gs_step, gs_accumulate_*, gs_quantize_round_multi_*, the scratch behind gs_presort_split's table).  A binding must refuse a library whose gs_version() differs from the
  * GS_ABI_VERSION of the header it was generated from, and SHOULD also compare gs_header_hash() (the first 8 bytes of the
  * SHA-256 of the header file the library was compiled against, big-endian) with the hash of its own copy: ctypes / cgo call
  * through shifted argument lists silently otherwise. */
@@ -486,7 +486,11 @@ int32_t gs_sort_first_hist_applicable(uint64_t n);
  * 0x7fffffff on the keys of gs_isect_count_keys -- perm = the elements in (depth bits, element) order, culled ones dropped --
  * in 4 launches instead of 11 for the sizes where every radix launch sits at its latency floor (gs_presort_applicable(n):
  * n <= 2 M elements):
- *   gs_presort_split     255 splitters at equal ranks among up to 4096 regularly sampled visible keys (one workgroup; an LDS sort)
+ *   gs_presort_split     255 splitters at equal ranks among the visible ones of 8192 elements sampled at a regular stride
+ *                        (round 6: individual elements fetched by 8 workgroups instead of 512 runs of 16 by one -- a spatially
+ *                        sorted splat array made the runs' depths nearly equal and the buckets overflow).  splitters: int64
+ *                        [gs_presort_split_elems()]: the 256-entry table in front, the call's candidate slots behind it (no
+ *                        initialisation needed; two launches: 32 sampling workgroups, then the splitter workgroup)
  *   gs_isect_count_keys  (bucket_splitters = the table, sort_temp = temp) counts every 1024-element block's keys per bucket
  *   gs_presort_buckets   scan + ONE stable partition pass by bucket + local sorts: workgroup w finishes the buckets starting in
  *                        positions [1024 w, 1024 (w + 1)) with an LSD sort in LDS on the depth bits that differ inside its range.
@@ -497,8 +501,10 @@ int32_t gs_sort_first_hist_applicable(uint64_t n);
 int32_t gs_presort_applicable(uint64_t n);
 uint32_t gs_presort_capacity(void);
 size_t gs_presort_temp_bytes(uint64_t n);
+uint32_t gs_presort_split_elems(void);
 int32_t gs_presort_split(
-    uint32_t n_elems, const int32_t *radii, const float *depths, int64_t *splitters /* [256] */, gs_stream_t stream);
+    uint32_t n_elems, const int32_t *radii, const float *depths, int64_t *splitters /* [gs_presort_split_elems()], see above */,
+    gs_stream_t stream);
 int32_t gs_presort_buckets(
     uint64_t n, int64_t *keys_in /* DESTROYED: on return [0, *n_kept) holds the sorted keys (depth bits << 32 | element), what
     gs_isect_finish_presorted takes as sorted_keys */, const int32_t *vals_in /* unused (may be NULL) */, const int64_t *splitters,

@@ -23,7 +23,7 @@ int main() {
         depths[i] = 0.6f + 7.7f * (float)rand() / RAND_MAX * (float)rand() / RAND_MAX;
     }
     int32_t *d_r; float *d_d; int64_t *d_split, *d_keys; int32_t *d_vals, *d_perm, *d_tiles; uint32_t *d_nk, *d_gs; void *temp;
-    hipMalloc(&d_r, n * 4); hipMalloc(&d_d, n * 4); hipMalloc(&d_split, 256 * 8); hipMalloc(&d_keys, n * 8); hipMalloc(&d_vals, n * 4);
+    hipMalloc(&d_r, n * 4); hipMalloc(&d_d, n * 4); hipMalloc(&d_split, (size_t)gs_presort_split_elems() * 8); hipMalloc(&d_keys, n * 8); hipMalloc(&d_vals, n * 4);
     hipMalloc(&d_perm, n * 4); hipMalloc(&d_tiles, n * 4); hipMalloc(&d_nk, 4); hipMalloc(&d_gs, (n / 128 + 1) * 4);
     const size_t tb = gs_presort_temp_bytes(n);
     hipMalloc(&temp, tb);
