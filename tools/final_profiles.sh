@@ -66,6 +66,8 @@ cp "$out/${tag}_pmc_traffic_dynamic.json" profiles/${tag}_pmc_traffic_dynamic.js
   for f in reference activate fused full; do for d in 3 9; do
     python bench.py --dynamic --dynamic-form $f --dynamic-channels $d 2>/dev/null < /dev/null | tail -1
   done; done
+  # the same splats in Z-order (config.splat_order = "morton"): what a spatially sorted array buys the streaming stages
+  for f in reference full; do python bench.py --dynamic --dynamic-form $f --dynamic-order morton 2>/dev/null < /dev/null | tail -1; done
 } > "$out/${tag}_bench_dynamic.jsonl"
 for f in reference full; do
   bash tools/prof.sh ${tag}dyn_$f --dynamic --dynamic-form $f > "$out/prof_dyn_$f.log" 2>&1
