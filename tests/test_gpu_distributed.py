@@ -235,7 +235,7 @@ def _span_reduce(rank, world, port, backend):
         dist.destroy_process_group()
 
 
-def _dynamic_round_robin(rank, world, port, backend, frames):
+def _dynamic_round_robin(rank, world, port, backend, frames, fused=False):
     """BASELINE config 5's multi-GPU half at fixture size: ``frames`` timestamps of ONE dynamic scene handed out round-robin
     (frame f -> rank f % world, reference examples/simple_trainer_dyngs.py: one (camera, timestamp) sample per rank and step),
     per frame round-quantize hooks -> temporal slice -> render -> backward, gradients accumulated over a rank's frames and
@@ -255,30 +255,38 @@ def _dynamic_round_robin(rank, world, port, backend, frames):
         t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)  # noqa: E731
         cams = [(t(fx["viewmats"][f % 3])[None], t(fx["Ks"][f % 3])[None], f / max(frames - 1, 1)) for f in range(frames)]
 
-        def run(P, frame_ids):
+        def run(P, frame_ids, use_fused=False):
             sim = STGCompressionSimulation(quantization_sim_type="round", entropy_steps={})
             imgs = {}
             for f in frame_ids:
                 vm, Ks, ts = cams[f]
-                _, rc, _, _ = _dyn_step(P, sim, vm, Ks, W, H, ts)
+                if use_fused:  # round 6: hooks + activations + slice inside the projection kernels (dynamic.render_dynamic)
+                    from gscodec_studio_amd.dynamic import render_dynamic
+
+                    rc, _, _ = render_dynamic(P, ts, vm, Ks, W, H, compression_sim=sim, step=0, packed=False)
+                else:
+                    _, rc, _, _ = _dyn_step(P, sim, vm, Ks, W, H, ts)
                 rc.sum().backward()
                 imgs[f] = rc.detach()
             return imgs
 
         P = {k: torch.nn.Parameter(t(v)) for k, v in raw.items()}
-        mine = run(P, range(rank, frames, world))
+        mine = run(P, range(rank, frames, world), use_fused=fused)
         D.all_reduce_splat_grads(P, average=False)
         R = {k: torch.nn.Parameter(t(v)) for k, v in raw.items()}
         ref = run(R, range(frames))
         for f, img in mine.items():
-            assert torch.allclose(img, ref[f], rtol=1e-5, atol=1e-6), f
+            if fused:  # (torch's exp / sigmoid in the reference chain: a splat on a threshold may flip in a pixel or two)
+                assert float(((img - ref[f]).abs() > 1e-4).float().mean()) < 1e-3, f
+            else:
+                assert torch.allclose(img, ref[f], rtol=1e-5, atol=1e-6), f
         seen = 0
         for k in P:
             if R[k].grad is None:
                 assert P[k].grad is None or float(P[k].grad.abs().max()) == 0.0, k
                 continue
             seen += 1
-            assert _rel(P[k].grad, R[k].grad) < 5e-4, (k, _rel(P[k].grad, R[k].grad))
+            assert _rel(P[k].grad, R[k].grad) < (5e-3 if fused else 5e-4), (k, _rel(P[k].grad, R[k].grad))
         assert seen >= 9
         for k in ("scales", "quats", "opacities", "colors"):  # the in-place clamp of the round hooks is the same on every rank
             assert torch.equal(P[k].detach(), R[k].detach()), k
@@ -370,6 +378,13 @@ def test_gaussian_sharded_world8(sparse):
 @pytest.mark.parametrize("world,frames", [(8, 8), (8, 19), (2, 5)])
 def test_config5_dynamic_frames_round_robin(world, frames):
     _spawn(_dynamic_round_robin, (world, _free_port(), _backend_for(world), frames), world, deadline_s=240)
+
+
+@pytest.mark.parametrize("world,frames", [(8, 8), (2, 5)])
+def test_config5_dynamic_frames_round_robin_fused(world, frames):
+    """The same with every rank rendering through ``dynamic.render_dynamic`` (the fused projection), against the single-process sum of
+    the trainer's own sequence over all frames."""
+    _spawn(_dynamic_round_robin, (world, _free_port(), _backend_for(world), frames, True), world, deadline_s=240)
 
 
 def test_camera_sharded_rccl_world1():
