@@ -181,21 +181,40 @@ def _finish(s, sp, stream, bufs, n_sums, C, N, height, width, tile_height, tile_
     offsets = empty((C, tile_height, tile_width), dtype=i32, device=dev)
     s.offsets = ptr(offsets)
     sentinel = W._SentinelEvent(pinned, stream=torch.cuda.current_stream(dev))  # (the launch stream: what the wait watches for faults)
+    # The phase-2 buffers are sized by n_isects, which only the read-back below delivers -- and everything the host does between the
+    # read-back and the binning launch is time the GPU may spend idle (round 6, tools/host_timeline.py: three allocations, a size query
+    # and the descriptor fields took 46 us there against the ~56 us of pre-sort the GPU still has when the sums land; 12-17 us of idle
+    # GPU per step).  So they are allocated BEFORE the wait, with the capacity the same call shape needed last time (+ 3 %), and the
+    # outputs are prefix views of them; a step that needs more falls back to exact allocations after the wait.
+    key = (dev.index, C, N, tile_height, tile_width)
+    cap = _ISECT_CAP.get(key, 0) if _PREALLOC else 0
+    ids_buf = flat_buf = work = None
+    wb = 0
+    if cap:
+        ids_buf = empty(cap, dtype=i64, device=dev)
+        flat_buf = empty(cap, dtype=i32, device=dev)
+        wb = B.query("gs_isect_finish_work_bytes", cap)
+        work = empty(wb, dtype=u8, device=dev)
+        s.isect_ids, s.flatten_ids, s.work, s.work_bytes = ptr(ids_buf), ptr(flat_buf), ptr(work), wb
     # ---- the one host sync: the count kernel's block sums land in pinned memory (-1 -> >= 0).  From here to the
-    # binning launches the GPU has ~40 us of pre-sort left: nothing that can be done earlier or later sits in between
+    # binning launches the GPU has ~40 us of pre-sort left
     W._wait_event(sentinel)
-    totals = sentinel.np.reshape(-1, 2).sum(0, dtype="int64")
-    n_isects = int(totals[0])
-    s.n_kept_host = int(totals[1]) if W._PACKED_PAIRS else 0
-    isect_ids = empty(n_isects, dtype=i64, device=dev)
-    flatten_ids = empty(n_isects, dtype=i32, device=dev)
-    wb = B.query("gs_isect_finish_work_bytes", n_isects)
-    work = empty(wb, dtype=u8, device=dev)
-    s.n_isects, s.isect_ids, s.flatten_ids, s.work, s.work_bytes = n_isects, ptr(isect_ids), ptr(flatten_ids), ptr(work), wb
+    n_isects, n_kept_host = W.block_sum_totals(sentinel.np)
+    s.n_kept_host = n_kept_host if W._PACKED_PAIRS else 0
+    s.n_isects = n_isects
+    if ids_buf is None or n_isects > cap:
+        ids_buf = empty(n_isects, dtype=i64, device=dev)
+        flat_buf = empty(n_isects, dtype=i32, device=dev)
+        wb = B.query("gs_isect_finish_work_bytes", n_isects)
+        work = empty(wb, dtype=u8, device=dev)
+        s.isect_ids, s.flatten_ids, s.work, s.work_bytes = ptr(ids_buf), ptr(flat_buf), ptr(work), wb
     # the binning half goes out at once (the GPU has been waiting for this call since the pre-sort ended); the
     # compositing scratch is sized and allocated while it runs
     s.finish_phase = 1
     B.call("gs_step_fwd_finish", sp, stream)
+    isect_ids = ids_buf if ids_buf.shape[0] == n_isects else ids_buf[:n_isects]
+    flatten_ids = flat_buf if flat_buf.shape[0] == n_isects else flat_buf[:n_isects]
+    _ISECT_CAP[key] = n_isects + (n_isects >> 5) + 4096
     W._PINNED_FREE.setdefault(2 * n_sums, []).append(pinned)
     bufs["pinned"] = None
     # ---- the compositing buffers (made while the GPU is busy with the binning)
@@ -224,6 +243,10 @@ def _finish(s, sp, stream, bufs, n_sums, C, N, height, width, tile_height, tile_
     s.finish_phase = 2
     B.call("gs_step_fwd_finish", sp, stream)
     return offsets, isect_ids, flatten_ids, render_colors, render_alphas, last_ids, fill, prefill, scratch, plan
+
+
+_ISECT_CAP: dict = {}  # (device, C, N, tile grid) -> capacity for the next call's intersection buffers (last count + 3 %)
+_PREALLOC = os.environ.get("GS_ISECT_PREALLOC", "1") != "0"
 
 
 class _StepProject(torch.autograd.Function):

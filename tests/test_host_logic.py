@@ -180,3 +180,17 @@ def test_dynamic_slice_descriptor_logic():
     with pytest.raises(RuntimeError):  # quantized colours that do not reach the projection (more than three channels)
         DynamicSlice(mo, om, c, s, 0.5, quantize={"colors": (-7.5, 7.5, 8)}).bind(torch.zeros(n, 4), torch.zeros(n, 3), torch.zeros(n), None,
                                                                                     mo, om, c, s)
+
+
+def test_block_sum_totals_is_exact():
+    """``_wrapper.block_sum_totals`` (the host's reduction of the count kernel's per-block (intersections, visible) pairs, read as int64
+    words) against the plain column sums, including totals beyond 2^32."""
+    import numpy as np
+
+    from gscodec_studio_amd._wrapper import block_sum_totals
+
+    rng = np.random.default_rng(0)
+    for n, hi_val in ((1, 10), (3930, 5000), (2048, 2_000_000), (2048, 2_100_000_000)):
+        a = rng.integers(0, hi_val, size=2 * n, dtype=np.int64).astype(np.int32)
+        want = a.reshape(-1, 2).sum(0, dtype=np.int64)
+        assert block_sum_totals(a) == (int(want[0]), int(want[1])), (n, hi_val)
