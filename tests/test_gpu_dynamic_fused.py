@@ -120,7 +120,8 @@ def test_fused_slice_on_the_step_driver_route():
         assert rel_l2(N(grads[0][k]), N(grads[1][k])) < 1e-4, (k, rel_l2(N(grads[0][k]), N(grads[1][k])))
 
 
-def test_fused_raw_parameters_and_round_quantizer_in_the_kernel():
+@pytest.mark.parametrize("C", [1, 2])
+def test_fused_raw_parameters_and_round_quantizer_in_the_kernel(C):
     """The trainer's RAW parameters handed over as they are: round STE hooks (in-place clamp) -> exp / sigmoid -> slice in the projection
     kernel, against STE(activation) -> torch.exp(trbf_scale) -> temporal_slice -> rasterization."""
     fx, raw = _params(6000, seed=3, activated=False)
@@ -132,7 +133,7 @@ def test_fused_raw_parameters_and_round_quantizer_in_the_kernel():
     outs, grads, Ps = [], [], []
     for fused in (True, False):
         P = _P(raw)
-        rc, ra, meta = _render(P, fx, 0.45, fused=fused, raw=names, quantize=BDS, packed=False, deterministic=True)
+        rc, ra, meta = _render(P, fx, 0.45, C=C, fused=fused, raw=names, quantize=BDS, packed=False, deterministic=True)
         (rc * torch.linspace(0.2, 1.0, rc.numel(), device=rc.device).view_as(rc)).sum().backward()
         outs.append((rc.detach(), ra.detach(), meta))
         grads.append({k: p.grad.clone() for k, p in P.items()})
