@@ -13,6 +13,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gscodec_studio_amd import rasterization  # noqa: E402
 from gscodec_studio_amd._helper import sh_workload  # noqa: E402
 
+import gc  # noqa: E402
+
+# a full collection over the ~10^5 objects torch's import leaves behind takes 30-50 ms and lands in the middle of a timed loop
+# (one 33 ms call in 30: a "2.1 ms" forward that is 0.44): park them in the permanent generation
+gc.collect()
+gc.freeze()
+
 
 def run(D, steps=30, grid=3):
     dev = torch.device("cuda")
@@ -37,10 +44,16 @@ def run(D, steps=30, grid=3):
             step(bwd)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        calls = []
         for _ in range(steps):
+            t1 = time.perf_counter()
             meta = step(bwd)
+            calls.append((time.perf_counter() - t1) * 1e3)
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps * 1e3, meta
+        t = (time.perf_counter() - t0) / steps * 1e3
+        if os.environ.get("GS_BENCH_CALLS"):
+            print(f"    host ms per call ({'fwd+bwd' if bwd else 'fwd'}):", " ".join(f"{c:.2f}" for c in calls), flush=True)
+        return t, meta
 
     with torch.no_grad():
         t_f, _ = timed(False)
@@ -54,7 +67,7 @@ if __name__ == "__main__":
     Ds = [int(a) for a in sys.argv[1:]] or [3, 9, 16, 32]
     base = None
     for D in Ds:
-        torch.cuda.empty_cache()  # (a run after several other widths once read 2.9 ms forward-only at D = 32 against 0.86 alone: allocator state)
+        torch.cuda.empty_cache()
         t = run(D)
         if D == 3:
             base = t

@@ -13,6 +13,13 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gscodec_studio_amd.compression_simulation import Entropy_factorized_optimized_refactor as M  # noqa: E402
 
+import gc  # noqa: E402
+
+# a full collection over the ~10^5 objects torch's import leaves behind takes 30-50 ms and lands in the middle of a timed loop
+# (one 33 ms call in 30: a "2.1 ms" forward that is 0.44): park them in the permanent generation
+gc.collect()
+gc.freeze()
+
 
 def eager_bits(m, x, q):
     C = m.channel

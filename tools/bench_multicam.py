@@ -2,6 +2,13 @@ import torch, time, sys
 sys.path.insert(0, "/root/repo")
 from gscodec_studio_amd import rasterization
 from gscodec_studio_amd._helper import sh_workload
+
+import gc  # noqa: E402
+
+# a full collection over the ~10^5 objects torch's import leaves behind takes 30-50 ms and lands in the middle of a timed loop
+# (one 33 ms call in 30: a "2.1 ms" forward that is 0.44): park them in the permanent generation
+gc.collect()
+gc.freeze()
 for C in (1, 2, 4, 8):
     w = sh_workload(scene_grid=3, device="cuda:0", n_cameras=C, camera_mode="jitter0")
     P = [w[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "sh")]

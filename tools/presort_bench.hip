@@ -79,9 +79,8 @@ int main() {
     hipMemcpyFromSymbol(st, HIP_SYMBOL(ps_stamps), sizeof(st));
     auto us = [&](int a, int b) { return (double)(st[b] - st[a]) / 100.0; };
     printf("split kernel (us): gather %.1f  scan+compaction %.1f  histogram+prefix %.1f  splitters %.1f  total %.1f\n", us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(0, 4));
-    printf("  sort detail: setup %.1f", us(2, 16));
-    for (int p = 0; p < 2; ++p) printf(" | pass %d: zero %.1f rank %.1f scan %.1f", p, us(17 + 4 * p, 17 + 4 * p) , us(17 + 4 * p, 18 + 4 * p), us(18 + 4 * p, 19 + 4 * p));
-    printf("\n");
+    printf("  block-0 in-LDS sort (us):");
+    for (int p = 0; p < 2; ++p) printf(" pass %d: rank %.1f scan %.1f%s", p, us(17 + 4 * p, 18 + 4 * p), us(18 + 4 * p, 19 + 4 * p), p ? "\n" : " |");
     printf("local kernel, block %d (us): prelude %.1f  load %.1f  sort %.1f  output %.1f  total %.1f\n", 0, us(8, 9), us(9, 10), us(10, 11), us(11, 12), us(8, 12));
     return 0;
 }
