@@ -457,6 +457,8 @@ def main_dynamic(args):
     from gscodec_studio_amd.dynamic import render_dynamic, temporal_slice
 
     B.lib()
+    gc.collect()
+    gc.freeze()  # (see main())
     w = dynamic_workload(args.dynamic_splats, args.width, args.height, device=dev, order=args.dynamic_order)
     N, W_, H_ = w["N"], w["width"], w["height"]
     viewmats, Ks = w["viewmats"], w["Ks"]
@@ -688,6 +690,10 @@ def main():
     from gscodec_studio_amd.distributed import all_reduce_splat_grads, plan_sparse_grad_exchange
 
     B.lib()  # fail loudly if the HIP library is missing
+    # everything imported so far goes to the permanent generation: a full collection over it is 30-50 ms, and the untimed calibration
+    # and the cold-protocol region below run with the collector on (the headline regions park it altogether)
+    gc.collect()
+    gc.freeze()
     w = sh_workload(scene_grid=args.scene_grid, width=args.width, height=args.height, n_cameras=world,
                     sh_degree=args.sh_degree, device=dev, camera_mode="jitter0")  # equal work per rank (weak scaling)
     N = w["N"]

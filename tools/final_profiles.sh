@@ -57,6 +57,7 @@ cp gpurun_out/prof_${tag}_ch32_kernel_stats.csv "$out/${tag}_channels32_kernel_s
 {
   for k in ${FUZZ_OFFSETS:-6100 6200 6300 6400 6500 6600 6700 6800}; do
     echo "GS_FUZZ_SEED_OFFSET=$k: $(GS_FUZZ_SEED_OFFSET=$k python -m pytest tests/test_gpu_fuzz.py -q 2>&1 | tail -1)"
+    echo "GS_FUZZ_SEED_OFFSET=$k (dynamic, fused vs chain): $(GS_FUZZ_SEED_OFFSET=$k python -m pytest tests/test_gpu_dynamic_fused.py -q -k fuzz 2>&1 | tail -1)"
   done
 } > "$out/${tag}_fuzz_extended.txt" 2>&1
 # ---- round 6: BASELINE config 5's step (bench.py --dynamic): counters, bench lines per form, kernel tables, timelines
