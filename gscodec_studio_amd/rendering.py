@@ -143,6 +143,7 @@ def rasterization(
 
     N = means.shape[0]
     C = viewmats.shape[0]
+    assert C > 0, "rasterization needs at least one camera (the reference fails on an empty batch too: log2(0) in isect_tiles)"
     device = means.device
     if dynamic is not None:
         from .dynamic import DynamicSlice
