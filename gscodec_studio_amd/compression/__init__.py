@@ -13,7 +13,7 @@
   directory layout (PNG image grids, ``shN.npz`` + ``mask.bin``, ``meta.json``) and a self-contained 8-bit PNG reader /
   writer (the image has no imageio), so directories written by either implementation are read by the other.
 """
-from .decode import decode_to_rasterizer_inputs, kmeans_decode, kmeans_encode, morton_order, sort_splats
+from .decode import decode_to_rasterizer_inputs, kmeans_decode, kmeans_encode, morton_order, reorder_splats, sort_splats
 from .png_compression import PngCompression, png_read, png_write
 from .grid_codec import (
     compress_to_arrays,
@@ -26,4 +26,4 @@ from .grid_codec import (
 
 __all__ = ["quantize_grid", "dequantize_grid", "compress_to_arrays", "decompress_from_arrays", "log_transform",
            "inverse_log_transform", "decode_to_rasterizer_inputs", "kmeans_decode", "kmeans_encode", "morton_order",
-           "sort_splats", "PngCompression", "png_read", "png_write"]
+           "sort_splats", "reorder_splats", "PngCompression", "png_read", "png_write"]

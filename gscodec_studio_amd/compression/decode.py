@@ -147,6 +147,46 @@ def morton_order(means: Tensor, bits: int = 10) -> Tensor:
     return torch.argsort(code, stable=True)
 
 
+@torch.no_grad()
+def reorder_splats(params, optimizers=None, perm: Optional[Tensor] = None, state: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """Permute a trainer's splats IN MEMORY: every per-gaussian parameter, its optimizer state and the densification strategy's running
+    statistics, along ``perm`` (default: ``morton_order(params["means"])``).  Rendering does not depend on the order of the splats, its
+    speed does: the per-gaussian kernels read and write the rows of the gaussians a camera sees, and in a spatially sorted array those
+    rows are neighbours (BASELINE config 2: -2 % per step against the fixture's order, -5 % against a shuffled array; config 5: -11..15 %;
+    profiles/r06_splat_order.txt).  Densification appends new splats at the end, so call it after the set changed (or every few
+    thousand steps): one gather per tensor.
+
+    ``params``: dict / ParameterDict name -> Parameter [N, ...]; ``optimizers``: dict name -> Optimizer holding that parameter (the
+    layout of the reference's trainers and of its ``strategy/ops.py:_update_param_with_optimizer``, whose replace-the-parameter-and-move-
+    the-state mechanics this follows); ``state``: the strategy's per-gaussian tensors (``grad2d``, ``count``, ``radii`` ...), permuted in
+    place of the dict.  Tensors whose first dimension is not N (an MLP decoder's weights, scalar steps) are left alone.  Returns perm."""
+    n = int(params["means"].shape[0])
+    if perm is None:
+        perm = morton_order(params["means"].detach())
+    assert perm.shape == (n,), perm.shape
+    for name in list(params.keys()):
+        p = params[name]
+        if p.dim() == 0 or p.shape[0] != n:
+            continue
+        new = torch.nn.Parameter(p.detach()[perm].contiguous(), requires_grad=p.requires_grad)
+        opt = None if optimizers is None else optimizers.get(name)
+        if opt is not None:
+            for group in opt.param_groups:
+                for i, q in enumerate(group["params"]):
+                    if q is p:
+                        group["params"][i] = new
+            st = opt.state.pop(p, None)
+            if st is not None:
+                opt.state[new] = {k: (v[perm].contiguous() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n else v)
+                                  for k, v in st.items()}
+        params[name] = new
+    if state is not None:
+        for k, v in list(state.items()):
+            if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n:
+                state[k] = v[perm].contiguous()
+    return perm
+
+
 def sort_splats(splats: Dict[str, Tensor], verbose: bool = True, return_indices: bool = False, sort_with_shN: bool = False):
     """The reference's ``sort_splats`` (gsplat/compression/sort.py:7-59): Parallel Linear Assignment Sorting of the splats
     on the square grid, through the external ``plas`` package -- a randomised heuristic (``torch.randperm`` start) whose

@@ -194,3 +194,55 @@ def test_block_sum_totals_is_exact():
         a = rng.integers(0, hi_val, size=2 * n, dtype=np.int64).astype(np.int32)
         want = a.reshape(-1, 2).sum(0, dtype=np.int64)
         assert block_sum_totals(a) == (int(want[0]), int(want[1])), (n, hi_val)
+
+
+def test_reorder_splats_moves_parameters_optimizer_state_and_strategy_state_together():
+    """compression.reorder_splats: one permutation for every per-gaussian tensor of a trainer (parameters, Adam moments, the strategy's
+    running statistics); training continues as if nothing happened -- the same updates, permuted."""
+    from gscodec_studio_amd.compression import morton_order, reorder_splats
+
+    g = torch.Generator().manual_seed(3)
+    n = 257
+
+    def make():
+        params = torch.nn.ParameterDict({"means": torch.nn.Parameter(torch.randn(n, 3, generator=torch.Generator().manual_seed(1))),
+                                         "sh0": torch.nn.Parameter(torch.randn(n, 1, 3, generator=torch.Generator().manual_seed(2))),
+                                         "decoder_w": torch.nn.Parameter(torch.ones(4, 4))})
+        opts = {k: torch.optim.Adam([params[k]], lr=1e-2) for k in params}
+        return params, opts
+
+    def train(params, opts, steps, weight):
+        for _ in range(steps):
+            loss = ((params["means"] ** 2).sum(-1) * weight).sum() + (params["sh0"].reshape(len(weight), -1).sum(-1) * weight).sum() \
+                + params["decoder_w"].sum()
+            for o in opts.values():
+                o.zero_grad()
+            loss.backward()
+            for o in opts.values():
+                o.step()
+
+    w = torch.rand(n, generator=g)
+    pa, oa = make()
+    pb, ob = make()
+    train(pa, oa, 3, w)
+    train(pb, ob, 3, w)
+    state = {"count": torch.arange(n, dtype=torch.float32), "scene_scale": torch.tensor(2.0)}
+    perm = reorder_splats(pb, ob, state=state)
+    assert torch.equal(perm, morton_order(pa["means"].detach())) and sorted(perm.tolist()) == list(range(n))
+    assert torch.equal(state["count"], perm.float()) and float(state["scene_scale"]) == 2.0
+    assert torch.equal(pb["decoder_w"], pa["decoder_w"])  # not a per-gaussian tensor: untouched, same object in its optimizer
+    assert ob["decoder_w"].param_groups[0]["params"][0] is pb["decoder_w"]
+    for k in ("means", "sh0"):
+        assert torch.equal(pb[k].detach(), pa[k].detach()[perm]) and ob[k].param_groups[0]["params"][0] is pb[k]
+        sa, sb = oa[k].state[pa[k]], ob[k].state[pb[k]]
+        assert torch.equal(sb["exp_avg"], sa["exp_avg"][perm]) and torch.equal(sb["exp_avg_sq"], sa["exp_avg_sq"][perm])
+        assert float(sb["step"]) == float(sa["step"])
+    # ... and the training goes on identically
+    train(pa, oa, 2, w)
+    train(pb, ob, 2, w[perm])
+    for k in ("means", "sh0"):
+        assert torch.allclose(pb[k].detach(), pa[k].detach()[perm], rtol=0, atol=1e-7), k
+    # an explicit permutation, plain dict, no optimizers
+    d = {"means": torch.nn.Parameter(torch.arange(12.0).reshape(4, 3)), "opacities": torch.nn.Parameter(torch.arange(4.0))}
+    reorder_splats(d, perm=torch.tensor([3, 1, 0, 2]))
+    assert d["opacities"].tolist() == [3.0, 1.0, 0.0, 2.0] and d["means"][0].tolist() == [9.0, 10.0, 11.0]
