@@ -1658,7 +1658,12 @@ def isect_tiles_finish(st_, offsets_for: Optional[int] = None):
                    B.ptr(keys32), B.ptr(vals), st)
             tb = B.query("gs_sort_isect_temp_bytes", n_isects)
             temp = torch.empty(tb, dtype=torch.uint8, device=dev)
-            B.call("gs_sort_isect_pairs", n_isects, B.ptr(keys32), B.ptr(vals), B.ptr(depths), st_["tile_n_bits"] + st_["cam_n_bits"],
+            # (only the bits a key can have set take part in the sort: C = 8 is 3 camera bits, not the 4 of the id layout -- two passes
+            # instead of three at 1080p; with all 32 bits in use the ids' sign matters to the last pass: left alone)
+            key_bits = st_["tile_n_bits"] + st_["cam_n_bits"]
+            if key_bits < 32:
+                key_bits = max(1, st_["tile_n_bits"] + max(st_["C"] - 1, 0).bit_length())
+            B.call("gs_sort_isect_pairs", n_isects, B.ptr(keys32), B.ptr(vals), B.ptr(depths), key_bits,
                    B.ptr(isect_ids), B.ptr(flatten_ids), B.ptr(temp), tb, st)
         elif n_isects > 0:
             B.call("gs_isect_emit", st_["n_elems"], max(st_["N"], 1), B.ptr(st_["perm"]), B.ptr(st_["n_kept"]), B.ptr(st_["camera_ids"]),

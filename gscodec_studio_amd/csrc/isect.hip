@@ -741,7 +741,10 @@ extern "C" int32_t gs_isect_finish_presorted(
                                              group_sums, group_prefix, tile_size, tile_width, tile_height, tile_n_bits, 1, nullptr,
                                              keys32, vals, stream);
         if (rc != 0) return rc;
-        rc = gs_sort_isect_pairs(n_isects, keys32, vals, depths, (int32_t)(tile_n_bits + cam_n_bits), isect_ids, flatten_ids, temp,
+        // (only the bits a key can have set take part: 8 cameras are 3 bits, not the 4 of the id layout -- 16 key bits = two passes
+        // instead of three; with all 32 bits in use the last pass also orders the ids as the signed values they are: left alone)
+        const uint32_t sort_bits = (tile_n_bits + cam_n_bits < 32u && key_bits_eff >= 1u) ? key_bits_eff : tile_n_bits + cam_n_bits;
+        rc = gs_sort_isect_pairs(n_isects, keys32, vals, depths, (int32_t)sort_bits, isect_ids, flatten_ids, temp,
                                  work_bytes - 2 * pb, stream);
         if (rc != 0) return rc;
     }
