@@ -215,6 +215,62 @@ class DynamicSlice:
         return means_t, quats_t, scales, opacity_t, colors
 
 
+_STG_PARTS = ("colors", "features_dir", "features_time")  # bit p of gs_stg_features_fwd's quant_mask
+_F3 = ctypes.c_float * 3
+
+
+class _StgFeatures(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, colors, features_dir, features_time, trbf_center, timestamp, quantize):
+        if not colors.is_cuda:
+            raise RuntimeError("stg_features: the HIP path needs device tensors (no CPU fallback)")
+        n = colors.shape[0]
+        for name, t in zip(_STG_PARTS, (colors, features_dir, features_time)):
+            assert t.shape == (n, 3), (name, t.shape)
+            if name in quantize and not (t.dtype == torch.float32 and t.is_contiguous()):
+                raise RuntimeError(f"stg_features: quantize[{name!r}] clamps the tensor in place -- hand over the contiguous float32 parameter")
+        parts = [t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float() for t in (colors, features_dir, features_time)]
+        center = trbf_center.detach().reshape(-1).contiguous().float()
+        assert center.numel() == n, trbf_center.shape
+        lo, hi, rng, qn = [0.0] * 3, [0.0] * 3, [1.0] * 3, [1.0] * 3
+        mask = 0
+        for k, (l_, h_, bits) in quantize.items():
+            i = _STG_PARTS.index(k)
+            mask |= 1 << i
+            lo[i], hi[i], rng[i], qn[i] = _f32(l_), _f32(h_), _f32(h_ - l_), _f32(1 / (2 ** bits - 1))
+        out = torch.empty((n, 9), dtype=torch.float32, device=colors.device)
+        with torch.cuda.device(colors.device):
+            B.call("gs_stg_features_fwd", n, *[B.ptr(t) for t in parts], B.ptr(center), float(timestamp), mask,
+                   _F3(*lo), _F3(*hi), _F3(*rng), _F3(*qn), B.ptr(out), torch.cuda.current_stream(colors.device).cuda_stream)
+        ctx.save_for_backward(center)
+        ctx.timestamp = float(timestamp)
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out):
+        (center,) = ctx.saved_tensors
+        n = center.shape[0]
+        need = ctx.needs_input_grad
+        v_out = v_out.contiguous().float()
+        grads = [torch.empty((n, 3), dtype=torch.float32, device=center.device) if need[i] else None for i in range(3)]
+        with torch.cuda.device(center.device):
+            B.call("gs_stg_features_bwd", n, B.ptr(v_out), B.ptr(center), ctx.timestamp, *[B.ptr(g) for g in grads],
+                   torch.cuda.current_stream(center.device).cuda_stream)
+        return (*grads, None, None, None)
+
+
+def stg_features(colors: Tensor, features_dir: Tensor, features_time: Tensor, trbf_center: Tensor, timestamp: float,
+                 quantize: Optional[Dict[str, Tuple[float, float, int]]] = None) -> Tensor:
+    """The spacetime trainer's nine colour channels ``torch.cat((colors, features_dir, tforpoly * features_time), dim=1)`` with
+    ``tforpoly = (timestamp - trbf_center).detach()`` (reference examples/simple_trainer_STG.py:506-551) in one kernel each way
+    (``gs_stg_features_fwd`` / ``_bwd``, csrc/dynamic.hip) -- same values bit for bit, no [N,9] copy by ``cat``, no split + copies by
+    autograd on the way back.  ``quantize``: {"colors" | "features_dir" | "features_time": (lower, upper, bits)} runs that part through
+    the compression simulation's round-to-grid STE first (the tensor is CLAMPED IN PLACE like ``STE.apply``'s input; identity gradient)."""
+    quantize = dict(quantize or {})
+    assert all(k in _STG_PARTS for k in quantize), f"quantize: keys among {_STG_PARTS}, got {tuple(quantize)}"
+    return _StgFeatures.apply(colors, features_dir, features_time, trbf_center, timestamp, quantize)
+
+
 def render_dynamic(splats: Dict[str, Tensor], timestamp: float, viewmats: Tensor, Ks: Tensor, width: int, height: int,
                    compression_sim=None, step: int = 0, features: str = "colors", temp_vis_mask: bool = False, **kwargs):
     """The dynamic trainer's ``rasterize_splats`` (reference examples/simple_trainer_dyngs.py:463-577, compression_sim on or off) on
@@ -240,8 +296,9 @@ def render_dynamic(splats: Dict[str, Tensor], timestamp: float, viewmats: Tensor
     if sim is not None:
         in_kernel = []
         if getattr(sim, "q_type", None) == "round":
-            for name in _QUANT_SLOTS:
-                if name == "colors" and features != "colors":
+            # (the nine-channel render takes its three colour parts through stg_features: their hooks ride in THAT kernel)
+            for name in _QUANT_SLOTS + (("features_dir", "features_time") if (features == "stg" and P["colors"].is_cuda) else ()):
+                if name == "colors" and features != "colors" and not P["colors"].is_cuda:
                     continue
                 needs_bits = (sim.entropy_model_enable and sim.entropy_model_option.get(name, False)
                               and step > sim.entropy_steps.get(name, -1) and sim.entropy_models.get(name) is not None)
@@ -255,10 +312,13 @@ def render_dynamic(splats: Dict[str, Tensor], timestamp: float, viewmats: Tensor
         for name in in_kernel:
             lo, hi = sim.bds[name]
             quantize[name] = (lo, hi, sim.q_bitwidth[name])
-    tau = None
     if features == "stg":
-        tau = (float(timestamp) - P["trbf_center"]).detach()
-        colors = torch.cat((P["colors"], P["features_dir"], tau * P["features_time"]), dim=1)
+        if P["colors"].is_cuda:
+            colors = stg_features(P["colors"], P["features_dir"], P["features_time"], P["trbf_center"], timestamp,
+                                  quantize={k: quantize.pop(k) for k in _STG_PARTS if k in quantize})
+        else:
+            tau = (float(timestamp) - P["trbf_center"]).detach()
+            colors = torch.cat((P["colors"], P["features_dir"], tau * P["features_time"]), dim=1)
     else:
         colors = P["colors"]
     ds = DynamicSlice(P["motion"], P["omega"], P["trbf_center"], P["trbf_scale"], timestamp, raw=raw, quantize=quantize,

@@ -343,7 +343,9 @@ def rasterization(
             colors = gather_rows(colors, gaussian_ids) if colors.dim() == 2 else colors[camera_ids, gaussian_ids]
         else:
             if colors.dim() == 2:
-                colors = colors.expand(C, -1, -1)
+                # (one camera: a view -- autograd's expand backward is a sum over the camera axis, a 35 us reduce kernel at 2 M x 9
+                # floats even when that axis has one entry)
+                colors = colors[None] if C == 1 else colors.expand(C, -1, -1)
     else:
         fused_sh = False
         fuse = fuse_sh

@@ -884,6 +884,23 @@ int32_t gs_temporal_slice_bwd(
     float *v_means, float *v_motion, float *v_quats, float *v_omega, float *v_opacities,
     float *v_trbf_center, float *v_trbf_scale, gs_stream_t stream);
 
+/* The spacetime trainer's nine colour channels in one pass each way (round 6; examples/simple_trainer_STG.py:506-551):
+ *     out[n] = (colors[n] | features_dir[n] | (timestamp - trbf_center[n]) * features_time[n]),   [N,9] from three [N,3]
+ * replacing torch.cat + the tforpoly multiply (and autograd's split + copies on the way back).  quant_mask bit p (0 colors, 1
+ * features_dir, 2 features_time): that part first goes through the round-to-grid STE hook of the compression simulation
+ * (gsplat/compression_simulation/ops.py:57-75 with q_type "round": the PARAMETER is clamped in place to [lo, hi], the value used is
+ * round((x - lo) / range / step_norm) * step_norm * range + lo with range = hi - lo, step_norm = 1 / (2^bits - 1), as
+ * gs_quantize_round_fwd computes it); tables of 3 floats each, NULL with quant_mask 0.  bwd: the hook's gradient is the identity;
+ * v_features_time = (timestamp - trbf_center) * v_out[:, 6:9]; trbf_center receives none (tforpoly is detached).  Output pointers of
+ * bwd may be NULL (not needed). */
+int32_t gs_stg_features_fwd(
+    uint32_t n, float *colors, float *features_dir, float *features_time, const float *trbf_center, float timestamp,
+    uint32_t quant_mask, const float *quant_lo, const float *quant_hi, const float *quant_range, const float *quant_step_norm,
+    float *out, gs_stream_t stream);
+int32_t gs_stg_features_bwd(
+    uint32_t n, const float *v_out, const float *trbf_center, float timestamp, float *v_colors, float *v_features_dir,
+    float *v_features_time, gs_stream_t stream);
+
 /* The same slice evaluated INSIDE the row-form projection (round 6; SURVEY 8f rank 2: "folded into the projection kernel's load
  * phase"): gs_projection_rows_dyn_fwd == gs_temporal_slice_fwd followed by gs_projection_rows_fwd (colours [N,3] or none, no SH),
  * bit for bit -- the per-splat arithmetic is one shared definition (csrc/dynamic_dev.h, projection_dev.h) -- without the round trip of

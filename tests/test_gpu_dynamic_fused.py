@@ -416,3 +416,55 @@ def test_fused_slice_fuzz_over_the_call_options(seed):
         assert rel_l2(N(g0), N(g1)) < 2e-4, (k, tag, rel_l2(N(g0), N(g1)))
     if kw["absgrad"]:
         assert "means2d" in outs[0][2]
+
+
+@pytest.mark.parametrize("n", [5003, 1024, 1, 257])
+@pytest.mark.parametrize("hooks", [(), ("colors", "features_dir", "features_time"), ("features_time",)])
+def test_stg_features_equal_cat_and_the_hooks_bit_for_bit(hooks, n):
+    """``dynamic.stg_features`` (gs_stg_features_fwd / _bwd): the spacetime trainer's nine colour channels
+    cat(colors, features_dir, (t - trbf_center).detach() * features_time) (examples/simple_trainer_STG.py:506-551), optionally with the
+    round STE hook of each part in front -- the same values, the same in-place clamps, the same gradients as the torch chain."""
+    from gscodec_studio_amd.compression_simulation.ops import STE
+    from gscodec_studio_amd.dynamic import stg_features
+
+    rs = np.random.RandomState(11)
+    bds = {"colors": (-7.5, 7.5, 8), "features_dir": (-10.0, 10.0, 8), "features_time": (-10.0, 10.0, 8)}
+    raw = {k: (rs.randn(n, 3) * 6).astype(np.float32) for k in bds}  # (some values beyond the ranges: clamped in the parameter)
+    center = rs.rand(n, 1).astype(np.float32)
+    t = 0.37
+    v = T(rs.randn(n, 9).astype(np.float32))
+    # fused
+    P = {k: torch.nn.Parameter(T(x)) for k, x in raw.items()}
+    c = torch.nn.Parameter(T(center))
+    out = stg_features(P["colors"], P["features_dir"], P["features_time"], c, t, quantize={k: bds[k] for k in hooks})
+    (out * v).sum().backward()
+    # the chain
+    P2 = {k: torch.nn.Parameter(T(x)) for k, x in raw.items()}
+    c2 = torch.nn.Parameter(T(center))
+    q = {k: (STE.apply(P2[k], bds[k][2], bds[k][0], bds[k][1], 0) if k in hooks else P2[k]) for k in bds}
+    ref = torch.cat((q["colors"], q["features_dir"], (t - c2).detach() * q["features_time"]), dim=1)
+    (ref * v).sum().backward()
+    assert out.shape == (n, 9) and torch.equal(out, ref)
+    for k in bds:
+        assert torch.equal(P[k].detach(), P2[k].detach()), k  # clamped in place where hooked, untouched elsewhere
+        assert torch.equal(P[k].grad, P2[k].grad), k
+        if k in hooks:
+            assert float(P[k].detach().abs().max()) <= max(abs(bds[k][0]), abs(bds[k][1]))
+        else:
+            assert np.array_equal(N(P[k]), raw[k])
+    assert c.grad is None and c2.grad is None  # tforpoly is detached
+    # partial requires_grad
+    P3 = {k: T(x).requires_grad_(k == "features_dir") for k, x in raw.items()}
+    out3 = stg_features(P3["colors"], P3["features_dir"], P3["features_time"], T(center), t)
+    (out3 * v).sum().backward()
+    assert P3["colors"].grad is None and P3["features_time"].grad is None and torch.equal(P3["features_dir"].grad, v[:, 3:6])
+    # views that are not 16-byte aligned take the element-per-lane kernels: same results
+    big = {k: torch.zeros(n * 3 + 1, device="cuda") for k in bds}
+    P4 = {}
+    for k in bds:
+        big[k][1:] = T(raw[k]).reshape(-1)
+        P4[k] = big[k][1:].view(n, 3).requires_grad_(True)
+    out4 = stg_features(P4["colors"], P4["features_dir"], P4["features_time"], T(center), t, quantize={k: bds[k] for k in hooks})
+    assert torch.equal(out4, ref)
+    for k in bds:
+        assert torch.equal(P4[k].detach(), P2[k].detach()), k
