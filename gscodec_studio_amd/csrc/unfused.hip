@@ -303,6 +303,68 @@ __global__ void indices_in_range_kernel(uint32_t range_start, uint32_t range_end
 
 } // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Accumulated depth -> expected depth: the image-level tail of rasterization()'s "ED" / "RGB+ED" modes (reference
+// gsplat/rendering.py:471-477):  out = cat(render[..., :-1], render[..., -1:] / alphas.clamp(min=1e-10)).  One lane per pixel; the
+// backward is torch's: d/d render_last = v / a_c, d/d alpha = -v ((render_last / a_c) / a_c) where alpha >= 1e-10 (the clamp passes the
+// gradient there), 0 below.
+namespace {
+
+constexpr float ED_ALPHA_MIN = 1e-10f;
+
+__global__ void __launch_bounds__(GS_BLOCK) expected_depth_fwd_kernel(uint64_t n_pix, uint32_t ch, const float *__restrict__ renders,
+                                                                      const float *__restrict__ alphas, float *__restrict__ out) {
+    GS_FP_STRICT;
+    const uint64_t p = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (p >= n_pix) return;
+    const float a = fmaxf(alphas[p], ED_ALPHA_MIN);
+    const float *r = renders + p * ch;
+    float *o = out + p * ch;
+    for (uint32_t k = 0; k + 1u < ch; ++k) o[k] = r[k];
+    o[ch - 1u] = (r[ch - 1u] / a);
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) expected_depth_bwd_kernel(uint64_t n_pix, uint32_t ch, const float *__restrict__ renders,
+                                                                      const float *__restrict__ alphas, const float *__restrict__ v_out,
+                                                                      float *__restrict__ v_renders, float *__restrict__ v_alphas) {
+    GS_FP_STRICT;
+    const uint64_t p = (uint64_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (p >= n_pix) return;
+    const float a0 = alphas[p], a = fmaxf(a0, ED_ALPHA_MIN);
+    const float *v = v_out + p * ch;
+    const float vd = v[ch - 1u];
+    if (v_renders != nullptr) {
+        float *o = v_renders + p * ch;
+        for (uint32_t k = 0; k + 1u < ch; ++k) o[k] = v[k];
+        o[ch - 1u] = (vd / a);
+    }
+    if (v_alphas != nullptr) v_alphas[p] = a0 >= ED_ALPHA_MIN ? (-vd * ((renders[p * ch + ch - 1u] / a) / a)) : 0.f;
+}
+
+} // namespace
+
+extern "C" int32_t gs_expected_depth_fwd(uint64_t n_pix, uint32_t channels, const float *renders, const float *alphas, float *out,
+                                         gs_stream_t stream) {
+    if (n_pix == 0) return 0;
+    GS_CHECK_ARG(renders && alphas && out && channels >= 1, "null pointer / no channels");
+    GS_CHECK_ARG(n_pix < ((uint64_t)1 << 32) * GS_BLOCK, "too many pixels");
+    hipLaunchKernelGGL(expected_depth_fwd_kernel, dim3((uint32_t)((n_pix + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
+                       n_pix, channels, renders, alphas, out);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int32_t gs_expected_depth_bwd(uint64_t n_pix, uint32_t channels, const float *renders, const float *alphas, const float *v_out,
+                                         float *v_renders, float *v_alphas, gs_stream_t stream) {
+    if (n_pix == 0) return 0;
+    GS_CHECK_ARG(renders && alphas && v_out && channels >= 1, "null pointer / no channels");
+    GS_CHECK_ARG(n_pix < ((uint64_t)1 << 32) * GS_BLOCK, "too many pixels");
+    hipLaunchKernelGGL(expected_depth_bwd_kernel, dim3((uint32_t)((n_pix + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
+                       n_pix, channels, renders, alphas, v_out, v_renders, v_alphas);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int32_t gs_world_to_cam_fwd(uint32_t C, uint32_t N, const float *means, const float *covars, const float *viewmats,
                                        float *means_c, float *covars_c, gs_stream_t stream) {
     if (C == 0 || N == 0) return 0;

@@ -26,6 +26,7 @@ from typing_extensions import Literal
 from . import _step
 from .compression_simulation.ada_mask import MaskedShN
 from ._wrapper import (
+    ROW_COLOR,
     fully_fused_projection,
     project_rows,
     GradPrefill,
@@ -81,6 +82,53 @@ def _step_max_elems() -> int:
     from ._wrapper import _PINNED_DIRECT_MAX
 
     return _PINNED_DIRECT_MAX * 1024  # (the count kernel's block sums go straight into pinned memory up to this size)
+
+
+class _RowsColorDepth(torch.autograd.Function):
+    """``cat((colors, depths[..., None]), -1)`` when ``colors`` are columns 6:9 of the splat rows: column 9 of the same rows holds the
+    depth (include/gsplat_hip.h "Splat rows"), so the four channels are the view ``rows[..., 6:10]`` -- nothing is copied, and on the
+    way back the compositing backward's gradient rows stay the one buffer the projection backward reads in place."""
+
+    @staticmethod
+    def forward(ctx, colors, depths, hold):
+        ctx.set_materialize_grads(False)
+        return hold[0][..., ROW_COLOR:ROW_COLOR + 4]
+
+    @staticmethod
+    def backward(ctx, v):
+        if v is None:
+            return None, None, None
+        return v[..., :3], v[..., 3], None
+
+
+class _ExpectedDepth(torch.autograd.Function):
+    """The tail of the "ED" / "RGB+ED" modes in one kernel each way (``gs_expected_depth_fwd`` / ``_bwd``)."""
+
+    @staticmethod
+    def forward(ctx, renders, alphas):
+        from . import _backend as B
+
+        renders, alphas = renders.contiguous(), alphas.contiguous()
+        out = torch.empty_like(renders)
+        n_pix, ch = alphas.numel(), renders.shape[-1]
+        with torch.cuda.device(renders.device):
+            B.call("gs_expected_depth_fwd", n_pix, ch, B.ptr(renders), B.ptr(alphas), B.ptr(out), torch.cuda.current_stream(renders.device).cuda_stream)
+        ctx.save_for_backward(renders, alphas)
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out):
+        from . import _backend as B
+
+        renders, alphas = ctx.saved_tensors
+        v_out = v_out.contiguous().float()
+        need = ctx.needs_input_grad
+        v_r = torch.empty_like(renders) if need[0] else None
+        v_a = torch.empty_like(alphas) if need[1] else None
+        with torch.cuda.device(renders.device):
+            B.call("gs_expected_depth_bwd", alphas.numel(), renders.shape[-1], B.ptr(renders), B.ptr(alphas), B.ptr(v_out), B.ptr(v_r), B.ptr(v_a),
+                   torch.cuda.current_stream(renders.device).cuda_stream)
+        return v_r, v_a
 
 
 def rasterization(
@@ -420,7 +468,13 @@ def rasterization(
             return render_colors, render_alphas, meta
 
     if render_mode in ["RGB+D", "RGB+ED"]:
-        colors = torch.cat((colors, depths[..., None]), dim=-1)
+        if (rows is not None and colors.dim() == 3 and colors.shape[-1] == 3 and colors.data_ptr() == rows.data_ptr() + 4 * ROW_COLOR
+                and colors.stride() == rows.stride()[:-1] + (1,) and not distributed):
+            # the colours ride in the splat rows, whose next column IS the depth: the four channels are a view (no cat, and the
+            # compositing backward's gradient rows reach the projection backward in place instead of through autograd's split)
+            colors = _RowsColorDepth.apply(colors, depths, (rows,))
+        else:
+            colors = torch.cat((colors, depths[..., None]), dim=-1)
         if backgrounds is not None:
             backgrounds = torch.cat([backgrounds, torch.zeros(C, 1, device=backgrounds.device)], dim=-1)
     elif render_mode in ["D", "ED"]:
@@ -474,9 +528,12 @@ def rasterization(
             backgrounds=backgrounds, packed=packed, absgrad=absgrad, deterministic=deterministic, prefill=prefill,
         )
     if render_mode in ["ED", "RGB+ED"]:
-        # accumulated depth -> expected depth
-        render_colors = torch.cat(
-            [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1
-        )
+        # accumulated depth -> expected depth (reference rendering.py:471-477: cat(rc[..., :-1], rc[..., -1:] / ra.clamp(min=1e-10)))
+        if render_colors.is_cuda and render_colors.dtype == torch.float32 and render_alphas.dtype == torch.float32:
+            render_colors = _ExpectedDepth.apply(render_colors, render_alphas)
+        else:
+            render_colors = torch.cat(
+                [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1
+            )
 
     return render_colors, render_alphas, meta

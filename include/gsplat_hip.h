@@ -865,6 +865,15 @@ int32_t gs_accumulate_bwd(uint64_t M, uint32_t C, uint32_t N, uint32_t channels,
                           const float *weights, const float *v_renders, const float *v_alphas, float *v_alpha_pair,
                           float *v_means2d, float *v_conics, float *v_opacities, float *v_colors, gs_stream_t stream);
 
+/* Accumulated depth -> expected depth, the image-level tail of rasterization()'s "ED" / "RGB+ED" render modes
+ * (gsplat/rendering.py:471-477): out = cat(renders[..., :-1], renders[..., -1:] / alphas.clamp(min=1e-10)) over n_pix pixels of
+ * `channels` floats, one pass each way instead of slice / clamp / div / cat and their autograd twins.  bwd: v_renders[..., :-1] =
+ * v_out[..., :-1], v_renders[..., -1] = v_out[..., -1] / clamp(alpha), v_alphas = -v_out[..., -1] ((renders[..., -1] / clamp) / clamp)
+ * where alpha >= 1e-10, else 0 (torch's div and clamp derivatives); either output may be NULL. */
+int32_t gs_expected_depth_fwd(uint64_t n_pix, uint32_t channels, const float *renders, const float *alphas, float *out, gs_stream_t stream);
+int32_t gs_expected_depth_bwd(uint64_t n_pix, uint32_t channels, const float *renders, const float *alphas, const float *v_out,
+                              float *v_renders, float *v_alphas, gs_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Temporal slicing of dynamic (spacetime) gaussians at one timestamp: the elementwise
  * chain in front of rasterization() in examples/simple_trainer_dyngs.py:506-521 -- trbf opacity decay

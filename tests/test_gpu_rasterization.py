@@ -710,3 +710,62 @@ def test_empty_and_invisible_inputs(sh_degree):
         (rc.sum() + ra.sum()).backward()
         for p in ps:
             assert p.grad is not None and p.grad.shape == p.shape and (p.numel() == 0 or float(p.grad.abs().max()) == 0.0), case
+
+
+@pytest.mark.parametrize("mode", ["RGB+D", "RGB+ED", "ED", "D"])
+@pytest.mark.parametrize("colors_kind", ["sh", "rgb"])
+def test_depth_modes_on_the_rows_route_equal_the_cat_route(mode, colors_kind):
+    """RGB+D / RGB+ED with the colours in the splat rows: the four channels are a VIEW of the rows (column 9 is the depth) and the
+    expected-depth tail is one kernel -- against the reference's own formulation (cat of colours and depths, slice / clamp / div /
+    cat on the image: gsplat/rendering.py:418-424, 471-477) evaluated through the separate-array route (packed projection outputs)."""
+    from gscodec_studio_amd import rasterization
+    from util import garden
+
+    fx = garden(5000)
+    n = fx["means"].shape[0]
+    rs = np.random.RandomState(4)
+    cols = (rs.randn(n, 16, 3) * 0.3).astype(np.float32) if colors_kind == "sh" else fx["rgb"].astype(np.float32)
+    kw = dict(sh_degree=3) if colors_kind == "sh" else {}
+    vm, Ks, W, H = T(fx["viewmats"][:2]), T(fx["Ks"][:2]), fx["width"], fx["height"]
+    outs = []
+    for route in ("rows", "reference"):
+        P = [T(fx[k], True) for k in ("means", "quats", "scales", "opacities")] + [T(cols, True)]
+        if route == "rows":
+            rc, ra, meta = rasterization(*P, vm, Ks, W, H, packed=False, render_mode=mode, **kw)
+        else:
+            # the reference's composition on top of the RGB call's pieces: render colours and depths as channels, then the ED tail in torch
+            rc_, ra, meta = rasterization(*P, vm, Ks, W, H, packed=True, render_mode=mode.replace("ED", "D"), **kw)
+            rc = torch.cat([rc_[..., :-1], rc_[..., -1:] / ra.clamp(min=1e-10)], dim=-1) if mode.endswith("ED") else rc_
+        wgt = torch.linspace(0.5, 1.5, rc.numel(), device=rc.device).view_as(rc)
+        ((rc * wgt).sum() + 0.3 * ra.sum()).backward()
+        outs.append((rc.detach(), ra.detach(), [None if p.grad is None else p.grad.clone() for p in P]))
+    (rc0, ra0, g0), (rc1, ra1, g1) = outs
+    assert rc0.shape == rc1.shape and rc0.shape[-1] == {"RGB+D": 4, "RGB+ED": 4, "ED": 1, "D": 1}[mode]
+    assert_close(N(rc0), N(rc1), 1e-4, 1e-5, f"{mode} render", max_bad_frac=2e-4)
+    assert_close(N(ra0), N(ra1), 1e-4, 1e-5, f"{mode} alphas", max_bad_frac=2e-4)
+    for name, a, b in zip(("means", "quats", "scales", "opacities", "colors"), g0, g1):
+        if a is None or b is None:  # (depth-only modes: the colours take no part)
+            assert name == "colors" and mode in ("D", "ED") and (a is None or float(a.abs().max()) == 0.0) and (b is None or float(b.abs().max()) == 0.0)
+            continue
+        assert rel_l2(N(a), N(b)) < 2e-3, (mode, colors_kind, name, rel_l2(N(a), N(b)))
+
+
+def test_expected_depth_kernels_equal_the_torch_formulation():
+    from gscodec_studio_amd.rendering import _ExpectedDepth
+
+    rs = np.random.RandomState(0)
+    for ch in (1, 4):
+        r = T(rs.rand(2, 37, 41, ch).astype(np.float32), True)
+        a_np = rs.rand(2, 37, 41, 1).astype(np.float32)
+        a_np[0, :3, :5] = 0.0          # empty pixels: the clamp's flat side
+        a_np[1, 5, 7] = 1e-10
+        a = T(a_np, True)
+        v = T(rs.randn(2, 37, 41, ch).astype(np.float32))
+        out = _ExpectedDepth.apply(r, a)
+        (out * v).sum().backward()
+        r2, a2 = T(N(r), True), T(a_np, True)
+        ref = torch.cat([r2[..., :-1], r2[..., -1:] / a2.clamp(min=1e-10)], dim=-1)
+        (ref * v).sum().backward()
+        assert torch.equal(out, ref)
+        assert torch.equal(r.grad, r2.grad)
+        assert_close(N(a.grad), N(a2.grad), 1e-6, 0.0, "d/d alpha")
