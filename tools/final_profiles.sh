@@ -81,6 +81,7 @@ cp gpurun_out/prof_${tag}dyn_full9_kernel_stats.csv "$out/${tag}_dynamic_full_ch
 PMC_CMD="python $root/tools/bench_channels.py 9" bash tools/pmc_any.sh ${tag}_ch9 FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU > "$out/pmc_ch9.log" 2>&1
 cp gpurun_out/pmc_${tag}_ch9.txt "$out/${tag}_channels9_pmc.txt"
 python tools/bench_order.py 2>&1 | grep -v amdgpu.ids > "$out/${tag}_splat_order.txt"
+python tools/bench_modes.py 2>&1 | grep -v amdgpu.ids > "$out/${tag}_modes.txt"
 timeout 600 python tools/probe_big.py 2>&1 | grep -v amdgpu.ids > "$out/${tag}_big_sizes.txt"
 timeout 300 python tools/probe_two_streams.py > "$out/${tag}_probe_two_streams.txt" 2>&1
 echo done
